@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Generate golden vectors by importing the REFERENCE (read-only, /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).
+Outputs small .npz fixtures into tests/golden/.  Nothing from the reference is
+copied: it is imported, fed seeded weights/inputs (drn_amd.utils.synthetic) and
+its outputs are recorded.
+
+Harness-side shims, none of which touch reference files:
+  1. stub `fcos_core` (absent third-party CUDA extension) in sys.modules;
+  2. `torch.Tensor.cuda` -> identity (model/loss.py:239, model/inference.py:193-196);
+  3. wrap the focal-loss gamma/alpha in lists so the in-repo CPU formula
+     (model/layers/sigmoid_focal_loss.py:40-52) indexes them.
+
+usage: python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from drn_amd.utils.synthetic import (VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict,  # noqa: E402
+                                     synthetic_batch)
+
+
+def install_shims():
+    names = ["fcos_core", "fcos_core.modeling", "fcos_core.modeling.box_coder", "fcos_core.modeling.utils",
+             "fcos_core.structures", "fcos_core.structures.bounding_box", "fcos_core.structures.boxlist_ops"]
+    for n in names:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["fcos_core"]._C = types.SimpleNamespace(nms=None)
+    sys.modules["fcos_core.modeling.box_coder"].BoxCoder = object
+    sys.modules["fcos_core.modeling.utils"].cat = torch.cat
+    sys.modules["fcos_core.structures.bounding_box"].BoxList = object
+    for f in ("cat_boxlist", "boxlist_nms", "remove_small_boxes"):
+        setattr(sys.modules["fcos_core.structures.boxlist_ops"], f, None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def build_reference(cfg, seed=0):
+    from model.main_model import mainModel
+    m = mainModel(VOCAB_SIZE, as_namespace(cfg))
+    f = m.fcos.loss_evaluator.cls_loss_func
+    f.gamma, f.alpha = [f.gamma], [f.alpha]
+    m.load_state_dict(seeded_state_dict(m, seed))
+    return m
+
+
+def checksum(t):
+    t = t.detach().double()
+    flat = t.reshape(-1)
+    step = max(1, flat.numel() // 64)
+    return np.array([flat.sum().item(), flat.abs().sum().item()]), flat[::step][:64].float().numpy()
+
+
+TAPS = ["prop_fc", "backbone_net.forward_conv0", "backbone_net.forward_conv1", "backbone_net.forward_conv2",
+        "fpn.fpn_layer1", "fpn.fpn_layer2", "fpn.fpn_layer3"]
+
+
+def matched_gt(m, batch):
+    """Pick GT = one of the model's own train-mode predictions so tIoU>0.9 positives exist."""
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    caught = {}
+    def grab(mod, i, o):
+        caught["reg"] = o[1]
+    h = m.fcos.head.register_forward_hook(grab)
+    m.train()
+    with torch.no_grad():
+        m(*batch)
+    h.remove()
+    m.load_state_dict(state)
+    m.fcos.loss_evaluator.total_points = []
+    reg0 = caught["reg"][0]                                # (B,2,T) level 0
+    B, _, T = reg0.shape
+    gt = []
+    for b in range(B):
+        t = (5 + 7 * b) % T
+        loc = t + 0.5
+        s = max((loc - reg0[b, 0, t].item()) / 32.0, 0.0)
+        e = min((loc + reg0[b, 1, t].item()) / 32.0, 1.0)
+        gt.append([s, e])
+    return torch.tensor(gt, dtype=torch.float64)
+
+
+def run_case(name, B, T, D, stage, train=True, match=False):
+    ftype = "C3D" if D == 4096 else "TINY"
+    cfg = default_cfg(ftype, D, stage)
+    m = build_reference(cfg, seed=0)
+    batch = list(synthetic_batch(B, T, D, seed=1))
+    if match:
+        batch[4] = matched_gt(m, batch)
+    out = {"B": B, "T": T, "D": D, "stage": stage, "train": int(train), "gt": batch[4].numpy()}
+    taps = {}
+    hooks = []
+    mods = dict(m.named_modules())
+    for tname in TAPS:
+        hooks.append(mods[tname].register_forward_hook(lambda mod, i, o, n=tname: taps.__setitem__(n, o)))
+    hooks.append(m.fcos.head.register_forward_hook(lambda mod, i, o: taps.__setitem__("head", o)))
+    m.train(train)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)                                      # model/fcos.py:182 pickles into cwd in eval
+        try:
+            boxes, losses = m(*batch)
+        finally:
+            os.chdir(cwd)
+    for h in hooks:
+        h.remove()
+    for k in ("loss_cls", "loss_reg", "loss_iou"):
+        out[k] = losses[k].detach().double().numpy().reshape(-1)
+    logits, reg, _, iou = taps["head"]
+    for l in range(3):
+        out["logits%d" % l] = logits[l].detach().numpy()
+        out["reg%d" % l] = reg[l].detach().numpy()
+        out["iou%d" % l] = iou[l].detach().numpy()
+    for tname in TAPS:
+        cs, smp = checksum(taps[tname])
+        out["cs/" + tname] = cs
+        out["smp/" + tname] = smp
+    if train:
+        if stage == 2:
+            loss = losses["loss_iou"]
+        else:
+            loss = sum(l for l in losses.values())
+        loss.backward()
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach().double().reshape(-1)
+            step = max(1, g.numel() // 16)
+            out["gn/" + k] = np.array([g.norm().item()])
+            out["gs/" + k] = g[::step][:16].float().numpy()
+        for k, v in m.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out["bn/" + k] = v.numpy().copy()
+    else:
+        out["n_det"] = np.array([len(b["detections"]) for b in boxes])
+        out["det"] = torch.cat([b["detections"] for b in boxes]).detach().numpy()
+        out["score"] = torch.cat([b["scores"] for b in boxes]).detach().numpy()
+        out["loc"] = torch.cat([b["locations"] for b in boxes]).detach().numpy()
+        out["level"] = np.array([x for b in boxes for lv in b["level"] for x in lv])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: out[k] for k in ("loss_cls", "loss_reg", "loss_iou")},
+          "npos_iou" if stage != 1 else "", flush=True)
+
+
+def run_lgp():
+    from model.LGP import LGP
+    torch.manual_seed(0)
+    g = np.random.default_rng(7)
+    B, C, t = 4, 64, 16
+    net = LGP(input_dim=C, query_dim=C)
+    net.load_state_dict(seeded_state_dict(net, seed=3))
+    net.train()
+    x = torch.from_numpy(g.standard_normal((B, C, t)).astype(np.float32)).requires_grad_()
+    q = torch.from_numpy(g.standard_normal((B, C)).astype(np.float32)).requires_grad_()
+    y = net(x, q)
+    w = torch.from_numpy(g.standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * w).sum().backward()
+    np.savez_compressed(os.path.join(HERE, "lgp.npz"), x=x.detach().numpy(), q=q.detach().numpy(), w=w.numpy(),
+                        y=y.detach().numpy(), dx=x.grad.numpy(), dq=q.grad.numpy(),
+                        dw=net.query_fc[0].weight.grad.numpy(), dgamma=net.query_fc[1].weight.grad.numpy(),
+                        dbeta=net.query_fc[1].bias.grad.numpy(),
+                        rm=net.query_fc[1].running_mean.numpy(), rv=net.query_fc[1].running_var.numpy())
+    print("lgp", float(y.abs().sum()))
+
+
+def run_metrics():
+    """utils/evaluate_utils.py:328-354 on a hand-made results dict."""
+    cwd = os.getcwd()
+    os.chdir(REF)                                          # evaluate_utils.py:16 reads a relative csv
+    try:
+        from utils.evaluate_utils import PostProcessRunner
+    finally:
+        os.chdir(cwd)
+    g = np.random.default_rng(11)
+    results = {}
+    for i in range(12):
+        n = int(g.integers(3, 12))
+        s = g.uniform(0, 0.6, size=n)
+        e = np.minimum(s + g.uniform(0.05, 0.5, size=n), 1.0)
+        gs = g.uniform(0, 0.5)
+        results["vid%d_%d" % (i // 2, i)] = {
+            "vid": "vid%d" % (i // 2), "timestamp": [[float(a), float(b)] for a, b in zip(s, e)],
+            "scores": [float(x) for x in g.uniform(0, 1, size=n)],
+            "gt": [float(gs), float(gs + g.uniform(0.1, 0.5))],
+            "query": "q%d" % i, "level": [0] * n, "locations": [0.5] * n}
+    import json
+    try:
+        runner = PostProcessRunner(results)
+        topks, acc = runner.run_evaluate(iou_topk_dict={"iou": [0.5, 0.7], "topk": [1, 5]}, temporal_nms=True)
+        with open(os.path.join(HERE, "metrics.json"), "w") as f:
+            json.dump({"results": results, "topks": topks,
+                       "acc": {str(k): v for k, v in acc.items()} if isinstance(acc, dict) else acc}, f)
+        print("metrics", topks, acc)
+    except Exception as e:                                 # metrics are a "next" row; do not block goldens
+        print("metrics golden skipped:", repr(e))
+
+
+def run_keys():
+    import json
+    m = build_reference(default_cfg("C3D", 4096, 1))
+    with open(os.path.join(HERE, "state_keys.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, f, indent=0)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    install_shims()
+    run_keys()
+    run_case("tiny_s1", 2, 32, 64, 1)
+    run_case("tiny_s3", 2, 32, 64, 3, match=True)
+    run_case("tiny_s2", 2, 32, 64, 2, match=True)
+    run_case("tiny_eval", 2, 32, 64, 3, train=False)
+    run_case("tiny_eval_s1", 3, 64, 64, 1, train=False)
+    run_case("c3d_s1", 2, 64, 4096, 1)
+    run_case("c3d_s3", 2, 64, 4096, 3, match=True)
+    run_lgp()
+    run_metrics()

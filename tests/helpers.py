@@ -1,0 +1,125 @@
+"""Shared test helpers: golden loading + comparison of a model run against a golden fixture."""
+import os
+
+import numpy as np
+import torch
+
+from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TAPS = ["prop_fc", "backbone_net.forward_conv0", "backbone_net.forward_conv1", "backbone_net.forward_conv2",
+        "fpn.fpn_layer1", "fpn.fpn_layer2", "fpn.fpn_layer3"]
+
+# gradients that are analytically zero (pure rounding noise)
+ZERO_GRADS = ("fcos.head.cls_tower.0.bias", "fcos.head.bbox_tower.0.bias", "fcos.head.mix_fc.0.bias",
+              "fcos.head.iou_scores.0.bias", "query_encoder.cmd_inter2logits.bias")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+
+def case_inputs(g, device="cpu"):
+    B, T, D, stage = int(g["B"]), int(g["T"]), int(g["D"]), int(g["stage"])
+    cfg = default_cfg("C3D" if D == 4096 else "TINY", D, stage)
+    batch = list(synthetic_batch(B, T, D, seed=1, device=device))
+    batch[4] = torch.from_numpy(g["gt"]).to(device)
+    return cfg, batch
+
+
+def build_model(model_cls, cfg, device="cpu", **kw):
+    m = model_cls(VOCAB_SIZE, as_namespace(cfg), **kw)
+    m.load_state_dict(seeded_state_dict(m, 0))
+    return m.to(device)
+
+
+def checksum(t):
+    flat = t.detach().double().reshape(-1).cpu()
+    step = max(1, flat.numel() // 64)
+    return np.array([flat.sum().item(), flat.abs().sum().item()]), flat[::step][:64].float().numpy()
+
+
+def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=True):
+    """Run model `m` on the golden case and assert every recorded quantity matches.
+
+    atol: absolute tolerance on activations / head outputs / losses (A.6: never pure relative).
+    grad_rtol: relative-L2 tolerance on per-parameter gradient norms & samples.
+    """
+    stage, train = int(g["stage"]), bool(int(g["train"]))
+    caught = {}
+    hooks = []
+    mods = dict(m.named_modules())
+    if taps:
+        for t in TAPS:
+            hooks.append(mods[t].register_forward_hook(lambda mod, i, o, n=t: caught.__setitem__(n, o)))
+    hooks.append(m.fcos.head.register_forward_hook(lambda mod, i, o: caught.__setitem__("head", o)))
+    m.train(train)
+    boxes, losses = m(*batch)
+    for h in hooks:
+        h.remove()
+    for k in ("loss_cls", "loss_reg", "loss_iou"):
+        got = losses[k].detach().double().cpu().numpy().reshape(-1)
+        np.testing.assert_allclose(got, g[k], atol=atol, rtol=0, err_msg=k)
+    logits, reg, _, iou = caught["head"]
+    for l in range(3):
+        for nm, ten in (("logits", logits), ("reg", reg), ("iou", iou)):
+            got = ten[l].detach().float().cpu().numpy()
+            ref = g["%s%d" % (nm, l)]
+            assert got.shape == ref.shape, (nm, l, got.shape, ref.shape)
+            np.testing.assert_allclose(got, ref, atol=atol * max(1.0, np.abs(ref).max()), rtol=0,
+                                       err_msg="%s%d" % (nm, l))
+    if taps:
+        for t in TAPS:
+            cs, smp = checksum(caught[t])
+            ref = g["smp/" + t]
+            np.testing.assert_allclose(smp, ref, atol=atol * max(1.0, np.abs(ref).max()), rtol=0, err_msg="smp/" + t)
+            n = caught[t].numel()
+            np.testing.assert_allclose(cs, g["cs/" + t], atol=atol * n * 0.05 + 1e-3, rtol=1e-5, err_msg="cs/" + t)
+    if train:
+        loss = losses["loss_iou"] if stage == 2 else sum(l for l in losses.values())
+        loss.backward()
+        seen = 0
+        for k, p in m.named_parameters():
+            key = "gn/" + k
+            if key not in g:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, "unexpected grad for " + k
+                continue
+            assert p.grad is not None, "missing grad for " + k
+            seen += 1
+            gr = p.grad.detach().double().reshape(-1).cpu()
+            step = max(1, gr.numel() // 16)
+            ref_n, ref_s = float(g[key][0]), g["gs/" + k].astype(np.float64)
+            if k in ZERO_GRADS or ref_n < 1e-7:
+                assert float(gr.abs().max()) <= 1e-5, (k, float(gr.abs().max()))
+                continue
+            assert abs(gr.norm().item() - ref_n) <= grad_rtol * ref_n + 1e-9, (k, gr.norm().item(), ref_n)
+            got_s = gr[::step][:16].numpy()
+            assert np.abs(got_s - ref_s).max() <= grad_rtol * max(ref_n / np.sqrt(gr.numel()) * 30, np.abs(ref_s).max()) + 1e-9, \
+                (k, got_s, ref_s)
+        assert seen > 20
+        if check_bn:
+            sd = m.state_dict()
+            for key in g:
+                if key.startswith("bn/"):
+                    got = sd[key[3:]].float().cpu().numpy()
+                    np.testing.assert_allclose(got, g[key], atol=atol * max(1.0, np.abs(g[key]).max()), rtol=0,
+                                               err_msg=key)
+    else:
+        n_det = np.array([len(b["detections"]) for b in boxes])
+        np.testing.assert_array_equal(n_det, g["n_det"])
+        # per-clip order inside a level is top-k(sorted=False) order: compare as sorted sets per clip
+        off = 0
+        for bi, b in enumerate(boxes):
+            n = int(n_det[bi])
+            got = np.concatenate([b["detections"].detach().float().cpu().numpy(),
+                                  b["scores"].detach().float().cpu().numpy()[:, None],
+                                  b["locations"].detach().float().cpu().numpy()[:, None]], 1)
+            ref = np.concatenate([g["det"][off:off + n], g["score"][off:off + n, None], g["loc"][off:off + n, None]], 1)
+            got = got[np.lexsort((got[:, 0], got[:, 3]))]
+            ref = ref[np.lexsort((ref[:, 0], ref[:, 3]))]
+            np.testing.assert_allclose(got, ref, atol=atol, rtol=0, err_msg="detections clip %d" % bi)
+            lv = np.array([x for l in b["level"] for x in l])
+            np.testing.assert_array_equal(np.sort(lv), np.sort(g["level"][off:off + n]))
+            off += n
+    return boxes, losses

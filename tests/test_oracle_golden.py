@@ -1,0 +1,74 @@
+"""Pin the CPU oracle (oracle/drn_oracle.py) against golden vectors recorded from the reference
+itself (tests/golden/gen_golden.py).  CPU-only; runs in the build container and on the GPU box."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import drn_oracle as O
+from drn_amd.utils.synthetic import seeded_state_dict
+from helpers import build_model, case_inputs, load_golden, run_and_compare
+
+CASES = ["tiny_s1", "tiny_s2", "tiny_s3", "tiny_eval", "tiny_eval_s1", "c3d_s1", "c3d_s3"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_golden(name):
+    torch.manual_seed(0)
+    g = load_golden(name)
+    cfg, batch = case_inputs(g)
+    m = build_model(O.mainModel, cfg)
+    run_and_compare(m, g, batch, atol=2e-5, grad_rtol=2e-5)
+
+
+def test_state_dict_keys_match_appendix_a1():
+    from drn_amd.utils.synthetic import default_cfg, as_namespace, VOCAB_SIZE
+    m = O.mainModel(VOCAB_SIZE, as_namespace(default_cfg("C3D")))
+    sd = m.state_dict()
+    import json, os
+    from helpers import GOLDEN_DIR
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "state_keys.json")))
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+    for k, shape in {"backbone_net.forward_conv0.0.weight": (256, 4352, 3), "fpn.fpn_inner3.0.weight": (512, 1024, 1),
+                     "fcos.head.mix_fc.0.weight": (512, 1024, 1), "fcos.head.iou_scores.3.weight": (1, 256, 1),
+                     "fcos.head.scales.2.scale": (1,), "prop_fc.weight": (4096, 4096), "qInput1.weight": (256, 1024),
+                     "query_encoder.biLSTM.weight_hh_l0_reverse": (2048, 512),
+                     "query_encoder.textualAttention.W3.weight": (2048, 2048)}.items():
+        assert tuple(sd[k].shape) == shape, k
+
+
+def test_lgp_oracle_matches_reference_golden():
+    g = load_golden("lgp")
+    net = O.LGP(input_dim=64, query_dim=64)
+    net.load_state_dict(seeded_state_dict(net, seed=3))
+    net.train()
+    x = torch.from_numpy(g["x"]).requires_grad_()
+    q = torch.from_numpy(g["q"]).requires_grad_()
+    y = net(x, q)
+    (y * torch.from_numpy(g["w"])).sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], atol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], atol=1e-5)
+    np.testing.assert_allclose(q.grad.numpy(), g["dq"], atol=1e-4)
+    np.testing.assert_allclose(net.query_fc[0].weight.grad.numpy(), g["dw"], atol=1e-4)
+    np.testing.assert_allclose(net.query_fc[1].running_var.numpy(), g["rv"], atol=1e-6)
+
+
+def test_known_answers():
+    """Analytic known-answer tests."""
+    # focal loss at logit 0: alpha*0.25*ln2 for a positive, (1-alpha)*0.25*ln2 for a negative
+    z = torch.zeros(2, 1)
+    t = torch.tensor([1, 0], dtype=torch.int32)
+    got = O.sigmoid_focal_loss_sum(z, t, 2.0, 0.25).item()
+    assert abs(got - (0.25 * 0.25 + 0.75 * 0.25) * np.log(2)) < 1e-7
+    # IoU loss = 0 when pred == target
+    p = torch.tensor([[1.0, 2.0], [0.5, 3.0]])
+    assert abs(O.iou_loss_mean(p, p.clone()).item()) < 1e-6
+    # locations = arange*stride + stride/2 (model/fcos.py:204-211)
+    loc = O.FCOSModule.locations_for(4, 4, "cpu")
+    assert loc.tolist() == [2.0, 6.0, 10.0, 14.0]
+    # target assignment: gt (0.25, 0.5)*32 = (8, 16); level0 loc 10.5 -> l=2.5,r=5.5, max 5.5 in [-1,6] -> positive
+    lab, reg = O.fcos_targets([torch.arange(32.) + 0.5], torch.tensor([[0.25, 0.5]]))
+    assert lab[10].item() == 1.0 and lab[8].item() == 0.0   # 8.5: l=.5,r=7.5 -> max 7.5 > 6
+    assert reg[10].tolist() == [2.5, 5.5]
+    # tIoU of identical segments ~ 1
+    a = torch.tensor([[[0.2, 0.6]]])
+    assert abs(O.segment_tiou(a, a).item() - 1.0) < 1e-5
