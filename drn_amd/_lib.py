@@ -1,0 +1,63 @@
+"""ctypes loader for libdrn_hip.so (the C-ABI in include/drn_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails,
+an exception is raised.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C drn_amd/csrc`.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrn_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "drn_hip.h")
+_lib = None
+
+c_int, c_void_p, c_float, c_int64, c_int32 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64, ctypes.c_int32
+MAX_GROUPS = 4
+
+
+class DrnError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p),
+                ("bias", c_void_p), ("gate", c_void_p), ("stats", c_void_p),
+                ("M", c_int32), ("N", c_int32),
+                ("Cin", c_int32), ("taps", c_int32), ("stride", c_int32), ("pad", c_int32), ("mode", c_int32),
+                ("Lout", c_int32), ("Lsrc", c_int32),
+                ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldg", c_int32),
+                ("accumulate", c_int32)]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [("dY", c_void_p), ("X", c_void_p),
+                ("M", c_int32), ("Lout", c_int32), ("Lsrc", c_int32),
+                ("ldy", c_int32), ("ldx", c_int32)]
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises DrnError loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DrnError("libdrn_hip.so not found at %s -- the HIP extension is required (no CPU fallback). "
+                           "Run __graft_entry__.build() or `make -C drn_amd/csrc`." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.drn_last_error.restype = ctypes.c_char_p
+        if hasattr(_lib, "drn_wgrad_ws_elems"):
+            _lib.drn_wgrad_ws_elems.restype = c_int64
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DrnError("%s failed (%d): %s" % (what, rc, lib().drn_last_error().decode()))
+
+
+def declared_symbols():
+    """Every function declared in include/drn_hip.h (parsed from the header itself)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(drn_[a-z0-9_]+)\s*\(", txt)))

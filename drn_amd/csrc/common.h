@@ -1,0 +1,78 @@
+// Shared device/host helpers for libdrn_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define DRN_OK 0
+#define DRN_ERR_ARG (-1)
+#define DRN_ERR_LAUNCH (-2)
+#define DRN_ERR_UNSUPPORTED (-3)
+
+#define DRN_F32 0
+#define DRN_BF16 1
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+void drn_set_error(const char* fmt, ...);
+
+#define DRN_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      drn_set_error(__VA_ARGS__);         \
+      return DRN_ERR_ARG;                 \
+    }                                     \
+  } while (0)
+
+static inline int drn_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    drn_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return DRN_ERR_LAUNCH;
+  }
+  return DRN_OK;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------
+// zero-initialised source for masked 16-byte global_load_lds (one copy per translation unit)
+static __device__ uint4 g_zero_page[4];
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* sh /* >= 17 floats */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  if (w == 0) {
+    float t = l < nw ? sh[l] : 0.f;
+    t = wave_sum(t);
+    if (l == 0) sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}

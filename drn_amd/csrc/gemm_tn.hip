@@ -1,0 +1,303 @@
+// Weight-gradient implicit GEMM (TN) on CDNA4 MFMA.
+//
+//   dW[n][tap][c] = sum_m dY[m][n] * X[src(m,tap)][c]          (fp32 result)
+//
+// is the backward-weights of nn.Conv1d (model/basic_blocks.py:9-18, model/fcos.py:33-69) and,
+// with taps==1, of nn.Linear (model/main_model.py:33).  Both operands are channels-last, so the
+// reduction index m is the strided one: tiles are staged in their natural [rows][channels] order
+// with global_load_lds and the MFMA fragments are gathered with the gfx950 hardware transpose
+// read (ds_read_b64_tr_b16) for bf16, or plain ds_read_b32 (one k per lane) for exact-f32.
+//
+// Tile: 128 (n) x 128 (c, inside one tap) per 256-thread workgroup, 4 waves 2x2, 64x64 per wave.
+// LDS image per operand and stage (16 KB): [8 column blocks of 16][R rows][16 cols], R = 64 (bf16)
+// or 32 (f32) so one wave-instruction of global_load_lds fills 1 KB of it linearly.
+// The row range (all groups concatenated) is split over gridDim.z; partial tiles go to an fp32
+// workspace and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics).
+#include "common.h"
+#include "../../include/drn_hip.h"
+
+#define TILE 128
+#define TN_THREADS 256
+#define STAGE_BYTES 32768
+
+
+struct WgradGroup {
+  const void* dY;
+  const void* X;
+  int M, Lout, Lsrc, ldy, ldx;
+  int blk_start;  // first row-block (of R rows) of this group in the concatenated space
+};
+struct WgradParams {
+  int ngroups;
+  WgradGroup g[DRN_MAX_GROUPS];
+  int total_blks, blks_per_split;
+  int N, Cin, taps, stride, pad;
+  int ctiles;     // ceil(Cin/128)
+  float* out;     // workspace [nsplit][N][taps*Cin] or final dW when nsplit==1
+  int direct;     // 1: out is the final dW (nsplit==1)
+  int w_layout;   // direct only: 0 = [N][taps][Cin], 1 = [N][Cin][taps]
+  int accumulate; // direct only
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T> struct TnMma;
+
+template <> struct TnMma<bf16_t> {
+  static constexpr int R = 64;
+  // image: [cb][r][16 cols] bf16, 32 B per row piece.  One stage = 2 MFMA k-steps of 32 rows.
+  static __device__ __forceinline__ bf16x8 frag(const char* img, int cb, int ks, int l) {
+    const int g = l >> 4, i = l & 15;
+    const char* base = img + cb * 2048 + (i & 3) * 8;
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + (ks * 32 + g * 4 + (i >> 2)) * 32));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + (ks * 32 + 16 + g * 4 + (i >> 2)) * 32));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+  }
+  static __device__ __forceinline__ void compute(const char* Ys, const char* Xs, int wr, int wc, int l, f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = frag(Ys, wr * 4 + mi, ks, l);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b[ni] = frag(Xs, wc * 4 + ni, ks, l);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+};
+
+template <> struct TnMma<float> {
+  static constexpr int R = 32;
+  // image: [cb][r][16 cols] f32, 64 B per row piece.  One stage = 8 MFMA k-steps of 4 rows.
+  static __device__ __forceinline__ void compute(const char* Ys, const char* Xs, int wr, int wc, int l, f32x4 (&acc)[4][4]) {
+    const int g = l >> 4, i = l & 15;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float a[4], b[4];
+      const int off = (ks * 4 + g) * 64 + i * 4;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = *(const float*)(Ys + (wr * 4 + mi) * 2048 + off);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b[ni] = *(const float*)(Xs + (wc * 4 + ni) * 2048 + off);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const WgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = TnMma<T>::R;
+  constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int CPR = (int)sizeof(T);       // 16-byte chunks per 16-column row piece
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int tn = blockIdx.x;                // 128-wide block of output channels n
+  const int tap = blockIdx.y / P.ctiles;
+  const int c0 = (blockIdx.y - tap * P.ctiles) * TILE;
+  const int n0 = tn * TILE;
+  const int split = blockIdx.z;
+  const int blk_lo = split * P.blks_per_split;
+  const int blk_hi = min(blk_lo + P.blks_per_split, P.total_blks);
+  const T* zero = (const T*)g_zero_page;
+
+  // lane-constant piece of the staging map: instr q = w*4+i covers chunks p = q*64 + l
+  int s_cb[4], s_r[4], s_sub[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = w * 4 + i;
+    const int within = (q & 1) * 64 + l;
+    s_cb[i] = q >> 1;
+    s_r[i] = within / CPR;
+    s_sub[i] = within % CPR;
+  }
+
+  auto stage = [&](int buf, int blk) {
+    char* Ys = smem + buf * STAGE_BYTES;
+    char* Xs = Ys + 16384;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+      if (i < P.ngroups && blk >= P.g[i].blk_start) g = i;
+    const WgradGroup& G = P.g[g];
+    const int mbase = (blk - G.blk_start) * R;
+    const T* __restrict__ Yg = (const T*)G.dY;
+    const T* __restrict__ Xg = (const T*)G.X;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + s_r[i];
+      const int col = s_cb[i] * 16 + s_sub[i] * CH;
+      const T* ys = zero;
+      const T* xs = zero;
+      if (m < G.M) {
+        if (n0 + col < P.N) ys = Yg + ((long)m * G.ldy + n0 + col);
+        if (c0 + col < P.Cin) {
+          const int seq = m / G.Lout;
+          const int st = (m - seq * G.Lout) * P.stride + tap - P.pad;
+          if (st >= 0 && st < G.Lsrc) xs = Xg + ((long)(seq * G.Lsrc + st) * G.ldx + c0 + col);
+        }
+      }
+      glds16(ys, Ys + (w * 4 + i) * 1024);
+      glds16(xs, Xs + (w * 4 + i) * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wr = w >> 1, wc = w & 1;
+
+  if (blk_lo < blk_hi) {
+    stage(0, blk_lo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+      if (blk + 1 < blk_hi) stage(cur ^ 1, blk + 1);
+      const char* Ys = smem + cur * STAGE_BYTES;
+      TnMma<T>::compute(Ys, Ys + 16384, wr, wc, l, acc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // epilogue: acc[mi][ni][r] -> n = n0 + wr*64 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*64 + ni*16 + (l&15)
+  const int KW = P.taps * P.Cin;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wr * 64 + mi * 16 + (l >> 4) * 4 + r;
+      if (n >= P.N) continue;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int c = c0 + wc * 64 + ni * 16 + (l & 15);
+        if (c >= P.Cin) continue;
+        float v = acc[mi][ni][r];
+        if (P.direct) {
+          float* dst = P.w_layout == 0 ? P.out + ((long)n * KW + tap * P.Cin + c)
+                                       : P.out + ((long)n * KW + (long)c * P.taps + tap);
+          if (P.accumulate) v += *dst;
+          *dst = v;
+        } else {
+          P.out[((long)split * P.N + n) * KW + tap * P.Cin + c] = v;
+        }
+      }
+    }
+}
+
+// out[n][...] = (accumulate ? out : 0) + sum_z ws[z][n][tap*Cin+c], in the requested parameter layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, int N, int Cin,
+                                    int taps, int w_layout, int accumulate) {
+  const long KW = (long)taps * Cin;
+  const long total = (long)N * KW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
+    long o = idx;
+    if (w_layout == 1) {
+      const long n = idx / KW;
+      const int rem = (int)(idx - n * KW);
+      const int tap = rem / Cin, c = rem - tap * Cin;
+      o = n * KW + (long)c * taps + tap;
+    }
+    if (accumulate) s += out[o];
+    out[o] = s;
+  }
+}
+
+static int wgrad_nsplit(int total_blks, int N, int Cin, int taps) {
+  const int tiles = cdiv(N, TILE) * taps * cdiv(Cin, TILE);
+  int ns = cdiv(768, tiles);            // aim for ~3 workgroups per CU
+  if (ns > total_blks) ns = total_blks;
+  if (ns < 1) ns = 1;
+  if (ns > 64) ns = 64;
+  return ns;
+}
+
+static int total_blocks_upper(int M_total, int ngroups_max) {
+  // row blocks use R = 32 in the worst case (f32); each group adds at most one partial block
+  return cdiv(M_total, 32) + ngroups_max;
+}
+
+extern "C" int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps) {
+  const int ns = wgrad_nsplit(total_blocks_upper(M_total, DRN_MAX_GROUPS), N, Cin, taps);
+  return ns > 1 ? (int64_t)ns * N * taps * Cin : 0;
+}
+
+extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int N, int Cin, int taps, int stride, int pad,
+                              int w_layout, int accumulate, float* ws, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_wgrad: ngroups=%d out of range", ngroups);
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_wgrad: bad dtype %d", dtype);
+  DRN_CHECK_ARG(dW && N > 0 && Cin > 0 && taps >= 1 && stride >= 1, "drn_gemm_wgrad: bad dims");
+  const int ch = dtype == DRN_BF16 ? 8 : 4;
+  const int R = dtype == DRN_BF16 ? 64 : 32;
+  WgradParams P;
+  memset(&P, 0, sizeof(P));
+  P.ngroups = ngroups;
+  int blks = 0, m_total = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const DrnWgradDesc& s = d[g];
+    DRN_CHECK_ARG(s.dY && s.X && s.M > 0 && s.Lout > 0 && s.Lsrc > 0 && s.M % s.Lout == 0, "drn_gemm_wgrad: bad group %d", g);
+    DRN_CHECK_ARG(s.ldy % ch == 0 && s.ldx % ch == 0 && N % ch == 0 && Cin % ch == 0,
+                  "drn_gemm_wgrad: N/Cin/ldy/ldx must be multiples of %d elements", ch);
+    DRN_CHECK_ARG(((uintptr_t)s.dY & 15) == 0 && ((uintptr_t)s.X & 15) == 0, "drn_gemm_wgrad: operands must be 16-byte aligned");
+    P.g[g].dY = s.dY; P.g[g].X = s.X; P.g[g].M = s.M; P.g[g].Lout = s.Lout; P.g[g].Lsrc = s.Lsrc;
+    P.g[g].ldy = s.ldy; P.g[g].ldx = s.ldx; P.g[g].blk_start = blks;
+    blks += cdiv(s.M, R);
+    m_total += s.M;
+  }
+  // the split count must not exceed what drn_wgrad_ws_elems() promised for this M_total
+  int ns = wgrad_nsplit(total_blocks_upper(m_total, DRN_MAX_GROUPS), N, Cin, taps);
+  if (ns > blks) ns = blks;
+  DRN_CHECK_ARG(ns == 1 || ws, "drn_gemm_wgrad: workspace required (drn_wgrad_ws_elems)");
+  P.total_blks = blks;
+  P.blks_per_split = cdiv(blks, ns);
+  ns = cdiv(blks, P.blks_per_split);
+  P.N = N; P.Cin = Cin; P.taps = taps; P.stride = stride; P.pad = pad;
+  P.ctiles = cdiv(Cin, TILE);
+  P.direct = ns == 1;
+  P.out = P.direct ? dW : ws;
+  P.w_layout = w_layout;
+  P.accumulate = accumulate;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(N, TILE), taps * P.ctiles, ns);
+  if (dtype == DRN_BF16)
+    conv_wgrad_tn_kernel<bf16_t><<<grid, TN_THREADS, 2 * STAGE_BYTES, stream>>>(P);
+  else
+    conv_wgrad_tn_kernel<float><<<grid, TN_THREADS, 2 * STAGE_BYTES, stream>>>(P);
+  int rc = drn_launch_status("drn_gemm_wgrad");
+  if (rc) return rc;
+  if (!P.direct) {
+    const long total = (long)N * taps * Cin;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    wgrad_reduce_kernel<<<nb, 256, 0, stream>>>(ws, dW, ns, N, Cin, taps, w_layout, accumulate);
+    rc = drn_launch_status("drn_gemm_wgrad(reduce)");
+  }
+  return rc;
+}

@@ -1,0 +1,196 @@
+"""GPU parity of the MFMA implicit-GEMM kernels (drn_gemm_nt / drn_gemm_wgrad) through the C-ABI,
+against plain PyTorch fp64/fp32 CPU references of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+# fp32: exact-f32 MFMA vs fp64 reference; bf16: inputs rounded to bf16 on both sides, fp32 accumulation
+TOL = {"f32": 2e-5, "bf16": 1e-2}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    return x.to(dtype)
+
+
+def close(got, ref, tol, what):
+    got = got.detach().double().cpu()
+    ref = ref.double()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, "%s: max abs err %.3e > %.3e (scale %.3g)" % (what, err, tol * scale, scale)
+
+
+def nlc(x_ncl):
+    return x_ncl.permute(0, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 264), (128, 128, 64), (1024, 512, 4096), (64, 40, 72)])
+def test_linear_fwd_bias_gate(dt, M, N, K):
+    from drn_amd import ops
+    T = 4 if M % 4 == 0 else 1
+    A, W = rnd((M, K), 1, DT[dt]), rnd((N, K), 2, DT[dt])
+    bias = rnd((N,), 3, torch.float32)
+    gate = rnd((M // T, N), 4, torch.float32)
+    pre = A.double() @ W.double().t() + bias.double()
+    ref = pre * gate.double().repeat_interleave(T, 0)
+    Ad, Wd = A.to(dev()), W.to(dev())
+    C = torch.full((M, N), float("nan"), dtype=DT[dt], device=dev())
+    C2 = torch.full((M, N), float("nan"), dtype=DT[dt], device=dev())
+    d = ops.gemm_desc(Ad, Wd, C, M, N, K, Lout=T, bias=bias.to(dev()), gate=gate.to(dev()), ldg=N, C2=C2)
+    ops.gemm_nt([d], ops.dtype_code(Ad))
+    torch.cuda.synchronize()
+    close(C2, pre, TOL[dt] * np.sqrt(K / 64), "pre-gate")
+    close(C, ref, TOL[dt] * np.sqrt(K / 64), "gated")
+
+
+def conv_case(dt, B, L, Cin, Cout, k, s, seed=0):
+    x = rnd((B, Cin, L), seed + 1, DT[dt])
+    w = rnd((Cout, Cin, k), seed + 2, DT[dt]) / np.sqrt(Cin * k)
+    w = w.to(DT[dt])
+    return x, w
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,L,Cin,Cout,k,s", [(3, 50, 72, 136, 3, 1), (2, 64, 64, 128, 3, 2), (2, 33, 40, 24, 1, 1),
+                                              (4, 256, 320, 256, 3, 1), (2, 30, 64, 64, 3, 2)])
+def test_conv_fwd_and_stats(dt, B, L, Cin, Cout, k, s):
+    from drn_amd import ops
+    x, w = conv_case(dt, B, L, Cin, Cout, k, s)
+    pad = (k - 1) // 2
+    ref = F.conv1d(x.double(), w.double(), stride=s, padding=pad)           # (B,Cout,Lo)
+    Lo = ref.shape[-1]
+    M = B * Lo
+    xd = nlc(x).to(dev())                                                   # (B,L,Cin)
+    wp = w.permute(0, 2, 1).contiguous().to(dev())                          # (Cout,k,Cin)
+    C = torch.full((M, Cout), float("nan"), dtype=DT[dt], device=dev())
+    tiles_m = (M + 127) // 128
+    stats = torch.full((tiles_m, 2, Cout), float("nan"), dtype=torch.float32, device=dev())
+    d = ops.gemm_desc(xd, wp, C, M, Cout, Cin, taps=k, stride=s, pad=pad, Lout=Lo, Lsrc=L, stats=stats)
+    ops.gemm_nt([d], ops.dtype_code(xd))
+    torch.cuda.synchronize()
+    refm = ref.permute(0, 2, 1).reshape(M, Cout)
+    close(C, refm, TOL[dt], "conv out")
+    st = stats.double().cpu().sum(0)
+    close(st[0], refm.sum(0), TOL[dt] * 4, "col sum")
+    close(st[1], (refm * refm).sum(0), TOL[dt] * 4, "col sumsq")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,L,Cin,Cout,k,s", [(3, 50, 72, 136, 3, 1), (2, 64, 64, 128, 3, 2), (2, 33, 40, 24, 1, 1),
+                                              (2, 30, 64, 64, 3, 2)])
+def test_conv_dgrad(dt, B, L, Cin, Cout, k, s):
+    from drn_amd import ops
+    x, w = conv_case(dt, B, L, Cin, Cout, k, s)
+    pad = (k - 1) // 2
+    xr = x.double().requires_grad_()
+    y = F.conv1d(xr, w.double(), stride=s, padding=pad)
+    Lo = y.shape[-1]
+    dy = rnd(tuple(y.shape), 9, DT[dt])
+    y.backward(dy.double())
+    ref = xr.grad.permute(0, 2, 1).reshape(B * L, Cin)
+    dyd = nlc(dy).to(dev())                                                 # (B,Lo,Cout)
+    wd = w.permute(1, 2, 0).contiguous().to(dev())                          # (Cin,k,Cout)
+    dX = torch.full((B * L, Cin), float("nan"), dtype=DT[dt], device=dev())
+    d = ops.gemm_desc(dyd, wd, dX, B * L, Cin, Cout, taps=k, stride=s, pad=pad, mode=1, Lout=L, Lsrc=Lo)
+    ops.gemm_nt([d], ops.dtype_code(dyd))
+    torch.cuda.synchronize()
+    close(dX, ref, TOL[dt], "dgrad")
+    # accumulate flag: run again into the same buffer -> 2x
+    d.accumulate = 1
+    ops.gemm_nt([d], ops.dtype_code(dyd))
+    torch.cuda.synchronize()
+    close(dX, 2 * ref, TOL[dt] * 2, "dgrad accumulate")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_grouped_shared_weights(dt):
+    """Three pyramid levels through one launch with shared weights (model/fcos.py:93-102)."""
+    from drn_amd import ops
+    B, Cin, Cout = 2, 64, 192
+    w = (rnd((Cout, Cin, 3), 5, DT[dt]) / np.sqrt(Cin * 3)).to(DT[dt])
+    wp = w.permute(0, 2, 1).contiguous().to(dev())
+    descs, outs, refs, stats = [], [], [], []
+    for lvl, L in enumerate((64, 32, 16)):
+        x = rnd((B, Cin, L), 10 + lvl, DT[dt])
+        ref = F.conv1d(x.double(), w.double(), padding=1).permute(0, 2, 1).reshape(B * L, Cout)
+        xd = nlc(x).to(dev())
+        C = torch.full((B * L, Cout), float("nan"), dtype=DT[dt], device=dev())
+        st = torch.zeros(((B * L + 127) // 128, 2, Cout), dtype=torch.float32, device=dev())
+        descs.append(ops.gemm_desc(xd, wp, C, B * L, Cout, Cin, taps=3, pad=1, Lout=L, Lsrc=L, stats=st))
+        outs.append((xd, C))
+        refs.append(ref)
+        stats.append(st)
+    ops.gemm_nt(descs, ops.dtype_code(wp))
+    torch.cuda.synchronize()
+    for lvl in range(3):
+        close(outs[lvl][1], refs[lvl], TOL[dt], "level %d" % lvl)
+        close(stats[lvl].double().cpu().sum(0)[0], refs[lvl].sum(0), TOL[dt] * 4, "stats level %d" % lvl)
+
+
+def test_bad_args_raise():
+    from drn_amd import ops, _lib
+    A = torch.zeros(16, 12, device=dev())
+    with pytest.raises(_lib.DrnError):
+        ops.gemm_nt([ops.gemm_desc(A, A, A, 16, 16, 12 + 1)], 0)            # Cin not multiple of 4
+    with pytest.raises(_lib.DrnError):
+        ops.gemm_desc(torch.zeros(4, 4), A, A, 4, 4, 4)                      # CPU tensor
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,L,Cin,Cout,k,s,layout", [(3, 50, 72, 136, 3, 1, 1), (2, 64, 64, 128, 3, 2, 0),
+                                                     (2, 33, 40, 24, 1, 1, 1), (8, 256, 320, 256, 3, 1, 1),
+                                                     (2, 30, 64, 64, 3, 2, 1), (1, 4096, 256, 128, 1, 1, 0)])
+def test_conv_wgrad(dt, B, L, Cin, Cout, k, s, layout):
+    from drn_amd import ops
+    x, w = conv_case(dt, B, L, Cin, Cout, k, s)
+    pad = (k - 1) // 2
+    wr = w.double().requires_grad_()
+    y = F.conv1d(x.double(), wr, stride=s, padding=pad)
+    Lo = y.shape[-1]
+    dy = rnd(tuple(y.shape), 9, DT[dt])
+    y.backward(dy.double())
+    ref = wr.grad                                                           # (Cout,Cin,k)
+    if layout == 0:
+        ref = ref.permute(0, 2, 1)
+    xd, dyd = nlc(x).to(dev()), nlc(dy).to(dev())
+    dW = torch.full(tuple(ref.shape), float("nan"), dtype=torch.float32, device=dev())
+    d = ops.wgrad_desc(dyd, xd, B * Lo, Lout=Lo, Lsrc=L)
+    ops.gemm_wgrad([d], dW, Cout, Cin, taps=k, stride=s, pad=pad, w_layout=layout, dtype=ops.dtype_code(xd))
+    torch.cuda.synchronize()
+    close(dW, ref, TOL[dt] * np.sqrt(B * Lo / 64), "wgrad")
+    ops.gemm_wgrad([d], dW, Cout, Cin, taps=k, stride=s, pad=pad, w_layout=layout, accumulate=True,
+                   dtype=ops.dtype_code(xd))
+    torch.cuda.synchronize()
+    close(dW, 2 * ref, TOL[dt] * 2 * np.sqrt(B * Lo / 64), "wgrad accumulate")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_wgrad_grouped_levels(dt):
+    """Shared-weight head conv: dW sums over the three pyramid levels (model/fcos.py:93-102)."""
+    from drn_amd import ops
+    B, Cin, Cout = 2, 64, 192
+    w = (rnd((Cout, Cin, 3), 5, DT[dt]) / np.sqrt(Cin * 3)).double().requires_grad_()
+    descs, keep, loss = [], [], 0
+    for lvl, L in enumerate((64, 32, 16)):
+        x = rnd((B, Cin, L), 10 + lvl, DT[dt])
+        dy = rnd((B, Cout, L), 20 + lvl, DT[dt])
+        loss = loss + (F.conv1d(x.double(), w, padding=1) * dy.double()).sum()
+        xd, dyd = nlc(x).to(dev()), nlc(dy).to(dev())
+        keep.append((xd, dyd))
+        descs.append(ops.wgrad_desc(dyd, xd, B * L, Lout=L, Lsrc=L))
+    loss.backward()
+    dW = torch.full((Cout, Cin, 3), float("nan"), dtype=torch.float32, device=dev())
+    ops.gemm_wgrad(descs, dW, Cout, Cin, taps=3, pad=1, w_layout=1, dtype=ops.dtype_code(keep[0][0]))
+    torch.cuda.synchronize()
+    close(dW, w.grad, TOL[dt] * 2, "grouped wgrad")
