@@ -28,13 +28,25 @@ class GemmDesc(ctypes.Structure):
                 ("Cin", c_int32), ("taps", c_int32), ("stride", c_int32), ("pad", c_int32), ("mode", c_int32),
                 ("Lout", c_int32), ("Lsrc", c_int32),
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldg", c_int32),
-                ("accumulate", c_int32)]
+                ("accumulate", c_int32), ("ldc2", c_int32)]
 
 
 class WgradDesc(ctypes.Structure):
     _fields_ = [("dY", c_void_p), ("X", c_void_p),
                 ("M", c_int32), ("Lout", c_int32), ("Lsrc", c_int32),
                 ("ldy", c_int32), ("ldx", c_int32)]
+
+
+class BnGroup(ctypes.Structure):
+    _fields_ = [("stats", c_void_p), ("tiles", c_int32), ("M", c_int32), ("scale_shift", c_void_p), ("save", c_void_p)]
+
+
+class HeadGroup(ctypes.Structure):
+    _fields_ = [("X", c_void_p), ("dX", c_void_p), ("ldx", c_int32), ("M", c_int32), ("L", c_int32), ("scale", c_void_p)]
+
+
+class LossLevel(ctypes.Structure):
+    _fields_ = [("L", c_int32), ("stride", c_float), ("lo", c_float), ("hi", c_float)]
 
 
 def lib():

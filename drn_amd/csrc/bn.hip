@@ -1,0 +1,247 @@
+// Train/eval BatchNorm1d (+ReLU) around the implicit-GEMM convs, channels-last.
+//
+// Reference: nn.BatchNorm1d inside conv blocks (model/basic_blocks.py:23-26, model/fcos.py:34,38,60,66),
+// momentum 0.1, eps 1e-5, biased batch variance for normalisation, unbiased for running_var.
+// Forward statistics come from the GEMM epilogue's per-tile column sums (deterministic); this file
+// finalises them (double accumulation), applies scale/shift(+ReLU) with the fused consumers'
+// prologues -- query gating (model/backbone.py:28-30) and FPN nearest-x2 upsample-add
+// (model/FPN.py:63-68) -- and implements the backward pass (reduce -> finalize -> apply).
+// A conv bias in front of a train-mode BN cancels in the output; it only shifts running_mean, so
+// the GEMM never adds it (its gradient is analytically zero).
+#include "vec.h"
+#include "../../include/drn_hip.h"
+
+struct BnFinGroup {
+  const float* stats;
+  int tiles, M;
+  float* scale_shift;
+  float* save;
+};
+struct BnFinParams {
+  int ngroups;
+  BnFinGroup g[DRN_MAX_GROUPS];
+};
+
+__global__ void bn_finalize_kernel(const BnFinParams P, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ conv_bias, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
+  const float cb = conv_bias ? conv_bias[c] : 0.f;
+  for (int g = 0; g < P.ngroups; ++g) {   // shared modules: levels update the running stats in order
+    const BnFinGroup& G = P.g[g];
+    double s = 0.0, q = 0.0;
+    for (int t = 0; t < G.tiles; ++t) {
+      s += (double)G.stats[((long)t * 2 + 0) * C + c];
+      q += (double)G.stats[((long)t * 2 + 1) * C + c];
+    }
+    const double mean = s / G.M;
+    double var = q / G.M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    G.scale_shift[c] = sc;
+    G.scale_shift[C + c] = beta[c] - (float)mean * sc;
+    G.save[c] = (float)mean;
+    G.save[C + c] = invstd;
+    const double unbiased = G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var;
+    rm = (1.f - momentum) * rm + momentum * ((float)mean + cb);
+    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+  }
+  if (running_mean) running_mean[c] = rm;
+  if (running_var) running_var[c] = rv;
+}
+
+extern "C" int drn_bn_finalize(const DrnBnGroup* groups, int ngroups, int C, const float* gamma, const float* beta,
+                               const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
+                               void* stream) {
+  DRN_CHECK_ARG(groups && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS && C > 0 && gamma && beta, "drn_bn_finalize: bad args");
+  BnFinParams P;
+  P.ngroups = ngroups;
+  for (int g = 0; g < ngroups; ++g) {
+    DRN_CHECK_ARG(groups[g].stats && groups[g].scale_shift && groups[g].save && groups[g].M > 0 && groups[g].tiles > 0,
+                  "drn_bn_finalize: bad group %d", g);
+    P.g[g].stats = groups[g].stats; P.g[g].tiles = groups[g].tiles; P.g[g].M = groups[g].M;
+    P.g[g].scale_shift = groups[g].scale_shift; P.g[g].save = groups[g].save;
+  }
+  bn_finalize_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(P, C, gamma, beta, conv_bias, running_mean, running_var, momentum, eps);
+  return drn_launch_status("drn_bn_finalize");
+}
+
+// eval mode: scale/shift from the running statistics (conv bias folded into the shift)
+__global__ void bn_eval_ss_kernel(int C, const float* gamma, const float* beta, const float* conv_bias, const float* rm, const float* rv,
+                                  float eps, float* ss) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  ss[c] = sc;
+  ss[C + c] = beta[c] + ((conv_bias ? conv_bias[c] : 0.f) - rm[c]) * sc;
+}
+extern "C" int drn_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const float* conv_bias, const float* running_mean,
+                                       const float* running_var, float eps, float* scale_shift, void* stream) {
+  DRN_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale_shift, "drn_bn_eval_scale_shift: bad args");
+  bn_eval_ss_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(C, gamma, beta, conv_bias, running_mean, running_var, eps, scale_shift);
+  return drn_launch_status("drn_bn_eval_scale_shift");
+}
+
+// out = [relu](raw*scale + shift) [+ up[s, t/2]] ;  gated = out * gate[s]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ raw, int ld_raw, const float* __restrict__ ss,
+                                                       T* __restrict__ out, int ld_out, int M, int C, int L,
+                                                       const T* __restrict__ up, int ld_up, const float* __restrict__ gate, int ldg,
+                                                       T* __restrict__ gated, int ld_gated, int relu) {
+  constexpr int N = V16<T>::N;
+  const int nvec = C / N;
+  const long total = (long)M * nvec;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const long m = i / nvec;
+    const int c0 = v * N;
+    float x[N];
+    V16<T>::load(raw + m * ld_raw + c0, x);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float y = fmaf(x[k], ss[c0 + k], ss[C + c0 + k]);
+      x[k] = relu ? fmaxf(y, 0.f) : y;
+    }
+    const long s = m / L;
+    if (up) {
+      const long t = m - s * L;
+      float u[N];
+      V16<T>::load(up + (s * (L >> 1) + (t >> 1)) * ld_up + c0, u);
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[k] += u[k];
+    }
+    V16<T>::store(out + m * ld_out + c0, x);
+    if (gated) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[k] *= gate[s * ldg + c0 + k];
+      V16<T>::store(gated + m * ld_gated + c0, x);
+    }
+  }
+}
+
+extern "C" int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shift, void* out, int ld_out, int M, int C, int L,
+                            const void* up, int ld_up, const float* gate, int ldg, void* gated, int ld_gated, int relu, int dtype,
+                            void* stream) {
+  DRN_CHECK_ARG(raw && scale_shift && out && M > 0 && C > 0 && L > 0 && M % L == 0, "drn_bn_apply: bad args");
+  DRN_CHECK_ARG(!up || (L % 2 == 0), "drn_bn_apply: upsample-add needs an even sequence length");
+  DRN_CHECK_ARG((gate != nullptr) == (gated != nullptr), "drn_bn_apply: gate and gated must come together");
+  DISPATCH_DT(dtype, "drn_bn_apply", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(C % N == 0 && ld_raw % N == 0 && ld_out % N == 0 && (!up || ld_up % N == 0) && (!gated || ld_gated % N == 0),
+                  "drn_bn_apply: C/ld must be 16-byte multiples");
+    bn_apply_kernel<T><<<ew_blocks((long)M * (C / N), 256), 256, 0, (hipStream_t)stream>>>(
+        (const T*)raw, ld_raw, scale_shift, (T*)out, ld_out, M, C, L, (const T*)up, ld_up, gate, ldg, (T*)gated, ld_gated, relu);
+  });
+  return drn_launch_status("drn_bn_apply");
+}
+
+// ---------------------------------------------------------------- backward
+// The ReLU mask is recomputed as fma(raw, scale, shift) > 0 with the forward's own scale/shift, so it is
+// bit-identical to the forward decision even when `out` had the FPN upsample added on top.
+// g = dOut * mask;  partial[blk][0][c] = sum g ; partial[blk][1][c] = sum g * xhat
+template <typename T>
+__global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const T* __restrict__ dout, int ld_dout, const T* __restrict__ raw, int ld_raw,
+                                                           const float* __restrict__ ss, const float* __restrict__ save, int M, int C,
+                                                           int relu, float* __restrict__ partial) {
+  constexpr int N = V16<T>::N;
+  const int nvec = C / N;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvec) return;
+  const int c0 = v * N;
+  float mean[N], istd[N], sc[N], sh[N], sg[N], sx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    mean[k] = save[c0 + k];
+    istd[k] = save[C + c0 + k];
+    sc[k] = ss[c0 + k];
+    sh[k] = ss[C + c0 + k];
+    sg[k] = 0.f;
+    sx[k] = 0.f;
+  }
+  for (int m = r0; m < r1; ++m) {
+    float g[N], x[N];
+    V16<T>::load(dout + (long)m * ld_dout + c0, g);
+    V16<T>::load(raw + (long)m * ld_raw + c0, x);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
+      sg[k] += gg;
+      sx[k] = fmaf(gg, (x[k] - mean[k]) * istd[k], sx[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    partial[((long)blockIdx.y * 2 + 0) * C + c0 + k] = sg[k];
+    partial[((long)blockIdx.y * 2 + 1) * C + c0 + k] = sx[k];
+  }
+}
+
+// dgamma/dbeta (+)= level sums;  coef: dRaw = A*g + B*raw + Cc
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ save, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       int accumulate, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sx = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    sg += (double)partial[((long)b * 2 + 0) * C + c];
+    sx += (double)partial[((long)b * 2 + 1) * C + c];
+  }
+  const float mean = save[c], istd = save[C + c];
+  const float s = gamma[c] * istd;
+  const float dg = (float)sx, db = (float)sg;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+  const float invM = 1.f / (float)M;
+  coef[c] = s;
+  coef[C + c] = -s * dg * istd * invM;
+  coef[2 * C + c] = -s * db * invM + s * dg * istd * mean * invM;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, int ld_dout, const T* __restrict__ raw, int ld_raw,
+                                                           const float* __restrict__ ss, const float* __restrict__ coef,
+                                                           T* __restrict__ draw, int ld_draw, int M, int C, int relu) {
+  constexpr int N = V16<T>::N;
+  const int nvec = C / N;
+  const long total = (long)M * nvec;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const long m = i / nvec;
+    const int c0 = v * N;
+    float g[N], x[N];
+    V16<T>::load(dout + m * ld_dout + c0, g);
+    V16<T>::load(raw + m * ld_raw + c0, x);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float gg = (relu && !(fmaf(x[k], ss[c0 + k], ss[C + c0 + k]) > 0.f)) ? 0.f : g[k];
+      x[k] = fmaf(coef[c0 + k], gg, fmaf(coef[C + c0 + k], x[k], coef[2 * C + c0 + k]));
+    }
+    V16<T>::store(draw + m * ld_draw + c0, x);
+  }
+}
+
+// draw may alias dout (in place).
+extern "C" int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld_raw, const float* scale_shift, const float* save,
+                          const float* gamma, void* draw, int ld_draw, float* dgamma, float* dbeta, int accumulate, int M, int C,
+                          int relu, float* ws /* >= (2*256+3)*C floats */, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(dout && raw && scale_shift && save && gamma && draw && ws && M > 0 && C > 0, "drn_bn_bwd: bad args");
+  const int nblk = M >= 256 * 8 ? 256 : (M >= 8 ? M / 8 : 1);
+  float* coef = ws + (long)2 * 256 * C;
+  DISPATCH_DT(dtype, "drn_bn_bwd", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(C % N == 0 && ld_dout % N == 0 && ld_raw % N == 0 && ld_draw % N == 0, "drn_bn_bwd: C/ld must be 16-byte multiples");
+    dim3 grid(cdiv(C / N, 64), nblk);
+    bn_bwd_reduce_kernel<T><<<grid, 64, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw, scale_shift, save, M, C, relu, ws);
+    bn_bwd_finalize_kernel<<<cdiv(C, 128), 128, 0, stream>>>(ws, nblk, M, C, gamma, save, dgamma, dbeta, accumulate, coef);
+    bn_bwd_apply_kernel<T><<<ew_blocks((long)M * (C / N), 256), 256, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw,
+                                                                                 scale_shift, coef, (T*)draw, ld_draw, M, C, relu);
+  });
+  return drn_launch_status("drn_bn_bwd");
+}

@@ -1,0 +1,261 @@
+// HBM-bound helpers of the DRN path: casts / weight packing, position embedding
+// (model/main_model.py:51-55), FPN top-down pair-sum (backward of F.interpolate nearest x2,
+// model/FPN.py:63), query-gate backward (model/backbone.py:28-30), column sums (bias gradients).
+// All activation tensors are channels-last; 16 bytes per lane per access.
+#include "vec.h"
+#include "../../include/drn_hip.h"
+
+// ---------------------------------------------------------------- cast fp32 -> T
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, long nvec) {
+  constexpr int N = V16<T>::N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float v[N];
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      const f32x4 t = *(const f32x4*)(in + i * N + j);
+      v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
+    }
+    V16<T>::store(out + i * N, v);
+  }
+}
+template <typename T>
+__global__ void cast_tail_kernel(const float* __restrict__ in, T* __restrict__ out, long start, long n) {
+  const long i = start + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) DT<T>::st(out + i, in[i]);
+}
+
+extern "C" int drn_cast(const float* in, void* out, int64_t n, int dtype, void* stream) {
+  DRN_CHECK_ARG(in && out && n >= 0, "drn_cast: bad args");
+  if (n == 0) return DRN_OK;
+  DISPATCH_DT(dtype, "drn_cast", {
+    constexpr int N = V16<T>::N;
+    const long nvec = n / N;
+    if (nvec) cast_kernel<T><<<ew_blocks(nvec, 256), 256, 0, (hipStream_t)stream>>>(in, (T*)out, nvec);
+    if (n - nvec * N) cast_tail_kernel<T><<<1, 64, 0, (hipStream_t)stream>>>(in, (T*)out, nvec * N, n);
+  });
+  return drn_launch_status("drn_cast");
+}
+
+// ---------------------------------------------------------------- weight packing (permute + cast)
+// out[a][b][c] = in[a*sa + b*sb + c*sc]
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ in, T* __restrict__ out, int A, int B, int C, long sa, long sb, long sc) {
+  const long total = (long)A * B * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long ab = i / C;
+    const int b = (int)(ab % B);
+    const long a = ab / B;
+    DT<T>::st(out + i, in[a * sa + b * sb + c * sc]);
+  }
+}
+
+extern "C" int drn_pack_weight(const float* in, void* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, int dtype,
+                               void* stream) {
+  DRN_CHECK_ARG(in && out && A > 0 && B > 0 && C > 0, "drn_pack_weight: bad args");
+  DISPATCH_DT(dtype, "drn_pack_weight", {
+    pack_kernel<T><<<ew_blocks((long)A * B * C, 256), 256, 0, (hipStream_t)stream>>>(in, (T*)out, A, B, C, sa, sb, sc);
+  });
+  return drn_launch_status("drn_pack_weight");
+}
+
+// ---------------------------------------------------------------- position embedding
+// out[m][j] = W[j][0]*f0 + W[j][1]*f1 + W[j][2]*f2 + b[j]   (nn.Linear(3,256), main_model.py:34,55)
+template <typename T>
+__global__ void pos_embed_kernel(const float* __restrict__ feat, const float* __restrict__ W, const float* __restrict__ b,
+                                 T* __restrict__ out, int ld, int M, int C) {
+  const long total = (long)M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % C);
+    const long m = i / C;
+    const float* f = feat + m * 3;
+    // same association order as a row-times-matrix product: ((f0*w0 + f1*w1) + f2*w2) + b
+    float v = f[0] * W[j * 3 + 0];
+    v = fmaf(f[1], W[j * 3 + 1], v);
+    v = fmaf(f[2], W[j * 3 + 2], v);
+    DT<T>::st(out + m * ld + j, v + b[j]);
+  }
+}
+extern "C" int drn_pos_embed_fwd(const float* feat, const float* W, const float* b, void* out, int ld_out, int M, int C, int dtype,
+                                 void* stream) {
+  DRN_CHECK_ARG(feat && W && b && out && M > 0 && C > 0, "drn_pos_embed_fwd: bad args");
+  DISPATCH_DT(dtype, "drn_pos_embed_fwd",
+              { pos_embed_kernel<T><<<ew_blocks((long)M * C, 256), 256, 0, (hipStream_t)stream>>>(feat, W, b, (T*)out, ld_out, M, C); });
+  return drn_launch_status("drn_pos_embed_fwd");
+}
+
+// partial[blk][k][j], k<4: sum_m dOut[m][j] * {f0,f1,f2,1}
+template <typename T>
+__global__ void pos_embed_bwd_kernel(const T* __restrict__ dout, int ld, const float* __restrict__ feat, int M, int C,
+                                     float* __restrict__ partial) {
+  const int rows_per = (M + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  for (int j = threadIdx.x; j < C; j += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int m = r0; m < r1; ++m) {
+      const float g = DT<T>::ld(dout + (long)m * ld + j);
+      a0 = fmaf(g, feat[m * 3 + 0], a0);
+      a1 = fmaf(g, feat[m * 3 + 1], a1);
+      a2 = fmaf(g, feat[m * 3 + 2], a2);
+      a3 += g;
+    }
+    float* p = partial + (long)blockIdx.x * 4 * C;
+    p[0 * C + j] = a0; p[1 * C + j] = a1; p[2 * C + j] = a2; p[3 * C + j] = a3;
+  }
+}
+__global__ void pos_embed_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dW,
+                                           float* __restrict__ db, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < nblk; ++b)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += partial[((long)b * 4 + k) * C + j];
+  if (accumulate) {
+    s[0] += dW[j * 3 + 0]; s[1] += dW[j * 3 + 1]; s[2] += dW[j * 3 + 2]; s[3] += db[j];
+  }
+  dW[j * 3 + 0] = s[0]; dW[j * 3 + 1] = s[1]; dW[j * 3 + 2] = s[2]; db[j] = s[3];
+}
+extern "C" int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, int M, int C, float* dW, float* db, int accumulate,
+                                 float* ws /* >= 64*4*C floats */, int dtype, void* stream) {
+  DRN_CHECK_ARG(dout && feat && dW && db && ws && M > 0 && C > 0, "drn_pos_embed_bwd: bad args");
+  const int nblk = M < 64 ? 1 : 64;
+  DISPATCH_DT(dtype, "drn_pos_embed_bwd",
+              { pos_embed_bwd_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>((const T*)dout, ld, feat, M, C, ws); });
+  pos_embed_bwd_final_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, dW, db, accumulate);
+  return drn_launch_status("drn_pos_embed_bwd");
+}
+
+// ---------------------------------------------------------------- FPN top-down backward: dst[s,t] += src[s,2t] + src[s,2t+1]
+template <typename T>
+__global__ void pairsum_add_kernel(T* __restrict__ dst, int ld_dst, const T* __restrict__ src, int ld_src, int Mdst, int C) {
+  constexpr int N = V16<T>::N;
+  const int nvec = C / N;
+  const long total = (long)Mdst * nvec;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const long m = i / nvec;  // rows of src are exactly 2m, 2m+1 (sequence lengths are even)
+    float d[N], a[N], b[N];
+    V16<T>::load(dst + m * ld_dst + v * N, d);
+    V16<T>::load(src + (2 * m) * ld_src + v * N, a);
+    V16<T>::load(src + (2 * m + 1) * ld_src + v * N, b);
+#pragma unroll
+    for (int k = 0; k < N; ++k) d[k] += a[k] + b[k];
+    V16<T>::store(dst + m * ld_dst + v * N, d);
+  }
+}
+extern "C" int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int dtype, void* stream) {
+  DRN_CHECK_ARG(dst && src && Mdst > 0 && C > 0, "drn_pairsum_add: bad args");
+  DISPATCH_DT(dtype, "drn_pairsum_add", {
+    DRN_CHECK_ARG(C % V16<T>::N == 0 && ld_dst % V16<T>::N == 0 && ld_src % V16<T>::N == 0, "drn_pairsum_add: C/ld must be 16-byte multiples");
+    pairsum_add_kernel<T><<<ew_blocks((long)Mdst * (C / V16<T>::N), 256), 256, 0, (hipStream_t)stream>>>((T*)dst, ld_dst, (const T*)src, ld_src, Mdst, C);
+  });
+  return drn_launch_status("drn_pairsum_add");
+}
+
+// ---------------------------------------------------------------- query-gate backward
+// forward was G[s,t,c] = act[s,t,c] * gate[s,c].  Here:
+//   dC[s,t,c] (+)= dG[s,t,c] * gate[s,c]        dgate[s,c] = sum_t dG[s,t,c] * act[s,t,c]
+// grid (ceil(nvec/32), nseq); block 256 = 32 channel vectors x 8 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG, int ld_dg, const T* __restrict__ act, int ld_act,
+                                                       const float* __restrict__ gate, int ldg, T* __restrict__ dC, int ld_dc,
+                                                       int accumulate, float* __restrict__ dgate, int ld_dgate, int L, int C) {
+  constexpr int N = V16<T>::N;
+  __shared__ float red[8][32 * N + 1];
+  const int vx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int v = blockIdx.x * 32 + vx;
+  const int s = blockIdx.y;
+  const int c0 = v * N;
+  const bool live = c0 < C;
+  float gt[N], acc[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    gt[k] = live ? gate[(long)s * ldg + c0 + k] : 0.f;
+    acc[k] = 0.f;
+  }
+  if (live) {
+    for (int t = ry; t < L; t += 8) {
+      const long m = (long)s * L + t;
+      float g[N], a[N];
+      V16<T>::load(dG + m * ld_dg + c0, g);
+      V16<T>::load(act + m * ld_act + c0, a);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = fmaf(g[k], a[k], acc[k]);
+      if (dC) {
+        float o[N];
+        if (accumulate) V16<T>::load(dC + m * ld_dc + c0, o);
+#pragma unroll
+        for (int k = 0; k < N; ++k) o[k] = accumulate ? fmaf(g[k], gt[k], o[k]) : g[k] * gt[k];
+        V16<T>::store(dC + m * ld_dc + c0, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) red[ry][vx * N + k] = acc[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * N; i += 256) {
+    const int c = blockIdx.x * 32 * N + i;
+    if (c < C) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r][i];
+      dgate[(long)s * ld_dgate + c] = sum;
+    }
+  }
+}
+extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, void* dC, int ld_dc,
+                            int accumulate, float* dgate, int ld_dgate, int nseq, int L, int C, int dtype, void* stream) {
+  DRN_CHECK_ARG(dG && act && gate && dgate && nseq > 0 && L > 0 && C > 0, "drn_gate_bwd: bad args");
+  DISPATCH_DT(dtype, "drn_gate_bwd", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && (!dC || ld_dc % N == 0), "drn_gate_bwd: C/ld must be 16-byte multiples");
+    dim3 grid(cdiv(C / N, 32), nseq);
+    gate_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (T*)dC, ld_dc,
+                                                                accumulate, dgate, ld_dgate, L, C);
+  });
+  return drn_launch_status("drn_gate_bwd");
+}
+
+// ---------------------------------------------------------------- column sum (bias gradients): out[c] (+)= sum_m X[m][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int ld, int M, int C, float* __restrict__ partial) {
+  constexpr int N = V16<T>::N;
+  const int nvec = C / N;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvec) return;
+  float acc[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = 0.f;
+  for (int m = r0; m < r1; ++m) {
+    float x[N];
+    V16<T>::load(X + (long)m * ld + v * N, x);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] += x[k];
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) partial[(long)blockIdx.y * C + v * N + k] = acc[k];
+}
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ out, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(long)b * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+extern "C" int drn_colsum(const void* X, int ld, int M, int C, float* out, int accumulate, float* ws /* >= 64*C floats */, int dtype,
+                          void* stream) {
+  DRN_CHECK_ARG(X && out && ws && M > 0 && C > 0, "drn_colsum: bad args");
+  const int nblk = M >= 64 * 16 ? 64 : (M >= 16 ? M / 16 : 1);
+  DISPATCH_DT(dtype, "drn_colsum", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(C % N == 0 && ld % N == 0, "drn_colsum: C/ld must be 16-byte multiples");
+    dim3 grid(cdiv(C / N, 256), nblk);
+    colsum_partial_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)X, ld, M, C, ws);
+  });
+  reduce_partials_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, out, accumulate);
+  return drn_launch_status("drn_colsum");
+}

@@ -34,7 +34,7 @@ struct GemmProb {
   int M, N, K;
   int Cin, taps, stride, pad, mode;
   int Lout, Lsrc;
-  int lda, ldb, ldc, ldg;
+  int lda, ldb, ldc, ldg, ldc2;
   int accumulate;
   int tiles_n, tile_start;
 };
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void conv_gemm_nt_kernel(const GemmP
         float v = acc[mi][ni][r];
         if (pr.bias) v += pr.bias[n];
         const long off = (long)m * pr.ldc + n;
-        if (C2g) DT<T>::st(C2g + off, v);
+        if (C2g) DT<T>::st(C2g + ((long)m * pr.ldc2 + n), v);
         if (grow) v *= grow[n];
         if (pr.accumulate) v += DT<T>::ld(Cg + off);
         DT<T>::st(Cg + off, v);
@@ -275,7 +275,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     DRN_CHECK_ARG(s.Lout > 0 && s.Lsrc > 0 && s.M % s.Lout == 0, "drn_gemm_nt: M=%d not a multiple of Lout=%d", s.M, s.Lout);
     p.A = s.A; p.B = s.B; p.C = s.C; p.C2 = s.C2; p.bias = s.bias; p.gate = s.gate; p.stats = s.stats;
     p.M = s.M; p.N = s.N; p.K = s.taps * s.Cin; p.Cin = s.Cin; p.taps = s.taps; p.stride = s.stride; p.pad = s.pad;
-    p.mode = s.mode; p.Lout = s.Lout; p.Lsrc = s.Lsrc; p.lda = s.lda; p.ldb = s.ldb; p.ldc = s.ldc; p.ldg = s.ldg;
+    p.mode = s.mode; p.Lout = s.Lout; p.Lsrc = s.Lsrc; p.lda = s.lda; p.ldb = s.ldb; p.ldc = s.ldc; p.ldg = s.ldg; p.ldc2 = s.ldc2;
     p.accumulate = s.accumulate;
     p.tiles_n = cdiv(s.N, TILE);
     p.tile_start = total;

@@ -1,0 +1,225 @@
+// FCOS-style target assignment and the three DRN losses, forward and backward, fused into two
+// single-workgroup kernels (<= ~30k locations; everything is a few hundred KB).
+//
+// Reference: FCOSLossComputation (model/loss.py:40-239): compute_targets_for_locations (90-127),
+// SigmoidFocalLoss (model/layers/sigmoid_focal_loss.py:40-52; the CUDA kernel of fcos_core._C is the same
+// function in its numerically stable form, which is what is computed here), IOULoss
+// (model/layers/iou_loss.py:6-24), segment_tiou + SmoothL1 on predictions with tIoU > 0.9 (loss.py:168-197).
+// Quirks reproduced: divisor n_pos + B; the clamp at loss.py:180-181 hits LOCATION
+// index 0 (level 0, t = 0) of every clip; the SmoothL1 target carries gradient back into the box
+// regression; ties in min/max split their gradient evenly (torch's elementwise min/max rule).
+// No host synchronisation: positive counts stay on the device (out[3], out[4]) and the backward
+// kernel reads them there.
+#include "common.h"
+#include "../../include/drn_hip.h"
+
+#define LOSS_THREADS 1024
+
+struct LossParams {
+  int nlevels, B, total_rows;
+  int row_start[DRN_MAX_GROUPS], L[DRN_MAX_GROUPS];
+  float stride[DRN_MAX_GROUPS], lo[DRN_MAX_GROUPS], hi[DRN_MAX_GROUPS];
+  float gamma, alpha, target_scale;  // 2.0, 0.25, 32
+  int iou_stage;                     // 0: first stage (no IoU-score loss)
+};
+
+struct Loc {
+  int level, b, t;
+  float loc;
+};
+__device__ __forceinline__ Loc locate(const LossParams& P, int r) {
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.nlevels && r >= P.row_start[i]) g = i;
+  Loc o;
+  o.level = g;
+  const int m = r - P.row_start[g];
+  o.b = m / P.L[g];
+  o.t = m - o.b * P.L[g];
+  o.loc = (float)o.t * P.stride[g] + P.stride[g] * 0.5f;  // model/fcos.py:204-211
+  return o;
+}
+
+__device__ __forceinline__ float softplus(float x) { return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
+
+struct IouTerm {
+  bool masked;
+  float tiou, p, d;
+  float dt_ds, dt_de;  // d tIoU / d pred_start, d pred_end (already including the clamp mask)
+};
+__device__ __forceinline__ IouTerm iou_term(const LossParams& P, const Loc& q, float r0, float r1, float gs, float ge, float iou_logit) {
+  IouTerm o;
+  float ps = (q.loc - r0) / P.target_scale, pe = (q.loc + r1) / P.target_scale;
+  float ms = 1.f, me = 1.f;
+  if (q.level == 0 && q.t == 0) {  // loss.py:180-181
+    ms = (ps >= 0.f && ps <= 1.f) ? 1.f : 0.f;
+    me = (pe >= 0.f && pe <= 1.f) ? 1.f : 0.f;
+    ps = fminf(fmaxf(ps, 0.f), 1.f);
+    pe = fminf(fmaxf(pe, 0.f), 1.f);
+  }
+  const float imax = fminf(pe, ge), imin = fmaxf(ps, gs);
+  const float umax = fmaxf(pe, ge), umin = fminf(ps, gs);
+  const float inter = fmaxf(imax - imin, 0.f), uni = fmaxf(umax - umin, 0.f);
+  o.tiou = inter / (uni + 1e-6f);
+  o.masked = o.tiou > 0.9f;
+  o.p = 1.f / (1.f + expf(-iou_logit));
+  o.d = o.p - o.tiou;
+  // gradients of tIoU (only used where masked: inter > 0 and union > 0 there)
+  const float di_de = (imax - imin >= 0.f) ? (pe < ge ? 1.f : (pe == ge ? 0.5f : 0.f)) : 0.f;
+  const float di_ds = (imax - imin >= 0.f) ? -(ps > gs ? 1.f : (ps == gs ? 0.5f : 0.f)) : 0.f;
+  const float du_de = (umax - umin >= 0.f) ? (pe > ge ? 1.f : (pe == ge ? 0.5f : 0.f)) : 0.f;
+  const float du_ds = (umax - umin >= 0.f) ? -(ps < gs ? 1.f : (ps == gs ? 0.5f : 0.f)) : 0.f;
+  const float den = uni + 1e-6f;
+  o.dt_de = me * (di_de * den - inter * du_de) / (den * den);
+  o.dt_ds = ms * (di_ds * den - inter * du_ds) / (den * den);
+  return o;
+}
+
+__device__ __forceinline__ bool assign_label(const LossParams& P, const Loc& q, float gs, float ge, float& tl, float& tr) {
+  tl = q.loc - gs * P.target_scale;   // loss.py:98-101
+  tr = ge * P.target_scale - q.loc;
+  const float mn = fminf(tl, tr), mx = fmaxf(tl, tr);
+  return mn > 0.f && mx >= P.lo[q.level] && mx <= P.hi[q.level];
+}
+
+// out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ; out[4] = n_iou_pos ; labels[r] (optional) for inspection
+__global__ __launch_bounds__(LOSS_THREADS) void fcos_loss_fwd_kernel(const LossParams P, const float* __restrict__ logits,
+                                                                     const float* __restrict__ reg, const float* __restrict__ iou,
+                                                                     const float* __restrict__ gt, float* __restrict__ out,
+                                                                     float* __restrict__ labels) {
+  __shared__ float sh[17];
+  float s_focal = 0.f, s_ioul = 0.f, s_sl1 = 0.f, n_pos = 0.f, n_iou = 0.f;
+  for (int r = threadIdx.x; r < P.total_rows; r += LOSS_THREADS) {
+    const Loc q = locate(P, r);
+    const float gs = gt[q.b * 2], ge = gt[q.b * 2 + 1];
+    float tl, tr;
+    const bool pos = assign_label(P, q, gs, ge, tl, tr);
+    if (labels) labels[r] = pos ? 1.f : 0.f;
+    const float x = logits[r];
+    const float p = 1.f / (1.f + expf(-x));
+    // -log(p) = softplus(-x), -log(1-p) = softplus(x)
+    if (pos) s_focal += P.alpha * powf(1.f - p, P.gamma) * softplus(-x);
+    else s_focal += (1.f - P.alpha) * powf(p, P.gamma) * softplus(x);
+    const float pl = reg[r * 2], prr = reg[r * 2 + 1];
+    if (pos) {
+      n_pos += 1.f;
+      const float inter = fminf(prr, tr) + fminf(pl, tl);
+      const float uni = (tl + tr) + (pl + prr) - inter;
+      s_ioul += -logf((inter + 1e-8f) / (uni + 1e-8f));
+    }
+    if (P.iou_stage) {
+      const IouTerm it = iou_term(P, q, pl, prr, gs, ge, iou[r]);
+      if (it.masked) {
+        n_iou += 1.f;
+        const float ad = fabsf(it.d);
+        s_sl1 += ad < 1.f ? 0.5f * it.d * it.d : ad - 0.5f;
+      }
+    }
+  }
+  s_focal = block_sum(s_focal, sh);
+  s_ioul = block_sum(s_ioul, sh);
+  s_sl1 = block_sum(s_sl1, sh);
+  n_pos = block_sum(n_pos, sh);
+  n_iou = block_sum(n_iou, sh);
+  if (threadIdx.x == 0) {
+    out[0] = s_focal / (n_pos + (float)P.B);          // loss.py:213
+    out[1] = n_pos > 0.f ? s_ioul / n_pos : 0.f;       // loss.py:219-231
+    out[2] = n_iou > 0.f ? s_sl1 / n_iou : 0.f;        // loss.py:194-197
+    out[3] = n_pos;
+    out[4] = n_iou;
+  }
+}
+
+// gin[0..2]: upstream gradients of (loss_cls, loss_reg, loss_iou).  Outputs: dlogits[r], dreg[r][2], diou[r].
+__global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, const float* __restrict__ logits,
+                                                                     const float* __restrict__ reg, const float* __restrict__ iou,
+                                                                     const float* __restrict__ gt, const float* __restrict__ fwd_out,
+                                                                     const float* __restrict__ gin, float* __restrict__ dlogits,
+                                                                     float* __restrict__ dreg, float* __restrict__ diou) {
+  const float n_pos = fwd_out[3], n_iou = fwd_out[4];
+  const float k_cls = gin[0] / (n_pos + (float)P.B);
+  const float k_reg = n_pos > 0.f ? gin[1] / n_pos : 0.f;
+  const float k_iou = (P.iou_stage && n_iou > 0.f) ? gin[2] / n_iou : 0.f;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P.total_rows; r += gridDim.x * blockDim.x) {
+    const Loc q = locate(P, r);
+    const float gs = gt[q.b * 2], ge = gt[q.b * 2 + 1];
+    float tl, tr;
+    const bool pos = assign_label(P, q, gs, ge, tl, tr);
+    const float x = logits[r];
+    const float p = 1.f / (1.f + expf(-x));
+    float dx;
+    if (pos) {
+      // d/dx [ alpha (1-p)^g softplus(-x) ] = alpha (1-p)^g [ -g p softplus(-x) - (1-p) ]   
+      const float om = 1.f - p;
+      dx = P.alpha * powf(om, P.gamma) * (-P.gamma * p * softplus(-x) - om);
+    } else {
+      dx = (1.f - P.alpha) * powf(p, P.gamma) * (P.gamma * (1.f - p) * softplus(x) + p);
+    }
+    dlogits[r] = dx * k_cls;
+    const float pl = reg[r * 2], prr = reg[r * 2 + 1];
+    float d0 = 0.f, d1 = 0.f;  // gradient w.r.t. reg[r][0..1]
+    if (pos && k_reg != 0.f) {
+      const float inter = fminf(prr, tr) + fminf(pl, tl);
+      const float uni = (tl + tr) + (pl + prr) - inter;
+      const float dil = pl < tl ? 1.f : (pl == tl ? 0.5f : 0.f);
+      const float dir = prr < tr ? 1.f : (prr == tr ? 0.5f : 0.f);
+      d0 = k_reg * (-dil / (inter + 1e-8f) + (1.f - dil) / (uni + 1e-8f));
+      d1 = k_reg * (-dir / (inter + 1e-8f) + (1.f - dir) / (uni + 1e-8f));
+    }
+    if (P.iou_stage) {
+      float di = 0.f;
+      const IouTerm it = iou_term(P, q, pl, prr, gs, ge, iou[r]);
+      if (it.masked && k_iou != 0.f) {
+        const float sl = fabsf(it.d) < 1.f ? it.d : (it.d > 0.f ? 1.f : -1.f);
+        di = k_iou * sl * it.p * (1.f - it.p);
+        const float dt = -k_iou * sl;                 // the target carries gradient (A.3 #2)
+        d0 += dt * it.dt_ds * (-1.f / P.target_scale);
+        d1 += dt * it.dt_de * (1.f / P.target_scale);
+      }
+      diou[r] = di;
+    }
+    dreg[r * 2] = d0;
+    dreg[r * 2 + 1] = d1;
+  }
+}
+
+static int fill_loss_params(LossParams& P, const DrnLossLevel* levels, int nlevels, int B, float gamma, float alpha, float target_scale,
+                            int iou_stage, const char* who) {
+  DRN_CHECK_ARG(levels && nlevels >= 1 && nlevels <= DRN_MAX_GROUPS && B > 0, "%s: bad level table", who);
+  memset(&P, 0, sizeof(P));
+  P.nlevels = nlevels; P.B = B;
+  int rows = 0;
+  for (int l = 0; l < nlevels; ++l) {
+    DRN_CHECK_ARG(levels[l].L > 0, "%s: level %d has no locations", who, l);
+    P.row_start[l] = rows; P.L[l] = levels[l].L; P.stride[l] = levels[l].stride; P.lo[l] = levels[l].lo; P.hi[l] = levels[l].hi;
+    rows += B * levels[l].L;
+  }
+  P.total_rows = rows;
+  P.gamma = gamma; P.alpha = alpha; P.target_scale = target_scale; P.iou_stage = iou_stage;
+  return DRN_OK;
+}
+
+extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg, const float* iou,
+                                 const float* gt, float gamma, float alpha, float target_scale, int iou_stage, float* out5,
+                                 float* labels, void* stream) {
+  LossParams P;
+  int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_fwd");
+  if (rc) return rc;
+  DRN_CHECK_ARG(logits && reg && gt && out5 && (!iou_stage || iou), "drn_fcos_loss_fwd: null pointer");
+  fcos_loss_fwd_kernel<<<1, LOSS_THREADS, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, out5, labels);
+  return drn_launch_status("drn_fcos_loss_fwd");
+}
+
+extern "C" int drn_fcos_loss_bwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg,
+                                 const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
+                                 const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream) {
+  LossParams P;
+  int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_bwd");
+  if (rc) return rc;
+  DRN_CHECK_ARG(logits && reg && gt && fwd_out5 && grad_in3 && dlogits && dreg && (!iou_stage || (iou && diou)),
+                "drn_fcos_loss_bwd: null pointer");
+  fcos_loss_bwd_kernel<<<cdiv(P.total_rows, 256), 256, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, fwd_out5, grad_in3, dlogits,
+                                                                                 dreg, diou);
+  return drn_launch_status("drn_fcos_loss_bwd");
+}

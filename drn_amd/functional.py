@@ -1,0 +1,395 @@
+"""Autograd glue between the reference-shaped Python modules (drn_amd/model) and the HIP kernels.
+
+Each `torch.autograd.Function` below owns one fused stage of the DRN hot path; forward and
+backward are sequences of libdrn_hip.so launches (drn_amd/ops.py) on torch's current stream.
+Activations are channels-last ("NLC", shape (B, L, C), C contiguous, row stride may exceed C for
+column slices of a wider buffer) in the compute dtype (float32 = exact-f32 MFMA parity mode,
+bfloat16 = storage with fp32 accumulation).  Parameters stay fp32 and are re-laid / cast per use.
+"""
+import weakref
+
+import torch
+
+from . import ops
+from ._lib import DrnError
+
+_pack_cache = {}
+
+
+def packed(w, perm, code):
+    """Weight `w` (3-D fp32 parameter) permuted + cast for the GEMM; cached on the parameter version."""
+    if not isinstance(w, torch.nn.Parameter):
+        # temporaries (e.g. stacked tower weights) may reuse an address with version 0: never cache them
+        return ops.pack_weight(w.detach(), perm, code)
+    key = (id(w), w.data_ptr(), perm, code)
+    ver = w._version
+    hit = _pack_cache.get(key)
+    # the weakref guards against a new Parameter re-using a dead one's id / address / version
+    if hit is not None and hit[0] == ver and hit[2]() is w and hit[1].device == w.device:
+        return hit[1]
+    out = ops.pack_weight(w.detach(), perm, code)
+    if len(_pack_cache) > 256:
+        _pack_cache.clear()
+    _pack_cache[key] = (ver, out, weakref.ref(w))
+    return out
+
+
+def code_of(dtype):
+    return ops.BF16 if dtype == torch.bfloat16 else ops.F32
+
+
+def geom(x):
+    """(B, L, C, ld) of a channels-last activation; validates the layout."""
+    if x.dim() != 3 or x.stride(2) != 1 or (x.shape[0] > 1 and x.stride(0) != x.shape[1] * x.stride(1)):
+        raise DrnError("expected a channels-last (B, L, C) activation, got shape %s strides %s"
+                       % (tuple(x.shape), x.stride()))
+    return x.shape[0], x.shape[1], x.shape[2], x.stride(1)
+
+
+def as_nlc(x_ncl, dtype):
+    """Logical (B, C, L) tensor -> (B, L, C) channels-last view in the compute dtype (copy only if needed)."""
+    x = x_ncl.permute(0, 2, 1)
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    if x.stride(2) != 1 or (x.shape[0] > 1 and x.stride(0) != x.shape[1] * x.stride(1)):
+        x = x.contiguous()
+    return x
+
+
+def _grad_nlc(g, like_shape, dtype):
+    if g is None:
+        return None
+    if g.dtype != dtype:
+        g = g.to(dtype)
+    if not g.is_contiguous():
+        g = g.contiguous()
+    return g
+
+
+class ConvMeta(object):
+    """Static (non-tensor) description of one conv+BN(+ReLU) block call."""
+
+    def __init__(self, stride, bn, training, dtype, relu=True):
+        self.stride, self.bn, self.training, self.dtype, self.relu = stride, bn, training, dtype, relu
+
+
+class _ConvBlockFn(torch.autograd.Function):
+    """Conv1d(k, stride, pad=(k-1)//2) -> BatchNorm1d -> ReLU over 1..3 pyramid levels with shared weights
+    (model/basic_blocks.py:5-33; model/fcos.py:29-42,58-69), with the consumer prologues fused into the
+    BN-apply pass: `gate` (B,C) -> second output out*gate (model/backbone.py:28-30), `up` (B,L/2,C) ->
+    out += nearest-x2 upsample (model/FPN.py:63-68).  Implicit GEMM on MFMA, batch statistics from the
+    GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, meta, weight, cbias, gamma, beta, gate, up, *xs):
+        dt = meta.dtype
+        code = code_of(dt)
+        Cout, Cin, k = weight.shape
+        pad = (k - 1) // 2
+        nl = len(xs)
+        assert nl == 1 or (gate is None and up is None)
+        wp = packed(weight, (0, 2, 1), code)
+        dev = weight.device
+        geo, raws, stats, descs = [], [], [], []
+        for x in xs:
+            if x.dtype != dt:
+                raise DrnError("activation dtype %s != compute dtype %s" % (x.dtype, dt))
+            B, L, C, ld = geom(x)
+            assert C == Cin, (C, Cin)
+            Lo = (L + 2 * pad - k) // meta.stride + 1
+            M = B * Lo
+            raw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+            st = torch.empty(((M + 127) // 128, 2, Cout), dtype=torch.float32, device=dev) if meta.training else None
+            descs.append(ops.gemm_desc(x, wp, raw, M, Cout, Cin, taps=k, stride=meta.stride, pad=pad, Lout=Lo, Lsrc=L,
+                                       lda=ld, stats=st))
+            geo.append((B, L, Lo, M, ld))
+            raws.append(raw)
+            stats.append(st)
+        ops.gemm_nt(descs, code)
+        bn = meta.bn
+        sss, saves = [], []
+        if meta.training:
+            if bn.momentum is None:
+                raise DrnError("cumulative-average BatchNorm (momentum=None) is not supported")
+            groups = []
+            for l in range(nl):
+                ss = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                sv = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                groups.append((stats[l], stats[l].shape[0], geo[l][3], ss, sv))
+                sss.append(ss)
+                saves.append(sv)
+            track = bn.track_running_stats and bn.running_mean is not None
+            ops.bn_finalize(groups, Cout, gamma, beta, cbias, bn.running_mean if track else None,
+                            bn.running_var if track else None, bn.momentum, bn.eps)
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(nl)
+        else:
+            ss = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+            ops.bn_eval_scale_shift(Cout, gamma, beta, cbias, bn.running_mean, bn.running_var, bn.eps, ss)
+            sss = [ss] * nl
+        outs, gated = [], None
+        for l in range(nl):
+            B, L, Lo, M, ld = geo[l]
+            out = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+            if gate is not None:
+                gated = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+            upl = None
+            if up is not None:
+                ub, ul, uc, uld = geom(up)
+                assert (ub, ul * 2, uc) == (B, Lo, Cout), "upsample source must be (B, L/2, C)"
+                upl = up
+            ops.bn_apply(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, C=Cout, L=Lo, dtype=code,
+                         up=upl, ld_up=upl.stride(1) if upl is not None else 0, gate=gate, gated=gated, ld_gated=Cout,
+                         relu=meta.relu)
+            outs.append(out)
+        ctx.meta, ctx.nl, ctx.geo, ctx.k = meta, nl, geo, k
+        ctx.has_gate, ctx.has_up, ctx.has_cbias = gate is not None, up is not None, cbias is not None
+        ctx.save_for_backward(weight, gamma, gate if gate is not None else weight.new_empty(0), *xs, *raws, *sss, *saves, *outs)
+        res = tuple(outs)
+        if gate is not None:
+            res = res + (gated,)
+        return res
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        meta, nl, geo, k = ctx.meta, ctx.nl, ctx.geo, ctx.k
+        if not meta.training:
+            raise DrnError("backward through an eval-mode BatchNorm block is not supported")
+        dt = meta.dtype
+        code = code_of(dt)
+        sv = ctx.saved_tensors
+        weight, gamma, gate = sv[0], sv[1], sv[2]
+        xs = sv[3:3 + nl]
+        raws = sv[3 + nl:3 + 2 * nl]
+        sss = sv[3 + 2 * nl:3 + 3 * nl]
+        saves = sv[3 + 3 * nl:3 + 4 * nl]
+        outs = sv[3 + 4 * nl:3 + 5 * nl]
+        Cout, Cin, _ = weight.shape
+        pad = (k - 1) // 2
+        dev = weight.device
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        dgate = dup = None
+        draws = []
+        for l in range(nl):
+            B, L, Lo, M, ld = geo[l]
+            d = _grad_nlc(gouts[l], None, dt)
+            if ctx.has_gate:
+                dG = _grad_nlc(gouts[nl], None, dt)
+                dgate = torch.zeros((B, Cout), dtype=torch.float32, device=dev)
+                if dG is not None:
+                    if d is None:
+                        d = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+                        acc = False
+                    else:
+                        d = d.clone()
+                        acc = True
+                    ops.gate_bwd(dG, Cout, outs[l], Cout, gate, d, Cout, acc, dgate, B, Lo, Cout, code)
+            if d is None:
+                d = torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
+            if ctx.has_up:
+                dup = torch.zeros((B, Lo // 2, Cout), dtype=dt, device=dev)
+                ops.pairsum_add(dup, Cout, d, Cout, B * (Lo // 2), Cout, code)
+            draw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+            ops.bn_bwd(d, Cout, raws[l], Cout, sss[l], saves[l], gamma, draw, Cout, dgamma, dbeta, l > 0, M, Cout, code,
+                       relu=meta.relu)
+            draws.append(draw)
+        dxs = [None] * nl
+        if any(ctx.needs_input_grad[7 + l] for l in range(nl)):
+            wd = packed(weight, (1, 2, 0), code)                       # (Cin, k, Cout)
+            descs = []
+            for l in range(nl):
+                B, L, Lo, M, ld = geo[l]
+                dx = torch.empty((B, L, Cin), dtype=dt, device=dev)
+                descs.append(ops.gemm_desc(draws[l], wd, dx, B * L, Cin, Cout, taps=k, stride=meta.stride, pad=pad, mode=1,
+                                           Lout=L, Lsrc=Lo))
+                dxs[l] = dx
+            ops.gemm_nt(descs, code)
+        dW = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
+                  for l in range(nl)]
+        ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
+        dcb = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_cbias else None   # cancels in train-mode BN
+        return (None, dW, dcb, dgamma, dbeta, dgate, dup) + tuple(dxs)
+
+
+def conv_block(xs, conv, bn, training, dtype, gate=None, up=None, relu=True):
+    """Apply conv->BN->ReLU (modules are parameter holders) to a list of channels-last level inputs."""
+    meta = ConvMeta(conv.stride[0], bn, training, dtype, relu)
+    res = _ConvBlockFn.apply(meta, conv.weight, conv.bias, bn.weight, bn.bias, gate, up, *xs)
+    if gate is not None:
+        return list(res[:-1]), res[-1]
+    return list(res), None
+
+
+class _InputStageFn(torch.autograd.Function):
+    """prop_fc + level-0 query gating + position embedding, written into one (B, T, D+P) buffer that is conv0's
+    input (model/main_model.py:51-59,67 + model/backbone.py:28-32: Linear, `q * x`, cat) -- one MFMA GEMM whose
+    epilogue adds the bias, keeps the pre-gate value for backward and applies the gate, plus one tiny kernel."""
+
+    @staticmethod
+    def forward(ctx, dtype, feats, posfeat, Wfc, bfc, gate0, Wpos, bpos):
+        code = code_of(dtype)
+        B, T, D = feats.shape
+        P = Wpos.shape[0]
+        dev = feats.device
+        xc = feats.contiguous()
+        if xc.dtype != dtype:
+            xc = ops.cast(xc.float(), code)
+        wfc = Wfc.detach() if code == ops.F32 else ops.cast(Wfc.detach(), code)
+        G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
+        Z = torch.empty((B, T, D), dtype=dtype, device=dev)
+        ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),
+                                   C2=Z, ldc2=D)], code)
+        pf = posfeat.reshape(B * T, 3).contiguous().float()
+        pos_slice = G0.view(B * T, D + P)[:, D:]
+        ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
+        ctx.dtype, ctx.dims = dtype, (B, T, D, P)
+        ctx.save_for_backward(xc, pf, gate0, Z)
+        return G0
+
+    @staticmethod
+    def backward(ctx, dG0):
+        dtype = ctx.dtype
+        code = code_of(dtype)
+        B, T, D, P = ctx.dims
+        xc, pf, gate0, Z = ctx.saved_tensors
+        dev = xc.device
+        dG0 = _grad_nlc(dG0, None, dtype)
+        dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
+        dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
+        ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, False, dgate, B, T, D, code)
+        dW = torch.empty((D, D), dtype=torch.float32, device=dev)
+        ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
+        db = torch.empty(D, dtype=torch.float32, device=dev)
+        ops.colsum(dZ, D, B * T, D, db, code)
+        dWp = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        dbp = torch.empty(P, dtype=torch.float32, device=dev)
+        ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, dWp, dbp, code)
+        return None, None, None, dW, db, dgate, dWp, dbp
+
+
+def input_stage(feats, posfeat, prop_fc, gate0, position_transform, dtype):
+    return _InputStageFn.apply(dtype, feats, posfeat, prop_fc.weight, prop_fc.bias, gate0, position_transform.weight,
+                               position_transform.bias)
+
+
+class _HeadOutFn(torch.autograd.Function):
+    """Per-location output convs with 1-2 channels over all pyramid levels: `nheads` heads, head h reading the
+    column slice [col[h], col[h]+C) of every level tensor (cls_logits / bbox_pred on the two tower halves,
+    model/fcos.py:96-100; or the final iou_scores conv, fcos.py:68,102).  Outputs are fp32 (R, N_h), rows
+    ordered level-first / clip-major (the order model/loss.py:150-166 flattens to)."""
+
+    @staticmethod
+    def forward(ctx, meta, *args):
+        nheads, nl, dtype = meta["nheads"], meta["nl"], meta["dtype"]
+        code = code_of(dtype)
+        heads = [args[3 * h:3 * h + 3] for h in range(nheads)]           # (W, bias, scales|None)
+        xs = args[3 * nheads:]
+        dev = xs[0].device
+        geo = [geom(x) for x in xs]
+        R = sum(g[0] * g[1] for g in geo)
+        outs, zs = [], []
+        for h, (W, bias, scales) in enumerate(heads):
+            N, C, taps = W.shape
+            c0 = meta["cols"][h]
+            xsl = [(x[:, :, c0:c0 + C], g[3], g[0] * g[1], g[1]) for x, g in zip(xs, geo)]
+            groups = ops.head_groups(xsl, scales=scales)
+            out = torch.empty((R, N), dtype=torch.float32, device=dev)
+            z = torch.empty((R, N), dtype=torch.float32, device=dev) if scales is not None else None
+            ops.head_out_fwd(groups, W, bias, N, C, taps, scales is not None, out, z, code)
+            outs.append(out)
+            zs.append(z if z is not None else out.new_empty(0))
+        ctx.meta, ctx.geo, ctx.R = meta, geo, R
+        ctx.save_for_backward(*args, *outs, *zs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        meta, geo, R = ctx.meta, ctx.geo, ctx.R
+        nheads, nl, dtype = meta["nheads"], meta["nl"], meta["dtype"]
+        code = code_of(dtype)
+        sv = ctx.saved_tensors
+        nargs = 3 * nheads + nl
+        args, outs, zs = sv[:nargs], sv[nargs:nargs + nheads], sv[nargs + nheads:]
+        xs = args[3 * nheads:]
+        dev = xs[0].device
+        width = xs[0].shape[2]
+        covered = sorted((meta["cols"][h], meta["cols"][h] + args[3 * h].shape[1]) for h in range(nheads))
+        full = covered[0][0] == 0 and covered[-1][1] == width and all(covered[i][1] == covered[i + 1][0]
+                                                                      for i in range(len(covered) - 1))
+        alloc = torch.empty if full else torch.zeros
+        dxs = [alloc((g[0], g[1], g[2]), dtype=dtype, device=dev) for g in geo]
+        grads = []
+        for h in range(nheads):
+            W, bias, scales = args[3 * h:3 * h + 3]
+            N, C, taps = W.shape
+            c0 = meta["cols"][h]
+            dout = douts[h]
+            dW = torch.zeros(W.shape, dtype=torch.float32, device=dev)
+            db = torch.zeros(N, dtype=torch.float32, device=dev)
+            dsc = torch.zeros(nl, dtype=torch.float32, device=dev) if scales is not None else None
+            if dout is not None:
+                dout = dout.contiguous().float()
+                xsl = [(x[:, :, c0:c0 + C], g[3], g[0] * g[1], g[1]) for x, g in zip(xs, geo)]
+                dsl = [dx[:, :, c0:c0 + C] for dx in dxs]
+                groups = ops.head_groups(xsl, dxs=dsl, scales=scales)
+                # dX geometry must match X's: both are slices of equally wide buffers
+                for x, dx in zip(xs, dxs):
+                    assert x.stride(1) == dx.stride(1), "head input must be contiguous in backward"
+                ops.head_out_bwd(groups, W, dout, outs[h], zs[h] if scales is not None else None, N, C, taps,
+                                 scales is not None, False, dW, db, dsc, R, code)
+            elif full:
+                for dx in dxs:
+                    dx[:, :, c0:c0 + C].zero_()
+            grads += [dW, db, dsc]
+        return (None,) + tuple(grads) + tuple(dxs)
+
+
+def head_out(xs, heads, cols, dtype):
+    """heads: list of (conv_module, scales_tensor_or_None); cols: first input channel of each head."""
+    meta = {"nheads": len(heads), "nl": len(xs), "dtype": dtype, "cols": list(cols)}
+    args = []
+    for conv, scales in heads:
+        args += [conv.weight, conv.bias, scales]
+    return _HeadOutFn.apply(meta, *args, *xs)
+
+
+class _FCOSLossFn(torch.autograd.Function):
+    """Target assignment + focal / IoU / IoU-score losses (model/loss.py:40-239) in one kernel each way.
+    Returns (losses3, counts2): losses3 = [loss_cls, loss_reg, loss_iou], counts2 = [n_pos, n_iou_pos]."""
+
+    @staticmethod
+    def forward(ctx, meta, logits, reg, iou, gt):
+        levels = ops.loss_levels(meta["levels"])
+        B = meta["B"]
+        out5 = torch.empty(5, dtype=torch.float32, device=logits.device)
+        logits, reg = logits.contiguous(), reg.contiguous()
+        iou = iou.contiguous() if iou is not None else None
+        gt = gt.contiguous().float()
+        ops.fcos_loss_fwd(levels, B, logits, reg, iou, gt, meta["gamma"], meta["alpha"], meta["target_scale"],
+                          meta["iou_stage"], out5)
+        ctx.meta = meta
+        ctx.save_for_backward(logits, reg, iou if iou is not None else logits.new_empty(0), gt, out5)
+        counts = out5[3:5].clone()
+        ctx.mark_non_differentiable(counts)
+        return out5[:3].clone(), counts
+
+    @staticmethod
+    def backward(ctx, gl, _gc):
+        meta = ctx.meta
+        logits, reg, iou, gt, out5 = ctx.saved_tensors
+        levels = ops.loss_levels(meta["levels"])
+        has_iou = bool(meta["iou_stage"])
+        dlogits = torch.empty_like(logits)
+        dreg = torch.empty_like(reg)
+        diou = torch.empty_like(iou) if has_iou else None
+        ops.fcos_loss_bwd(levels, meta["B"], logits, reg, iou if has_iou else None, gt, meta["gamma"], meta["alpha"],
+                          meta["target_scale"], meta["iou_stage"], out5, gl.contiguous().float(), dlogits, dreg, diou)
+        return None, dlogits, dreg, diou, None
+
+
+def fcos_loss(logits, reg, iou, gt, levels, B, gamma, alpha, target_scale, iou_stage):
+    meta = {"levels": levels, "B": B, "gamma": float(gamma), "alpha": float(alpha), "target_scale": float(target_scale),
+            "iou_stage": int(bool(iou_stage))}
+    return _FCOSLossFn.apply(meta, logits, reg, iou if iou_stage else None, gt)

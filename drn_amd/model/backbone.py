@@ -1,0 +1,37 @@
+"""Query-gated temporal conv backbone (reference: model/backbone.py:4-36)."""
+import torch
+import torch.nn as nn
+
+from .. import functional as DF
+
+
+class Backbone(nn.Module):
+    compute_dtype = torch.float32
+
+    def __init__(self, channels_list, conv_block):
+        super(Backbone, self).__init__()
+        self.num_layers = len(channels_list)
+        self.blocks = []
+        for idx, (cin, cout, k, stride) in enumerate(channels_list):
+            name = "forward_conv{}".format(idx)
+            self.add_module(name, conv_block(cin, cout, kernel_size=k, stride=stride))
+            self.blocks.append(name)
+
+    def forward_from_stage(self, g0, gates):
+        """g0: (B, T, D+P) channels-last = cat(q0 * prop_fc(x), position feats) (drn_amd.functional.input_stage);
+        gates[i]: (B, C_i) fp32.  The gate of level i+1 is fused into level i's BN-apply pass."""
+        outs, x = [], g0
+        for idx in range(self.num_layers):
+            nxt = gates[idx + 1] if idx + 1 < self.num_layers else None
+            out, gated = getattr(self, self.blocks[idx]).forward_nlc([x], gate=nxt)
+            outs.append(out[0])
+            x = gated
+        return outs
+
+    def forward(self, x, query_fts, position_fts):
+        """Reference signature (model/backbone.py:17): x (B, C, T), query_fts[i] (B, C_i), position_fts[0] (B, P, T).
+        The level-0 gate + concat is plain tensor glue here; mainModel uses the fused input stage instead."""
+        dt = self.compute_dtype
+        g0 = torch.cat([DF.as_nlc(x, dt) * query_fts[0].to(dt)[:, None, :], DF.as_nlc(position_fts[0], dt)], dim=2)
+        outs = self.forward_from_stage(g0, [q.float() for q in query_fts])
+        return tuple(o.permute(0, 2, 1) for o in outs)

@@ -1,0 +1,159 @@
+"""Dense regression heads + FCOS module (reference: model/fcos.py:10-241)."""
+import math
+import types
+
+import torch
+from torch import nn
+
+from .. import functional as DF
+from .inference import make_fcos_postprocessor
+from .loss import make_fcos_loss_evaluator
+
+
+class Scale(nn.Module):
+    """model/fcos.py:10-16.  In the head, the multiply is fused with exp() into the bbox_pred kernel."""
+
+    def __init__(self, init_value=1.0):
+        super(Scale, self).__init__()
+        self.scale = nn.Parameter(torch.FloatTensor([init_value]))
+
+    def forward(self, input):
+        return input * self.scale
+
+
+class LevelList(list):
+    """Per-level (B, N, L) views of one fp32 (R, N) buffer; `.flat` keeps the buffer so the loss can
+    consume it without re-concatenating (rows are level-first / clip-major, model/loss.py:150-166)."""
+    flat = None
+
+
+class FCOSHead(torch.nn.Module):
+    compute_dtype = torch.float32
+
+    def __init__(self, cfg, in_channels):
+        super(FCOSHead, self).__init__()
+        num_classes = cfg["fcos_num_class"] - 1
+        cls_tower, bbox_tower = [], []
+        for _ in range(cfg["fcos_conv_layers"]):
+            cls_tower += [nn.Conv1d(in_channels, in_channels, 3, stride=1, padding=1), nn.BatchNorm1d(in_channels), nn.ReLU()]
+            bbox_tower += [nn.Conv1d(in_channels, in_channels, 3, stride=1, padding=1), nn.BatchNorm1d(in_channels), nn.ReLU()]
+        self.add_module('cls_tower', nn.Sequential(*cls_tower))
+        self.add_module('bbox_tower', nn.Sequential(*bbox_tower))
+        self.cls_logits = nn.Conv1d(in_channels, num_classes, kernel_size=3, stride=1, padding=1)
+        self.bbox_pred = nn.Conv1d(in_channels, 2, kernel_size=3, stride=1, padding=1)
+        self.centerness = nn.Conv1d(in_channels, 1, kernel_size=3, stride=1, padding=1)    # declared, never called
+        self.mix_fc = nn.Sequential(nn.Conv1d(2 * in_channels, in_channels, kernel_size=1, stride=1),
+                                    nn.BatchNorm1d(in_channels), nn.ReLU())
+        self.iou_scores = nn.Sequential(nn.Conv1d(in_channels, in_channels // 2, kernel_size=3, stride=1, padding=1),
+                                        nn.BatchNorm1d(in_channels // 2), nn.ReLU(),
+                                        nn.Conv1d(in_channels // 2, 1, kernel_size=1, stride=1))
+        for modules in [self.cls_tower, self.bbox_tower, self.cls_logits, self.bbox_pred, self.centerness,
+                        self.iou_scores, self.mix_fc]:
+            for l in modules.modules():
+                if isinstance(l, nn.Conv1d):
+                    torch.nn.init.normal_(l.weight, std=0.01)
+                    torch.nn.init.constant_(l.bias, 0)
+        prior_prob = cfg["fcos_prior_prob"]
+        torch.nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_prob) / prior_prob))
+        self.scales = nn.ModuleList([Scale(init_value=1.0) for _ in range(3)])
+        if num_classes != 1:
+            raise NotImplementedError("DRN uses a single foreground class (fcos_num_class=2)")
+
+    # -- towers -----------------------------------------------------------------------------------------
+    def _towers(self, xs):
+        """cat(cls_tower(x), bbox_tower(x)) per level as ONE implicit GEMM with N = 2C: the two towers' first
+        convs read the same input, so their weights are stacked and the result is already the concatenation
+        mix_fc wants (model/fcos.py:94-95,101).  BN statistics stay per level and per channel."""
+        dt = self.compute_dtype
+        nlayers = len(self.cls_tower) // 3
+        if nlayers != 1:
+            ct, bt = xs, xs
+            for i in range(nlayers):
+                ct, _ = DF.conv_block(ct, self.cls_tower[3 * i], self.cls_tower[3 * i + 1], self.training, dt)
+                bt, _ = DF.conv_block(bt, self.bbox_tower[3 * i], self.bbox_tower[3 * i + 1], self.training, dt)
+            return [torch.cat([c, b], dim=2) for c, b in zip(ct, bt)]
+        cc, cb, bc, bb = self.cls_tower[0], self.cls_tower[1], self.bbox_tower[0], self.bbox_tower[1]
+        conv = types.SimpleNamespace(weight=torch.cat([cc.weight, bc.weight], 0), bias=torch.cat([cc.bias, bc.bias], 0),
+                                     stride=(1,))
+        rm = torch.cat([cb.running_mean, bb.running_mean]) if cb.running_mean is not None else None
+        rv = torch.cat([cb.running_var, bb.running_var]) if cb.running_var is not None else None
+        bn = types.SimpleNamespace(weight=torch.cat([cb.weight, bb.weight]), bias=torch.cat([cb.bias, bb.bias]),
+                                   running_mean=rm, running_var=rv, num_batches_tracked=None, momentum=cb.momentum,
+                                   eps=cb.eps, track_running_stats=cb.track_running_stats)
+        out, _ = DF.conv_block(xs, conv, bn, self.training, dt)
+        if self.training and rm is not None:
+            C = cb.num_features
+            with torch.no_grad():
+                cb.running_mean.copy_(rm[:C]); bb.running_mean.copy_(rm[C:])
+                cb.running_var.copy_(rv[:C]); bb.running_var.copy_(rv[C:])
+                cb.num_batches_tracked.add_(len(xs)); bb.num_batches_tracked.add_(len(xs))
+        return out
+
+    def forward_nlc(self, xs):
+        """xs: channels-last (B, L_l, C) pyramid levels.  Returns flat fp32 buffers
+        (logits (R,1), reg (R,2), iou (R,1)) plus the level geometry [(B, L_l)]."""
+        dt = self.compute_dtype
+        C = xs[0].shape[2]
+        ctbt = self._towers(xs)                                            # (B, L, 2C) per level
+        scales = torch.cat([s.scale for s in self.scales[:len(xs)]])
+        logits, reg = DF.head_out(ctbt, [(self.cls_logits, None), (self.bbox_pred, scales)], cols=[0, C], dtype=dt)
+        mix, _ = DF.conv_block(ctbt, self.mix_fc[0], self.mix_fc[1], self.training, dt)
+        iouf, _ = DF.conv_block(mix, self.iou_scores[0], self.iou_scores[1], self.training, dt)
+        (iou,) = DF.head_out(iouf, [(self.iou_scores[3], None)], cols=[0], dtype=dt)
+        return logits, reg, iou, [(x.shape[0], x.shape[1]) for x in xs]
+
+    @staticmethod
+    def split_levels(flat, geo):
+        out, r = LevelList(), 0
+        for B, L in geo:
+            out.append(flat[r:r + B * L].view(B, L, -1).permute(0, 2, 1))
+            r += B * L
+        out.flat = flat
+        return out
+
+    def forward(self, x):
+        """Reference signature (model/fcos.py:87-105): list of (B, C, L) -> (logits, bbox_reg, centerness=[], iou_scores)."""
+        logits, reg, iou, geo = self.forward_nlc([DF.as_nlc(f, self.compute_dtype) for f in x])
+        return self.split_levels(logits, geo), self.split_levels(reg, geo), [], self.split_levels(iou, geo)
+
+
+class FCOSModule(torch.nn.Module):
+    """model/fcos.py:108-211 without the per-batch pickle side effect."""
+
+    def __init__(self, cfg, in_channels):
+        super(FCOSModule, self).__init__()
+        self.head = FCOSHead(cfg, in_channels)
+        self.is_first_stage = cfg['is_first_stage']
+        self.box_selector_test = make_fcos_postprocessor(cfg)
+        self.loss_evaluator = make_fcos_loss_evaluator(cfg)
+        self.fpn_strides = cfg["fpn_stride"]
+        self.loss_evaluator.fpn_strides = list(self.fpn_strides)
+
+    def forward(self, features, targets=None):
+        box_cls, box_regression, centerness, iou_scores = self.head(features)
+        locations = self.compute_locations(features)
+        if self.training:
+            return self._forward_train(locations, box_cls, box_regression, targets, iou_scores)
+        return self._forward_test(locations, box_cls, box_regression, targets, iou_scores)
+
+    def _forward_train(self, locations, box_cls, box_regression, targets, iou_scores):
+        loss_box_cls, loss_box_reg, loss_iou = self.loss_evaluator(
+            locations, box_cls, box_regression, targets, iou_scores, self.is_first_stage)
+        return None, {"loss_cls": loss_box_cls, "loss_reg": loss_box_reg, "loss_iou": loss_iou}
+
+    def _forward_test(self, locations, box_cls, box_regression, targets, iou_scores):
+        boxes = self.box_selector_test(locations, box_cls, box_regression, iou_scores)
+        loss_box_cls, loss_box_reg, loss_iou = self.loss_evaluator(
+            locations, box_cls, box_regression, targets, iou_scores, self.is_first_stage)
+        return boxes, {"loss_cls": loss_box_cls, "loss_reg": loss_box_reg, "loss_iou": loss_iou}
+
+    def compute_locations(self, features):
+        return [self.compute_locations_per_level(f.size(-1), self.fpn_strides[l], f.device) for l, f in enumerate(features)]
+
+    def compute_locations_per_level(self, t, stride, device):
+        shifts_t = torch.arange(0, t * stride, step=stride, dtype=torch.float32, device=device)
+        return shifts_t.reshape(-1) + stride / 2
+
+
+def build_fcos(cfg, in_channels):
+    return FCOSModule(cfg, in_channels)

@@ -1,0 +1,69 @@
+"""Query encoder (reference: model/language_module.py:9-98, model/ops.py:16-25,74-85).
+
+SURVEY section 8 keeps this off the hand-written path for now (1.2 % of forward time; row 8f-4 "next"):
+it is stock PyTorch-ROCm (Embedding, MIOpen LSTM, small Linears) producing the three (B, 1024) query
+vectors that feed the HIP path's gates."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+
+class Linear(nn.Linear):
+    """model/ops.py:16-25: TensorFlow-style xavier uniform, zero bias."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        bound = np.sqrt(3. / ((self.in_features + self.out_features) / 2.))
+        nn.init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, 0.)
+
+
+class TextualAttention(nn.Module):
+    """model/language_module.py:65-74: constructed by the reference but never called (keeps checkpoint keys)."""
+
+    def __init__(self, hidden_dim=1024):
+        super(TextualAttention, self).__init__()
+        self.hidden_dim = hidden_dim
+        self.q_dim = hidden_dim * 2
+        self.W1 = nn.Linear(self.hidden_dim, 1)
+        self.W2 = nn.Linear(self.q_dim, self.hidden_dim)
+        self.W3 = nn.Linear(self.q_dim, self.q_dim)
+
+
+class QueryEncoder(nn.Module):
+    def __init__(self, vocab_size, hidden_dim=512, embed_dim=300, num_layers=1, bidirection=True):
+        super(QueryEncoder, self).__init__()
+        self.hidden_dim = hidden_dim
+        self.embed_dim = embed_dim
+        self.embedding = nn.Embedding(vocab_size + 1, embed_dim, padding_idx=0)
+        self.biLSTM = nn.LSTM(embed_dim, self.hidden_dim, num_layers, dropout=0.0, batch_first=True,
+                              bidirectional=bidirection)
+        self.textualAttention = TextualAttention()
+        self.qInput = Linear(self.hidden_dim * 4, self.hidden_dim)
+        for t in range(3):
+            setattr(self, "qInput%d" % t, Linear(self.hidden_dim, self.hidden_dim * 2))
+        self.cmd_inter2logits = Linear(self.hidden_dim * 2, 1)
+
+    def forward(self, query_tokens, query_length):
+        emb = self.embedding(query_tokens)
+        lengths_cpu = query_length.detach().to("cpu", torch.int64)
+        packed = pack_padded_sequence(emb, lengths_cpu, batch_first=True)
+        self.biLSTM.flatten_parameters()
+        output, _ = self.biLSTM(packed)
+        output, _ = pad_packed_sequence(output, batch_first=True)         # (B, Lmax, 2H)
+        B, Lmax, H2 = output.shape
+        lengths = lengths_cpu.to(output.device)
+        last = output.gather(1, (lengths - 1).view(B, 1, 1).expand(B, 1, H2)).squeeze(1)
+        q_vector = torch.cat((output[:, 0], last), dim=-1)                # language_module.py:48-54
+        base = F.relu(self.qInput(q_vector))
+        pad = torch.arange(Lmax, device=output.device).view(1, Lmax) >= lengths.view(B, 1)
+        outputs = []
+        for t in range(3):                                                # language_module.py:27-36
+            q_cmd = getattr(self, "qInput%d" % t)(base)
+            raw_att = self.cmd_inter2logits(q_cmd[:, None, :] * output).squeeze(-1)
+            att = F.softmax(raw_att.masked_fill(pad, -1e30), dim=-1)
+            outputs.append(torch.bmm(att[:, None, :], output).squeeze(1))
+        return outputs

@@ -1,0 +1,77 @@
+"""DRN top-level model (reference: model/main_model.py:13-81): same constructor/forward signature, attribute
+names and state_dict keys, so main.py-style trainers and reference checkpoints work unchanged."""
+import torch
+import torch.nn as nn
+
+from .. import functional as DF
+from .._lib import DrnError
+from .backbone import Backbone
+from .basic_blocks import conv_with_kaiming_uniform
+from .fcos import FCOSHead, build_fcos
+from .FPN import FPN
+from .language_module import QueryEncoder
+
+
+class mainModel(nn.Module):
+    def __init__(self, vocab_size, dataset_configs, hidden_dim=512, embed_dim=300, bidirection=True,
+                 graph_node_features=1024, compute_dtype=torch.float32):
+        super(mainModel, self).__init__()
+        dataset_configs = vars(dataset_configs) if not isinstance(dataset_configs, dict) else dataset_configs
+        self.first_output_dim = dataset_configs["first_output_dim"]
+        self.fpn_feature_dim = dataset_configs["fpn_feature_dim"]
+        self.feature_dim = dataset_configs[dataset_configs['feature_type']]['feature_dim']
+        self.query_encoder = QueryEncoder(vocab_size, hidden_dim, embed_dim, dataset_configs["lstm_layers"], bidirection)
+        channels_list = [
+            (self.feature_dim + 256, self.first_output_dim, 3, 1),
+            (self.first_output_dim, self.first_output_dim * 2, 3, 2),
+            ((self.first_output_dim * 2), self.first_output_dim * 4, 3, 2),
+        ]
+        conv_func = conv_with_kaiming_uniform(use_bn=True, use_relu=True)
+        self.backbone_net = Backbone(channels_list, conv_func)
+        self.fpn = FPN([256, 512, 1024], 512, conv_func)
+        self.fcos = build_fcos(dataset_configs, self.fpn_feature_dim)
+        self.prop_fc = nn.Linear(self.feature_dim, self.feature_dim)
+        self.position_transform = nn.Linear(3, 256)
+        for t in range(len(channels_list)):
+            setattr(self, "qInput%d" % t, nn.Linear(1024, self.feature_dim if t == 0 else channels_list[t - 1][1]))
+        self.set_compute_dtype(compute_dtype)
+        self.taps = None      # set to a dict to record intermediate activations (tests / debugging)
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32: exact-f32 MFMA (<=1e-4 parity with the reference); torch.bfloat16: bf16 storage + fp32 accumulate."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise DrnError("compute dtype must be float32 or bfloat16")
+        for m in self.modules():
+            if hasattr(type(m), "compute_dtype"):
+                m.compute_dtype = dtype
+        self.compute_dtype = dtype
+        return self
+
+    def forward(self, query_tokens, query_length, props_features, props_start_end, gt_start_end, props_num=None,
+                num_frames=None):
+        if not props_features.is_cuda:
+            raise DrnError("drn_amd.mainModel runs on an MI355X only (inputs on %s); no CPU fallback" % props_features.device)
+        dt = self.compute_dtype
+        query_features = self.query_encoder(query_tokens, query_length)
+        gates = [getattr(self, "qInput%d" % i)(query_features[i]) for i in range(len(query_features))]
+        # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
+        duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
+        position_feat = torch.cat((props_start_end, duration), dim=-1).float()
+        g0 = DF.input_stage(props_features, position_feat, self.prop_fc, gates[0], self.position_transform, dt)
+        backbone_feats = self.backbone_net.forward_from_stage(g0, gates)
+        feats = self.fpn.forward_nlc(backbone_feats)
+        head = self.fcos.head
+        logits, reg, iou, geo = head.forward_nlc(feats)
+        box_cls, box_reg, iou_scores = (FCOSHead.split_levels(t, geo) for t in (logits, reg, iou))
+        if self.taps is not None:
+            for i, f in enumerate(backbone_feats):
+                self.taps["backbone_net.forward_conv%d" % i] = f.permute(0, 2, 1)
+            for i, f in enumerate(feats):
+                self.taps["fpn.fpn_layer%d" % (i + 1)] = f.permute(0, 2, 1)
+            self.taps["head"] = (box_cls, box_reg, [], iou_scores)
+        fc = self.fcos
+        locations = [fc.compute_locations_per_level(L, fc.fpn_strides[l], logits.device) for l, (_, L) in enumerate(geo)]
+        targets = gt_start_end.float()
+        if self.training:
+            return fc._forward_train(locations, box_cls, box_reg, targets, iou_scores)
+        return fc._forward_test(locations, box_cls, box_reg, targets, iou_scores)

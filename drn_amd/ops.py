@@ -37,14 +37,15 @@ def _need_gpu(*ts):
 
 
 def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Lsrc=None, lda=None, ldb=None,
-              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, accumulate=False):
+              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, ldc2=None, accumulate=False):
     _need_gpu(A, B, C, bias, gate, stats, C2)
     Lout = M if Lout is None else Lout
     Lsrc = Lout if Lsrc is None else Lsrc
     return GemmDesc(A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), gate=_p(gate), stats=_p(stats),
                     M=M, N=N, Cin=Cin, taps=taps, stride=stride, pad=pad, mode=mode, Lout=Lout, Lsrc=Lsrc,
                     lda=Cin if lda is None else lda, ldb=taps * Cin if ldb is None else ldb,
-                    ldc=N if ldc is None else ldc, ldg=ldg, accumulate=int(accumulate))
+                    ldc=N if ldc is None else ldc, ldg=ldg, accumulate=int(accumulate),
+                    ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2)
 
 
 def gemm_nt(descs, dtype):
@@ -69,3 +70,134 @@ def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulat
     arr = (WgradDesc * len(descs))(*descs)
     check(lib().drn_gemm_wgrad(arr, len(descs), _p(dW), N, Cin, taps, stride, pad, w_layout, int(accumulate),
                                _p(ws), dtype, _stream()), "drn_gemm_wgrad")
+
+
+# ---------------------------------------------------------------------------------------------
+# HBM-bound helpers
+# ---------------------------------------------------------------------------------------------
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+_ws_cache = {}
+
+
+def workspace(n_floats, device):
+    """A grow-only fp32 scratch buffer per device (stream-ordered reuse on torch's current stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def cast(x, dtype):
+    """fp32 -> compute dtype (contiguous)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=TORCH_DT[dtype], device=x.device)
+    check(lib().drn_cast(_p(x), _p(out), ctypes.c_int64(x.numel()), dtype, _stream()), "drn_cast")
+    return out
+
+
+def pack_weight(w, perm, dtype):
+    """out = w.permute(perm).contiguous() in compute dtype; w is a 3-D fp32 parameter (any strides)."""
+    _need_gpu(w)
+    assert w.dtype == torch.float32 and w.dim() == 3
+    shape = [w.shape[i] for i in perm]
+    st = [w.stride(i) for i in perm]
+    out = torch.empty(shape, dtype=TORCH_DT[dtype], device=w.device)
+    check(lib().drn_pack_weight(_p(w), _p(out), shape[0], shape[1], shape[2], ctypes.c_int64(st[0]), ctypes.c_int64(st[1]),
+                                ctypes.c_int64(st[2]), dtype, _stream()), "drn_pack_weight")
+    return out
+
+
+def pos_embed_fwd(feat, W, b, out2d, ld_out, M, C, dtype):
+    check(lib().drn_pos_embed_fwd(_p(feat), _p(W), _p(b), _p(out2d), ld_out, M, C, dtype, _stream()), "drn_pos_embed_fwd")
+
+
+def pos_embed_bwd(dout, ld, feat, M, C, dW, db, dtype, accumulate=False):
+    ws = workspace(256 * C, dW.device)
+    check(lib().drn_pos_embed_bwd(_p(dout), ld, _p(feat), M, C, _p(dW), _p(db), int(accumulate), _p(ws), dtype, _stream()),
+          "drn_pos_embed_bwd")
+
+
+def pairsum_add(dst, ld_dst, src, ld_src, Mdst, C, dtype):
+    check(lib().drn_pairsum_add(_p(dst), ld_dst, _p(src), ld_src, Mdst, C, dtype, _stream()), "drn_pairsum_add")
+
+
+def gate_bwd(dG, ld_dg, act, ld_act, gate, dC, ld_dc, accumulate, dgate, nseq, L, C, dtype):
+    check(lib().drn_gate_bwd(_p(dG), ld_dg, _p(act), ld_act, _p(gate), gate.stride(0), _p(dC), ld_dc, int(accumulate), _p(dgate),
+                             dgate.stride(0), nseq, L, C, dtype, _stream()), "drn_gate_bwd")
+
+
+def colsum(X, ld, M, C, out, dtype, accumulate=False):
+    ws = workspace(64 * C, out.device)
+    check(lib().drn_colsum(_p(X), ld, M, C, _p(out), int(accumulate), _p(ws), dtype, _stream()), "drn_colsum")
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm
+# ---------------------------------------------------------------------------------------------
+def bn_finalize(groups, C, gamma, beta, conv_bias, running_mean, running_var, momentum, eps):
+    """groups: list of (stats, tiles, M, scale_shift, save)."""
+    arr = (_lib.BnGroup * len(groups))(*[_lib.BnGroup(stats=_p(s), tiles=t, M=m, scale_shift=_p(ss), save=_p(sv))
+                                         for (s, t, m, ss, sv) in groups])
+    check(lib().drn_bn_finalize(arr, len(groups), C, _p(gamma), _p(beta), _p(conv_bias), _p(running_mean), _p(running_var),
+                                ctypes.c_float(momentum), ctypes.c_float(eps), _stream()), "drn_bn_finalize")
+
+
+def bn_eval_scale_shift(C, gamma, beta, conv_bias, running_mean, running_var, eps, ss):
+    check(lib().drn_bn_eval_scale_shift(C, _p(gamma), _p(beta), _p(conv_bias), _p(running_mean), _p(running_var),
+                                        ctypes.c_float(eps), _p(ss), _stream()), "drn_bn_eval_scale_shift")
+
+
+def bn_apply(raw, ld_raw, ss, out, ld_out, M, C, L, dtype, up=None, ld_up=0, gate=None, gated=None, ld_gated=0, relu=True):
+    check(lib().drn_bn_apply(_p(raw), ld_raw, _p(ss), _p(out), ld_out, M, C, L, _p(up), ld_up, _p(gate),
+                             gate.stride(0) if gate is not None else 0, _p(gated), ld_gated, int(relu), dtype, _stream()),
+          "drn_bn_apply")
+
+
+def bn_bwd(dout, ld_dout, raw, ld_raw, ss, save, gamma, draw, ld_draw, dgamma, dbeta, accumulate, M, C, dtype, relu=True):
+    ws = workspace(515 * C, draw.device)
+    check(lib().drn_bn_bwd(_p(dout), ld_dout, _p(raw), ld_raw, _p(ss), _p(save), _p(gamma), _p(draw), ld_draw, _p(dgamma),
+                           _p(dbeta), int(accumulate), M, C, int(relu), _p(ws), dtype, _stream()), "drn_bn_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# 1-2 channel heads and losses
+# ---------------------------------------------------------------------------------------------
+def head_groups(xs, dxs=None, scales=None):
+    """xs: list of (tensor2d_or_slice, ldx, M, L)."""
+    gs = []
+    for i, (x, ldx, M, L) in enumerate(xs):
+        gs.append(_lib.HeadGroup(X=_p(x), dX=_p(dxs[i]) if dxs is not None else None, ldx=ldx, M=M, L=L,
+                                 scale=ctypes.c_void_p(scales.data_ptr() + 4 * i) if scales is not None else None))
+    return (_lib.HeadGroup * len(gs))(*gs)
+
+
+def head_out_fwd(groups, W, bias, N, C, taps, exp_mode, out, z, dtype):
+    check(lib().drn_head_out_fwd(groups, len(groups), _p(W), _p(bias), N, C, taps, int(exp_mode), _p(out), _p(z), dtype,
+                                 _stream()), "drn_head_out_fwd")
+
+
+def head_out_bwd(groups, W, dout, out, z, N, C, taps, exp_mode, accumulate_dx, dW, dbias, dscale, R, dtype):
+    ws = workspace(R * N + 64 + 128 * N * taps * C, dW.device)
+    check(lib().drn_head_out_bwd(groups, len(groups), _p(W), _p(dout), _p(out), _p(z), N, C, taps, int(exp_mode),
+                                 int(accumulate_dx), _p(dW), _p(dbias), _p(dscale), 0, _p(ws), dtype, _stream()),
+          "drn_head_out_bwd")
+
+
+def loss_levels(levels):
+    """levels: list of (L, stride, lo, hi)."""
+    return (_lib.LossLevel * len(levels))(*[_lib.LossLevel(L=L, stride=s, lo=lo, hi=hi) for (L, s, lo, hi) in levels])
+
+
+def fcos_loss_fwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, labels=None):
+    check(lib().drn_fcos_loss_fwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
+                                  ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(labels),
+                                  _stream()), "drn_fcos_loss_fwd")
+
+
+def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, gin3, dlogits, dreg, diou):
+    check(lib().drn_fcos_loss_bwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
+                                  ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(gin3),
+                                  _p(dlogits), _p(dreg), _p(diou), _stream()), "drn_fcos_loss_bwd")

@@ -44,7 +44,7 @@ typedef struct DrnGemmDesc {
   const void* A;
   const void* B;
   void* C;
-  void* C2;          /* optional pre-gate copy of C (same ldc), or NULL */
+  void* C2;          /* optional pre-gate copy of C (row stride ldc2), or NULL */
   const float* bias; /* [N] fp32 or NULL */
   const float* gate; /* [(M/Lout)][ldg] fp32 or NULL */
   float* stats;      /* [ceil(M/128)][2][N] fp32 or NULL */
@@ -53,6 +53,7 @@ typedef struct DrnGemmDesc {
   int32_t Lout, Lsrc;
   int32_t lda, ldb, ldc, ldg;
   int32_t accumulate; /* 1: C += result */
+  int32_t ldc2;       /* row stride of C2 */
 } DrnGemmDesc;
 
 /* Grouped NT implicit GEMM on MFMA (conv1d fwd / dgrad, linear fwd / dgrad).
@@ -73,6 +74,82 @@ typedef struct DrnWgradDesc {
 int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps);
 int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, int N, int Cin, int taps, int stride,
                    int pad, int w_layout, int accumulate, float* ws, int dtype, void* stream);
+
+/* ---- HBM-bound helpers (drn_amd/csrc/elementwise.hip) -------------------------------------------------- */
+/* fp32 -> dtype cast of n contiguous elements (feature tensor / weights; the reference is fp32-only). */
+int drn_cast(const float* in, void* out, int64_t n, int dtype, void* stream);
+/* out[a][b][c] (dtype) = in[a*sa + b*sb + c*sc] (fp32): re-lays nn.Conv1d weights (Cout,Cin,k) as the GEMM's
+ * B operands [Cout][k][Cin] (forward) and [Cin][k][Cout] (data gradient). */
+int drn_pack_weight(const float* in, void* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, int dtype, void* stream);
+/* position_transform = nn.Linear(3,256) on [start,end,duration] (model/main_model.py:34,51-55), written straight
+ * into the channel slice of conv0's input (replaces torch.cat at model/backbone.py:31-32). */
+int drn_pos_embed_fwd(const float* feat /*[M][3]*/, const float* W /*[C][3]*/, const float* b, void* out, int ld_out, int M, int C,
+                      int dtype, void* stream);
+int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, int M, int C, float* dW, float* db, int accumulate,
+                      float* ws /* >= 256*C floats */, int dtype, void* stream);
+/* backward of F.interpolate(nearest, x2) + add (model/FPN.py:63-68): dst[s,t] += src[s,2t] + src[s,2t+1] */
+int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int dtype, void* stream);
+/* backward of the query gating x = q[:, :, None] * x (model/backbone.py:28-30):
+ * dC (+)= dG * gate[seq] (skipped when dC is NULL); dgate[seq][c] = sum_t dG*act */
+int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, void* dC, int ld_dc,
+                 int accumulate, float* dgate, int ld_dgate, int nseq, int L, int C, int dtype, void* stream);
+/* out[c] (+)= sum_m X[m][c]  (bias gradients) */
+int drn_colsum(const void* X, int ld, int M, int C, float* out, int accumulate, float* ws /* >= 64*C floats */, int dtype,
+               void* stream);
+
+/* ---- BatchNorm1d(+ReLU) (drn_amd/csrc/bn.hip; model/basic_blocks.py:23-26, model/fcos.py:34,38,60,66) ---- */
+typedef struct DrnBnGroup {
+  const float* stats; /* [tiles][2][C] from drn_gemm_nt */
+  int32_t tiles, M;
+  float* scale_shift; /* out [2][C] */
+  float* save;        /* out [2][C]: mean, invstd (for backward) */
+} DrnBnGroup;
+/* Train mode: batch statistics -> scale/shift; running stats updated once per group IN ORDER (shared head modules
+ * are applied once per pyramid level, model/fcos.py:93-102).  conv_bias (or NULL) only shifts running_mean. */
+int drn_bn_finalize(const DrnBnGroup* groups /*host*/, int ngroups, int C, const float* gamma, const float* beta,
+                    const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps, void* stream);
+int drn_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const float* conv_bias, const float* running_mean,
+                            const float* running_var, float eps, float* scale_shift, void* stream);
+/* out = [relu](raw*scale+shift) [+ up[seq, t/2]] ; gated = out*gate[seq]  (fused consumers' prologues) */
+int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shift, void* out, int ld_out, int M, int C, int L, const void* up,
+                 int ld_up, const float* gate, int ldg, void* gated, int ld_gated, int relu, int dtype, void* stream);
+/* dRaw, dgamma, dbeta from dOut; ReLU mask recomputed from raw; draw may alias dout. */
+int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld_raw, const float* scale_shift, const float* save,
+               const float* gamma, void* draw, int ld_draw, float* dgamma, float* dbeta, int accumulate, int M, int C, int relu,
+               float* ws /* >= 515*C floats */, int dtype, void* stream);
+
+/* ---- 1-2 channel output heads (drn_amd/csrc/heads.hip; model/fcos.py:43-49,68,96-102) ------------------- */
+typedef struct DrnHeadGroup {
+  const void* X; /* level activations, channels-last (may be a column slice) */
+  void* dX;      /* backward: gradient buffer, same geometry */
+  int32_t ldx, M, L;
+  const float* scale; /* exp mode: scales[l].scale (1 float) */
+} DrnHeadGroup;
+/* out[r][n] = bias[n] + conv(X, W)[r][n]; exp_mode: z = that, out = exp(scale_l*z).  W is the nn.Conv1d weight (N,C,taps). */
+int drn_head_out_fwd(const DrnHeadGroup* groups /*host*/, int ngroups, const float* W, const float* bias, int N, int C, int taps,
+                     int exp_mode, float* out, float* z, int dtype, void* stream);
+/* dout is the gradient w.r.t. `out`; exp_mode applies d out/d z = scale*out and accumulates dscale[l];
+ * dX (+)= conv^T(dz), dW/dbias/dscale (+)= ... over all levels. */
+int drn_head_out_bwd(const DrnHeadGroup* groups /*host*/, int ngroups, const float* W, const float* dout, const float* out,
+                     const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
+                     float* dscale, int accumulate_dw, float* ws /* >= R*N + 64 + 128*N*taps*C floats */, int dtype, void* stream);
+
+/* ---- losses (drn_amd/csrc/loss.hip; model/loss.py:40-239, model/layers/{iou_loss,sigmoid_focal_loss}.py) -- */
+typedef struct DrnLossLevel {
+  int32_t L;    /* locations per clip on this level */
+  float stride; /* fpn_stride: location = t*stride + stride/2 (model/fcos.py:204-211) */
+  float lo, hi; /* object_sizes_of_interest (model/loss.py:47-51) */
+} DrnLossLevel;
+/* logits [R], reg [R][2], iou [R] are fp32 over R = B*sum(L) rows ordered level-first, clip-major (the reference's
+ * flatten order, model/loss.py:150-166).  out5 = {loss_cls, loss_reg, loss_iou, n_pos, n_iou_pos}.
+ * Replaces fcos_core._C.sigmoid_focalloss_forward/backward (model/layers/sigmoid_focal_loss.py:18,31) + IOULoss +
+ * segment_tiou/SmoothL1. */
+int drn_fcos_loss_fwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg,
+                      const float* iou, const float* gt /*[B][2]*/, float gamma, float alpha, float target_scale, int iou_stage,
+                      float* out5, float* labels /*[R] or NULL*/, void* stream);
+int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg,
+                      const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
+                      const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream);
 
 #ifdef __cplusplus
 }

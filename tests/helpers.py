@@ -40,7 +40,7 @@ def checksum(t):
     return np.array([flat.sum().item(), flat.abs().sum().item()]), flat[::step][:64].float().numpy()
 
 
-def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=True):
+def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=True, tap_names=None):
     """Run model `m` on the golden case and assert every recorded quantity matches.
 
     atol: absolute tolerance on activations / head outputs / losses (A.6: never pure relative).
@@ -50,14 +50,21 @@ def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=
     caught = {}
     hooks = []
     mods = dict(m.named_modules())
-    if taps:
-        for t in TAPS:
-            hooks.append(mods[t].register_forward_hook(lambda mod, i, o, n=t: caught.__setitem__(n, o)))
-    hooks.append(m.fcos.head.register_forward_hook(lambda mod, i, o: caught.__setitem__("head", o)))
+    tap_names = TAPS if tap_names is None else tap_names
+    self_taps = hasattr(m, "taps")            # drn_amd.mainModel records its own (no per-module forward calls)
+    if self_taps:
+        m.taps = caught
+    else:
+        if taps:
+            for t in tap_names:
+                hooks.append(mods[t].register_forward_hook(lambda mod, i, o, n=t: caught.__setitem__(n, o)))
+        hooks.append(m.fcos.head.register_forward_hook(lambda mod, i, o: caught.__setitem__("head", o)))
     m.train(train)
     boxes, losses = m(*batch)
     for h in hooks:
         h.remove()
+    if self_taps:
+        m.taps = None
     for k in ("loss_cls", "loss_reg", "loss_iou"):
         got = losses[k].detach().double().cpu().numpy().reshape(-1)
         np.testing.assert_allclose(got, g[k], atol=atol, rtol=0, err_msg=k)
@@ -70,7 +77,7 @@ def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=
             np.testing.assert_allclose(got, ref, atol=atol * max(1.0, np.abs(ref).max()), rtol=0,
                                        err_msg="%s%d" % (nm, l))
     if taps:
-        for t in TAPS:
+        for t in tap_names:
             cs, smp = checksum(caught[t])
             ref = g["smp/" + t]
             np.testing.assert_allclose(smp, ref, atol=atol * max(1.0, np.abs(ref).max()), rtol=0, err_msg="smp/" + t)

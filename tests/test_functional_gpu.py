@@ -1,0 +1,195 @@
+"""GPU parity of each fused autograd stage (drn_amd.functional) against plain PyTorch fp64 on the same inputs:
+forward values AND gradients, stage by stage, so no ReLU sign flip of an upstream layer can leak in.
+fp32 compute: 2e-5 relative to the tensor scale; bf16 compute: 3e-2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float32: 3e-5, torch.bfloat16: 4e-2}
+
+
+def close(got, ref, tol, what):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    err = float((got - ref).abs().max())
+    scale = max(float(ref.abs().max()), 1e-3)
+    assert err <= tol * scale, "%s: max|err| %.3e > %.1e * %.3g" % (what, err, tol, scale)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64) * scale
+
+
+def ref_block(x, w, gamma, beta, stride, dt, eps=1e-5):
+    """fp64 conv -> train-mode BN -> ReLU.  In bf16 mode the conv output is rounded to bf16 (straight-through
+    gradient) exactly where the kernel stores it, with statistics taken before rounding as the GEMM epilogue
+    does, so both sides take the same ReLU decisions and the comparison is well-posed."""
+    raw = F.conv1d(x, w, stride=stride, padding=(w.shape[2] - 1) // 2)
+    mean = raw.mean(dim=(0, 2), keepdim=True)
+    var = raw.var(dim=(0, 2), unbiased=False, keepdim=True)
+    rq = raw + (raw.bfloat16().double() - raw).detach() if dt == torch.bfloat16 else raw
+    y = (rq - mean) / torch.sqrt(var + eps) * gamma[None, :, None] + beta[None, :, None]
+    n = raw.numel() / raw.shape[1]
+    return F.relu(y), mean.reshape(-1), var.reshape(-1) * n / (n - 1)
+
+
+def q(t, dt):
+    return t.bfloat16().double() if dt == torch.bfloat16 else t
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,stride,gate,up", [(3, 1, False, False), (3, 2, True, False), (1, 1, False, True), (3, 1, True, False)])
+def test_conv_block_fwd_bwd(dt, k, stride, gate, up):
+    from drn_amd import functional as DF
+    B, L, Cin, Cout = 3, 32, 64, 128
+    w = q(rnd(Cout, Cin, k, seed=11) / np.sqrt(Cin * k), dt).requires_grad_()
+    gamma = (rnd(Cout, seed=1).abs() + 0.5).requires_grad_()
+    beta = (rnd(Cout, seed=2) * 0.3).requires_grad_()
+    x = q(rnd(B, Cin, L, seed=3), dt)
+    Lo = (L + 2 * ((k - 1) // 2) - k) // stride + 1
+    qg = rnd(B, Cout, seed=4) if gate else None
+    u = q(rnd(B, Cout, Lo // 2, seed=5), dt) if up else None
+    # ---- reference (fp64)
+    xr = x.clone().requires_grad_()
+    qr = qg.clone().requires_grad_() if gate else None
+    ur = u.clone().requires_grad_() if up else None
+    y, mean, uvar = ref_block(xr, w, gamma, beta, stride, dt)
+    if up:
+        y = y + ur.repeat_interleave(2, dim=-1)
+    w1, w2 = rnd(B, Cout, Lo, seed=6), rnd(B, Cout, Lo, seed=7)
+    loss = (y * w1).sum()
+    if gate:
+        loss = loss + ((y * qr[:, :, None]) * w2).sum()
+    loss.backward()
+    # ---- HIP
+    conv_h = nn.Conv1d(Cin, Cout, k, stride=stride, padding=(k - 1) // 2, bias=False).to(DEV)
+    bn_h = nn.BatchNorm1d(Cout).to(DEV)
+    with torch.no_grad():
+        conv_h.weight.copy_(w.float()); bn_h.weight.copy_(gamma.float()); bn_h.bias.copy_(beta.float())
+    xh = x.permute(0, 2, 1).contiguous().to(DEV, dt).requires_grad_()
+    qh = qg.float().to(DEV).requires_grad_() if gate else None
+    uh = u.permute(0, 2, 1).contiguous().to(DEV, dt).requires_grad_() if up else None
+    outs, gated = DF.conv_block([xh], conv_h, bn_h, True, dt, gate=qh, up=uh)
+    lh = (outs[0].float() * w1.permute(0, 2, 1).float().to(DEV)).sum()
+    if gate:
+        lh = lh + (gated.float() * w2.permute(0, 2, 1).float().to(DEV)).sum()
+    lh.backward()
+    tol = TOL[dt]
+    close(outs[0].permute(0, 2, 1), y, tol, "out")
+    if gate:
+        close(gated.permute(0, 2, 1), y * qg[:, :, None], tol, "gated")
+        close(qh.grad, qr.grad, tol * 3, "dgate")
+    if up:
+        close(uh.grad.permute(0, 2, 1), ur.grad, tol, "dup")
+    close(xh.grad.permute(0, 2, 1), xr.grad, tol * 3, "dx")
+    close(conv_h.weight.grad, w.grad, tol * 3, "dW")
+    close(bn_h.weight.grad, gamma.grad, tol * 3, "dgamma")
+    close(bn_h.bias.grad, beta.grad, tol * 3, "dbeta")
+    close(bn_h.running_mean, 0.1 * mean, tol, "running_mean")
+    close(bn_h.running_var, 0.9 + 0.1 * uvar, tol, "running_var")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_block_three_levels_shared(dt):
+    """Shared module applied per level: per-level batch statistics, running stats updated 3x in order (model/fcos.py:93-102)."""
+    from drn_amd import functional as DF
+    B, C = 2, 64
+    w = q(rnd(C, C, 3, seed=30) / np.sqrt(3 * C), dt).requires_grad_()
+    cb = rnd(C, seed=31) * 0.2
+    gamma, beta = torch.ones(C, dtype=torch.float64, requires_grad=True), torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    xs = [q(rnd(B, C, L, seed=10 + i), dt) for i, L in enumerate((32, 16, 8))]
+    xr = [x.clone().requires_grad_() for x in xs]
+    ws = [rnd(B, C, L, seed=20 + i) for i, L in enumerate((32, 16, 8))]
+    rm, rv, loss = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64), 0
+    for x, wgt in zip(xr, ws):
+        y, mean, uvar = ref_block(x, w, gamma, beta, 1, dt)
+        loss = loss + (y * wgt).sum()
+        rm, rv = 0.9 * rm + 0.1 * (mean.detach() + cb), 0.9 * rv + 0.1 * uvar.detach()
+    loss.backward()
+    conv_h, bn_h = nn.Conv1d(C, C, 3, padding=1).to(DEV), nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        conv_h.weight.copy_(w.float()); conv_h.bias.copy_(cb.float())
+    xh = [x.permute(0, 2, 1).contiguous().to(DEV, dt).requires_grad_() for x in xs]
+    outs, _ = DF.conv_block(xh, conv_h, bn_h, True, dt)
+    sum((o.float() * wgt.permute(0, 2, 1).float().to(DEV)).sum() for o, wgt in zip(outs, ws)).backward()
+    tol = TOL[dt]
+    for i in range(3):
+        close(xh[i].grad.permute(0, 2, 1), xr[i].grad, tol * 3, "dx level %d" % i)
+    close(conv_h.weight.grad, w.grad, tol * 3, "dW")
+    close(bn_h.weight.grad, gamma.grad, tol * 3, "dgamma")
+    assert float(conv_h.bias.grad.abs().max()) == 0.0          # a conv bias in front of train-mode BN has zero gradient
+    close(bn_h.running_mean, rm, tol, "running_mean (the conv bias shifts it)")
+    close(bn_h.running_var, rv, tol, "running_var")
+    assert int(bn_h.num_batches_tracked) == 3
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_input_stage_fwd_bwd(dt):
+    from drn_amd import functional as DF
+    B, T, D, P = 2, 16, 64, 256
+    torch.manual_seed(0)
+    fc, pt = nn.Linear(D, D).double(), nn.Linear(3, P).double()
+    feats = torch.rand(B, T, D, generator=torch.Generator().manual_seed(1), dtype=torch.float64).float().double()
+    if dt == torch.bfloat16:
+        feats = feats.bfloat16().double()
+        with torch.no_grad():
+            fc.weight.copy_(fc.weight.bfloat16().double())
+    pos = rnd(B, T, 3, seed=2).float().double()
+    q = rnd(B, D, seed=3).float().double().requires_grad_()
+    ref = torch.cat([fc(feats) * q[:, None, :], pt(pos)], dim=2)
+    w = rnd(B, T, D + P, seed=4)
+    (ref * w).sum().backward()
+    fch, pth = nn.Linear(D, D).to(DEV), nn.Linear(3, P).to(DEV)
+    with torch.no_grad():
+        fch.weight.copy_(fc.weight.float()); fch.bias.copy_(fc.bias.float())
+        pth.weight.copy_(pt.weight.float()); pth.bias.copy_(pt.bias.float())
+    qh = q.detach().float().to(DEV).requires_grad_()
+    g0 = DF.input_stage(feats.float().to(DEV), pos.float().to(DEV), fch, qh, pth, dt)
+    (g0.float() * w.float().to(DEV)).sum().backward()
+    tol = TOL[dt]
+    close(g0, ref, tol, "G0")
+    close(qh.grad, q.grad, tol * 3, "dgate0")
+    close(fch.weight.grad, fc.weight.grad, tol * 3, "dW prop_fc")
+    close(fch.bias.grad, fc.bias.grad, tol * 3, "db prop_fc")
+    close(pth.weight.grad, pt.weight.grad, tol * 3, "dW pos")
+    close(pth.bias.grad, pt.bias.grad, tol * 3, "db pos")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_head_out_fwd_bwd(dt):
+    """cls_logits + exp(scale*bbox_pred) on the two halves of the stacked tower output, 3 levels (model/fcos.py:96-100)."""
+    from drn_amd import functional as DF
+    B, C = 2, 64
+    torch.manual_seed(0)
+    cls, box = nn.Conv1d(C, 1, 3, padding=1).double(), nn.Conv1d(C, 2, 3, padding=1).double()
+    scales = (rnd(3, seed=1) * 0.1 + 1.0).requires_grad_()
+    xs = [rnd(B, 2 * C, L, seed=2 + i) for i, L in enumerate((32, 16, 8))]
+    if dt == torch.bfloat16:
+        xs = [x.bfloat16().double() for x in xs]
+    xr = [x.clone().requires_grad_() for x in xs]
+    lo = [cls(x[:, :C]) for x in xr]
+    rg = [torch.exp(scales[l] * box(x[:, C:])) for l, x in enumerate(xr)]
+    flat = lambda ts: torch.cat([t.permute(0, 2, 1).reshape(-1, t.size(1)) for t in ts])
+    w1, w2 = rnd(B * 56, 1, seed=8), rnd(B * 56, 2, seed=9)
+    ((flat(lo) * w1).sum() + (flat(rg) * w2).sum()).backward()
+    ch, bh = nn.Conv1d(C, 1, 3, padding=1).to(DEV), nn.Conv1d(C, 2, 3, padding=1).to(DEV)
+    with torch.no_grad():
+        ch.weight.copy_(cls.weight.float()); ch.bias.copy_(cls.bias.float())
+        bh.weight.copy_(box.weight.float()); bh.bias.copy_(box.bias.float())
+    sh = scales.detach().float().to(DEV).requires_grad_()
+    xh = [x.permute(0, 2, 1).contiguous().to(DEV, dt).requires_grad_() for x in xs]
+    logits, reg = DF.head_out(xh, [(ch, None), (bh, sh)], cols=[0, C], dtype=dt)
+    ((logits * w1.float().to(DEV)).sum() + (reg * w2.float().to(DEV)).sum()).backward()
+    tol = TOL[dt]
+    close(logits, flat(lo), tol, "logits")
+    close(reg, flat(rg), tol, "reg")
+    for i in range(3):
+        close(xh[i].grad.permute(0, 2, 1), xr[i].grad, tol * 3, "dx level %d" % i)
+    close(ch.weight.grad, cls.weight.grad, tol * 3, "dW cls")
+    close(bh.weight.grad, box.weight.grad, tol * 3, "dW box")
+    close(ch.bias.grad, cls.bias.grad, tol * 3, "db cls")
+    close(bh.bias.grad, box.bias.grad, tol * 3, "db box")
+    close(sh.grad, scales.grad, tol * 3, "dscale")

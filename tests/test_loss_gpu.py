@@ -1,0 +1,64 @@
+"""GPU parity of the fused FCOS loss kernels (drn_fcos_loss_fwd/bwd) against the CPU oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import drn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(B, T, seed, matched):
+    g = torch.Generator().manual_seed(seed)
+    Ls = [T, T // 2, T // 4]
+    strides = [1, 2, 4]
+    logits = [torch.randn(B, 1, L, generator=g) for L in Ls]
+    reg = [torch.exp(torch.randn(B, 2, L, generator=g)) * (1.5 + l) for l, L in enumerate(Ls)]
+    iou = [torch.randn(B, 1, L, generator=g) for L in Ls]
+    gt = torch.stack([torch.rand(B, generator=g) * 0.4, 0.5 + torch.rand(B, generator=g) * 0.4], 1)
+    if matched:     # GT equal to one prediction per clip -> tIoU>0.9 positives with exact ties
+        rows = []
+        for b in range(B):
+            t = (3 + 5 * b) % T
+            loc = t + 0.5
+            rows.append([max((loc - reg[0][b, 0, t].item()) / 32.0, 0.0), min((loc + reg[0][b, 1, t].item()) / 32.0, 1.0)])
+        gt = torch.tensor(rows, dtype=torch.float64).float()
+    locs = [O.FCOSModule.locations_for(L, s, "cpu") for L, s in zip(Ls, strides)]
+    return Ls, strides, logits, reg, iou, gt, locs
+
+
+@pytest.mark.parametrize("B,T,stage,matched,seed", [(2, 32, 1, False, 0), (3, 32, 3, True, 1), (4, 64, 3, True, 2),
+                                                    (2, 32, 3, False, 3), (5, 256, 3, True, 4)])
+def test_loss_fwd_bwd(B, T, stage, matched, seed):
+    from drn_amd import functional as DF
+    Ls, strides, logits, reg, iou, gt, locs = make_case(B, T, seed, matched)
+    cfg = {"fcos_loss_gamma": 2.0, "fcos_loss_alpha": 0.25}
+    lr = [x.clone().requires_grad_() for x in logits]
+    rr = [x.clone().requires_grad_() for x in reg]
+    ir = [x.clone().requires_grad_() for x in iou]
+    lc, lg, li = O.FCOSLoss(cfg)(locs, lr, rr, gt, ir, stage == 1)
+    w = torch.tensor([0.7, 1.3, 2.1])
+    tot = w[0] * lc + w[1] * lg
+    if li.requires_grad:
+        tot = tot + w[2] * li.reshape(())
+    tot.backward()
+    flat = lambda ts: torch.cat([t.permute(0, 2, 1).reshape(-1, t.size(1)) for t in ts])
+    dev = torch.device("cuda:0")
+    L_, R_, I_ = (flat(x).to(dev).requires_grad_() for x in (logits, reg, iou))
+    levels = [(Ls[i], float(strides[i]), float(O.SIZES_OF_INTEREST[i][0]), float(O.SIZES_OF_INTEREST[i][1])) for i in range(3)]
+    losses, counts = DF.fcos_loss(L_, R_, I_, gt.to(dev), levels, B, 2.0, 0.25, 32.0, stage != 1)
+    (losses * w.to(dev)).sum().backward()
+    got = losses.detach().cpu().numpy()
+    np.testing.assert_allclose(got[0], lc.item(), atol=1e-5)
+    np.testing.assert_allclose(got[1], lg.item(), atol=1e-5)
+    if stage != 1:
+        np.testing.assert_allclose(got[2], float(li.reshape(-1)[0]), atol=1e-5)
+        if matched:
+            assert counts[1].item() >= B
+    gl = flat([x.grad for x in lr])
+    gr = flat([x.grad if x.grad is not None else torch.zeros_like(x) for x in rr])
+    np.testing.assert_allclose(L_.grad.cpu().numpy(), gl.numpy(), atol=1e-6)
+    np.testing.assert_allclose(R_.grad.cpu().numpy(), gr.numpy(), atol=2e-6, rtol=1e-4)
+    if stage != 1 and ir[0].grad is not None:
+        gi = flat([x.grad for x in ir])
+        np.testing.assert_allclose(I_.grad.cpu().numpy(), gi.numpy(), atol=1e-6)
