@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""DRN hot-path benchmark on MI355X (driver contract: one JSON line from rank 0).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Charades-STA-shaped synthetic C3D features, T=256 proposals, D=4096,
+batch 32 per GPU, first-stage losses, bf16 storage / fp32 accumulation.  One step = forward + backward of
+drn_amd.model.mainModel + gradient all-reduce (N>1) + clip_grad_norm_(0.5) + Adam (main.py:218-243), inputs
+already resident in HBM.  `value` = clips/s over all ranks (weak scaling: per-GPU batch fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def build(model_cls, cfg, device, **kw):
+    m = model_cls(VOCAB_SIZE, as_namespace(cfg), **kw)
+    m.load_state_dict(seeded_state_dict(m, 0))
+    return m.to(device)
+
+
+def stage_params(model, stage):
+    """main.py:124-138: stage 1 freezes iou_scores / mix_fc."""
+    for n, p in model.named_parameters():
+        if stage == 1 and ("iou_scores" in n or "mix_fc" in n):
+            p.requires_grad_(False)
+    return [p for p in model.parameters() if p.requires_grad]
+
+
+def cpu_baseline(cfg, B, T, D, stage, steps):
+    """The CPU oracle (oracle/drn_oracle.py, pinned to the reference's goldens) timed on this box's host cores."""
+    from oracle import drn_oracle as O
+    m = build(O.mainModel, cfg, "cpu")
+    stage_params(m, stage)
+    m.train()
+    batch = synthetic_batch(B, T, D, seed=1)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        m.zero_grad(set_to_none=True)
+        _, losses = m(*batch)
+        sum(l for l in losses.values()).backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": B / t, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "median of %d fwd+bwd steps (after 1 warm-up) of B=%d,T=%d,D=%d stage-%d, fp32, oracle/drn_oracle.py"
+                      % (steps, B, T, D, stage)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--T", type=int, default=256)
+    ap.add_argument("--D", type=int, default=4096)
+    ap.add_argument("--stage", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--cpu-steps", type=int, default=3, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--verbose", action="store_true", help="per-kernel MFMA timing table on stderr")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from drn_amd import dist as ddist
+    from drn_amd import ops
+    from drn_amd.model import mainModel
+    rank, local, world = ddist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, T, D, stage = args.batch, args.T, args.D, args.stage
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg = default_cfg("C3D" if D == 4096 else "SYN", D, stage)
+
+    model = build(mainModel, cfg, dev, compute_dtype=cdt)
+    params = stage_params(model, stage)
+    model.train()
+    reducer = ddist.GradReducer(params, world_size=world)
+    opt = torch.optim.Adam(params, lr=1e-3)                          # main.py:140
+    batch = [b.to(dev) if i != 1 else b for i, b in enumerate(synthetic_batch(B, T, D, seed=1 + rank))]
+
+    def step():
+        reducer.zero()
+        _, losses = model(*batch)
+        loss = losses["loss_iou"] if stage == 2 else sum(l for l in losses.values())   # main.py:222-225
+        loss.backward()
+        reducer.finish()
+        torch.nn.utils.clip_grad_norm_(params, 0.5)                  # main.py:238-239
+        opt.step()
+        return losses
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timers = None
+    if not args.no_kernel_timing:
+        timers = ops.kernel_timer = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.kernel_timer = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    roof = None
+    if timers:
+        agg = {}
+        for tag, flops, e0, e1 in timers:
+            a = agg.setdefault(tag, [0.0, 0, flops])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+        if args.verbose and rank == 0:
+            for t_, (ms_, n_, fl_) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                print("%-60s %3d/step  %8.3f ms/launch  %7.1f TFLOP/s" % (t_, n_ // args.steps, ms_ / n_, fl_ / (ms_ / n_ * 1e-3) / 1e12),
+                      file=sys.stderr)
+        tag, (tot_ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])
+        avg_ms = tot_ms / n
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        gemm_ms = sum(a[0] for a in agg.values()) / args.steps
+        roof = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "launches_per_step": n // args.steps, "mfma_kernels_ms_per_step": round(gemm_ms, 3),
+                "note": "dominant kernel by total time; flops = 2*M*N*K of that launch; HIP events on the launch stream"}
+
+    out = {"metric": "clips/sec fwd+bwd (BxT=256x4096 C3D feats)", "value": round(value, 2), "unit": "clips/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "Charades-STA-shaped C3D features, T=%d, D=%d, batch %d/GPU, stage-%d losses; "
+                                  "step = fwd+bwd+grad all-reduce+clip(0.5)+Adam" % (T, D, B, stage),
+                      "global_batch": B * world, "T": T, "D": D, "parallelism": "dp%d" % world,
+                      "loss_cls": float(losses["loss_cls"].detach().reshape(-1)[0])},
+           "roofline": roof}
+    if rank == 0:
+        if world == 1 and args.cpu_steps > 0:
+            # stock PyTorch oversubscribes badly on these small convs beyond ~32 threads
+            torch.set_num_threads(min(32, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(cfg, B, T, D, stage, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

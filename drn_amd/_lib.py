@@ -5,6 +5,8 @@ an exception is raised.  Build it with `python -c "import __graft_entry__ as g; 
 or `make -C drn_amd/csrc`.
 """
 import ctypes
+
+import torch  # noqa: F401  (first: libdrn_hip.so must bind to the HIP runtime PyTorch-ROCm already loaded)
 import os
 import re
 

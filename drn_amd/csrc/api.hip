@@ -12,5 +12,6 @@ void drn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int drn_abi_version(void) { return DRN_ABI_VERSION; }
+extern "C" int drn_abi_version(void) {
+  drn_clear_status(); return DRN_ABI_VERSION; }
 extern "C" const char* drn_last_error(void) { return g_err; }

@@ -56,6 +56,7 @@ __global__ void bn_finalize_kernel(const BnFinParams P, int C, const float* __re
 extern "C" int drn_bn_finalize(const DrnBnGroup* groups, int ngroups, int C, const float* gamma, const float* beta,
                                const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
                                void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(groups && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS && C > 0 && gamma && beta, "drn_bn_finalize: bad args");
   BnFinParams P;
   P.ngroups = ngroups;
@@ -80,6 +81,7 @@ __global__ void bn_eval_ss_kernel(int C, const float* gamma, const float* beta, 
 }
 extern "C" int drn_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const float* conv_bias, const float* running_mean,
                                        const float* running_var, float eps, float* scale_shift, void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale_shift, "drn_bn_eval_scale_shift: bad args");
   bn_eval_ss_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(C, gamma, beta, conv_bias, running_mean, running_var, eps, scale_shift);
   return drn_launch_status("drn_bn_eval_scale_shift");
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ raw
 extern "C" int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shift, void* out, int ld_out, int M, int C, int L,
                             const void* up, int ld_up, const float* gate, int ldg, void* gated, int ld_gated, int relu, int dtype,
                             void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(raw && scale_shift && out && M > 0 && C > 0 && L > 0 && M % L == 0, "drn_bn_apply: bad args");
   DRN_CHECK_ARG(!up || (L % 2 == 0), "drn_bn_apply: upsample-add needs an even sequence length");
   DRN_CHECK_ARG((gate != nullptr) == (gated != nullptr), "drn_bn_apply: gate and gated must come together");

@@ -30,6 +30,10 @@ void drn_set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+// HIP's "last error" is sticky per thread: clear whatever an unrelated earlier runtime call left behind
+// before launching, so drn_launch_status() reports only this entry point's own launches.
+static inline void drn_clear_status() { (void)hipGetLastError(); }
+
 static inline int drn_launch_status(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -26,6 +26,7 @@ __global__ void cast_tail_kernel(const float* __restrict__ in, T* __restrict__ o
 }
 
 extern "C" int drn_cast(const float* in, void* out, int64_t n, int dtype, void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(in && out && n >= 0, "drn_cast: bad args");
   if (n == 0) return DRN_OK;
   DISPATCH_DT(dtype, "drn_cast", {
@@ -53,6 +54,7 @@ __global__ void pack_kernel(const float* __restrict__ in, T* __restrict__ out, i
 
 extern "C" int drn_pack_weight(const float* in, void* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, int dtype,
                                void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(in && out && A > 0 && B > 0 && C > 0, "drn_pack_weight: bad args");
   DISPATCH_DT(dtype, "drn_pack_weight", {
     pack_kernel<T><<<ew_blocks((long)A * B * C, 256), 256, 0, (hipStream_t)stream>>>(in, (T*)out, A, B, C, sa, sb, sc);
@@ -79,6 +81,7 @@ __global__ void pos_embed_kernel(const float* __restrict__ feat, const float* __
 }
 extern "C" int drn_pos_embed_fwd(const float* feat, const float* W, const float* b, void* out, int ld_out, int M, int C, int dtype,
                                  void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(feat && W && b && out && M > 0 && C > 0, "drn_pos_embed_fwd: bad args");
   DISPATCH_DT(dtype, "drn_pos_embed_fwd",
               { pos_embed_kernel<T><<<ew_blocks((long)M * C, 256), 256, 0, (hipStream_t)stream>>>(feat, W, b, (T*)out, ld_out, M, C); });
@@ -119,6 +122,7 @@ __global__ void pos_embed_bwd_final_kernel(const float* __restrict__ partial, in
 }
 extern "C" int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, int M, int C, float* dW, float* db, int accumulate,
                                  float* ws /* >= 64*4*C floats */, int dtype, void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(dout && feat && dW && db && ws && M > 0 && C > 0, "drn_pos_embed_bwd: bad args");
   const int nblk = M < 64 ? 1 : 64;
   DISPATCH_DT(dtype, "drn_pos_embed_bwd",
@@ -146,6 +150,7 @@ __global__ void pairsum_add_kernel(T* __restrict__ dst, int ld_dst, const T* __r
   }
 }
 extern "C" int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int dtype, void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(dst && src && Mdst > 0 && C > 0, "drn_pairsum_add: bad args");
   DISPATCH_DT(dtype, "drn_pairsum_add", {
     DRN_CHECK_ARG(C % V16<T>::N == 0 && ld_dst % V16<T>::N == 0 && ld_src % V16<T>::N == 0, "drn_pairsum_add: C/ld must be 16-byte multiples");
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
 }
 extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, void* dC, int ld_dc,
                             int accumulate, float* dgate, int ld_dgate, int nseq, int L, int C, int dtype, void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(dG && act && gate && dgate && nseq > 0 && L > 0 && C > 0, "drn_gate_bwd: bad args");
   DISPATCH_DT(dtype, "drn_gate_bwd", {
     constexpr int N = V16<T>::N;
@@ -248,6 +254,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int nb
 }
 extern "C" int drn_colsum(const void* X, int ld, int M, int C, float* out, int accumulate, float* ws /* >= 64*C floats */, int dtype,
                           void* stream) {
+  drn_clear_status();
   DRN_CHECK_ARG(X && out && ws && M > 0 && C > 0, "drn_colsum: bad args");
   const int nblk = M >= 64 * 16 ? 64 : (M >= 16 ? M / 16 : 1);
   DISPATCH_DT(dtype, "drn_colsum", {

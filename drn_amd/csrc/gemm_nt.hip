@@ -295,5 +295,6 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
 }
 
 extern "C" int drn_gemm_nt(const DrnGemmDesc* descs, int ngroups, int dtype, void* stream) {
+  drn_clear_status();
   return launch_nt(descs, ngroups, dtype, (hipStream_t)stream);
 }

@@ -245,6 +245,7 @@ extern "C" int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps) {
 
 extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int N, int Cin, int taps, int stride, int pad,
                               int w_layout, int accumulate, float* ws, int dtype, void* stream_) {
+  drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_wgrad: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_wgrad: bad dtype %d", dtype);

@@ -266,6 +266,7 @@ static int fill_head_params(HeadParams& P, const DrnHeadGroup* groups, int ngrou
 
 extern "C" int drn_head_out_fwd(const DrnHeadGroup* groups, int ngroups, const float* W, const float* bias, int N, int C, int taps,
                                 int exp_mode, float* out, float* z, int dtype, void* stream) {
+  drn_clear_status();
   HeadParams P;
   int rc = fill_head_params(P, groups, ngroups, N, C, taps, exp_mode, dtype, false, "drn_head_out_fwd");
   if (rc) return rc;
@@ -281,6 +282,7 @@ extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const f
                                 const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
                                 float* dscale, int accumulate_dw, float* ws /* >= R*N + 128*N*taps*C floats */, int dtype,
                                 void* stream_) {
+  drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   HeadParams P;
   int rc = fill_head_params(P, groups, ngroups, N, C, taps, exp_mode, dtype, true, "drn_head_out_bwd");

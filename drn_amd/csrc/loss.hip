@@ -203,6 +203,7 @@ static int fill_loss_params(LossParams& P, const DrnLossLevel* levels, int nleve
 extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg, const float* iou,
                                  const float* gt, float gamma, float alpha, float target_scale, int iou_stage, float* out5,
                                  float* labels, void* stream) {
+  drn_clear_status();
   LossParams P;
   int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_fwd");
   if (rc) return rc;
@@ -214,6 +215,7 @@ extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B,
 extern "C" int drn_fcos_loss_bwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg,
                                  const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
                                  const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream) {
+  drn_clear_status();
   LossParams P;
   int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_bwd");
   if (rc) return rc;

@@ -48,9 +48,28 @@ def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Ls
                     ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2)
 
 
+# Optional per-launch timing of the MFMA kernels (bench.py): a list collecting (tag, flops, start_event, end_event),
+# the events recorded on the same stream the kernels run on.
+kernel_timer = None
+
+
+def _timed(tag, flops, launch):
+    if kernel_timer is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    kernel_timer.append((tag, flops, e0, e1))
+
+
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
-    check(lib().drn_gemm_nt(arr, len(descs), dtype, _stream()), "drn_gemm_nt")
+    flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
+    d0 = descs[0]
+    tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=%d" % ("bf16" if dtype == BF16 else "f32", len(descs),
+                                                      sum(d.M for d in descs), d0.N, d0.taps * d0.Cin, d0.mode)
+    _timed(tag, flops, lambda: check(lib().drn_gemm_nt(arr, len(descs), dtype, _stream()), "drn_gemm_nt"))
 
 
 def wgrad_desc(dY, X, M, Lout=None, Lsrc=None, ldy=None, ldx=None):
@@ -68,8 +87,10 @@ def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulat
     n_ws = lib().drn_wgrad_ws_elems(m_total, N, Cin, taps)
     ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=dW.device)
     arr = (WgradDesc * len(descs))(*descs)
-    check(lib().drn_gemm_wgrad(arr, len(descs), _p(dW), N, Cin, taps, stride, pad, w_layout, int(accumulate),
-                               _p(ws), dtype, _stream()), "drn_gemm_wgrad")
+    tag = "gemm_wgrad[%s] g=%d M=%d N=%d K=%d" % ("bf16" if dtype == BF16 else "f32", len(descs), m_total, N, taps * Cin)
+    _timed(tag, 2.0 * m_total * N * taps * Cin,
+           lambda: check(lib().drn_gemm_wgrad(arr, len(descs), _p(dW), N, Cin, taps, stride, pad, w_layout, int(accumulate),
+                                              _p(ws), dtype, _stream()), "drn_gemm_wgrad"))
 
 
 # ---------------------------------------------------------------------------------------------
