@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3, help="0 disables the cpu_baseline leg")
     ap.add_argument("--verbose", action="store_true", help="per-kernel MFMA timing table on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="torch clip_grad_norm_ + optim.Adam instead of the fused HIP step")
     args = ap.parse_args()
 
     from drn_amd import dist as ddist
@@ -92,7 +93,11 @@ def main():
     params = stage_params(model, stage)
     model.train()
     reducer = ddist.GradReducer(params, world_size=world)
-    opt = torch.optim.Adam(params, lr=1e-3)                          # main.py:140
+    if args.torch_adam:
+        opt = torch.optim.Adam(params, lr=1e-3)                      # main.py:140
+    else:
+        from drn_amd.optim import FusedAdam
+        opt = FusedAdam(reducer, lr=1e-3, max_norm=0.5)              # clip_grad_norm_(0.5) + Adam in two HIP kernels/bucket
     batch = [b.to(dev) if i != 1 else b for i, b in enumerate(synthetic_batch(B, T, D, seed=1 + rank))]
 
     def step():
@@ -101,7 +106,8 @@ def main():
         loss = losses["loss_iou"] if stage == 2 else sum(l for l in losses.values())   # main.py:222-225
         loss.backward()
         reducer.finish()
-        torch.nn.utils.clip_grad_norm_(params, 0.5)                  # main.py:238-239
+        if args.torch_adam:
+            torch.nn.utils.clip_grad_norm_(params, 0.5)              # main.py:238-239
         opt.step()
         return losses
 

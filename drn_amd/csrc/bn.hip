@@ -22,35 +22,55 @@ struct BnFinParams {
   BnFinGroup g[DRN_MAX_GROUPS];
 };
 
-__global__ void bn_finalize_kernel(const BnFinParams P, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ conv_bias, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float momentum, float eps) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
-  const float cb = conv_bias ? conv_bias[c] : 0.f;
+// 256 threads = 16 channels x 16 lanes; the lanes split the per-tile partial sums, LDS combines them in a fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinParams P, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ conv_bias,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float momentum, float eps) {
+  __shared__ double sh[2][16][17];
+  const int ci = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + ci;
+  const bool live = c < C;
+  float rm = 0.f, rv = 1.f, cb = 0.f;
+  if (live && j == 0) {
+    rm = running_mean ? running_mean[c] : 0.f;
+    rv = running_var ? running_var[c] : 1.f;
+    cb = conv_bias ? conv_bias[c] : 0.f;
+  }
   for (int g = 0; g < P.ngroups; ++g) {   // shared modules: levels update the running stats in order
     const BnFinGroup& G = P.g[g];
     double s = 0.0, q = 0.0;
-    for (int t = 0; t < G.tiles; ++t) {
-      s += (double)G.stats[((long)t * 2 + 0) * C + c];
-      q += (double)G.stats[((long)t * 2 + 1) * C + c];
+    if (live)
+      for (int t = j; t < G.tiles; t += 16) {
+        s += (double)G.stats[((long)t * 2 + 0) * C + c];
+        q += (double)G.stats[((long)t * 2 + 1) * C + c];
+      }
+    __syncthreads();
+    sh[0][ci][j] = s;
+    sh[1][ci][j] = q;
+    __syncthreads();
+    if (live && j == 0) {
+      s = 0.0; q = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { s += sh[0][ci][k]; q += sh[1][ci][k]; }
+      const double mean = s / G.M;
+      double var = q / G.M - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[c] * invstd;
+      G.scale_shift[c] = sc;
+      G.scale_shift[C + c] = beta[c] - (float)mean * sc;
+      G.save[c] = (float)mean;
+      G.save[C + c] = invstd;
+      const double unbiased = G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var;
+      rm = (1.f - momentum) * rm + momentum * ((float)mean + cb);
+      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
     }
-    const double mean = s / G.M;
-    double var = q / G.M - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * invstd;
-    G.scale_shift[c] = sc;
-    G.scale_shift[C + c] = beta[c] - (float)mean * sc;
-    G.save[c] = (float)mean;
-    G.save[C + c] = invstd;
-    const double unbiased = G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var;
-    rm = (1.f - momentum) * rm + momentum * ((float)mean + cb);
-    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
   }
-  if (running_mean) running_mean[c] = rm;
-  if (running_var) running_var[c] = rv;
+  if (live && j == 0) {
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+  }
 }
 
 extern "C" int drn_bn_finalize(const DrnBnGroup* groups, int ngroups, int C, const float* gamma, const float* beta,
@@ -66,7 +86,7 @@ extern "C" int drn_bn_finalize(const DrnBnGroup* groups, int ngroups, int C, con
     P.g[g].stats = groups[g].stats; P.g[g].tiles = groups[g].tiles; P.g[g].M = groups[g].M;
     P.g[g].scale_shift = groups[g].scale_shift; P.g[g].save = groups[g].save;
   }
-  bn_finalize_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(P, C, gamma, beta, conv_bias, running_mean, running_var, momentum, eps);
+  bn_finalize_kernel<<<cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(P, C, gamma, beta, conv_bias, running_mean, running_var, momentum, eps);
   return drn_launch_status("drn_bn_finalize");
 }
 
@@ -88,6 +108,8 @@ extern "C" int drn_bn_eval_scale_shift(int C, const float* gamma, const float* b
 }
 
 // out = [relu](raw*scale + shift) [+ up[s, t/2]] ;  gated = out * gate[s]
+// Launch geometry keeps (total threads) % nvec == 0, so each thread owns one 16-byte channel vector for all its
+// rows: scale/shift live in registers and the row loop has no integer division by nvec.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ raw, int ld_raw, const float* __restrict__ ss,
                                                        T* __restrict__ out, int ld_out, int M, int C, int L,
@@ -95,33 +117,49 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ raw
                                                        T* __restrict__ gated, int ld_gated, int relu) {
   constexpr int N = V16<T>::N;
   const int nvec = C / N;
-  const long total = (long)M * nvec;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % nvec);
-    const long m = i / nvec;
-    const int c0 = v * N;
+  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  const int v = gtid % nvec, c0 = v * N;
+  const int rstride = (gridDim.x * 256) / nvec;
+  float sc[N], sh[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { sc[k] = ss[c0 + k]; sh[k] = ss[C + c0 + k]; }
+  for (int m = gtid / nvec; m < M; m += rstride) {
     float x[N];
-    V16<T>::load(raw + m * ld_raw + c0, x);
+    V16<T>::load(raw + (long)m * ld_raw + c0, x);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      float y = fmaf(x[k], ss[c0 + k], ss[C + c0 + k]);
+      const float y = fmaf(x[k], sc[k], sh[k]);
       x[k] = relu ? fmaxf(y, 0.f) : y;
     }
-    const long s = m / L;
+    const int s = m / L;
     if (up) {
-      const long t = m - s * L;
+      const int t = m - s * L;
       float u[N];
-      V16<T>::load(up + (s * (L >> 1) + (t >> 1)) * ld_up + c0, u);
+      V16<T>::load(up + ((long)s * (L >> 1) + (t >> 1)) * ld_up + c0, u);
 #pragma unroll
       for (int k = 0; k < N; ++k) x[k] += u[k];
     }
-    V16<T>::store(out + m * ld_out + c0, x);
+    V16<T>::store(out + (long)m * ld_out + c0, x);
     if (gated) {
+      const float* gp = gate + (long)s * ldg + c0;
 #pragma unroll
-      for (int k = 0; k < N; ++k) x[k] *= gate[s * ldg + c0 + k];
-      V16<T>::store(gated + m * ld_gated + c0, x);
+      for (int k = 0; k < N; ++k) x[k] *= gp[k];
+      V16<T>::store(gated + (long)m * ld_gated + c0, x);
     }
   }
+}
+
+// grid size with (blocks*256) % nvec == 0, ~8 rows per thread, capped
+static int row_grid(int M, int nvec) {
+  int unit = nvec;                       // blocks must be a multiple of nvec / gcd(nvec, 256)
+  int a = nvec, b = 256;
+  while (b) { int t = a % b; a = b; b = t; }
+  unit = nvec / a;
+  long want = ((long)M * nvec + 256 * 4 - 1) / (256 * 4);
+  if (want < 1) want = 1;
+  if (want > 4096) want = 4096;
+  long blocks = (want + unit - 1) / unit * unit;
+  return (int)blocks;
 }
 
 extern "C" int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shift, void* out, int ld_out, int M, int C, int L,
@@ -135,7 +173,7 @@ extern "C" int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shif
     constexpr int N = V16<T>::N;
     DRN_CHECK_ARG(C % N == 0 && ld_raw % N == 0 && ld_out % N == 0 && (!up || ld_up % N == 0) && (!gated || ld_gated % N == 0),
                   "drn_bn_apply: C/ld must be 16-byte multiples");
-    bn_apply_kernel<T><<<ew_blocks((long)M * (C / N), 256), 256, 0, (hipStream_t)stream>>>(
+    bn_apply_kernel<T><<<row_grid(M, C / N), 256, 0, (hipStream_t)stream>>>(
         (const T*)raw, ld_raw, scale_shift, (T*)out, ld_out, M, C, L, (const T*)up, ld_up, gate, ldg, (T*)gated, ld_gated, relu);
   });
   return drn_launch_status("drn_bn_apply");
@@ -184,17 +222,27 @@ __global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const T* __restrict__
   }
 }
 
-// dgamma/dbeta (+)= level sums;  coef: dRaw = A*g + B*raw + Cc
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, const float* __restrict__ gamma,
-                                       const float* __restrict__ save, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       int accumulate, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dgamma/dbeta (+)= level sums;  coef: dRaw = A*g + B*raw + Cc.   256 threads = 16 channels x 16 lanes over the partials.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ save,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ coef) {
+  __shared__ double sh[2][16][17];
+  const int ci = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + ci;
   double sg = 0.0, sx = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    sg += (double)partial[((long)b * 2 + 0) * C + c];
-    sx += (double)partial[((long)b * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int b = j; b < nblk; b += 16) {
+      sg += (double)partial[((long)b * 2 + 0) * C + c];
+      sx += (double)partial[((long)b * 2 + 1) * C + c];
+    }
+  sh[0][ci][j] = sg;
+  sh[1][ci][j] = sx;
+  __syncthreads();
+  if (c >= C || j != 0) return;
+  sg = 0.0; sx = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { sg += sh[0][ci][k]; sx += sh[1][ci][k]; }
   const float mean = save[c], istd = save[C + c];
   const float s = gamma[c] * istd;
   const float dg = (float)sx, db = (float)sg;
@@ -212,20 +260,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ draw, int ld_draw, int M, int C, int relu) {
   constexpr int N = V16<T>::N;
   const int nvec = C / N;
-  const long total = (long)M * nvec;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % nvec);
-    const long m = i / nvec;
-    const int c0 = v * N;
+  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  const int v = gtid % nvec, c0 = v * N;
+  const int rstride = (gridDim.x * 256) / nvec;
+  float sc[N], sh[N], ka[N], kb[N], kc[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    sc[k] = ss[c0 + k]; sh[k] = ss[C + c0 + k];
+    ka[k] = coef[c0 + k]; kb[k] = coef[C + c0 + k]; kc[k] = coef[2 * C + c0 + k];
+  }
+  for (int m = gtid / nvec; m < M; m += rstride) {
     float g[N], x[N];
-    V16<T>::load(dout + m * ld_dout + c0, g);
-    V16<T>::load(raw + m * ld_raw + c0, x);
+    V16<T>::load(dout + (long)m * ld_dout + c0, g);
+    V16<T>::load(raw + (long)m * ld_raw + c0, x);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float gg = (relu && !(fmaf(x[k], ss[c0 + k], ss[C + c0 + k]) > 0.f)) ? 0.f : g[k];
-      x[k] = fmaf(coef[c0 + k], gg, fmaf(coef[C + c0 + k], x[k], coef[2 * C + c0 + k]));
+      const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
+      x[k] = fmaf(ka[k], gg, fmaf(kb[k], x[k], kc[k]));
     }
-    V16<T>::store(draw + m * ld_draw + c0, x);
+    V16<T>::store(draw + (long)m * ld_draw + c0, x);
   }
 }
 
@@ -242,8 +295,8 @@ extern "C" int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld
     DRN_CHECK_ARG(C % N == 0 && ld_dout % N == 0 && ld_raw % N == 0 && ld_draw % N == 0, "drn_bn_bwd: C/ld must be 16-byte multiples");
     dim3 grid(cdiv(C / N, 64), nblk);
     bn_bwd_reduce_kernel<T><<<grid, 64, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw, scale_shift, save, M, C, relu, ws);
-    bn_bwd_finalize_kernel<<<cdiv(C, 128), 128, 0, stream>>>(ws, nblk, M, C, gamma, save, dgamma, dbeta, accumulate, coef);
-    bn_bwd_apply_kernel<T><<<ew_blocks((long)M * (C / N), 256), 256, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw,
+    bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, stream>>>(ws, nblk, M, C, gamma, save, dgamma, dbeta, accumulate, coef);
+    bn_bwd_apply_kernel<T><<<row_grid(M, C / N), 256, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw,
                                                                                  scale_shift, coef, (T*)draw, ld_draw, M, C, relu);
   });
   return drn_launch_status("drn_bn_bwd");

@@ -1,0 +1,105 @@
+// Fused gradient-norm clipping + Adam over flat gradient buckets (main.py:238-243: clip_grad_norm_(0.5), Adam.step).
+// Gradients (already all-reduced) and the Adam moments are flat fp32 buffers per bucket; parameters stay where
+// PyTorch put them and are reached through a small device-resident segment table.  Two launches per bucket:
+//   1. drn_sumsq_partials : per-block sums of g^2 (fixed order -> deterministic norm); the first call of a step
+//      also advances the device-side step counter (no host scalar changes between steps -> hipGraph friendly);
+//   2. drn_adam_bucket    : every block re-derives the global clip coefficient from the partials, then
+//      m,v,p updates with torch.optim.Adam's formula (bias-corrected, eps outside the sqrt, no weight decay).
+#include "common.h"
+#include "../../include/drn_hip.h"
+
+#define OPT_THREADS 256
+#define OPT_ELEMS_PER_BLOCK 4096
+
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_kernel(const float* __restrict__ g, long n, float* __restrict__ partials,
+                                                                      int* __restrict__ step_counter) {
+  __shared__ float sh[17];
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
+  const long base = (long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+  float s = 0.f;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS) {
+    const long k = base + i;
+    if (k < n) {
+      const float v = g[k];
+      s = fmaf(v, v, s);
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+extern "C" int64_t drn_opt_nblocks(int64_t n) { return (n + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK; }
+
+extern "C" int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(g && partials && n > 0, "drn_sumsq_partials: bad args");
+  sumsq_partials_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(g, n, partials, step_counter);
+  return drn_launch_status("drn_sumsq_partials");
+}
+
+struct AdamArgs {
+  const float* g;           // flat gradients of this bucket
+  float* m;
+  float* v;
+  long n;
+  const long* seg_start;    // [nseg+1] prefix offsets of the tensors inside the flat buffers (device)
+  float* const* p_ptr;      // [nseg] parameter base pointers (device)
+  int nseg;
+  const float* partials;    // sums of g^2 over ALL buckets
+  int npartials;
+  const int* step_counter;
+  float lr, beta1, beta2, eps, max_norm;
+};
+
+__global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs A) {
+  __shared__ float sh[17];
+  __shared__ int first_seg;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < A.npartials; i += OPT_THREADS) s += A.partials[i];
+  s = block_sum(s, sh);
+  const float total_norm = sqrtf(s);
+  float clip = A.max_norm > 0.f ? A.max_norm / (total_norm + 1e-6f) : 1.f;   // torch.nn.utils.clip_grad_norm_
+  clip = fminf(clip, 1.f);
+  const int t = *A.step_counter;
+  const float bc1 = 1.f - powf(A.beta1, (float)t), bc2 = 1.f - powf(A.beta2, (float)t);
+  const float step_size = A.lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const long base = (long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+  if (threadIdx.x == 0) {   // binary search: last segment with start <= base
+    int lo = 0, hi = A.nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (A.seg_start[mid] <= base) lo = mid; else hi = mid - 1;
+    }
+    first_seg = lo;
+  }
+  __syncthreads();
+  int seg = first_seg;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS) {
+    const long k = base + i;
+    if (k >= A.n) break;
+    while (k >= A.seg_start[seg + 1]) ++seg;
+    const float g = A.g[k] * clip;
+    const float m = A.beta1 * A.m[k] + (1.f - A.beta1) * g;
+    const float v = A.beta2 * A.v[k] + (1.f - A.beta2) * g * g;
+    A.m[k] = m;
+    A.v[k] = v;
+    float* p = A.p_ptr[seg] + (k - A.seg_start[seg]);
+    *p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + A.eps);
+  }
+}
+
+extern "C" int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev,
+                               int nseg, const float* partials, int npartials, const int* step_counter, float lr, float beta1,
+                               float beta2, float eps, float max_norm, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(g && m && v && n > 0 && seg_start_dev && p_ptr_dev && nseg > 0 && partials && npartials > 0 && step_counter,
+                "drn_adam_bucket: bad args");
+  AdamArgs A;
+  A.g = g; A.m = m; A.v = v; A.n = n; A.seg_start = (const long*)seg_start_dev; A.p_ptr = p_ptr_dev; A.nseg = nseg;
+  A.partials = partials; A.npartials = npartials; A.step_counter = step_counter;
+  A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.max_norm = max_norm;
+  adam_bucket_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(A);
+  return drn_launch_status("drn_adam_bucket");
+}

@@ -14,6 +14,13 @@ from . import ops
 from ._lib import DrnError
 
 _pack_cache = {}
+_weights_epoch = 0
+
+
+def bump_weights_epoch():
+    """Invalidate every cached re-laid weight (called by optimizers that update parameters through raw pointers)."""
+    global _weights_epoch
+    _weights_epoch += 1
 
 
 def packed(w, perm, code):
@@ -22,7 +29,7 @@ def packed(w, perm, code):
         # temporaries (e.g. stacked tower weights) may reuse an address with version 0: never cache them
         return ops.pack_weight(w.detach(), perm, code)
     key = (id(w), w.data_ptr(), perm, code)
-    ver = w._version
+    ver = (w._version, _weights_epoch)
     hit = _pack_cache.get(key)
     # the weakref guards against a new Parameter re-using a dead one's id / address / version
     if hit is not None and hit[0] == ver and hit[2]() is w and hit[1].device == w.device:

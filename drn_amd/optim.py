@@ -1,0 +1,59 @@
+"""Fused clip_grad_norm_ + Adam on the flat gradient buckets of drn_amd.dist.GradReducer (HIP kernels in
+drn_amd/csrc/optim.hip).  Same arithmetic as `clip_grad_norm_(params, max_norm); torch.optim.Adam.step()`
+(main.py:140,238-243; weight_decay is configured but never used by the reference)."""
+import ctypes
+
+import torch
+
+from . import functional as DF
+from ._lib import check, lib
+
+
+class FusedAdam(object):
+    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5):
+        self.reducer, self.lr, self.betas, self.eps, self.max_norm = reducer, lr, betas, eps, max_norm
+        L = lib()
+        L.drn_opt_nblocks.restype = ctypes.c_int64
+        dev = reducer.buckets[0].flat.device
+        self.state = []
+        nparts = 0
+        for b in reducer.buckets:
+            n = b.flat.numel()
+            offs, ptrs, off = [0], [], 0
+            for p in b.params:
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdam needs contiguous fp32 parameters")
+                ptrs.append(p.data_ptr())
+                off += p.numel()
+                offs.append(off)
+            nb = int(L.drn_opt_nblocks(ctypes.c_int64(n)))
+            self.state.append({"m": torch.zeros_like(b.flat), "v": torch.zeros_like(b.flat),
+                               "seg": torch.tensor(offs, dtype=torch.int64, device=dev),
+                               "ptr": torch.tensor(ptrs, dtype=torch.int64, device=dev),
+                               "nseg": len(ptrs), "part_off": nparts, "nb": nb})
+            nparts += nb
+        self.partials = torch.zeros(nparts, dtype=torch.float32, device=dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def _check_ptrs(self):
+        for b, st in zip(self.reducer.buckets, self.state):
+            if [p.data_ptr() for p in b.params] != st["ptr"].tolist():
+                raise RuntimeError("parameter storage moved after FusedAdam was built")
+
+    def step(self):
+        L = lib()
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        for i, (b, st) in enumerate(zip(self.reducer.buckets, self.state)):
+            part = self.partials[st["part_off"]:]
+            check(L.drn_sumsq_partials(P(b.flat), ctypes.c_int64(b.flat.numel()), P(part),
+                                       P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials")
+        for b, st in zip(self.reducer.buckets, self.state):
+            check(L.drn_adam_bucket(P(b.flat), P(st["m"]), P(st["v"]), ctypes.c_int64(b.flat.numel()), P(st["seg"]), P(st["ptr"]),
+                                    st["nseg"], P(self.partials), self.partials.numel(), P(self.step_counter),
+                                    ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
+                                    ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
+        DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
+
+    def total_norm(self):
+        return self.partials.sum().sqrt()

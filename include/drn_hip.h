@@ -151,6 +151,16 @@ int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, c
                       const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
                       const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream);
 
+/* ---- fused clip_grad_norm_ + Adam over flat gradient buckets (drn_amd/csrc/optim.hip; main.py:140,238-243) ---- */
+int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */
+/* partials[b] = sum of g^2 over block b; step_counter (device int, or NULL) is incremented once per call. */
+int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream);
+/* One bucket: g/m/v flat [n]; tensor i covers [seg_start[i], seg_start[i+1]) and lives at p_ptr[i] (both tables on the
+ * device).  partials = g^2 sums of ALL buckets (global norm); clip coef = min(1, max_norm/(norm+1e-6)) (max_norm<=0: off). */
+int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev, int nseg,
+                    const float* partials, int npartials, const int* step_counter, float lr, float beta1, float beta2, float eps,
+                    float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
