@@ -15,6 +15,7 @@
 //   bf16: v_mfma_f32_16x16x32_bf16 (8 bf16 = 16 B per lane per operand)
 //   f32 : 4 x v_mfma_f32_16x16x4_f32 per 16-B fragment (exact fp32, parity mode);
 //         the k-permutation this implies is applied identically to A and B.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/drn_hip.h"
 
@@ -74,8 +75,14 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(NT_THREADS, 2) void conv_gemm_nt_kernel(const GemmParams P) {
+// STAGES-deep LDS ring (STAGES x 32 KB).  Iteration kt: wait until tile kt's global_load_lds have landed with a COUNTED
+// vmcnt (the STAGES-2 younger tiles stay in flight across the barrier), one raw s_barrier, issue tile kt+STAGES-1 into the
+// slot everybody just finished reading, then MFMA on tile kt.  Past-the-end tiles read the zero page so the count is uniform.
+// FAST (every group has Cin % BK == 0, so a K-tile never straddles two taps): the tap and channel offset of a tile are
+// wave-uniform scalars advanced incrementally, and each thread keeps 4+4 precomputed row pointers -- ~10 VALU per
+// global_load_lds instead of a per-lane integer division and 64-bit multiply.  The generic path keeps those.
+template <typename T, int STAGES, bool FAST>
+__global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_nt_kernel(const GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 8 * CH;               // elements per K-step (128 bytes)
@@ -96,72 +103,96 @@ __global__ __launch_bounds__(NT_THREADS, 2) void conv_gemm_nt_kernel(const GemmP
   const T* zero = (const T*)g_zero_page;
 
   // ---- per-thread staging state: 4 A rows + 4 B rows (one 16-byte chunk each per K-step)
-  int a_base[4], a_t[4];
-  long b_off[4];
   const int pch = l & 7;
+  const int div = mode ? stride : 1;
+  const long lda = pr.lda;
+  const int sh = div == 2 ? 1 : 0;
+  int a_s[4];            // mode 0: t*stride - pad ; mode 1: t + pad ; hugely negative when the row is out of range
+  const T* pA[4];        // A + (seq*Lsrc)*lda + lane chunk offset
+  const T* pB[4];        // B + n*ldb + lane chunk offset
+  bool okb[4];
+  int a_base[4];         // generic path
+  long b_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (w * 4 + i) * 8 + (l >> 3);
     const int m = m0 + row;
+    const int coff = (pch ^ (((i & 1) << 2) + (l >> 4))) * CH;
+    int seq = 0, t = -(1 << 28);
     if (m < M) {
-      const int seq = m / pr.Lout;
-      a_t[i] = m - seq * pr.Lout;
-      a_base[i] = seq * Lsrc;
-    } else {
-      a_t[i] = -(1 << 28);  // never valid
-      a_base[i] = 0;
+      seq = m / pr.Lout;
+      t = m - seq * pr.Lout;
     }
+    a_s[i] = m < M ? (mode ? t + pad : t * stride - pad) : -(1 << 28);
+    a_base[i] = seq * Lsrc;
+    pA[i] = Ag + ((long)seq * Lsrc * lda + coff);
     const int n = n0 + row;
+    okb[i] = n < N;
     b_off[i] = n < N ? (long)n * pr.ldb : -1;
+    pB[i] = Bg + ((long)(n < N ? n : 0) * pr.ldb + coff);
   }
 
-  auto stage = [&](int buf, int kt) {
+  // tiles are staged strictly in order; these advance by one tile per stage() call
+  int s_kt = 0, s_tap = 0, s_c0 = 0;
+  const int nkt = (K + BK - 1) / BK;
+
+  // Every thread issues exactly 8 global_load_lds per tile (the counted vmcnt below depends on it); masked lanes and
+  // past-the-end tiles read the zero page.
+  auto stage = [&](int buf) {
     char* As = smem + buf * STAGE_BYTES;
     char* Bs = As + 16384;
-    int tap2[2], cc2[2], kk2[2];
+    if constexpr (FAST) {
+      const bool kin = s_kt < nkt;
+      const long koff = (long)s_kt * BK;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = pch ^ ((h << 2) + (l >> 4));
-      const int kk = kt * BK + c * CH;
-      kk2[h] = kk;
-      if (taps == 1) {
-        tap2[h] = 0;
-        cc2[h] = kk;
-      } else {
-        tap2[h] = kk / Cin;
-        cc2[h] = kk - tap2[h] * Cin;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int h = i & 1;
-      const T* src = zero;
-      if (kk2[h] < K) {
+      for (int i = 0; i < 4; ++i) {
         int st;
         bool ok;
         if (mode == 0) {
-          st = a_t[i] * stride + tap2[h] - pad;
-          ok = st >= 0 && st < Lsrc;
+          st = a_s[i] + s_tap;
+          ok = kin & ((unsigned)st < (unsigned)Lsrc);
         } else {
-          const int num = a_t[i] + pad - tap2[h];
-          if (stride == 1) {
-            st = num;
-            ok = num >= 0 && num < Lsrc;
-          } else if (stride == 2) {
-            st = num >> 1;
-            ok = num >= 0 && (num & 1) == 0 && st < Lsrc;
-          } else {
-            st = num / stride;
-            ok = num >= 0 && st * stride == num && st < Lsrc;
-          }
+          const int num = a_s[i] - s_tap;
+          st = num >> sh;
+          ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
         }
-        if (ok) src = Ag + ((long)(a_base[i] + st) * pr.lda + cc2[h]);
+        const T* src = ok ? pA[i] + ((long)st * lda + s_c0) : zero;
+        glds16(src, As + (w * 4 + i) * 1024);
+        const T* bsrc = (kin & okb[i]) ? pB[i] + koff : zero;
+        glds16(bsrc, Bs + (w * 4 + i) * 1024);
       }
-      glds16(src, As + (w * 4 + i) * 1024);
-      const T* bsrc = zero;
-      if (kk2[h] < K && b_off[i] >= 0) bsrc = Bg + (b_off[i] + kk2[h]);
-      glds16(bsrc, Bs + (w * 4 + i) * 1024);
+      s_c0 += BK;
+      if (s_c0 >= Cin) {
+        s_c0 -= Cin;
+        ++s_tap;
+      }
+    } else {
+      int tap2[2], cc2[2], kk2[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = pch ^ ((h << 2) + (l >> 4));
+        const int kk = s_kt * BK + c * CH;
+        kk2[h] = kk;
+        const int tp = taps == 1 ? 0 : kk / Cin;
+        tap2[h] = tp;
+        cc2[h] = kk - tp * Cin;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int h = i & 1;
+        const bool kin = kk2[h] < K;
+        const int num = mode ? a_s[i] - tap2[h] : a_s[i] + tap2[h];
+        const int st = div == 1 ? num : (div == 2 ? num >> 1 : num / div);
+        const bool ok = kin & (num >= 0) & (st * div == num) & (st < Lsrc);
+        const long aoff = (long)(a_base[i] + st) * lda + cc2[h];
+        const T* src = ok ? Ag + aoff : zero;
+        glds16(src, As + (w * 4 + i) * 1024);
+        const bool okb2 = kin & (b_off[i] >= 0);
+        const T* bsrc = okb2 ? Bg + (b_off[i] + kk2[h]) : zero;
+        glds16(bsrc, Bs + (w * 4 + i) * 1024);
+      }
     }
+    ++s_kt;
   };
 
   f32x4 acc[4][4];
@@ -172,14 +203,21 @@ __global__ __launch_bounds__(NT_THREADS, 2) void conv_gemm_nt_kernel(const GemmP
 
   const int wr = w >> 1, wc = w & 1;
   const int swz = (l >> 1) & 7;
-  const int nkt = (K + BK - 1) / BK;
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st) stage(st);
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    // each thread issues 8 loads per tile; tiles kt+1 .. kt+STAGES-2 may still be in flight
+    if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      int nxt = cur + STAGES - 1;
+      if (nxt >= STAGES) nxt -= STAGES;
+      stage(nxt);
+    }
     const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + 16384;
 #pragma unroll
@@ -194,10 +232,10 @@ __global__ __launch_bounds__(NT_THREADS, 2) void conv_gemm_nt_kernel(const GemmP
         b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * 64 + ni * 16 + (l & 15)) * 128 + pc);
       Mma<T>::run(a, b, acc);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // ---- epilogue.  acc[mi][ni][r]: m = wr*64+mi*16+(l>>4)*4+r, n = wc*64+ni*16+(l&15)
   if (pr.stats) {
@@ -281,16 +319,34 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     p.tile_start = total;
     total += cdiv(s.M, TILE) * p.tiles_n;
   }
+  // Pipeline depth: 2 stages leave room for two workgroups per CU (best when the grid oversubscribes the chip);
+  // 4 stages (one workgroup per CU) hide HBM/L2 latency inside a single workgroup, which is what the small
+  // pyramid-level GEMMs need.  DRN_NT_STAGES overrides for experiments.
+  int stages = total > 2 * 256 ? 2 : 4;
+  if (const char* e = getenv("DRN_NT_STAGES")) stages = atoi(e);
+  bool fast = true;
+  for (int g = 0; g < ngroups; ++g) {
+    const int bk = 8 * ch;
+    if (d[g].Cin % bk != 0 || (d[g].mode == 1 && d[g].stride > 2)) fast = false;
+  }
+  if (getenv("DRN_NT_GENERIC")) fast = false;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+#define NT_ATTR(TT, SS) \
+    (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SS * STAGE_BYTES); \
+    (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SS * STAGE_BYTES)
+    NT_ATTR(float, 2); NT_ATTR(bf16_t, 2); NT_ATTR(float, 4); NT_ATTR(bf16_t, 4);
+#undef NT_ATTR
     attr_set = true;
   }
-  if (dtype == DRN_BF16)
-    conv_gemm_nt_kernel<bf16_t><<<total, NT_THREADS, 2 * STAGE_BYTES, stream>>>(P);
-  else
-    conv_gemm_nt_kernel<float><<<total, NT_THREADS, 2 * STAGE_BYTES, stream>>>(P);
+#define NT_LAUNCH(TT, SS) do { if (fast) conv_gemm_nt_kernel<TT, SS, true><<<total, NT_THREADS, SS * STAGE_BYTES, stream>>>(P); \
+                               else conv_gemm_nt_kernel<TT, SS, false><<<total, NT_THREADS, SS * STAGE_BYTES, stream>>>(P); } while (0)
+  if (dtype == DRN_BF16) {
+    if (stages == 2) NT_LAUNCH(bf16_t, 2); else NT_LAUNCH(bf16_t, 4);
+  } else {
+    if (stages == 2) NT_LAUNCH(float, 2); else NT_LAUNCH(float, 4);
+  }
+#undef NT_LAUNCH
   return drn_launch_status("drn_gemm_nt");
 }
 

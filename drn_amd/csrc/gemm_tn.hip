@@ -139,19 +139,16 @@ __global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const Wgra
     const T* __restrict__ Yg = (const T*)G.dY;
     const T* __restrict__ Xg = (const T*)G.X;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {   // branch-free: masked lanes read the zero page
       const int m = mbase + s_r[i];
       const int col = s_cb[i] * 16 + s_sub[i] * CH;
-      const T* ys = zero;
-      const T* xs = zero;
-      if (m < G.M) {
-        if (n0 + col < P.N) ys = Yg + ((long)m * G.ldy + n0 + col);
-        if (c0 + col < P.Cin) {
-          const int seq = m / G.Lout;
-          const int st = (m - seq * G.Lout) * P.stride + tap - P.pad;
-          if (st >= 0 && st < G.Lsrc) xs = Xg + ((long)(seq * G.Lsrc + st) * G.ldx + c0 + col);
-        }
-      }
+      const bool min_ = m < G.M;
+      const bool oky = min_ & (n0 + col < P.N);
+      const T* ys = oky ? Yg + ((long)m * G.ldy + n0 + col) : zero;
+      const int seq = m / G.Lout;
+      const int st = (m - seq * G.Lout) * P.stride + tap - P.pad;
+      const bool okx = min_ & (c0 + col < P.Cin) & (st >= 0) & (st < G.Lsrc);
+      const T* xs = okx ? Xg + ((long)(seq * G.Lsrc + st) * G.ldx + c0 + col) : zero;
       glds16(ys, Ys + (w * 4 + i) * 1024);
       glds16(xs, Xs + (w * 4 + i) * 1024);
     }

@@ -47,13 +47,16 @@ class mainModel(nn.Module):
         self.compute_dtype = dtype
         return self
 
-    def forward(self, query_tokens, query_length, props_features, props_start_end, gt_start_end, props_num=None,
-                num_frames=None):
+    def encode_query(self, query_tokens, query_length):
+        """Query encoder + per-level gate projections (model/main_model.py:47-50): three (B, C_l) fp32 gate tensors."""
+        query_features = self.query_encoder(query_tokens, query_length)
+        return [getattr(self, "qInput%d" % i)(query_features[i]) for i in range(len(query_features))]
+
+    def forward_core(self, gates, props_features, props_start_end, gt_start_end):
+        """Everything downstream of the gates: the HIP path proper (no host-side data dependence, hipGraph-capturable)."""
         if not props_features.is_cuda:
             raise DrnError("drn_amd.mainModel runs on an MI355X only (inputs on %s); no CPU fallback" % props_features.device)
         dt = self.compute_dtype
-        query_features = self.query_encoder(query_tokens, query_length)
-        gates = [getattr(self, "qInput%d" % i)(query_features[i]) for i in range(len(query_features))]
         # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
         duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
         position_feat = torch.cat((props_start_end, duration), dim=-1).float()
@@ -75,3 +78,8 @@ class mainModel(nn.Module):
         if self.training:
             return fc._forward_train(locations, box_cls, box_reg, targets, iou_scores)
         return fc._forward_test(locations, box_cls, box_reg, targets, iou_scores)
+
+    def forward(self, query_tokens, query_length, props_features, props_start_end, gt_start_end, props_num=None,
+                num_frames=None):
+        gates = self.encode_query(query_tokens, query_length)
+        return self.forward_core(gates, props_features, props_start_end, gt_start_end)
