@@ -1,0 +1,58 @@
+"""CPU checks of the drop-in boundary: libdrn_hip.so loads and exports every symbol include/drn_hip.h declares;
+the product path refuses to run without a GPU / without the library (no CPU fallback, no oracle import)."""
+import ast
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from drn_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 20, names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.drn_abi_version() == 1
+    assert lib.drn_last_error() is not None
+
+
+def test_product_path_has_no_cpu_fallback():
+    from drn_amd import _lib, ops
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, synthetic_batch
+    m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", 64, 1)))
+    with pytest.raises(_lib.DrnError):
+        m(*synthetic_batch(2, 32, 64))
+    with pytest.raises(_lib.DrnError):
+        ops.gemm_desc(torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, 4), 4, 4, 4)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "drn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                tree = ast.parse(open(os.path.join(dirpath, f)).read())
+                for node in ast.walk(tree):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        mods = [node.module or ""]
+                    assert not any(m.split(".")[0] == "oracle" for m in mods), (f, mods)
+
+
+def test_state_dict_keys_match_reference():
+    import json
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
+    m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("C3D", 4096, 1)))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref

@@ -1,0 +1,77 @@
+"""world_size-2 gloo tests of the data-parallel exchange step (drn_amd.dist.GradReducer) on CPU tensors."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from drn_amd.dist import GradReducer, init_from_env
+    init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+    unused = torch.nn.Linear(4, 4)                                    # never gets a gradient (like textualAttention)
+    params = list(net.parameters()) + list(unused.parameters())
+    red = GradReducer(params, world_size=world, bucket_bytes=256)     # several small buckets
+    assert len(red.buckets) >= 3
+    results = []
+    for it in range(2):
+        g = torch.Generator().manual_seed(100 * it + rank)
+        x = torch.randn(5, 16, generator=g)
+        red.zero()
+        net(x).pow(2).sum().backward()
+        red.finish()
+        results.append([p.grad.clone() for p in params])
+    # reference: average of both ranks' local gradients, computed independently on every rank
+    for it in range(2):
+        acc = None
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 * it + r)
+            x = torch.randn(5, 16, generator=g)
+            net.zero_grad(set_to_none=True)
+            for p in params:
+                p.grad = None
+            net(x).pow(2).sum().backward()
+            gs = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+            acc = gs if acc is None else [a + b for a, b in zip(acc, gs)]
+        for a, b in zip(acc, results[it]):
+            assert torch.allclose(a / world, b, atol=1e-6), (it, float((a / world - b).abs().max()))
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_grad_reducer_single_process_is_identity():
+    from drn_amd.dist import GradReducer
+    net = torch.nn.Linear(4, 3)
+    red = GradReducer(net.parameters(), world_size=1)
+    red.zero()
+    net(torch.ones(2, 4)).sum().backward()
+    red.finish()
+    assert torch.allclose(net.weight.grad, torch.full((3, 4), 2.0))
+    assert net.weight.grad.data_ptr() == red.buckets[0].flat.data_ptr() or net.bias.grad.data_ptr() == red.buckets[0].flat.data_ptr()
