@@ -99,7 +99,7 @@ def main():
     else:
         from drn_amd.optim import FusedAdam
         opt = FusedAdam(reducer, lr=1e-3, max_norm=0.5)              # clip_grad_norm_(0.5) + Adam in two HIP kernels/bucket
-    batch = [b.to(dev) if i != 1 else b for i, b in enumerate(synthetic_batch(B, T, D, seed=1 + rank))]
+    batch = [b.to(dev) for b in synthetic_batch(B, T, D, seed=1 + rank)]     # everything resident in HBM, lengths included
 
     loss_of = lambda losses: losses["loss_iou"] if stage == 2 else sum(l for l in losses.values())   # main.py:222-225
 
@@ -116,31 +116,6 @@ def main():
         opt_step()
         return losses
 
-    # hipGraph mode: the query encoder (stock PyTorch-ROCm: MIOpen LSTM on packed sequences, host-side lengths) is
-    # not capturable, so it runs eagerly around ONE captured graph holding the whole HIP path's forward+backward:
-    #   eager  gates = encode_query(tokens)            -> copied into static leaf buffers
-    #   graph  forward_core(static gates) ; backward   -> parameter grads + d(gates) in static buffers
-    #   eager  backward through the query encoder ; fused clip+Adam
-    static_gates, core_graph, core_out = [], [None], [None]
-
-    def core_fwd_bwd():
-        for g in static_gates:
-            g.grad = None
-        _, losses = model.forward_core(static_gates, batch[2], batch[3], batch[4])
-        loss_of(losses).backward()
-        return losses
-
-    def graphed_step():
-        reducer.zero()
-        gates = model.encode_query(batch[0], batch[1])
-        with torch.no_grad():
-            for s_, g_ in zip(static_gates, gates):
-                s_.copy_(g_)
-        core_graph[0].replay()
-        torch.autograd.backward(gates, [s_.grad for s_ in static_gates])
-        opt_step()
-        return core_out[0]
-
     def barrier():
         if world > 1:
             torch.distributed.barrier()
@@ -150,23 +125,11 @@ def main():
         step()
     run, mode = step, "eager"
     if args.graph and world == 1:
+        # the whole step (query encoder, HIP path forward+backward, fused clip+Adam) replays as ONE hipGraph
+        from drn_amd.graph import GraphedStep
         try:
-            with torch.no_grad():
-                static_gates.extend(g.detach().clone().requires_grad_() for g in model.encode_query(batch[0], batch[1]))
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    reducer.zero()
-                    core_fwd_bwd()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            reducer.zero()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                core_out[0] = core_fwd_bwd()
-            core_graph[0] = g
-            run, mode = graphed_step, "hipGraph replay of the HIP path (fwd+bwd); query encoder + optimizer eager"
+            run = GraphedStep(step, warmup=2).capture()
+            mode = "hipGraph replay of the full step"
             run()
         except Exception as e:                                          # keep the eager path measurable
             print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).split(chr(10))[0]), file=sys.stderr)

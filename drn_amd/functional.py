@@ -400,3 +400,60 @@ def fcos_loss(logits, reg, iou, gt, levels, B, gamma, alpha, target_scale, iou_s
     meta = {"levels": levels, "B": B, "gamma": float(gamma), "alpha": float(alpha), "target_scale": float(target_scale),
             "iou_stage": int(bool(iou_stage))}
     return _FCOSLossFn.apply(meta, logits, reg, iou if iou_stage else None, gt)
+
+
+class _BiLSTMFn(torch.autograd.Function):
+    """Bidirectional 1-layer LSTM over padded sequences with device-side lengths (model/language_module.py:38-45:
+    pack_padded_sequence -> nn.LSTM -> pad_packed_sequence).  The input projections and the weight-gradient products
+    are plain library GEMMs (tiny); the recurrence runs in drn_amd/csrc/lstm.hip, one launch per time step."""
+
+    @staticmethod
+    def forward(ctx, emb, lengths, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        B, L, E = emb.shape
+        H = w_hh_f.shape[1]
+        dev = emb.device
+        emb_tm = emb.detach().transpose(0, 1).reshape(L * B, E).float()
+        xproj = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
+        torch.addmm((b_ih_f + b_hh_f).detach(), emb_tm, w_ih_f.detach().t(), out=xproj[0].view(L * B, 4 * H))
+        torch.addmm((b_ih_r + b_hh_r).detach(), emb_tm, w_ih_r.detach().t(), out=xproj[1].view(L * B, 4 * H))
+        hseq = torch.zeros((2, L + 1, B, H), dtype=torch.float32, device=dev)
+        cseq = torch.zeros((2, L + 1, B, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
+        out = torch.empty((B, L, 2 * H), dtype=torch.float32, device=dev)
+        lens = lengths.to(torch.int32).contiguous()
+        whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
+        for s in range(L):
+            ops.lstm_step_fwd(xproj, whf, whr, hseq, cseq, gates, out, lens, B, L, H, s)
+        ctx.dims = (B, L, E, H)
+        ctx.save_for_backward(emb_tm, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, hseq, cseq, gates)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, L, E, H = ctx.dims
+        emb_tm, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, hseq, cseq, gates = ctx.saved_tensors
+        dev = emb_tm.device
+        dout = dout.contiguous().float()
+        wtf, wtr = w_hh_f.t().contiguous(), w_hh_r.t().contiguous()
+        dgates = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
+        dh = torch.zeros((2, B, H), dtype=torch.float32, device=dev)
+        dc = torch.zeros((2, B, H), dtype=torch.float32, device=dev)
+        dh_pass = torch.empty((2, B, H), dtype=torch.float32, device=dev)
+        for s in range(L - 1, -1, -1):
+            ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dh, dc, dh_pass, lens, B, L, H, s)
+        dgf, dgr = dgates[0].view(L * B, 4 * H), dgates[1].view(L * B, 4 * H)
+        # the reverse direction's step s sits at time L-1-s
+        emb_rev = emb_tm.view(L, B, E).flip(0).reshape(L * B, E)
+        dwih_f, dwih_r = dgf.t() @ emb_tm, dgr.t() @ emb_rev
+        dwhh_f = dgf.t() @ hseq[0, :L].reshape(L * B, H)
+        dwhh_r = dgr.t() @ hseq[1, :L].reshape(L * B, H)
+        db_f, db_r = dgf.sum(0), dgr.sum(0)
+        demb = (dgf @ w_ih_f).view(L, B, E) + (dgr @ w_ih_r).view(L, B, E).flip(0)
+        return demb.transpose(0, 1), None, dwih_f, dwhh_f, db_f, db_f, dwih_r, dwhh_r, db_r, db_r
+
+
+def bilstm(emb, lengths, lstm):
+    """lstm: an nn.LSTM(num_layers=1, bidirectional=True, batch_first=True) used as a parameter holder."""
+    return _BiLSTMFn.apply(emb, lengths, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+                           lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
+                           lstm.bias_hh_l0_reverse)

@@ -1,13 +1,14 @@
-"""Query encoder (reference: model/language_module.py:9-98, model/ops.py:16-25,74-85).
+"""Query encoder (reference: model/language_module.py:9-98, model/ops.py:16-25,74-85) -- SURVEY row 8f-4.
 
-SURVEY section 8 keeps this off the hand-written path for now (1.2 % of forward time; row 8f-4 "next"):
-it is stock PyTorch-ROCm (Embedding, MIOpen LSTM, small Linears) producing the three (B, 1024) query
-vectors that feed the HIP path's gates."""
+The BiLSTM recurrence runs in drn_amd/csrc/lstm.hip with sequence lengths on the device (no packed sequences,
+no host-side control flow), so the whole training step is hipGraph-capturable; the embedding lookup, the small
+Linears, the masked softmax and the (B,1,L)x(B,L,1024) products are stock PyTorch-ROCm library calls."""
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+from .. import functional as DF
 
 
 class Linear(nn.Linear):
@@ -49,13 +50,11 @@ class QueryEncoder(nn.Module):
 
     def forward(self, query_tokens, query_length):
         emb = self.embedding(query_tokens)
-        lengths_cpu = query_length.detach().to("cpu", torch.int64)
-        packed = pack_padded_sequence(emb, lengths_cpu, batch_first=True)
-        self.biLSTM.flatten_parameters()
-        output, _ = self.biLSTM(packed)
-        output, _ = pad_packed_sequence(output, batch_first=True)         # (B, Lmax, 2H)
+        lengths = query_length if query_length.device == emb.device else query_length.to(emb.device)
+        # (B, Lmax, 2H), zeros at padded positions like pad_packed_sequence(batch_first=True)
+        output = DF.bilstm(emb, lengths, self.biLSTM)
         B, Lmax, H2 = output.shape
-        lengths = lengths_cpu.to(output.device)
+        lengths = lengths.to(torch.int64)
         last = output.gather(1, (lengths - 1).view(B, 1, 1).expand(B, 1, H2)).squeeze(1)
         q_vector = torch.cat((output[:, 0], last), dim=-1)                # language_module.py:48-54
         base = F.relu(self.qInput(q_vector))

@@ -222,3 +222,17 @@ def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, i
     check(lib().drn_fcos_loss_bwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
                                   ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(gin3),
                                   _p(dlogits), _p(dreg), _p(diou), _stream()), "drn_fcos_loss_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# query-encoder LSTM recurrence
+# ---------------------------------------------------------------------------------------------
+def lstm_step_fwd(xproj, whf, whr, hseq, cseq, gates, out, lens, B, L, H, s):
+    _need_gpu(xproj, out)
+    check(lib().drn_lstm_step_fwd(_p(xproj), _p(whf), _p(whr), _p(hseq), _p(cseq), _p(gates), _p(out), _p(lens), B, L, H, s,
+                                  _stream()), "drn_lstm_step_fwd")
+
+
+def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dh, dc, dh_pass, lens, B, L, H, s):
+    check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), _p(dgates), _p(dh), _p(dc), _p(dh_pass),
+                                  _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")

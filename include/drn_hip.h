@@ -151,6 +151,20 @@ int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, c
                       const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
                       const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream);
 
+/* ---- query-encoder BiLSTM recurrence (drn_amd/csrc/lstm.hip; model/language_module.py:13-15,38-45) ------------
+ * One launch per time step for both directions; sequence lengths on the device (replaces pack_padded_sequence +
+ * the cuDNN/MIOpen RNN).  fp32.  xproj [2][L][B][4H] = x_t W_ih^T + b_ih + b_hh (gate order i,f,g,o);
+ * hseq/cseq [2][L+1][B][H] (slot 0 zero-filled by the caller); gates [2][L][B][4H]; out [B][L][2H].
+ * Step s handles t = s (forward direction) and t = L-1-s (reverse).  B <= 64, H % 64 == 0. */
+int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, float* hseq, float* cseq, float* gates,
+                      float* out, const int* lengths, int B, int L, int H, int s, void* stream);
+/* Backward of step s (call with s = L-1 .. 0): consumes dout [B][L][2H] and the running dh/dc [2][B][H] (zero-filled
+ * before the first call), writes dgates [2][L][B][4H] (for the weight-gradient GEMMs) and the new dh/dc.
+ * WhhT_* = Whh^T as [H][4H]; dh_pass is [2][B][H] scratch. */
+int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const float* WhhT_f, const float* WhhT_r,
+                      float* dgates, float* dh, float* dc, float* dh_pass, const int* lengths, int B, int L, int H, int s,
+                      void* stream);
+
 /* ---- fused clip_grad_norm_ + Adam over flat gradient buckets (drn_amd/csrc/optim.hip; main.py:140,238-243) ---- */
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */
 /* partials[b] = sum of g^2 over block b; step_counter (device int, or NULL) is incremented once per call. */
