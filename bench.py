@@ -79,7 +79,11 @@ def main():
     from drn_amd import dist as ddist
     from drn_amd import ops
     from drn_amd.model import mainModel
-    rank, local, world = ddist.init_from_env()
+    # DRN_DIST_BACKEND=gloo + DRN_FORCE_DEVICE=0 lets several ranks share one GPU to exercise the N>1 code path on a
+    # single-GPU box (test only; the real runs use RCCL, one GPU per rank)
+    rank, local, world = ddist.init_from_env(backend=os.environ.get("DRN_DIST_BACKEND"))
+    if os.environ.get("DRN_FORCE_DEVICE") is not None:
+        local = int(os.environ["DRN_FORCE_DEVICE"])
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -93,7 +97,9 @@ def main():
     model = build(mainModel, cfg, dev, compute_dtype=cdt)
     params = stage_params(model, stage)
     model.train()
-    reducer = ddist.GradReducer(params, world_size=world)
+    # N>1 with hipGraph: forward+backward replay as a graph, so the collectives are issued after it (no overlap);
+    # eager mode overlaps bucket all-reduces with backward from post-accumulate-grad hooks.
+    reducer = ddist.GradReducer(params, world_size=world, overlap=not (args.graph and world > 1))
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-3)                      # main.py:140
     else:
@@ -124,16 +130,34 @@ def main():
     for _ in range(args.warmup):
         step()
     run, mode = step, "eager"
-    if args.graph and world == 1:
-        # the whole step (query encoder, HIP path forward+backward, fused clip+Adam) replays as ONE hipGraph
+    if args.graph:
         from drn_amd.graph import GraphedStep
         try:
-            run = GraphedStep(step, warmup=2).capture()
-            mode = "hipGraph replay of the full step"
+            if world == 1:
+                # the whole step (query encoder, HIP path forward+backward, fused clip+Adam) replays as ONE hipGraph
+                run = GraphedStep(step, warmup=2).capture()
+                mode = "hipGraph replay of the full step"
+            else:
+                # forward+backward replay as one hipGraph per rank; RCCL all-reduce + fused optimizer stay outside it
+                def fwd_bwd():
+                    reducer.zero()
+                    _, losses = model(*batch)
+                    loss_of(losses).backward()
+                    return losses
+                core = GraphedStep(fwd_bwd, warmup=2).capture()
+
+                def run():
+                    losses = core()
+                    for b_ in reducer.buckets:        # re-arm: hooks only ran at capture time
+                        b_.launched, b_.handle = False, None
+                    opt_step()
+                    return losses
+                mode = "hipGraph replay of forward+backward; RCCL all-reduce + optimizer eager"
             run()
         except Exception as e:                                          # keep the eager path measurable
             print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).split(chr(10))[0]), file=sys.stderr)
             torch.cuda.synchronize()
+            reducer.overlap = True
             run, mode = step, "eager (capture failed)"
     barrier()
     t0 = time.perf_counter()

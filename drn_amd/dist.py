@@ -26,6 +26,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif os.environ.get("DRN_FORCE_DEVICE") is not None and torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ["DRN_FORCE_DEVICE"]))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -42,8 +44,11 @@ class GradReducer(object):
     in 32 MB buckets = 5 collectives per step.
     """
 
-    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None):
+    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True):
+        """overlap=False defers every collective to finish() (required when backward is replayed from a hipGraph:
+        hooks only run at capture time and collectives must stay outside the captured region)."""
         self.group = group
+        self.overlap = overlap
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
         self.buckets, self._of = [], {}
@@ -78,7 +83,7 @@ class GradReducer(object):
     def _on_grad(self, p):
         b = self._of[p]
         b.pending -= 1
-        if b.pending == 0 and not b.launched:
+        if self.overlap and b.pending == 0 and not b.launched:
             self._launch(b)
 
     def zero(self):
