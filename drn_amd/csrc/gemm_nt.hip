@@ -61,6 +61,14 @@ template <> struct Mma<bf16_t> {
       for (int ni = 0; ni < 4; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
   }
+  // rows mi0, mi0+1 of the 4x4 tile grid
+  static __device__ __forceinline__ void half(const frag (&a)[4], const frag (&b)[4], f32x4 (&acc)[4][4], int mi0) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi0 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi0 + mi], b[ni], acc[mi0 + mi][ni], 0, 0, 0);
+  }
 };
 template <> struct Mma<float> {
   typedef f32x4 frag;
@@ -72,6 +80,15 @@ template <> struct Mma<float> {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+  }
+  static __device__ __forceinline__ void half(const frag (&a)[4], const frag (&b)[4], f32x4 (&acc)[4][4], int mi0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi0 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi0 + mi][j], b[ni][j], acc[mi0 + mi][ni], 0, 0, 0);
   }
 };
 
@@ -138,61 +155,59 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
 
   // Every thread issues exactly 8 global_load_lds per tile (the counted vmcnt below depends on it); masked lanes and
   // past-the-end tiles read the zero page.
-  auto stage = [&](int buf) {
+  // piece(buf, i): the A and B loads of staging row-group i (2 of the 8 global_load_lds of a tile); advance(): next tile.
+  auto piece = [&](int buf, int i) {
     char* As = smem + buf * STAGE_BYTES;
     char* Bs = As + 16384;
     if constexpr (FAST) {
       const bool kin = s_kt < nkt;
       const long koff = (long)s_kt * BK;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int st;
-        bool ok;
-        if (mode == 0) {
-          st = a_s[i] + s_tap;
-          ok = kin & ((unsigned)st < (unsigned)Lsrc);
-        } else {
-          const int num = a_s[i] - s_tap;
-          st = num >> sh;
-          ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
-        }
-        const T* src = ok ? pA[i] + ((long)st * lda + s_c0) : zero;
-        glds16(src, As + (w * 4 + i) * 1024);
-        const T* bsrc = (kin & okb[i]) ? pB[i] + koff : zero;
-        glds16(bsrc, Bs + (w * 4 + i) * 1024);
+      int st;
+      bool ok;
+      if (mode == 0) {
+        st = a_s[i] + s_tap;
+        ok = kin & ((unsigned)st < (unsigned)Lsrc);
+      } else {
+        const int num = a_s[i] - s_tap;
+        st = num >> sh;
+        ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
       }
+      const T* src = ok ? pA[i] + ((long)st * lda + s_c0) : zero;
+      glds16(src, As + (w * 4 + i) * 1024);
+      const T* bsrc = (kin & okb[i]) ? pB[i] + koff : zero;
+      glds16(bsrc, Bs + (w * 4 + i) * 1024);
+    } else {
+      const int h = i & 1;
+      const int c = pch ^ ((h << 2) + (l >> 4));
+      const int kk = s_kt * BK + c * CH;
+      const int tp = taps == 1 ? 0 : kk / Cin;
+      const int cc = kk - tp * Cin;
+      const bool kin = kk < K;
+      const int num = mode ? a_s[i] - tp : a_s[i] + tp;
+      const int st = div == 1 ? num : (div == 2 ? num >> 1 : num / div);
+      const bool ok = kin & (num >= 0) & (st * div == num) & (st < Lsrc);
+      const long aoff = (long)(a_base[i] + st) * lda + cc;
+      const T* src = ok ? Ag + aoff : zero;
+      glds16(src, As + (w * 4 + i) * 1024);
+      const bool okb2 = kin & (b_off[i] >= 0);
+      const T* bsrc = okb2 ? Bg + (b_off[i] + kk) : zero;
+      glds16(bsrc, Bs + (w * 4 + i) * 1024);
+    }
+  };
+  auto advance = [&]() {
+    if constexpr (FAST) {
       s_c0 += BK;
       if (s_c0 >= Cin) {
         s_c0 -= Cin;
         ++s_tap;
       }
-    } else {
-      int tap2[2], cc2[2], kk2[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = pch ^ ((h << 2) + (l >> 4));
-        const int kk = s_kt * BK + c * CH;
-        kk2[h] = kk;
-        const int tp = taps == 1 ? 0 : kk / Cin;
-        tap2[h] = tp;
-        cc2[h] = kk - tp * Cin;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int h = i & 1;
-        const bool kin = kk2[h] < K;
-        const int num = mode ? a_s[i] - tap2[h] : a_s[i] + tap2[h];
-        const int st = div == 1 ? num : (div == 2 ? num >> 1 : num / div);
-        const bool ok = kin & (num >= 0) & (st * div == num) & (st < Lsrc);
-        const long aoff = (long)(a_base[i] + st) * lda + cc2[h];
-        const T* src = ok ? Ag + aoff : zero;
-        glds16(src, As + (w * 4 + i) * 1024);
-        const bool okb2 = kin & (b_off[i] >= 0);
-        const T* bsrc = okb2 ? Bg + (b_off[i] + kk2[h]) : zero;
-        glds16(bsrc, Bs + (w * 4 + i) * 1024);
-      }
     }
     ++s_kt;
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece(buf, i);
+    advance();
   };
 
   f32x4 acc[4][4];
@@ -213,13 +228,12 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
     if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {
-      int nxt = cur + STAGES - 1;
-      if (nxt >= STAGES) nxt -= STAGES;
-      stage(nxt);
-    }
+    int nxt = cur + STAGES - 1;
+    if (nxt >= STAGES) nxt -= STAGES;
     const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + 16384;
+    // The 8 loads of tile kt+STAGES-1 are issued in 4 pairs BETWEEN the MFMA groups of tile kt, so their issue cost
+    // (~100 cycles each) overlaps the matrix pipe instead of preceding it.
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int pc = ((ks * 4 + (l >> 4)) ^ swz) * 16;
@@ -230,8 +244,16 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * 64 + ni * 16 + (l & 15)) * 128 + pc);
-      Mma<T>::run(a, b, acc);
+      piece(nxt, ks * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      Mma<T>::half(a, b, acc, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(nxt, ks * 2 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      Mma<T>::half(a, b, acc, 2);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    advance();
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

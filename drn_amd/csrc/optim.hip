@@ -17,12 +17,13 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_kernel(const float
   if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
   const long base = (long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
   float s = 0.f;
-#pragma unroll 4
-  for (int i = threadIdx.x; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS) {
+  for (int i = threadIdx.x * 4; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS * 4) {
     const long k = base + i;
-    if (k < n) {
-      const float v = g[k];
-      s = fmaf(v, v, s);
+    if (k + 4 <= n) {
+      const f32x4 v = *(const f32x4*)(g + k);
+      s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+    } else {
+      for (int e = 0; e < 4 && k + e < n; ++e) s = fmaf(g[k + e], g[k + e], s);
     }
   }
   s = block_sum(s, sh);
@@ -75,18 +76,39 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
   }
   __syncthreads();
   int seg = first_seg;
-#pragma unroll 4
-  for (int i = threadIdx.x; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS) {
+  // 4 elements per thread per trip.  Segment starts are 4-aligned in the flat buffers (drn_amd.dist pads them), so a
+  // quad never straddles two tensors; only a tensor's last (partial) quad takes the scalar path.
+  for (int i = threadIdx.x * 4; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS * 4) {
     const long k = base + i;
     if (k >= A.n) break;
     while (k >= A.seg_start[seg + 1]) ++seg;
-    const float g = A.g[k] * clip;
-    const float m = A.beta1 * A.m[k] + (1.f - A.beta1) * g;
-    const float v = A.beta2 * A.v[k] + (1.f - A.beta2) * g * g;
-    A.m[k] = m;
-    A.v[k] = v;
-    float* p = A.p_ptr[seg] + (k - A.seg_start[seg]);
-    *p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + A.eps);
+    const long s0 = A.seg_start[seg], s1 = A.seg_start[seg + 1];
+    float* pbase = A.p_ptr[seg];
+    if (pbase == nullptr) continue;                       // padding between tensors
+    float* p = pbase + (k - s0);
+    if (k + 4 <= s1 && k + 4 <= A.n && (((uintptr_t)p) & 15) == 0) {
+      const f32x4 g4 = *(const f32x4*)(A.g + k);
+      f32x4 m4 = *(const f32x4*)(A.m + k), v4 = *(const f32x4*)(A.v + k), p4 = *(const f32x4*)p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = g4[e] * clip;
+        m4[e] = A.beta1 * m4[e] + (1.f - A.beta1) * g;
+        v4[e] = A.beta2 * v4[e] + (1.f - A.beta2) * g * g;
+        p4[e] -= step_size * m4[e] / (sqrtf(v4[e]) * inv_sqrt_bc2 + A.eps);
+      }
+      *(f32x4*)(A.m + k) = m4;
+      *(f32x4*)(A.v + k) = v4;
+      *(f32x4*)p = p4;
+    } else {
+      for (int e = 0; e < 4 && k + e < s1 && k + e < A.n; ++e) {
+        const float g = A.g[k + e] * clip;
+        const float m = A.beta1 * A.m[k + e] + (1.f - A.beta1) * g;
+        const float v = A.beta2 * A.v[k + e] + (1.f - A.beta2) * g * g;
+        A.m[k + e] = m;
+        A.v[k + e] = v;
+        p[e] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + A.eps);
+      }
+    }
   }
 }
 

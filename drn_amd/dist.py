@@ -12,6 +12,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import functional as DF
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*). Returns (rank, local_rank, world)."""
@@ -33,7 +35,7 @@ def init_from_env(backend=None):
 
 
 class _Bucket(object):
-    __slots__ = ("flat", "params", "pending", "handle", "launched")
+    __slots__ = ("flat", "params", "offsets", "views", "pending", "handle", "launched")
 
 
 class GradReducer(object):
@@ -44,11 +46,15 @@ class GradReducer(object):
     in 32 MB buckets = 5 collectives per step.
     """
 
-    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True):
+    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True, steal=True):
         """overlap=False defers every collective to finish() (required when backward is replayed from a hipGraph:
         hooks only run at capture time and collectives must stay outside the captured region)."""
         self.group = group
         self.overlap = overlap
+        # steal=True: p.grad is None at the start of backward; backward kernels that know the sink write straight into
+        # the flat bucket and autograd adopts that view (no zero-fill, no accumulate-add); anything else is copied in.
+        self.steal = steal
+        self._dirty = {}
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
         self.buckets, self._of = [], {}
@@ -63,16 +69,27 @@ class GradReducer(object):
             self._make_bucket(cur)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
+    @staticmethod
+    def _offsets(params):
+        """4-element (16-byte) aligned start of every tensor inside the flat buffer (vector access in the fused optimizer)."""
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        return offs, off
+
     def _make_bucket(self, params):
         b = _Bucket()
-        n = sum(p.numel() for p in params)
+        offs, n = self._offsets(params)
         b.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
-        off = 0
-        for p in params:
-            p.grad = b.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-            self._of[p] = b
-        b.params, b.pending, b.handle, b.launched = params, len(params), None, False
+        b.views = []
+        for p, off in zip(params, offs):
+            v = b.flat[off:off + p.numel()]
+            b.views.append(v)
+            p.grad = v.view_as(p)
+            self._of[p] = (b, len(b.views) - 1)
+            DF.register_grad_sink(p, v)
+        b.params, b.offsets, b.pending, b.handle, b.launched = params, offs, len(params), None, False
         self.buckets.append(b)
 
     def _launch(self, b):
@@ -81,26 +98,47 @@ class GradReducer(object):
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
-        b = self._of[p]
+        b, i = self._of[p]
+        sink = b.views[i]
+        if p.grad is not None and p.grad.data_ptr() != sink.data_ptr():
+            with torch.no_grad():
+                sink.copy_(p.grad.reshape(-1))          # gradient produced elsewhere (stock autograd ops): move it in
+            p.grad = sink.view_as(p)
+        self._dirty[p] = True
         b.pending -= 1
         if self.overlap and b.pending == 0 and not b.launched:
             self._launch(b)
 
     def zero(self):
-        """Call before each backward: zero the flat buffers (p.grad stay views) and re-arm the buckets."""
+        """Call before each backward: re-arm the buckets.  steal mode drops p.grad (the flat slices get overwritten by
+        backward); otherwise the flat buffers are zeroed and p.grad stay views that autograd accumulates into."""
         for b in self.buckets:
-            b.flat.zero_()
             b.pending, b.handle, b.launched = len(b.params), None, False
-            off = 0
-            for p in b.params:                                # something may have replaced p.grad (e.g. set_to_none)
-                if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * b.flat.element_size():
-                    p.grad = b.flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            if self.steal:
+                for p in b.params:
+                    p.grad = None
+            else:
+                b.flat.zero_()
+                for p, v in zip(b.params, b.views):
+                    if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                        p.grad = v.view_as(p)
 
     def finish(self):
         """Call after backward: reduce the buckets whose parameters got no gradient this step (unused / frozen
         branches contribute zeros), wait for all collectives and turn sums into means."""
         for b in self.buckets:
+            if self.steal:
+                for p, v in zip(b.params, b.views):
+                    if p.grad is None:                          # no gradient this step: the slice must read as zero
+                        if self._dirty.get(p, False):
+                            v.zero_()
+                            self._dirty[p] = False
+                        p.grad = v.view_as(p)
+                    elif p.grad.data_ptr() != v.data_ptr():     # hook did not run (e.g. grads set by hand)
+                        with torch.no_grad():
+                            v.copy_(p.grad.reshape(-1))
+                        p.grad = v.view_as(p)
+                        self._dirty[p] = True
             if not b.launched:
                 self._launch(b)
         if self.world > 1:
@@ -111,3 +149,4 @@ class GradReducer(object):
     def remove(self):
         for h in self._hooks:
             h.remove()
+        DF.clear_grad_sinks()

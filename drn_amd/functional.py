@@ -41,6 +41,28 @@ def packed(w, perm, code):
     return out
 
 
+# Gradient sinks: drn_amd.dist.GradReducer registers, per parameter storage, the slice of its flat bucket where that
+# parameter's gradient must end up.  A backward that writes the weight gradient straight into a fresh VIEW of the
+# slice lets autograd's AccumulateGrad adopt it (p.grad is None -> the incoming tensor is kept, no zero-fill, no add).
+_grad_sinks = {}
+
+
+def register_grad_sink(param, flat_slice):
+    _grad_sinks[param.data_ptr()] = flat_slice
+
+
+def clear_grad_sinks():
+    _grad_sinks.clear()
+
+
+def grad_buffer(param, dtype=torch.float32):
+    """Uninitialised fp32 buffer shaped like `param` for its gradient: the registered sink when there is one."""
+    sink = _grad_sinks.get(param.data_ptr())
+    if sink is not None and sink.numel() == param.numel() and sink.dtype == dtype and sink.device == param.device:
+        return sink.view(param.shape)
+    return torch.empty(param.shape, dtype=dtype, device=param.device)
+
+
 def code_of(dtype):
     return ops.BF16 if dtype == torch.bfloat16 else ops.F32
 
@@ -151,6 +173,7 @@ class _ConvBlockFn(torch.autograd.Function):
             outs.append(out)
         ctx.meta, ctx.nl, ctx.geo, ctx.k = meta, nl, geo, k
         ctx.has_gate, ctx.has_up, ctx.has_cbias = gate is not None, up is not None, cbias is not None
+        ctx.beta_ref = beta
         ctx.save_for_backward(weight, gamma, gate if gate is not None else weight.new_empty(0), *xs, *raws, *sss, *saves, *outs)
         res = tuple(outs)
         if gate is not None:
@@ -174,8 +197,8 @@ class _ConvBlockFn(torch.autograd.Function):
         Cout, Cin, _ = weight.shape
         pad = (k - 1) // 2
         dev = weight.device
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
+        dgamma = grad_buffer(gamma)
+        dbeta = grad_buffer(ctx.beta_ref) if ctx.beta_ref is not None else torch.empty_like(gamma)
         dgate = dup = None
         draws = []
         for l in range(nl):
@@ -212,7 +235,7 @@ class _ConvBlockFn(torch.autograd.Function):
                                            Lout=L, Lsrc=Lo))
                 dxs[l] = dx
             ops.gemm_nt(descs, code)
-        dW = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        dW = grad_buffer(weight)
         wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
                   for l in range(nl)]
         ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
@@ -252,6 +275,7 @@ class _InputStageFn(torch.autograd.Function):
         pos_slice = G0.view(B * T, D + P)[:, D:]
         ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
         ctx.dtype, ctx.dims = dtype, (B, T, D, P)
+        ctx.param_refs = (Wfc, bfc, Wpos, bpos)
         ctx.save_for_backward(xc, pf, gate0, Z)
         return G0
 
@@ -266,12 +290,13 @@ class _InputStageFn(torch.autograd.Function):
         dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
         dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
         ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, False, dgate, B, T, D, code)
-        dW = torch.empty((D, D), dtype=torch.float32, device=dev)
+        Wfc, bfc, Wpos, bpos = ctx.param_refs
+        dW = grad_buffer(Wfc)
         ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
-        db = torch.empty(D, dtype=torch.float32, device=dev)
+        db = grad_buffer(bfc)
         ops.colsum(dZ, D, B * T, D, db, code)
-        dWp = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        dbp = torch.empty(P, dtype=torch.float32, device=dev)
+        dWp = grad_buffer(Wpos)
+        dbp = grad_buffer(bpos)
         ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, dWp, dbp, code)
         return None, None, None, dW, db, dgate, dWp, dbp
 

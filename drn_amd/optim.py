@@ -19,13 +19,17 @@ class FusedAdam(object):
         nparts = 0
         for b in reducer.buckets:
             n = b.flat.numel()
-            offs, ptrs, off = [0], [], 0
-            for p in b.params:
+            offs, ptrs = [], []
+            for p, off in zip(b.params, b.offsets):
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdam needs contiguous fp32 parameters")
-                ptrs.append(p.data_ptr())
-                off += p.numel()
                 offs.append(off)
+                ptrs.append(p.data_ptr())
+                pad_start = off + p.numel()
+                if pad_start % 4:                             # alignment padding: a segment with a null pointer
+                    offs.append(pad_start)
+                    ptrs.append(0)
+            offs.append(n)
             nb = int(L.drn_opt_nblocks(ctypes.c_int64(n)))
             self.state.append({"m": torch.zeros_like(b.flat), "v": torch.zeros_like(b.flat),
                                "seg": torch.tensor(offs, dtype=torch.int64, device=dev),
@@ -37,7 +41,7 @@ class FusedAdam(object):
 
     def _check_ptrs(self):
         for b, st in zip(self.reducer.buckets, self.state):
-            if [p.data_ptr() for p in b.params] != st["ptr"].tolist():
+            if [p.data_ptr() for p in b.params] != [x for x in st["ptr"].tolist() if x]:
                 raise RuntimeError("parameter storage moved after FusedAdam was built")
 
     def step(self):

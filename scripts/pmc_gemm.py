@@ -1,0 +1,19 @@
+"""One-shape GEMM launches for PMC collection: python scripts/pmc_gemm.py <shape> (prop_fc | l3 | towers)."""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from drn_amd import ops
+dev = "cuda:0"; dt = torch.bfloat16; code = ops.BF16
+shape = sys.argv[1]
+B = 32
+def mk(levels, N, Cin, taps=1):
+    W = torch.randn(N, taps * Cin, device=dev).to(dt); descs = []; keep = []
+    for (b, L) in levels:
+        A = torch.randn(b * L, Cin, device=dev).to(dt); C = torch.empty(b * L, N, device=dev, dtype=dt)
+        descs.append(ops.gemm_desc(A, W, C, b * L, N, Cin, taps=taps, pad=(taps - 1) // 2, Lout=L, Lsrc=L)); keep.append((A, C))
+    return descs, keep, W
+if shape == "prop_fc": d, k, W = mk([(B, 256)], 4096, 4096)
+elif shape == "l3": d, k, W = mk([(B, 64)], 512, 512, 3)
+else: d, k, W = mk([(B, 256), (B, 128), (B, 64)], 1024, 512, 3)
+for _ in range(5):
+    ops.gemm_nt(d, code)
+torch.cuda.synchronize()
