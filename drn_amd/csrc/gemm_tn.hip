@@ -117,40 +117,73 @@ __global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const Wgra
   const T* zero = (const T*)g_zero_page;
 
   // lane-constant piece of the staging map: instr q = w*4+i covers chunks p = q*64 + l
-  int s_cb[4], s_r[4], s_sub[4];
+  int s_r[4];
+  long y_off[4], x_off[4];          // column offsets inside a row (or -1 when the 16-column block is out of range)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = w * 4 + i;
     const int within = (q & 1) * 64 + l;
-    s_cb[i] = q >> 1;
+    const int col = (q >> 1) * 16 + (within % CPR) * CH;
     s_r[i] = within / CPR;
-    s_sub[i] = within % CPR;
+    y_off[i] = n0 + col < P.N ? n0 + col : -1;
+    x_off[i] = c0 + col < P.Cin ? c0 + col : -1;
   }
 
-  auto stage = [&](int buf, int blk) {
+  // Row blocks are consumed strictly in order; (group, first row of the block) advance incrementally and the
+  // (sequence, position) of each of the thread's 4 rows is carried along, so the K-loop has no integer division.
+  int s_blk = blk_lo, s_g = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.ngroups && blk_lo >= P.g[i].blk_start) s_g = i;
+  int s_seq[4], s_t[4];             // of row (block base + s_r[i]) in the current group
+  auto locate = [&]() {
+    const WgradGroup& G = P.g[s_g];
+    const int mbase = (s_blk - G.blk_start) * R;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + s_r[i];
+      s_seq[i] = m / G.Lout;
+      s_t[i] = m - s_seq[i] * G.Lout;
+    }
+  };
+  locate();
+
+  // branch-free: masked lanes read the zero page; every thread issues exactly 8 global_load_lds per block
+  auto stage = [&](int buf) {
     char* Ys = smem + buf * STAGE_BYTES;
     char* Xs = Ys + 16384;
-    int g = 0;
-#pragma unroll
-    for (int i = 1; i < DRN_MAX_GROUPS; ++i)
-      if (i < P.ngroups && blk >= P.g[i].blk_start) g = i;
-    const WgradGroup& G = P.g[g];
-    const int mbase = (blk - G.blk_start) * R;
+    const bool live = s_blk < blk_hi;
+    const WgradGroup& G = P.g[s_g];
+    const int mbase = (s_blk - G.blk_start) * R;
     const T* __restrict__ Yg = (const T*)G.dY;
     const T* __restrict__ Xg = (const T*)G.X;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // branch-free: masked lanes read the zero page
+    for (int i = 0; i < 4; ++i) {
       const int m = mbase + s_r[i];
-      const int col = s_cb[i] * 16 + s_sub[i] * CH;
-      const bool min_ = m < G.M;
-      const bool oky = min_ & (n0 + col < P.N);
-      const T* ys = oky ? Yg + ((long)m * G.ldy + n0 + col) : zero;
-      const int seq = m / G.Lout;
-      const int st = (m - seq * G.Lout) * P.stride + tap - P.pad;
-      const bool okx = min_ & (c0 + col < P.Cin) & (st >= 0) & (st < G.Lsrc);
-      const T* xs = okx ? Xg + ((long)(seq * G.Lsrc + st) * G.ldx + c0 + col) : zero;
+      const bool min_ = live & (m < G.M);
+      const bool oky = min_ & (y_off[i] >= 0);
+      const T* ys = oky ? Yg + ((long)m * G.ldy + y_off[i]) : zero;
+      const int st = s_t[i] * P.stride + tap - P.pad;
+      const bool okx = min_ & (x_off[i] >= 0) & (st >= 0) & (st < G.Lsrc);
+      const T* xs = okx ? Xg + ((long)(s_seq[i] * G.Lsrc + st) * G.ldx + x_off[i]) : zero;
       glds16(ys, Ys + (w * 4 + i) * 1024);
       glds16(xs, Xs + (w * 4 + i) * 1024);
+    }
+    // advance to the next row block
+    ++s_blk;
+    if (s_g + 1 < P.ngroups && s_blk >= P.g[s_g + 1].blk_start) {
+      ++s_g;
+      locate();
+    } else {
+      const int Lout = G.Lout;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_t[i] += R;
+        while (s_t[i] >= Lout) {
+          s_t[i] -= Lout;
+          ++s_seq[i];
+        }
+      }
     }
   };
 
@@ -161,20 +194,20 @@ __global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const Wgra
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int wr = w >> 1, wc = w & 1;
 
-  if (blk_lo < blk_hi) {
-    stage(0, blk_lo);
+  // 2-deep ring, one barrier per row block: wait for block b, barrier (everyone also finished block b-1), issue b+1
+  // into the slot b-1 used, compute b.
+  stage(0);
+  int cur = 0;
+  for (int blk = blk_lo; blk < blk_hi; ++blk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int blk = blk_lo; blk < blk_hi; ++blk) {
-      if (blk + 1 < blk_hi) stage(cur ^ 1, blk + 1);
-      const char* Ys = smem + cur * STAGE_BYTES;
-      TnMma<T>::compute(Ys, Ys + 16384, wr, wc, l, acc);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
-    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage(cur ^ 1);
+    const char* Ys = smem + cur * STAGE_BYTES;
+    TnMma<T>::compute(Ys, Ys + 16384, wr, wc, l, acc);
+    cur ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: acc[mi][ni][r] -> n = n0 + wr*64 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*64 + ni*16 + (l&15)
   const int KW = P.taps * P.Cin;

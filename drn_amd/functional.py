@@ -63,6 +63,24 @@ def grad_buffer(param, dtype=torch.float32):
     return torch.empty(param.shape, dtype=dtype, device=param.device)
 
 
+import os
+
+_side_streams = {}
+# Forking the weight-gradient GEMM of a block onto a second stream (parallel hipGraph branches) measured SLOWER on
+# MI355X/ROCm 7.2 (6.05 vs 4.7 ms per step): cross-queue dependencies cost more than the idle CUs they fill.
+FORK_WGRAD = os.environ.get("DRN_FORK_WGRAD", "0") == "1"
+
+
+def side_stream(device):
+    """A second HIP stream per device: independent kernels of one backward node (weight gradient vs data gradient)
+    are forked onto it, so under-filled launches share the 256 CUs; the fork/join is captured into the hipGraph."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def code_of(dtype):
     return ops.BF16 if dtype == torch.bfloat16 else ops.F32
 
@@ -224,6 +242,15 @@ class _ConvBlockFn(torch.autograd.Function):
             ops.bn_bwd(d, Cout, raws[l], Cout, sss[l], saves[l], gamma, draw, Cout, dgamma, dbeta, l > 0, M, Cout, code,
                        relu=meta.relu)
             draws.append(draw)
+        # weight gradient on the side stream, data gradient on the main one: both only read `draws`
+        main = torch.cuda.current_stream()
+        side = side_stream(dev) if FORK_WGRAD else main
+        side.wait_stream(main) if side is not main else None
+        with torch.cuda.stream(side):
+            dW = grad_buffer(weight)
+            wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
+                      for l in range(nl)]
+            ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[7 + l] for l in range(nl)):
             wd = packed(weight, (1, 2, 0), code)                       # (Cin, k, Cout)
@@ -235,10 +262,8 @@ class _ConvBlockFn(torch.autograd.Function):
                                            Lout=L, Lsrc=Lo))
                 dxs[l] = dx
             ops.gemm_nt(descs, code)
-        dW = grad_buffer(weight)
-        wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
-                  for l in range(nl)]
-        ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
+        if side is not main:
+            main.wait_stream(side)
         dcb = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_cbias else None   # cancels in train-mode BN
         return (None, dW, dcb, dgamma, dbeta, dgate, dup) + tuple(dxs)
 
