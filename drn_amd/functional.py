@@ -507,3 +507,70 @@ def bilstm(emb, lengths, lstm):
     return _BiLSTMFn.apply(emb, lengths, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
                            lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
                            lstm.bias_hh_l0_reverse)
+
+
+class _LGPFn(torch.autograd.Function):
+    """Language-guided pooling (model/LGP.py:29-51).  The 1x1 conv on the tiled query is one (B, Cq)x(Cq, C) product and
+    its train-mode BN sees B*t samples that repeat t times, i.e. batch statistics over B (unbiased factor from B*t):
+    both run as the small exact-fp32 GEMM + BN kernels; the pooling itself is drn_lgp_fwd/bwd on the (B, t, C) tensor."""
+
+    @staticmethod
+    def forward(ctx, dtype, bn, training, x, query, weight, gamma, beta):
+        code = code_of(dtype)
+        B, t, C, ldx = geom(x)
+        Cq = weight.shape[1]
+        dev = x.device
+        q = query.contiguous().float()
+        w2 = weight.detach().reshape(C, Cq).contiguous()
+        raw = torch.empty((B, C), dtype=torch.float32, device=dev)
+        stats = torch.empty((1 if B <= 128 else (B + 127) // 128, 2, C), dtype=torch.float32, device=dev)
+        ops.gemm_nt([ops.gemm_desc(q, w2, raw, B, C, Cq, Lout=1, Lsrc=1, stats=stats)], ops.F32)
+        ss = torch.empty((2, C), dtype=torch.float32, device=dev)
+        save = torch.empty((2, C), dtype=torch.float32, device=dev)
+        if training:
+            ops.bn_finalize([(stats, stats.shape[0], B, ss, save)], C, gamma, beta, None, None, None, 0.0, bn.eps)
+            if bn.track_running_stats and bn.running_mean is not None:
+                n = B * t
+                with torch.no_grad():        # (C,)-sized buffer updates: n = B*t samples for the unbiased variance
+                    var = 1.0 / (save[1] * save[1]) - bn.eps
+                    bn.running_mean.mul_(1 - bn.momentum).add_(save[0], alpha=bn.momentum)
+                    bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+                    bn.num_batches_tracked.add_(1)
+        else:
+            ops.bn_eval_scale_shift(C, gamma, beta, None, bn.running_mean, bn.running_var, bn.eps, ss)
+        qn = torch.empty((B, C), dtype=torch.float32, device=dev)
+        ops.bn_apply(raw, C, ss, qn, C, B, C, 1, ops.F32, relu=False)
+        out = torch.empty((B, t // 2, C), dtype=dtype, device=dev)
+        att = torch.empty((B, t // 2, 2), dtype=torch.float32, device=dev)
+        ops.lgp_fwd(x, ldx, qn, out, att, B, t, C, code)
+        ctx.dtype, ctx.dims, ctx.training = dtype, (B, t, C, Cq, ldx), training
+        ctx.save_for_backward(x, q, weight, gamma, raw, ss, save, qn, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise DrnError("backward through eval-mode LGP is not supported")
+        dtype = ctx.dtype
+        code = code_of(dtype)
+        B, t, C, Cq, ldx = ctx.dims
+        x, q, weight, gamma, raw, ss, save, qn, att = ctx.saved_tensors
+        dev = x.device
+        dout = _grad_nlc(dout, None, dtype)
+        dx = torch.empty((B, t, C), dtype=dtype, device=dev)
+        dqn = torch.empty((B, C), dtype=torch.float32, device=dev)
+        ops.lgp_bwd(x, ldx, qn, att, dout, dx, dqn, B, t, C, code)
+        draw = torch.empty((B, C), dtype=torch.float32, device=dev)
+        dgamma, dbeta = grad_buffer(gamma), torch.empty_like(gamma)
+        ops.bn_bwd(dqn, C, raw, C, ss, save, gamma, draw, C, dgamma, dbeta, False, B, C, ops.F32, relu=False)
+        dW = grad_buffer(weight)
+        ops.gemm_wgrad([ops.wgrad_desc(draw, q, B, Lout=1, Lsrc=1, ldy=C, ldx=Cq)], dW.view(C, Cq, 1), C, Cq, taps=1, w_layout=1,
+                       dtype=ops.F32)
+        wt = ops.pack_weight(weight.detach().reshape(C, Cq, 1), (1, 2, 0), ops.F32).view(Cq, C)
+        dq = torch.empty((B, Cq), dtype=torch.float32, device=dev)
+        ops.gemm_nt([ops.gemm_desc(draw, wt, dq, B, Cq, C, Lout=1, Lsrc=1)], ops.F32)
+        return None, None, None, dx, dq, dW, dgamma, dbeta
+
+
+def lgp(x, query, conv, bn, training, dtype):
+    return _LGPFn.apply(dtype, bn, training, x, query, conv.weight, bn.weight, bn.bias)

@@ -236,3 +236,16 @@ def lstm_step_fwd(xproj, whf, whr, hseq, cseq, gates, out, lens, B, L, H, s):
 def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dh, dc, dh_pass, lens, B, L, H, s):
     check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), _p(dgates), _p(dh), _p(dc), _p(dh_pass),
                                   _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# language-guided pooling
+# ---------------------------------------------------------------------------------------------
+def lgp_fwd(x, ldx, qn, out, att, B, t, C, dtype):
+    check(lib().drn_lgp_fwd(_p(x), ldx, _p(qn), _p(out), C, _p(att), B, t, C, dtype, _stream()), "drn_lgp_fwd")
+
+
+def lgp_bwd(x, ldx, qn, att, dout, dx, dqn, B, t, C, dtype):
+    ws = workspace(B * ((t // 2 + 3) // 4) * C, dqn.device)
+    check(lib().drn_lgp_bwd(_p(x), ldx, _p(qn), _p(att), _p(dout), C, _p(dx), C, _p(dqn), _p(ws), B, t, C, dtype, _stream()),
+          "drn_lgp_bwd")

@@ -151,6 +151,15 @@ int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, c
                       const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
                       const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream);
 
+/* ---- language-guided pooling (drn_amd/csrc/lgp.hip; model/LGP.py:29-51) ---------------------------------------
+ * x (B, t, C) channels-last, qn (B, C) fp32 = BN(conv1x1(query)) prepared by the caller, out (B, t/2, C),
+ * att (B, t/2, 2) fp32 (saved for backward).  C <= 2048 (bf16) / 1024 (f32). */
+int drn_lgp_fwd(const void* x, int ldx, const float* qn, void* out, int ld_out, float* att, int B, int t, int C, int dtype,
+                void* stream);
+/* dx (B, t, C) and dqn (B, C) = gradient w.r.t. qn; ws >= B*ceil(t/8)*C floats. */
+int drn_lgp_bwd(const void* x, int ldx, const float* qn, const float* att, const void* dout, int ld_dout, void* dx, int ld_dx,
+                float* dqn, float* ws, int B, int t, int C, int dtype, void* stream);
+
 /* ---- query-encoder BiLSTM recurrence (drn_amd/csrc/lstm.hip; model/language_module.py:13-15,38-45) ------------
  * One launch per time step for both directions; sequence lengths on the device (replaces pack_padded_sequence +
  * the cuDNN/MIOpen RNN).  fp32.  xproj [2][L][B][4H] = x_t W_ih^T + b_ih + b_hh (gate order i,f,g,o);
