@@ -19,9 +19,6 @@
 #include "common.h"
 #include "../../include/drn_hip.h"
 
-#define TILE 128
-#define NT_THREADS 256
-#define STAGE_BYTES 32768  // 16 KB A + 16 KB B
 
 
 struct GemmProb {
@@ -54,40 +51,26 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   typedef bf16x8 frag;
-  static __device__ __forceinline__ void run(const frag (&a)[4], const frag (&b)[4], f32x4 (&acc)[4][4]) {
+  // rows [mi0, mi0+MH) of the MI x NI grid of 16x16 MFMA tiles
+  template <int MI, int NI, int MH>
+  static __device__ __forceinline__ void part(const frag (&a)[MI], const frag (&b)[NI], f32x4 (&acc)[MI][NI], int mi0) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-  }
-  // rows mi0, mi0+1 of the 4x4 tile grid
-  static __device__ __forceinline__ void half(const frag (&a)[4], const frag (&b)[4], f32x4 (&acc)[4][4], int mi0) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
         acc[mi0 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi0 + mi], b[ni], acc[mi0 + mi][ni], 0, 0, 0);
   }
 };
 template <> struct Mma<float> {
   typedef f32x4 frag;
-  static __device__ __forceinline__ void run(const frag (&a)[4], const frag (&b)[4], f32x4 (&acc)[4][4]) {
+  template <int MI, int NI, int MH>
+  static __device__ __forceinline__ void part(const frag (&a)[MI], const frag (&b)[NI], f32x4 (&acc)[MI][NI], int mi0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
-  }
-  static __device__ __forceinline__ void half(const frag (&a)[4], const frag (&b)[4], f32x4 (&acc)[4][4], int mi0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi0 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi0 + mi][j], b[ni][j], acc[mi0 + mi][ni], 0, 0, 0);
   }
 };
@@ -98,11 +81,20 @@ template <> struct Mma<float> {
 // FAST (every group has Cin % BK == 0, so a K-tile never straddles two taps): the tap and channel offset of a tile are
 // wave-uniform scalars advanced incrementally, and each thread keeps 4+4 precomputed row pointers -- ~10 VALU per
 // global_load_lds instead of a per-lane integer division and 64-bit multiply.  The generic path keeps those.
-template <typename T, int STAGES, bool FAST>
-__global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_nt_kernel(const GemmParams P) {
+// Tile shape: WM x WN waves, each owning MI x NI MFMA tiles of 16x16 -> TM = WM*MI*16 rows, TN = WN*NI*16 columns.
+//   <2,2,4,4>: 128x128, 4 waves, 32 KB/stage (2 workgroups per CU at 2 stages)    -- general purpose
+//   <2,4,8,4>: 256x256, 8 waves (2 per SIMD), 64 KB/stage, 2 stages               -- large GEMMs: half the operand
+//              traffic and half the global_load_lds / ds_read per MFMA
+template <typename T, int STAGES, bool FAST, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 : 1))) void conv_gemm_nt_kernel(const GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 8 * CH;               // elements per K-step (128 bytes)
+  constexpr int NW = WM * WN, TM = WM * MI * 16, TN = WN * NI * 16;
+  constexpr int PA = TM / (8 * NW), PB = TN / (8 * NW);      // 1-KB staging pieces per wave and operand
+  constexpr int PMAX = PA > PB ? PA : PB;
+  constexpr int A_BYTES = TM * 128, STAGE_B = (TM + TN) * 128;
+  static_assert(PA * 8 * NW == TM && PB * 8 * NW == TN && PMAX == 4, "staging assumes 4 pieces per wave");
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
 
   int g = 0;
@@ -112,7 +104,7 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
   const GemmProb& pr = P.p[g];
   const int t_local = blockIdx.x - pr.tile_start;
   const int tm = t_local / pr.tiles_n, tn = t_local - tm * pr.tiles_n;
-  const int m0 = tm * TILE, n0 = tn * TILE;
+  const int m0 = tm * TM, n0 = tn * TN;
   const int M = pr.M, N = pr.N, K = pr.K, Cin = pr.Cin, taps = pr.taps;
   const int stride = pr.stride, pad = pr.pad, mode = pr.mode, Lsrc = pr.Lsrc;
   const T* __restrict__ Ag = (const T*)pr.A;
@@ -124,15 +116,15 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
   const int div = mode ? stride : 1;
   const long lda = pr.lda;
   const int sh = div == 2 ? 1 : 0;
-  int a_s[4];            // mode 0: t*stride - pad ; mode 1: t + pad ; hugely negative when the row is out of range
-  const T* pA[4];        // A + (seq*Lsrc)*lda + lane chunk offset
-  const T* pB[4];        // B + n*ldb + lane chunk offset
-  bool okb[4];
-  int a_base[4];         // generic path
-  long b_off[4];
+  int a_s[PA];           // mode 0: t*stride - pad ; mode 1: t + pad ; hugely negative when the row is out of range
+  const T* pA[PA];       // A + (seq*Lsrc)*lda + lane chunk offset
+  const T* pB[PB];       // B + n*ldb + lane chunk offset
+  bool okb[PB];
+  int a_base[PA];        // generic path
+  long b_off[PB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (w * 4 + i) * 8 + (l >> 3);
+  for (int i = 0; i < PMAX; ++i) {
+    const int row = (w * PMAX + i) * 8 + (l >> 3);
     const int m = m0 + row;
     const int coff = (pch ^ (((i & 1) << 2) + (l >> 4))) * CH;
     int seq = 0, t = -(1 << 28);
@@ -157,8 +149,8 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
   // past-the-end tiles read the zero page.
   // piece(buf, i): the A and B loads of staging row-group i (2 of the 8 global_load_lds of a tile); advance(): next tile.
   auto piece = [&](int buf, int i) {
-    char* As = smem + buf * STAGE_BYTES;
-    char* Bs = As + 16384;
+    char* As = smem + buf * STAGE_B;
+    char* Bs = As + A_BYTES;
     if constexpr (FAST) {
       const bool kin = s_kt < nkt;
       const long koff = (long)s_kt * BK;
@@ -210,13 +202,13 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
     advance();
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = w / WN, wc = w % WN;
   const int swz = (l >> 1) & 7;
 
 #pragma unroll
@@ -230,27 +222,27 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
     asm volatile("" ::: "memory");
     int nxt = cur + STAGES - 1;
     if (nxt >= STAGES) nxt -= STAGES;
-    const char* As = smem + cur * STAGE_BYTES;
-    const char* Bs = As + 16384;
+    const char* As = smem + cur * STAGE_B;
+    const char* Bs = As + A_BYTES;
     // The 8 loads of tile kt+STAGES-1 are issued in 4 pairs BETWEEN the MFMA groups of tile kt, so their issue cost
     // (~100 cycles each) overlaps the matrix pipe instead of preceding it.
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int pc = ((ks * 4 + (l >> 4)) ^ swz) * 16;
-      typename Mma<T>::frag a[4], b[4];
+      typename Mma<T>::frag a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        a[mi] = *(const typename Mma<T>::frag*)(As + (wr * 64 + mi * 16 + (l & 15)) * 128 + pc);
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *(const typename Mma<T>::frag*)(As + (wr * (MI * 16) + mi * 16 + (l & 15)) * 128 + pc);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * 64 + ni * 16 + (l & 15)) * 128 + pc);
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * (NI * 16) + ni * 16 + (l & 15)) * 128 + pc);
       piece(nxt, ks * 2);
       __builtin_amdgcn_sched_barrier(0);
-      Mma<T>::half(a, b, acc, 0);
+      Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, 0);
       __builtin_amdgcn_sched_barrier(0);
       piece(nxt, ks * 2 + 1);
       __builtin_amdgcn_sched_barrier(0);
-      Mma<T>::half(a, b, acc, 2);
+      Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, MI / 2);
       __builtin_amdgcn_sched_barrier(0);
     }
     advance();
@@ -259,15 +251,18 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- epilogue.  acc[mi][ni][r]: m = wr*64+mi*16+(l>>4)*4+r, n = wc*64+ni*16+(l&15)
+  // ---- epilogue.  acc[mi][ni][r]: m = wr*MI*16 + mi*16 + (l>>4)*4 + r, n = wc*NI*16 + ni*16 + (l&15)
   if (pr.stats) {
-    // per-tile column sums of the raw fp32 accumulators (rows >= M contribute exact zeros)
-    float* sh = (float*)smem;  // [2 wr][2 kind][128 n]
+    // Column sums of the raw fp32 accumulators per 128-row slab (rows >= M contribute exact zeros):
+    // stats[(slab*2 + kind)*N + n], slab = m / 128, whatever the tile shape.
+    constexpr int WROWS = MI * 16;            // rows owned by one wave row: 64 or 128
+    constexpr int WPS = 128 / WROWS;          // wave rows per 128-row slab
+    float* shs = (float*)smem;                // [WM][2 kinds][TN]
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = acc[mi][ni][r];
@@ -279,29 +274,36 @@ __global__ __launch_bounds__(NT_THREADS, (STAGES <= 2 ? 2 : 1)) void conv_gemm_n
       s += __shfl_xor(s, 32, 64);
       q += __shfl_xor(q, 32, 64);
       if (l < 16) {
-        sh[(wr * 2 + 0) * 128 + wc * 64 + ni * 16 + l] = s;
-        sh[(wr * 2 + 1) * 128 + wc * 64 + ni * 16 + l] = q;
+        shs[(wr * 2 + 0) * TN + wc * (NI * 16) + ni * 16 + l] = s;
+        shs[(wr * 2 + 1) * TN + wc * (NI * 16) + ni * 16 + l] = q;
       }
     }
     __syncthreads();
-    {
-      const int kind = tid >> 7, n = tid & 127;
-      if (n0 + n < N) pr.stats[((long)tm * 2 + kind) * N + n0 + n] = sh[(0 * 2 + kind) * 128 + n] + sh[(1 * 2 + kind) * 128 + n];
+    constexpr int SLABS = TM / 128;
+    for (int i = tid; i < SLABS * 2 * TN; i += 64 * NW) {
+      const int n = i % TN, kind = (i / TN) & 1, slab = i / (2 * TN);
+      const int grow = tm * SLABS + slab;       // global 128-row slab index
+      if (n0 + n < N && grow * 128 < M) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < WPS; ++k) v += shs[((slab * WPS + k) * 2 + kind) * TN + n];
+        pr.stats[((long)grow * 2 + kind) * N + n0 + n] = v;
+      }
     }
   }
 
   T* __restrict__ Cg = (T*)pr.C;
   T* __restrict__ C2g = (T*)pr.C2;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wr * 64 + mi * 16 + (l >> 4) * 4 + r;
+      const int m = m0 + wr * (MI * 16) + mi * 16 + (l >> 4) * 4 + r;
       if (m >= M) continue;
       const float* grow = pr.gate ? pr.gate + (long)(m / pr.Lout) * pr.ldg : nullptr;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wc * 64 + ni * 16 + (l & 15);
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wc * (NI * 16) + ni * 16 + (l & 15);
         if (n >= N) continue;
         float v = acc[mi][ni][r];
         if (pr.bias) v += pr.bias[n];
@@ -319,13 +321,12 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_nt: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_nt: bad dtype %d", dtype);
   const int ch = dtype == DRN_BF16 ? 8 : 4;
-  GemmParams P;
-  memset(&P, 0, sizeof(P));
-  P.ngroups = ngroups;
-  int total = 0;
+  // Tile choice: 256x256 (8 waves) when every group is large enough to keep the chip busy with such tiles,
+  // else 128x128.  DRN_NT_TILE=128|256 overrides (tests exercise both).
+  long big_tiles = 0;
+  bool fast = true;
   for (int g = 0; g < ngroups; ++g) {
     const DrnGemmDesc& s = d[g];
-    GemmProb& p = P.p[g];
     DRN_CHECK_ARG(s.A && s.B && s.C, "drn_gemm_nt: null operand in group %d", g);
     DRN_CHECK_ARG(s.M > 0 && s.N > 0 && s.Cin > 0 && s.taps >= 1 && s.stride >= 1, "drn_gemm_nt: bad dims in group %d", g);
     DRN_CHECK_ARG(s.Cin % ch == 0 && s.lda % ch == 0 && s.ldb % ch == 0,
@@ -333,40 +334,51 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
                   s.Cin, s.lda, s.ldb);
     DRN_CHECK_ARG(((uintptr_t)s.A & 15) == 0 && ((uintptr_t)s.B & 15) == 0, "drn_gemm_nt: A/B must be 16-byte aligned");
     DRN_CHECK_ARG(s.Lout > 0 && s.Lsrc > 0 && s.M % s.Lout == 0, "drn_gemm_nt: M=%d not a multiple of Lout=%d", s.M, s.Lout);
+    big_tiles += (long)cdiv(s.M, 256) * cdiv(s.N, 256);
+    if (s.Cin % (8 * ch) != 0 || (s.mode == 1 && s.stride > 2)) fast = false;
+  }
+  int tile = big_tiles >= 200 ? 256 : 128;
+  if (const char* e = getenv("DRN_NT_TILE")) tile = atoi(e) == 256 ? 256 : 128;
+  if (getenv("DRN_NT_GENERIC")) fast = false;
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  P.ngroups = ngroups;
+  int total = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const DrnGemmDesc& s = d[g];
+    GemmProb& p = P.p[g];
     p.A = s.A; p.B = s.B; p.C = s.C; p.C2 = s.C2; p.bias = s.bias; p.gate = s.gate; p.stats = s.stats;
     p.M = s.M; p.N = s.N; p.K = s.taps * s.Cin; p.Cin = s.Cin; p.taps = s.taps; p.stride = s.stride; p.pad = s.pad;
     p.mode = s.mode; p.Lout = s.Lout; p.Lsrc = s.Lsrc; p.lda = s.lda; p.ldb = s.ldb; p.ldc = s.ldc; p.ldg = s.ldg; p.ldc2 = s.ldc2;
     p.accumulate = s.accumulate;
-    p.tiles_n = cdiv(s.N, TILE);
+    p.tiles_n = cdiv(s.N, tile);
     p.tile_start = total;
-    total += cdiv(s.M, TILE) * p.tiles_n;
+    total += cdiv(s.M, tile) * p.tiles_n;
   }
-  // Pipeline depth: 2 stages leave room for two workgroups per CU (best when the grid oversubscribes the chip);
-  // 4 stages (one workgroup per CU) hide HBM/L2 latency inside a single workgroup, which is what the small
-  // pyramid-level GEMMs need.  DRN_NT_STAGES overrides for experiments.
-  int stages = total > 2 * 256 ? 2 : 4;
-  if (const char* e = getenv("DRN_NT_STAGES")) stages = atoi(e);
-  bool fast = true;
-  for (int g = 0; g < ngroups; ++g) {
-    const int bk = 8 * ch;
-    if (d[g].Cin % bk != 0 || (d[g].mode == 1 && d[g].stride > 2)) fast = false;
-  }
-  if (getenv("DRN_NT_GENERIC")) fast = false;
+  // Pipeline depth for the 128x128 tile: 2 stages leave room for two workgroups per CU (best when the grid
+  // oversubscribes the chip); 4 stages (one workgroup per CU) otherwise.  DRN_NT_STAGES overrides for experiments.
+  int stages = total > 256 ? 2 : 4;
+  if (const char* e = getenv("DRN_NT_STAGES")) stages = atoi(e) == 2 ? 2 : 4;
+  if (tile == 256) stages = 2;
   static bool attr_set = false;
   if (!attr_set) {
-#define NT_ATTR(TT, SS) \
-    (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SS * STAGE_BYTES); \
-    (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SS * STAGE_BYTES)
-    NT_ATTR(float, 2); NT_ATTR(bf16_t, 2); NT_ATTR(float, 4); NT_ATTR(bf16_t, 4);
+#define NT_ATTR(TT, SS, ...) \
+    (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+    (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)
+    NT_ATTR(float, 2, 2, 2, 4, 4); NT_ATTR(bf16_t, 2, 2, 2, 4, 4); NT_ATTR(float, 4, 2, 2, 4, 4); NT_ATTR(bf16_t, 4, 2, 2, 4, 4);
+    NT_ATTR(float, 2, 2, 4, 8, 4); NT_ATTR(bf16_t, 2, 2, 4, 8, 4);
 #undef NT_ATTR
     attr_set = true;
   }
-#define NT_LAUNCH(TT, SS) do { if (fast) conv_gemm_nt_kernel<TT, SS, true><<<total, NT_THREADS, SS * STAGE_BYTES, stream>>>(P); \
-                               else conv_gemm_nt_kernel<TT, SS, false><<<total, NT_THREADS, SS * STAGE_BYTES, stream>>>(P); } while (0)
-  if (dtype == DRN_BF16) {
-    if (stages == 2) NT_LAUNCH(bf16_t, 2); else NT_LAUNCH(bf16_t, 4);
+#define NT_LAUNCH(TT, SS, THREADS, LDS, ...) do { \
+    if (fast) conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__><<<total, THREADS, LDS, stream>>>(P); \
+    else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<total, THREADS, LDS, stream>>>(P); } while (0)
+  if (tile == 256) {
+    if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 65536, 2, 4, 8, 4); else NT_LAUNCH(float, 2, 512, 2 * 65536, 2, 4, 8, 4);
+  } else if (dtype == DRN_BF16) {
+    if (stages == 2) NT_LAUNCH(bf16_t, 2, 256, 2 * 32768, 2, 2, 4, 4); else NT_LAUNCH(bf16_t, 4, 256, 4 * 32768, 2, 2, 4, 4);
   } else {
-    if (stages == 2) NT_LAUNCH(float, 2); else NT_LAUNCH(float, 4);
+    if (stages == 2) NT_LAUNCH(float, 2, 256, 2 * 32768, 2, 2, 4, 4); else NT_LAUNCH(float, 4, 256, 4 * 32768, 2, 2, 4, 4);
   }
 #undef NT_LAUNCH
   return drn_launch_status("drn_gemm_nt");
