@@ -13,12 +13,10 @@
 // or 32 (f32) so one wave-instruction of global_load_lds fills 1 KB of it linearly.
 // The row range (all groups concatenated) is split over gridDim.z; partial tiles go to an fp32
 // workspace and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/drn_hip.h"
 
-#define TILE 128
-#define TN_THREADS 256
-#define STAGE_BYTES 32768
 
 
 struct WgradGroup {
@@ -61,18 +59,19 @@ template <> struct TnMma<bf16_t> {
     u.s.b = hi;
     return u.v;
   }
-  static __device__ __forceinline__ void compute(const char* Ys, const char* Xs, int wr, int wc, int l, f32x4 (&acc)[4][4]) {
+  template <int MI, int NI>
+  static __device__ __forceinline__ void compute(const char* Ys, const char* Xs, int wr, int wc, int l, f32x4 (&acc)[MI][NI]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
+      bf16x8 a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) a[mi] = frag(Ys, wr * 4 + mi, ks, l);
+      for (int mi = 0; mi < MI; ++mi) a[mi] = frag(Ys, wr * MI + mi, ks, l);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b[ni] = frag(Xs, wc * 4 + ni, ks, l);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = frag(Xs, wc * NI + ni, ks, l);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
   }
@@ -81,36 +80,42 @@ template <> struct TnMma<bf16_t> {
 template <> struct TnMma<float> {
   static constexpr int R = 32;
   // image: [cb][r][16 cols] f32, 64 B per row piece.  One stage = 8 MFMA k-steps of 4 rows.
-  static __device__ __forceinline__ void compute(const char* Ys, const char* Xs, int wr, int wc, int l, f32x4 (&acc)[4][4]) {
+  template <int MI, int NI>
+  static __device__ __forceinline__ void compute(const char* Ys, const char* Xs, int wr, int wc, int l, f32x4 (&acc)[MI][NI]) {
     const int g = l >> 4, i = l & 15;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      float a[4], b[4];
+      float a[MI], b[NI];
       const int off = (ks * 4 + g) * 64 + i * 4;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) a[mi] = *(const float*)(Ys + (wr * 4 + mi) * 2048 + off);
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const float*)(Ys + (wr * MI + mi) * 2048 + off);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b[ni] = *(const float*)(Xs + (wc * 4 + ni) * 2048 + off);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const float*)(Xs + (wc * NI + ni) * 2048 + off);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const WgradParams P) {
+// Tile: WM x WN waves of MI x NI MFMA tiles -> TNn = WM*MI*16 output channels x TC = WN*NI*16 input channels.
+//   <2,2,4,4> 128x128 (4 waves, 2 workgroups/CU)   <2,4,8,4> 256x256 (8 waves) for the 4096x4096 prop_fc gradient.
+template <typename T, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const WgradParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = TnMma<T>::R;
+  constexpr int NW = WM * WN, TNn = WM * MI * 16, TC = WN * NI * 16;
+  constexpr int IMG_Y = TNn * 128, IMG_X = TC * 128, STAGE_B = IMG_Y + IMG_X;   // bytes (R rows x 2 B or 32 rows x 4 B = 128 B/col)
+  static_assert(TNn == TC && TNn * 128 == NW * 4 * 1024, "square tiles, 4 one-KB staging pieces per wave and operand");
   constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int CPR = (int)sizeof(T);       // 16-byte chunks per 16-column row piece
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int tn = blockIdx.x;                // 128-wide block of output channels n
   const int tap = blockIdx.y / P.ctiles;
-  const int c0 = (blockIdx.y - tap * P.ctiles) * TILE;
-  const int n0 = tn * TILE;
+  const int c0 = (blockIdx.y - tap * P.ctiles) * TC;
+  const int n0 = tn * TNn;
   const int split = blockIdx.z;
   const int blk_lo = split * P.blks_per_split;
   const int blk_hi = min(blk_lo + P.blks_per_split, P.total_blks);
@@ -150,8 +155,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const Wgra
 
   // branch-free: masked lanes read the zero page; every thread issues exactly 8 global_load_lds per block
   auto stage = [&](int buf) {
-    char* Ys = smem + buf * STAGE_BYTES;
-    char* Xs = Ys + 16384;
+    char* Ys = smem + buf * STAGE_B;
+    char* Xs = Ys + IMG_Y;
     const bool live = s_blk < blk_hi;
     const WgradGroup& G = P.g[s_g];
     const int mbase = (s_blk - G.blk_start) * R;
@@ -187,12 +192,12 @@ __global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const Wgra
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int wr = w >> 1, wc = w & 1;
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wr = w / WN, wc = w % WN;
 
   // 2-deep ring, one barrier per row block: wait for block b, barrier (everyone also finished block b-1), issue b+1
   // into the slot b-1 used, compute b.
@@ -203,8 +208,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const Wgra
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stage(cur ^ 1);
-    const char* Ys = smem + cur * STAGE_BYTES;
-    TnMma<T>::compute(Ys, Ys + 16384, wr, wc, l, acc);
+    const char* Ys = smem + cur * STAGE_B;
+    TnMma<T>::template compute<MI, NI>(Ys, Ys + IMG_Y, wr, wc, l, acc);
     cur ^= 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -212,14 +217,14 @@ __global__ __launch_bounds__(TN_THREADS, 2) void conv_wgrad_tn_kernel(const Wgra
   // epilogue: acc[mi][ni][r] -> n = n0 + wr*64 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*64 + ni*16 + (l&15)
   const int KW = P.taps * P.Cin;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wr * 64 + mi * 16 + (l >> 4) * 4 + r;
+      const int n = n0 + wr * (MI * 16) + mi * 16 + (l >> 4) * 4 + r;
       if (n >= P.N) continue;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int c = c0 + wc * 64 + ni * 16 + (l & 15);
+      for (int ni = 0; ni < NI; ++ni) {
+        const int c = c0 + wc * (NI * 16) + ni * 16 + (l & 15);
         if (c >= P.Cin) continue;
         float v = acc[mi][ni][r];
         if (P.direct) {
@@ -254,9 +259,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+// 256x256 tiles only when they alone fill half the chip (the 4096x4096 prop_fc gradient: 256 tiles)
+static int wgrad_tile(int N, int Cin, int taps) {
+  if (const char* e = getenv("DRN_TN_TILE")) return atoi(e) == 256 ? 256 : 128;
+  return (long)cdiv(N, 256) * taps * cdiv(Cin, 256) >= 128 ? 256 : 128;
+}
+
 static int wgrad_nsplit(int total_blks, int N, int Cin, int taps) {
-  const int tiles = cdiv(N, TILE) * taps * cdiv(Cin, TILE);
-  int ns = cdiv(768, tiles);            // aim for ~3 workgroups per CU
+  const int tile = wgrad_tile(N, Cin, taps);
+  const int tiles = cdiv(N, tile) * taps * cdiv(Cin, tile);
+  int ns = cdiv(tile == 256 ? 256 : 768, tiles);   // ~1 (8-wave) or ~3 (4-wave) workgroups per CU
   if (ns > total_blks) ns = total_blks;
   if (ns < 1) ns = 1;
   if (ns > 64) ns = 64;
@@ -305,22 +317,28 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
   P.blks_per_split = cdiv(blks, ns);
   ns = cdiv(blks, P.blks_per_split);
   P.N = N; P.Cin = Cin; P.taps = taps; P.stride = stride; P.pad = pad;
-  P.ctiles = cdiv(Cin, TILE);
+  const int tile = wgrad_tile(N, Cin, taps);
+  P.ctiles = cdiv(Cin, tile);
   P.direct = ns == 1;
   P.out = P.direct ? dW : ws;
   P.w_layout = w_layout;
   P.accumulate = accumulate;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float, 2, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
-  dim3 grid(cdiv(N, TILE), taps * P.ctiles, ns);
-  if (dtype == DRN_BF16)
-    conv_wgrad_tn_kernel<bf16_t><<<grid, TN_THREADS, 2 * STAGE_BYTES, stream>>>(P);
-  else
-    conv_wgrad_tn_kernel<float><<<grid, TN_THREADS, 2 * STAGE_BYTES, stream>>>(P);
+  dim3 grid(cdiv(N, tile), taps * P.ctiles, ns);
+  if (tile == 256) {
+    if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 4, 8, 4><<<grid, 512, 2 * 65536, stream>>>(P);
+    else conv_wgrad_tn_kernel<float, 2, 4, 8, 4><<<grid, 512, 2 * 65536, stream>>>(P);
+  } else {
+    if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+    else conv_wgrad_tn_kernel<float, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+  }
   int rc = drn_launch_status("drn_gemm_wgrad");
   if (rc) return rc;
   if (!P.direct) {
