@@ -38,6 +38,8 @@ struct GemmProb {
 };
 struct GemmParams {
   int ngroups;
+  int ksplit;       // > 1: gridDim.y splits of the K loop, raw fp32 partial tiles go to `ws` (single group only)
+  float* ws;        // [ksplit][M][N]
   GemmProb p[DRN_MAX_GROUPS];
 };
 
@@ -141,9 +143,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     pB[i] = Bg + ((long)(n < N ? n : 0) * pr.ldb + coff);
   }
 
-  // tiles are staged strictly in order; these advance by one tile per stage() call
-  int s_kt = 0, s_tap = 0, s_c0 = 0;
-  const int nkt = (K + BK - 1) / BK;
+  // tiles are staged strictly in order; these advance by one tile per stage() call.  Split-K: this workgroup owns
+  // K-tiles [kt_lo, nkt) of the problem.
+  const int nkt_all = (K + BK - 1) / BK;
+  const int kt_per = (nkt_all + P.ksplit - 1) / P.ksplit;
+  const int kt_lo = (int)blockIdx.y * kt_per;
+  const int nkt = min(nkt_all, kt_lo + kt_per);
+  int s_kt = kt_lo, s_tap = 0, s_c0 = 0;
+  if (FAST && kt_lo > 0) {
+    s_tap = (kt_lo * BK) / Cin;
+    s_c0 = kt_lo * BK - s_tap * Cin;
+  }
 
   // Every thread issues exactly 8 global_load_lds per tile (the counted vmcnt below depends on it); masked lanes and
   // past-the-end tiles read the zero page.
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st) stage(st);
   int cur = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt_lo; kt < nkt; ++kt) {
     // each thread issues 8 loads per tile; tiles kt+1 .. kt+STAGES-2 may still be in flight
     if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -252,6 +262,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   __syncthreads();
 
   // ---- epilogue.  acc[mi][ni][r]: m = wr*MI*16 + mi*16 + (l>>4)*4 + r, n = wc*NI*16 + ni*16 + (l&15)
+  if (P.ksplit > 1) {   // raw partial tile; bias / gate / stats / conversion happen in splitk_reduce_kernel
+    float* wsp = P.ws + (long)blockIdx.y * M * N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wr * (MI * 16) + mi * 16 + (l >> 4) * 4 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int n = n0 + wc * (NI * 16) + ni * 16 + (l & 15);
+          if (n < N) wsp[(long)m * N + n] = acc[mi][ni][r];
+        }
+      }
+    return;
+  }
   if (pr.stats) {
     // Column sums of the raw fp32 accumulators per 128-row slab (rows >= M contribute exact zeros):
     // stats[(slab*2 + kind)*N + n], slab = m / 128, whatever the tile shape.
@@ -317,7 +343,67 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   }
 }
 
-static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream) {
+// Sum the split-K partial tiles in a fixed order and run the epilogue the GEMM skipped: bias, pre-gate copy, gate,
+// accumulate, conversion, per-128-row-slab column sums for BatchNorm.  grid (ceil(N/64), ceil(M/128)), 256 threads =
+// 16 column quads x 16 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, const GemmProb pr) {
+  __shared__ float red[2][16][65];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + cx * 4;
+  const int M = pr.M, N = pr.N;
+  const int mbase = blockIdx.y * 128;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  T* Cg = (T*)pr.C;
+  T* C2g = (T*)pr.C2;
+  if (n < N) {
+    for (int r = ry; r < 128; r += 16) {
+      const int m = mbase + r;
+      if (m >= M) break;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < ksplit; ++z) {
+        const float* p = ws + ((long)z * M + m) * N + n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (n + k < N) v[k] += p[k];
+      }
+      const float* grow = pr.gate ? pr.gate + (long)(m / pr.Lout) * pr.ldg : nullptr;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (n + k >= N) continue;
+        cs[k] += v[k];
+        cq[k] = fmaf(v[k], v[k], cq[k]);
+        float o = v[k];
+        if (pr.bias) o += pr.bias[n + k];
+        if (C2g) DT<T>::st(C2g + ((long)m * pr.ldc2 + n + k), o);
+        if (grow) o *= grow[n + k];
+        const long off = (long)m * pr.ldc + n + k;
+        if (pr.accumulate) o += DT<T>::ld(Cg + off);
+        DT<T>::st(Cg + off, o);
+      }
+    }
+  }
+  if (pr.stats) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[0][ry][cx * 4 + k] = cs[k];
+      red[1][ry][cx * 4 + k] = cq[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int kind = threadIdx.x >> 6, c = threadIdx.x & 63;
+      const int nn = blockIdx.x * 64 + c;
+      if (nn < N && mbase < M) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[kind][r][c];
+        pr.stats[((long)blockIdx.y * 2 + kind) * N + nn] = t;
+      }
+    }
+  }
+}
+
+static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr) {
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_nt: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_nt: bad dtype %d", dtype);
   const int ch = dtype == DRN_BF16 ? 8 : 4;
@@ -343,6 +429,9 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   GemmParams P;
   memset(&P, 0, sizeof(P));
   P.ngroups = ngroups;
+  P.ksplit = ksplit;
+  P.ws = ws;
+  if (ksplit > 1) tile = 128;
   int total = 0;
   for (int g = 0; g < ngroups; ++g) {
     const DrnGemmDesc& s = d[g];
@@ -357,7 +446,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   }
   // Pipeline depth for the 128x128 tile: 2 stages leave room for two workgroups per CU (best when the grid
   // oversubscribes the chip); 4 stages (one workgroup per CU) otherwise.  DRN_NT_STAGES overrides for experiments.
-  int stages = total > 256 ? 2 : 4;
+  int stages = (long)total * ksplit > 256 ? 2 : 4;
   if (const char* e = getenv("DRN_NT_STAGES")) stages = atoi(e) == 2 ? 2 : 4;
   if (tile == 256) stages = 2;
   static bool attr_set = false;
@@ -371,8 +460,8 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     attr_set = true;
   }
 #define NT_LAUNCH(TT, SS, THREADS, LDS, ...) do { \
-    if (fast) conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__><<<total, THREADS, LDS, stream>>>(P); \
-    else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<total, THREADS, LDS, stream>>>(P); } while (0)
+    if (fast) conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); \
+    else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
   if (tile == 256) {
     if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 65536, 2, 4, 8, 4); else NT_LAUNCH(float, 2, 512, 2 * 65536, 2, 4, 8, 4);
   } else if (dtype == DRN_BF16) {
@@ -381,10 +470,21 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     if (stages == 2) NT_LAUNCH(float, 2, 256, 2 * 32768, 2, 2, 4, 4); else NT_LAUNCH(float, 4, 256, 4 * 32768, 2, 2, 4, 4);
   }
 #undef NT_LAUNCH
+  if (ksplit > 1) {
+    dim3 rg(cdiv(P.p[0].N, 64), cdiv(P.p[0].M, 128));
+    if (dtype == DRN_BF16) splitk_reduce_kernel<bf16_t><<<rg, 256, 0, stream>>>(ws, ksplit, P.p[0]);
+    else splitk_reduce_kernel<float><<<rg, 256, 0, stream>>>(ws, ksplit, P.p[0]);
+  }
   return drn_launch_status("drn_gemm_nt");
 }
 
 extern "C" int drn_gemm_nt(const DrnGemmDesc* descs, int ngroups, int dtype, void* stream) {
   drn_clear_status();
   return launch_nt(descs, ngroups, dtype, (hipStream_t)stream);
+}
+
+extern "C" int drn_gemm_nt_splitk(const DrnGemmDesc* desc, int ksplit, float* ws, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(desc && ksplit >= 1 && ksplit <= 64 && (ksplit == 1 || ws), "drn_gemm_nt_splitk: bad ksplit/workspace");
+  return launch_nt(desc, 1, dtype, (hipStream_t)stream, ksplit, ws);
 }

@@ -51,6 +51,9 @@ def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Ls
 # Optional per-launch timing of the MFMA kernels (bench.py): a list collecting (tag, flops, start_event, end_event),
 # the events recorded on the same stream the kernels run on.
 kernel_timer = None
+# Split-K of under-filled NT GEMMs is implemented (drn_gemm_nt_splitk) but OFF by default: on MI355X it bought 0.4 % of a
+# step (those launches are bound by operand traffic, not by idle CUs) while changing the fp32 summation order.
+SPLITK = __import__("os").environ.get("DRN_SPLITK", "0") == "1"
 
 
 def _timed(tag, flops, launch):
@@ -63,9 +66,27 @@ def _timed(tag, flops, launch):
     kernel_timer.append((tag, flops, e0, e1))
 
 
+def _ksplit(d, dtype):
+    """Split-K factor for a single problem that cannot fill 256 CUs with 128x128 tiles."""
+    tiles = ((d.M + 127) // 128) * ((d.N + 127) // 128)
+    nkt = (d.taps * d.Cin) // (64 if dtype == BF16 else 32)
+    if tiles > 160 or nkt < 12:
+        return 1
+    return max(1, min(8, 512 // tiles, nkt // 6))
+
+
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
+    if len(descs) == 1 and SPLITK:
+        ks = _ksplit(descs[0], dtype)
+        if ks > 1:
+            d0 = descs[0]
+            ws = torch.empty(ks * d0.M * d0.N, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            tag = "gemm_nt[%s] g=1 M=%d N=%d K=%d mode=%d splitK=%d" % ("bf16" if dtype == BF16 else "f32", d0.M, d0.N,
+                                                                        d0.taps * d0.Cin, d0.mode, ks)
+            return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk(arr, ks, _p(ws), dtype, _stream()),
+                                                    "drn_gemm_nt_splitk"))
     d0 = descs[0]
     tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=%d" % ("bf16" if dtype == BF16 else "f32", len(descs),
                                                       sum(d.M for d in descs), d0.N, d0.taps * d0.Cin, d0.mode)

@@ -60,6 +60,9 @@ typedef struct DrnGemmDesc {
  * Replaces nn.Linear (model/main_model.py:59), nn.Conv1d (model/basic_blocks.py:9,
  * model/fcos.py:33,37,59,65) forward and their input gradients. */
 int drn_gemm_nt(const DrnGemmDesc* descs /*host*/, int ngroups, int dtype, void* stream);
+/* Same for ONE problem with the K loop split `ksplit` ways (few output tiles, long K: conv0, the coarse pyramid levels):
+ * partial tiles go to ws (fp32, ksplit*M*N elements) and a deterministic reduce pass applies the epilogue. */
+int drn_gemm_nt_splitk(const DrnGemmDesc* desc /*host*/, int ksplit, float* ws, int dtype, void* stream);
 
 /* Weight gradient:  dW[n][tap][c] (fp32) = sum_m dY[m][n] * X[src(m,tap)][c]   (mode-0 addressing of X).
  * dW is written as [N][taps][Cin] when w_layout==0 or [N][Cin][taps] (the nn.Conv1d parameter layout) when 1.

@@ -194,3 +194,34 @@ def test_wgrad_grouped_levels(dt):
     ops.gemm_wgrad(descs, dW, Cout, Cin, taps=3, pad=1, w_layout=1, dtype=ops.dtype_code(keep[0][0]))
     torch.cuda.synchronize()
     close(dW, w.grad, TOL[dt] * 2, "grouped wgrad")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("ksplit", [2, 5])
+def test_conv_fwd_splitk_with_stats_bias_gate(dt, ksplit):
+    """drn_gemm_nt_splitk: K loop split over workgroups, deterministic reduce pass runs the epilogue."""
+    import ctypes
+    from drn_amd import ops, _lib
+    B, L, Cin, Cout, k = 3, 40, 192, 136, 3
+    x, w = conv_case(dt, B, L, Cin, Cout, k, 1)
+    ref = F.conv1d(x.double(), w.double(), padding=1).permute(0, 2, 1).reshape(B * L, Cout)
+    bias = rnd((Cout,), 3, torch.float32)
+    gate = rnd((B, Cout), 4, torch.float32)
+    M = B * L
+    xd, wp = nlc(x).to(dev()), w.permute(0, 2, 1).contiguous().to(dev())
+    C = torch.full((M, Cout), float("nan"), dtype=DT[dt], device=dev())
+    C2 = torch.full((M, Cout), float("nan"), dtype=DT[dt], device=dev())
+    stats = torch.full(((M + 127) // 128, 2, Cout), float("nan"), dtype=torch.float32, device=dev())
+    d = ops.gemm_desc(xd, wp, C, M, Cout, Cin, taps=k, pad=1, Lout=L, Lsrc=L, stats=stats, bias=bias.to(dev()),
+                      gate=gate.to(dev()), ldg=Cout, C2=C2)
+    ws = torch.empty(ksplit * M * Cout, dtype=torch.float32, device=dev())
+    arr = (_lib.GemmDesc * 1)(d)
+    _lib.check(_lib.lib().drn_gemm_nt_splitk(arr, ksplit, ctypes.c_void_p(ws.data_ptr()), ops.dtype_code(xd),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "splitk")
+    torch.cuda.synchronize()
+    pre = ref + bias.double()
+    close(C2, pre, TOL[dt] * 2, "pre-gate")
+    close(C, pre * gate.double().repeat_interleave(L, 0), TOL[dt] * 2, "gated")
+    st = stats.double().cpu().sum(0)
+    close(st[0], ref.sum(0), TOL[dt] * 4, "col sum (raw conv)")
+    close(st[1], (ref * ref).sum(0), TOL[dt] * 4, "col sumsq")
