@@ -127,15 +127,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
     run, mode = step, "eager"
     if args.graph:
+        # all warm-up steps run on the capture stream (see drn_amd/graph.py), then the step is captured once
         from drn_amd.graph import GraphedStep
         try:
             if world == 1:
                 # the whole step (query encoder, HIP path forward+backward, fused clip+Adam) replays as ONE hipGraph
-                run = GraphedStep(step, warmup=2).capture()
+                run = GraphedStep(step, warmup=max(args.warmup, 2)).capture()
                 mode = "hipGraph replay of the full step"
             else:
                 # forward+backward replay as one hipGraph per rank; RCCL all-reduce + fused optimizer stay outside it
@@ -144,14 +143,17 @@ def main():
                     _, losses = model(*batch)
                     loss_of(losses).backward()
                     return losses
-                core = GraphedStep(fwd_bwd, warmup=2).capture()
+                core = GraphedStep(fwd_bwd, warmup=0)
 
                 def run():
                     losses = core()
-                    for b_ in reducer.buckets:        # re-arm: hooks only ran at capture time
+                    for b_ in reducer.buckets:        # re-arm: hooks only run eagerly / at capture time
                         b_.launched, b_.handle = False, None
                     opt_step()
                     return losses
+                for _ in range(max(args.warmup, 2)):
+                    run()
+                core.capture()
                 mode = "hipGraph replay of forward+backward; RCCL all-reduce + optimizer eager"
             run()
         except Exception as e:                                          # keep the eager path measurable
@@ -159,6 +161,9 @@ def main():
             torch.cuda.synchronize()
             reducer.overlap = True
             run, mode = step, "eager (capture failed)"
+    else:
+        for _ in range(args.warmup):
+            step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
