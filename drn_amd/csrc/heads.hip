@@ -191,14 +191,22 @@ __global__ __launch_bounds__(256) void head_out_bwd_w_kernel(const HeadParams P,
     }
 }
 
-// dW[n][c][tap] (+)= sum_blk partial[blk][n][tap][c]
-__global__ void head_out_bwd_w_final_kernel(const float* __restrict__ partial, int nblk, int N, int C, int taps, float* __restrict__ dW,
-                                            int accumulate) {
+// dW[n][c][tap] (+)= sum_blk partial[blk][n][tap][c];  256 threads = 16 outputs x 16 lanes over the partial blocks
+__global__ __launch_bounds__(256) void head_out_bwd_w_final_kernel(const float* __restrict__ partial, int nblk, int N, int C, int taps,
+                                                                   float* __restrict__ dW, int accumulate) {
+  __shared__ float sh[16][17];
   const int total = N * taps * C;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+  const int oi = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + oi;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(long)b * total + i];
+  if (i < total)
+    for (int b = j; b < nblk; b += 16) s += partial[(long)b * total + i];
+  sh[oi][j] = s;
+  __syncthreads();
+  if (j != 0 || i >= total) return;
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += sh[oi][k];
   const int c = i % C, tn = i / C, tap = tn % taps, n = tn / taps;
   float* dst = dW + ((long)n * C + c) * taps + tap;
   *dst = accumulate ? *dst + s : s;
@@ -280,7 +288,7 @@ extern "C" int drn_head_out_fwd(const DrnHeadGroup* groups, int ngroups, const f
 
 extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const float* W, const float* dout, const float* out,
                                 const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
-                                float* dscale, int accumulate_dw, float* ws /* >= R*N + 128*N*taps*C floats */, int dtype,
+                                float* dscale, int accumulate_dw, float* ws /* >= R*N + 64 + 256*N*taps*C floats */, int dtype,
                                 void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
@@ -291,7 +299,7 @@ extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const f
   float* dz = ws;
   float* part = ws + (((long)P.total_rows * N + 63) / 64) * 64;
   const size_t shm = (size_t)N * taps * C * sizeof(float);
-  const int nblk = P.total_rows >= 128 * 16 ? 128 : (P.total_rows >= 16 ? P.total_rows / 16 : 1);
+  const int nblk = P.total_rows >= 256 * 16 ? 256 : (P.total_rows >= 16 ? P.total_rows / 16 : 1);
   head_out_bwd_pre_kernel<<<1, 1024, 0, stream>>>(P, dout, out, z, dz, dbias, dscale, accumulate_dw);
   DISPATCH_DT(dtype, "drn_head_out_bwd", {
     constexpr int VN = V16<T>::N;
@@ -299,6 +307,6 @@ extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const f
     dim3 grid(cdiv(C / VN, 64), nblk);
     head_out_bwd_w_kernel<T><<<grid, 256, 0, stream>>>(P, dz, part);
   });
-  head_out_bwd_w_final_kernel<<<cdiv(N * taps * C, 256), 256, 0, stream>>>(part, nblk, N, C, taps, dW, accumulate_dw);
+  head_out_bwd_w_final_kernel<<<cdiv(N * taps * C, 16), 256, 0, stream>>>(part, nblk, N, C, taps, dW, accumulate_dw);
   return drn_launch_status("drn_head_out_bwd");
 }

@@ -83,14 +83,15 @@ __device__ __forceinline__ bool assign_label(const LossParams& P, const Loc& q, 
   return mn > 0.f && mx >= P.lo[q.level] && mx <= P.hi[q.level];
 }
 
-// out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ; out[4] = n_iou_pos ; labels[r] (optional) for inspection
-__global__ __launch_bounds__(LOSS_THREADS) void fcos_loss_fwd_kernel(const LossParams P, const float* __restrict__ logits,
-                                                                     const float* __restrict__ reg, const float* __restrict__ iou,
-                                                                     const float* __restrict__ gt, float* __restrict__ out,
-                                                                     float* __restrict__ labels) {
+// Phase 1: one location per thread, per-block partial sums partial[blk][5] = {focal, iou-loss, smooth-l1, n_pos, n_iou}.
+__global__ __launch_bounds__(256) void fcos_loss_fwd_partial_kernel(const LossParams P, const float* __restrict__ logits,
+                                                                    const float* __restrict__ reg, const float* __restrict__ iou,
+                                                                    const float* __restrict__ gt, float* __restrict__ partial,
+                                                                    float* __restrict__ labels) {
   __shared__ float sh[17];
   float s_focal = 0.f, s_ioul = 0.f, s_sl1 = 0.f, n_pos = 0.f, n_iou = 0.f;
-  for (int r = threadIdx.x; r < P.total_rows; r += LOSS_THREADS) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < P.total_rows) {
     const Loc q = locate(P, r);
     const float gs = gt[q.b * 2], ge = gt[q.b * 2 + 1];
     float tl, tr;
@@ -99,21 +100,21 @@ __global__ __launch_bounds__(LOSS_THREADS) void fcos_loss_fwd_kernel(const LossP
     const float x = logits[r];
     const float p = 1.f / (1.f + expf(-x));
     // -log(p) = softplus(-x), -log(1-p) = softplus(x)
-    if (pos) s_focal += P.alpha * powf(1.f - p, P.gamma) * softplus(-x);
-    else s_focal += (1.f - P.alpha) * powf(p, P.gamma) * softplus(x);
+    if (pos) s_focal = P.alpha * powf(1.f - p, P.gamma) * softplus(-x);
+    else s_focal = (1.f - P.alpha) * powf(p, P.gamma) * softplus(x);
     const float pl = reg[r * 2], prr = reg[r * 2 + 1];
     if (pos) {
-      n_pos += 1.f;
+      n_pos = 1.f;
       const float inter = fminf(prr, tr) + fminf(pl, tl);
       const float uni = (tl + tr) + (pl + prr) - inter;
-      s_ioul += -logf((inter + 1e-8f) / (uni + 1e-8f));
+      s_ioul = -logf((inter + 1e-8f) / (uni + 1e-8f));
     }
     if (P.iou_stage) {
       const IouTerm it = iou_term(P, q, pl, prr, gs, ge, iou[r]);
       if (it.masked) {
-        n_iou += 1.f;
+        n_iou = 1.f;
         const float ad = fabsf(it.d);
-        s_sl1 += ad < 1.f ? 0.5f * it.d * it.d : ad - 0.5f;
+        s_sl1 = ad < 1.f ? 0.5f * it.d * it.d : ad - 0.5f;
       }
     }
   }
@@ -123,11 +124,26 @@ __global__ __launch_bounds__(LOSS_THREADS) void fcos_loss_fwd_kernel(const LossP
   n_pos = block_sum(n_pos, sh);
   n_iou = block_sum(n_iou, sh);
   if (threadIdx.x == 0) {
-    out[0] = s_focal / (n_pos + (float)P.B);          // loss.py:213
-    out[1] = n_pos > 0.f ? s_ioul / n_pos : 0.f;       // loss.py:219-231
-    out[2] = n_iou > 0.f ? s_sl1 / n_iou : 0.f;        // loss.py:194-197
-    out[3] = n_pos;
-    out[4] = n_iou;
+    float* p = partial + (long)blockIdx.x * 5;
+    p[0] = s_focal; p[1] = s_ioul; p[2] = s_sl1; p[3] = n_pos; p[4] = n_iou;
+  }
+}
+
+// Phase 2 (one workgroup, fixed order): out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ; out[4] = n_iou_pos
+__global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ out) {
+  __shared__ float sh[17];
+  float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] += partial[(long)b * 5 + k];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) v[k] = block_sum(v[k], sh);
+  if (threadIdx.x == 0) {
+    out[0] = v[0] / (v[3] + (float)B);               // loss.py:213
+    out[1] = v[3] > 0.f ? v[1] / v[3] : 0.f;          // loss.py:219-231
+    out[2] = v[4] > 0.f ? v[2] / v[4] : 0.f;          // loss.py:194-197
+    out[3] = v[3];
+    out[4] = v[4];
   }
 }
 
@@ -202,13 +218,16 @@ static int fill_loss_params(LossParams& P, const DrnLossLevel* levels, int nleve
 
 extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg, const float* iou,
                                  const float* gt, float gamma, float alpha, float target_scale, int iou_stage, float* out5,
-                                 float* labels, void* stream) {
+                                 float* labels, float* ws, void* stream) {
   drn_clear_status();
   LossParams P;
   int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_fwd");
   if (rc) return rc;
   DRN_CHECK_ARG(logits && reg && gt && out5 && (!iou_stage || iou), "drn_fcos_loss_fwd: null pointer");
-  fcos_loss_fwd_kernel<<<1, LOSS_THREADS, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, out5, labels);
+  const int nblk = cdiv(P.total_rows, 256);
+  DRN_CHECK_ARG(ws, "drn_fcos_loss_fwd: workspace (5*ceil(R/256) floats) required");
+  fcos_loss_fwd_partial_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, ws, labels);
+  fcos_loss_fwd_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, nblk, B, out5);
   return drn_launch_status("drn_fcos_loss_fwd");
 }
 

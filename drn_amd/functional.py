@@ -466,8 +466,10 @@ class _BiLSTMFn(torch.autograd.Function):
         xproj = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
         torch.addmm((b_ih_f + b_hh_f).detach(), emb_tm, w_ih_f.detach().t(), out=xproj[0].view(L * B, 4 * H))
         torch.addmm((b_ih_r + b_hh_r).detach(), emb_tm, w_ih_r.detach().t(), out=xproj[1].view(L * B, 4 * H))
-        hseq = torch.zeros((2, L + 1, B, H), dtype=torch.float32, device=dev)
-        cseq = torch.zeros((2, L + 1, B, H), dtype=torch.float32, device=dev)
+        hseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
+        cseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
+        hseq[:, 0].zero_()
+        cseq[:, 0].zero_()
         gates = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
         out = torch.empty((B, L, 2 * H), dtype=torch.float32, device=dev)
         lens = lengths.to(torch.int32).contiguous()
@@ -475,6 +477,7 @@ class _BiLSTMFn(torch.autograd.Function):
         for s in range(L):
             ops.lstm_step_fwd(xproj, whf, whr, hseq, cseq, gates, out, lens, B, L, H, s)
         ctx.dims = (B, L, E, H)
+        ctx.param_refs = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.save_for_backward(emb_tm, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, hseq, cseq, gates)
         return out
 
@@ -494,12 +497,18 @@ class _BiLSTMFn(torch.autograd.Function):
         dgf, dgr = dgates[0].view(L * B, 4 * H), dgates[1].view(L * B, 4 * H)
         # the reverse direction's step s sits at time L-1-s
         emb_rev = emb_tm.view(L, B, E).flip(0).reshape(L * B, E)
-        dwih_f, dwih_r = dgf.t() @ emb_tm, dgr.t() @ emb_rev
-        dwhh_f = dgf.t() @ hseq[0, :L].reshape(L * B, H)
-        dwhh_r = dgr.t() @ hseq[1, :L].reshape(L * B, H)
-        db_f, db_r = dgf.sum(0), dgr.sum(0)
+        wihf, whhf, bihf, bhhf, wihr, whhr, bihr, bhhr = ctx.param_refs
+        # weight gradients go straight into the reducer's flat buckets when sinks are registered
+        dwih_f = torch.mm(dgf.t(), emb_tm, out=grad_buffer(wihf))
+        dwih_r = torch.mm(dgr.t(), emb_rev, out=grad_buffer(wihr))
+        dwhh_f = torch.mm(dgf.t(), hseq[0, :L].reshape(L * B, H), out=grad_buffer(whhf))
+        dwhh_r = torch.mm(dgr.t(), hseq[1, :L].reshape(L * B, H), out=grad_buffer(whhr))
+        db_f = torch.sum(dgf, 0, out=grad_buffer(bihf))
+        db_r = torch.sum(dgr, 0, out=grad_buffer(bihr))
+        db_f2 = grad_buffer(bhhf).copy_(db_f)
+        db_r2 = grad_buffer(bhhr).copy_(db_r)
         demb = (dgf @ w_ih_f).view(L, B, E) + (dgr @ w_ih_r).view(L, B, E).flip(0)
-        return demb.transpose(0, 1), None, dwih_f, dwhh_f, db_f, db_f, dwih_r, dwhh_r, db_r, db_r
+        return demb.transpose(0, 1), None, dwih_f, dwhh_f, db_f, db_f2, dwih_r, dwhh_r, db_r, db_r2
 
 
 def bilstm(emb, lengths, lstm):

@@ -59,10 +59,13 @@ class QueryEncoder(nn.Module):
         q_vector = torch.cat((output[:, 0], last), dim=-1)                # language_module.py:48-54
         base = F.relu(self.qInput(q_vector))
         pad = torch.arange(Lmax, device=output.device).view(1, Lmax) >= lengths.view(B, 1)
-        outputs = []
-        for t in range(3):                                                # language_module.py:27-36
-            q_cmd = getattr(self, "qInput%d" % t)(base)
-            raw_att = self.cmd_inter2logits(q_cmd[:, None, :] * output).squeeze(-1)
-            att = F.softmax(raw_att.masked_fill(pad, -1e30), dim=-1)
-            outputs.append(torch.bmm(att[:, None, :], output).squeeze(1))
-        return outputs
+        # language_module.py:27-36 for the three "commands" at once (same arithmetic, batched):
+        #   raw_att[b,t,l] = sum_c (q_cmd[b,t,c] * w[c]) * output[b,l,c] + bias  ==  cmd_inter2logits(q_cmd[:,None,:] * output)
+        W3 = torch.cat([getattr(self, "qInput%d" % t).weight for t in range(3)], dim=0)
+        b3 = torch.cat([getattr(self, "qInput%d" % t).bias for t in range(3)], dim=0)
+        q_cmd = F.linear(base, W3, b3).view(B, 3, H2)
+        raw_att = torch.baddbmm(self.cmd_inter2logits.bias.view(1, 1, 1), q_cmd * self.cmd_inter2logits.weight.view(1, 1, H2),
+                                output.transpose(1, 2))                  # (B, 3, Lmax)
+        att = F.softmax(raw_att.masked_fill(pad[:, None, :], -1e30), dim=-1)
+        cmds = torch.bmm(att, output)                                    # (B, 3, 2H)
+        return [cmds[:, t] for t in range(3)]

@@ -222,7 +222,7 @@ def head_out_fwd(groups, W, bias, N, C, taps, exp_mode, out, z, dtype):
 
 
 def head_out_bwd(groups, W, dout, out, z, N, C, taps, exp_mode, accumulate_dx, dW, dbias, dscale, R, dtype):
-    ws = workspace(R * N + 64 + 128 * N * taps * C, dW.device)
+    ws = workspace(R * N + 64 + 256 * N * taps * C, dW.device)
     check(lib().drn_head_out_bwd(groups, len(groups), _p(W), _p(dout), _p(out), _p(z), N, C, taps, int(exp_mode),
                                  int(accumulate_dx), _p(dW), _p(dbias), _p(dscale), 0, _p(ws), dtype, _stream()),
           "drn_head_out_bwd")
@@ -234,9 +234,10 @@ def loss_levels(levels):
 
 
 def fcos_loss_fwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, labels=None):
+    ws = workspace(5 * ((logits.shape[0] + 255) // 256), logits.device)
     check(lib().drn_fcos_loss_fwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
                                   ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(labels),
-                                  _stream()), "drn_fcos_loss_fwd")
+                                  _p(ws), _stream()), "drn_fcos_loss_fwd")
 
 
 def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, gin3, dlogits, dreg, diou):
