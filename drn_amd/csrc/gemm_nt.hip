@@ -320,6 +320,73 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
 
   T* __restrict__ Cg = (T*)pr.C;
   T* __restrict__ C2g = (T*)pr.C2;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const bool vec_ok = (pr.ldc % VEC == 0) && (((uintptr_t)Cg & 15) == 0) &&
+                      (!C2g || ((pr.ldc2 % VEC == 0) && (((uintptr_t)C2g & 15) == 0)));
+  if (vec_ok) {
+    // Coalesced epilogue: every wave transposes its 64-column slab through a private LDS patch, 32 rows at a time, and
+    // writes it out as 16-byte row segments (8 store instructions per wave and 64x64 bf16 tile instead of 64 two-byte
+    // ones -- the narrow stores were ~8 us of issue-bound tail per launch).
+    constexpr int PITCH = 64 * (int)sizeof(T) + 16;          // bytes per staged row (+16: conflict-free column writes)
+    constexpr int LPR = 64 * (int)sizeof(T) / 16;            // lanes per staged row in the 16-byte read-back
+    constexpr int RPI = 64 / LPR;                            // rows per read-back instruction
+    __syncthreads();                                         // stats (if any) are done with LDS
+    char* wbuf = smem + w * (32 * PITCH);
+    float bias_v[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wc * (NI * 16) + ni * 16 + (l & 15);
+      bias_v[ni] = (pr.bias && n < N) ? pr.bias[n] : 0.f;
+    }
+    const int npass = C2g ? 2 : 1;
+#pragma unroll
+    for (int ch = 0; ch < MI / 2; ++ch) {
+      const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
+      for (int pass = 0; pass < npass; ++pass) {
+        const bool gated = pr.gate && pass == npass - 1;
+        T* dst = (C2g && pass == 0) ? C2g : Cg;
+        const int ldd = (C2g && pass == 0) ? pr.ldc2 : pr.ldc;
+#pragma unroll
+        for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = mi2 * 16 + (l >> 4) * 4 + r;
+            const int m = mrow0 + rl;
+            const float* grow = (gated && m < M) ? pr.gate + (long)(m / pr.Lout) * pr.ldg : nullptr;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              float v = acc[ch * 2 + mi2][ni][r] + bias_v[ni];
+              if (grow) {
+                const int n = n0 + wc * (NI * 16) + ni * 16 + (l & 15);
+                v *= n < N ? grow[n] : 0.f;
+              }
+              DT<T>::st((T*)(wbuf + rl * PITCH) + ni * 16 + (l & 15), v);
+            }
+          }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int rl = it * RPI + l / LPR, cv = l % LPR;
+          const int m = mrow0 + rl, n = n0 + wc * (NI * 16) + cv * VEC;
+          if (m < M && n < N) {
+            const uint4 raw = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
+            T* g = dst + ((long)m * ldd + n);
+            const bool acc_c = pr.accumulate && dst == Cg;
+            if (n + VEC <= N && !acc_c) {
+              *(uint4*)g = raw;
+            } else {
+              const T* e = (const T*)&raw;
+#pragma unroll
+              for (int k = 0; k < VEC; ++k)
+                if (n + k < N) DT<T>::st(g + k, acc_c ? DT<T>::ld(e + k) + DT<T>::ld(g + k) : DT<T>::ld(e + k));
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll

@@ -47,7 +47,8 @@ def test_linear_fwd_bias_gate(dt, M, N, K):
     Ad, Wd = A.to(dev()), W.to(dev())
     C = torch.full((M, N), float("nan"), dtype=DT[dt], device=dev())
     C2 = torch.full((M, N), float("nan"), dtype=DT[dt], device=dev())
-    d = ops.gemm_desc(Ad, Wd, C, M, N, K, Lout=T, bias=bias.to(dev()), gate=gate.to(dev()), ldg=N, C2=C2)
+    bias_d, gate_d = bias.to(dev()), gate.to(dev())       # descriptors hold raw pointers: keep the tensors alive
+    d = ops.gemm_desc(Ad, Wd, C, M, N, K, Lout=T, bias=bias_d, gate=gate_d, ldg=N, C2=C2)
     ops.gemm_nt([d], ops.dtype_code(Ad))
     torch.cuda.synchronize()
     close(C2, pre, TOL[dt] * np.sqrt(K / 64), "pre-gate")
@@ -212,8 +213,9 @@ def test_conv_fwd_splitk_with_stats_bias_gate(dt, ksplit):
     C = torch.full((M, Cout), float("nan"), dtype=DT[dt], device=dev())
     C2 = torch.full((M, Cout), float("nan"), dtype=DT[dt], device=dev())
     stats = torch.full(((M + 127) // 128, 2, Cout), float("nan"), dtype=torch.float32, device=dev())
-    d = ops.gemm_desc(xd, wp, C, M, Cout, Cin, taps=k, pad=1, Lout=L, Lsrc=L, stats=stats, bias=bias.to(dev()),
-                      gate=gate.to(dev()), ldg=Cout, C2=C2)
+    bias_d, gate_d = bias.to(dev()), gate.to(dev())       # descriptors hold raw pointers: keep the tensors alive
+    d = ops.gemm_desc(xd, wp, C, M, Cout, Cin, taps=k, pad=1, Lout=L, Lsrc=L, stats=stats, bias=bias_d,
+                      gate=gate_d, ldg=Cout, C2=C2)
     ws = torch.empty(ksplit * M * Cout, dtype=torch.float32, device=dev())
     arr = (_lib.GemmDesc * 1)(d)
     _lib.check(_lib.lib().drn_gemm_nt_splitk(arr, ksplit, ctypes.c_void_p(ws.data_ptr()), ops.dtype_code(xd),
