@@ -214,8 +214,40 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // epilogue: acc[mi][ni][r] -> n = n0 + wr*64 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*64 + ni*16 + (l&15)
+  // epilogue: acc[mi][ni][r] -> n = n0 + wr*MI*16 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*NI*16 + ni*16 + (l&15)
   const int KW = P.taps * P.Cin;
+  const bool rowmajor = !P.direct || (P.w_layout == 0 && !P.accumulate);   // destination rows contiguous along c
+  float* obase = P.direct ? P.out : P.out + (long)split * P.N * KW;
+  if (rowmajor && (KW % 4 == 0) && (P.Cin % 4 == 0) && (((uintptr_t)obase & 15) == 0)) {
+    // coalesced: each wave transposes its 64-column slab through a private LDS patch (32 rows at a time) and writes
+    // 16-byte row segments instead of 64 scattered 4-byte stores per lane
+    constexpr int PITCH = 64 * 4 + 16;
+    __syncthreads();
+    char* wbuf = smem + w * (32 * PITCH);
+#pragma unroll
+    for (int ch = 0; ch < MI / 2; ++ch) {
+      const int nrow0 = n0 + wr * (MI * 16) + ch * 32;
+#pragma unroll
+      for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCH) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {          // 16 lanes per 64-float row, 4 rows per instruction
+        const int rl = it * 4 + (l >> 4), cv = l & 15;
+        const int n = nrow0 + rl, c = c0 + wc * (NI * 16) + cv * 4;
+        if (n < P.N && c < P.Cin) {             // Cin % 4 == 0: a quad never crosses the row end
+          const f32x4 v = *(const f32x4*)(wbuf + rl * PITCH + cv * 16);
+          *(f32x4*)(obase + ((long)n * KW + tap * P.Cin + c)) = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
