@@ -183,42 +183,52 @@ extern "C" int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shif
 // The ReLU mask is recomputed as fma(raw, scale, shift) > 0 with the forward's own scale/shift, so it is
 // bit-identical to the forward decision even when `out` had the FPN upsample added on top.
 // g = dOut * mask;  partial[blk][0][c] = sum g ; partial[blk][1][c] = sum g * xhat
+// block 256 = 64 channel vectors x 4 row lanes (LDS-combined in a fixed order); grid (ceil(nvec/64), nblk)
 template <typename T>
-__global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const T* __restrict__ dout, int ld_dout, const T* __restrict__ raw, int ld_raw,
-                                                           const float* __restrict__ ss, const float* __restrict__ save, int M, int C,
-                                                           int relu, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, int ld_dout, const T* __restrict__ raw, int ld_raw,
+                                                            const float* __restrict__ ss, const float* __restrict__ save, int M, int C,
+                                                            int relu, float* __restrict__ partial) {
   constexpr int N = V16<T>::N;
+  __shared__ float red[2][4][64 * N + 1];
   const int nvec = C / N;
   const int rows_per = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nvec) return;
+  const int vx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int v = blockIdx.x * 64 + vx;
+  const bool live = v < nvec;
   const int c0 = v * N;
   float mean[N], istd[N], sc[N], sh[N], sg[N], sx[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    mean[k] = save[c0 + k];
-    istd[k] = save[C + c0 + k];
-    sc[k] = ss[c0 + k];
-    sh[k] = ss[C + c0 + k];
+    mean[k] = live ? save[c0 + k] : 0.f;
+    istd[k] = live ? save[C + c0 + k] : 0.f;
+    sc[k] = live ? ss[c0 + k] : 0.f;
+    sh[k] = live ? ss[C + c0 + k] : 0.f;
     sg[k] = 0.f;
     sx[k] = 0.f;
   }
-  for (int m = r0; m < r1; ++m) {
-    float g[N], x[N];
-    V16<T>::load(dout + (long)m * ld_dout + c0, g);
-    V16<T>::load(raw + (long)m * ld_raw + c0, x);
+  if (live)
+    for (int m = r0 + ry; m < r1; m += 4) {
+      float g[N], x[N];
+      V16<T>::load(dout + (long)m * ld_dout + c0, g);
+      V16<T>::load(raw + (long)m * ld_raw + c0, x);
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
-      sg[k] += gg;
-      sx[k] = fmaf(gg, (x[k] - mean[k]) * istd[k], sx[k]);
+      for (int k = 0; k < N; ++k) {
+        const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
+        sg[k] += gg;
+        sx[k] = fmaf(gg, (x[k] - mean[k]) * istd[k], sx[k]);
+      }
     }
-  }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    partial[((long)blockIdx.y * 2 + 0) * C + c0 + k] = sg[k];
-    partial[((long)blockIdx.y * 2 + 1) * C + c0 + k] = sx[k];
+    red[0][ry][vx * N + k] = sg[k];
+    red[1][ry][vx * N + k] = sx[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 64 * N; i += 256) {
+    const int kind = i / (64 * N), cc = i % (64 * N);
+    const int c = blockIdx.x * 64 * N + cc;
+    if (c < C) partial[((long)blockIdx.y * 2 + kind) * C + c] = red[kind][0][cc] + red[kind][1][cc] + red[kind][2][cc] + red[kind][3][cc];
   }
 }
 
@@ -288,13 +298,13 @@ extern "C" int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld
                           int relu, float* ws /* >= (2*256+3)*C floats */, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(dout && raw && scale_shift && save && gamma && draw && ws && M > 0 && C > 0, "drn_bn_bwd: bad args");
-  const int nblk = M >= 256 * 8 ? 256 : (M >= 8 ? M / 8 : 1);
+  const int nblk = M >= 256 * 16 ? 256 : (M >= 16 ? M / 16 : 1);
   float* coef = ws + (long)2 * 256 * C;
   DISPATCH_DT(dtype, "drn_bn_bwd", {
     constexpr int N = V16<T>::N;
     DRN_CHECK_ARG(C % N == 0 && ld_dout % N == 0 && ld_raw % N == 0 && ld_draw % N == 0, "drn_bn_bwd: C/ld must be 16-byte multiples");
     dim3 grid(cdiv(C / N, 64), nblk);
-    bn_bwd_reduce_kernel<T><<<grid, 64, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw, scale_shift, save, M, C, relu, ws);
+    bn_bwd_reduce_kernel<T><<<grid, 256, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw, scale_shift, save, M, C, relu, ws);
     bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, stream>>>(ws, nblk, M, C, gamma, save, dgamma, dbeta, accumulate, coef);
     bn_bwd_apply_kernel<T><<<row_grid(M, C / N), 256, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw,
                                                                                  scale_shift, coef, (T*)draw, ld_draw, M, C, relu);

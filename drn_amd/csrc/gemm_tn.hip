@@ -301,7 +301,9 @@ static int wgrad_nsplit(int total_blks, int N, int Cin, int taps) {
   const int tile = wgrad_tile(N, Cin, taps);
   const int tiles = cdiv(N, tile) * taps * cdiv(Cin, tile);
   int ns = cdiv(tile == 256 ? 256 : 768, tiles);   // ~1 (8-wave) or ~3 (4-wave) workgroups per CU
-  if (ns > total_blks) ns = total_blks;
+  // every split must own enough row blocks to amortise its fp32 partial tile (write + re-read in the reduce pass)
+  const int cap = total_blks / 12;
+  if (ns > cap) ns = cap;
   if (ns < 1) ns = 1;
   if (ns > 64) ns = 64;
   return ns;

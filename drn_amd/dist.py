@@ -100,10 +100,10 @@ class GradReducer(object):
     def _on_grad(self, p):
         b, i = self._of[p]
         sink = b.views[i]
-        if p.grad is not None and p.grad.data_ptr() != sink.data_ptr():
+        if p.grad is not None and p.grad.data_ptr() != sink.data_ptr() and self.world > 1 and self.overlap:
             with torch.no_grad():
                 sink.copy_(p.grad.reshape(-1))          # gradient produced elsewhere (stock autograd ops): move it in
-            p.grad = sink.view_as(p)
+            p.grad = sink.view_as(p)                    # (single process / deferred mode: finish() batches these copies)
         self._dirty[p] = True
         b.pending -= 1
         if self.overlap and b.pending == 0 and not b.launched:
@@ -128,17 +128,21 @@ class GradReducer(object):
         branches contribute zeros), wait for all collectives and turn sums into means."""
         for b in self.buckets:
             if self.steal:
+                dsts, srcs = [], []
                 for p, v in zip(b.params, b.views):
                     if p.grad is None:                          # no gradient this step: the slice must read as zero
                         if self._dirty.get(p, False):
                             v.zero_()
                             self._dirty[p] = False
                         p.grad = v.view_as(p)
-                    elif p.grad.data_ptr() != v.data_ptr():     # hook did not run (e.g. grads set by hand)
-                        with torch.no_grad():
-                            v.copy_(p.grad.reshape(-1))
+                    elif p.grad.data_ptr() != v.data_ptr():     # produced by stock autograd ops / set by hand: move it in
+                        dsts.append(v)
+                        srcs.append(p.grad.detach().reshape(-1))
                         p.grad = v.view_as(p)
                         self._dirty[p] = True
+                if dsts:
+                    with torch.no_grad():
+                        torch._foreach_copy_(dsts, srcs)        # one multi-tensor launch per bucket
             if not b.launched:
                 self._launch(b)
         if self.world > 1:

@@ -36,4 +36,5 @@ class FPN(nn.Module):
 
     def forward(self, x):
         outs = self.forward_nlc([DF.as_nlc(f, self.compute_dtype) for f in x])
+        DF.flush_bn_counters()
         return tuple(o.permute(0, 2, 1) for o in outs)

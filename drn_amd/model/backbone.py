@@ -34,4 +34,5 @@ class Backbone(nn.Module):
         dt = self.compute_dtype
         g0 = torch.cat([DF.as_nlc(x, dt) * query_fts[0].to(dt)[:, None, :], DF.as_nlc(position_fts[0], dt)], dim=2)
         outs = self.forward_from_stage(g0, [q.float() for q in query_fts])
+        DF.flush_bn_counters()
         return tuple(o.permute(0, 2, 1) for o in outs)

@@ -17,6 +17,7 @@ class ConvBlock(nn.Sequential):
 
     def forward(self, x):
         out, _ = self.forward_nlc([DF.as_nlc(x, self.compute_dtype)])
+        DF.flush_bn_counters()
         return out[0].permute(0, 2, 1)
 
 

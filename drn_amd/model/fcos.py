@@ -86,7 +86,7 @@ class FCOSHead(torch.nn.Module):
             with torch.no_grad():
                 cb.running_mean.copy_(rm[:C]); bb.running_mean.copy_(rm[C:])
                 cb.running_var.copy_(rv[:C]); bb.running_var.copy_(rv[C:])
-                cb.num_batches_tracked.add_(len(xs)); bb.num_batches_tracked.add_(len(xs))
+                DF.bump_bn_counter(cb.num_batches_tracked, len(xs)); DF.bump_bn_counter(bb.num_batches_tracked, len(xs))
         return out
 
     def forward_nlc(self, xs):
@@ -114,6 +114,7 @@ class FCOSHead(torch.nn.Module):
     def forward(self, x):
         """Reference signature (model/fcos.py:87-105): list of (B, C, L) -> (logits, bbox_reg, centerness=[], iou_scores)."""
         logits, reg, iou, geo = self.forward_nlc([DF.as_nlc(f, self.compute_dtype) for f in x])
+        DF.flush_bn_counters()
         return self.split_levels(logits, geo), self.split_levels(reg, geo), [], self.split_levels(iou, geo)
 
 

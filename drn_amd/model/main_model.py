@@ -75,6 +75,7 @@ class mainModel(nn.Module):
         fc = self.fcos
         locations = [fc.compute_locations_per_level(L, fc.fpn_strides[l], logits.device) for l, (_, L) in enumerate(geo)]
         targets = gt_start_end.float()
+        DF.flush_bn_counters()
         if self.training:
             return fc._forward_train(locations, box_cls, box_reg, targets, iou_scores)
         return fc._forward_test(locations, box_cls, box_reg, targets, iou_scores)

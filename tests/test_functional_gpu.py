@@ -123,6 +123,7 @@ def test_conv_block_three_levels_shared(dt):
     assert float(conv_h.bias.grad.abs().max()) == 0.0          # a conv bias in front of train-mode BN has zero gradient
     close(bn_h.running_mean, rm, tol, "running_mean (the conv bias shifts it)")
     close(bn_h.running_var, rv, tol, "running_var")
+    DF.flush_bn_counters()          # counter increments are batched; modules flush at the end of their forward
     assert int(bn_h.num_batches_tracked) == 3
 
 
