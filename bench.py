@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--D", type=int, default=4096)
     ap.add_argument("--stage", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--cpu-steps", type=int, default=3, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="timed oracle steps for cpu_baseline (~1 s each on 32 threads); 0 disables")
     ap.add_argument("--verbose", action="store_true", help="per-kernel MFMA timing table on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from Python instead of replaying a hipGraph")

@@ -11,6 +11,12 @@ def mk(levels, N, Cin, taps=1):
         A = torch.randn(b * L, Cin, device=dev).to(dt); C = torch.empty(b * L, N, device=dev, dtype=dt)
         descs.append(ops.gemm_desc(A, W, C, b * L, N, Cin, taps=taps, pad=(taps - 1) // 2, Lout=L, Lsrc=L)); keep.append((A, C))
     return descs, keep, W
+if shape == "wgrad":
+    dY = torch.randn(B * 256, 4096, device=dev).to(dt); X = torch.randn(B * 256, 4096, device=dev).to(dt)
+    dW = torch.empty(4096, 4096, 1, device=dev)
+    for _ in range(5):
+        ops.gemm_wgrad([ops.wgrad_desc(dY, X, B * 256)], dW, 4096, 4096, dtype=code)
+    torch.cuda.synchronize(); sys.exit()
 if shape == "prop_fc": d, k, W = mk([(B, 256)], 4096, 4096)
 elif shape == "l3": d, k, W = mk([(B, 64)], 512, 512, 3)
 else: d, k, W = mk([(B, 256), (B, 128), (B, 64)], 1024, 512, 3)

@@ -10,7 +10,7 @@ ki = cols.index("kernel_name") if "kernel_name" in cols else None
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in cur.execute("select * from counters_collection"):
     d = dict(zip(cols, r))
-    if "conv_gemm" not in str(d.get("kernel_name", "")): continue
+    if "conv_" not in str(d.get("kernel_name", "")): continue
     agg[d["kernel_name"][:30]][d["counter_name"]].append(d["value"])
 for k, v in agg.items():
     print(k)
