@@ -298,6 +298,127 @@ def conv_block(xs, conv, bn, training, dtype, gate=None, up=None, relu=True):
     return list(res), None
 
 
+class _MultiConvFn(torch.autograd.Function):
+    """n INDEPENDENT conv->BN->ReLU blocks (different weights, one input each) launched together: the implicit GEMMs of
+    all blocks go through ONE grouped launch forward and ONE for the data gradients, so the coarse pyramid levels (64-128
+    workgroups on their own) share the chip with the fine one.  With chain_up the blocks are the FPN laterals:
+    out_l = relu(bn(conv_l(x_l))) + nearest_x2(out_{l+1}) (model/FPN.py:54-68), resolved coarse-to-fine in the BN-apply
+    passes; without it they are the FPN output convs (FPN.py:56,69)."""
+
+    @staticmethod
+    def forward(ctx, meta, *args):
+        n, dt, training, chain_up = meta["n"], meta["dtype"], meta["training"], meta["chain_up"]
+        code = code_of(dt)
+        weights, gammas, betas, xs = args[0:n], args[n:2 * n], args[2 * n:3 * n], args[3 * n:4 * n]
+        bns, strides = meta["bns"], meta["strides"]
+        dev = xs[0].device
+        geo, raws, stats, descs = [], [], [], []
+        for l in range(n):
+            w, x = weights[l], xs[l]
+            Cout, Cin, k = w.shape
+            pad = (k - 1) // 2
+            B, L, C, ld = geom(x)
+            assert C == Cin and x.dtype == dt
+            Lo = (L + 2 * pad - k) // strides[l] + 1
+            M = B * Lo
+            raw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+            st = torch.empty(((M + 127) // 128, 2, Cout), dtype=torch.float32, device=dev) if training else None
+            descs.append(ops.gemm_desc(x, packed(w, (0, 2, 1), code), raw, M, Cout, Cin, taps=k, stride=strides[l], pad=pad,
+                                       Lout=Lo, Lsrc=L, lda=ld, stats=st))
+            geo.append((B, L, Lo, M, ld, Cout, Cin, k, pad))
+            raws.append(raw)
+            stats.append(st)
+        ops.gemm_nt(descs, code)
+        sss, saves = [], []
+        for l in range(n):
+            bn, Cout = bns[l], geo[l][5]
+            ss = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+            if training:
+                sv = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                track = bn.track_running_stats and bn.running_mean is not None
+                ops.bn_finalize([(stats[l], stats[l].shape[0], geo[l][3], ss, sv)], Cout, gammas[l], betas[l], None,
+                                bn.running_mean if track else None, bn.running_var if track else None, bn.momentum, bn.eps)
+                if track and bn.num_batches_tracked is not None:
+                    bump_bn_counter(bn.num_batches_tracked, 1)
+                saves.append(sv)
+            else:
+                ops.bn_eval_scale_shift(Cout, gammas[l], betas[l], None, bn.running_mean, bn.running_var, bn.eps, ss)
+                saves.append(ss)
+            sss.append(ss)
+        outs = [None] * n
+        for l in range(n - 1, -1, -1):                        # coarse to fine (the chain needs out_{l+1})
+            B, L, Lo, M, ld, Cout = geo[l][:6]
+            out = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+            up = outs[l + 1] if (chain_up and l + 1 < n) else None
+            ops.bn_apply(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, C=Cout, L=Lo, dtype=code, up=up,
+                         ld_up=Cout if up is not None else 0, relu=True)
+            outs[l] = out
+        ctx.meta, ctx.geo = meta, geo
+        ctx.save_for_backward(*weights, *gammas, *xs, *raws, *sss, *saves)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        meta, geo = ctx.meta, ctx.geo
+        n, dt, chain_up, strides = meta["n"], meta["dtype"], meta["chain_up"], meta["strides"]
+        if not meta["training"]:
+            raise DrnError("backward through an eval-mode BatchNorm block is not supported")
+        code = code_of(dt)
+        sv = ctx.saved_tensors
+        weights, gammas, xs = sv[0:n], sv[n:2 * n], sv[2 * n:3 * n]
+        raws, sss, saves = sv[3 * n:4 * n], sv[4 * n:5 * n], sv[5 * n:6 * n]
+        dev = xs[0].device
+        dtot = [None] * n
+        for l in range(n):                                    # fine to coarse: out_l also fed out_{l-1} through the upsample
+            B, L, Lo, M, ld, Cout = geo[l][:6]
+            d = _grad_nlc(gouts[l], None, dt)
+            if chain_up and l > 0:
+                d = d.clone() if d is not None else torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
+                ops.pairsum_add(d, Cout, dtot[l - 1], Cout, M, Cout, code)
+            elif d is None:
+                d = torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
+            dtot[l] = d
+        draws, dgammas, dbetas = [], [], []
+        for l in range(n):
+            B, L, Lo, M, ld, Cout = geo[l][:6]
+            draw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+            dg, db = grad_buffer(gammas[l]), torch.empty_like(gammas[l])
+            ops.bn_bwd(dtot[l], Cout, raws[l], Cout, sss[l], saves[l], gammas[l], draw, Cout, dg, db, False, M, Cout, code)
+            draws.append(draw)
+            dgammas.append(dg)
+            dbetas.append(db)
+        dxs = [None] * n
+        need = [ctx.needs_input_grad[1 + 3 * n + l] for l in range(n)]
+        descs = []
+        for l in range(n):
+            if not need[l]:
+                continue
+            B, L, Lo, M, ld, Cout, Cin, k, pad = geo[l]
+            dx = torch.empty((B, L, Cin), dtype=dt, device=dev)
+            descs.append(ops.gemm_desc(draws[l], packed(weights[l], (1, 2, 0), code), dx, B * L, Cin, Cout, taps=k,
+                                       stride=strides[l], pad=pad, mode=1, Lout=L, Lsrc=Lo))
+            dxs[l] = dx
+        if descs:
+            ops.gemm_nt(descs, code)
+        dWs = []
+        for l in range(n):
+            B, L, Lo, M, ld, Cout, Cin, k, pad = geo[l]
+            dW = grad_buffer(weights[l])
+            ops.gemm_wgrad([ops.wgrad_desc(draws[l], xs[l], M, Lout=Lo, Lsrc=L, ldy=Cout, ldx=ld)], dW, Cout, Cin, taps=k,
+                           stride=strides[l], pad=pad, w_layout=1, dtype=code)
+            dWs.append(dW)
+        return (None,) + tuple(dWs) + tuple(dgammas) + tuple(dbetas) + tuple(dxs)
+
+
+def multi_conv_block(xs, blocks, training, dtype, chain_up=False):
+    """blocks: list of (conv, bn) parameter holders (bias-free convs), one per input."""
+    n = len(xs)
+    meta = {"n": n, "dtype": dtype, "training": training, "chain_up": chain_up, "bns": [b for _, b in blocks],
+            "strides": [c.stride[0] for c, _ in blocks]}
+    args = [c.weight for c, _ in blocks] + [b.weight for _, b in blocks] + [b.bias for _, b in blocks] + list(xs)
+    return list(_MultiConvFn.apply(meta, *args))
+
+
 class _InputStageFn(torch.autograd.Function):
     """prop_fc + level-0 query gating + position embedding, written into one (B, T, D+P) buffer that is conv0's
     input (model/main_model.py:51-59,67 + model/backbone.py:28-32: Linear, `q * x`, cat) -- one MFMA GEMM whose

@@ -24,15 +24,14 @@ class FPN(nn.Module):
         self.top_blocks = None
 
     def forward_nlc(self, feats):
-        """feats: channels-last (B, L_l, C_l), highest resolution first.  The nearest-x2 upsample + add of the
-        top-down path (FPN.py:63-68) is fused into the lateral block's BN-apply pass."""
-        last, _ = getattr(self, self.inner_blocks[-1]).forward_nlc([feats[-1]])
-        last = last[0]
-        results = [getattr(self, self.layer_blocks[-1]).forward_nlc([last])[0][0]]
-        for feat, inner, layer in zip(feats[:-1][::-1], self.inner_blocks[:-1][::-1], self.layer_blocks[:-1][::-1]):
-            last = getattr(self, inner).forward_nlc([feat], up=last)[0][0]
-            results.insert(0, getattr(self, layer).forward_nlc([last])[0][0])
-        return results
+        """feats: channels-last (B, L_l, C_l), highest resolution first.  The three lateral 1x1 convs run as ONE grouped
+        implicit-GEMM launch, their BN-apply passes resolve the top-down chain last_l = lateral_l + nearest_x2(last_{l+1})
+        coarse to fine (FPN.py:54-68), then the three output convs run as one grouped launch (FPN.py:56,69)."""
+        inner = [(getattr(self, nm)[0], getattr(self, nm)[1]) for nm in self.inner_blocks]
+        layer = [(getattr(self, nm)[0], getattr(self, nm)[1]) for nm in self.layer_blocks]
+        dt = self.compute_dtype
+        last = DF.multi_conv_block(list(feats), inner, self.training, dt, chain_up=True)
+        return DF.multi_conv_block(last, layer, self.training, dt, chain_up=False)
 
     def forward(self, x):
         outs = self.forward_nlc([DF.as_nlc(f, self.compute_dtype) for f in x])
