@@ -39,22 +39,32 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinParams P, i
   }
   for (int g = 0; g < P.ngroups; ++g) {   // shared modules: levels update the running stats in order
     const BnFinGroup& G = P.g[g];
-    double s = 0.0, q = 0.0;
+    // slab t holds (sum, M2 about the slab mean) of n_t = min(128, M - 128 t) rows; merge in double (Chan et al.)
+    double s = 0.0;
     if (live)
-      for (int t = j; t < G.tiles; t += 16) {
-        s += (double)G.stats[((long)t * 2 + 0) * C + c];
-        q += (double)G.stats[((long)t * 2 + 1) * C + c];
-      }
+      for (int t = j; t < G.tiles; t += 16) s += (double)G.stats[((long)t * 2 + 0) * C + c];
     __syncthreads();
     sh[0][ci][j] = s;
+    __syncthreads();
+    double mean = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mean += sh[0][ci][k];
+    mean /= G.M;
+    double q = 0.0;
+    if (live)
+      for (int t = j; t < G.tiles; t += 16) {
+        const int nt = min(128, G.M - t * 128);
+        const double d = (double)G.stats[((long)t * 2 + 0) * C + c] / nt - mean;
+        q += (double)G.stats[((long)t * 2 + 1) * C + c] + nt * d * d;
+      }
+    __syncthreads();
     sh[1][ci][j] = q;
     __syncthreads();
     if (live && j == 0) {
-      s = 0.0; q = 0.0;
+      q = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { s += sh[0][ci][k]; q += sh[1][ci][k]; }
-      const double mean = s / G.M;
-      double var = q / G.M - mean * mean;
+      for (int k = 0; k < 16; ++k) q += sh[1][ci][k];
+      double var = q / G.M;
       if (var < 0.0) var = 0.0;
       const float invstd = (float)(1.0 / sqrt(var + (double)eps));
       const float sc = gamma[c] * invstd;

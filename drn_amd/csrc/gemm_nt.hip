@@ -279,41 +279,65 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     return;
   }
   if (pr.stats) {
-    // Column sums of the raw fp32 accumulators per 128-row slab (rows >= M contribute exact zeros):
-    // stats[(slab*2 + kind)*N + n], slab = m / 128, whatever the tile shape.
+    // BatchNorm statistics of the raw fp32 accumulators per 128-row slab, in the numerically robust (count, sum, M2)
+    // form: stats[(slab*2 + 0)*N + n] = sum_rows x, stats[(slab*2 + 1)*N + n] = sum_rows (x - slab mean)^2.
+    // bn_finalize_kernel merges the slabs with Chan's parallel-variance formula (no E[x^2]-E[x]^2 cancellation).
     constexpr int WROWS = MI * 16;            // rows owned by one wave row: 64 or 128
     constexpr int WPS = 128 / WROWS;          // wave rows per 128-row slab
-    float* shs = (float*)smem;                // [WM][2 kinds][TN]
+    constexpr int SLABS = TM / 128;
+    float* shs = (float*)smem;                // [WM][TN] partial sums, then [SLABS][TN] slab means
+    float* shm = shs + WM * TN;
+    // pass 1: column sums (rows >= M hold exact zeros)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      float s = 0.f, q = 0.f;
+      float sm = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm += acc[mi][ni][r];
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (l < 16) shs[wr * TN + wc * (NI * 16) + ni * 16 + l] = sm;
+    }
+    __syncthreads();
+    for (int i = tid; i < SLABS * TN; i += 64 * NW) {
+      const int n = i % TN, slab = i / TN;
+      const int grow = tm * SLABS + slab;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < WPS; ++k) v += shs[(slab * WPS + k) * TN + n];
+      const int rows = min(128, M - grow * 128);
+      shm[i] = rows > 0 ? v / (float)rows : 0.f;
+      if (n0 + n < N && rows > 0) pr.stats[((long)grow * 2 + 0) * N + n0 + n] = v;
+    }
+    __syncthreads();
+    // pass 2: centred sums of squares (only rows < M)
+    const int slab_w = (wr * WROWS) / 128;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float mean = shm[slab_w * TN + wc * (NI * 16) + ni * 16 + (l & 15)];
+      float q = 0.f;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[mi][ni][r];
-          s += v;
-          q += v * v;
+          const int m = m0 + wr * WROWS + mi * 16 + (l >> 4) * 4 + r;
+          const float dlt = acc[mi][ni][r] - mean;
+          q += m < M ? dlt * dlt : 0.f;
         }
-      s += __shfl_xor(s, 16, 64);
       q += __shfl_xor(q, 16, 64);
-      s += __shfl_xor(s, 32, 64);
       q += __shfl_xor(q, 32, 64);
-      if (l < 16) {
-        shs[(wr * 2 + 0) * TN + wc * (NI * 16) + ni * 16 + l] = s;
-        shs[(wr * 2 + 1) * TN + wc * (NI * 16) + ni * 16 + l] = q;
-      }
+      if (l < 16) shs[wr * TN + wc * (NI * 16) + ni * 16 + l] = q;
     }
     __syncthreads();
-    constexpr int SLABS = TM / 128;
-    for (int i = tid; i < SLABS * 2 * TN; i += 64 * NW) {
-      const int n = i % TN, kind = (i / TN) & 1, slab = i / (2 * TN);
-      const int grow = tm * SLABS + slab;       // global 128-row slab index
+    for (int i = tid; i < SLABS * TN; i += 64 * NW) {
+      const int n = i % TN, slab = i / TN;
+      const int grow = tm * SLABS + slab;
       if (n0 + n < N && grow * 128 < M) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < WPS; ++k) v += shs[((slab * WPS + k) * 2 + kind) * TN + n];
-        pr.stats[((long)grow * 2 + kind) * N + n0 + n] = v;
+        for (int k = 0; k < WPS; ++k) v += shs[(slab * WPS + k) * TN + n];
+        pr.stats[((long)grow * 2 + 1) * N + n0 + n] = v;
       }
     }
   }
@@ -415,32 +439,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
 // 16 column quads x 16 row lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, const GemmProb pr) {
-  __shared__ float red[2][16][65];
+  __shared__ float red[16][65];
+  __shared__ float colmean[64];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + cx * 4;
   const int M = pr.M, N = pr.N;
   const int mbase = blockIdx.y * 128;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  float vals[8][4];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   T* Cg = (T*)pr.C;
   T* C2g = (T*)pr.C2;
-  if (n < N) {
-    for (int r = ry; r < 128; r += 16) {
-      const int m = mbase + r;
-      if (m >= M) break;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int m = mbase + ry + 16 * j;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vals[j][k] = 0.f;
+    if (n < N && m < M) {
       for (int z = 0; z < ksplit; ++z) {
         const float* p = ws + ((long)z * M + m) * N + n;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (n + k < N) v[k] += p[k];
+          if (n + k < N) vals[j][k] += p[k];
       }
       const float* grow = pr.gate ? pr.gate + (long)(m / pr.Lout) * pr.ldg : nullptr;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (n + k >= N) continue;
-        cs[k] += v[k];
-        cq[k] = fmaf(v[k], v[k], cq[k]);
-        float o = v[k];
+        cs[k] += vals[j][k];
+        float o = vals[j][k];
         if (pr.bias) o += pr.bias[n + k];
         if (C2g) DT<T>::st(C2g + ((long)m * pr.ldc2 + n + k), o);
         if (grow) o *= grow[n + k];
@@ -450,22 +476,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       }
     }
   }
-  if (pr.stats) {
+  if (pr.stats) {   // (sum, centred sum of squares) of this 128-row slab, same format as the GEMM epilogue
+    const int rows = min(128, M - mbase);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      red[0][ry][cx * 4 + k] = cs[k];
-      red[1][ry][cx * 4 + k] = cq[k];
+    for (int k = 0; k < 4; ++k) red[ry][cx * 4 + k] = cs[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+      colmean[threadIdx.x] = t / (float)rows;
+      const int nn = blockIdx.x * 64 + threadIdx.x;
+      if (nn < N) pr.stats[((long)blockIdx.y * 2 + 0) * N + nn] = t;
     }
     __syncthreads();
-    if (threadIdx.x < 128) {
-      const int kind = threadIdx.x >> 6, c = threadIdx.x & 63;
-      const int nn = blockIdx.x * 64 + c;
-      if (nn < N && mbase < M) {
-        float t = 0.f;
+    float cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += red[kind][r][c];
-        pr.stats[((long)blockIdx.y * 2 + kind) * N + nn] = t;
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int m = mbase + ry + 16 * j;
+      if (m < M)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dlt = vals[j][k] - colmean[cx * 4 + k];
+          cq[k] = fmaf(dlt, dlt, cq[k]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[ry][cx * 4 + k] = cq[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+      const int nn = blockIdx.x * 64 + threadIdx.x;
+      if (nn < N) pr.stats[((long)blockIdx.y * 2 + 1) * N + nn] = t;
     }
   }
 }

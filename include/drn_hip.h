@@ -37,8 +37,9 @@ const char* drn_last_error(void); /* thread-local, valid until the next failing 
  *   out-of-range taps read zero.  B is [N][taps*Cin] (K contiguous).
  * Epilogue: + bias[n];  optional second output C2 = value before gating;
  *   * gate[(m / Lout)*ldg + n]  (query gating, model/backbone.py:28-30);
- *   per-tile column sums / sums of squares for train-mode BatchNorm
- *   (stats[(tile_m*2 + {0,1})*N + n], tile_m = m/128) -- deterministic, no atomics.
+ *   per-128-row-slab BatchNorm statistics in (sum, M2) form: stats[(slab*2 + 0)*N + n] = sum of the slab's rows,
+ *   stats[(slab*2 + 1)*N + n] = sum of squared deviations from the SLAB mean (merged by drn_bn_finalize with the
+ *   parallel-variance formula: no E[x^2]-E[x]^2 cancellation) -- deterministic, no atomics.
  */
 typedef struct DrnGemmDesc {
   const void* A;

@@ -30,6 +30,17 @@ def close(got, ref, tol, what):
     assert err <= tol * scale, "%s: max abs err %.3e > %.3e (scale %.3g)" % (what, err, tol * scale, scale)
 
 
+def merged_stats(stats, M):
+    """Merge per-128-row-slab (sum, M2) partials (drn_gemm_nt's BN statistics) into total (sum, M2) -- Chan et al."""
+    st = stats.double().cpu()
+    tiles = st.shape[0]
+    n_t = torch.tensor([min(128, M - 128 * t) for t in range(tiles)], dtype=torch.float64)[:, None]
+    total = st[:, 0].sum(0)
+    mean = total / M
+    m2 = (st[:, 1] + n_t * (st[:, 0] / n_t - mean) ** 2).sum(0)
+    return total, m2
+
+
 def nlc(x_ncl):
     return x_ncl.permute(0, 2, 1).contiguous()
 
@@ -82,9 +93,9 @@ def test_conv_fwd_and_stats(dt, B, L, Cin, Cout, k, s):
     torch.cuda.synchronize()
     refm = ref.permute(0, 2, 1).reshape(M, Cout)
     close(C, refm, TOL[dt], "conv out")
-    st = stats.double().cpu().sum(0)
-    close(st[0], refm.sum(0), TOL[dt] * 4, "col sum")
-    close(st[1], (refm * refm).sum(0), TOL[dt] * 4, "col sumsq")
+    tot, m2 = merged_stats(stats, M)
+    close(tot, refm.sum(0), TOL[dt] * 4, "col sum")
+    close(m2, ((refm - refm.mean(0)) ** 2).sum(0), TOL[dt] * 4, "col M2")
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -136,7 +147,9 @@ def test_grouped_shared_weights(dt):
     torch.cuda.synchronize()
     for lvl in range(3):
         close(outs[lvl][1], refs[lvl], TOL[dt], "level %d" % lvl)
-        close(stats[lvl].double().cpu().sum(0)[0], refs[lvl].sum(0), TOL[dt] * 4, "stats level %d" % lvl)
+        tot, m2 = merged_stats(stats[lvl], refs[lvl].shape[0])
+        close(tot, refs[lvl].sum(0), TOL[dt] * 4, "stats level %d" % lvl)
+        close(m2, ((refs[lvl] - refs[lvl].mean(0)) ** 2).sum(0), TOL[dt] * 4, "M2 level %d" % lvl)
 
 
 def test_bad_args_raise():
@@ -224,6 +237,6 @@ def test_conv_fwd_splitk_with_stats_bias_gate(dt, ksplit):
     pre = ref + bias.double()
     close(C2, pre, TOL[dt] * 2, "pre-gate")
     close(C, pre * gate.double().repeat_interleave(L, 0), TOL[dt] * 2, "gated")
-    st = stats.double().cpu().sum(0)
-    close(st[0], ref.sum(0), TOL[dt] * 4, "col sum (raw conv)")
-    close(st[1], (ref * ref).sum(0), TOL[dt] * 4, "col sumsq")
+    tot, m2 = merged_stats(stats, M)
+    close(tot, ref.sum(0), TOL[dt] * 4, "col sum (raw conv)")
+    close(m2, ((ref - ref.mean(0)) ** 2).sum(0), TOL[dt] * 4, "col M2")
