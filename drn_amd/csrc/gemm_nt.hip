@@ -38,6 +38,7 @@ struct GemmProb {
 };
 struct GemmParams {
   int ngroups;
+  int xcd_swizzle;
   int ksplit;       // > 1: gridDim.y splits of the K loop, raw fp32 partial tiles go to `ws` (single group only)
   float* ws;        // [ksplit][M][N]
   GemmProb p[DRN_MAX_GROUPS];
@@ -99,12 +100,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   static_assert(PA * 8 * NW == TM && PB * 8 * NW == TN && PMAX == 4, "staging assumes 4 pieces per wave");
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
 
+  // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness), so give each
+  // XCD a CONTIGUOUS run of logical tiles (same A row-panels, all B column-panels) instead of every 8th one -- the A panel
+  // of a tile row is then fetched into one L2 instead of eight.  Bijective for any grid size.
+  int bid = blockIdx.x;
+  if (P.xcd_swizzle) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
   int g = 0;
 #pragma unroll
   for (int i = 1; i < DRN_MAX_GROUPS; ++i)
-    if (i < P.ngroups && (int)blockIdx.x >= P.p[i].tile_start) g = i;
+    if (i < P.ngroups && bid >= P.p[i].tile_start) g = i;
   const GemmProb& pr = P.p[g];
-  const int t_local = blockIdx.x - pr.tile_start;
+  const int t_local = bid - pr.tile_start;
   const int tm = t_local / pr.tiles_n, tn = t_local - tm * pr.tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
   const int M = pr.M, N = pr.N, K = pr.K, Cin = pr.Cin, taps = pr.taps;
@@ -543,6 +552,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   P.ngroups = ngroups;
   P.ksplit = ksplit;
   P.ws = ws;
+  P.xcd_swizzle = getenv("DRN_NO_XCD_SWIZZLE") ? 0 : 1;
   if (ksplit > 1) tile = 128;
   int total = 0;
   for (int g = 0; g < ngroups; ++g) {
