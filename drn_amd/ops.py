@@ -53,7 +53,9 @@ def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Ls
 kernel_timer = None
 # Split-K of under-filled NT GEMMs is implemented (drn_gemm_nt_splitk) but OFF by default: on MI355X it bought 0.4 % of a
 # step (those launches are bound by operand traffic, not by idle CUs) while changing the fp32 summation order.
-SPLITK = __import__("os").environ.get("DRN_SPLITK", "0") == "1"
+# split-K only pays for long-K problems that cannot fill the chip (conv0 forward: 128 tiles x 204 K-steps -> 2.2x faster);
+# short-K ones lose more to the extra reduce launch than they gain.  DRN_SPLITK=0 disables, =all uses the old wide rule.
+SPLITK = __import__("os").environ.get("DRN_SPLITK", "1")
 
 
 def _timed(tag, flops, launch):
@@ -70,7 +72,7 @@ def _ksplit(d, dtype):
     """Split-K factor for a single problem that cannot fill 256 CUs with 128x128 tiles."""
     tiles = ((d.M + 127) // 128) * ((d.N + 127) // 128)
     nkt = (d.taps * d.Cin) // (64 if dtype == BF16 else 32)
-    if tiles > 160 or nkt < 12:
+    if tiles > 160 or nkt < (12 if SPLITK == "all" else 48):
         return 1
     return max(1, min(8, 512 // tiles, nkt // 6))
 
@@ -78,7 +80,7 @@ def _ksplit(d, dtype):
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
-    if len(descs) == 1 and SPLITK:
+    if len(descs) == 1 and SPLITK != "0":
         ks = _ksplit(descs[0], dtype)
         if ks > 1:
             d0 = descs[0]

@@ -66,6 +66,7 @@ nt("fpn layer L3 2048x512x1536", [(B, 64)], 512, 512, taps=3, stats=True)
 nt("fpn inner1 8192x512x256", [(B, 256)], 512, 256, stats=True)
 nt("towers fwd 14336x1024x1536", [(B, 256), (B, 128), (B, 64)], 1024, 512, taps=3, stats=True)
 nt("towers dgrad 14336x512x3072", [(B, 256), (B, 128), (B, 64)], 512, 1024, taps=3, mode=1)
+nt("conv2 dgrad 4096x512x3072", [(B, 128)], 512, 1024, taps=3, stride=2, mode=1)
 if "wgrad" in sys.argv:
     wg("prop_fc wgrad 4096x4096 r8192", [(B, 256)], 4096, 4096)
     wg("conv0 wgrad 256x13056 r8192", [(B, 256)], 256, 4352, taps=3)
