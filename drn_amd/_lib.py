@@ -39,6 +39,11 @@ class WgradDesc(ctypes.Structure):
                 ("ldy", c_int32), ("ldx", c_int32)]
 
 
+class PackDesc(ctypes.Structure):
+    _fields_ = [("in_", c_void_p), ("out", c_void_p), ("sa", ctypes.c_int64), ("sb", ctypes.c_int64), ("sc", ctypes.c_int64),
+                ("A", c_int32), ("B", c_int32), ("C", c_int32)]
+
+
 class BnGroup(ctypes.Structure):
     _fields_ = [("stats", c_void_p), ("tiles", c_int32), ("M", c_int32), ("scale_shift", c_void_p), ("save", c_void_p)]
 

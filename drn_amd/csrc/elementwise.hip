@@ -62,6 +62,94 @@ extern "C" int drn_pack_weight(const float* in, void* out, int A, int B, int C, 
   return drn_launch_status("drn_pack_weight");
 }
 
+// Several weights in one launch (the whole model's GEMM operands after an optimizer step): per-launch cost dominates
+// these small tensors, so the items ride in the kernel-argument block and workgroups are dealt out by size.
+#define DRN_PACK_MAX 24
+struct PackItem {
+  const float* in;
+  void* out;
+  long sa, sb, sc;
+  int A, B, C, blk_start;
+};
+struct PackParams {
+  PackItem it[DRN_PACK_MAX];
+  int n, total_blocks;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_multi_kernel(PackParams P) {
+  __shared__ float tile[64][65];
+  int g = 0;
+  for (int i = 1; i < P.n; ++i)
+    if ((int)blockIdx.x >= P.it[i].blk_start) g = i;
+  const PackItem& it = P.it[g];
+  const int nblk = (g + 1 < P.n ? P.it[g + 1].blk_start : P.total_blocks) - it.blk_start;
+  const int lb = blockIdx.x - it.blk_start;
+  T* out = (T*)it.out;
+  if (it.sb == 1 && it.sa == it.B && it.sc == (long)it.A * it.B && (it.C & 3) == 0 && (((long)it.A * it.B) & 3) == 0) {
+    // data-gradient layout of a contiguous (Cout, Cin, k) weight: a plain 2-D transpose (R x S) -> (S x R) with
+    // R = Cout, S = Cin*k; 64x64 tiles through LDS so that both the fp32 reads and the T writes are coalesced
+    const int R = it.C, S = it.A * it.B;
+    const int ts = (S + 63) >> 6, tr = (R + 63) >> 6;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (int t = lb; t < ts * tr; t += nblk) {
+      const int r0 = (t / ts) << 6, s0 = (t % ts) << 6;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 16 * j, sx = s0 + tx * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && sx < S) v = *(const float4*)(it.in + (long)r * S + sx);
+        tile[ty + 16 * j][tx * 4 + 0] = v.x; tile[ty + 16 * j][tx * 4 + 1] = v.y;
+        tile[ty + 16 * j][tx * 4 + 2] = v.z; tile[ty + 16 * j][tx * 4 + 3] = v.w;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sl = ty + 16 * j, sx = s0 + sl, r = r0 + tx * 4;
+        if (sx < S && r < R) {
+          T* o = out + (long)sx * R + r;
+          DT<T>::st(o + 0, tile[tx * 4 + 0][sl]); DT<T>::st(o + 1, tile[tx * 4 + 1][sl]);
+          DT<T>::st(o + 2, tile[tx * 4 + 2][sl]); DT<T>::st(o + 3, tile[tx * 4 + 3][sl]);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const long total = (long)it.A * it.B * it.C;
+  for (long i = (long)lb * blockDim.x + threadIdx.x; i < total; i += (long)nblk * blockDim.x) {
+    const int c = (int)(i % it.C);
+    const long ab = i / it.C;
+    const int b = (int)(ab % it.B);
+    const long a = ab / it.B;
+    DT<T>::st(out + i, it.in[a * it.sa + b * it.sb + c * it.sc]);
+  }
+}
+
+extern "C" int drn_pack_weights(const DrnPackDesc* d, int n, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(d && n > 0, "drn_pack_weights: bad args");
+  for (int i = 0; i < n; ++i)
+    DRN_CHECK_ARG(d[i].in && d[i].out && d[i].A > 0 && d[i].B > 0 && d[i].C > 0, "drn_pack_weights: bad item");
+  for (int base = 0; base < n; base += DRN_PACK_MAX) {
+    PackParams P;
+    P.n = n - base < DRN_PACK_MAX ? n - base : DRN_PACK_MAX;
+    int blocks = 0;
+    for (int i = 0; i < P.n; ++i) {
+      const DrnPackDesc& s = d[base + i];
+      PackItem& it = P.it[i];
+      it.in = s.in; it.out = s.out; it.sa = s.sa; it.sb = s.sb; it.sc = s.sc; it.A = s.A; it.B = s.B; it.C = s.C;
+      it.blk_start = blocks;
+      const long total = (long)s.A * s.B * s.C;
+      long nb = (total + 2047) / 2048;            // 8 elements per thread
+      blocks += (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+    }
+    P.total_blocks = blocks;
+    DISPATCH_DT(dtype, "drn_pack_weights", { pack_multi_kernel<T><<<blocks, 256, 0, (hipStream_t)stream>>>(P); });
+  }
+  return drn_launch_status("drn_pack_weights");
+}
+
 // ---------------------------------------------------------------- position embedding
 // out[m][j] = W[j][0]*f0 + W[j][1]*f1 + W[j][2]*f2 + b[j]   (nn.Linear(3,256), main_model.py:34,55)
 template <typename T>

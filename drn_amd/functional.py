@@ -23,22 +23,48 @@ def bump_weights_epoch():
     _weights_epoch += 1
 
 
+def _w3(w):
+    """A Linear weight (N, K) packs like a k=1 conv weight (N, K, 1)."""
+    return w.detach().unsqueeze(-1) if w.dim() == 2 else w.detach()
+
+
 def packed(w, perm, code):
-    """Weight `w` (3-D fp32 parameter) permuted + cast for the GEMM; cached on the parameter version."""
+    """Weight `w` (fp32 conv (Cout,Cin,k) or linear (N,K) parameter) permuted + cast for the GEMM; cached on the
+    parameter version.  Linear weights come back 2-D."""
+    two_d = w.dim() == 2
     if not isinstance(w, torch.nn.Parameter):
         # temporaries (e.g. stacked tower weights) may reuse an address with version 0: never cache them
-        return ops.pack_weight(w.detach(), perm, code)
+        out = ops.pack_weight(_w3(w), perm, code)
+        return out.view(out.shape[0], -1) if two_d else out
     key = (id(w), w.data_ptr(), perm, code)
     ver = (w._version, _weights_epoch)
     hit = _pack_cache.get(key)
     # the weakref guards against a new Parameter re-using a dead one's id / address / version
     if hit is not None and hit[0] == ver and hit[2]() is w and hit[1].device == w.device:
-        return hit[1]
-    out = ops.pack_weight(w.detach(), perm, code)
-    if len(_pack_cache) > 256:
-        _pack_cache.clear()
-    _pack_cache[key] = (ver, out, weakref.ref(w))
-    return out
+        out = hit[1]
+    else:
+        out = ops.pack_weight(_w3(w), perm, code)
+        if len(_pack_cache) > 256:
+            _pack_cache.clear()
+        _pack_cache[key] = (ver, out, weakref.ref(w))
+    return out.view(out.shape[0], -1) if two_d else out
+
+
+def repack_all():
+    """Refresh every cached re-laid weight IN PLACE with one launch per dtype (drn_pack_weights) and mark it current:
+    an optimizer that has just updated all parameters calls this instead of leaving ~20 small per-use launches to
+    the next forward pass.  The copies keep their addresses, so captured hipGraphs stay valid."""
+    by_code = {}
+    for key, (ver, out, ref) in list(_pack_cache.items()):
+        w = ref()
+        if w is None or w.data_ptr() != key[1] or out.device != w.device:
+            del _pack_cache[key]
+            continue
+        by_code.setdefault(key[3], []).append((key, w, out))
+    for code, items in by_code.items():
+        ops.pack_weights_into([(_w3(w), key[2], out) for key, w, out in items], code)
+        for key, w, out in items:
+            _pack_cache[key] = ((w._version, _weights_epoch), out, weakref.ref(w))
 
 
 # Gradient sinks: drn_amd.dist.GradReducer registers, per parameter storage, the slice of its flat bucket where that
@@ -433,7 +459,7 @@ class _InputStageFn(torch.autograd.Function):
         xc = feats.contiguous()
         if xc.dtype != dtype:
             xc = ops.cast(xc.float(), code)
-        wfc = Wfc.detach() if code == ops.F32 else ops.cast(Wfc.detach(), code)
+        wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
         G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
         Z = torch.empty((B, T, D), dtype=dtype, device=dev)
         ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),

@@ -154,6 +154,19 @@ def pack_weight(w, perm, dtype):
     return out
 
 
+def pack_weights_into(items, dtype):
+    """items: [(w, perm, out)] -- refresh existing re-laid copies `out` of fp32 weights `w` in one launch."""
+    from ._lib import PackDesc
+    arr = (PackDesc * len(items))()
+    for i, (w, perm, out) in enumerate(items):
+        _need_gpu(w, out)
+        d = arr[i]
+        d.in_, d.out = _p(w), _p(out)
+        d.A, d.B, d.C = (w.shape[j] for j in perm)
+        d.sa, d.sb, d.sc = (w.stride(j) for j in perm)
+    check(lib().drn_pack_weights(arr, len(items), dtype, _stream()), "drn_pack_weights")
+
+
 def pos_embed_fwd(feat, W, b, out2d, ld_out, M, C, dtype):
     check(lib().drn_pos_embed_fwd(_p(feat), _p(W), _p(b), _p(out2d), ld_out, M, C, dtype, _stream()), "drn_pos_embed_fwd")
 

@@ -58,6 +58,7 @@ class FusedAdam(object):
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                                     ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
         DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
+        DF.repack_all()               # refresh the GEMM-layout copies of all weights in one launch
 
     def total_norm(self):
         return self.partials.sum().sqrt()

@@ -85,6 +85,15 @@ int drn_cast(const float* in, void* out, int64_t n, int dtype, void* stream);
 /* out[a][b][c] (dtype) = in[a*sa + b*sb + c*sc] (fp32): re-lays nn.Conv1d weights (Cout,Cin,k) as the GEMM's
  * B operands [Cout][k][Cin] (forward) and [Cin][k][Cout] (data gradient). */
 int drn_pack_weight(const float* in, void* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, int dtype, void* stream);
+/* The same for n weights in one launch (all GEMM operands of the model after an optimizer step; the reference's cuDNN
+ * re-lays its filters inside every call). */
+typedef struct {
+  const float* in;
+  void* out;
+  int64_t sa, sb, sc;
+  int32_t A, B, C;
+} DrnPackDesc;
+int drn_pack_weights(const DrnPackDesc* items /*host*/, int n, int dtype, void* stream);
 /* position_transform = nn.Linear(3,256) on [start,end,duration] (model/main_model.py:34,51-55), written straight
  * into the channel slice of conv0's input (replaces torch.cat at model/backbone.py:31-32). */
 int drn_pos_embed_fwd(const float* feat /*[M][3]*/, const float* W /*[C][3]*/, const float* b, void* out, int ld_out, int M, int C,

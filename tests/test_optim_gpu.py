@@ -31,3 +31,37 @@ def test_fused_adam_matches_torch(max_norm):
         assert abs(float(fused.total_norm()) - float(tn)) <= 1e-4 * float(tn)
         for p, q in zip(pa, pb):
             assert torch.allclose(p, q, atol=2e-6, rtol=1e-5), float((p - q).abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_repack_all_refreshes_cached_weight_layouts_in_place(dt):
+    """FusedAdam.step() ends with one drn_pack_weights launch over every cached GEMM-layout copy: same addresses,
+    contents equal to a fresh permute+cast of the updated parameters (conv and linear weights, > 24 items)."""
+    from drn_amd import functional as DF
+    from drn_amd import ops
+    from drn_amd.dist import GradReducer
+    from drn_amd.optim import FusedAdam
+    dev = "cuda:0"
+    code = ops.BF16 if dt == torch.bfloat16 else ops.F32
+    g = torch.Generator().manual_seed(1)
+    shapes = [(24 + i, 16 + 8 * (i % 3), 3 if i % 2 else 1) for i in range(28)] + [(40, 72), (8, 1000)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    perms = [(0, 2, 1), (1, 2, 0)]
+    copies = [(p, perm, DF.packed(p, perm, code)) for p in params for perm in (perms if p.dim() == 3 else perms[:1])]
+    ptrs = [c.data_ptr() for _, _, c in copies]
+    red = GradReducer(params, world_size=1)
+    opt = FusedAdam(red, lr=1e-1, max_norm=1e9)
+    red.zero()
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    red.finish()
+    before = [p.detach().clone() for p in params]
+    opt.step()
+    assert all(not torch.equal(a, p) for a, p in zip(before, params))
+    for (p, perm, c), ptr in zip(copies, ptrs):
+        again = DF.packed(p, perm, code)
+        assert again.data_ptr() == ptr                       # cache hit, refreshed in place
+        w3 = p.detach().unsqueeze(-1) if p.dim() == 2 else p.detach()
+        want = w3.permute(*perm).contiguous().to(dt)
+        want = want.view(want.shape[0], -1) if p.dim() == 2 else want
+        assert torch.equal(again, want)
