@@ -176,52 +176,75 @@ extern "C" int drn_pos_embed_fwd(const float* feat, const float* W, const float*
   return drn_launch_status("drn_pos_embed_fwd");
 }
 
-// partial[blk][k][j], k<4: sum_m dOut[m][j] * {f0,f1,f2,1}
+// partial[blk][k][j], k<4: sum_m dOut[m][j] * {f0,f1,f2,1}; block = 32 rows x all channels, 8 row lanes per channel vector
 template <typename T>
-__global__ void pos_embed_bwd_kernel(const T* __restrict__ dout, int ld, const float* __restrict__ feat, int M, int C,
-                                     float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void pos_embed_bwd_kernel(const T* __restrict__ dout, int ld, const float* __restrict__ feat, int M,
+                                                            int C, float* __restrict__ partial) {
+  __shared__ float red[8][4][33];
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
-  for (int j = threadIdx.x; j < C; j += blockDim.x) {
+  const int jl = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  for (int j0 = 0; j0 < C; j0 += 32) {
+    const int j = j0 + jl;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int m = r0; m < r1; ++m) {
-      const float g = DT<T>::ld(dout + (long)m * ld + j);
-      a0 = fmaf(g, feat[m * 3 + 0], a0);
-      a1 = fmaf(g, feat[m * 3 + 1], a1);
-      a2 = fmaf(g, feat[m * 3 + 2], a2);
-      a3 += g;
+    if (j < C)
+      for (int m = r0 + ry; m < r1; m += 8) {
+        const float g = DT<T>::ld(dout + (long)m * ld + j);
+        a0 = fmaf(g, feat[m * 3 + 0], a0);
+        a1 = fmaf(g, feat[m * 3 + 1], a1);
+        a2 = fmaf(g, feat[m * 3 + 2], a2);
+        a3 += g;
+      }
+    red[ry][0][jl] = a0; red[ry][1][jl] = a1; red[ry][2][jl] = a2; red[ry][3][jl] = a3;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int k = threadIdx.x >> 5;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r][k][jl];
+      if (j < C) partial[((long)blockIdx.x * 4 + k) * C + j] = sum;
     }
-    float* p = partial + (long)blockIdx.x * 4 * C;
-    p[0 * C + j] = a0; p[1 * C + j] = a1; p[2 * C + j] = a2; p[3 * C + j] = a3;
+    __syncthreads();
   }
 }
-__global__ void pos_embed_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dW,
-                                           float* __restrict__ db, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= C) return;
+// block = 32 channels x 8 partial lanes
+__global__ __launch_bounds__(256) void pos_embed_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                  float* __restrict__ dW, float* __restrict__ db, int accumulate) {
+  __shared__ float red[8][4][33];
+  const int jl = threadIdx.x & 31, by = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < nblk; ++b)
+  if (j < C)
+    for (int b = by; b < nblk; b += 8)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] += partial[((long)b * 4 + k) * C + j];
-  if (accumulate) {
-    s[0] += dW[j * 3 + 0]; s[1] += dW[j * 3 + 1]; s[2] += dW[j * 3 + 2]; s[3] += db[j];
+      for (int k = 0; k < 4; ++k) s[k] += partial[((long)b * 4 + k) * C + j];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[by][k][jl] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 128 && j < C) {
+    const int k = threadIdx.x >> 5;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sum += red[r][k][jl];
+    float* dst = k < 3 ? dW + j * 3 + k : db + j;
+    *dst = accumulate ? *dst + sum : sum;
   }
-  dW[j * 3 + 0] = s[0]; dW[j * 3 + 1] = s[1]; dW[j * 3 + 2] = s[2]; db[j] = s[3];
 }
 extern "C" int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, int M, int C, float* dW, float* db, int accumulate,
-                                 float* ws /* >= 64*4*C floats */, int dtype, void* stream) {
+                                 float* ws /* >= 256*4*C floats */, int dtype, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(dout && feat && dW && db && ws && M > 0 && C > 0, "drn_pos_embed_bwd: bad args");
-  const int nblk = M < 64 ? 1 : 64;
+  const int nblk = M < 64 ? 1 : (M < 32 * 256 ? (M + 31) / 32 : 256);
   DISPATCH_DT(dtype, "drn_pos_embed_bwd",
               { pos_embed_bwd_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>((const T*)dout, ld, feat, M, C, ws); });
-  pos_embed_bwd_final_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, dW, db, accumulate);
+  pos_embed_bwd_final_kernel<<<cdiv(C, 32), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, dW, db, accumulate);
   return drn_launch_status("drn_pos_embed_bwd");
 }
 
 // ---------------------------------------------------------------- FPN top-down backward: dst[s,t] += src[s,2t] + src[s,2t+1]
 template <typename T>
-__global__ void pairsum_add_kernel(T* __restrict__ dst, int ld_dst, const T* __restrict__ src, int ld_src, int Mdst, int C) {
+__global__ void pairsum_add_kernel(T* __restrict__ dst, int ld_dst, const T* __restrict__ src, int ld_src, int Mdst, int C,
+                                   int accumulate) {
   constexpr int N = V16<T>::N;
   const int nvec = C / N;
   const long total = (long)Mdst * nvec;
@@ -229,32 +252,35 @@ __global__ void pairsum_add_kernel(T* __restrict__ dst, int ld_dst, const T* __r
     const int v = (int)(i % nvec);
     const long m = i / nvec;  // rows of src are exactly 2m, 2m+1 (sequence lengths are even)
     float d[N], a[N], b[N];
-    V16<T>::load(dst + m * ld_dst + v * N, d);
+    if (accumulate) V16<T>::load(dst + m * ld_dst + v * N, d);
     V16<T>::load(src + (2 * m) * ld_src + v * N, a);
     V16<T>::load(src + (2 * m + 1) * ld_src + v * N, b);
 #pragma unroll
-    for (int k = 0; k < N; ++k) d[k] += a[k] + b[k];
+    for (int k = 0; k < N; ++k) d[k] = accumulate ? d[k] + (a[k] + b[k]) : a[k] + b[k];
     V16<T>::store(dst + m * ld_dst + v * N, d);
   }
 }
-extern "C" int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int dtype, void* stream) {
+extern "C" int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int accumulate, int dtype,
+                               void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(dst && src && Mdst > 0 && C > 0, "drn_pairsum_add: bad args");
   DISPATCH_DT(dtype, "drn_pairsum_add", {
     DRN_CHECK_ARG(C % V16<T>::N == 0 && ld_dst % V16<T>::N == 0 && ld_src % V16<T>::N == 0, "drn_pairsum_add: C/ld must be 16-byte multiples");
-    pairsum_add_kernel<T><<<ew_blocks((long)Mdst * (C / V16<T>::N), 256), 256, 0, (hipStream_t)stream>>>((T*)dst, ld_dst, (const T*)src, ld_src, Mdst, C);
+    pairsum_add_kernel<T><<<ew_blocks((long)Mdst * (C / V16<T>::N), 256), 256, 0, (hipStream_t)stream>>>((T*)dst, ld_dst, (const T*)src, ld_src, Mdst, C, accumulate);
   });
   return drn_launch_status("drn_pairsum_add");
 }
 
 // ---------------------------------------------------------------- query-gate backward
 // forward was G[s,t,c] = act[s,t,c] * gate[s,c].  Here:
-//   dC[s,t,c] (+)= dG[s,t,c] * gate[s,c]        dgate[s,c] = sum_t dG[s,t,c] * act[s,t,c]
+//   dC[s,t,c] = (add ? add[s,t,c] : 0) + dG[s,t,c] * gate[s,c]        dgate[s,c] = sum_t dG[s,t,c] * act[s,t,c]
+//   dsum[s,c] = sum_t dG[s,t,c] * gate[s,c]   (optional: per-sequence column sums of the gated gradient = bias gradient partials)
 // grid (ceil(nvec/32), nseq); block 256 = 32 channel vectors x 8 row lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG, int ld_dg, const T* __restrict__ act, int ld_act,
-                                                       const float* __restrict__ gate, int ldg, T* __restrict__ dC, int ld_dc,
-                                                       int accumulate, float* __restrict__ dgate, int ld_dgate, int L, int C) {
+                                                       const float* __restrict__ gate, int ldg, const T* __restrict__ add, int ld_add,
+                                                       T* __restrict__ dC, int ld_dc, float* __restrict__ dgate, int ld_dgate,
+                                                       float* __restrict__ dsum, int L, int C) {
   constexpr int N = V16<T>::N;
   __shared__ float red[8][32 * N + 1];
   const int vx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -262,11 +288,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
   const int s = blockIdx.y;
   const int c0 = v * N;
   const bool live = c0 < C;
-  float gt[N], acc[N];
+  float gt[N], acc[N], cs[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     gt[k] = live ? gate[(long)s * ldg + c0 + k] : 0.f;
     acc[k] = 0.f;
+    cs[k] = 0.f;
   }
   if (live) {
     for (int t = ry; t < L; t += 8) {
@@ -275,12 +302,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
       V16<T>::load(dG + m * ld_dg + c0, g);
       V16<T>::load(act + m * ld_act + c0, a);
 #pragma unroll
-      for (int k = 0; k < N; ++k) acc[k] = fmaf(g[k], a[k], acc[k]);
+      for (int k = 0; k < N; ++k) {
+        acc[k] = fmaf(g[k], a[k], acc[k]);
+        cs[k] += g[k];
+      }
       if (dC) {
         float o[N];
-        if (accumulate) V16<T>::load(dC + m * ld_dc + c0, o);
+        if (add) V16<T>::load(add + m * ld_add + c0, o);
 #pragma unroll
-        for (int k = 0; k < N; ++k) o[k] = accumulate ? fmaf(g[k], gt[k], o[k]) : g[k] * gt[k];
+        for (int k = 0; k < N; ++k) o[k] = add ? fmaf(g[k], gt[k], o[k]) : g[k] * gt[k];
         V16<T>::store(dC + m * ld_dc + c0, o);
       }
     }
@@ -297,24 +327,42 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
       dgate[(long)s * ld_dgate + c] = sum;
     }
   }
+  if (dsum) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[ry][vx * N + k] = cs[k] * gt[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * N; i += 256) {
+      const int c = blockIdx.x * 32 * N + i;
+      if (c < C) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += red[r][i];
+        dsum[(long)s * C + c] = sum;
+      }
+    }
+  }
 }
-extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, void* dC, int ld_dc,
-                            int accumulate, float* dgate, int ld_dgate, int nseq, int L, int C, int dtype, void* stream) {
+extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, const void* add,
+                            int ld_add, void* dC, int ld_dc, float* dgate, int ld_dgate, float* dsum, int nseq, int L, int C,
+                            int dtype, void* stream) {
   drn_clear_status();
-  DRN_CHECK_ARG(dG && act && gate && dgate && nseq > 0 && L > 0 && C > 0, "drn_gate_bwd: bad args");
+  DRN_CHECK_ARG(dG && act && gate && dgate && nseq > 0 && L > 0 && C > 0 && (dC || !add), "drn_gate_bwd: bad args");
   DISPATCH_DT(dtype, "drn_gate_bwd", {
     constexpr int N = V16<T>::N;
-    DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && (!dC || ld_dc % N == 0), "drn_gate_bwd: C/ld must be 16-byte multiples");
+    DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && (!dC || ld_dc % N == 0) && (!add || ld_add % N == 0),
+                  "drn_gate_bwd: C/ld must be 16-byte multiples");
     dim3 grid(cdiv(C / N, 32), nseq);
-    gate_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (T*)dC, ld_dc,
-                                                                accumulate, dgate, ld_dgate, L, C);
+    gate_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (const T*)add,
+                                                                ld_add, (T*)dC, ld_dc, dgate, ld_dgate, dsum, L, C);
   });
   return drn_launch_status("drn_gate_bwd");
 }
 
 // ---------------------------------------------------------------- column sum (bias gradients): out[c] (+)= sum_m X[m][c]
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int ld, int M, int C, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int ld, int M, int C, float* __restrict__ partial,
+                                                             int direct) {
   constexpr int N = V16<T>::N;
   const int nvec = C / N;
   const int rows_per = (M + gridDim.y - 1) / gridDim.y;
@@ -330,6 +378,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k] += x[k];
   }
+  if (direct) {   // single row block: `partial` is the output itself
+#pragma unroll
+    for (int k = 0; k < N; ++k) partial[v * N + k] = direct == 2 ? partial[v * N + k] + acc[k] : acc[k];
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < N; ++k) partial[(long)blockIdx.y * C + v * N + k] = acc[k];
 }
@@ -344,13 +397,14 @@ extern "C" int drn_colsum(const void* X, int ld, int M, int C, float* out, int a
                           void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(X && out && ws && M > 0 && C > 0, "drn_colsum: bad args");
-  const int nblk = M >= 64 * 16 ? 64 : (M >= 16 ? M / 16 : 1);
+  const int nblk = M >= 64 * 16 ? 64 : (M >= 128 ? M / 16 : 1);
   DISPATCH_DT(dtype, "drn_colsum", {
     constexpr int N = V16<T>::N;
     DRN_CHECK_ARG(C % N == 0 && ld % N == 0, "drn_colsum: C/ld must be 16-byte multiples");
-    dim3 grid(cdiv(C / N, 256), nblk);
-    colsum_partial_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)X, ld, M, C, ws);
+    dim3 grid(cdiv(C / N, nblk == 1 ? 64 : 256), nblk);
+    colsum_partial_kernel<T><<<grid, nblk == 1 ? 64 : 256, 0, (hipStream_t)stream>>>((const T*)X, ld, M, C, nblk == 1 ? out : ws,
+                                                                                      nblk == 1 ? 1 + (accumulate != 0) : 0);
   });
-  reduce_partials_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, out, accumulate);
+  if (nblk > 1) reduce_partials_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, out, accumulate);
   return drn_launch_status("drn_colsum");
 }

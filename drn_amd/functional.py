@@ -271,20 +271,17 @@ class _ConvBlockFn(torch.autograd.Function):
             d = _grad_nlc(gouts[l], None, dt)
             if ctx.has_gate:
                 dG = _grad_nlc(gouts[nl], None, dt)
-                dgate = torch.zeros((B, Cout), dtype=torch.float32, device=dev)
                 if dG is not None:
-                    if d is None:
-                        d = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
-                        acc = False
-                    else:
-                        d = d.clone()
-                        acc = True
-                    ops.gate_bwd(dG, Cout, outs[l], Cout, gate, d, Cout, acc, dgate, B, Lo, Cout, code)
+                    dgate = torch.empty((B, Cout), dtype=torch.float32, device=dev)
+                    add, d = d, torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+                    ops.gate_bwd(dG, Cout, outs[l], Cout, gate, d, Cout, add, Cout, dgate, B, Lo, Cout, code)
+                else:
+                    dgate = torch.zeros((B, Cout), dtype=torch.float32, device=dev)
             if d is None:
                 d = torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
             if ctx.has_up:
-                dup = torch.zeros((B, Lo // 2, Cout), dtype=dt, device=dev)
-                ops.pairsum_add(dup, Cout, d, Cout, B * (Lo // 2), Cout, code)
+                dup = torch.empty((B, Lo // 2, Cout), dtype=dt, device=dev)
+                ops.pairsum_add(dup, Cout, d, Cout, B * (Lo // 2), Cout, code, accumulate=False)
             draw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
             ops.bn_bwd(d, Cout, raws[l], Cout, sss[l], saves[l], gamma, draw, Cout, dgamma, dbeta, l > 0, M, Cout, code,
                        relu=meta.relu)
@@ -482,12 +479,13 @@ class _InputStageFn(torch.autograd.Function):
         dG0 = _grad_nlc(dG0, None, dtype)
         dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
         dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
-        ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, False, dgate, B, T, D, code)
+        dsum = torch.empty((B, D), dtype=torch.float32, device=dev)      # per-clip column sums of dZ: prop_fc bias gradient
+        ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
         Wfc, bfc, Wpos, bpos = ctx.param_refs
         dW = grad_buffer(Wfc)
         ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
         db = grad_buffer(bfc)
-        ops.colsum(dZ, D, B * T, D, db, code)
+        ops.colsum(dsum, D, B, D, db, ops.F32)
         dWp = grad_buffer(Wpos)
         dbp = grad_buffer(bpos)
         ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, dWp, dbp, code)

@@ -172,18 +172,19 @@ def pos_embed_fwd(feat, W, b, out2d, ld_out, M, C, dtype):
 
 
 def pos_embed_bwd(dout, ld, feat, M, C, dW, db, dtype, accumulate=False):
-    ws = workspace(256 * C, dW.device)
+    ws = workspace(1024 * C, dW.device)
     check(lib().drn_pos_embed_bwd(_p(dout), ld, _p(feat), M, C, _p(dW), _p(db), int(accumulate), _p(ws), dtype, _stream()),
           "drn_pos_embed_bwd")
 
 
-def pairsum_add(dst, ld_dst, src, ld_src, Mdst, C, dtype):
-    check(lib().drn_pairsum_add(_p(dst), ld_dst, _p(src), ld_src, Mdst, C, dtype, _stream()), "drn_pairsum_add")
+def pairsum_add(dst, ld_dst, src, ld_src, Mdst, C, dtype, accumulate=True):
+    check(lib().drn_pairsum_add(_p(dst), ld_dst, _p(src), ld_src, Mdst, C, int(accumulate), dtype, _stream()), "drn_pairsum_add")
 
 
-def gate_bwd(dG, ld_dg, act, ld_act, gate, dC, ld_dc, accumulate, dgate, nseq, L, C, dtype):
-    check(lib().drn_gate_bwd(_p(dG), ld_dg, _p(act), ld_act, _p(gate), gate.stride(0), _p(dC), ld_dc, int(accumulate), _p(dgate),
-                             dgate.stride(0), nseq, L, C, dtype, _stream()), "drn_gate_bwd")
+def gate_bwd(dG, ld_dg, act, ld_act, gate, dC, ld_dc, add, ld_add, dgate, nseq, L, C, dtype, dsum=None):
+    """dC = (add or 0) + dG * gate; dgate = sum_t dG * act; dsum (nseq, C) fp32 = sum_t dG * gate."""
+    check(lib().drn_gate_bwd(_p(dG), ld_dg, _p(act), ld_act, _p(gate), gate.stride(0), _p(add), ld_add, _p(dC), ld_dc, _p(dgate),
+                             dgate.stride(0), _p(dsum), nseq, L, C, dtype, _stream()), "drn_gate_bwd")
 
 
 def colsum(X, ld, M, C, out, dtype, accumulate=False):

@@ -99,13 +99,14 @@ int drn_pack_weights(const DrnPackDesc* items /*host*/, int n, int dtype, void* 
 int drn_pos_embed_fwd(const float* feat /*[M][3]*/, const float* W /*[C][3]*/, const float* b, void* out, int ld_out, int M, int C,
                       int dtype, void* stream);
 int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, int M, int C, float* dW, float* db, int accumulate,
-                      float* ws /* >= 256*C floats */, int dtype, void* stream);
+                      float* ws /* >= 1024*C floats */, int dtype, void* stream);
 /* backward of F.interpolate(nearest, x2) + add (model/FPN.py:63-68): dst[s,t] += src[s,2t] + src[s,2t+1] */
-int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int dtype, void* stream);
+int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int accumulate, int dtype, void* stream);
 /* backward of the query gating x = q[:, :, None] * x (model/backbone.py:28-30):
- * dC (+)= dG * gate[seq] (skipped when dC is NULL); dgate[seq][c] = sum_t dG*act */
-int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, void* dC, int ld_dc,
-                 int accumulate, float* dgate, int ld_dgate, int nseq, int L, int C, int dtype, void* stream);
+ * dC = (add ? add : 0) + dG * gate[seq] (skipped when dC is NULL); dgate[seq][c] = sum_t dG*act;
+ * dsum (optional, [nseq][C]) = sum_t dG * gate[seq]: per-clip column sums of dC's gated term (bias-gradient partials) */
+int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, const void* add, int ld_add,
+                 void* dC, int ld_dc, float* dgate, int ld_dgate, float* dsum, int nseq, int L, int C, int dtype, void* stream);
 /* out[c] (+)= sum_m X[m][c]  (bias gradients) */
 int drn_colsum(const void* X, int ld, int M, int C, float* out, int accumulate, float* ws /* >= 64*C floats */, int dtype,
                void* stream);

@@ -1,0 +1,110 @@
+"""HBM-bound helper kernels of the path (drn_amd/csrc/elementwise.hip) against plain torch fp32/fp64 references."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTS = [torch.float32, torch.bfloat16]
+
+
+def _code(dt):
+    from drn_amd import ops
+    return ops.BF16 if dt == torch.bfloat16 else ops.F32
+
+
+def _tol(dt):
+    return dict(rtol=1e-5, atol=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("with_add", [False, True])
+@pytest.mark.parametrize("shape", [(3, 10, 24), (32, 256, 512), (2, 7, 1032)])
+def test_gate_bwd(dt, with_add, shape):
+    """backward of x = q[:, :, None] * x (model/backbone.py:28-30) + the per-clip column sums used for prop_fc's bias."""
+    from drn_amd import ops
+    B, L, C = shape
+    g = torch.Generator().manual_seed(0)
+    dev = "cuda:0"
+    ld = C + 8                                            # dG is a column slice of a wider buffer
+    dGw = torch.randn(B, L, ld, generator=g).to(dev).to(dt)
+    act = torch.randn(B, L, C, generator=g).to(dev).to(dt)
+    gate = torch.randn(B, C, generator=g).to(dev)
+    add = torch.randn(B, L, C, generator=g).to(dev).to(dt) if with_add else None
+    dC = torch.empty(B, L, C, device=dev, dtype=dt)
+    dgate = torch.empty(B, C, device=dev)
+    dsum = torch.empty(B, C, device=dev)
+    ops.gate_bwd(dGw, ld, act, C, gate, dC, C, add, C, dgate, B, L, C, _code(dt), dsum=dsum)
+    dG = dGw[:, :, :C].double()
+    want_dC = dG * gate.double()[:, None, :] + (add.double() if with_add else 0)
+    assert torch.allclose(dC.double(), want_dC, **_tol(dt))
+    assert torch.allclose(dgate.double(), (dG * act.double()).sum(1), rtol=1e-4, atol=1e-4 * L ** 0.5)
+    assert torch.allclose(dsum.double(), (dG * gate.double()[:, None, :]).sum(1), rtol=1e-4, atol=1e-4 * L ** 0.5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_pairsum_add(dt, accumulate):
+    """backward of F.interpolate(nearest, x2) + add (model/FPN.py:63-68)."""
+    from drn_amd import ops
+    B, L, C = 5, 12, 40
+    g = torch.Generator().manual_seed(1)
+    dev = "cuda:0"
+    src = torch.randn(B, 2 * L, C, generator=g).to(dev).to(dt)
+    dst0 = torch.randn(B, L, C, generator=g).to(dev).to(dt)
+    dst = dst0.clone()
+    ops.pairsum_add(dst, C, src, C, B * L, C, _code(dt), accumulate=accumulate)
+    want = src.double().view(B, L, 2, C).sum(2) + (dst0.double() if accumulate else 0)
+    assert torch.allclose(dst.double(), want, **_tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,C", [(5, 8), (100, 256), (8192, 256), (9001, 264)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_pos_embed_bwd(dt, M, C, accumulate):
+    """gradients of position_transform = nn.Linear(3, C) (model/main_model.py:34,51-55) from a column slice."""
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(2)
+    dev = "cuda:0"
+    ld = C + 16
+    dwide = torch.randn(M, ld, generator=g).to(dev).to(dt)
+    feat = torch.rand(M, 3, generator=g).to(dev)
+    dW0, db0 = torch.randn(C, 3, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    dW, db = dW0.clone(), db0.clone()
+    ops.pos_embed_bwd(dwide[:, 16:], ld, feat, M, C, dW, db, _code(dt), accumulate=accumulate)
+    d = dwide[:, 16:].double()
+    want_W = d.t() @ feat.double() + (dW0.double() if accumulate else 0)
+    want_b = d.sum(0) + (db0.double() if accumulate else 0)
+    assert torch.allclose(dW.double(), want_W, rtol=1e-4, atol=1e-4 * M ** 0.5)
+    assert torch.allclose(db.double(), want_b, rtol=1e-4, atol=1e-4 * M ** 0.5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,C", [(1, 8), (32, 4096), (127, 24), (128, 24), (5000, 520)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_colsum(dt, M, C, accumulate):
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    dev = "cuda:0"
+    X = torch.randn(M, C, generator=g).to(dev).to(dt)
+    out0 = torch.randn(C, generator=g).to(dev)
+    out = out0.clone()
+    ops.colsum(X, C, M, C, out, _code(dt), accumulate=accumulate)
+    want = X.double().sum(0) + (out0.double() if accumulate else 0)
+    assert torch.allclose(out.double(), want, rtol=1e-4, atol=1e-4 * M ** 0.5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_cast_and_pack(dt):
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(4)
+    dev = "cuda:0"
+    x = torch.randn(1000003, generator=g).to(dev)
+    assert torch.equal(ops.cast(x, _code(dt)), x.to(dt))
+    for shape in [(20, 12, 3), (64, 64, 3), (260, 132, 3), (7, 5, 1), (128, 256, 1)]:
+        w = torch.randn(shape, generator=g).to(dev)
+        for perm in [(0, 2, 1), (1, 2, 0)]:
+            want = w.permute(*perm).contiguous().to(dt)
+            assert torch.equal(ops.pack_weight(w, perm, _code(dt)), want)
+            out = torch.empty_like(want)
+            ops.pack_weights_into([(w, perm, out)], _code(dt))
+            assert torch.equal(out, want)
