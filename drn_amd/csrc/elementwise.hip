@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
     cs[k] = 0.f;
   }
   if (live) {
+#pragma unroll 4
     for (int t = ry; t < L; t += 8) {
       const long m = (long)s * L + t;
       float g[N], a[N];

@@ -29,49 +29,82 @@ __device__ __forceinline__ int head_group_of(const HeadParams& P, int r) {
   return g;
 }
 
-// out[r][n] (and z[r][n] in exp mode); r = concatenated row over levels
+// Work decomposition shared by the three kernels: a lane owns one 16-byte channel vector (its N x taps x VN weights live
+// in registers), a wavefront owns a run of consecutive rows of the level-concatenated row space.
+#define HEAD_RPW 8     // rows per wavefront (forward / data gradient)
+
+template <typename T>
+__device__ __forceinline__ void head_load_w(const float* __restrict__ W, int C, int taps, int N, int c0, bool live,
+                                            float (&wr)[HEAD_MAX_N][HEAD_MAX_TAPS][V16<T>::N]) {
+  constexpr int VN = V16<T>::N;
+#pragma unroll
+  for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp)
+#pragma unroll
+      for (int k = 0; k < VN; ++k) wr[n][tp][k] = (live && n < N && tp < taps) ? W[((long)n * C + c0 + k) * taps + tp] : 0.f;
+}
+
+// dz[r][n] = exp_mode ? scale_l * out[r][n] * dout[r][n] : dout[r][n]   (chain rule of exp(scale * z))
+__device__ __forceinline__ float head_dz(const HeadParams& P, const HeadGroup& G, const float* __restrict__ dout,
+                                         const float* __restrict__ out, long idx) {
+  const float d = dout[idx];
+  return P.exp_mode ? G.scale[0] * out[idx] * d : d;
+}
+
+// out[r][n] (and z[r][n] in exp mode); r = concatenated row over levels.  grid = ceil(rows / (4*HEAD_RPW)), block 256.
 template <typename T>
 __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, const float* __restrict__ W /*[N][C][taps]*/,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            float* __restrict__ z) {
-  extern __shared__ float wl[];  // [N][taps][C]
   constexpr int VN = V16<T>::N;
   const int N = P.N, C = P.C, taps = P.taps;
-  for (int i = threadIdx.x; i < N * taps * C; i += blockDim.x) {
-    const int c = i % C, tn = i / C, tap = tn % taps, n = tn / taps;
-    wl[i] = W[((long)n * C + c) * taps + tap];
-  }
-  __syncthreads();
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * HEAD_RPW;
+  if (r0 >= P.total_rows) return;
   const int nvec = C / VN;
-  for (int r = blockIdx.x * 4 + w; r < P.total_rows; r += gridDim.x * 4) {
-    const int g = head_group_of(P, r);
-    const HeadGroup& G = P.g[g];
-    const int m = r - G.row_start;
-    const int s = m / G.L, t = m - s * G.L;
-    const T* __restrict__ X = (const T*)G.X;
-    float acc[HEAD_MAX_N] = {0.f, 0.f};
-    for (int tap = 0; tap < taps; ++tap) {
-      const int st = t + tap - P.pad;
-      if (st < 0 || st >= G.L) continue;
-      const T* row = X + (long)(s * G.L + st) * G.ldx;
-      for (int v = l; v < nvec; v += 64) {
+  float acc[HEAD_RPW][HEAD_MAX_N];
+#pragma unroll
+  for (int i = 0; i < HEAD_RPW; ++i)
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) acc[i][n] = 0.f;
+  for (int vb = 0; vb < nvec; vb += 64) {
+    const int v = vb + lane;
+    const bool live = v < nvec;
+    float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
+    head_load_w<T>(W, C, taps, N, v * VN, live, wr);
+    if (!live) continue;
+#pragma unroll
+    for (int i = 0; i < HEAD_RPW; ++i) {
+      const int r = r0 + i;
+      if (r >= P.total_rows) break;
+      const HeadGroup& G = P.g[head_group_of(P, r)];
+      const int m = r - G.row_start;
+      const int s = m / G.L, t = m - s * G.L;
+      const T* __restrict__ X = (const T*)G.X;
+#pragma unroll
+      for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+        const int st = t + tp - P.pad;
+        if (tp >= taps || st < 0 || st >= G.L) continue;
         float x[VN];
-        V16<T>::load(row + v * VN, x);
+        V16<T>::load(X + (long)(s * G.L + st) * G.ldx + v * VN, x);
 #pragma unroll
         for (int n = 0; n < HEAD_MAX_N; ++n)
-          if (n < N) {
-            const float* wp = wl + (n * taps + tap) * C + v * VN;
 #pragma unroll
-            for (int k = 0; k < VN; ++k) acc[n] = fmaf(x[k], wp[k], acc[n]);
-          }
+          for (int k = 0; k < VN; ++k) acc[i][n] = fmaf(x[k], wr[n][tp][k], acc[i][n]);
       }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < HEAD_RPW; ++i) {
+    const int r = r0 + i;
+    if (r >= P.total_rows) break;
+    const HeadGroup& G = P.g[head_group_of(P, r)];
 #pragma unroll
     for (int n = 0; n < HEAD_MAX_N; ++n)
       if (n < N) {
-        float v = wave_sum(acc[n]) + bias[n];
-        if (l == 0) {
+        float v = wave_sum(acc[i][n]) + bias[n];
+        if (lane == 0) {
           if (P.exp_mode) {
             z[(long)r * N + n] = v;
             v = expf(G.scale[0] * v);
@@ -82,25 +115,23 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
   }
 }
 
-// dX[m][c] (+)= sum_n sum_tap dz[row(s, t - tap + pad)][n] * W[n][c][tap]
+// dX[m][c] (+)= sum_n sum_tap dz[row(s, t - tap + pad)][n] * W[n][c][tap].  grid (ceil(nvec/64), ceil(rows/(4*HEAD_RPW)))
 template <typename T>
 __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadParams P, const float* __restrict__ W,
-                                                                const float* __restrict__ dz, int accumulate) {
-  extern __shared__ float wl[];  // [N][taps][C]
+                                                                const float* __restrict__ dout, const float* __restrict__ out,
+                                                                int accumulate) {
   constexpr int VN = V16<T>::N;
   const int N = P.N, C = P.C, taps = P.taps;
-  for (int i = threadIdx.x; i < N * taps * C; i += blockDim.x) {
-    const int c = i % C, tn = i / C, tap = tn % taps, n = tn / taps;
-    wl[i] = W[((long)n * C + c) * taps + tap];
-  }
-  __syncthreads();
-  const int nvec = C / VN;
-  const long total = (long)P.total_rows * nvec;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % nvec);
-    const int r = (int)(i / nvec);
-    const int g = head_group_of(P, r);
-    const HeadGroup& G = P.g[g];
+  const int v = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * HEAD_RPW;
+  if (v * VN >= C || r0 >= P.total_rows) return;
+  float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
+  head_load_w<T>(W, C, taps, N, v * VN, true, wr);
+#pragma unroll 2
+  for (int i = 0; i < HEAD_RPW; ++i) {
+    const int r = r0 + i;
+    if (r >= P.total_rows) break;
+    const HeadGroup& G = P.g[head_group_of(P, r)];
     const int m = r - G.row_start;
     const int s = m / G.L, t = m - s * G.L;
     T* dst = (T*)G.dX + (long)m * G.ldx + v * VN;
@@ -110,35 +141,41 @@ __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadParams
 #pragma unroll
       for (int k = 0; k < VN; ++k) a[k] = 0.f;
     }
-    for (int tap = 0; tap < taps; ++tap) {
-      const int to = t - tap + P.pad;   // output position that read this input through `tap`
-      if (to < 0 || to >= G.L) continue;
-      const float* d = dz + (long)(G.row_start + s * G.L + to) * N;
+#pragma unroll
+    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+      const int to = t - tp + P.pad;   // output position that read this input through tap `tp`
+      if (tp >= taps || to < 0 || to >= G.L) continue;
+      const long ro = (long)(G.row_start + s * G.L + to) * N;
 #pragma unroll
       for (int n = 0; n < HEAD_MAX_N; ++n)
         if (n < N) {
-          const float dv = d[n];
-          const float* wp = wl + (n * taps + tap) * C + v * VN;
+          const float dv = head_dz(P, G, dout, out, ro + n);
 #pragma unroll
-          for (int k = 0; k < VN; ++k) a[k] = fmaf(dv, wp[k], a[k]);
+          for (int k = 0; k < VN; ++k) a[k] = fmaf(dv, wr[n][tp][k], a[k]);
         }
     }
     V16<T>::store(dst, a);
   }
 }
 
-// partial[blk][n][tap][c] = sum over the block's rows of dz[r][n] * X[src(r,tap)][c]
-// grid (ceil(nvec/64), nblk); block 256 = 64 channel vectors x 4 row lanes
+// partial[blk][...]: per row block, [n][tap][c] = sum_rows dz[r][n] * X[src(r,tap)][c], then 8 extras:
+// [0..1] = sum_rows dz[r][n] (bias gradient), [2..5] = per level sum z*out*dout (scale gradient, exp mode).
+// grid (ceil(nvec/64), nblk); block 1024 = 64 channel vectors x 16 row lanes
+#define HEAD_EXTRA 8
 template <typename T>
-__global__ __launch_bounds__(256) void head_out_bwd_w_kernel(const HeadParams P, const float* __restrict__ dz, float* __restrict__ partial) {
+__global__ __launch_bounds__(1024) void head_out_bwd_w_kernel(const HeadParams P, const float* __restrict__ dout,
+                                                              const float* __restrict__ out, const float* __restrict__ z,
+                                                              float* __restrict__ partial) {
   constexpr int VN = V16<T>::N;
-  __shared__ float red[4][64 * VN + 1];
+  __shared__ float red[16][64 * VN + 1];
   const int N = P.N, C = P.C, taps = P.taps;
   const int vx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int v = blockIdx.x * 64 + vx;
   const bool live = v * VN < C;
   const int rows_per = (P.total_rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(P.total_rows, r0 + rows_per);
+  const long pstride = (long)N * taps * C + HEAD_EXTRA;
+  float* prow = partial + (long)blockIdx.y * pstride;
   float acc[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
 #pragma unroll
   for (int n = 0; n < HEAD_MAX_N; ++n)
@@ -146,56 +183,81 @@ __global__ __launch_bounds__(256) void head_out_bwd_w_kernel(const HeadParams P,
     for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp)
 #pragma unroll
       for (int k = 0; k < VN; ++k) acc[n][tp][k] = 0.f;
-  if (live) {
-    for (int r = r0 + ry; r < r1; r += 4) {
-      const int g = head_group_of(P, r);
-      const HeadGroup& G = P.g[g];
-      const int m = r - G.row_start;
-      const int s = m / G.L, t = m - s * G.L;
-      const T* __restrict__ X = (const T*)G.X;
-      float d[HEAD_MAX_N];
+  float ex[HEAD_EXTRA];
 #pragma unroll
-      for (int n = 0; n < HEAD_MAX_N; ++n) d[n] = n < N ? dz[(long)r * N + n] : 0.f;
+  for (int k = 0; k < HEAD_EXTRA; ++k) ex[k] = 0.f;
+  for (int r = r0 + ry; r < r1; r += 16) {
+    const int g = head_group_of(P, r);
+    const HeadGroup& G = P.g[g];
+    const int m = r - G.row_start;
+    const int s = m / G.L, t = m - s * G.L;
+    const T* __restrict__ X = (const T*)G.X;
+    float d[HEAD_MAX_N];
 #pragma unroll
-      for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
-        if (tp >= taps) continue;
-        const int st = t + tp - P.pad;
-        if (st < 0 || st >= G.L) continue;
-        float x[VN];
-        V16<T>::load(X + (long)(s * G.L + st) * G.ldx + v * VN, x);
+    for (int n = 0; n < HEAD_MAX_N; ++n) {
+      d[n] = n < N ? head_dz(P, G, dout, out, (long)r * N + n) : 0.f;
+      ex[n] += d[n];
+      if (P.exp_mode && n < N) {
+        const float zz = z[(long)r * N + n] * out[(long)r * N + n] * dout[(long)r * N + n];
 #pragma unroll
-        for (int n = 0; n < HEAD_MAX_N; ++n)
-#pragma unroll
-          for (int k = 0; k < VN; ++k) acc[n][tp][k] = fmaf(d[n], x[k], acc[n][tp][k]);
+        for (int l = 0; l < DRN_MAX_GROUPS; ++l)
+          if (l == g) ex[2 + l] += zz;
       }
+    }
+    if (!live) continue;
+#pragma unroll
+    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+      const int st = t + tp - P.pad;
+      if (tp >= taps || st < 0 || st >= G.L) continue;
+      float x[VN];
+      V16<T>::load(X + (long)(s * G.L + st) * G.ldx + v * VN, x);
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+        for (int k = 0; k < VN; ++k) acc[n][tp][k] = fmaf(d[n], x[k], acc[n][tp][k]);
     }
   }
-  for (int n = 0; n < N; ++n)
-    for (int tp = 0; tp < taps; ++tp) {
+#pragma unroll
+  for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+      if (n >= N || tp >= taps) continue;          // uniform
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < VN; ++k) {
-        float val = 0.f;
-#pragma unroll
-        for (int nn = 0; nn < HEAD_MAX_N; ++nn)
-#pragma unroll
-          for (int tt = 0; tt < HEAD_MAX_TAPS; ++tt)
-            if (nn == n && tt == tp) val = acc[nn][tt][k];
-        red[ry][vx * VN + k] = val;
-      }
+      for (int k = 0; k < VN; ++k) red[ry][vx * VN + k] = acc[n][tp][k];
       __syncthreads();
-      for (int i = threadIdx.x; i < 64 * VN; i += 256) {
+      for (int i = threadIdx.x; i < 64 * VN; i += 1024) {
         const int c = blockIdx.x * 64 * VN + i;
-        if (c < C) partial[(((long)blockIdx.y * N + n) * taps + tp) * C + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        if (c < C) {
+          float sum = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sum += red[q][i];
+          prow[((long)n * taps + tp) * C + c] = sum;
+        }
       }
     }
+  if (blockIdx.x == 0) {   // every lane of a row lane saw the same rows: lane 0 of each speaks for it
+    __syncthreads();
+    if (vx == 0)
+#pragma unroll
+      for (int k = 0; k < HEAD_EXTRA; ++k) red[ry][k] = ex[k];
+    __syncthreads();
+    if (threadIdx.x < HEAD_EXTRA) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += red[q][threadIdx.x];
+      prow[(long)N * taps * C + threadIdx.x] = sum;
+    }
+  }
 }
 
-// dW[n][c][tap] (+)= sum_blk partial[blk][n][tap][c];  256 threads = 16 outputs x 16 lanes over the partial blocks
+// dW[n][c][tap] / dbias[n] / dscale[l] (+)= sum_blk partial[blk][...];  256 threads = 16 outputs x 16 lanes over the row blocks
 __global__ __launch_bounds__(256) void head_out_bwd_w_final_kernel(const float* __restrict__ partial, int nblk, int N, int C, int taps,
-                                                                   float* __restrict__ dW, int accumulate) {
+                                                                   int ngroups, int exp_mode, float* __restrict__ dW,
+                                                                   float* __restrict__ dbias, float* __restrict__ dscale,
+                                                                   int accumulate) {
   __shared__ float sh[16][17];
-  const int total = N * taps * C;
+  const int nw = N * taps * C, total = nw + HEAD_EXTRA;
   const int oi = threadIdx.x & 15, j = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + oi;
   float s = 0.f;
@@ -207,47 +269,21 @@ __global__ __launch_bounds__(256) void head_out_bwd_w_final_kernel(const float* 
   s = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s += sh[oi][k];
-  const int c = i % C, tn = i / C, tap = tn % taps, n = tn / taps;
-  float* dst = dW + ((long)n * C + c) * taps + tap;
+  float* dst;
+  if (i < nw) {
+    const int c = i % C, tn = i / C, tap = tn % taps, n = tn / taps;
+    dst = dW + ((long)n * C + c) * taps + tap;
+  } else {
+    const int e = i - nw;
+    if (e < 2) {
+      if (e >= N) return;
+      dst = dbias + e;
+    } else {
+      if (!exp_mode || e - 2 >= ngroups) return;
+      dst = dscale + (e - 2);
+    }
+  }
   *dst = accumulate ? *dst + s : s;
-}
-
-// exp-mode chain rule + bias gradients, one workgroup:
-//   dz[r][n] = exp_mode ? scale_l * out[r][n] * dout[r][n] : dout[r][n]
-//   dscale[l] (+)= sum_{r in level l} z * out * dout ;  dbias[n] (+)= sum_r dz[r][n]
-__global__ __launch_bounds__(1024) void head_out_bwd_pre_kernel(const HeadParams P, const float* __restrict__ dout,
-                                                                const float* __restrict__ out, const float* __restrict__ z,
-                                                                float* __restrict__ dz, float* __restrict__ dbias,
-                                                                float* __restrict__ dscale, int accumulate) {
-  __shared__ float sh[17];
-  const int N = P.N;
-  float db[HEAD_MAX_N] = {0.f, 0.f}, ds[DRN_MAX_GROUPS] = {0.f, 0.f, 0.f, 0.f};
-  for (int r = threadIdx.x; r < P.total_rows; r += blockDim.x) {
-    const int g = head_group_of(P, r);
-#pragma unroll
-    for (int n = 0; n < HEAD_MAX_N; ++n)
-      if (n < N) {
-        float d = dout[(long)r * N + n];
-        if (P.exp_mode) {
-          const float rd = out[(long)r * N + n] * d;
-#pragma unroll
-          for (int l = 0; l < DRN_MAX_GROUPS; ++l)
-            if (l == g) ds[l] += z[(long)r * N + n] * rd;
-          d = P.g[g].scale[0] * rd;
-        }
-        dz[(long)r * N + n] = d;
-        db[n] += d;
-      }
-  }
-#pragma unroll
-  for (int n = 0; n < HEAD_MAX_N; ++n) db[n] = block_sum(db[n], sh);
-#pragma unroll
-  for (int l = 0; l < DRN_MAX_GROUPS; ++l) ds[l] = block_sum(ds[l], sh);
-  if (threadIdx.x == 0) {
-    for (int n = 0; n < N; ++n) dbias[n] = accumulate ? dbias[n] + db[n] : db[n];
-    if (P.exp_mode)
-      for (int l = 0; l < P.ngroups; ++l) dscale[l] = accumulate ? dscale[l] + ds[l] : ds[l];
-  }
 }
 
 static int fill_head_params(HeadParams& P, const DrnHeadGroup* groups, int ngroups, int N, int C, int taps, int exp_mode, int dtype,
@@ -279,16 +315,14 @@ extern "C" int drn_head_out_fwd(const DrnHeadGroup* groups, int ngroups, const f
   int rc = fill_head_params(P, groups, ngroups, N, C, taps, exp_mode, dtype, false, "drn_head_out_fwd");
   if (rc) return rc;
   DRN_CHECK_ARG(W && bias && out && (!exp_mode || z), "drn_head_out_fwd: null pointer");
-  const size_t shm = (size_t)N * taps * C * sizeof(float);
-  int nb = cdiv(P.total_rows, 4);
-  if (nb > 1024) nb = 1024;
-  DISPATCH_DT(dtype, "drn_head_out_fwd", { head_out_fwd_kernel<T><<<nb, 256, shm, (hipStream_t)stream>>>(P, W, bias, out, z); });
+  const int nb = cdiv(P.total_rows, 4 * HEAD_RPW);
+  DISPATCH_DT(dtype, "drn_head_out_fwd", { head_out_fwd_kernel<T><<<nb, 256, 0, (hipStream_t)stream>>>(P, W, bias, out, z); });
   return drn_launch_status("drn_head_out_fwd");
 }
 
 extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const float* W, const float* dout, const float* out,
                                 const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
-                                float* dscale, int accumulate_dw, float* ws /* >= R*N + 64 + 256*N*taps*C floats */, int dtype,
+                                float* dscale, int accumulate_dw, float* ws /* >= 256*(N*taps*C + 8) floats */, int dtype,
                                 void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
@@ -296,17 +330,15 @@ extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const f
   int rc = fill_head_params(P, groups, ngroups, N, C, taps, exp_mode, dtype, true, "drn_head_out_bwd");
   if (rc) return rc;
   DRN_CHECK_ARG(W && dout && dW && dbias && ws && (!exp_mode || (out && z && dscale)), "drn_head_out_bwd: null pointer");
-  float* dz = ws;
-  float* part = ws + (((long)P.total_rows * N + 63) / 64) * 64;
-  const size_t shm = (size_t)N * taps * C * sizeof(float);
   const int nblk = P.total_rows >= 256 * 16 ? 256 : (P.total_rows >= 16 ? P.total_rows / 16 : 1);
-  head_out_bwd_pre_kernel<<<1, 1024, 0, stream>>>(P, dout, out, z, dz, dbias, dscale, accumulate_dw);
   DISPATCH_DT(dtype, "drn_head_out_bwd", {
     constexpr int VN = V16<T>::N;
-    head_out_bwd_data_kernel<T><<<ew_blocks((long)P.total_rows * (C / VN), 256, 2048), 256, shm, stream>>>(P, W, dz, accumulate_dx);
+    dim3 dgrid(cdiv(C / VN, 64), cdiv(P.total_rows, 4 * HEAD_RPW));
+    head_out_bwd_data_kernel<T><<<dgrid, 256, 0, stream>>>(P, W, dout, out, accumulate_dx);
     dim3 grid(cdiv(C / VN, 64), nblk);
-    head_out_bwd_w_kernel<T><<<grid, 256, 0, stream>>>(P, dz, part);
+    head_out_bwd_w_kernel<T><<<grid, 1024, 0, stream>>>(P, dout, out, z, ws);
   });
-  head_out_bwd_w_final_kernel<<<cdiv(N * taps * C, 16), 256, 0, stream>>>(part, nblk, N, C, taps, dW, accumulate_dw);
+  head_out_bwd_w_final_kernel<<<cdiv(N * taps * C + HEAD_EXTRA, 16), 256, 0, stream>>>(ws, nblk, N, C, taps, ngroups, exp_mode, dW,
+                                                                                          dbias, dscale, accumulate_dw);
   return drn_launch_status("drn_head_out_bwd");
 }

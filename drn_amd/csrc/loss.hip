@@ -147,16 +147,17 @@ __global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* _
   }
 }
 
-// gin[0..2]: upstream gradients of (loss_cls, loss_reg, loss_iou).  Outputs: dlogits[r], dreg[r][2], diou[r].
+// g_cls / g_reg / g_iou: upstream gradients (one float each, NULL = 0) of (loss_cls, loss_reg, loss_iou).  Outputs: dlogits[r], dreg[r][2], diou[r].
 __global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, const float* __restrict__ logits,
                                                                      const float* __restrict__ reg, const float* __restrict__ iou,
                                                                      const float* __restrict__ gt, const float* __restrict__ fwd_out,
-                                                                     const float* __restrict__ gin, float* __restrict__ dlogits,
+                                                                     const float* __restrict__ g_cls, const float* __restrict__ g_reg,
+                                                                     const float* __restrict__ g_iou, float* __restrict__ dlogits,
                                                                      float* __restrict__ dreg, float* __restrict__ diou) {
   const float n_pos = fwd_out[3], n_iou = fwd_out[4];
-  const float k_cls = gin[0] / (n_pos + (float)P.B);
-  const float k_reg = n_pos > 0.f ? gin[1] / n_pos : 0.f;
-  const float k_iou = (P.iou_stage && n_iou > 0.f) ? gin[2] / n_iou : 0.f;
+  const float k_cls = (g_cls ? g_cls[0] : 0.f) / (n_pos + (float)P.B);
+  const float k_reg = n_pos > 0.f ? (g_reg ? g_reg[0] : 0.f) / n_pos : 0.f;
+  const float k_iou = (P.iou_stage && n_iou > 0.f) ? (g_iou ? g_iou[0] : 0.f) / n_iou : 0.f;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P.total_rows; r += gridDim.x * blockDim.x) {
     const Loc q = locate(P, r);
     const float gs = gt[q.b * 2], ge = gt[q.b * 2 + 1];
@@ -233,14 +234,15 @@ extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B,
 
 extern "C" int drn_fcos_loss_bwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg,
                                  const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
-                                 const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream) {
+                                 const float* fwd_out5, const float* g_cls, const float* g_reg, const float* g_iou, float* dlogits,
+                                 float* dreg, float* diou, void* stream) {
   drn_clear_status();
   LossParams P;
   int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_bwd");
   if (rc) return rc;
-  DRN_CHECK_ARG(logits && reg && gt && fwd_out5 && grad_in3 && dlogits && dreg && (!iou_stage || (iou && diou)),
+  DRN_CHECK_ARG(logits && reg && gt && fwd_out5 && dlogits && dreg && (!iou_stage || (iou && diou)),
                 "drn_fcos_loss_bwd: null pointer");
-  fcos_loss_bwd_kernel<<<cdiv(P.total_rows, 256), 256, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, fwd_out5, grad_in3, dlogits,
+  fcos_loss_bwd_kernel<<<cdiv(P.total_rows, 256), 256, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, fwd_out5, g_cls, g_reg, g_iou, dlogits,
                                                                                  dreg, diou);
   return drn_launch_status("drn_fcos_loss_bwd");
 }

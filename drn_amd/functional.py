@@ -549,9 +549,12 @@ class _HeadOutFn(torch.autograd.Function):
             N, C, taps = W.shape
             c0 = meta["cols"][h]
             dout = douts[h]
-            dW = torch.zeros(W.shape, dtype=torch.float32, device=dev)
-            db = torch.zeros(N, dtype=torch.float32, device=dev)
-            dsc = torch.zeros(nl, dtype=torch.float32, device=dev) if scales is not None else None
+            if dout is not None:                         # the kernels write every element of the three gradients
+                dW, db = grad_buffer(W), grad_buffer(bias)
+                dsc = torch.empty(nl, dtype=torch.float32, device=dev) if scales is not None else None
+            else:
+                dW, db = torch.zeros_like(W), torch.zeros_like(bias)
+                dsc = torch.zeros(nl, dtype=torch.float32, device=dev) if scales is not None else None
             if dout is not None:
                 dout = dout.contiguous().float()
                 xsl = [(x[:, :, c0:c0 + C], g[3], g[0] * g[1], g[1]) for x, g in zip(xs, geo)]
@@ -580,7 +583,8 @@ def head_out(xs, heads, cols, dtype):
 
 class _FCOSLossFn(torch.autograd.Function):
     """Target assignment + focal / IoU / IoU-score losses (model/loss.py:40-239) in one kernel each way.
-    Returns (losses3, counts2): losses3 = [loss_cls, loss_reg, loss_iou], counts2 = [n_pos, n_iou_pos]."""
+    Returns (loss_cls, loss_reg, loss_iou, counts2), each loss of shape (1,), counts2 = [n_pos, n_iou_pos]; all four are
+    views of one 5-float result buffer (no per-loss slicing kernels in either direction)."""
 
     @staticmethod
     def forward(ctx, meta, logits, reg, iou, gt):
@@ -594,12 +598,12 @@ class _FCOSLossFn(torch.autograd.Function):
                           meta["iou_stage"], out5)
         ctx.meta = meta
         ctx.save_for_backward(logits, reg, iou if iou is not None else logits.new_empty(0), gt, out5)
-        counts = out5[3:5].clone()
+        counts = out5[3:5]
         ctx.mark_non_differentiable(counts)
-        return out5[:3].clone(), counts
+        return out5[0:1], out5[1:2], out5[2:3], counts
 
     @staticmethod
-    def backward(ctx, gl, _gc):
+    def backward(ctx, g_cls, g_reg, g_iou, _gc):
         meta = ctx.meta
         logits, reg, iou, gt, out5 = ctx.saved_tensors
         levels = ops.loss_levels(meta["levels"])
@@ -608,7 +612,8 @@ class _FCOSLossFn(torch.autograd.Function):
         dreg = torch.empty_like(reg)
         diou = torch.empty_like(iou) if has_iou else None
         ops.fcos_loss_bwd(levels, meta["B"], logits, reg, iou if has_iou else None, gt, meta["gamma"], meta["alpha"],
-                          meta["target_scale"], meta["iou_stage"], out5, gl.contiguous().float(), dlogits, dreg, diou)
+                          meta["target_scale"], meta["iou_stage"], out5,
+                          [None if g is None else g.contiguous().float() for g in (g_cls, g_reg, g_iou)], dlogits, dreg, diou)
         return None, dlogits, dreg, diou, None
 
 

@@ -129,6 +129,7 @@ class FCOSModule(torch.nn.Module):
         self.loss_evaluator = make_fcos_loss_evaluator(cfg)
         self.fpn_strides = cfg["fpn_stride"]
         self.loss_evaluator.fpn_strides = list(self.fpn_strides)
+        self._locations = {}
 
     def forward(self, features, targets=None):
         box_cls, box_regression, centerness, iou_scores = self.head(features)
@@ -152,8 +153,13 @@ class FCOSModule(torch.nn.Module):
         return [self.compute_locations_per_level(f.size(-1), self.fpn_strides[l], f.device) for l, f in enumerate(features)]
 
     def compute_locations_per_level(self, t, stride, device):
-        shifts_t = torch.arange(0, t * stride, step=stride, dtype=torch.float32, device=device)
-        return shifts_t.reshape(-1) + stride / 2
+        """model/fcos.py:232-241; constant per (length, stride), so built once per device."""
+        key = (int(t), stride, str(device))
+        loc = self._locations.get(key)
+        if loc is None:
+            shifts_t = torch.arange(0, t * stride, step=stride, dtype=torch.float32, device=device)
+            loc = self._locations[key] = shifts_t.reshape(-1) + stride / 2
+        return loc
 
 
 def build_fcos(cfg, in_channels):

@@ -238,7 +238,7 @@ def head_out_fwd(groups, W, bias, N, C, taps, exp_mode, out, z, dtype):
 
 
 def head_out_bwd(groups, W, dout, out, z, N, C, taps, exp_mode, accumulate_dx, dW, dbias, dscale, R, dtype):
-    ws = workspace(R * N + 64 + 256 * N * taps * C, dW.device)
+    ws = workspace(256 * (N * taps * C + 8), dW.device)
     check(lib().drn_head_out_bwd(groups, len(groups), _p(W), _p(dout), _p(out), _p(z), N, C, taps, int(exp_mode),
                                  int(accumulate_dx), _p(dW), _p(dbias), _p(dscale), 0, _p(ws), dtype, _stream()),
           "drn_head_out_bwd")
@@ -256,9 +256,10 @@ def fcos_loss_fwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, i
                                   _p(ws), _stream()), "drn_fcos_loss_fwd")
 
 
-def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, gin3, dlogits, dreg, diou):
+def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, g3, dlogits, dreg, diou):
+    """g3: upstream gradients (1-element fp32 tensors or None) of loss_cls, loss_reg, loss_iou."""
     check(lib().drn_fcos_loss_bwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
-                                  ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(gin3),
+                                  ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(g3[0]), _p(g3[1]), _p(g3[2]),
                                   _p(dlogits), _p(dreg), _p(diou), _stream()), "drn_fcos_loss_bwd")
 
 

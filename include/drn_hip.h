@@ -146,7 +146,7 @@ int drn_head_out_fwd(const DrnHeadGroup* groups /*host*/, int ngroups, const flo
  * dX (+)= conv^T(dz), dW/dbias/dscale (+)= ... over all levels. */
 int drn_head_out_bwd(const DrnHeadGroup* groups /*host*/, int ngroups, const float* W, const float* dout, const float* out,
                      const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
-                     float* dscale, int accumulate_dw, float* ws /* >= R*N + 64 + 256*N*taps*C floats */, int dtype, void* stream);
+                     float* dscale, int accumulate_dw, float* ws /* >= 256*(N*taps*C + 8) floats */, int dtype, void* stream);
 
 /* ---- losses (drn_amd/csrc/loss.hip; model/loss.py:40-239, model/layers/{iou_loss,sigmoid_focal_loss}.py) -- */
 typedef struct DrnLossLevel {
@@ -163,7 +163,8 @@ int drn_fcos_loss_fwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, c
                       float* out5, float* labels /*[R] or NULL*/, float* ws /* >= 5*ceil(R/256) floats */, void* stream);
 int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg,
                       const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
-                      const float* fwd_out5, const float* grad_in3, float* dlogits, float* dreg, float* diou, void* stream);
+                      const float* fwd_out5, const float* g_cls, const float* g_reg, const float* g_iou /* 1 float each, NULL = 0 */,
+                      float* dlogits, float* dreg, float* diou, void* stream);
 
 /* ---- language-guided pooling (drn_amd/csrc/lgp.hip; model/LGP.py:29-51) ---------------------------------------
  * x (B, t, C) channels-last, qn (B, C) fp32 = BN(conv1x1(query)) prepared by the caller, out (B, t/2, C),

@@ -46,7 +46,9 @@ def test_loss_fwd_bwd(B, T, stage, matched, seed):
     dev = torch.device("cuda:0")
     L_, R_, I_ = (flat(x).to(dev).requires_grad_() for x in (logits, reg, iou))
     levels = [(Ls[i], float(strides[i]), float(O.SIZES_OF_INTEREST[i][0]), float(O.SIZES_OF_INTEREST[i][1])) for i in range(3)]
-    losses, counts = DF.fcos_loss(L_, R_, I_, gt.to(dev), levels, B, 2.0, 0.25, 32.0, stage != 1)
+    l_cls, l_reg, l_iou, counts = DF.fcos_loss(L_, R_, I_, gt.to(dev), levels, B, 2.0, 0.25, 32.0, stage != 1)
+    assert l_cls.shape == l_reg.shape == l_iou.shape == (1,)
+    losses = torch.cat([l_cls, l_reg, l_iou])
     (losses * w.to(dev)).sum().backward()
     got = losses.detach().cpu().numpy()
     np.testing.assert_allclose(got[0], lc.item(), atol=1e-5)
