@@ -44,6 +44,10 @@ class PackDesc(ctypes.Structure):
                 ("A", c_int32), ("B", c_int32), ("C", c_int32)]
 
 
+class ColSeg(ctypes.Structure):
+    _fields_ = [("dst", c_void_p), ("col0", c_int32), ("n", c_int32)]
+
+
 class BnGroup(ctypes.Structure):
     _fields_ = [("stats", c_void_p), ("tiles", c_int32), ("M", c_int32), ("scale_shift", c_void_p), ("save", c_void_p)]
 

@@ -9,9 +9,12 @@
 // into the epilogue.  Padded positions (t >= len[b]) keep the state and emit zeros, which reproduces
 // pack_padded_sequence / pad_packed_sequence semantics for both directions.
 //
-// Layouts (fp32): xproj [2][L][B][4H] (gate order i,f,g,o as in PyTorch), Whh [2] pointers to [4H][H],
-// hseq / cseq [2][L+1][B][H] (slot 0 = zeros, slot s+1 = state after step s), gates [2][L][B][4H] (activated),
-// out [B][L][2H].  Step s handles t = s for the forward direction and t = L-1-s for the reverse one.
+// Layouts (fp32): xproj / gates / dgates [L][B][2][4H] indexed by TIME t and direction (gate order i,f,g,o as in
+// PyTorch) -- one (L*B) x 8H matrix, so the input projection and its weight / input gradients are single GEMMs over
+// both directions; Whh [2] pointers to [4H][H]; hseq / cseq [2][L+1][B][H] by STEP (slot s+1 = state after step s; slot 0
+// is never read, the initial state is zero); hprev_t [L][B][2][H] = hidden state that entered time t (operand of the
+// W_hh gradient); out [B][L][2H].  Step s handles t = s for the forward direction and t = L-1-s for the reverse one.
+// xproj holds x_t W_ih^T only: both bias vectors are added here.
 #include "common.h"
 #include "../../include/drn_hip.h"
 
@@ -27,7 +30,10 @@ struct LstmFwdArgs {
   float* cseq;
   float* gates;
   float* out;
-  const int* lengths;   // [B] int32
+  float* hprev_t;
+  const float* b_ih[2];
+  const float* b_hh[2];
+  const long long* lengths;   // [B] int64 (the dtype the data layer hands over)
   int B, L, H, s;
 };
 
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
 #pragma unroll
     for (int bt = 0; bt < NBT; ++bt) {
       const int bb = bt * 16 + row;
-      a[bt] = bb < B ? *(const f32x4*)(hprev + (long)bb * H + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      a[bt] = (bb < B && s > 0) ? *(const f32x4*)(hprev + (long)bb * H + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) b[g] = *(const f32x4*)(W + (long)(g * H + j0 + row) * H + k0 + kc);
@@ -83,32 +89,36 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float v = red[0][g * NBT + bt][l][r] + red[1][g * NBT + bt][l][r] + red[2][g * NBT + bt][l][r] + red[3][g * NBT + bt][l][r];
-        pre[g] = v + A.xproj[((long)(dir * L + t) * B + bb) * 4 * H + g * H + j];
+        pre[g] = v + A.xproj[(((long)t * B + bb) * 2 + dir) * 4 * H + g * H + j] + A.b_ih[dir][g * H + j] + A.b_hh[dir][g * H + j];
       }
       const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
       const long st_prev = ((long)(dir * (L + 1) + s) * B + bb) * H + j;
       const long st_new = ((long)(dir * (L + 1) + s + 1) * B + bb) * H + j;
-      const float cp = A.cseq[st_prev], hp = A.hseq[st_prev];
+      const float cp = s > 0 ? A.cseq[st_prev] : 0.f, hp = s > 0 ? A.hseq[st_prev] : 0.f;
       const float cn = fg * cp + ig * gg;
       const float hn = og * tanhf(cn);
       const bool valid = t < A.lengths[bb];
       A.cseq[st_new] = valid ? cn : cp;
       A.hseq[st_new] = valid ? hn : hp;
-      float* gs = A.gates + ((long)(dir * L + s) * B + bb) * 4 * H + j;
+      float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
       gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+      A.hprev_t[(((long)t * B + bb) * 2 + dir) * H + j] = hp;
       A.out[((long)bb * L + t) * 2 * H + dir * H + j] = valid ? hn : 0.f;
     }
   }
 }
 
-extern "C" int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, float* hseq, float* cseq, float* gates,
-                                 float* out, const int* lengths, int B, int L, int H, int s, void* stream) {
+extern "C" int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, const float* b_ih_f, const float* b_hh_f,
+                                 const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out,
+                                 float* hprev_t, const int64_t* lengths, int B, int L, int H, int s, void* stream) {
   drn_clear_status();
-  DRN_CHECK_ARG(xproj && Whh_f && Whh_r && hseq && cseq && gates && out && lengths, "drn_lstm_step_fwd: null pointer");
+  DRN_CHECK_ARG(xproj && Whh_f && Whh_r && b_ih_f && b_hh_f && b_ih_r && b_hh_r && hseq && cseq && gates && out && hprev_t && lengths,
+                "drn_lstm_step_fwd: null pointer");
   DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0 && s >= 0 && s < L, "drn_lstm_step_fwd: need B<=64, H%%64==0");
   LstmFwdArgs A;
   A.xproj = xproj; A.Whh[0] = Whh_f; A.Whh[1] = Whh_r; A.hseq = hseq; A.cseq = cseq; A.gates = gates; A.out = out;
-  A.lengths = lengths; A.B = B; A.L = L; A.H = H; A.s = s;
+  A.hprev_t = hprev_t; A.b_ih[0] = b_ih_f; A.b_hh[0] = b_hh_f; A.b_ih[1] = b_ih_r; A.b_hh[1] = b_hh_r;
+  A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
   dim3 grid(H / 16, 2);
   const int nbt = cdiv(B, 16);
   if (nbt == 1) lstm_step_fwd_kernel<1><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
@@ -123,11 +133,11 @@ struct LstmBwdArgs {
   const float* gates;    // activated i,f,g,o
   const float* cseq;
   const float* WhhT[2];  // [H][4H] = Whh^T (contiguous along the gate row index)
-  float* dgates;         // [2][L][B][4H]
+  float* dgates;         // [L][B][2][4H] by time
   float* dh;             // [2][B][H]  recurrent dL/dh entering step s (in/out)
   float* dc;             // [2][B][H]
   float* dh_pass;        // [2][B][H]  scratch
-  const int* lengths;
+  const long long* lengths;
   int B, L, H, s;
 };
 
@@ -140,14 +150,15 @@ __global__ void lstm_step_bwd_pointwise_kernel(const LstmBwdArgs A) {
     const int t = dir == 0 ? s : L - 1 - s;
     const bool valid = t < A.lengths[bb];
     const long sidx = ((long)dir * B + bb) * H + j;
-    float* dg = A.dgates + ((long)(dir * L + s) * B + bb) * 4 * H + j;
-    const float dh = A.dh[sidx] + (valid ? A.dout[((long)bb * L + t) * 2 * H + dir * H + j] : 0.f);
-    const float dcn = A.dc[sidx];
+    float* dg = A.dgates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+    const bool first = s == L - 1;                       // nothing flows in from beyond the last step
+    const float dh = (first ? 0.f : A.dh[sidx]) + (valid ? A.dout[((long)bb * L + t) * 2 * H + dir * H + j] : 0.f);
+    const float dcn = first ? 0.f : A.dc[sidx];
     if (valid) {
-      const float* gs = A.gates + ((long)(dir * L + s) * B + bb) * 4 * H + j;
+      const float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
       const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
       const float cn = A.cseq[((long)(dir * (L + 1) + s + 1) * B + bb) * H + j];
-      const float cp = A.cseq[((long)(dir * (L + 1) + s) * B + bb) * H + j];
+      const float cp = s > 0 ? A.cseq[((long)(dir * (L + 1) + s) * B + bb) * H + j] : 0.f;
       const float tc = tanhf(cn);
       const float dcv = dcn + dh * og * (1.f - tc * tc);
       dg[0] = dcv * gg * ig * (1.f - ig);
@@ -172,7 +183,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_gemm_kernel(const 
   const int dir = blockIdx.y, k0 = blockIdx.x * 16;
   const int B = A.B, L = A.L, H = A.H, s = A.s;
   const int K = 4 * H, kq = K / 4;
-  const float* dg = A.dgates + ((long)(dir * L + s) * B) * K;
+  const int t = dir == 0 ? s : L - 1 - s;
+  const float* dg = A.dgates + ((long)t * B * 2 + dir) * K;      // row bb at dg + bb * 2K
   const float* WT = A.WhhT[dir];
   f32x4 acc[NBT];
 #pragma unroll
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_gemm_kernel(const 
 #pragma unroll
     for (int bt = 0; bt < NBT; ++bt) {
       const int bb = bt * 16 + row;
-      a[bt] = bb < B ? *(const f32x4*)(dg + (long)bb * K + r0 + rc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      a[bt] = bb < B ? *(const f32x4*)(dg + (long)bb * 2 * K + r0 + rc) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const f32x4 b = *(const f32x4*)(WT + (long)(k0 + row) * K + r0 + rc);
 #pragma unroll
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_gemm_kernel(const 
 }
 
 extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const float* WhhT_f, const float* WhhT_r,
-                                 float* dgates, float* dh, float* dc, float* dh_pass, const int* lengths, int B, int L, int H, int s,
+                                 float* dgates, float* dh, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s,
                                  void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
@@ -215,7 +227,7 @@ extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const fl
   DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0 && s >= 0 && s < L, "drn_lstm_step_bwd: need B<=64, H%%64==0");
   LstmBwdArgs A;
   A.dout = dout; A.gates = gates; A.cseq = cseq; A.WhhT[0] = WhhT_f; A.WhhT[1] = WhhT_r; A.dgates = dgates; A.dh = dh; A.dc = dc;
-  A.dh_pass = dh_pass; A.lengths = lengths; A.B = B; A.L = L; A.H = H; A.s = s;
+  A.dh_pass = dh_pass; A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
   lstm_step_bwd_pointwise_kernel<<<cdiv(2 * B * H, 256), 256, 0, stream>>>(A);
   dim3 grid(H / 16, 2);
   const int nbt = cdiv(B, 16);

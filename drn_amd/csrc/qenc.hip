@@ -1,0 +1,284 @@
+// Query-encoder glue of the DRN path (model/language_module.py:17-63): everything around the LSTM recurrence
+// (lstm.hip) and the few dense products (library GEMMs issued by the caller) that used to be ~60 tiny framework
+// kernels per step: embedding gather / scatter, the [first ; last] sentence vector, and the three attention
+// "commands" (logits -> masked softmax -> weighted sum) with their backward.  All fp32, batch-sized work, one
+// workgroup per clip where a reduction over words or channels is needed; no atomics (bitwise reproducible).
+#include "common.h"
+#include "../../include/drn_hip.h"
+
+#define QE_MAX_L 64      // words per query (Charades-STA / ANet / TACoS queries are shorter after the data layer truncates them)
+#define QE_NCMD 3
+
+// ---------------------------------------------------------------- embedding
+// out_tm[t][b][:] = table[tokens[b][t]][:]   (time-major, the layout the input projection GEMM and the LSTM read)
+__global__ void qe_embed_fwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ table, float* __restrict__ out_tm,
+                                    int B, int L, int E) {
+  const long total = (long)L * B * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E);
+    const int tb = (int)(i / E);
+    const int b = tb % B, t = tb / B;
+    out_tm[i] = table[tokens[(long)b * L + t] * E + e];
+  }
+}
+extern "C" int drn_qe_embed_fwd(const int64_t* tokens, const float* table, float* out_tm, int B, int L, int E, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(tokens && table && out_tm && B > 0 && L > 0 && E > 0, "drn_qe_embed_fwd: bad args");
+  const long total = (long)L * B * E;
+  qe_embed_fwd_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>((const long long*)tokens, table, out_tm, B, L, E);
+  return drn_launch_status("drn_qe_embed_fwd");
+}
+
+// dtable[v][:] = sum over (b,t) with tokens[b][t] == v of demb_tm[t][b][:], row `padding_idx` = 0 (nn.Embedding(padding_idx));
+// one workgroup per vocabulary row scans the B*L tokens in order, so the sum order is fixed and the dense
+// gradient needs no zero-fill pass.
+__global__ __launch_bounds__(128) void qe_embed_bwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ demb_tm,
+                                                           float* __restrict__ dtable, int B, int L, int E, int padding_idx) {
+  __shared__ unsigned char hit[QE_MAX_L * 64];
+  const int v = blockIdx.x, n = B * L;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) hit[i] = (v != padding_idx && tokens[i] == v) ? 1 : 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i)
+      if (hit[i]) acc += demb_tm[((long)(i % L) * B + i / L) * E + e];      // (b,t) -> time-major row, in token order
+    dtable[(long)v * E + e] = acc;
+  }
+}
+extern "C" int drn_qe_embed_bwd(const int64_t* tokens, const float* demb_tm, float* dtable, int B, int L, int E, int V,
+                                int padding_idx, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(tokens && demb_tm && dtable && B > 0 && L > 0 && E > 0 && V > 0, "drn_qe_embed_bwd: bad args");
+  DRN_CHECK_ARG(B * L <= QE_MAX_L * 64, "drn_qe_embed_bwd: B*L > %d", QE_MAX_L * 64);
+  qe_embed_bwd_kernel<<<V, 128, 0, (hipStream_t)stream>>>((const long long*)tokens, demb_tm, dtable, B, L, E, padding_idx);
+  return drn_launch_status("drn_qe_embed_bwd");
+}
+
+// ---------------------------------------------------------------- [first ; last] sentence vector (language_module.py:48-54)
+// qvec[b] = [out[b][0][:], out[b][len_b - 1][:]]
+__global__ void qe_qvec_fwd_kernel(const float* __restrict__ out, const long long* __restrict__ lengths, float* __restrict__ qvec,
+                                   int B, int L, int C) {
+  const int total = B * 2 * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % C, half = (i / C) & 1, b = i / (2 * C);
+    const int t = half ? (int)lengths[b] - 1 : 0;
+    qvec[i] = out[((long)b * L + t) * C + c];
+  }
+}
+// dout[b][0] += dqvec[b][:C]; dout[b][len_b-1] += dqvec[b][C:]  (one thread does both, so len_b == 1 is race-free)
+__global__ void qe_qvec_bwd_kernel(const float* __restrict__ dqvec, const long long* __restrict__ lengths, float* __restrict__ dout,
+                                   int B, int L, int C) {
+  const int total = B * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % C, b = i / C;
+    const int t = (int)lengths[b] - 1;
+    dout[((long)b * L) * C + c] += dqvec[(long)b * 2 * C + c];
+    dout[((long)b * L + t) * C + c] += dqvec[(long)b * 2 * C + C + c];
+  }
+}
+extern "C" int drn_qe_qvec_fwd(const float* out, const int64_t* lengths, float* qvec, int B, int L, int C, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(out && lengths && qvec && B > 0 && L > 0 && C > 0, "drn_qe_qvec_fwd: bad args");
+  qe_qvec_fwd_kernel<<<cdiv(B * 2 * C, 256), 256, 0, (hipStream_t)stream>>>(out, (const long long*)lengths, qvec, B, L, C);
+  return drn_launch_status("drn_qe_qvec_fwd");
+}
+extern "C" int drn_qe_qvec_bwd(const float* dqvec, const int64_t* lengths, float* dout, int B, int L, int C, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(dqvec && lengths && dout && B > 0 && L > 0 && C > 0, "drn_qe_qvec_bwd: bad args");
+  qe_qvec_bwd_kernel<<<cdiv(B * C, 256), 256, 0, (hipStream_t)stream>>>(dqvec, (const long long*)lengths, dout, B, L, C);
+  return drn_launch_status("drn_qe_qvec_bwd");
+}
+
+// ---------------------------------------------------------------- attention commands (language_module.py:17-36)
+//   logit[b][t][l] = bias + sum_c q_cmd[b][t][c] * w[c] * out[b][l][c]      (cmd_inter2logits on q_cmd[:,None,:] * out)
+//   att[b][t][:]   = softmax over l < len_b (padded positions masked out)
+//   cmd[t][b][:]   = sum_l att[b][t][l] * out[b][l][:]
+// one workgroup (256 threads) per clip.
+__global__ __launch_bounds__(256) void qe_attn_fwd_kernel(const float* __restrict__ out, const float* __restrict__ qcmd,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const long long* __restrict__ lengths, float* __restrict__ att,
+                                                          float* __restrict__ cmds, int B, int L, int C) {
+  __shared__ float lg[QE_NCMD][QE_MAX_L];
+  const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int len = min((int)lengths[b], L);
+  const float* ob = out + (long)b * L * C;
+  const float* qb = qcmd + (long)b * QE_NCMD * C;
+  for (int p = wv; p < QE_NCMD * len; p += 4) {
+    const int t = p / len, l = p - t * len;
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(qb[t * C + c] * w[c], ob[(long)l * C + c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) lg[t][l] = acc + bias[0];
+  }
+  __syncthreads();
+  if (threadIdx.x < QE_NCMD) {
+    const int t = threadIdx.x;
+    float mx = -INFINITY;
+    for (int l = 0; l < len; ++l) mx = fmaxf(mx, lg[t][l]);
+    float sum = 0.f;
+    for (int l = 0; l < len; ++l) {
+      const float e = expf(lg[t][l] - mx);
+      lg[t][l] = e;
+      sum += e;
+    }
+    for (int l = 0; l < L; ++l) {
+      const float a = l < len ? lg[t][l] / sum : 0.f;
+      if (l < QE_MAX_L) lg[t][l] = a;
+      att[((long)b * QE_NCMD + t) * L + l] = a;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int l = 0; l < len; ++l) {
+      const float o = ob[(long)l * C + c];
+      a0 = fmaf(lg[0][l], o, a0);
+      a1 = fmaf(lg[1][l], o, a1);
+      a2 = fmaf(lg[2][l], o, a2);
+    }
+    cmds[((long)0 * B + b) * C + c] = a0;
+    cmds[((long)1 * B + b) * C + c] = a1;
+    cmds[((long)2 * B + b) * C + c] = a2;
+  }
+}
+extern "C" int drn_qe_attn_fwd(const float* out, const float* qcmd, const float* w, const float* bias, const int64_t* lengths,
+                               float* att, float* cmds, int B, int L, int C, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(out && qcmd && w && bias && lengths && att && cmds && B > 0 && C > 0, "drn_qe_attn_fwd: bad args");
+  DRN_CHECK_ARG(L > 0 && L <= QE_MAX_L, "drn_qe_attn_fwd: at most %d words per query", QE_MAX_L);
+  qe_attn_fwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(out, qcmd, w, bias, (const long long*)lengths, att, cmds, B, L, C);
+  return drn_launch_status("drn_qe_attn_fwd");
+}
+
+// backward of the block above for one clip per workgroup.  dcmd[t] may be NULL (= zero gradient).
+//   datt[t][l] = <dcmd[t][b], out[b][l]>;  dlog = att * (datt - sum_l att*datt)
+//   S[t][c] = sum_l dlog[t][l] * out[b][l][c]
+//   dqcmd[b][t][c] = w[c] * S[t][c];  dw_part[b][c] = sum_t qcmd[b][t][c] * S[t][c];  dbias_part[b] = sum_{t,l} dlog
+//   dout[b][l][c] = sum_t att[t][l] * dcmd[t][b][c] + dlog[t][l] * qcmd[b][t][c] * w[c]   (0 for l >= len_b)
+__global__ __launch_bounds__(256) void qe_attn_bwd_kernel(const float* __restrict__ dcmd0, const float* __restrict__ dcmd1,
+                                                          const float* __restrict__ dcmd2, const float* __restrict__ att,
+                                                          const float* __restrict__ out, const float* __restrict__ qcmd,
+                                                          const float* __restrict__ w, const long long* __restrict__ lengths,
+                                                          float* __restrict__ dqcmd, float* __restrict__ dout,
+                                                          float* __restrict__ dw_part, float* __restrict__ dbias_part, int B, int L,
+                                                          int C) {
+  __shared__ float at[QE_NCMD][QE_MAX_L], dl[QE_NCMD][QE_MAX_L];
+  const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int len = min((int)lengths[b], L);
+  const float* ob = out + (long)b * L * C;
+  const float* qb = qcmd + (long)b * QE_NCMD * C;
+  const float* dc[QE_NCMD] = {dcmd0 ? dcmd0 + (long)b * C : nullptr, dcmd1 ? dcmd1 + (long)b * C : nullptr,
+                              dcmd2 ? dcmd2 + (long)b * C : nullptr};
+  for (int i = threadIdx.x; i < QE_NCMD * QE_MAX_L; i += 256) {
+    const int t = i / QE_MAX_L, l = i % QE_MAX_L;
+    at[t][l] = l < len ? att[((long)b * QE_NCMD + t) * L + l] : 0.f;
+    dl[t][l] = 0.f;
+  }
+  __syncthreads();
+  for (int p = wv; p < QE_NCMD * len; p += 4) {
+    const int t = p / len, l = p - t * len;
+    float acc = 0.f;
+    if (dc[t])
+      for (int c = lane; c < C; c += 64) acc = fmaf(dc[t][c], ob[(long)l * C + c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) dl[t][l] = acc;          // datt for now
+  }
+  __syncthreads();
+  if (threadIdx.x < QE_NCMD) {
+    const int t = threadIdx.x;
+    float dot = 0.f;
+    for (int l = 0; l < len; ++l) dot = fmaf(at[t][l], dl[t][l], dot);
+    for (int l = 0; l < len; ++l) dl[t][l] = at[t][l] * (dl[t][l] - dot);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int t = 0; t < QE_NCMD; ++t)
+      for (int l = 0; l < len; ++l) s += dl[t][l];
+    dbias_part[b] = s;
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float wc = w[c];
+    float S[QE_NCMD] = {0.f, 0.f, 0.f}, q[QE_NCMD], d[QE_NCMD];
+#pragma unroll
+    for (int t = 0; t < QE_NCMD; ++t) {
+      q[t] = qb[t * C + c];
+      d[t] = dc[t] ? dc[t][c] : 0.f;
+    }
+    for (int l = 0; l < L; ++l) {
+      float g = 0.f;
+      if (l < len) {
+        const float o = ob[(long)l * C + c];
+#pragma unroll
+        for (int t = 0; t < QE_NCMD; ++t) {
+          S[t] = fmaf(dl[t][l], o, S[t]);
+          g = fmaf(at[t][l], d[t], g);
+          g = fmaf(dl[t][l] * q[t], wc, g);
+        }
+      }
+      dout[((long)b * L + l) * C + c] = g;
+    }
+    float dw = 0.f;
+#pragma unroll
+    for (int t = 0; t < QE_NCMD; ++t) {
+      dqcmd[((long)b * QE_NCMD + t) * C + c] = wc * S[t];
+      dw = fmaf(q[t], S[t], dw);
+    }
+    dw_part[(long)b * C + c] = dw;
+  }
+}
+extern "C" int drn_qe_attn_bwd(const float* dcmd0, const float* dcmd1, const float* dcmd2, const float* att, const float* out,
+                               const float* qcmd, const float* w, const int64_t* lengths, float* dqcmd, float* dout, float* dw_part,
+                               float* dbias_part, int B, int L, int C, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(att && out && qcmd && w && lengths && dqcmd && dout && dw_part && dbias_part && B > 0 && C > 0,
+                "drn_qe_attn_bwd: bad args");
+  DRN_CHECK_ARG(L > 0 && L <= QE_MAX_L, "drn_qe_attn_bwd: at most %d words per query", QE_MAX_L);
+  qe_attn_bwd_kernel<<<B, 256, 0, (hipStream_t)stream>>>(dcmd0, dcmd1, dcmd2, att, out, qcmd, w, (const long long*)lengths, dqcmd, dout,
+                                                          dw_part, dbias_part, B, L, C);
+  return drn_launch_status("drn_qe_attn_bwd");
+}
+
+// ---------------------------------------------------------------- column sums of an fp32 matrix into several destinations
+// seg s: dst[s][j] = sum_m X[m][col0[s] + j], j < n[s]  (bias gradients that live in different parameters; a column range
+// may appear twice, e.g. b_ih and b_hh of an LSTM receive the same gradient).  block 256 = 32 columns x 8 row lanes.
+struct ColSegParams {
+  float* dst[DRN_COLSEG_MAX];
+  int col0[DRN_COLSEG_MAX], n[DRN_COLSEG_MAX], blk0[DRN_COLSEG_MAX];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void colsum_segs_kernel(const float* __restrict__ X, int ld, int M, ColSegParams P) {
+  __shared__ float red[8][33];
+  int s = 0;
+  for (int i = 1; i < P.nseg; ++i)
+    if ((int)blockIdx.x >= P.blk0[i]) s = i;
+  const int jl = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int j = (blockIdx.x - P.blk0[s]) * 32 + jl;
+  float acc = 0.f;
+  if (j < P.n[s])
+#pragma unroll 4
+    for (int m = ry; m < M; m += 8) acc += X[(long)m * ld + P.col0[s] + j];
+  red[ry][jl] = acc;
+  __syncthreads();
+  if (ry == 0 && j < P.n[s]) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][jl];
+    P.dst[s][j] = t;
+  }
+}
+extern "C" int drn_colsum_segs(const float* X, int ld, int M, const DrnColSeg* segs, int nsegs, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(X && segs && M > 0 && nsegs > 0 && nsegs <= DRN_COLSEG_MAX, "drn_colsum_segs: bad args (at most %d segments)",
+                DRN_COLSEG_MAX);
+  ColSegParams P;
+  int blocks = 0;
+  for (int i = 0; i < nsegs; ++i) {
+    DRN_CHECK_ARG(segs[i].dst && segs[i].n > 0 && segs[i].col0 >= 0 && segs[i].col0 + segs[i].n <= ld, "drn_colsum_segs: bad segment %d", i);
+    P.dst[i] = segs[i].dst; P.col0[i] = segs[i].col0; P.n[i] = segs[i].n; P.blk0[i] = blocks;
+    blocks += cdiv(segs[i].n, 32);
+  }
+  P.nseg = nsegs;
+  colsum_segs_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, ld, M, P);
+  return drn_launch_status("drn_colsum_segs");
+}

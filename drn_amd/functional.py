@@ -50,6 +50,38 @@ def packed(w, perm, code):
     return out.view(out.shape[0], -1) if two_d else out
 
 
+_stack_cache = {}
+
+
+def _stack_items(out, params):
+    items, r = [], 0
+    for p in params:
+        n = p.shape[0]
+        src = p.detach().reshape(n, 1, -1) if p.dim() > 1 else p.detach().view(1, 1, n)
+        items.append((src, (0, 1, 2), out[r:r + n]))
+        r += n
+    return items
+
+
+def stacked(params):
+    """fp32 concatenation along dim 0 of several parameters (e.g. the three qInput{t} weights, W_ih of both LSTM
+    directions) so that one GEMM serves them all; built by one drn_pack_weights launch, cached on the parameter versions
+    and refreshed in place by repack_all().  Not differentiable: callers compute the per-parameter gradients themselves."""
+    key = tuple((id(p), p.data_ptr()) for p in params)
+    ver = (tuple(p._version for p in params), _weights_epoch)
+    hit = _stack_cache.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == params[0].device and all(r() is p for r, p in zip(hit[2], params)):
+        return hit[1]
+    shape = (sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:])
+    out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
+        torch.empty(shape, dtype=torch.float32, device=params[0].device)
+    ops.pack_weights_into(_stack_items(out, params), ops.F32)
+    if len(_stack_cache) > 64:
+        _stack_cache.clear()
+    _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
+    return out
+
+
 def repack_all():
     """Refresh every cached re-laid weight IN PLACE with one launch per dtype (drn_pack_weights) and mark it current:
     an optimizer that has just updated all parameters calls this instead of leaving ~20 small per-use launches to
@@ -61,10 +93,21 @@ def repack_all():
             del _pack_cache[key]
             continue
         by_code.setdefault(key[3], []).append((key, w, out))
+    stack_items = []
+    for key, (ver, out, refs) in list(_stack_cache.items()):
+        ps = [r() for r in refs]
+        if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key or out.device != ps[0].device:
+            del _stack_cache[key]
+            continue
+        stack_items += _stack_items(out, ps)
+        _stack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
     for code, items in by_code.items():
-        ops.pack_weights_into([(_w3(w), key[2], out) for key, w, out in items], code)
+        extra = stack_items if code == ops.F32 else []
+        ops.pack_weights_into([(_w3(w), key[2], out) for key, w, out in items] + extra, code)
         for key, w, out in items:
             _pack_cache[key] = ((w._version, _weights_epoch), out, weakref.ref(w))
+    if stack_items and ops.F32 not in by_code:
+        ops.pack_weights_into(stack_items, ops.F32)
 
 
 # Gradient sinks: drn_amd.dist.GradReducer registers, per parameter storage, the slice of its flat bucket where that
@@ -623,70 +666,164 @@ def fcos_loss(logits, reg, iou, gt, levels, B, gamma, alpha, target_scale, iou_s
     return _FCOSLossFn.apply(meta, logits, reg, iou if iou_stage else None, gt)
 
 
+def _lstm_forward(emb_tm, lens, lstm_params, B, L):
+    """emb_tm (L*B, E) time-major fp32.  Returns out (B, L, 2H) and the tensors backward needs."""
+    w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = lstm_params
+    H = w_hh_f.shape[1]
+    dev = emb_tm.device
+    wih_s = stacked([w_ih_f, w_ih_r])                                    # (8H, E): one input projection for both directions
+    xproj = torch.mm(emb_tm, wih_s.t())                                  # (L*B, 8H) = [L][B][2][4H]
+    hseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
+    cseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
+    gates = torch.empty((L, B, 2, 4 * H), dtype=torch.float32, device=dev)
+    hprev = torch.empty((L, B, 2, H), dtype=torch.float32, device=dev)
+    out = torch.empty((B, L, 2 * H), dtype=torch.float32, device=dev)
+    biases = (b_ih_f.detach(), b_hh_f.detach(), b_ih_r.detach(), b_hh_r.detach())
+    whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
+    for s in range(L):
+        ops.lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev, lens, B, L, H, s)
+    return out, (cseq, gates, hprev)
+
+
+def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L):
+    """dout (B, L, 2H) contiguous fp32.  Returns (demb_tm (L*B, E), the eight parameter gradients); weight gradients
+    land in the reducer's flat buckets when sinks are registered."""
+    w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = lstm_params
+    cseq, gates, hprev = saved
+    H = w_hh_f.shape[1]
+    dev = dout.device
+    wtf, wtr = packed(w_hh_f, (1, 2, 0), ops.F32), packed(w_hh_r, (1, 2, 0), ops.F32)      # W_hh^T, cached
+    dgates = torch.empty((L, B, 2, 4 * H), dtype=torch.float32, device=dev)
+    scratch = torch.empty((3, 2, B, H), dtype=torch.float32, device=dev)
+    for s in range(L - 1, -1, -1):
+        ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], scratch[2], lens, B, L, H, s)
+    dg = dgates.view(L * B, 8 * H)
+    hp = hprev.view(L * B, 2 * H)
+    dwih_f = torch.mm(dg[:, :4 * H].t(), emb_tm, out=grad_buffer(w_ih_f))
+    dwih_r = torch.mm(dg[:, 4 * H:].t(), emb_tm, out=grad_buffer(w_ih_r))
+    dwhh_f = torch.mm(dg[:, :4 * H].t(), hp[:, :H], out=grad_buffer(w_hh_f))
+    dwhh_r = torch.mm(dg[:, 4 * H:].t(), hp[:, H:], out=grad_buffer(w_hh_r))
+    dbs = [grad_buffer(b) for b in (b_ih_f, b_hh_f, b_ih_r, b_hh_r)]
+    ops.colsum_segs(dg, 8 * H, L * B, [(dbs[0], 0, 4 * H), (dbs[1], 0, 4 * H), (dbs[2], 4 * H, 4 * H), (dbs[3], 4 * H, 4 * H)])
+    demb_tm = torch.mm(dg, stacked([w_ih_f, w_ih_r]))
+    return demb_tm, (dwih_f, dwhh_f, dbs[0], dbs[1], dwih_r, dwhh_r, dbs[2], dbs[3])
+
+
+def _dev_lengths(lengths, dev):
+    if lengths.device != dev or lengths.dtype != torch.int64:
+        lengths = lengths.to(device=dev, dtype=torch.int64)
+    return lengths.contiguous()
+
+
 class _BiLSTMFn(torch.autograd.Function):
     """Bidirectional 1-layer LSTM over padded sequences with device-side lengths (model/language_module.py:38-45:
-    pack_padded_sequence -> nn.LSTM -> pad_packed_sequence).  The input projections and the weight-gradient products
+    pack_padded_sequence -> nn.LSTM -> pad_packed_sequence).  The input projection and the weight-gradient products
     are plain library GEMMs (tiny); the recurrence runs in drn_amd/csrc/lstm.hip, one launch per time step."""
 
     @staticmethod
-    def forward(ctx, emb, lengths, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, emb, lengths, *lstm_params):
         B, L, E = emb.shape
-        H = w_hh_f.shape[1]
-        dev = emb.device
         emb_tm = emb.detach().transpose(0, 1).reshape(L * B, E).float()
-        xproj = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
-        torch.addmm((b_ih_f + b_hh_f).detach(), emb_tm, w_ih_f.detach().t(), out=xproj[0].view(L * B, 4 * H))
-        torch.addmm((b_ih_r + b_hh_r).detach(), emb_tm, w_ih_r.detach().t(), out=xproj[1].view(L * B, 4 * H))
-        hseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
-        cseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
-        hseq[:, 0].zero_()
-        cseq[:, 0].zero_()
-        gates = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
-        out = torch.empty((B, L, 2 * H), dtype=torch.float32, device=dev)
-        lens = lengths.to(torch.int32).contiguous()
-        whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
-        for s in range(L):
-            ops.lstm_step_fwd(xproj, whf, whr, hseq, cseq, gates, out, lens, B, L, H, s)
-        ctx.dims = (B, L, E, H)
-        ctx.param_refs = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
-        ctx.save_for_backward(emb_tm, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, hseq, cseq, gates)
+        lens = _dev_lengths(lengths, emb.device)
+        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L)
+        ctx.dims = (B, L, E)
+        ctx.lstm_params = lstm_params
+        ctx.save_for_backward(emb_tm, lens, *saved)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        B, L, E, H = ctx.dims
-        emb_tm, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, hseq, cseq, gates = ctx.saved_tensors
-        dev = emb_tm.device
-        dout = dout.contiguous().float()
-        wtf, wtr = w_hh_f.t().contiguous(), w_hh_r.t().contiguous()
-        dgates = torch.empty((2, L, B, 4 * H), dtype=torch.float32, device=dev)
-        dh = torch.zeros((2, B, H), dtype=torch.float32, device=dev)
-        dc = torch.zeros((2, B, H), dtype=torch.float32, device=dev)
-        dh_pass = torch.empty((2, B, H), dtype=torch.float32, device=dev)
-        for s in range(L - 1, -1, -1):
-            ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dh, dc, dh_pass, lens, B, L, H, s)
-        dgf, dgr = dgates[0].view(L * B, 4 * H), dgates[1].view(L * B, 4 * H)
-        # the reverse direction's step s sits at time L-1-s
-        emb_rev = emb_tm.view(L, B, E).flip(0).reshape(L * B, E)
-        wihf, whhf, bihf, bhhf, wihr, whhr, bihr, bhhr = ctx.param_refs
-        # weight gradients go straight into the reducer's flat buckets when sinks are registered
-        dwih_f = torch.mm(dgf.t(), emb_tm, out=grad_buffer(wihf))
-        dwih_r = torch.mm(dgr.t(), emb_rev, out=grad_buffer(wihr))
-        dwhh_f = torch.mm(dgf.t(), hseq[0, :L].reshape(L * B, H), out=grad_buffer(whhf))
-        dwhh_r = torch.mm(dgr.t(), hseq[1, :L].reshape(L * B, H), out=grad_buffer(whhr))
-        db_f = torch.sum(dgf, 0, out=grad_buffer(bihf))
-        db_r = torch.sum(dgr, 0, out=grad_buffer(bihr))
-        db_f2 = grad_buffer(bhhf).copy_(db_f)
-        db_r2 = grad_buffer(bhhr).copy_(db_r)
-        demb = (dgf @ w_ih_f).view(L, B, E) + (dgr @ w_ih_r).view(L, B, E).flip(0)
-        return demb.transpose(0, 1), None, dwih_f, dwhh_f, db_f, db_f2, dwih_r, dwhh_r, db_r, db_r2
+        B, L, E = ctx.dims
+        emb_tm, lens = ctx.saved_tensors[:2]
+        demb_tm, grads = _lstm_backward(dout.contiguous().float(), emb_tm, lens, ctx.lstm_params, ctx.saved_tensors[2:], B, L)
+        return (demb_tm.view(L, B, E).transpose(0, 1), None) + grads
 
 
 def bilstm(emb, lengths, lstm):
     """lstm: an nn.LSTM(num_layers=1, bidirectional=True, batch_first=True) used as a parameter holder."""
-    return _BiLSTMFn.apply(emb, lengths, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
-                           lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
-                           lstm.bias_hh_l0_reverse)
+    return _BiLSTMFn.apply(emb, lengths, *_lstm_param_list(lstm))
+
+
+def _lstm_param_list(lstm):
+    return (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+            lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)
+
+
+class _QueryEncoderFn(torch.autograd.Function):
+    """The whole query encoder (model/language_module.py:38-63 + 17-36) as one autograd node: embedding lookup, BiLSTM,
+    [first ; last] sentence vector, qInput + ReLU, the three qInput{t} projections and the three attention commands.
+    Dense products are library GEMMs on stacked weights; everything else is drn_amd/csrc/{lstm,qenc}.hip.  Every
+    parameter gradient is written by a kernel straight into its final buffer (no autograd glue kernels)."""
+
+    @staticmethod
+    def forward(ctx, tokens, lengths, table, *params):
+        lstm_params, (Wq, bq, W0, b0, W1, b1, W2, b2, wl, bl) = params[:8], params[8:]
+        B, L = tokens.shape
+        E = table.shape[1]
+        H = lstm_params[1].shape[1]
+        C = 2 * H
+        dev = table.device
+        tokens = tokens.to(device=dev, dtype=torch.int64).contiguous()
+        lens = _dev_lengths(lengths, dev)
+        emb_tm = torch.empty((L * B, E), dtype=torch.float32, device=dev)
+        ops.qe_embed_fwd(tokens, table.detach(), emb_tm, B, L, E)
+        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L)
+        qvec = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
+        ops.qe_qvec_fwd(out, lens, qvec, B, L, C)                          # language_module.py:48-54
+        base = torch.addmm(bq.detach(), qvec, Wq.detach().t()).relu_()     # language_module.py:55-56
+        qcmd = torch.addmm(stacked([b0, b1, b2]), base, stacked([W0, W1, W2]).t())     # (B, 3*C): all three qInput{t}
+        att = torch.empty((B, 3, L), dtype=torch.float32, device=dev)
+        cmds = torch.empty((3, B, C), dtype=torch.float32, device=dev)
+        ops.qe_attn_fwd(out, qcmd, wl.detach(), bl.detach(), lens, att, cmds, B, L, C)
+        ctx.dims = (B, L, E, H)
+        ctx.params = params
+        ctx.table = table
+        ctx.save_for_backward(tokens, lens, emb_tm, out, qvec, base, qcmd, att, *saved)
+        return cmds[0], cmds[1], cmds[2]
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        B, L, E, H = ctx.dims
+        C = 2 * H
+        tokens, lens, emb_tm, out, qvec, base, qcmd, att = ctx.saved_tensors[:8]
+        params = ctx.params
+        lstm_params, (Wq, bq, W0, b0, W1, b1, W2, b2, wl, bl) = params[:8], params[8:]
+        dev = out.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dcmds = [None if d is None else d.contiguous().float() for d in (d0, d1, d2)]
+        dqcmd, dout = torch.empty((B, 3 * C), **f32), torch.empty((B, L, C), **f32)
+        dw_part, db_part = torch.empty((B, C), **f32), torch.empty((B, 1), **f32)
+        ops.qe_attn_bwd(dcmds, att, out, qcmd, wl.detach(), lens, dqcmd, dout, dw_part, db_part, B, L, C)
+        dwl, dbl = grad_buffer(wl), grad_buffer(bl)
+        ops.colsum_segs(dw_part, C, B, [(dwl, 0, C)])
+        ops.colsum_segs(db_part, 1, B, [(dbl, 0, 1)])
+        # qInput{t}: q_cmd_t = base W_t^T + b_t
+        dbase = torch.mm(dqcmd, stacked([W0, W1, W2]))
+        dW = [torch.mm(dqcmd[:, t * C:(t + 1) * C].t(), base, out=grad_buffer(W)) for t, W in enumerate((W0, W1, W2))]
+        db = [grad_buffer(b) for b in (b0, b1, b2)]
+        ops.colsum_segs(dqcmd, 3 * C, B, [(db[t], t * C, C) for t in range(3)])
+        # qInput + ReLU
+        dpre = torch.ops.aten.threshold_backward(dbase, base, 0)
+        dqvec = torch.mm(dpre, Wq.detach())
+        dWq = torch.mm(dpre.t(), qvec, out=grad_buffer(Wq))
+        dbq = grad_buffer(bq)
+        ops.colsum_segs(dpre, H, B, [(dbq, 0, H)])
+        ops.qe_qvec_bwd(dqvec, lens, dout, B, L, C)
+        demb_tm, lstm_grads = _lstm_backward(dout, emb_tm, lens, lstm_params, ctx.saved_tensors[8:], B, L)
+        table = ctx.table
+        dtable = grad_buffer(table)
+        ops.qe_embed_bwd(tokens, demb_tm, dtable, B, L, E, table.shape[0], 0)      # nn.Embedding(padding_idx=0)
+        return (None, None, dtable) + lstm_grads + (dWq, dbq, dW[0], db[0], dW[1], db[1], dW[2], db[2], dwl, dbl)
+
+
+def query_encoder(tokens, lengths, enc):
+    """enc: drn_amd.model.language_module.QueryEncoder (parameter holder).  Returns the three (B, 2H) commands."""
+    if enc.embedding.padding_idx != 0:
+        raise DrnError("query encoder kernels assume nn.Embedding(padding_idx=0) (model/language_module.py:13)")
+    return _QueryEncoderFn.apply(tokens, lengths, enc.embedding.weight, *_lstm_param_list(enc.biLSTM),
+                                 enc.qInput.weight, enc.qInput.bias, enc.qInput0.weight, enc.qInput0.bias,
+                                 enc.qInput1.weight, enc.qInput1.bias, enc.qInput2.weight, enc.qInput2.bias,
+                                 enc.cmd_inter2logits.weight, enc.cmd_inter2logits.bias)
 
 
 class _LGPFn(torch.autograd.Function):

@@ -266,15 +266,55 @@ def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, i
 # ---------------------------------------------------------------------------------------------
 # query-encoder LSTM recurrence
 # ---------------------------------------------------------------------------------------------
-def lstm_step_fwd(xproj, whf, whr, hseq, cseq, gates, out, lens, B, L, H, s):
+def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens, B, L, H, s):
+    """biases = (b_ih_f, b_hh_f, b_ih_r, b_hh_r); lens int64 on the device; layouts in include/drn_hip.h."""
     _need_gpu(xproj, out)
-    check(lib().drn_lstm_step_fwd(_p(xproj), _p(whf), _p(whr), _p(hseq), _p(cseq), _p(gates), _p(out), _p(lens), B, L, H, s,
-                                  _stream()), "drn_lstm_step_fwd")
+    check(lib().drn_lstm_step_fwd(_p(xproj), _p(whf), _p(whr), _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(biases[3]),
+                                  _p(hseq), _p(cseq), _p(gates), _p(out), _p(hprev_t), _p(lens), B, L, H, s, _stream()),
+          "drn_lstm_step_fwd")
 
 
 def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dh, dc, dh_pass, lens, B, L, H, s):
     check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), _p(dgates), _p(dh), _p(dc), _p(dh_pass),
                                   _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# query-encoder glue (drn_amd/csrc/qenc.hip)
+# ---------------------------------------------------------------------------------------------
+def qe_embed_fwd(tokens, table, out_tm, B, L, E):
+    _need_gpu(tokens, table, out_tm)
+    check(lib().drn_qe_embed_fwd(_p(tokens), _p(table), _p(out_tm), B, L, E, _stream()), "drn_qe_embed_fwd")
+
+
+def qe_embed_bwd(tokens, demb_tm, dtable, B, L, E, V, padding_idx):
+    check(lib().drn_qe_embed_bwd(_p(tokens), _p(demb_tm), _p(dtable), B, L, E, V, padding_idx, _stream()), "drn_qe_embed_bwd")
+
+
+def qe_qvec_fwd(out, lens, qvec, B, L, C):
+    check(lib().drn_qe_qvec_fwd(_p(out), _p(lens), _p(qvec), B, L, C, _stream()), "drn_qe_qvec_fwd")
+
+
+def qe_qvec_bwd(dqvec, lens, dout, B, L, C):
+    check(lib().drn_qe_qvec_bwd(_p(dqvec), _p(lens), _p(dout), B, L, C, _stream()), "drn_qe_qvec_bwd")
+
+
+def qe_attn_fwd(out, qcmd, w, bias, lens, att, cmds, B, L, C):
+    _need_gpu(out, qcmd, cmds)
+    check(lib().drn_qe_attn_fwd(_p(out), _p(qcmd), _p(w), _p(bias), _p(lens), _p(att), _p(cmds), B, L, C, _stream()),
+          "drn_qe_attn_fwd")
+
+
+def qe_attn_bwd(dcmds, att, out, qcmd, w, lens, dqcmd, dout, dw_part, dbias_part, B, L, C):
+    check(lib().drn_qe_attn_bwd(_p(dcmds[0]), _p(dcmds[1]), _p(dcmds[2]), _p(att), _p(out), _p(qcmd), _p(w), _p(lens), _p(dqcmd),
+                                _p(dout), _p(dw_part), _p(dbias_part), B, L, C, _stream()), "drn_qe_attn_bwd")
+
+
+def colsum_segs(X, ld, M, segs):
+    """segs: [(dst fp32 tensor, first column, columns)]: dst[j] = sum_m X[m][col0 + j]."""
+    _need_gpu(X)
+    arr = (_lib.ColSeg * len(segs))(*[_lib.ColSeg(dst=_p(d), col0=c0, n=n) for d, c0, n in segs])
+    check(lib().drn_colsum_segs(_p(X), ld, M, arr, len(segs), _stream()), "drn_colsum_segs")
 
 
 # ---------------------------------------------------------------------------------------------

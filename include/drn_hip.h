@@ -166,6 +166,31 @@ int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, c
                       const float* fwd_out5, const float* g_cls, const float* g_reg, const float* g_iou /* 1 float each, NULL = 0 */,
                       float* dlogits, float* dreg, float* diou, void* stream);
 
+/* ---- query-encoder glue (drn_amd/csrc/qenc.hip; model/language_module.py:17-63), all fp32 ----------------------
+ * Word embedding lookup written time-major (L, B, E) and its dense gradient (row padding_idx stays zero). */
+int drn_qe_embed_fwd(const int64_t* tokens /*[B][L]*/, const float* table /*[V][E]*/, float* out_tm, int B, int L, int E, void* stream);
+int drn_qe_embed_bwd(const int64_t* tokens, const float* demb_tm, float* dtable /*[V][E], fully written*/, int B, int L, int E, int V,
+                     int padding_idx, void* stream);
+/* q_vector = [output[b][0] ; output[b][len_b-1]] (language_module.py:48-54); bwd ADDS into dout (B, L, C). */
+int drn_qe_qvec_fwd(const float* out /*[B][L][C]*/, const int64_t* lengths, float* qvec /*[B][2C]*/, int B, int L, int C, void* stream);
+int drn_qe_qvec_bwd(const float* dqvec, const int64_t* lengths, float* dout, int B, int L, int C, void* stream);
+/* The three attention "commands" (language_module.py:17-36): logits = cmd_inter2logits(q_cmd[:,None,:] * output),
+ * softmax over the words of each query (padding masked), cmd = att @ output.  qcmd (B,3,C), att (B,3,L), cmds (3,B,C).
+ * bwd: dcmd0..2 (B,C) each or NULL; writes dqcmd (B,3,C), dout (B,L,C) and per-clip partials dw_part (B,C), dbias_part (B)
+ * of the cmd_inter2logits weight / bias gradients (sum them over B). */
+int drn_qe_attn_fwd(const float* out, const float* qcmd, const float* w /*[C]*/, const float* bias /*[1]*/, const int64_t* lengths,
+                    float* att, float* cmds, int B, int L, int C, void* stream);
+int drn_qe_attn_bwd(const float* dcmd0, const float* dcmd1, const float* dcmd2, const float* att, const float* out, const float* qcmd,
+                    const float* w, const int64_t* lengths, float* dqcmd, float* dout, float* dw_part, float* dbias_part, int B, int L,
+                    int C, void* stream);
+/* dst_s[j] = sum_m X[m][col0_s + j] for up to DRN_COLSEG_MAX column ranges of one fp32 matrix (bias gradients). */
+#define DRN_COLSEG_MAX 8
+typedef struct {
+  float* dst;
+  int32_t col0, n;
+} DrnColSeg;
+int drn_colsum_segs(const float* X, int ld, int M, const DrnColSeg* segs /*host*/, int nsegs, void* stream);
+
 /* ---- language-guided pooling (drn_amd/csrc/lgp.hip; model/LGP.py:29-51) ---------------------------------------
  * x (B, t, C) channels-last, qn (B, C) fp32 = BN(conv1x1(query)) prepared by the caller, out (B, t/2, C),
  * att (B, t/2, 2) fp32 (saved for backward).  C <= 2048 (bf16) / 1024 (f32). */
@@ -176,17 +201,20 @@ int drn_lgp_bwd(const void* x, int ldx, const float* qn, const float* att, const
                 float* dqn, float* ws, int B, int t, int C, int dtype, void* stream);
 
 /* ---- query-encoder BiLSTM recurrence (drn_amd/csrc/lstm.hip; model/language_module.py:13-15,38-45) ------------
- * One launch per time step for both directions; sequence lengths on the device (replaces pack_padded_sequence +
- * the cuDNN/MIOpen RNN).  fp32.  xproj [2][L][B][4H] = x_t W_ih^T + b_ih + b_hh (gate order i,f,g,o);
- * hseq/cseq [2][L+1][B][H] (slot 0 zero-filled by the caller); gates [2][L][B][4H]; out [B][L][2H].
- * Step s handles t = s (forward direction) and t = L-1-s (reverse).  B <= 64, H % 64 == 0. */
-int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, float* hseq, float* cseq, float* gates,
-                      float* out, const int* lengths, int B, int L, int H, int s, void* stream);
-/* Backward of step s (call with s = L-1 .. 0): consumes dout [B][L][2H] and the running dh/dc [2][B][H] (zero-filled
- * before the first call), writes dgates [2][L][B][4H] (for the weight-gradient GEMMs) and the new dh/dc.
- * WhhT_* = Whh^T as [H][4H]; dh_pass is [2][B][H] scratch. */
+ * One launch per time step for both directions; sequence lengths (int64) on the device (replaces pack_padded_sequence +
+ * the cuDNN/MIOpen RNN).  fp32, gate order i,f,g,o.  xproj / gates / dgates are [L][B][2][4H] indexed by time and
+ * direction (one (L*B) x 8H matrix); xproj = x_t W_ih^T without biases (b_ih + b_hh are added here); hseq/cseq
+ * [2][L+1][B][H] by step (slot 0 is never read: zero initial state); hprev_t [L][B][2][H] = hidden state that entered
+ * time t (operand of the W_hh gradient); out [B][L][2H].  Step s handles t = s (forward direction) and t = L-1-s
+ * (reverse).  B <= 64, H % 64 == 0. */
+int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, const float* b_ih_f, const float* b_hh_f,
+                      const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out, float* hprev_t,
+                      const int64_t* lengths, int B, int L, int H, int s, void* stream);
+/* Backward of step s (call with s = L-1 .. 0): consumes dout [B][L][2H] and the running dh/dc [2][B][H] (ignored at
+ * s = L-1), writes dgates (for the weight-gradient GEMMs) and the new dh/dc.  WhhT_* = Whh^T as [H][4H]; dh_pass is
+ * [2][B][H] scratch. */
 int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const float* WhhT_f, const float* WhhT_r,
-                      float* dgates, float* dh, float* dc, float* dh_pass, const int* lengths, int B, int L, int H, int s,
+                      float* dgates, float* dh, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s,
                       void* stream);
 
 /* ---- fused clip_grad_norm_ + Adam over flat gradient buckets (drn_amd/csrc/optim.hip; main.py:140,238-243) ---- */
