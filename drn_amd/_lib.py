@@ -30,7 +30,7 @@ class GemmDesc(ctypes.Structure):
                 ("Cin", c_int32), ("taps", c_int32), ("stride", c_int32), ("pad", c_int32), ("mode", c_int32),
                 ("Lout", c_int32), ("Lsrc", c_int32),
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldg", c_int32),
-                ("accumulate", c_int32), ("ldc2", c_int32)]
+                ("accumulate", c_int32), ("ldc2", c_int32), ("out_f32", c_int32)]
 
 
 class WgradDesc(ctypes.Structure):

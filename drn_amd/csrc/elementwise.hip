@@ -38,6 +38,50 @@ extern "C" int drn_cast(const float* in, void* out, int64_t n, int dtype, void* 
   return drn_launch_status("drn_cast");
 }
 
+// ---------------------------------------------------------------- 2-D transpose out[k][m] = in[m][k]
+// 64 x 64 tiles through LDS: 16-byte loads along k, element scatter into the transposed tile, 16-byte stores along m.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int M,
+                                                          int K) {
+  constexpr int VN = V16<T>::N;
+  constexpr int CPR = 64 / VN;                 // 16-byte chunks per 64-element tile row
+  __shared__ T tile[64][64 + 2 * VN / 4 + 2];  // [k][m], odd dword pitch
+  const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  for (int q = threadIdx.x; q < 64 * CPR; q += 256) {
+    const int r = q / CPR, cv = q % CPR;
+    const int m = m0 + r, k = k0 + cv * VN;
+    if (m < M && k < K) {                       // K % VN == 0: a chunk never crosses the row end
+      T v[VN];
+      *(uint4*)v = *(const uint4*)(in + (long)m * ld_in + k);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) tile[cv * VN + e][r] = v[e];
+    }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 64 * CPR; q += 256) {
+    const int r = q / CPR, cv = q % CPR;       // r: k within the tile, cv: chunk of m
+    const int k = k0 + r, m = m0 + cv * VN;
+    if (k < K && m < M) {
+      T v[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) v[e] = tile[r][cv * VN + e];
+      *(uint4*)(out + (long)k * ld_out + m) = *(const uint4*)v;
+    }
+  }
+}
+extern "C" int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out, int M, int K, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(in && out && M > 0 && K > 0, "drn_transpose2d: bad args");
+  DISPATCH_DT(dtype, "drn_transpose2d", {
+    constexpr int VN = V16<T>::N;
+    DRN_CHECK_ARG(M % VN == 0 && K % VN == 0 && ld_in % VN == 0 && ld_out % VN == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0,
+                  "drn_transpose2d: dims / strides must be 16-byte multiples");
+    dim3 grid(cdiv(K, 64), cdiv(M, 64));
+    transpose2d_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)in, ld_in, (T*)out, ld_out, M, K);
+  });
+  return drn_launch_status("drn_transpose2d");
+}
+
 // ---------------------------------------------------------------- weight packing (permute + cast)
 // out[a][b][c] = in[a*sa + b*sb + c*sc]
 template <typename T>

@@ -34,6 +34,7 @@ struct GemmProb {
   int Lout, Lsrc;
   int lda, ldb, ldc, ldg, ldc2;
   int accumulate;
+  int out_f32;      // C is fp32 [M][ldc] whatever T is (weight gradients computed as an NT product of transposed operands)
   int tiles_n, tile_start;
 };
 struct GemmParams {
@@ -285,6 +286,47 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
           if (n < N) wsp[(long)m * N + n] = acc[mi][ni][r];
         }
       }
+    return;
+  }
+  if (pr.out_f32) {
+    // fp32 destination (a weight gradient): each wave transposes its 64-column slab through a private LDS patch, 32 rows
+    // at a time, and writes 16-byte row segments.  Only bias / accumulate apply here.
+    float* __restrict__ Cf = (float*)pr.C;
+    constexpr int PITCHF = 64 * 4 + 16;
+    char* wbuf = smem + w * (32 * PITCHF);
+    const bool vec4 = (pr.ldc % 4 == 0) && (((uintptr_t)Cf & 15) == 0);
+#pragma unroll
+    for (int ch = 0; ch < MI / 2; ++ch) {
+      const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
+#pragma unroll
+      for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCHF) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {          // 16 lanes per 64-float row, 4 rows per instruction
+        const int rl = it * 4 + (l >> 4), cv = l & 15;
+        const int m = mrow0 + rl, n = n0 + wc * (NI * 16) + cv * 4;
+        if (m < M && n < N) {
+          f32x4 v = *(const f32x4*)(wbuf + rl * PITCHF + cv * 16);
+          float* g = Cf + ((long)m * pr.ldc + n);
+          if (pr.bias)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += n + k < N ? pr.bias[n + k] : 0.f;
+          if (vec4 && n + 4 <= N && !pr.accumulate) {
+            *(f32x4*)g = v;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (n + k < N) g[k] = pr.accumulate ? g[k] + v[k] : v[k];
+          }
+        }
+      }
+      __syncthreads();
+    }
     return;
   }
   if (pr.stats) {
@@ -562,6 +604,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     p.M = s.M; p.N = s.N; p.K = s.taps * s.Cin; p.Cin = s.Cin; p.taps = s.taps; p.stride = s.stride; p.pad = s.pad;
     p.mode = s.mode; p.Lout = s.Lout; p.Lsrc = s.Lsrc; p.lda = s.lda; p.ldb = s.ldb; p.ldc = s.ldc; p.ldg = s.ldg; p.ldc2 = s.ldc2;
     p.accumulate = s.accumulate;
+    p.out_f32 = s.out_f32;
     p.tiles_n = cdiv(s.N, tile);
     p.tile_start = total;
     total += cdiv(s.M, tile) * p.tiles_n;

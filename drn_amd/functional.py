@@ -134,6 +134,9 @@ def grad_buffer(param, dtype=torch.float32):
 
 import os
 
+# prop_fc weight gradient through the NT kernel on transposed operands (bf16 only); DRN_NT_WGRAD=0 keeps the TN kernel
+NT_WGRAD = os.environ.get("DRN_NT_WGRAD", "1") == "1"
+
 # BatchNorm `num_batches_tracked` increments are collected during a forward pass and applied by ONE multi-tensor add
 # (flush_bn_counters) instead of one tiny launch per BN call.
 _bn_pending = {}
@@ -526,7 +529,14 @@ class _InputStageFn(torch.autograd.Function):
         ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
         Wfc, bfc, Wpos, bpos = ctx.param_refs
         dW = grad_buffer(Wfc)
-        ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
+        if code == ops.BF16 and NT_WGRAD and (B * T) % 8 == 0 and D % 8 == 0:
+            # dW[n][c] = sum_m dZ[m][n] * x[m][c] as an NT product of the K-major copies dZ^T (D, B*T) and x^T (D, B*T):
+            # the NT kernel streams both operands with 16-byte LDS reads (1.1 PFLOP/s on this shape), while the TN
+            # kernel's transposing ds_read_b64_tr_b16 fragments hold it to ~0.7; the two transposes cost ~60 us
+            ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ.view(B * T, D), code), ops.transpose2d(xc.view(B * T, D), code), dW,
+                                       D, D, B * T, out_f32=True)], code)
+        else:
+            ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
         db = grad_buffer(bfc)
         ops.colsum(dsum, D, B, D, db, ops.F32)
         dWp = grad_buffer(Wpos)

@@ -37,7 +37,7 @@ def _need_gpu(*ts):
 
 
 def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Lsrc=None, lda=None, ldb=None,
-              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, ldc2=None, accumulate=False):
+              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, ldc2=None, accumulate=False, out_f32=False):
     _need_gpu(A, B, C, bias, gate, stats, C2)
     Lout = M if Lout is None else Lout
     Lsrc = Lout if Lsrc is None else Lsrc
@@ -45,7 +45,7 @@ def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Ls
                     M=M, N=N, Cin=Cin, taps=taps, stride=stride, pad=pad, mode=mode, Lout=Lout, Lsrc=Lsrc,
                     lda=Cin if lda is None else lda, ldb=taps * Cin if ldb is None else ldb,
                     ldc=N if ldc is None else ldc, ldg=ldg, accumulate=int(accumulate),
-                    ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2)
+                    ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2, out_f32=int(out_f32))
 
 
 # Optional per-launch timing of the MFMA kernels (bench.py): a list collecting (tag, flops, start_event, end_event),
@@ -139,6 +139,16 @@ def cast(x, dtype):
     assert x.dtype == torch.float32 and x.is_contiguous()
     out = torch.empty(x.shape, dtype=TORCH_DT[dtype], device=x.device)
     check(lib().drn_cast(_p(x), _p(out), ctypes.c_int64(x.numel()), dtype, _stream()), "drn_cast")
+    return out
+
+
+def transpose2d(x, dtype):
+    """(M, K) row-major -> (K, M) row-major, compute dtype, one LDS-tiled pass."""
+    _need_gpu(x)
+    M, K = x.shape
+    assert x.stride(1) == 1
+    out = torch.empty((K, M), dtype=x.dtype, device=x.device)
+    check(lib().drn_transpose2d(_p(x), x.stride(0), _p(out), M, M, K, dtype, _stream()), "drn_transpose2d")
     return out
 
 

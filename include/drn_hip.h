@@ -55,6 +55,7 @@ typedef struct DrnGemmDesc {
   int32_t lda, ldb, ldc, ldg;
   int32_t accumulate; /* 1: C += result */
   int32_t ldc2;       /* row stride of C2 */
+  int32_t out_f32;    /* 1: C is fp32 [M][ldc] regardless of dtype (no C2 / gate / stats): weight gradients as an NT product */
 } DrnGemmDesc;
 
 /* Grouped NT implicit GEMM on MFMA (conv1d fwd / dgrad, linear fwd / dgrad).
@@ -84,6 +85,9 @@ int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, i
 int drn_cast(const float* in, void* out, int64_t n, int dtype, void* stream);
 /* out[a][b][c] (dtype) = in[a*sa + b*sb + c*sc] (fp32): re-lays nn.Conv1d weights (Cout,Cin,k) as the GEMM's
  * B operands [Cout][k][Cin] (forward) and [Cin][k][Cout] (data gradient). */
+/* out[k][m] = in[m][k] for a row-major M x K matrix of dtype elements (row strides ld_in / ld_out): K-major copies of the
+ * operands let the largest weight gradient run as an NT product (see drn_amd/functional.py, _InputStageFn). */
+int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out, int M, int K, int dtype, void* stream);
 int drn_pack_weight(const float* in, void* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, int dtype, void* stream);
 /* The same for n weights in one launch (all GEMM operands of the model after an optimizer step; the reference's cuDNN
  * re-lays its filters inside every call). */

@@ -57,6 +57,7 @@ def wg(name, levels, N, Cin, taps=1, stride=1):
 B = 32
 print("DRN_NT_STAGES=%s dtype=%s" % (os.environ.get("DRN_NT_STAGES", "auto"), dt))
 nt("prop_fc fwd 8192x4096x4096", [(B, 256)], 4096, 4096)
+nt("wgrad-as-NT 4096x4096x8192", [(1, 4096)], 4096, 8192)
 nt("conv0 fwd 8192x256x13056", [(B, 256)], 256, 4352, taps=3, stats=True)
 nt("conv0 dgrad 8192x4352x768", [(B, 256)], 4352, 256, taps=3, mode=1)
 nt("conv1 fwd s2 4096x512x768", [(B, 128)], 512, 256, taps=3, stride=2, stats=True)

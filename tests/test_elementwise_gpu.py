@@ -108,3 +108,12 @@ def test_cast_and_pack(dt):
             out = torch.empty_like(want)
             ops.pack_weights_into([(w, perm, out)], _code(dt))
             assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,K", [(8, 8), (64, 64), (72, 200), (8192, 4096), (1000, 24)])
+def test_transpose2d(dt, M, K):
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g).to("cuda:0").to(dt)
+    assert torch.equal(ops.transpose2d(x, _code(dt)), x.t().contiguous())

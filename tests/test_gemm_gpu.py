@@ -240,3 +240,38 @@ def test_conv_fwd_splitk_with_stats_bias_gate(dt, ksplit):
     tot, m2 = merged_stats(stats, M)
     close(tot, ref.sum(0), TOL[dt] * 4, "col sum (raw conv)")
     close(m2, ((ref - ref.mean(0)) ** 2).sum(0), TOL[dt] * 4, "col M2")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (200, 136, 72), (4096, 512, 1024)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_nt_fp32_output_is_a_weight_gradient(dt, M, N, K, accumulate):
+    """out_f32: C (fp32) (+)= A (M,K) x B (N,K)^T in the compute dtype with fp32 accumulation -- the prop_fc weight gradient
+    dW = dZ^T x as an NT product of the transposed operands (drn_amd/functional.py, _InputStageFn.backward)."""
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g).to(dev()).to(dt)
+    B = torch.randn(N, K, generator=g).to(dev()).to(dt)
+    C0 = torch.randn(M, N, generator=g).to(dev())
+    C = C0.clone()
+    ops.gemm_nt([ops.gemm_desc(A, B, C, M, N, K, out_f32=True, accumulate=accumulate)], ops.dtype_code(A))
+    want = A.double() @ B.double().t() + (C0.double() if accumulate else 0)
+    err = float((C.double() - want).abs().max())
+    assert err <= 2e-5 * float(want.abs().max()) + 1e-4, err
+
+
+def test_prop_fc_weight_gradient_nt_path_matches_tn_kernel():
+    """The same gradient through drn_gemm_wgrad (TN) and through transposes + drn_gemm_nt(out_f32): fp32 accumulation of
+    identical bf16 products, only the summation order differs."""
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(12)
+    R, D = 2048, 512
+    dZ = torch.randn(R, D, generator=g).to(dev()).to(torch.bfloat16)
+    X = torch.randn(R, D, generator=g).to(dev()).to(torch.bfloat16)
+    a = torch.empty(D, D, device=dev())
+    b = torch.empty(D, D, device=dev())
+    ops.gemm_wgrad([ops.wgrad_desc(dZ, X, R)], a.view(D, D, 1), D, D, taps=1, w_layout=0, dtype=ops.BF16)
+    ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ, ops.BF16), ops.transpose2d(X, ops.BF16), b, D, D, R, out_f32=True)], ops.BF16)
+    want = dZ.double().t() @ X.double()
+    assert float((a.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert float((b.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
