@@ -16,6 +16,12 @@ struct BnFinGroup {
   int tiles, M;
   float* scale_shift;
   float* save;
+  const float* gamma;
+  const float* beta;
+  const float* conv_bias;
+  float* running_mean;
+  float* running_var;
+  float momentum, eps;
 };
 struct BnFinParams {
   int ngroups;
@@ -23,21 +29,15 @@ struct BnFinParams {
 };
 
 // 256 threads = 16 channels x 16 lanes; the lanes split the per-tile partial sums, LDS combines them in a fixed order.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinParams P, int C, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ conv_bias,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          float momentum, float eps) {
+// Groups are processed IN ORDER by the thread that owns the channel, so groups that share one BatchNorm module (the
+// head modules applied once per pyramid level) update its running statistics sequentially like the reference does,
+// and groups with their own modules (FPN levels) simply carry different pointers.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinParams P, int C) {
   __shared__ double sh[2][16][17];
   const int ci = threadIdx.x & 15, j = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + ci;
   const bool live = c < C;
-  float rm = 0.f, rv = 1.f, cb = 0.f;
-  if (live && j == 0) {
-    rm = running_mean ? running_mean[c] : 0.f;
-    rv = running_var ? running_var[c] : 1.f;
-    cb = conv_bias ? conv_bias[c] : 0.f;
-  }
-  for (int g = 0; g < P.ngroups; ++g) {   // shared modules: levels update the running stats in order
+  for (int g = 0; g < P.ngroups; ++g) {
     const BnFinGroup& G = P.g[g];
     // slab t holds (sum, M2 about the slab mean) of n_t = min(128, M - 128 t) rows; merge in double (Chan et al.)
     double s = 0.0;
@@ -66,38 +66,55 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinParams P, i
       for (int k = 0; k < 16; ++k) q += sh[1][ci][k];
       double var = q / G.M;
       if (var < 0.0) var = 0.0;
-      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-      const float sc = gamma[c] * invstd;
+      const float invstd = (float)(1.0 / sqrt(var + (double)G.eps));
+      const float sc = G.gamma[c] * invstd;
       G.scale_shift[c] = sc;
-      G.scale_shift[C + c] = beta[c] - (float)mean * sc;
+      G.scale_shift[C + c] = G.beta[c] - (float)mean * sc;
       G.save[c] = (float)mean;
       G.save[C + c] = invstd;
       const double unbiased = G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var;
-      rm = (1.f - momentum) * rm + momentum * ((float)mean + cb);
-      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+      const float cb = G.conv_bias ? G.conv_bias[c] : 0.f;
+      if (G.running_mean) G.running_mean[c] = (1.f - G.momentum) * G.running_mean[c] + G.momentum * ((float)mean + cb);
+      if (G.running_var) G.running_var[c] = (1.f - G.momentum) * G.running_var[c] + G.momentum * (float)unbiased;
     }
   }
-  if (live && j == 0) {
-    if (running_mean) running_mean[c] = rm;
-    if (running_var) running_var[c] = rv;
+}
+
+static int bn_finalize_launch(const DrnBnFinDesc* d, int n, int C, void* stream, const char* who) {
+  DRN_CHECK_ARG(d && n >= 1 && n <= DRN_MAX_GROUPS && C > 0, "%s: bad args", who);
+  BnFinParams P;
+  P.ngroups = n;
+  for (int g = 0; g < n; ++g) {
+    DRN_CHECK_ARG(d[g].stats && d[g].scale_shift && d[g].save && d[g].gamma && d[g].beta && d[g].M > 0 && d[g].tiles > 0,
+                  "%s: bad group %d", who, g);
+    P.g[g].stats = d[g].stats; P.g[g].tiles = d[g].tiles; P.g[g].M = d[g].M;
+    P.g[g].scale_shift = d[g].scale_shift; P.g[g].save = d[g].save;
+    P.g[g].gamma = d[g].gamma; P.g[g].beta = d[g].beta; P.g[g].conv_bias = d[g].conv_bias;
+    P.g[g].running_mean = d[g].running_mean; P.g[g].running_var = d[g].running_var;
+    P.g[g].momentum = d[g].momentum; P.g[g].eps = d[g].eps;
   }
+  bn_finalize_kernel<<<cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(P, C);
+  return drn_launch_status(who);
+}
+
+extern "C" int drn_bn_finalize_multi(const DrnBnFinDesc* descs, int n, int C, void* stream) {
+  drn_clear_status();
+  return bn_finalize_launch(descs, n, C, stream, "drn_bn_finalize_multi");
 }
 
 extern "C" int drn_bn_finalize(const DrnBnGroup* groups, int ngroups, int C, const float* gamma, const float* beta,
                                const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps,
                                void* stream) {
   drn_clear_status();
-  DRN_CHECK_ARG(groups && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS && C > 0 && gamma && beta, "drn_bn_finalize: bad args");
-  BnFinParams P;
-  P.ngroups = ngroups;
+  DRN_CHECK_ARG(groups && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_bn_finalize: bad args");
+  DrnBnFinDesc d[DRN_MAX_GROUPS];
   for (int g = 0; g < ngroups; ++g) {
-    DRN_CHECK_ARG(groups[g].stats && groups[g].scale_shift && groups[g].save && groups[g].M > 0 && groups[g].tiles > 0,
-                  "drn_bn_finalize: bad group %d", g);
-    P.g[g].stats = groups[g].stats; P.g[g].tiles = groups[g].tiles; P.g[g].M = groups[g].M;
-    P.g[g].scale_shift = groups[g].scale_shift; P.g[g].save = groups[g].save;
+    d[g].stats = groups[g].stats; d[g].tiles = groups[g].tiles; d[g].M = groups[g].M;
+    d[g].scale_shift = groups[g].scale_shift; d[g].save = groups[g].save;
+    d[g].gamma = gamma; d[g].beta = beta; d[g].conv_bias = conv_bias;
+    d[g].running_mean = running_mean; d[g].running_var = running_var; d[g].momentum = momentum; d[g].eps = eps;
   }
-  bn_finalize_kernel<<<cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(P, C, gamma, beta, conv_bias, running_mean, running_var, momentum, eps);
-  return drn_launch_status("drn_bn_finalize");
+  return bn_finalize_launch(d, ngroups, C, stream, "drn_bn_finalize");
 }
 
 // eval mode: scale/shift from the running statistics (conv bias folded into the shift)
@@ -118,24 +135,47 @@ extern "C" int drn_bn_eval_scale_shift(int C, const float* gamma, const float* b
 }
 
 // out = [relu](raw*scale + shift) [+ up[s, t/2]] ;  gated = out * gate[s]
-// Launch geometry keeps (total threads) % nvec == 0, so each thread owns one 16-byte channel vector for all its
-// rows: scale/shift live in registers and the row loop has no integer division by nvec.
+// One launch covers up to DRN_MAX_GROUPS levels (same C): level l owns the blocks [blk0_l, blk0_{l+1}).  Per level the
+// launch geometry keeps (level threads) % nvec == 0, so each thread owns one 16-byte channel vector for all its rows:
+// scale/shift live in registers and the row loop has no integer division by nvec.
+struct BnApplyLv {
+  const void* raw;
+  void* out;
+  const void* up;
+  void* gated;
+  const float* ss;
+  const float* gate;
+  int ld_raw, ld_out, ld_up, ld_gated, ldg, M, L, blk0;
+};
+struct BnApplyParams {
+  BnApplyLv lv[DRN_MAX_GROUPS];
+  int n, C, relu, total_blocks;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ raw, int ld_raw, const float* __restrict__ ss,
-                                                       T* __restrict__ out, int ld_out, int M, int C, int L,
-                                                       const T* __restrict__ up, int ld_up, const float* __restrict__ gate, int ldg,
-                                                       T* __restrict__ gated, int ld_gated, int relu) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams P) {
   constexpr int N = V16<T>::N;
-  const int nvec = C / N;
-  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.n && (int)blockIdx.x >= P.lv[i].blk0) li = i;
+  const BnApplyLv& G = P.lv[li];
+  const int nblk = (li + 1 < P.n ? P.lv[li + 1].blk0 : P.total_blocks) - G.blk0;
+  const int C = P.C, nvec = C / N, relu = P.relu;
+  const int gtid = (blockIdx.x - G.blk0) * 256 + threadIdx.x;
   const int v = gtid % nvec, c0 = v * N;
-  const int rstride = (gridDim.x * 256) / nvec;
+  const int rstride = (nblk * 256) / nvec;
+  const T* __restrict__ raw = (const T*)G.raw;
+  const T* __restrict__ up = (const T*)G.up;
+  T* __restrict__ out = (T*)G.out;
+  T* __restrict__ gated = (T*)G.gated;
+  const int M = G.M, L = G.L;
   float sc[N], sh[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) { sc[k] = ss[c0 + k]; sh[k] = ss[C + c0 + k]; }
+  for (int k = 0; k < N; ++k) { sc[k] = G.ss[c0 + k]; sh[k] = G.ss[C + c0 + k]; }
   for (int m = gtid / nvec; m < M; m += rstride) {
     float x[N];
-    V16<T>::load(raw + (long)m * ld_raw + c0, x);
+    V16<T>::load(raw + (long)m * G.ld_raw + c0, x);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const float y = fmaf(x[k], sc[k], sh[k]);
@@ -145,16 +185,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ raw
     if (up) {
       const int t = m - s * L;
       float u[N];
-      V16<T>::load(up + ((long)s * (L >> 1) + (t >> 1)) * ld_up + c0, u);
+      V16<T>::load(up + ((long)s * (L >> 1) + (t >> 1)) * G.ld_up + c0, u);
 #pragma unroll
       for (int k = 0; k < N; ++k) x[k] += u[k];
     }
-    V16<T>::store(out + (long)m * ld_out + c0, x);
+    V16<T>::store(out + (long)m * G.ld_out + c0, x);
     if (gated) {
-      const float* gp = gate + (long)s * ldg + c0;
+      const float* gp = G.gate + (long)s * G.ldg + c0;
 #pragma unroll
       for (int k = 0; k < N; ++k) x[k] *= gp[k];
-      V16<T>::store(gated + (long)m * ld_gated + c0, x);
+      V16<T>::store(gated + (long)m * G.ld_gated + c0, x);
     }
   }
 }
@@ -172,37 +212,90 @@ static int row_grid(int M, int nvec) {
   return (int)blocks;
 }
 
+static int bn_apply_launch(const DrnBnApplyDesc* d, int n, int C, int relu, int dtype, void* stream, const char* who) {
+  DRN_CHECK_ARG(d && n >= 1 && n <= DRN_MAX_GROUPS && C > 0, "%s: bad args", who);
+  const int vn = dtype == DRN_BF16 ? 8 : 4;
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "%s: bad dtype %d", who, dtype);
+  DRN_CHECK_ARG(C % vn == 0, "%s: C must be a 16-byte multiple", who);
+  BnApplyParams P;
+  memset(&P, 0, sizeof(P));
+  P.n = n; P.C = C; P.relu = relu;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const DrnBnApplyDesc& s = d[i];
+    DRN_CHECK_ARG(s.raw && s.scale_shift && s.out && s.M > 0 && s.L > 0 && s.M % s.L == 0, "%s: bad level %d", who, i);
+    DRN_CHECK_ARG(!s.up || (s.L % 2 == 0), "%s: upsample-add needs an even sequence length", who);
+    DRN_CHECK_ARG((s.gate != nullptr) == (s.gated != nullptr), "%s: gate and gated must come together", who);
+    DRN_CHECK_ARG(s.ld_raw % vn == 0 && s.ld_out % vn == 0 && (!s.up || s.ld_up % vn == 0) && (!s.gated || s.ld_gated % vn == 0),
+                  "%s: ld must be 16-byte multiples", who);
+    BnApplyLv& G = P.lv[i];
+    G.raw = s.raw; G.out = s.out; G.up = s.up; G.gated = s.gated; G.ss = s.scale_shift; G.gate = s.gate;
+    G.ld_raw = s.ld_raw; G.ld_out = s.ld_out; G.ld_up = s.ld_up; G.ld_gated = s.ld_gated; G.ldg = s.ldg; G.M = s.M; G.L = s.L;
+    G.blk0 = blocks;
+    blocks += row_grid(s.M, C / vn);
+  }
+  P.total_blocks = blocks;
+  if (dtype == DRN_BF16) bn_apply_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(P);
+  else bn_apply_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(P);
+  return drn_launch_status(who);
+}
+
+extern "C" int drn_bn_apply_multi(const DrnBnApplyDesc* descs, int n, int C, int relu, int dtype, void* stream) {
+  drn_clear_status();
+  return bn_apply_launch(descs, n, C, relu, dtype, stream, "drn_bn_apply_multi");
+}
+
 extern "C" int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shift, void* out, int ld_out, int M, int C, int L,
                             const void* up, int ld_up, const float* gate, int ldg, void* gated, int ld_gated, int relu, int dtype,
                             void* stream) {
   drn_clear_status();
-  DRN_CHECK_ARG(raw && scale_shift && out && M > 0 && C > 0 && L > 0 && M % L == 0, "drn_bn_apply: bad args");
-  DRN_CHECK_ARG(!up || (L % 2 == 0), "drn_bn_apply: upsample-add needs an even sequence length");
-  DRN_CHECK_ARG((gate != nullptr) == (gated != nullptr), "drn_bn_apply: gate and gated must come together");
-  DISPATCH_DT(dtype, "drn_bn_apply", {
-    constexpr int N = V16<T>::N;
-    DRN_CHECK_ARG(C % N == 0 && ld_raw % N == 0 && ld_out % N == 0 && (!up || ld_up % N == 0) && (!gated || ld_gated % N == 0),
-                  "drn_bn_apply: C/ld must be 16-byte multiples");
-    bn_apply_kernel<T><<<row_grid(M, C / N), 256, 0, (hipStream_t)stream>>>(
-        (const T*)raw, ld_raw, scale_shift, (T*)out, ld_out, M, C, L, (const T*)up, ld_up, gate, ldg, (T*)gated, ld_gated, relu);
-  });
-  return drn_launch_status("drn_bn_apply");
+  DrnBnApplyDesc d;
+  d.raw = raw; d.ld_raw = ld_raw; d.scale_shift = scale_shift; d.out = out; d.ld_out = ld_out; d.M = M; d.L = L;
+  d.up = up; d.ld_up = ld_up; d.gate = gate; d.ldg = ldg; d.gated = gated; d.ld_gated = ld_gated;
+  return bn_apply_launch(&d, 1, C, relu, dtype, stream, "drn_bn_apply");
 }
 
 // ---------------------------------------------------------------- backward
 // The ReLU mask is recomputed as fma(raw, scale, shift) > 0 with the forward's own scale/shift, so it is
 // bit-identical to the forward decision even when `out` had the FPN upsample added on top.
+// Three launches (reduce -> finalize -> apply) cover up to DRN_MAX_GROUPS levels of equal C; the levels may share one
+// BatchNorm module (dgamma/dbeta accumulate over them in order) or carry their own.
+struct BnBwdLv {
+  const void* dout;
+  const void* raw;
+  void* draw;
+  const float* ss;
+  const float* save;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  float* partial;   // [nblk][2][C]
+  float* coef;      // [3][C]
+  int ld_dout, ld_raw, ld_draw, M, accumulate, nblk, yblk0, ablk0;
+};
+struct BnBwdParams {
+  BnBwdLv lv[DRN_MAX_GROUPS];
+  int n, C, relu, total_yblk, total_ablk;
+};
+
 // g = dOut * mask;  partial[blk][0][c] = sum g ; partial[blk][1][c] = sum g * xhat
-// block 256 = 64 channel vectors x 4 row lanes (LDS-combined in a fixed order); grid (ceil(nvec/64), nblk)
+// block 256 = 64 channel vectors x 4 row lanes (LDS-combined in a fixed order); grid (ceil(nvec/64), sum of nblk)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, int ld_dout, const T* __restrict__ raw, int ld_raw,
-                                                            const float* __restrict__ ss, const float* __restrict__ save, int M, int C,
-                                                            int relu, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams P) {
   constexpr int N = V16<T>::N;
   __shared__ float red[2][4][64 * N + 1];
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.n && (int)blockIdx.y >= P.lv[i].yblk0) li = i;
+  const BnBwdLv& G = P.lv[li];
+  const int C = P.C, relu = P.relu, M = G.M;
+  const int by = blockIdx.y - G.yblk0;
+  const T* __restrict__ dout = (const T*)G.dout;
+  const T* __restrict__ raw = (const T*)G.raw;
   const int nvec = C / N;
-  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
-  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const int rows_per = (M + G.nblk - 1) / G.nblk;
+  const int r0 = by * rows_per, r1 = min(M, r0 + rows_per);
   const int vx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int v = blockIdx.x * 64 + vx;
   const bool live = v < nvec;
@@ -210,18 +303,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   float mean[N], istd[N], sc[N], sh[N], sg[N], sx[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    mean[k] = live ? save[c0 + k] : 0.f;
-    istd[k] = live ? save[C + c0 + k] : 0.f;
-    sc[k] = live ? ss[c0 + k] : 0.f;
-    sh[k] = live ? ss[C + c0 + k] : 0.f;
+    mean[k] = live ? G.save[c0 + k] : 0.f;
+    istd[k] = live ? G.save[C + c0 + k] : 0.f;
+    sc[k] = live ? G.ss[c0 + k] : 0.f;
+    sh[k] = live ? G.ss[C + c0 + k] : 0.f;
     sg[k] = 0.f;
     sx[k] = 0.f;
   }
   if (live)
+#pragma unroll 2
     for (int m = r0 + ry; m < r1; m += 4) {
       float g[N], x[N];
-      V16<T>::load(dout + (long)m * ld_dout + c0, g);
-      V16<T>::load(raw + (long)m * ld_raw + c0, x);
+      V16<T>::load(dout + (long)m * G.ld_dout + c0, g);
+      V16<T>::load(raw + (long)m * G.ld_raw + c0, x);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
@@ -238,86 +332,128 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int i = threadIdx.x; i < 2 * 64 * N; i += 256) {
     const int kind = i / (64 * N), cc = i % (64 * N);
     const int c = blockIdx.x * 64 * N + cc;
-    if (c < C) partial[((long)blockIdx.y * 2 + kind) * C + c] = red[kind][0][cc] + red[kind][1][cc] + red[kind][2][cc] + red[kind][3][cc];
+    if (c < C) G.partial[((long)by * 2 + kind) * C + c] = red[kind][0][cc] + red[kind][1][cc] + red[kind][2][cc] + red[kind][3][cc];
   }
 }
 
 // dgamma/dbeta (+)= level sums;  coef: dRaw = A*g + B*raw + Cc.   256 threads = 16 channels x 16 lanes over the partials.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C,
-                                                              const float* __restrict__ gamma, const float* __restrict__ save,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                                              float* __restrict__ coef) {
+// Levels are handled in order by the same thread, so shared dgamma/dbeta accumulate deterministically.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams P) {
   __shared__ double sh[2][16][17];
+  const int C = P.C;
   const int ci = threadIdx.x & 15, j = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + ci;
-  double sg = 0.0, sx = 0.0;
-  if (c < C)
-    for (int b = j; b < nblk; b += 16) {
-      sg += (double)partial[((long)b * 2 + 0) * C + c];
-      sx += (double)partial[((long)b * 2 + 1) * C + c];
-    }
-  sh[0][ci][j] = sg;
-  sh[1][ci][j] = sx;
-  __syncthreads();
-  if (c >= C || j != 0) return;
-  sg = 0.0; sx = 0.0;
+  for (int li = 0; li < P.n; ++li) {
+    const BnBwdLv& G = P.lv[li];
+    double sg = 0.0, sx = 0.0;
+    if (c < C)
+      for (int b = j; b < G.nblk; b += 16) {
+        sg += (double)G.partial[((long)b * 2 + 0) * C + c];
+        sx += (double)G.partial[((long)b * 2 + 1) * C + c];
+      }
+    __syncthreads();
+    sh[0][ci][j] = sg;
+    sh[1][ci][j] = sx;
+    __syncthreads();
+    if (c >= C || j != 0) continue;
+    sg = 0.0; sx = 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { sg += sh[0][ci][k]; sx += sh[1][ci][k]; }
-  const float mean = save[c], istd = save[C + c];
-  const float s = gamma[c] * istd;
-  const float dg = (float)sx, db = (float)sg;
-  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
-  const float invM = 1.f / (float)M;
-  coef[c] = s;
-  coef[C + c] = -s * dg * istd * invM;
-  coef[2 * C + c] = -s * db * invM + s * dg * istd * mean * invM;
+    for (int k = 0; k < 16; ++k) { sg += sh[0][ci][k]; sx += sh[1][ci][k]; }
+    const float mean = G.save[c], istd = G.save[C + c];
+    const float s = G.gamma[c] * istd;
+    const float dg = (float)sx, db = (float)sg;
+    if (G.dgamma) G.dgamma[c] = G.accumulate ? G.dgamma[c] + dg : dg;
+    if (G.dbeta) G.dbeta[c] = G.accumulate ? G.dbeta[c] + db : db;
+    const float invM = 1.f / (float)G.M;
+    G.coef[c] = s;
+    G.coef[C + c] = -s * dg * istd * invM;
+    G.coef[2 * C + c] = -s * db * invM + s * dg * istd * mean * invM;
+  }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, int ld_dout, const T* __restrict__ raw, int ld_raw,
-                                                           const float* __restrict__ ss, const float* __restrict__ coef,
-                                                           T* __restrict__ draw, int ld_draw, int M, int C, int relu) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams P) {
   constexpr int N = V16<T>::N;
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.n && (int)blockIdx.x >= P.lv[i].ablk0) li = i;
+  const BnBwdLv& G = P.lv[li];
+  const int nblk = (li + 1 < P.n ? P.lv[li + 1].ablk0 : P.total_ablk) - G.ablk0;
+  const int C = P.C, relu = P.relu, M = G.M;
+  const T* __restrict__ dout = (const T*)G.dout;
+  const T* __restrict__ raw = (const T*)G.raw;
+  T* __restrict__ draw = (T*)G.draw;
   const int nvec = C / N;
-  const int gtid = blockIdx.x * 256 + threadIdx.x;
+  const int gtid = (blockIdx.x - G.ablk0) * 256 + threadIdx.x;
   const int v = gtid % nvec, c0 = v * N;
-  const int rstride = (gridDim.x * 256) / nvec;
+  const int rstride = (nblk * 256) / nvec;
   float sc[N], sh[N], ka[N], kb[N], kc[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    sc[k] = ss[c0 + k]; sh[k] = ss[C + c0 + k];
-    ka[k] = coef[c0 + k]; kb[k] = coef[C + c0 + k]; kc[k] = coef[2 * C + c0 + k];
+    sc[k] = G.ss[c0 + k]; sh[k] = G.ss[C + c0 + k];
+    ka[k] = G.coef[c0 + k]; kb[k] = G.coef[C + c0 + k]; kc[k] = G.coef[2 * C + c0 + k];
   }
   for (int m = gtid / nvec; m < M; m += rstride) {
     float g[N], x[N];
-    V16<T>::load(dout + (long)m * ld_dout + c0, g);
-    V16<T>::load(raw + (long)m * ld_raw + c0, x);
+    V16<T>::load(dout + (long)m * G.ld_dout + c0, g);
+    V16<T>::load(raw + (long)m * G.ld_raw + c0, x);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
       x[k] = fmaf(ka[k], gg, fmaf(kb[k], x[k], kc[k]));
     }
-    V16<T>::store(draw + (long)m * ld_draw + c0, x);
+    V16<T>::store(draw + (long)m * G.ld_draw + c0, x);
   }
 }
 
-// draw may alias dout (in place).
+// draw may alias dout (in place).  ws >= n * (2*256 + 3) * C floats.
+static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* ws, int dtype, void* stream_, const char* who) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(d && n >= 1 && n <= DRN_MAX_GROUPS && C > 0 && ws, "%s: bad args", who);
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "%s: bad dtype %d", who, dtype);
+  const int vn = dtype == DRN_BF16 ? 8 : 4;
+  DRN_CHECK_ARG(C % vn == 0, "%s: C must be a 16-byte multiple", who);
+  BnBwdParams P;
+  memset(&P, 0, sizeof(P));
+  P.n = n; P.C = C; P.relu = relu;
+  int yb = 0, ab = 0;
+  for (int i = 0; i < n; ++i) {
+    const DrnBnBwdDesc& s = d[i];
+    DRN_CHECK_ARG(s.dout && s.raw && s.scale_shift && s.save && s.gamma && s.draw && s.M > 0, "%s: bad level %d", who, i);
+    DRN_CHECK_ARG(s.ld_dout % vn == 0 && s.ld_raw % vn == 0 && s.ld_draw % vn == 0, "%s: ld must be 16-byte multiples", who);
+    BnBwdLv& G = P.lv[i];
+    G.dout = s.dout; G.raw = s.raw; G.draw = s.draw; G.ss = s.scale_shift; G.save = s.save; G.gamma = s.gamma;
+    G.dgamma = s.dgamma; G.dbeta = s.dbeta; G.ld_dout = s.ld_dout; G.ld_raw = s.ld_raw; G.ld_draw = s.ld_draw; G.M = s.M;
+    G.accumulate = s.accumulate;
+    G.nblk = s.M >= 256 * 16 ? 256 : (s.M >= 16 ? s.M / 16 : 1);
+    G.partial = ws + (long)i * (2 * 256 + 3) * C;
+    G.coef = G.partial + (long)2 * 256 * C;
+    G.yblk0 = yb; G.ablk0 = ab;
+    yb += G.nblk;
+    ab += row_grid(s.M, C / vn);
+  }
+  P.total_yblk = yb; P.total_ablk = ab;
+  dim3 grid(cdiv(C / vn, 64), yb);
+  if (dtype == DRN_BF16) bn_bwd_reduce_kernel<bf16_t><<<grid, 256, 0, stream>>>(P);
+  else bn_bwd_reduce_kernel<float><<<grid, 256, 0, stream>>>(P);
+  bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, stream>>>(P);
+  if (dtype == DRN_BF16) bn_bwd_apply_kernel<bf16_t><<<ab, 256, 0, stream>>>(P);
+  else bn_bwd_apply_kernel<float><<<ab, 256, 0, stream>>>(P);
+  return drn_launch_status(who);
+}
+
+extern "C" int drn_bn_bwd_multi(const DrnBnBwdDesc* descs, int n, int C, int relu, float* ws, int dtype, void* stream) {
+  drn_clear_status();
+  return bn_bwd_launch(descs, n, C, relu, ws, dtype, stream, "drn_bn_bwd_multi");
+}
+
 extern "C" int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld_raw, const float* scale_shift, const float* save,
                           const float* gamma, void* draw, int ld_draw, float* dgamma, float* dbeta, int accumulate, int M, int C,
-                          int relu, float* ws /* >= (2*256+3)*C floats */, int dtype, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  DRN_CHECK_ARG(dout && raw && scale_shift && save && gamma && draw && ws && M > 0 && C > 0, "drn_bn_bwd: bad args");
-  const int nblk = M >= 256 * 16 ? 256 : (M >= 16 ? M / 16 : 1);
-  float* coef = ws + (long)2 * 256 * C;
-  DISPATCH_DT(dtype, "drn_bn_bwd", {
-    constexpr int N = V16<T>::N;
-    DRN_CHECK_ARG(C % N == 0 && ld_dout % N == 0 && ld_raw % N == 0 && ld_draw % N == 0, "drn_bn_bwd: C/ld must be 16-byte multiples");
-    dim3 grid(cdiv(C / N, 64), nblk);
-    bn_bwd_reduce_kernel<T><<<grid, 256, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw, scale_shift, save, M, C, relu, ws);
-    bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, stream>>>(ws, nblk, M, C, gamma, save, dgamma, dbeta, accumulate, coef);
-    bn_bwd_apply_kernel<T><<<row_grid(M, C / N), 256, 0, stream>>>((const T*)dout, ld_dout, (const T*)raw, ld_raw,
-                                                                                 scale_shift, coef, (T*)draw, ld_draw, M, C, relu);
-  });
-  return drn_launch_status("drn_bn_bwd");
+                          int relu, float* ws /* >= (2*256+3)*C floats */, int dtype, void* stream) {
+  drn_clear_status();
+  DrnBnBwdDesc d;
+  d.dout = dout; d.ld_dout = ld_dout; d.raw = raw; d.ld_raw = ld_raw; d.scale_shift = scale_shift; d.save = save; d.gamma = gamma;
+  d.draw = draw; d.ld_draw = ld_draw; d.dgamma = dgamma; d.dbeta = dbeta; d.accumulate = accumulate; d.M = M;
+  return bn_bwd_launch(&d, 1, C, relu, ws, dtype, stream, "drn_bn_bwd");
 }

@@ -267,7 +267,7 @@ class _ConvBlockFn(torch.autograd.Function):
             ss = torch.empty((2, Cout), dtype=torch.float32, device=dev)
             ops.bn_eval_scale_shift(Cout, gamma, beta, cbias, bn.running_mean, bn.running_var, bn.eps, ss)
             sss = [ss] * nl
-        outs, gated = [], None
+        outs, gated, levels = [], None, []
         for l in range(nl):
             B, L, Lo, M, ld = geo[l]
             out = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
@@ -278,10 +278,10 @@ class _ConvBlockFn(torch.autograd.Function):
                 ub, ul, uc, uld = geom(up)
                 assert (ub, ul * 2, uc) == (B, Lo, Cout), "upsample source must be (B, L/2, C)"
                 upl = up
-            ops.bn_apply(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, C=Cout, L=Lo, dtype=code,
-                         up=upl, ld_up=upl.stride(1) if upl is not None else 0, gate=gate, gated=gated, ld_gated=Cout,
-                         relu=meta.relu)
+            levels.append(dict(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, L=Lo, up=upl,
+                               ld_up=upl.stride(1) if upl is not None else 0, gate=gate, gated=gated, ld_gated=Cout))
             outs.append(out)
+        ops.bn_apply_multi(levels, Cout, code, relu=meta.relu)            # all pyramid levels in one launch
         ctx.meta, ctx.nl, ctx.geo, ctx.k = meta, nl, geo, k
         ctx.has_gate, ctx.has_up, ctx.has_cbias = gate is not None, up is not None, cbias is not None
         ctx.beta_ref = beta
@@ -311,7 +311,7 @@ class _ConvBlockFn(torch.autograd.Function):
         dgamma = grad_buffer(gamma)
         dbeta = grad_buffer(ctx.beta_ref) if ctx.beta_ref is not None else torch.empty_like(gamma)
         dgate = dup = None
-        draws = []
+        draws, blevels = [], []
         for l in range(nl):
             B, L, Lo, M, ld = geo[l]
             d = _grad_nlc(gouts[l], None, dt)
@@ -329,9 +329,10 @@ class _ConvBlockFn(torch.autograd.Function):
                 dup = torch.empty((B, Lo // 2, Cout), dtype=dt, device=dev)
                 ops.pairsum_add(dup, Cout, d, Cout, B * (Lo // 2), Cout, code, accumulate=False)
             draw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
-            ops.bn_bwd(d, Cout, raws[l], Cout, sss[l], saves[l], gamma, draw, Cout, dgamma, dbeta, l > 0, M, Cout, code,
-                       relu=meta.relu)
+            blevels.append(dict(dout=d, ld_dout=Cout, raw=raws[l], ld_raw=Cout, ss=sss[l], save=saves[l], gamma=gamma, draw=draw,
+                                ld_draw=Cout, dgamma=dgamma, dbeta=dbeta, accumulate=l > 0, M=M))
             draws.append(draw)
+        ops.bn_bwd_multi(blevels, Cout, code, relu=meta.relu)             # reduce / finalize / apply once for all levels
         # weight gradient on the side stream, data gradient on the main one: both only read `draws`
         main = torch.cuda.current_stream()
         side = side_stream(dev) if FORK_WGRAD else main
@@ -398,15 +399,19 @@ class _MultiConvFn(torch.autograd.Function):
             raws.append(raw)
             stats.append(st)
         ops.gemm_nt(descs, code)
-        sss, saves = [], []
+        sss, saves, fin = [], [], []
+        same_c = all(g[5] == geo[0][5] for g in geo)
         for l in range(n):
             bn, Cout = bns[l], geo[l][5]
             ss = torch.empty((2, Cout), dtype=torch.float32, device=dev)
             if training:
+                if bn.momentum is None:
+                    raise DrnError("cumulative-average BatchNorm (momentum=None) is not supported")
                 sv = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                 track = bn.track_running_stats and bn.running_mean is not None
-                ops.bn_finalize([(stats[l], stats[l].shape[0], geo[l][3], ss, sv)], Cout, gammas[l], betas[l], None,
-                                bn.running_mean if track else None, bn.running_var if track else None, bn.momentum, bn.eps)
+                fin.append(dict(stats=stats[l], tiles=stats[l].shape[0], M=geo[l][3], ss=ss, save=sv, gamma=gammas[l], beta=betas[l],
+                                running_mean=bn.running_mean if track else None, running_var=bn.running_var if track else None,
+                                momentum=bn.momentum, eps=bn.eps))
                 if track and bn.num_batches_tracked is not None:
                     bump_bn_counter(bn.num_batches_tracked, 1)
                 saves.append(sv)
@@ -414,14 +419,23 @@ class _MultiConvFn(torch.autograd.Function):
                 ops.bn_eval_scale_shift(Cout, gammas[l], betas[l], None, bn.running_mean, bn.running_var, bn.eps, ss)
                 saves.append(ss)
             sss.append(ss)
+        if fin:                                                # every level has its own BatchNorm module: one launch
+            for grp in ([fin] if same_c else [[f] for f in fin]):
+                ops.bn_finalize_multi(grp, grp[0]["ss"].shape[1])
         outs = [None] * n
+        levels = []
         for l in range(n - 1, -1, -1):                        # coarse to fine (the chain needs out_{l+1})
             B, L, Lo, M, ld, Cout = geo[l][:6]
             out = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
             up = outs[l + 1] if (chain_up and l + 1 < n) else None
-            ops.bn_apply(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, C=Cout, L=Lo, dtype=code, up=up,
-                         ld_up=Cout if up is not None else 0, relu=True)
+            lv = dict(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, L=Lo, up=up, ld_up=Cout if up is not None else 0)
+            if chain_up or not same_c:
+                ops.bn_apply_multi([lv], Cout, code)          # out_l reads out_{l+1}: one launch per level, in order
+            else:
+                levels.append(lv)
             outs[l] = out
+        if levels:
+            ops.bn_apply_multi(levels, geo[0][5], code)
         ctx.meta, ctx.geo = meta, geo
         ctx.save_for_backward(*weights, *gammas, *xs, *raws, *sss, *saves)
         return tuple(outs)
@@ -447,15 +461,21 @@ class _MultiConvFn(torch.autograd.Function):
             elif d is None:
                 d = torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
             dtot[l] = d
-        draws, dgammas, dbetas = [], [], []
+        draws, dgammas, dbetas, blevels = [], [], [], []
         for l in range(n):
             B, L, Lo, M, ld, Cout = geo[l][:6]
             draw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
             dg, db = grad_buffer(gammas[l]), torch.empty_like(gammas[l])
-            ops.bn_bwd(dtot[l], Cout, raws[l], Cout, sss[l], saves[l], gammas[l], draw, Cout, dg, db, False, M, Cout, code)
+            blevels.append(dict(dout=dtot[l], ld_dout=Cout, raw=raws[l], ld_raw=Cout, ss=sss[l], save=saves[l], gamma=gammas[l],
+                                draw=draw, ld_draw=Cout, dgamma=dg, dbeta=db, accumulate=False, M=M))
             draws.append(draw)
             dgammas.append(dg)
             dbetas.append(db)
+        if all(g[5] == geo[0][5] for g in geo):
+            ops.bn_bwd_multi(blevels, geo[0][5], code)
+        else:
+            for l in range(n):
+                ops.bn_bwd_multi([blevels[l]], geo[l][5], code)
         dxs = [None] * n
         need = [ctx.needs_input_grad[1 + 3 * n + l] for l in range(n)]
         descs = []

@@ -213,6 +213,41 @@ def bn_finalize(groups, C, gamma, beta, conv_bias, running_mean, running_var, mo
                                 ctypes.c_float(momentum), ctypes.c_float(eps), _stream()), "drn_bn_finalize")
 
 
+def bn_finalize_multi(groups, C):
+    """groups: list of dicts(stats, tiles, M, ss, save, gamma, beta, conv_bias, running_mean, running_var, momentum, eps);
+    one launch, groups processed in order (they may share a BatchNorm module or not)."""
+    arr = (_lib.BnFinDesc * len(groups))(*[
+        _lib.BnFinDesc(stats=_p(g["stats"]), tiles=g["tiles"], M=g["M"], scale_shift=_p(g["ss"]), save=_p(g["save"]),
+                       gamma=_p(g["gamma"]), beta=_p(g["beta"]), conv_bias=_p(g.get("conv_bias")),
+                       running_mean=_p(g.get("running_mean")), running_var=_p(g.get("running_var")),
+                       momentum=g["momentum"], eps=g["eps"]) for g in groups])
+    check(lib().drn_bn_finalize_multi(arr, len(groups), C, _stream()), "drn_bn_finalize_multi")
+
+
+def bn_apply_multi(levels, C, dtype, relu=True):
+    """levels: list of dicts(raw, ld_raw, ss, out, ld_out, M, L[, up, ld_up, gate, gated, ld_gated]): one launch."""
+    arr = (_lib.BnApplyDesc * len(levels))()
+    for d, v in zip(arr, levels):
+        gate = v.get("gate")
+        d.raw, d.scale_shift, d.out = _p(v["raw"]), _p(v["ss"]), _p(v["out"])
+        d.up, d.gate, d.gated = _p(v.get("up")), _p(gate), _p(v.get("gated"))
+        d.ld_raw, d.ld_out, d.ld_up = v["ld_raw"], v["ld_out"], v.get("ld_up", 0)
+        d.ldg, d.ld_gated = (gate.stride(0) if gate is not None else 0), v.get("ld_gated", 0)
+        d.M, d.L = v["M"], v["L"]
+    check(lib().drn_bn_apply_multi(arr, len(levels), C, int(relu), dtype, _stream()), "drn_bn_apply_multi")
+
+
+def bn_bwd_multi(levels, C, dtype, relu=True):
+    """levels: list of dicts(dout, ld_dout, raw, ld_raw, ss, save, gamma, draw, ld_draw, dgamma, dbeta, accumulate, M)."""
+    arr = (_lib.BnBwdDesc * len(levels))()
+    for d, v in zip(arr, levels):
+        d.dout, d.raw, d.scale_shift, d.save, d.gamma = _p(v["dout"]), _p(v["raw"]), _p(v["ss"]), _p(v["save"]), _p(v["gamma"])
+        d.draw, d.dgamma, d.dbeta = _p(v["draw"]), _p(v["dgamma"]), _p(v["dbeta"])
+        d.ld_dout, d.ld_raw, d.ld_draw, d.accumulate, d.M = v["ld_dout"], v["ld_raw"], v["ld_draw"], int(v["accumulate"]), v["M"]
+    ws = workspace(len(levels) * 515 * C, levels[0]["draw"].device)
+    check(lib().drn_bn_bwd_multi(arr, len(levels), C, int(relu), _p(ws), dtype, _stream()), "drn_bn_bwd_multi")
+
+
 def bn_eval_scale_shift(C, gamma, beta, conv_bias, running_mean, running_var, eps, ss):
     check(lib().drn_bn_eval_scale_shift(C, _p(gamma), _p(beta), _p(conv_bias), _p(running_mean), _p(running_var),
                                         ctypes.c_float(eps), _p(ss), _stream()), "drn_bn_eval_scale_shift")

@@ -128,13 +128,53 @@ int drn_bn_finalize(const DrnBnGroup* groups /*host*/, int ngroups, int C, const
                     const float* conv_bias, float* running_mean, float* running_var, float momentum, float eps, void* stream);
 int drn_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const float* conv_bias, const float* running_mean,
                             const float* running_var, float eps, float* scale_shift, void* stream);
+/* The same with per-group parameters, for groups that belong to different BatchNorm modules (the FPN levels) as well as
+ * groups sharing one (pass the same pointers: they are updated in order). */
+typedef struct DrnBnFinDesc {
+  const float* stats;
+  int32_t tiles, M;
+  float* scale_shift;
+  float* save;
+  const float* gamma;
+  const float* beta;
+  const float* conv_bias;  /* or NULL */
+  float* running_mean;     /* or NULL */
+  float* running_var;      /* or NULL */
+  float momentum, eps;
+} DrnBnFinDesc;
+int drn_bn_finalize_multi(const DrnBnFinDesc* descs /*host*/, int n, int C, void* stream);
 /* out = [relu](raw*scale+shift) [+ up[seq, t/2]] ; gated = out*gate[seq]  (fused consumers' prologues) */
 int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shift, void* out, int ld_out, int M, int C, int L, const void* up,
                  int ld_up, const float* gate, int ldg, void* gated, int ld_gated, int relu, int dtype, void* stream);
+/* ... for up to DRN_MAX_GROUPS pyramid levels of equal C in ONE launch (independent levels only). */
+typedef struct DrnBnApplyDesc {
+  const void* raw;
+  const float* scale_shift;
+  void* out;
+  const void* up;     /* or NULL */
+  const float* gate;  /* or NULL (with gated) */
+  void* gated;
+  int32_t ld_raw, ld_out, ld_up, ldg, ld_gated, M, L;
+} DrnBnApplyDesc;
+int drn_bn_apply_multi(const DrnBnApplyDesc* descs /*host*/, int n, int C, int relu, int dtype, void* stream);
 /* dRaw, dgamma, dbeta from dOut; ReLU mask recomputed from raw; draw may alias dout. */
 int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld_raw, const float* scale_shift, const float* save,
                const float* gamma, void* draw, int ld_draw, float* dgamma, float* dbeta, int accumulate, int M, int C, int relu,
                float* ws /* >= 515*C floats */, int dtype, void* stream);
+/* ... for up to DRN_MAX_GROUPS levels of equal C in three launches; levels sharing one module pass the same dgamma/dbeta
+ * with accumulate = 1 from the second level on (summed in level order).  ws >= n*515*C floats. */
+typedef struct DrnBnBwdDesc {
+  const void* dout;
+  const void* raw;
+  const float* scale_shift;
+  const float* save;
+  const float* gamma;
+  void* draw;
+  float* dgamma;
+  float* dbeta;
+  int32_t ld_dout, ld_raw, ld_draw, accumulate, M;
+} DrnBnBwdDesc;
+int drn_bn_bwd_multi(const DrnBnBwdDesc* descs /*host*/, int n, int C, int relu, float* ws, int dtype, void* stream);
 
 /* ---- 1-2 channel output heads (drn_amd/csrc/heads.hip; model/fcos.py:43-49,68,96-102) ------------------- */
 typedef struct DrnHeadGroup {
