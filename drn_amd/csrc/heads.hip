@@ -74,25 +74,40 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
     float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
     head_load_w<T>(W, C, taps, N, v * VN, live, wr);
     if (!live) continue;
+    // four rows at a time: all 12 source addresses first, then 12 independent 16-byte loads, then the FMAs (a masked tap
+    // re-reads the row itself and is skipped in the arithmetic) -- no control flow between the loads
 #pragma unroll
-    for (int i = 0; i < HEAD_RPW; ++i) {
-      const int r = r0 + i;
-      if (r >= P.total_rows) break;
-      const HeadGroup& G = P.g[head_group_of(P, r)];
-      const int m = r - G.row_start;
-      const int s = m / G.L, t = m - s * G.L;
-      const T* __restrict__ X = (const T*)G.X;
+    for (int h = 0; h < HEAD_RPW; h += 4) {
+      const T* src[4][HEAD_MAX_TAPS];
+      bool ok[4][HEAD_MAX_TAPS];
 #pragma unroll
-      for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
-        const int st = t + tp - P.pad;
-        if (tp >= taps || st < 0 || st >= G.L) continue;
-        float x[VN];
-        V16<T>::load(X + (long)(s * G.L + st) * G.ldx + v * VN, x);
+      for (int i = 0; i < 4; ++i) {
+        const bool rv = r0 + h + i < P.total_rows;
+        const int r = rv ? r0 + h + i : P.total_rows - 1;
+        const HeadGroup& G = P.g[head_group_of(P, r)];
+        const int m = r - G.row_start;
+        const int s = m / G.L, t = m - s * G.L;
 #pragma unroll
-        for (int n = 0; n < HEAD_MAX_N; ++n)
-#pragma unroll
-          for (int k = 0; k < VN; ++k) acc[i][n] = fmaf(x[k], wr[n][tp][k], acc[i][n]);
+        for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+          const int st = t + tp - P.pad;
+          ok[i][tp] = rv && tp < taps && st >= 0 && st < G.L;
+          src[i][tp] = (const T*)G.X + (long)(s * G.L + (ok[i][tp] ? st : t)) * G.ldx + v * VN;
+        }
       }
+      float x[4][HEAD_MAX_TAPS][VN];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) V16<T>::load(src[i][tp], x[i][tp]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp)
+          if (ok[i][tp])
+#pragma unroll
+            for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+              for (int k = 0; k < VN; ++k) acc[h + i][n] = fmaf(x[i][tp][k], wr[n][tp][k], acc[h + i][n]);
     }
   }
 #pragma unroll
@@ -127,34 +142,49 @@ __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadParams
   if (v * VN >= C || r0 >= P.total_rows) return;
   float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
   head_load_w<T>(W, C, taps, N, v * VN, true, wr);
-#pragma unroll 2
-  for (int i = 0; i < HEAD_RPW; ++i) {
-    const int r = r0 + i;
-    if (r >= P.total_rows) break;
-    const HeadGroup& G = P.g[head_group_of(P, r)];
-    const int m = r - G.row_start;
-    const int s = m / G.L, t = m - s * G.L;
-    T* dst = (T*)G.dX + (long)m * G.ldx + v * VN;
-    float a[VN];
-    if (accumulate) V16<T>::load(dst, a);
-    else {
+  // four rows at a time: the 4 x taps x N gradient scalars are fetched together (independent loads), then the FMAs
 #pragma unroll
-      for (int k = 0; k < VN; ++k) a[k] = 0.f;
-    }
+  for (int h = 0; h < HEAD_RPW; h += 4) {
+    float dv[4][HEAD_MAX_TAPS][HEAD_MAX_N];
+    T* dst[4];
+    bool rv[4];
 #pragma unroll
-    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
-      const int to = t - tp + P.pad;   // output position that read this input through tap `tp`
-      if (tp >= taps || to < 0 || to >= G.L) continue;
-      const long ro = (long)(G.row_start + s * G.L + to) * N;
+    for (int i = 0; i < 4; ++i) {
+      rv[i] = r0 + h + i < P.total_rows;
+      const int r = rv[i] ? r0 + h + i : P.total_rows - 1;
+      const HeadGroup& G = P.g[head_group_of(P, r)];
+      const int m = r - G.row_start;
+      const int s = m / G.L, t = m - s * G.L;
+      dst[i] = (T*)G.dX + (long)m * G.ldx + v * VN;
 #pragma unroll
-      for (int n = 0; n < HEAD_MAX_N; ++n)
-        if (n < N) {
-          const float dv = head_dz(P, G, dout, out, ro + n);
+      for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+        const int to = t - tp + P.pad;   // output position that read this input through tap `tp`
+        const bool ok = rv[i] && tp < taps && to >= 0 && to < G.L;
+        const long ro = (long)(G.row_start + s * G.L + (ok ? to : t)) * N;
 #pragma unroll
-          for (int k = 0; k < VN; ++k) a[k] = fmaf(dv, wr[n][tp][k], a[k]);
+        for (int n = 0; n < HEAD_MAX_N; ++n) {          // always a valid address; masked afterwards
+          const float z = head_dz(P, G, dout, out, ro + (n < N ? n : 0));
+          dv[i][tp][n] = (ok && n < N) ? z : 0.f;
         }
+      }
     }
-    V16<T>::store(dst, a);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!rv[i]) continue;
+      float a[VN];
+      if (accumulate) V16<T>::load(dst[i], a);
+      else {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) a[k] = 0.f;
+      }
+#pragma unroll
+      for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp)
+#pragma unroll
+        for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+          for (int k = 0; k < VN; ++k) a[k] = fmaf(dv[i][tp][n], wr[n][tp][k], a[k]);
+      V16<T>::store(dst[i], a);
+    }
   }
 }
 

@@ -34,14 +34,25 @@ extern "C" int drn_qe_embed_fwd(const int64_t* tokens, const float* table, float
 // gradient needs no zero-fill pass.
 __global__ __launch_bounds__(128) void qe_embed_bwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ demb_tm,
                                                            float* __restrict__ dtable, int B, int L, int E, int padding_idx) {
-  __shared__ unsigned char hit[QE_MAX_L * 64];
-  const int v = blockIdx.x, n = B * L;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) hit[i] = (v != padding_idx && tokens[i] == v) ? 1 : 0;
+  __shared__ unsigned long long mask[QE_MAX_L];          // one 64-token ballot per entry, B*L <= 64*QE_MAX_L
+  const int v = blockIdx.x, n = B * L, nch = (n + 63) >> 6;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int ch = wv; ch < nch; ch += 2) {
+    const int i = ch * 64 + lane;
+    const unsigned long long m = __ballot(i < n && v != padding_idx && tokens[i] == v);
+    if (lane == 0) mask[ch] = m;
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     float acc = 0.f;
-    for (int i = 0; i < n; ++i)
-      if (hit[i]) acc += demb_tm[((long)(i % L) * B + i / L) * E + e];      // (b,t) -> time-major row, in token order
+    for (int ch = 0; ch < nch; ++ch) {
+      unsigned long long m = mask[ch];
+      while (m) {                                          // set bits in ascending token order: fixed summation order
+        const int i = ch * 64 + __ffsll((long long)m) - 1;
+        m &= m - 1;
+        acc += demb_tm[((long)(i % L) * B + i / L) * E + e];   // (b,t) -> time-major row
+      }
+    }
     dtable[(long)v * E + e] = acc;
   }
 }
@@ -94,42 +105,79 @@ extern "C" int drn_qe_qvec_bwd(const float* dqvec, const int64_t* lengths, float
 //   att[b][t][:]   = softmax over l < len_b (padded positions masked out)
 //   cmd[t][b][:]   = sum_l att[b][t][l] * out[b][l][:]
 // one workgroup (256 threads) per clip.
+// All 3*len dot products of a clip are accumulated together: a thread owns channels c = tid, tid+256, ... and keeps one
+// partial per (command, word) of the current 8-word chunk, so `out` is read once with independent loads; wave shuffles
+// + a 4-wave LDS sum finish the chunk.
+template <bool BWD>
+__device__ __forceinline__ void qe_dots(const float* __restrict__ ob, const float* __restrict__ v0, const float* __restrict__ v1,
+                                        const float* __restrict__ v2, const float* __restrict__ w, int len, int C,
+                                        float (*res)[QE_MAX_L], float (*part)[QE_NCMD][8]) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int l0 = 0; l0 < len; l0 += 8) {
+    float acc[QE_NCMD][8];
+#pragma unroll
+    for (int t = 0; t < QE_NCMD; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float wc = BWD ? 1.f : w[c];
+      const float q0 = v0 ? v0[c] * wc : 0.f, q1 = v1 ? v1[c] * wc : 0.f, q2 = v2 ? v2[c] * wc : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float o = l0 + j < len ? ob[(long)(l0 + j) * C + c] : 0.f;
+        acc[0][j] = fmaf(q0, o, acc[0][j]);
+        acc[1][j] = fmaf(q1, o, acc[1][j]);
+        acc[2][j] = fmaf(q2, o, acc[2][j]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QE_NCMD; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float r = wave_sum(acc[t][j]);
+        if (lane == 0) part[wv][t][j] = r;
+      }
+    __syncthreads();
+    if (threadIdx.x < QE_NCMD * 8) {
+      const int t = threadIdx.x >> 3, j = threadIdx.x & 7;
+      if (l0 + j < len) res[t][l0 + j] = part[0][t][j] + part[1][t][j] + part[2][t][j] + part[3][t][j];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void qe_attn_fwd_kernel(const float* __restrict__ out, const float* __restrict__ qcmd,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           const long long* __restrict__ lengths, float* __restrict__ att,
                                                           float* __restrict__ cmds, int B, int L, int C) {
   __shared__ float lg[QE_NCMD][QE_MAX_L];
-  const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ float part[4][QE_NCMD][8];
+  const int b = blockIdx.x;
   const int len = min((int)lengths[b], L);
   const float* ob = out + (long)b * L * C;
   const float* qb = qcmd + (long)b * QE_NCMD * C;
-  for (int p = wv; p < QE_NCMD * len; p += 4) {
-    const int t = p / len, l = p - t * len;
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(qb[t * C + c] * w[c], ob[(long)l * C + c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) lg[t][l] = acc + bias[0];
-  }
-  __syncthreads();
+  qe_dots<false>(ob, qb, qb + C, qb + 2 * C, w, len, C, lg, part);
   if (threadIdx.x < QE_NCMD) {
     const int t = threadIdx.x;
+    const float bs = bias[0];
     float mx = -INFINITY;
-    for (int l = 0; l < len; ++l) mx = fmaxf(mx, lg[t][l]);
+    for (int l = 0; l < len; ++l) mx = fmaxf(mx, lg[t][l] + bs);
     float sum = 0.f;
     for (int l = 0; l < len; ++l) {
-      const float e = expf(lg[t][l] - mx);
+      const float e = expf(lg[t][l] + bs - mx);
       lg[t][l] = e;
       sum += e;
     }
     for (int l = 0; l < L; ++l) {
       const float a = l < len ? lg[t][l] / sum : 0.f;
-      if (l < QE_MAX_L) lg[t][l] = a;
+      if (l < len) lg[t][l] = a;
       att[((long)b * QE_NCMD + t) * L + l] = a;
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
     for (int l = 0; l < len; ++l) {
       const float o = ob[(long)l * C + c];
       a0 = fmaf(lg[0][l], o, a0);
@@ -163,7 +211,8 @@ __global__ __launch_bounds__(256) void qe_attn_bwd_kernel(const float* __restric
                                                           float* __restrict__ dw_part, float* __restrict__ dbias_part, int B, int L,
                                                           int C) {
   __shared__ float at[QE_NCMD][QE_MAX_L], dl[QE_NCMD][QE_MAX_L];
-  const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ float part[4][QE_NCMD][8];
+  const int b = blockIdx.x;
   const int len = min((int)lengths[b], L);
   const float* ob = out + (long)b * L * C;
   const float* qb = qcmd + (long)b * QE_NCMD * C;
@@ -175,15 +224,7 @@ __global__ __launch_bounds__(256) void qe_attn_bwd_kernel(const float* __restric
     dl[t][l] = 0.f;
   }
   __syncthreads();
-  for (int p = wv; p < QE_NCMD * len; p += 4) {
-    const int t = p / len, l = p - t * len;
-    float acc = 0.f;
-    if (dc[t])
-      for (int c = lane; c < C; c += 64) acc = fmaf(dc[t][c], ob[(long)l * C + c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) dl[t][l] = acc;          // datt for now
-  }
-  __syncthreads();
+  qe_dots<true>(ob, dc[0], dc[1], dc[2], w, len, C, dl, part);          // dl = datt for now
   if (threadIdx.x < QE_NCMD) {
     const int t = threadIdx.x;
     float dot = 0.f;
@@ -205,6 +246,7 @@ __global__ __launch_bounds__(256) void qe_attn_bwd_kernel(const float* __restric
       q[t] = qb[t * C + c];
       d[t] = dc[t] ? dc[t][c] : 0.f;
     }
+#pragma unroll 4
     for (int l = 0; l < L; ++l) {
       float g = 0.f;
       if (l < len) {
