@@ -37,74 +37,70 @@ struct LstmFwdArgs {
   int B, L, H, s;
 };
 
-// grid (H/16, 2 dirs); block 256 = 4 waves, wave w reduces k in [w*H/4, (w+1)*H/4)
-template <int NBT>
+// grid (H/16, 2 dirs, batch tiles of 16); block 256 = 4 waves, wave w reduces k in [w*H/4, (w+1)*H/4).  The step is
+// latency-bound, so every operand of a wave's K range is requested before the first MFMA (KU iterations of 16 at a time).
+template <int KU>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmFwdArgs A) {
-  __shared__ float red[4][4 * NBT][64][4];   // [wave][gate*NBT + bt][lane][reg]
+  __shared__ float red[4][4][64][4];   // [wave][gate][lane][reg]
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int dir = blockIdx.y, j0 = blockIdx.x * 16;
+  const int dir = blockIdx.y, j0 = blockIdx.x * 16, bt = blockIdx.z;
   const int B = A.B, L = A.L, H = A.H, s = A.s;
   const int t = dir == 0 ? s : L - 1 - s;
   const float* hprev = A.hseq + ((long)(dir * (L + 1) + s) * B) * H;
   const float* W = A.Whh[dir];
-  f32x4 acc[4][NBT];
+  f32x4 acc[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) acc[g][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int kq = H / 4;
   const int row = l & 15, kc = (l >> 4) * 4;
-  for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 16) {
-    f32x4 a[NBT], b[4];
+  const int bb_a = bt * 16 + row;
+  if (s > 0)                            // zero initial state: the first step has no recurrent term
+    for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 16 * KU) {
+      f32x4 a[KU], b[KU][4];
 #pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) {
-      const int bb = bt * 16 + row;
-      a[bt] = (bb < B && s > 0) ? *(const f32x4*)(hprev + (long)bb * H + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < KU; ++u) {
+        const int k = k0 + u * 16 + kc;
+        a[u] = bb_a < B ? *(const f32x4*)(hprev + (long)bb_a * H + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[u][g] = *(const f32x4*)(W + (long)(g * H + j0 + row) * H + k);
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][g][e], acc[g], 0, 0, 0);
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) b[g] = *(const f32x4*)(W + (long)(g * H + j0 + row) * H + k0 + kc);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int bt = 0; bt < NBT; ++bt)
-          acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bt][e], b[g][e], acc[g][bt], 0, 0, 0);
-  }
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int bt = 0; bt < NBT; ++bt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][g * NBT + bt][l][r] = acc[g][bt][r];
+    for (int r = 0; r < 4; ++r) red[w][g][l][r] = acc[g][r];
   __syncthreads();
-  // epilogue: wave w finishes batch tiles bt = w, w+4, ... ; D layout: b = bt*16 + (l>>4)*4 + r, j = j0 + (l&15)
-  for (int bt = w; bt < NBT; bt += 4) {
+  // epilogue: 256 threads = 64 lanes x 4 regs of the D tile; D layout: b = bt*16 + (l>>4)*4 + r, j = j0 + (l&15)
+  {
+    const int r = w;                    // wave w finishes register r of every lane
+    const int bb = bt * 16 + (l >> 4) * 4 + r;
+    if (bb >= B) return;
+    const int j = j0 + (l & 15);
+    float pre[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int bb = bt * 16 + (l >> 4) * 4 + r;
-      if (bb >= B) continue;
-      const int j = j0 + (l & 15);
-      float pre[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v = red[0][g * NBT + bt][l][r] + red[1][g * NBT + bt][l][r] + red[2][g * NBT + bt][l][r] + red[3][g * NBT + bt][l][r];
-        pre[g] = v + A.xproj[(((long)t * B + bb) * 2 + dir) * 4 * H + g * H + j] + A.b_ih[dir][g * H + j] + A.b_hh[dir][g * H + j];
-      }
-      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-      const long st_prev = ((long)(dir * (L + 1) + s) * B + bb) * H + j;
-      const long st_new = ((long)(dir * (L + 1) + s + 1) * B + bb) * H + j;
-      const float cp = s > 0 ? A.cseq[st_prev] : 0.f, hp = s > 0 ? A.hseq[st_prev] : 0.f;
-      const float cn = fg * cp + ig * gg;
-      const float hn = og * tanhf(cn);
-      const bool valid = t < A.lengths[bb];
-      A.cseq[st_new] = valid ? cn : cp;
-      A.hseq[st_new] = valid ? hn : hp;
-      float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
-      gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
-      A.hprev_t[(((long)t * B + bb) * 2 + dir) * H + j] = hp;
-      A.out[((long)bb * L + t) * 2 * H + dir * H + j] = valid ? hn : 0.f;
+    for (int g = 0; g < 4; ++g) {
+      const float v = red[0][g][l][r] + red[1][g][l][r] + red[2][g][l][r] + red[3][g][l][r];
+      pre[g] = v + A.xproj[(((long)t * B + bb) * 2 + dir) * 4 * H + g * H + j] + A.b_ih[dir][g * H + j] + A.b_hh[dir][g * H + j];
     }
+    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+    const long st_prev = ((long)(dir * (L + 1) + s) * B + bb) * H + j;
+    const long st_new = ((long)(dir * (L + 1) + s + 1) * B + bb) * H + j;
+    const float cp = s > 0 ? A.cseq[st_prev] : 0.f, hp = s > 0 ? A.hseq[st_prev] : 0.f;
+    const float cn = fg * cp + ig * gg;
+    const float hn = og * tanhf(cn);
+    const bool valid = t < A.lengths[bb];
+    A.cseq[st_new] = valid ? cn : cp;
+    A.hseq[st_new] = valid ? hn : hp;
+    float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+    gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+    A.hprev_t[(((long)t * B + bb) * 2 + dir) * H + j] = hp;
+    A.out[((long)bb * L + t) * 2 * H + dir * H + j] = valid ? hn : 0.f;
   }
 }
 
@@ -119,11 +115,12 @@ extern "C" int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const f
   A.xproj = xproj; A.Whh[0] = Whh_f; A.Whh[1] = Whh_r; A.hseq = hseq; A.cseq = cseq; A.gates = gates; A.out = out;
   A.hprev_t = hprev_t; A.b_ih[0] = b_ih_f; A.b_hh[0] = b_hh_f; A.b_ih[1] = b_ih_r; A.b_hh[1] = b_hh_r;
   A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
-  dim3 grid(H / 16, 2);
-  const int nbt = cdiv(B, 16);
-  if (nbt == 1) lstm_step_fwd_kernel<1><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
-  else if (nbt == 2) lstm_step_fwd_kernel<2><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
-  else lstm_step_fwd_kernel<4><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
+  dim3 grid(H / 16, 2, cdiv(B, 16));
+  const int kq16 = H / 64;               // 16-wide K iterations per wave
+  if (kq16 % 8 == 0) lstm_step_fwd_kernel<8><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
+  else if (kq16 % 4 == 0) lstm_step_fwd_kernel<4><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
+  else if (kq16 % 2 == 0) lstm_step_fwd_kernel<2><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
+  else lstm_step_fwd_kernel<1><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_lstm_step_fwd");
 }
 
@@ -134,105 +131,117 @@ struct LstmBwdArgs {
   const float* cseq;
   const float* WhhT[2];  // [H][4H] = Whh^T (contiguous along the gate row index)
   float* dgates;         // [L][B][2][4H] by time
-  float* dh;             // [2][B][H]  recurrent dL/dh entering step s (in/out)
   float* dc;             // [2][B][H]
-  float* dh_pass;        // [2][B][H]  scratch
+  float* dh_pass;        // [2][B][H]  dL/dh that bypasses the cell at padded positions (in/out)
   const long long* lengths;
   int B, L, H, s;
 };
 
-// pointwise: dgates for step s, dc for step s-1, and the part of dh that bypasses the cell at padded positions
-__global__ void lstm_step_bwd_pointwise_kernel(const LstmBwdArgs A) {
-  const int B = A.B, L = A.L, H = A.H, s = A.s;
-  const int total = 2 * B * H;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int j = idx % H, bb = (idx / H) % B, dir = idx / (H * B);
-    const int t = dir == 0 ? s : L - 1 - s;
-    const bool valid = t < A.lengths[bb];
-    const long sidx = ((long)dir * B + bb) * H + j;
-    float* dg = A.dgates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
-    const bool first = s == L - 1;                       // nothing flows in from beyond the last step
-    const float dh = (first ? 0.f : A.dh[sidx]) + (valid ? A.dout[((long)bb * L + t) * 2 * H + dir * H + j] : 0.f);
-    const float dcn = first ? 0.f : A.dc[sidx];
-    if (valid) {
-      const float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
-      const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
-      const float cn = A.cseq[((long)(dir * (L + 1) + s + 1) * B + bb) * H + j];
-      const float cp = s > 0 ? A.cseq[((long)(dir * (L + 1) + s) * B + bb) * H + j] : 0.f;
-      const float tc = tanhf(cn);
-      const float dcv = dcn + dh * og * (1.f - tc * tc);
-      dg[0] = dcv * gg * ig * (1.f - ig);
-      dg[H] = dcv * cp * fg * (1.f - fg);
-      dg[2 * H] = dcv * ig * (1.f - gg * gg);
-      dg[3 * H] = dh * tc * og * (1.f - og);
-      A.dc[sidx] = dcv * fg;
-      A.dh_pass[sidx] = 0.f;
-    } else {
-      dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
-      A.dc[sidx] = dcn;
-      A.dh_pass[sidx] = dh;
-    }
+// Cell backward for one (direction, clip, hidden unit) at step s given dL/dh entering that step: writes dgates for time
+// t(s), the running dL/dc for step s-1, and the part of dh that bypasses the cell at padded positions.
+__device__ __forceinline__ void lstm_cell_bwd(const LstmBwdArgs& A, int dir, int bb, int j, int s, float dh_in) {
+  const int B = A.B, L = A.L, H = A.H;
+  const int t = dir == 0 ? s : L - 1 - s;
+  const bool valid = t < A.lengths[bb];
+  const long sidx = ((long)dir * B + bb) * H + j;
+  float* dg = A.dgates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+  const float dh = dh_in + (valid ? A.dout[((long)bb * L + t) * 2 * H + dir * H + j] : 0.f);
+  const float dcn = s == L - 1 ? 0.f : A.dc[sidx];       // nothing flows in from beyond the last step
+  if (valid) {
+    const float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+    const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
+    const float cn = A.cseq[((long)(dir * (L + 1) + s + 1) * B + bb) * H + j];
+    const float cp = s > 0 ? A.cseq[((long)(dir * (L + 1) + s) * B + bb) * H + j] : 0.f;
+    const float tc = tanhf(cn);
+    const float dcv = dcn + dh * og * (1.f - tc * tc);
+    dg[0] = dcv * gg * ig * (1.f - ig);
+    dg[H] = dcv * cp * fg * (1.f - fg);
+    dg[2 * H] = dcv * ig * (1.f - gg * gg);
+    dg[3 * H] = dh * tc * og * (1.f - og);
+    A.dc[sidx] = dcv * fg;
+    A.dh_pass[sidx] = 0.f;
+  } else {
+    dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+    A.dc[sidx] = dcn;
+    A.dh_pass[sidx] = dh;
   }
 }
 
-// dh[dir][b][k] = dh_pass + sum_r dgates[dir][s][b][r] * Whh[dir][r][k];  grid (H/16, 2), 4 waves split r (K = 4H)
-template <int NBT>
-__global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_gemm_kernel(const LstmBwdArgs A) {
-  __shared__ float red[4][NBT][64][4];
+// first backward step (s = L-1): no recurrent gradient yet
+__global__ void lstm_bwd_first_kernel(const LstmBwdArgs A) {
+  const int B = A.B, H = A.H;
+  const int total = 2 * B * H;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+    lstm_cell_bwd(A, idx / (H * B), (idx / H) % B, idx % H, A.L - 1, 0.f);
+}
+
+// dh[dir][b][k] = dh_pass + sum_r dgates[t(s)][b][dir][r] * Whh[dir][r][k], immediately consumed by the cell backward of
+// step s-1 for the same (b, k) -- dh itself never goes to memory.  grid (H/16, 2, batch tiles), 4 waves split r (K = 4H),
+// KU iterations of 16 prefetched at a time.
+template <int KU>
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmBwdArgs A) {
+  __shared__ float red[4][64][4];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int dir = blockIdx.y, k0 = blockIdx.x * 16;
+  const int dir = blockIdx.y, k0 = blockIdx.x * 16, bt = blockIdx.z;
   const int B = A.B, L = A.L, H = A.H, s = A.s;
   const int K = 4 * H, kq = K / 4;
   const int t = dir == 0 ? s : L - 1 - s;
   const float* dg = A.dgates + ((long)t * B * 2 + dir) * K;      // row bb at dg + bb * 2K
   const float* WT = A.WhhT[dir];
-  f32x4 acc[NBT];
-#pragma unroll
-  for (int bt = 0; bt < NBT; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int row = l & 15, rc = (l >> 4) * 4;
-  for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 16) {
-    f32x4 a[NBT];
+  const int bb_a = bt * 16 + row;
+  for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 16 * KU) {
+    f32x4 a[KU], b[KU];
 #pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) {
-      const int bb = bt * 16 + row;
-      a[bt] = bb < B ? *(const f32x4*)(dg + (long)bb * 2 * K + r0 + rc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < KU; ++u) {
+      const int r = r0 + u * 16 + rc;
+      a[u] = bb_a < B ? *(const f32x4*)(dg + (long)bb_a * 2 * K + r) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      b[u] = *(const f32x4*)(WT + (long)(k0 + row) * K + r);
     }
-    const f32x4 b = *(const f32x4*)(WT + (long)(k0 + row) * K + r0 + rc);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int u = 0; u < KU; ++u)
 #pragma unroll
-      for (int bt = 0; bt < NBT; ++bt) acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bt][e], b[e], acc[bt], 0, 0, 0);
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
   }
 #pragma unroll
-  for (int bt = 0; bt < NBT; ++bt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[w][bt][l][r] = acc[bt][r];
+  for (int r = 0; r < 4; ++r) red[w][l][r] = acc[r];
   __syncthreads();
-  for (int bt = w; bt < NBT; bt += 4)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int bb = bt * 16 + (l >> 4) * 4 + r;
-      if (bb >= B) continue;
-      const long sidx = ((long)dir * B + bb) * H + k0 + (l & 15);
-      A.dh[sidx] = A.dh_pass[sidx] + red[0][bt][l][r] + red[1][bt][l][r] + red[2][bt][l][r] + red[3][bt][l][r];
-    }
+  const int r = w;
+  const int bb = bt * 16 + (l >> 4) * 4 + r;
+  if (bb >= B) return;
+  const int k = k0 + (l & 15);
+  const float dh = A.dh_pass[((long)dir * B + bb) * H + k] + red[0][l][r] + red[1][l][r] + red[2][l][r] + red[3][l][r];
+  lstm_cell_bwd(A, dir, bb, k, s - 1, dh);
+}
+
+extern "C" int drn_lstm_bwd_first(const float* dout, const float* gates, const float* cseq, float* dgates, float* dc, float* dh_pass,
+                                  const int64_t* lengths, int B, int L, int H, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(dout && gates && cseq && dgates && dc && dh_pass && lengths, "drn_lstm_bwd_first: null pointer");
+  DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0, "drn_lstm_bwd_first: need B<=64, H%%64==0");
+  LstmBwdArgs A;
+  memset(&A, 0, sizeof(A));
+  A.dout = dout; A.gates = gates; A.cseq = cseq; A.dgates = dgates; A.dc = dc; A.dh_pass = dh_pass;
+  A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = L - 1;
+  lstm_bwd_first_kernel<<<cdiv(2 * B * H, 256), 256, 0, (hipStream_t)stream>>>(A);
+  return drn_launch_status("drn_lstm_bwd_first");
 }
 
 extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const float* WhhT_f, const float* WhhT_r,
-                                 float* dgates, float* dh, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s,
+                                 float* dgates, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s,
                                  void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
-  DRN_CHECK_ARG(dout && gates && cseq && WhhT_f && WhhT_r && dgates && dh && dc && dh_pass && lengths, "drn_lstm_step_bwd: null pointer");
-  DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0 && s >= 0 && s < L, "drn_lstm_step_bwd: need B<=64, H%%64==0");
+  DRN_CHECK_ARG(dout && gates && cseq && WhhT_f && WhhT_r && dgates && dc && dh_pass && lengths, "drn_lstm_step_bwd: null pointer");
+  DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0 && s >= 1 && s < L, "drn_lstm_step_bwd: need B<=64, H%%64==0, 1<=s<L");
   LstmBwdArgs A;
-  A.dout = dout; A.gates = gates; A.cseq = cseq; A.WhhT[0] = WhhT_f; A.WhhT[1] = WhhT_r; A.dgates = dgates; A.dh = dh; A.dc = dc;
+  memset(&A, 0, sizeof(A));
+  A.dout = dout; A.gates = gates; A.cseq = cseq; A.WhhT[0] = WhhT_f; A.WhhT[1] = WhhT_r; A.dgates = dgates; A.dc = dc;
   A.dh_pass = dh_pass; A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
-  lstm_step_bwd_pointwise_kernel<<<cdiv(2 * B * H, 256), 256, 0, stream>>>(A);
-  dim3 grid(H / 16, 2);
-  const int nbt = cdiv(B, 16);
-  if (nbt == 1) lstm_step_bwd_gemm_kernel<1><<<grid, LSTM_THREADS, 0, stream>>>(A);
-  else if (nbt == 2) lstm_step_bwd_gemm_kernel<2><<<grid, LSTM_THREADS, 0, stream>>>(A);
-  else lstm_step_bwd_gemm_kernel<4><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  dim3 grid(H / 16, 2, cdiv(B, 16));
+  const int kq16 = H / 16;               // 16-wide K iterations per wave (K = 4H over 4 waves)
+  if (kq16 % 8 == 0) lstm_step_bwd_kernel<8><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  else lstm_step_bwd_kernel<4><<<grid, LSTM_THREADS, 0, stream>>>(A);
   return drn_launch_status("drn_lstm_step_bwd");
 }

@@ -724,9 +724,10 @@ def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L):
     dev = dout.device
     wtf, wtr = packed(w_hh_f, (1, 2, 0), ops.F32), packed(w_hh_r, (1, 2, 0), ops.F32)      # W_hh^T, cached
     dgates = torch.empty((L, B, 2, 4 * H), dtype=torch.float32, device=dev)
-    scratch = torch.empty((3, 2, B, H), dtype=torch.float32, device=dev)
-    for s in range(L - 1, -1, -1):
-        ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], scratch[2], lens, B, L, H, s)
+    scratch = torch.empty((2, 2, B, H), dtype=torch.float32, device=dev)
+    ops.lstm_bwd_first(dout, gates, cseq, dgates, scratch[0], scratch[1], lens, B, L, H)
+    for s in range(L - 1, 0, -1):           # W_hh product of step s + cell backward of step s-1 in one launch
+        ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], lens, B, L, H, s)
     dg = dgates.view(L * B, 8 * H)
     hp = hprev.view(L * B, 2 * H)
     dwih_f = torch.mm(dg[:, :4 * H].t(), emb_tm, out=grad_buffer(w_ih_f))

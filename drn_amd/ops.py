@@ -319,8 +319,13 @@ def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens
           "drn_lstm_step_fwd")
 
 
-def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dh, dc, dh_pass, lens, B, L, H, s):
-    check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), _p(dgates), _p(dh), _p(dc), _p(dh_pass),
+def lstm_bwd_first(dout, gates, cseq, dgates, dc, dh_pass, lens, B, L, H):
+    check(lib().drn_lstm_bwd_first(_p(dout), _p(gates), _p(cseq), _p(dgates), _p(dc), _p(dh_pass), _p(lens), B, L, H, _stream()),
+          "drn_lstm_bwd_first")
+
+
+def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dc, dh_pass, lens, B, L, H, s):
+    check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), _p(dgates), _p(dc), _p(dh_pass),
                                   _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")
 
 

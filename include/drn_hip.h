@@ -254,12 +254,14 @@ int drn_lgp_bwd(const void* x, int ldx, const float* qn, const float* att, const
 int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, const float* b_ih_f, const float* b_hh_f,
                       const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out, float* hprev_t,
                       const int64_t* lengths, int B, int L, int H, int s, void* stream);
-/* Backward of step s (call with s = L-1 .. 0): consumes dout [B][L][2H] and the running dh/dc [2][B][H] (ignored at
- * s = L-1), writes dgates (for the weight-gradient GEMMs) and the new dh/dc.  WhhT_* = Whh^T as [H][4H]; dh_pass is
- * [2][B][H] scratch. */
+/* Backward: drn_lstm_bwd_first does the cell backward of the last step (s = L-1) from dout [B][L][2H] alone; then
+ * drn_lstm_step_bwd for s = L-1 .. 1 propagates through W_hh of step s (dgates[t(s)] x Whh) and applies the cell backward
+ * of step s-1 in its epilogue (the recurrent dL/dh never goes to memory).  dgates is the operand of the weight-gradient
+ * GEMMs; dc / dh_pass are [2][B][H] running state.  WhhT_* = Whh^T as [H][4H]. */
+int drn_lstm_bwd_first(const float* dout, const float* gates, const float* cseq, float* dgates, float* dc, float* dh_pass,
+                       const int64_t* lengths, int B, int L, int H, void* stream);
 int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const float* WhhT_f, const float* WhhT_r,
-                      float* dgates, float* dh, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s,
-                      void* stream);
+                      float* dgates, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s, void* stream);
 
 /* ---- fused clip_grad_norm_ + Adam over flat gradient buckets (drn_amd/csrc/optim.hip; main.py:140,238-243) ---- */
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */
