@@ -41,7 +41,7 @@ class WgradDesc(ctypes.Structure):
 
 class PackDesc(ctypes.Structure):
     _fields_ = [("in_", c_void_p), ("out", c_void_p), ("sa", ctypes.c_int64), ("sb", ctypes.c_int64), ("sc", ctypes.c_int64),
-                ("A", c_int32), ("B", c_int32), ("C", c_int32)]
+                ("A", c_int32), ("B", c_int32), ("C", c_int32), ("ldo", ctypes.c_int64)]
 
 
 class ColSeg(ctypes.Structure):

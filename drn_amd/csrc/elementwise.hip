@@ -112,7 +112,7 @@ extern "C" int drn_pack_weight(const float* in, void* out, int A, int B, int C, 
 struct PackItem {
   const float* in;
   void* out;
-  long sa, sb, sc;
+  long sa, sb, sc, ldo;   // ldo: elements between consecutive (a,b) rows of out (C when contiguous)
   int A, B, C, blk_start;
 };
 struct PackParams {
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(PackParams P) {
       for (int j = 0; j < 4; ++j) {
         const int sl = ty + 16 * j, sx = s0 + sl, r = r0 + tx * 4;
         if (sx < S && r < R) {
-          T* o = out + (long)sx * R + r;
+          T* o = out + (long)sx * it.ldo + r;
           DT<T>::st(o + 0, tile[tx * 4 + 0][sl]); DT<T>::st(o + 1, tile[tx * 4 + 1][sl]);
           DT<T>::st(o + 2, tile[tx * 4 + 2][sl]); DT<T>::st(o + 3, tile[tx * 4 + 3][sl]);
         }
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(PackParams P) {
     const long ab = i / it.C;
     const int b = (int)(ab % it.B);
     const long a = ab / it.B;
-    DT<T>::st(out + i, it.in[a * it.sa + b * it.sb + c * it.sc]);
+    DT<T>::st(out + ab * it.ldo + c, it.in[a * it.sa + b * it.sb + c * it.sc]);
   }
 }
 
@@ -183,6 +183,7 @@ extern "C" int drn_pack_weights(const DrnPackDesc* d, int n, int dtype, void* st
       const DrnPackDesc& s = d[base + i];
       PackItem& it = P.it[i];
       it.in = s.in; it.out = s.out; it.sa = s.sa; it.sb = s.sb; it.sc = s.sc; it.A = s.A; it.B = s.B; it.C = s.C;
+      it.ldo = s.ldo > 0 ? s.ldo : s.C;
       it.blk_start = blocks;
       const long total = (long)s.A * s.B * s.C;
       long nb = (total + 2047) / 2048;            // 8 elements per thread

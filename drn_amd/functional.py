@@ -82,6 +82,33 @@ def stacked(params):
     return out
 
 
+def _stack_t_items(out, params):
+    items, c = [], 0
+    for p in params:                                    # p (N, K) -> out[:, c:c+N] = p^T
+        n = p.shape[0]
+        items.append((p.detach().unsqueeze(-1), (1, 2, 0), out[:, c:c + n]))
+        c += n
+    return items
+
+
+def stacked_t(params):
+    """[W_0^T | W_1^T | ...] for Linear weights W_i (N_i, K): a (K, sum N_i) fp32 matrix, so that the input gradient
+    dX = [dY_0 | dY_1 | ...] [W_0; W_1; ...] is one NT product.  Cached / refreshed like `stacked`."""
+    key = ("t",) + tuple((id(p), p.data_ptr()) for p in params)
+    ver = (tuple(p._version for p in params), _weights_epoch)
+    hit = _stack_cache.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == params[0].device and all(r() is p for r, p in zip(hit[2], params)):
+        return hit[1]
+    shape = (params[0].shape[1], sum(p.shape[0] for p in params))
+    out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
+        torch.empty(shape, dtype=torch.float32, device=params[0].device)
+    ops.pack_weights_into(_stack_t_items(out, params), ops.F32)
+    if len(_stack_cache) > 64:
+        _stack_cache.clear()
+    _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
+    return out
+
+
 def repack_all():
     """Refresh every cached re-laid weight IN PLACE with one launch per dtype (drn_pack_weights) and mark it current:
     an optimizer that has just updated all parameters calls this instead of leaving ~20 small per-use launches to
@@ -96,10 +123,12 @@ def repack_all():
     stack_items = []
     for key, (ver, out, refs) in list(_stack_cache.items()):
         ps = [r() for r in refs]
-        if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key or out.device != ps[0].device:
+        transposed = key[0] == "t"
+        if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != (key[1:] if transposed else key) \
+                or out.device != ps[0].device:
             del _stack_cache[key]
             continue
-        stack_items += _stack_items(out, ps)
+        stack_items += _stack_t_items(out, ps) if transposed else _stack_items(out, ps)
         _stack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
     for code, items in by_code.items():
         extra = stack_items if code == ops.F32 else []
@@ -740,6 +769,49 @@ def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L):
     return demb_tm, (dwih_f, dwhh_f, dbs[0], dbs[1], dwih_r, dwhh_r, dbs[2], dbs[3])
 
 
+def _linear_fwd(x, W, b, relu=False, Ws=None):
+    """y = x W^T + b (ReLU) for batch-sized fp32 x; W is a Parameter (or pass the stacked copy as Ws)."""
+    Wm = W.detach() if Ws is None else Ws
+    if ops.skinny_ok(x.shape[0], Wm.shape[0], Wm.shape[1]) and x.stride(1) == 1 and x.stride(0) % 4 == 0:
+        return ops.skinny_linear(x, Wm, b, relu)
+    y = torch.addmm(b, x, Wm.t())
+    return y.relu_() if relu else y
+
+
+def _linear_dx(dy, Wt):
+    """dx = dy W given the cached transposed copy Wt = W^T (K, N) (fp32)."""
+    if ops.skinny_ok(dy.shape[0], Wt.shape[0], Wt.shape[1]) and dy.stride(1) == 1 and dy.stride(0) % 4 == 0:
+        return ops.skinny_linear(dy, Wt)
+    return torch.mm(dy, Wt.t())
+
+
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear on a batch-sized fp32 input (the per-level gate projections qInput{t}, model/main_model.py:37-50):
+    forward / input gradient on the skinny MFMA kernel, weight gradient (an outer product over the batch) by the
+    library, bias gradient by drn_colsum_segs; parameter gradients land in the reducer's buckets."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.float().contiguous()
+        ctx.save_for_backward(x, W, b)
+        return _linear_fwd(x, W, b.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, b = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        dx = _linear_dx(dy, packed(W, (1, 2, 0), ops.F32)) if ctx.needs_input_grad[0] else None
+        dW = torch.mm(dy.t(), x, out=grad_buffer(W))
+        db = grad_buffer(b)
+        ops.colsum_segs(dy, dy.shape[1], dy.shape[0], [(db, 0, dy.shape[1])])
+        return dx, dW, db
+
+
+def linear(x, lin):
+    """lin: nn.Linear parameter holder; x (M <= 64, K) fp32 on the GPU."""
+    return _LinearFn.apply(x, lin.weight, lin.bias)
+
+
 def _dev_lengths(lengths, dev):
     if lengths.device != dev or lengths.dtype != torch.int64:
         lengths = lengths.to(device=dev, dtype=torch.int64)
@@ -801,8 +873,8 @@ class _QueryEncoderFn(torch.autograd.Function):
         out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L)
         qvec = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
         ops.qe_qvec_fwd(out, lens, qvec, B, L, C)                          # language_module.py:48-54
-        base = torch.addmm(bq.detach(), qvec, Wq.detach().t()).relu_()     # language_module.py:55-56
-        qcmd = torch.addmm(stacked([b0, b1, b2]), base, stacked([W0, W1, W2]).t())     # (B, 3*C): all three qInput{t}
+        base = _linear_fwd(qvec, Wq, bq.detach(), relu=True)               # language_module.py:55-56
+        qcmd = _linear_fwd(base, None, stacked([b0, b1, b2]), Ws=stacked([W0, W1, W2]))    # (B, 3*C): all three qInput{t}
         att = torch.empty((B, 3, L), dtype=torch.float32, device=dev)
         cmds = torch.empty((3, B, C), dtype=torch.float32, device=dev)
         ops.qe_attn_fwd(out, qcmd, wl.detach(), bl.detach(), lens, att, cmds, B, L, C)
@@ -829,13 +901,13 @@ class _QueryEncoderFn(torch.autograd.Function):
         ops.colsum_segs(dw_part, C, B, [(dwl, 0, C)])
         ops.colsum_segs(db_part, 1, B, [(dbl, 0, 1)])
         # qInput{t}: q_cmd_t = base W_t^T + b_t
-        dbase = torch.mm(dqcmd, stacked([W0, W1, W2]))
+        dbase = _linear_dx(dqcmd, stacked_t([W0, W1, W2]))
         dW = [torch.mm(dqcmd[:, t * C:(t + 1) * C].t(), base, out=grad_buffer(W)) for t, W in enumerate((W0, W1, W2))]
         db = [grad_buffer(b) for b in (b0, b1, b2)]
         ops.colsum_segs(dqcmd, 3 * C, B, [(db[t], t * C, C) for t in range(3)])
         # qInput + ReLU
         dpre = torch.ops.aten.threshold_backward(dbase, base, 0)
-        dqvec = torch.mm(dpre, Wq.detach())
+        dqvec = _linear_dx(dpre, packed(Wq, (1, 2, 0), ops.F32))
         dWq = torch.mm(dpre.t(), qvec, out=grad_buffer(Wq))
         dbq = grad_buffer(bq)
         ops.colsum_segs(dpre, H, B, [(dbq, 0, H)])

@@ -50,7 +50,7 @@ class mainModel(nn.Module):
     def encode_query(self, query_tokens, query_length):
         """Query encoder + per-level gate projections (model/main_model.py:47-50): three (B, C_l) fp32 gate tensors."""
         query_features = self.query_encoder(query_tokens, query_length)
-        return [getattr(self, "qInput%d" % i)(query_features[i]) for i in range(len(query_features))]
+        return [DF.linear(query_features[i], getattr(self, "qInput%d" % i)) for i in range(len(query_features))]
 
     def forward_core(self, gates, props_features, props_start_end, gt_start_end):
         """Everything downstream of the gates: the HIP path proper (no host-side data dependence, hipGraph-capturable)."""

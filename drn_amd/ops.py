@@ -164,8 +164,17 @@ def pack_weight(w, perm, dtype):
     return out
 
 
+def _row_stride(out):
+    """Elements between consecutive rows of `out` viewed as (rows, C); size-1 dims carry meaningless strides."""
+    for dim in range(out.dim() - 2, -1, -1):
+        if out.shape[dim] > 1:
+            return out.stride(dim)
+    return 0
+
+
 def pack_weights_into(items, dtype):
-    """items: [(w, perm, out)] -- refresh existing re-laid copies `out` of fp32 weights `w` in one launch."""
+    """items: [(w, perm, out)] -- refresh existing re-laid copies `out` of fp32 weights `w` in one launch.  `out` may be a
+    column block of a wider buffer (its row stride is honoured)."""
     from ._lib import PackDesc
     arr = (PackDesc * len(items))()
     for i, (w, perm, out) in enumerate(items):
@@ -174,7 +183,28 @@ def pack_weights_into(items, dtype):
         d.in_, d.out = _p(w), _p(out)
         d.A, d.B, d.C = (w.shape[j] for j in perm)
         d.sa, d.sb, d.sc = (w.stride(j) for j in perm)
+        d.ldo = _row_stride(out)
     check(lib().drn_pack_weights(arr, len(items), dtype, _stream()), "drn_pack_weights")
+
+
+def skinny_linear(x, W, bias=None, relu=False):
+    """y = x W^T (+ bias)(ReLU) for batch-sized x (M <= 64 rows), fp32, exact-fp32 MFMA (drn_amd/csrc/skinny.hip)."""
+    _need_gpu(x, W)
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and x.stride(1) == 1 and W.is_contiguous()
+    L = lib()
+    L.drn_skinny_ws_elems.restype = ctypes.c_int64
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    n_ws = int(L.drn_skinny_ws_elems(M, N, K))
+    ws = workspace(n_ws, x.device) if n_ws else None
+    check(L.drn_skinny_linear(_p(x), x.stride(0), _p(W), _p(bias), _p(y), N, M, N, K, int(relu), _p(ws), _stream()),
+          "drn_skinny_linear")
+    return y
+
+
+def skinny_ok(M, N, K):
+    return M <= 64 and N % 16 == 0 and K % 64 == 0
 
 
 def pos_embed_fwd(feat, W, b, out2d, ld_out, M, C, dtype):

@@ -96,6 +96,7 @@ typedef struct {
   void* out;
   int64_t sa, sb, sc;
   int32_t A, B, C;
+  int64_t ldo; /* elements between consecutive (a,b) rows of out; 0 = contiguous (C) */
 } DrnPackDesc;
 int drn_pack_weights(const DrnPackDesc* items /*host*/, int n, int dtype, void* stream);
 /* position_transform = nn.Linear(3,256) on [start,end,duration] (model/main_model.py:34,51-55), written straight
@@ -234,6 +235,14 @@ typedef struct {
   int32_t col0, n;
 } DrnColSeg;
 int drn_colsum_segs(const float* X, int ld, int M, const DrnColSeg* segs /*host*/, int nsegs, void* stream);
+
+/* ---- batch-sized dense layers (drn_amd/csrc/skinny.hip; model/language_module.py:20-23,55-56, model/main_model.py:37-50)
+ * Y[M][N] = X[M][K] * W[N][K]^T (+ bias[N]) (ReLU), fp32, M <= 64 rows (clips per GPU), N % 16 == 0, K % 64 == 0: the
+ * qInput* / gate projections forward, and their input gradients through transposed weight copies.  Exact-fp32 MFMA,
+ * K split over workgroups with a deterministic second pass; ws >= drn_skinny_ws_elems() floats (may be 0). */
+int64_t drn_skinny_ws_elems(int M, int N, int K);
+int drn_skinny_linear(const float* X, int ldx, const float* W, const float* bias /*or NULL*/, float* Y, int ldy, int M, int N, int K,
+                      int relu, float* ws, void* stream);
 
 /* ---- language-guided pooling (drn_amd/csrc/lgp.hip; model/LGP.py:29-51) ---------------------------------------
  * x (B, t, C) channels-last, qn (B, C) fp32 = BN(conv1x1(query)) prepared by the caller, out (B, t/2, C),

@@ -94,3 +94,36 @@ def test_query_encoder_rejects_overlong_queries():
     tokens = torch.ones(2, 65, dtype=torch.int64, device="cuda:0")
     with pytest.raises(DrnError):
         mod(tokens, torch.tensor([65, 65], device="cuda:0"))
+
+
+@pytest.mark.parametrize("M,N,K,relu,bias", [(32, 512, 2048, True, True), (32, 3072, 512, False, True), (5, 16, 64, False, False),
+                                             (64, 4096, 1024, False, True), (33, 48, 192, True, True), (32, 512, 3072, False, False)])
+def test_skinny_linear(M, N, K, relu, bias):
+    """drn_skinny_linear (exact-fp32 MFMA, K split over workgroups) against fp64."""
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to("cuda:0")
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to("cuda:0")
+    b = torch.randn(N, generator=g).to("cuda:0") if bias else None
+    y = ops.skinny_linear(x, W, b, relu)
+    want = x.double() @ W.double().t() + (b.double() if bias else 0)
+    want = want.clamp_min(0) if relu else want
+    _close(y, want.cpu(), 2e-6, "skinny")
+
+
+def test_gate_linear_function_matches_torch():
+    from drn_amd import functional as DF
+    g = torch.Generator().manual_seed(3)
+    for N, K in [(4096, 1024), (500, 1024), (256, 1024)]:          # 500: not a multiple of 16 -> library path
+        lin = torch.nn.Linear(K, N).to("cuda:0")
+        ref = torch.nn.Linear(K, N).double()
+        ref.load_state_dict({k: v.double().cpu() for k, v in lin.state_dict().items()})
+        x = torch.randn(32, K, generator=g)
+        xr = x.double().requires_grad_()
+        xh = x.to("cuda:0").requires_grad_()
+        w = torch.randn(32, N, generator=g)
+        (ref(xr) * w.double()).sum().backward()
+        (DF.linear(xh, lin) * w.to("cuda:0")).sum().backward()
+        _close(xh.grad, xr.grad, 1e-5, "dx")
+        _close(lin.weight.grad, ref.weight.grad, 1e-5, "dW")
+        _close(lin.bias.grad, ref.bias.grad, 1e-5, "db")
