@@ -3,8 +3,9 @@
 // PyTorch put them and are reached through a small device-resident segment table.  Two launches per bucket:
 //   1. drn_sumsq_partials : per-block sums of g^2 (fixed order -> deterministic norm); the first call of a step
 //      also advances the device-side step counter (no host scalar changes between steps -> hipGraph friendly);
-//   2. drn_adam_bucket    : every block re-derives the global clip coefficient from the partials, then
-//      m,v,p updates with torch.optim.Adam's formula (bias-corrected, eps outside the sqrt, no weight decay).
+//   2. drn_sumsq_finalize : ONE workgroup adds all partials of all buckets in a fixed order -> the squared global norm;
+//   3. drn_adam_bucket    : clip coefficient from that scalar, then m,v,p updates with torch.optim.Adam's formula
+//      (bias-corrected, eps outside the sqrt, no weight decay).
 #include "common.h"
 #include "../../include/drn_hip.h"
 
@@ -39,6 +40,21 @@ extern "C" int drn_sumsq_partials(const float* g, int64_t n, float* partials, in
   return drn_launch_status("drn_sumsq_partials");
 }
 
+__global__ __launch_bounds__(1024) void sumsq_finalize_kernel(const float* __restrict__ partials, int n, float* __restrict__ out) {
+  __shared__ float sh[17];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += partials[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+extern "C" int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(partials && total_sumsq && npartials > 0, "drn_sumsq_finalize: bad args");
+  sumsq_finalize_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partials, npartials, total_sumsq);
+  return drn_launch_status("drn_sumsq_finalize");
+}
+
 struct AdamArgs {
   const float* g;           // flat gradients of this bucket
   float* m;
@@ -47,19 +63,14 @@ struct AdamArgs {
   const long* seg_start;    // [nseg+1] prefix offsets of the tensors inside the flat buffers (device)
   float* const* p_ptr;      // [nseg] parameter base pointers (device)
   int nseg;
-  const float* partials;    // sums of g^2 over ALL buckets
-  int npartials;
+  const float* total_sumsq; // squared global gradient norm over ALL buckets (drn_sumsq_finalize)
   const int* step_counter;
   float lr, beta1, beta2, eps, max_norm;
 };
 
 __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs A) {
-  __shared__ float sh[17];
   __shared__ int first_seg;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < A.npartials; i += OPT_THREADS) s += A.partials[i];
-  s = block_sum(s, sh);
-  const float total_norm = sqrtf(s);
+  const float total_norm = sqrtf(A.total_sumsq[0]);
   float clip = A.max_norm > 0.f ? A.max_norm / (total_norm + 1e-6f) : 1.f;   // torch.nn.utils.clip_grad_norm_
   clip = fminf(clip, 1.f);
   const int t = *A.step_counter;
@@ -113,14 +124,14 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
 }
 
 extern "C" int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev,
-                               int nseg, const float* partials, int npartials, const int* step_counter, float lr, float beta1,
+                               int nseg, const float* total_sumsq, const int* step_counter, float lr, float beta1,
                                float beta2, float eps, float max_norm, void* stream) {
   drn_clear_status();
-  DRN_CHECK_ARG(g && m && v && n > 0 && seg_start_dev && p_ptr_dev && nseg > 0 && partials && npartials > 0 && step_counter,
+  DRN_CHECK_ARG(g && m && v && n > 0 && seg_start_dev && p_ptr_dev && nseg > 0 && total_sumsq && step_counter,
                 "drn_adam_bucket: bad args");
   AdamArgs A;
   A.g = g; A.m = m; A.v = v; A.n = n; A.seg_start = (const long*)seg_start_dev; A.p_ptr = p_ptr_dev; A.nseg = nseg;
-  A.partials = partials; A.npartials = npartials; A.step_counter = step_counter;
+  A.total_sumsq = total_sumsq; A.step_counter = step_counter;
   A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.max_norm = max_norm;
   adam_bucket_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_adam_bucket");

@@ -19,13 +19,13 @@ struct SkinnyArgs {
   int ldx, ldy, M, N, K, kslice, relu, direct;
 };
 
-// grid (N/16, ksplit); wave w of a workgroup reduces k in [ks*kslice + w*kslice/4, ... + kslice/4)
-template <int NBT, int KU>
-__global__ __launch_bounds__(SK_THREADS) void skinny_nt_kernel(const SkinnyArgs A) {
-  __shared__ float red[4][NBT][64][4];
+// grid (N/16, ksplit); wave w of a workgroup (NW = 4 or 16 waves) reduces k in [ks*kslice + w*kslice/NW, ... + kslice/NW)
+template <int NBT, int KU, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_nt_kernel(const SkinnyArgs A) {
+  __shared__ float red[NW][NBT][64][4];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int n0 = blockIdx.x * 16, ks = blockIdx.y;
-  const int kq = A.kslice / 4;
+  const int kq = A.kslice / NW;
   const int row = l & 15, kc = (l >> 4) * 4;
   f32x4 acc[NBT];
 #pragma unroll
@@ -55,13 +55,16 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_nt_kernel(const SkinnyArgs 
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][bt][l][r] = acc[bt][r];
   __syncthreads();
-  // D layout: m = bt*16 + (l>>4)*4 + r, n = n0 + (l&15); wave w finishes register r = w of every lane
+  // D layout: m = bt*16 + (l>>4)*4 + r, n = n0 + (l&15); wave w < 4 finishes register r = w of every lane
+  if (w >= 4) return;
   const int r = w, n = n0 + (l & 15);
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt) {
     const int m = bt * 16 + (l >> 4) * 4 + r;
     if (m >= A.M) continue;
-    float v = red[0][bt][l][r] + red[1][bt][l][r] + red[2][bt][l][r] + red[3][bt][l][r];
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) v += red[q][bt][l][r];
     if (A.direct) {
       if (A.bias) v += A.bias[n];
       if (A.relu) v = fmaxf(v, 0.f);
@@ -84,9 +87,13 @@ __global__ void skinny_reduce_kernel(const float* __restrict__ part, int ksplit,
   Y[(long)m * ldy + n] = v;
 }
 
+// 16 waves per workgroup split K inside the workgroup (no second pass); K is split over workgroups as well only when
+// there are too few column tiles to matter otherwise
+static int skinny_waves(int K) { return (K % 256 == 0 && K >= 1024) ? 16 : 4; }
 static int skinny_ksplit(int N, int K) {
+  const int per = 16 * skinny_waves(K);
   int ks = 1;
-  while (ks < 8 && (N / 16) * ks < 192 && K % (128 * ks) == 0 && K / (2 * ks) >= 128) ks *= 2;
+  while (ks < 8 && (N / 16) * ks < 16 && K % (per * 2 * ks) == 0) ks *= 2;
   return ks;
 }
 
@@ -110,18 +117,25 @@ extern "C" int drn_skinny_linear(const float* X, int ldx, const float* W, const 
   A.direct = ks == 1;
   A.Y = ks == 1 ? Y : ws;
   const int nbt = cdiv(M, 16);
-  const int it = A.kslice / 64;           // 16-wide K iterations per wave
+  const int nw = skinny_waves(K);
+  const int it = A.kslice / (16 * nw);    // 16-wide K iterations per wave
   dim3 grid(N / 16, ks);
-#define SK_LAUNCH(NBT, KU) skinny_nt_kernel<NBT, KU><<<grid, SK_THREADS, 0, stream>>>(A)
-#define SK_KU(NBT)                                   \
+#define SK_LAUNCH(NBT, KU, NW) skinny_nt_kernel<NBT, KU, NW><<<grid, 64 * NW, 0, stream>>>(A)
+#define SK_KU(NBT, NW)                               \
   do {                                               \
-    if (it % 4 == 0) SK_LAUNCH(NBT, 4);              \
-    else if (it % 2 == 0) SK_LAUNCH(NBT, 2);         \
-    else SK_LAUNCH(NBT, 1);                          \
+    if (it % 4 == 0) SK_LAUNCH(NBT, 4, NW);          \
+    else if (it % 2 == 0) SK_LAUNCH(NBT, 2, NW);     \
+    else SK_LAUNCH(NBT, 1, NW);                      \
   } while (0)
-  if (nbt == 1) SK_KU(1);
-  else if (nbt == 2) SK_KU(2);
-  else SK_KU(4);
+#define SK_NBT(NW)                                   \
+  do {                                               \
+    if (nbt == 1) SK_KU(1, NW);                      \
+    else if (nbt == 2) SK_KU(2, NW);                 \
+    else SK_KU(4, NW);                               \
+  } while (0)
+  if (nw == 16) SK_NBT(16);
+  else SK_NBT(4);
+#undef SK_NBT
 #undef SK_KU
 #undef SK_LAUNCH
   int rc = drn_launch_status("drn_skinny_linear");

@@ -203,8 +203,11 @@ def skinny_linear(x, W, bias=None, relu=False):
     return y
 
 
+SKINNY = __import__("os").environ.get("DRN_SKINNY", "1") == "1"     # 0: library GEMMs for the batch-sized linears
+
+
 def skinny_ok(M, N, K):
-    return M <= 64 and N % 16 == 0 and K % 64 == 0
+    return SKINNY and M <= 64 and N % 16 == 0 and K % 64 == 0
 
 
 def pos_embed_fwd(feat, W, b, out2d, ld_out, M, C, dtype):

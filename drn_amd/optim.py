@@ -37,6 +37,7 @@ class FusedAdam(object):
                                "nseg": len(ptrs), "part_off": nparts, "nb": nb})
             nparts += nb
         self.partials = torch.zeros(nparts, dtype=torch.float32, device=dev)
+        self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def _check_ptrs(self):
@@ -52,13 +53,14 @@ class FusedAdam(object):
             part = self.partials[st["part_off"]:]
             check(L.drn_sumsq_partials(P(b.flat), ctypes.c_int64(b.flat.numel()), P(part),
                                        P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials")
+        check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), s), "drn_sumsq_finalize")
         for b, st in zip(self.reducer.buckets, self.state):
             check(L.drn_adam_bucket(P(b.flat), P(st["m"]), P(st["v"]), ctypes.c_int64(b.flat.numel()), P(st["seg"]), P(st["ptr"]),
-                                    st["nseg"], P(self.partials), self.partials.numel(), P(self.step_counter),
+                                    st["nseg"], P(self.total_sumsq), P(self.step_counter),
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                                     ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
         DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
         DF.repack_all()               # refresh the GEMM-layout copies of all weights in one launch
 
     def total_norm(self):
-        return self.partials.sum().sqrt()
+        return self.total_sumsq[0].sqrt()

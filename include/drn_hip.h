@@ -276,10 +276,12 @@ int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, 
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */
 /* partials[b] = sum of g^2 over block b; step_counter (device int, or NULL) is incremented once per call. */
 int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream);
+/* total_sumsq[0] = sum of ALL buckets' partials, one workgroup, fixed order (the squared global gradient norm). */
+int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream);
 /* One bucket: g/m/v flat [n]; tensor i covers [seg_start[i], seg_start[i+1]) and lives at p_ptr[i] (both tables on the
- * device).  partials = g^2 sums of ALL buckets (global norm); clip coef = min(1, max_norm/(norm+1e-6)) (max_norm<=0: off). */
+ * device).  clip coef = min(1, max_norm/(sqrt(total_sumsq)+1e-6)) (max_norm<=0: off). */
 int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev, int nseg,
-                    const float* partials, int npartials, const int* step_counter, float lr, float beta1, float beta2, float eps,
+                    const float* total_sumsq, const int* step_counter, float lr, float beta1, float beta2, float eps,
                     float max_norm, void* stream);
 
 #ifdef __cplusplus
