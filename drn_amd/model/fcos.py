@@ -129,6 +129,7 @@ class FCOSModule(torch.nn.Module):
         self.loss_evaluator = make_fcos_loss_evaluator(cfg)
         self.fpn_strides = cfg["fpn_stride"]
         self.loss_evaluator.fpn_strides = list(self.fpn_strides)
+        self.box_selector_test.strides = [float(s) for s in self.fpn_strides]
         self._locations = {}
 
     def forward(self, features, targets=None):

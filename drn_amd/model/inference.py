@@ -1,7 +1,11 @@
 """Eval-time post-processing (reference: model/inference.py:11-237): sigmoid, 0.05 threshold before the
 IoU-score product, per-level top-k, segment decoding / 32, clamp to [0, 1], score = sqrt(cls[*iou]), merge levels.
-Host-side control flow over a few hundred tiny device values per clip, as in the reference (eval only)."""
+On the HIP path (head outputs in their flat loss layout) all of it is ONE kernel, drn_postprocess, and one
+device->host copy of the per-(clip, level) counts; the reference's per-clip host loop remains as the generic path for
+callers that hand over plain per-level tensors."""
 import torch
+
+from .. import ops
 
 
 class FCOSPostProcessor(torch.nn.Module):
@@ -17,6 +21,7 @@ class FCOSPostProcessor(torch.nn.Module):
         self.downsample_scale = 32
         self.is_first_stage = is_first_stage
         self.is_second_stage = is_second_stage
+        self.strides = None          # set by FCOSModule (fpn_stride); otherwise recovered from the locations
 
     def forward_for_single_feature_map(self, locations, box_cls, box_regression, level, iou_scores):
         N = box_cls.shape[0]
@@ -43,7 +48,33 @@ class FCOSPostProcessor(torch.nn.Module):
                             "locations": bloc / 32})
         return results
 
+    def forward_flat(self, locations, box_cls, box_regression, iou_scores):
+        """HIP path: box_cls / box_regression / iou_scores are LevelLists sharing flat (R, n) fp32 buffers."""
+        B = box_cls[0].shape[0]
+        nl = len(box_cls)
+        strides = [float(2 * loc[0]) for loc in locations] if self.strides is None else self.strides[:nl]
+        levels = ops.loss_levels([(int(c.shape[2]), float(strides[i]), 0.0, 0.0) for i, c in enumerate(box_cls)])
+        iou = None if self.is_first_stage else iou_scores.flat
+        det, scores, locs, counts = ops.postprocess(levels, B, box_cls.flat, box_regression.flat, iou, self.pre_nms_thresh,
+                                                    self.pre_nms_top_n, float(self.downsample_scale))
+        counts = counts.tolist()                                           # the only host sync of the eval path
+        results = []
+        for b in range(B):
+            n = sum(counts[b])
+            if n == 0:                                                     # inference.py:192-197
+                dev = det.device
+                results.append({"detections": torch.tensor([[0.0, 1.0]], device=dev), "labels": [],
+                                "scores": torch.tensor([1.0], device=dev), "level": [[-1]],
+                                "locations": torch.tensor([0.5], device=dev)})
+            else:
+                results.append({"detections": det[b, :n], "labels": [], "scores": scores[b, :n],
+                                "level": [[l] * c for l, c in enumerate(counts[b])], "locations": locs[b, :n]})
+        return results
+
     def forward(self, locations, box_cls, box_regression, iou_scores):
+        if all(getattr(x, "flat", None) is not None and x.flat.is_cuda for x in (box_cls, box_regression)) and \
+                (self.is_first_stage or getattr(iou_scores, "flat", None) is not None) and self.min_size == 0:
+            return self.forward_flat(locations, box_cls, box_regression, iou_scores)
         sampled = [self.forward_for_single_feature_map(l, o, b, i, s)
                    for i, (l, o, b, s) in enumerate(zip(locations, box_cls, box_regression, iou_scores))]
         return self.select_over_all_levels(list(zip(*sampled)))

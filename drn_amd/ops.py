@@ -362,6 +362,20 @@ def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dc, dh_pass, lens, B, L, 
                                   _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")
 
 
+def postprocess(levels, B, logits, reg, iou, thr, top_n, downsample):
+    """Eval post-processor on the loss-layout head outputs.  Returns (det (B,R,2), scores (B,R), locs (B,R), counts (B,nl))."""
+    _need_gpu(logits, reg)
+    R = sum(int(l.L) for l in levels)
+    dev = logits.device
+    det = torch.empty((B, R, 2), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, R), dtype=torch.float32, device=dev)
+    locs = torch.empty((B, R), dtype=torch.float32, device=dev)
+    counts = torch.empty((B, len(levels)), dtype=torch.int32, device=dev)
+    check(lib().drn_postprocess(levels, len(levels), B, _p(logits), _p(reg), _p(iou), ctypes.c_float(thr), int(top_n),
+                                ctypes.c_float(downsample), _p(det), _p(scores), _p(locs), _p(counts), _stream()), "drn_postprocess")
+    return det, scores, locs, counts
+
+
 # ---------------------------------------------------------------------------------------------
 # query-encoder glue (drn_amd/csrc/qenc.hip)
 # ---------------------------------------------------------------------------------------------

@@ -211,6 +211,14 @@ int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, c
                       const float* fwd_out5, const float* g_cls, const float* g_reg, const float* g_iou /* 1 float each, NULL = 0 */,
                       float* dlogits, float* dreg, float* diou, void* stream);
 
+/* ---- eval post-processor (drn_amd/csrc/postproc.hip; model/inference.py:51-120,166-199) ------------------------
+ * Per clip and level: candidates sigmoid(logit) > thr, score = sigmoid(logit)[*sigmoid(iou)] (iou NULL in the first stage),
+ * top_n per level, segments ((loc-reg0)/downsample, (loc+reg1)/downsample) clamped to [0,1], score = sqrt(.), loc/32.
+ * Inputs are the head outputs in the loss layout (rows level-first / clip-major).  Outputs are padded per clip:
+ * det [B][sum L][2], scores / locs [B][sum L], counts [B][nlevels] = kept candidates per level, written level after level. */
+int drn_postprocess(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg, const float* iou,
+                    float thr, int top_n, float downsample, float* det, float* scores, float* locs, int32_t* counts, void* stream);
+
 /* ---- query-encoder glue (drn_amd/csrc/qenc.hip; model/language_module.py:17-63), all fp32 ----------------------
  * Word embedding lookup written time-major (L, B, E) and its dense gradient (row padding_idx stays zero). */
 int drn_qe_embed_fwd(const int64_t* tokens /*[B][L]*/, const float* table /*[V][E]*/, float* out_tm, int B, int L, int E, void* stream);
