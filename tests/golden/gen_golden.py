@@ -178,35 +178,61 @@ def run_lgp():
 
 
 def run_metrics():
-    """utils/evaluate_utils.py:328-354 on a hand-made results dict."""
-    cwd = os.getcwd()
-    os.chdir(REF)                                          # evaluate_utils.py:16 reads a relative csv
-    try:
-        from utils.evaluate_utils import PostProcessRunner
-    finally:
-        os.chdir(cwd)
+    """utils/evaluate_utils.py:13-16,91-215,328-354 (PostProcessRunner.run_evaluate, the R@k / IoU metric of main.py:362-364)
+    on a synthetic raw-results dict in main.py:324-348's format.  cwd must be the reference root while the
+    runner exists (evaluate_utils.py:16 opens ./data/dataset/Charades/Charades_word2id.json)."""
+    import json
     g = np.random.default_rng(11)
     results = {}
-    for i in range(12):
-        n = int(g.integers(3, 12))
-        s = g.uniform(0, 0.6, size=n)
-        e = np.minimum(s + g.uniform(0.05, 0.5, size=n), 1.0)
-        gs = g.uniform(0, 0.5)
-        results["vid%d_%d" % (i // 2, i)] = {
-            "vid": "vid%d" % (i // 2), "timestamp": [[float(a), float(b)] for a, b in zip(s, e)],
-            "scores": [float(x) for x in g.uniform(0, 1, size=n)],
-            "gt": [float(gs), float(gs + g.uniform(0.1, 0.5))],
-            "query": "q%d" % i, "level": [0] * n, "locations": [0.5] * n}
-    import json
+    for v in range(9):
+        items = []
+        for q in range(int(g.integers(1, 4))):
+            gs = float(g.uniform(0, 0.5))
+            gt = [gs, float(min(1.0, gs + g.uniform(0.1, 0.5)))]
+            per_level = [int(g.integers(0, 9)) for _ in range(3)]
+            n = sum(per_level)
+            if n == 0:                                         # the post-processor's fallback entry (inference.py:192-197)
+                preds, level = [[0.0, 1.0, 1.0]], [[-1]]
+            else:
+                s = g.uniform(0, 0.7, size=n)
+                e = np.minimum(s + g.uniform(0.02, 0.5, size=n), 1.0)
+                if q == 0 and n > 2:                           # a few near-hits so R@1 / R@5 differ, and one exact score tie
+                    s[0], e[0] = gt[0] + 0.01, gt[1] - 0.01
+                sc = g.uniform(0, 1, size=n)
+                if n > 3:
+                    sc[2] = sc[3]
+                preds = [[float(a), float(b), float(c)] for a, b, c in zip(s, e, sc)]
+                level = [[l] * c for l, c in enumerate(per_level)]
+            items.append({"query": "person opens the door %d" % q, "gt": gt, "node_predictions": preds,
+                          "edge_predictions": preds, "level": level})
+        results["VID%02d" % v] = items
+    cwd = os.getcwd()
+    os.chdir(REF)
     try:
-        runner = PostProcessRunner(results)
-        topks, acc = runner.run_evaluate(iou_topk_dict={"iou": [0.5, 0.7], "topk": [1, 5]}, temporal_nms=True)
-        with open(os.path.join(HERE, "metrics.json"), "w") as f:
-            json.dump({"results": results, "topks": topks,
-                       "acc": {str(k): v for k, v in acc.items()} if isinstance(acc, dict) else acc}, f)
-        print("metrics", topks, acc)
-    except Exception as e:                                 # metrics are a "next" row; do not block goldens
-        print("metrics golden skipped:", repr(e))
+        from utils.evaluate_utils import PostProcessRunner
+        out = {"results": results, "cases": []}
+        for nms in (True, False):
+            runner = PostProcessRunner(json.loads(json.dumps(results)))
+            cfg = {"iou": [0.3, 0.5, 0.7], "topk": [1, 5]}
+            topks, acc = runner.run_evaluate(iou_topk_dict=cfg, temporal_nms=nms)
+            picked = {vid: [{"node_predictions": it["node_predictions"], "level": it["level"]} for it in items]
+                      for vid, items in runner.viz_processed_results.items()}
+            out["cases"].append({"temporal_nms": nms, "iou_topk": cfg, "topks": list(topks), "accuracy": list(acc),
+                                 "last_setting_picks": picked})
+            print("metrics nms=%s" % nms, topks, acc)
+        r = PostProcessRunner({})
+        out["nms_cases"] = []
+        for n in (1, 2, 7, 20):
+            x1 = g.uniform(0, 0.6, size=n); x2 = x1 + g.uniform(0.05, 0.4, size=n); sc = g.uniform(0, 1, size=n)
+            for ov in (0.25, 0.45, 0.65):
+                out["nms_cases"].append({"x1": x1.tolist(), "x2": x2.tolist(), "s": sc.tolist(), "overlap": ov,
+                                         "pick": r.nms_temporal(x1.tolist(), x2.tolist(), sc.tolist(), ov)})
+        out["iou_cases"] = [{"a": [0.1, 0.5], "b": [0.3, 0.9], "iou": r.calculate_IoU((0.1, 0.5), (0.3, 0.9))},
+                            {"a": [0.1, 0.2], "b": [0.6, 0.9], "iou": r.calculate_IoU((0.1, 0.2), (0.6, 0.9))}]
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(HERE, "metrics.json"), "w") as f:
+        json.dump(out, f)
 
 
 def run_keys():
@@ -219,6 +245,9 @@ def run_keys():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     install_shims()
+    if sys.argv[1:] == ["metrics"]:
+        run_metrics()
+        sys.exit(0)
     run_keys()
     run_case("tiny_s1", 2, 32, 64, 1)
     run_case("tiny_s3", 2, 32, 64, 3, match=True)
