@@ -235,6 +235,80 @@ def run_metrics():
         json.dump(out, f)
 
 
+MINI = os.path.join(HERE, "charades_mini")
+
+
+def make_mini_dataset():
+    """A 6-video synthetic dataset in the reference's on-disk formats (committed under tests/golden/charades_mini)."""
+    import json
+    g = np.random.default_rng(5)
+    base = os.path.join(MINI, "data", "dataset", "Charades")
+    os.makedirs(base, exist_ok=True)
+    os.makedirs(os.path.join(MINI, "features"), exist_ok=True)
+    words = ["a", "person", "is", "opens", "the", "door", "puts", "book", "on", "shelf", "sits", "down", "in", "chair", "and"]
+    json.dump({w: i + 1 for i, w in enumerate(words)}, open(os.path.join(base, "Charades_word2id.json"), "w"))
+    fps, dur, props_txt, lines = {}, {}, [], {"train": [], "test": []}
+    for v in range(6):
+        vid = "V%03dX" % v
+        nf = int(g.integers(200, 900))
+        f = [24.0, 25.0, 29.97, 30.0][v % 4]
+        fps[vid], dur[vid] = str(f), round(nf / f, 2)
+        props_txt += ["#", vid, str(nf)]
+        for k in range(8):                                     # 8 proposals: a ladder of scales, ends past the frame count
+            L = nf / (1 + k % 4)
+            s = float(g.uniform(0, max(1.0, nf - L)))
+            e = s + L * float(g.uniform(0.3, 1.2))
+            props_txt.append("%d %d" % (int(s), int(e)) if k % 2 else "%.2f %.2f" % (s, e))
+        nseg = max(1, (nf - 16) // 8 - (v % 2) * 3)             # some videos store fewer segments than frames imply
+        torch.save(torch.from_numpy(g.standard_normal((nseg, 12)).astype(np.float32)), os.path.join(MINI, "features", vid + ".pt"))
+        for q in range(2):
+            n = int(g.integers(3, 9))
+            sent = " ".join(words[int(i)] for i in g.integers(0, len(words), size=n)) + "."
+            s = float(g.uniform(0, dur[vid] * 0.6))
+            e = s + float(g.uniform(2.0, dur[vid]))             # may exceed the duration: capped by the reader
+            lines["train" if (v + q) % 3 else "test"].append("%s %.1f %.1f##%s" % (vid, s, e, sent))
+    json.dump(fps, open(os.path.join(base, "Charades_fps_dict.json"), "w"))
+    json.dump(dur, open(os.path.join(base, "Charades_duration.json"), "w"))
+    open(os.path.join(base, "mini_props.txt"), "w").write("\n".join(props_txt) + "\n")
+    for sp, ls in lines.items():
+        open(os.path.join(base, "Charades_sta_%s.txt" % sp), "w").write("\n".join(ls) + "\n")
+
+
+def mini_config():
+    return {"feature_type": "C3D", "C3D": {"feature_root": "./features", "feature_dim": 12, "ft_window_size": 16, "ft_overlap": 0.5},
+            "props_file_path": "./data/dataset/Charades/mini_props.txt"}
+
+
+def run_dataset():
+    """dataset.py:61-224 (CharadesSTA + collate_data) on the mini dataset.  dataset.py imports PIL / torchvision / nltk at
+    module level without needing them on this path: PIL and torchvision are stubbed, nltk.word_tokenize -> str.split (the
+    mini sentences are plain space-separated words, where the two agree)."""
+    import argparse
+    for name in ["PIL", "PIL.Image", "torchvision", "torchvision.transforms"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["PIL"].Image = sys.modules["PIL.Image"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    nl = types.ModuleType("nltk"); nl.word_tokenize = lambda s: s.split(); sys.modules["nltk"] = nl
+    make_mini_dataset()
+    cwd = os.getcwd()
+    os.chdir(MINI)
+    try:
+        import dataset as refds
+        out = {}
+        for split in ("train", "test"):
+            ds = refds.CharadesSTA(argparse.Namespace(**mini_config()), split=split)
+            items = [ds[i] for i in range(len(ds))]
+            names, pse, feats, gt, tok, qlen, nprops, nframes = refds.collate_data(items)
+            out[split + "/names"] = np.array(names)
+            out[split + "/props_s_e"] = pse.numpy(); out[split + "/feats"] = feats.numpy(); out[split + "/gt"] = gt.numpy()
+            out[split + "/tokens"] = tok.numpy(); out[split + "/qlen"] = qlen.numpy(); out[split + "/nprops"] = nprops.numpy()
+            out[split + "/nframes"] = nframes.numpy()
+            print("dataset", split, len(ds), feats.shape, float(feats.abs().sum()))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
+
+
 def run_keys():
     import json
     m = build_reference(default_cfg("C3D", 4096, 1))
@@ -248,6 +322,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["metrics"]:
         run_metrics()
         sys.exit(0)
+    if sys.argv[1:] == ["dataset"]:
+        run_dataset()
+        sys.exit(0)
     run_keys()
     run_case("tiny_s1", 2, 32, 64, 1)
     run_case("tiny_s3", 2, 32, 64, 3, match=True)
@@ -258,3 +335,4 @@ if __name__ == "__main__":
     run_case("c3d_s3", 2, 64, 4096, 3, match=True)
     run_lgp()
     run_metrics()
+    run_dataset()
