@@ -235,6 +235,55 @@ def run_metrics():
         json.dump(out, f)
 
 
+def run_trajectory(stage, steps=4, B=2, T=32, D=64, base_lr=1e-3, tag=""):
+    """main.py:124-138 (stage plan) + main.py:218-243 (one iteration), restated verbatim around the REFERENCE model
+    (main.py itself needs tensorboardX / ruamel / nltk and cannot be imported): per-step losses and end-of-run parameter
+    checksums for the trainer counterpart.  Matched GT so the IoU-score loss is live in stages 2 and 3."""
+    from torch.nn.utils import clip_grad_norm_
+    cfg = default_cfg("TINY", D, stage)
+    model = build_reference(cfg, seed=0)
+    batches = []
+    for seed in (1, 2):
+        b = list(synthetic_batch(B, T, D, seed=seed))
+        b[4] = matched_gt(model, b)
+        batches.append(b)
+    lr = base_lr
+    if stage == 1:
+        for name, value in model.named_parameters():
+            if 'iou_scores' in name or 'mix_fc' in name:
+                value.requires_grad = False
+        learned = filter(lambda p: p.requires_grad, model.parameters())
+    elif stage == 2:
+        learned = list(model.fcos.head.iou_scores.parameters()) + list(model.fcos.head.mix_fc.parameters())
+        lr /= 100
+    else:
+        learned = model.parameters()
+        lr /= 10000
+    opt = torch.optim.Adam(learned, lr)
+    model.train()
+    opt.zero_grad()
+    losses = []
+    for it in range(steps):
+        model.fcos.loss_evaluator.total_points = []
+        _, loss_dict = model(*batches[it % 2])
+        loss = loss_dict['loss_iou'] if stage == 2 else sum(l for l in loss_dict.values())
+        losses.append([float(loss_dict[k].reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
+        if loss != 0:
+            loss.backward()
+        clip_grad_norm_(model.parameters(), 0.5)
+        opt.step()
+        opt.zero_grad()
+    out = {"stage": stage, "B": B, "T": T, "D": D, "steps": steps, "lr": base_lr, "losses": np.array(losses),
+           "gt0": batches[0][4].numpy(), "gt1": batches[1][4].numpy()}
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            cs, smp = checksum(v)
+            out["cs/" + k] = cs
+            out["smp/" + k] = smp
+    np.savez_compressed(os.path.join(HERE, "traj_s%d%s.npz" % (stage, tag)), **out)
+    print("trajectory stage", stage, np.array(losses).round(5).tolist())
+
+
 MINI = os.path.join(HERE, "charades_mini")
 
 
@@ -325,6 +374,11 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["dataset"]:
         run_dataset()
         sys.exit(0)
+    if sys.argv[1:] == ["trajectory"]:
+        for st in (1, 2, 3):
+            run_trajectory(st)
+        run_trajectory(1, base_lr=1e-5, tag="_lowlr")
+        sys.exit(0)
     run_keys()
     run_case("tiny_s1", 2, 32, 64, 1)
     run_case("tiny_s3", 2, 32, 64, 3, match=True)
@@ -336,3 +390,6 @@ if __name__ == "__main__":
     run_lgp()
     run_metrics()
     run_dataset()
+    for st in (1, 2, 3):
+        run_trajectory(st)
+    run_trajectory(1, base_lr=1e-5, tag="_lowlr")
