@@ -82,6 +82,56 @@ extern "C" int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out,
   return drn_launch_status("drn_transpose2d");
 }
 
+// ---------------------------------------------------------------- cast + transpose in one pass over the fp32 input
+// out[m][k] = (T) in[m][k]  and  outT[k][m] = (T) in[m][k]: the proposal features are cast once per step anyway; writing
+// the K-major copy from the same tile saves re-reading them for the prop_fc weight gradient (NT product of transposes).
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ outT,
+                                                             int M, int K) {
+  constexpr int VN = V16<T>::N;
+  constexpr int CPR = 64 / VN;
+  __shared__ T tile[64][64 + 2 * VN / 4 + 2];  // [k][m]
+  const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  for (int q = threadIdx.x; q < 64 * 16; q += 256) {          // 64 rows x 16 float4 chunks
+    const int r = q >> 4, cv = q & 15;
+    const int m = m0 + r, k = k0 + cv * 4;
+    if (m < M && k < K) {                                      // K % 4 == 0
+      const f32x4 v = *(const f32x4*)(in + (long)m * K + k);
+      T t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        DT<T>::st(&t[e], v[e]);
+        tile[cv * 4 + e][r] = t[e];
+      }
+      if (sizeof(T) == 2) *(uint2*)(out + (long)m * K + k) = *(const uint2*)t;
+      else *(uint4*)(out + (long)m * K + k) = *(const uint4*)t;
+    }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 64 * CPR; q += 256) {
+    const int r = q / CPR, cv = q % CPR;
+    const int k = k0 + r, m = m0 + cv * VN;
+    if (k < K && m < M) {
+      T v[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) v[e] = tile[r][cv * VN + e];
+      *(uint4*)(outT + (long)k * M + m) = *(const uint4*)v;
+    }
+  }
+}
+extern "C" int drn_cast_transpose(const float* in, void* out, void* outT, int M, int K, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(in && out && outT && M > 0 && K > 0, "drn_cast_transpose: bad args");
+  DISPATCH_DT(dtype, "drn_cast_transpose", {
+    constexpr int VN = V16<T>::N;
+    DRN_CHECK_ARG(M % VN == 0 && K % VN == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)outT) & 15) == 0,
+                  "drn_cast_transpose: dims must be 16-byte multiples");
+    dim3 grid(cdiv(K, 64), cdiv(M, 64));
+    cast_transpose_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(in, (T*)out, (T*)outT, M, K);
+  });
+  return drn_launch_status("drn_cast_transpose");
+}
+
 // ---------------------------------------------------------------- weight packing (permute + cast)
 // out[a][b][c] = in[a*sa + b*sb + c*sc]
 template <typename T>
@@ -403,6 +453,112 @@ extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_a
                                                                 ld_add, (T*)dC, ld_dc, dgate, ld_dgate, dsum, L, C);
   });
   return drn_launch_status("drn_gate_bwd");
+}
+
+// Variant for the input stage: the gated gradient is only ever consumed as the K-major operand of the prop_fc weight
+// gradient, so it is written TRANSPOSED, dCT[c][s*L + t] = dG[s,t,c] * gate[s,c], 32 rows at a time through an LDS tile
+// (64-byte row segments), and never in its natural layout.  Requires L % 32 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_t_kernel(const T* __restrict__ dG, int ld_dg, const T* __restrict__ act, int ld_act,
+                                                         const float* __restrict__ gate, int ldg, T* __restrict__ dCT, long ldt,
+                                                         float* __restrict__ dgate, int ld_dgate, float* __restrict__ dsum, int L,
+                                                         int C) {
+  constexpr int N = V16<T>::N;
+  constexpr int TP = 32 * N + 16 / (int)sizeof(T);      // [row][channel] tile, pitch in elements (16-byte aligned rows)
+  __shared__ float red[8][32 * N + 1];
+  __shared__ __attribute__((aligned(16))) T tile[32][TP];
+  const int vx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int v = blockIdx.x * 32 + vx;
+  const int s = blockIdx.y;
+  const int c0 = v * N;
+  const bool live = c0 < C;
+  float gt[N], acc[N], cs[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    gt[k] = live ? gate[(long)s * ldg + c0 + k] : 0.f;
+    acc[k] = 0.f;
+    cs[k] = 0.f;
+  }
+  for (int t0 = 0; t0 < L; t0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = i * 8 + ry;
+      const long m = (long)s * L + t0 + rl;
+      float g[N], a[N];
+      if (live) {
+        V16<T>::load(dG + m * ld_dg + c0, g);
+        V16<T>::load(act + m * ld_act + c0, a);
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { g[k] = 0.f; a[k] = 0.f; }
+      }
+      float o[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        acc[k] = fmaf(g[k], a[k], acc[k]);
+        cs[k] += g[k];
+        o[k] = g[k] * gt[k];
+      }
+      V16<T>::store(&tile[rl][vx * N], o);              // natural layout: one conflict-free 16-byte LDS write
+    }
+    __syncthreads();
+    // flush transposed: a thread gathers EPC consecutive rows of one channel (column reads, neighbouring lanes hit
+    // neighbouring channels) and stores them as one 16-byte piece of dCT's row; 4 (bf16) / 8 (f32) lanes share a row
+    constexpr int EPC = 16 / (int)sizeof(T), CPR = 32 / EPC;
+    for (int q = threadIdx.x; q < 32 * N * CPR; q += 256) {
+      const int ch = q % (32 * N), part = q / (32 * N);
+      const int c = blockIdx.x * 32 * N + ch;
+      if (c < C) {
+        T pk[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) pk[e] = tile[part * EPC + e][ch];
+        *(uint4*)(dCT + (long)c * ldt + (long)s * L + t0 + part * EPC) = *(const uint4*)pk;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) red[ry][vx * N + k] = acc[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * N; i += 256) {
+    const int c = blockIdx.x * 32 * N + i;
+    if (c < C) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r][i];
+      dgate[(long)s * ld_dgate + c] = sum;
+    }
+  }
+  if (dsum) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[ry][vx * N + k] = cs[k] * gt[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * N; i += 256) {
+      const int c = blockIdx.x * 32 * N + i;
+      if (c < C) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += red[r][i];
+        dsum[(long)s * C + c] = sum;
+      }
+    }
+  }
+}
+extern "C" int drn_gate_bwd_t(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, void* dCT,
+                              int64_t ldt, float* dgate, int ld_dgate, float* dsum, int nseq, int L, int C, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(dG && act && gate && dCT && dgate && nseq > 0 && L > 0 && C > 0, "drn_gate_bwd_t: bad args");
+  DRN_CHECK_ARG(L % 32 == 0, "drn_gate_bwd_t: sequence length must be a multiple of 32");
+  DISPATCH_DT(dtype, "drn_gate_bwd_t", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && ldt % N == 0 && (((uintptr_t)dCT) & 15) == 0,
+                  "drn_gate_bwd_t: C/ld must be 16-byte multiples");
+    dim3 grid(cdiv(C / N, 32), nseq);
+    gate_bwd_t_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (T*)dCT, ldt,
+                                                                  dgate, ld_dgate, dsum, L, C);
+  });
+  return drn_launch_status("drn_gate_bwd_t");
 }
 
 // ---------------------------------------------------------------- column sum (bias gradients): out[c] (+)= sum_m X[m][c]

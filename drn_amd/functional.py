@@ -549,7 +549,15 @@ class _InputStageFn(torch.autograd.Function):
         P = Wpos.shape[0]
         dev = feats.device
         xc = feats.contiguous()
-        if xc.dtype != dtype:
+        # bf16 training: the prop_fc weight gradient runs as an NT product of K-major operands (see backward); the
+        # transposed copy of the features is written by the same pass that casts them
+        nt_wgrad = (code == ops.BF16 and NT_WGRAD and (B * T) % 8 == 0 and D % 8 == 0 and xc.dtype == torch.float32
+                    and ctx.needs_input_grad[3])
+        xcT = None
+        if nt_wgrad:
+            xc2, xcT = ops.cast_transpose(xc.view(B * T, D), code)
+            xc = xc2.view(B, T, D)
+        elif xc.dtype != dtype:
             xc = ops.cast(xc.float(), code)
         wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
         G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
@@ -561,7 +569,7 @@ class _InputStageFn(torch.autograd.Function):
         ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
         ctx.dtype, ctx.dims = dtype, (B, T, D, P)
         ctx.param_refs = (Wfc, bfc, Wpos, bpos)
-        ctx.save_for_backward(xc, pf, gate0, Z)
+        ctx.save_for_backward(xc, pf, gate0, Z, xcT if xcT is not None else xc.new_empty(0))
         return G0
 
     @staticmethod
@@ -569,22 +577,28 @@ class _InputStageFn(torch.autograd.Function):
         dtype = ctx.dtype
         code = code_of(dtype)
         B, T, D, P = ctx.dims
-        xc, pf, gate0, Z = ctx.saved_tensors
+        xc, pf, gate0, Z, xcT = ctx.saved_tensors
         dev = xc.device
         dG0 = _grad_nlc(dG0, None, dtype)
-        dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
         dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
         dsum = torch.empty((B, D), dtype=torch.float32, device=dev)      # per-clip column sums of dZ: prop_fc bias gradient
-        ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
         Wfc, bfc, Wpos, bpos = ctx.param_refs
         dW = grad_buffer(Wfc)
-        if code == ops.BF16 and NT_WGRAD and (B * T) % 8 == 0 and D % 8 == 0:
+        if xcT.numel():
             # dW[n][c] = sum_m dZ[m][n] * x[m][c] as an NT product of the K-major copies dZ^T (D, B*T) and x^T (D, B*T):
             # the NT kernel streams both operands with 16-byte LDS reads (1.1 PFLOP/s on this shape), while the TN
-            # kernel's transposing ds_read_b64_tr_b16 fragments hold it to ~0.7; the two transposes cost ~60 us
-            ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ.view(B * T, D), code), ops.transpose2d(xc.view(B * T, D), code), dW,
-                                       D, D, B * T, out_f32=True)], code)
+            # kernel's transposing ds_read_b64_tr_b16 fragments hold it to ~0.7.  dZ is only ever needed transposed.
+            if T % 32 == 0:
+                dZT = torch.empty((D, B * T), dtype=dtype, device=dev)
+                ops.gate_bwd_t(dG0, D + P, Z, D, gate0, dZT, dgate, B, T, D, code, dsum=dsum)
+            else:
+                dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
+                ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
+                dZT = ops.transpose2d(dZ.view(B * T, D), code)
+            ops.gemm_nt([ops.gemm_desc(dZT, xcT, dW, D, D, B * T, out_f32=True)], code)
         else:
+            dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
+            ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
             ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
         db = grad_buffer(bfc)
         ops.colsum(dsum, D, B, D, db, ops.F32)

@@ -142,6 +142,17 @@ def cast(x, dtype):
     return out
 
 
+def cast_transpose(x, dtype):
+    """fp32 (M, K) -> (compute-dtype copy (M, K), its transpose (K, M)) in one pass."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    M, K = x.shape
+    out = torch.empty((M, K), dtype=TORCH_DT[dtype], device=x.device)
+    outT = torch.empty((K, M), dtype=TORCH_DT[dtype], device=x.device)
+    check(lib().drn_cast_transpose(_p(x), _p(out), _p(outT), M, K, dtype, _stream()), "drn_cast_transpose")
+    return out, outT
+
+
 def transpose2d(x, dtype):
     """(M, K) row-major -> (K, M) row-major, compute dtype, one LDS-tiled pass."""
     _need_gpu(x)
@@ -228,6 +239,12 @@ def gate_bwd(dG, ld_dg, act, ld_act, gate, dC, ld_dc, add, ld_add, dgate, nseq, 
     """dC = (add or 0) + dG * gate; dgate = sum_t dG * act; dsum (nseq, C) fp32 = sum_t dG * gate."""
     check(lib().drn_gate_bwd(_p(dG), ld_dg, _p(act), ld_act, _p(gate), gate.stride(0), _p(add), ld_add, _p(dC), ld_dc, _p(dgate),
                              dgate.stride(0), _p(dsum), nseq, L, C, dtype, _stream()), "drn_gate_bwd")
+
+
+def gate_bwd_t(dG, ld_dg, act, ld_act, gate, dCT, dgate, nseq, L, C, dtype, dsum=None):
+    """dCT (C, nseq*L) = (dG * gate)^T; dgate = sum_t dG * act; dsum (nseq, C) = sum_t dG * gate."""
+    check(lib().drn_gate_bwd_t(_p(dG), ld_dg, _p(act), ld_act, _p(gate), gate.stride(0), _p(dCT), ctypes.c_int64(dCT.stride(0)),
+                               _p(dgate), dgate.stride(0), _p(dsum), nseq, L, C, dtype, _stream()), "drn_gate_bwd_t")
 
 
 def colsum(X, ld, M, C, out, dtype, accumulate=False):

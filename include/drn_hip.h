@@ -87,6 +87,8 @@ int drn_cast(const float* in, void* out, int64_t n, int dtype, void* stream);
  * B operands [Cout][k][Cin] (forward) and [Cin][k][Cout] (data gradient). */
 /* out[k][m] = in[m][k] for a row-major M x K matrix of dtype elements (row strides ld_in / ld_out): K-major copies of the
  * operands let the largest weight gradient run as an NT product (see drn_amd/functional.py, _InputStageFn). */
+/* out[m][k] = outT[k][m] = (dtype) in[m][k] for a contiguous fp32 M x K matrix: cast and K-major copy in one pass. */
+int drn_cast_transpose(const float* in, void* out, void* outT, int M, int K, int dtype, void* stream);
 int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out, int M, int K, int dtype, void* stream);
 int drn_pack_weight(const float* in, void* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, int dtype, void* stream);
 /* The same for n weights in one launch (all GEMM operands of the model after an optimizer step; the reference's cuDNN
@@ -112,6 +114,10 @@ int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst
  * dsum (optional, [nseq][C]) = sum_t dG * gate[seq]: per-clip column sums of dC's gated term (bias-gradient partials) */
 int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, const void* add, int ld_add,
                  void* dC, int ld_dc, float* dgate, int ld_dgate, float* dsum, int nseq, int L, int C, int dtype, void* stream);
+/* Input-stage variant: the gated gradient is written only TRANSPOSED, dCT[c][seq*L + t] (row stride ldt), as the K-major
+ * operand of the prop_fc weight gradient; dgate / dsum as above.  L % 32 == 0. */
+int drn_gate_bwd_t(const void* dG, int ld_dg, const void* act, int ld_act, const float* gate, int ldg, void* dCT, int64_t ldt,
+                   float* dgate, int ld_dgate, float* dsum, int nseq, int L, int C, int dtype, void* stream);
 /* out[c] (+)= sum_m X[m][c]  (bias gradients) */
 int drn_colsum(const void* X, int ld, int M, int C, float* out, int accumulate, float* ws /* >= 64*C floats */, int dtype,
                void* stream);

@@ -117,3 +117,34 @@ def test_transpose2d(dt, M, K):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(M, K, generator=g).to("cuda:0").to(dt)
     assert torch.equal(ops.transpose2d(x, _code(dt)), x.t().contiguous())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,K", [(64, 64), (200, 72), (8192, 4096)])
+def test_cast_transpose(dt, M, K):
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(M, K, generator=g).to("cuda:0")
+    a, b = ops.cast_transpose(x, _code(dt))
+    assert torch.equal(a, x.to(dt)) and torch.equal(b, x.to(dt).t().contiguous())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(3, 32, 24), (32, 256, 512), (2, 64, 1032)])
+def test_gate_bwd_transposed_output(dt, shape):
+    """drn_gate_bwd_t: same reductions as drn_gate_bwd, the gated gradient written only as its transpose."""
+    from drn_amd import ops
+    B, L, C = shape
+    g = torch.Generator().manual_seed(8)
+    dev = "cuda:0"
+    ld = C + 8
+    dGw = torch.randn(B, L, ld, generator=g).to(dev).to(dt)
+    act = torch.randn(B, L, C, generator=g).to(dev).to(dt)
+    gate = torch.randn(B, C, generator=g).to(dev)
+    dC = torch.empty(B, L, C, device=dev, dtype=dt)
+    dCT = torch.empty(C, B * L, device=dev, dtype=dt)
+    dgate, dsum, dgate2, dsum2 = (torch.empty(B, C, device=dev) for _ in range(4))
+    ops.gate_bwd(dGw, ld, act, C, gate, dC, C, None, 0, dgate, B, L, C, _code(dt), dsum=dsum)
+    ops.gate_bwd_t(dGw, ld, act, C, gate, dCT, dgate2, B, L, C, _code(dt), dsum=dsum2)
+    assert torch.equal(dCT, dC.view(B * L, C).t().contiguous())
+    assert torch.allclose(dgate2, dgate, rtol=1e-5, atol=1e-5) and torch.allclose(dsum2, dsum, rtol=1e-5, atol=1e-5)
