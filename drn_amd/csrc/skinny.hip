@@ -89,11 +89,20 @@ __global__ void skinny_reduce_kernel(const float* __restrict__ part, int ksplit,
 
 // 16 waves per workgroup split K inside the workgroup (no second pass); K is split over workgroups as well only when
 // there are too few column tiles to matter otherwise
-static int skinny_waves(int K) { return (K % 256 == 0 && K >= 1024) ? 16 : 4; }
+#include <stdlib.h>
+// Measured on MI355X (scripts/bench_skinny.py): 4 waves per workgroup are enough; what matters is that a long K
+// (>= 2048: qInput, the stacked qInput{t} input gradient, the level-0 gate's input gradient) is cut into slices of >= 256
+// over up to 8 workgroups per column tile until ~256 workgroups exist -- 25 -> 14 us for N=1024, K=4096 -- while short-K
+// problems stay single-pass (the second pass would cost more than it saves).  DRN_SKINNY_NW=16 selects the 16-wave variant.
+static int skinny_waves(int K) {
+  if (const char* e = getenv("DRN_SKINNY_NW")) return (atoi(e) == 16 && K % 256 == 0) ? 16 : 4;
+  return 4;
+}
 static int skinny_ksplit(int N, int K) {
+  if (K < 2048) return 1;
   const int per = 16 * skinny_waves(K);
   int ks = 1;
-  while (ks < 8 && (N / 16) * ks < 16 && K % (per * 2 * ks) == 0) ks *= 2;
+  while (ks < 8 && (N / 16) * ks < 256 && K / (2 * ks) >= 256 && K % (per * 2 * ks) == 0) ks *= 2;
   return ks;
 }
 
