@@ -28,56 +28,62 @@ struct BnFinParams {
   BnFinGroup g[DRN_MAX_GROUPS];
 };
 
-// 256 threads = 16 channels x 16 lanes; the lanes split the per-tile partial sums, LDS combines them in a fixed order.
-// Groups are processed IN ORDER by the thread that owns the channel, so groups that share one BatchNorm module (the
-// head modules applied once per pyramid level) update its running statistics sequentially like the reference does,
-// and groups with their own modules (FPN levels) simply carry different pointers.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinParams P, int C) {
-  __shared__ double sh[2][16][17];
-  const int ci = threadIdx.x & 15, j = threadIdx.x >> 4;
+// 256 threads per group (16 channels x 16 lanes over the per-tile partial sums, LDS-combined in a fixed order), one such
+// slice of the workgroup per group, so the groups of a launch run side by side.  Only the running-statistics update is
+// sequential: the thread that owns a channel applies the groups IN ORDER, so groups that share one BatchNorm module (the
+// head modules applied once per pyramid level) update it like the reference does, and groups with their own modules
+// (FPN levels) simply carry different pointers.
+__global__ __launch_bounds__(256 * DRN_MAX_GROUPS) void bn_finalize_kernel(const BnFinParams P, int C) {
+  __shared__ double sh[DRN_MAX_GROUPS][16][17];
+  __shared__ float s_mean[DRN_MAX_GROUPS][16], s_unb[DRN_MAX_GROUPS][16];
+  const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int ci = t & 15, j = t >> 4;
   const int c = blockIdx.x * 16 + ci;
   const bool live = c < C;
-  for (int g = 0; g < P.ngroups; ++g) {
-    const BnFinGroup& G = P.g[g];
-    // slab t holds (sum, M2 about the slab mean) of n_t = min(128, M - 128 t) rows; merge in double (Chan et al.)
-    double s = 0.0;
-    if (live)
-      for (int t = j; t < G.tiles; t += 16) s += (double)G.stats[((long)t * 2 + 0) * C + c];
-    __syncthreads();
-    sh[0][ci][j] = s;
-    __syncthreads();
-    double mean = 0.0;
+  const BnFinGroup& G = P.g[g];                     // blockDim.x = 256 * ngroups
+  // slab k holds (sum, M2 about the slab mean) of n_k = min(128, M - 128 k) rows; merge in double (Chan et al.)
+  double s = 0.0;
+  if (live)
+    for (int k = j; k < G.tiles; k += 16) s += (double)G.stats[((long)k * 2 + 0) * C + c];
+  sh[g][ci][j] = s;
+  __syncthreads();
+  double mean = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) mean += sh[0][ci][k];
-    mean /= G.M;
-    double q = 0.0;
-    if (live)
-      for (int t = j; t < G.tiles; t += 16) {
-        const int nt = min(128, G.M - t * 128);
-        const double d = (double)G.stats[((long)t * 2 + 0) * C + c] / nt - mean;
-        q += (double)G.stats[((long)t * 2 + 1) * C + c] + nt * d * d;
-      }
-    __syncthreads();
-    sh[1][ci][j] = q;
-    __syncthreads();
-    if (live && j == 0) {
-      q = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) q += sh[1][ci][k];
-      double var = q / G.M;
-      if (var < 0.0) var = 0.0;
-      const float invstd = (float)(1.0 / sqrt(var + (double)G.eps));
-      const float sc = G.gamma[c] * invstd;
-      G.scale_shift[c] = sc;
-      G.scale_shift[C + c] = G.beta[c] - (float)mean * sc;
-      G.save[c] = (float)mean;
-      G.save[C + c] = invstd;
-      const double unbiased = G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var;
-      const float cb = G.conv_bias ? G.conv_bias[c] : 0.f;
-      if (G.running_mean) G.running_mean[c] = (1.f - G.momentum) * G.running_mean[c] + G.momentum * ((float)mean + cb);
-      if (G.running_var) G.running_var[c] = (1.f - G.momentum) * G.running_var[c] + G.momentum * (float)unbiased;
+  for (int k = 0; k < 16; ++k) mean += sh[g][ci][k];
+  mean /= G.M;
+  double q = 0.0;
+  if (live)
+    for (int k = j; k < G.tiles; k += 16) {
+      const int nt = min(128, G.M - k * 128);
+      const double d = (double)G.stats[((long)k * 2 + 0) * C + c] / nt - mean;
+      q += (double)G.stats[((long)k * 2 + 1) * C + c] + nt * d * d;
     }
+  __syncthreads();
+  sh[g][ci][j] = q;
+  __syncthreads();
+  if (live && j == 0) {
+    q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) q += sh[g][ci][k];
+    double var = q / G.M;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)G.eps));
+    const float sc = G.gamma[c] * invstd;
+    G.scale_shift[c] = sc;
+    G.scale_shift[C + c] = G.beta[c] - (float)mean * sc;
+    G.save[c] = (float)mean;
+    G.save[C + c] = invstd;
+    s_mean[g][ci] = (float)mean;
+    s_unb[g][ci] = (float)(G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var);
   }
+  __syncthreads();
+  if (threadIdx.x < 16 && live)
+    for (int k = 0; k < P.ngroups; ++k) {
+      const BnFinGroup& H = P.g[k];
+      const float cb = H.conv_bias ? H.conv_bias[c] : 0.f;
+      if (H.running_mean) H.running_mean[c] = (1.f - H.momentum) * H.running_mean[c] + H.momentum * (s_mean[k][ci] + cb);
+      if (H.running_var) H.running_var[c] = (1.f - H.momentum) * H.running_var[c] + H.momentum * s_unb[k][ci];
+    }
 }
 
 static int bn_finalize_launch(const DrnBnFinDesc* d, int n, int C, void* stream, const char* who) {
@@ -93,7 +99,7 @@ static int bn_finalize_launch(const DrnBnFinDesc* d, int n, int C, void* stream,
     P.g[g].running_mean = d[g].running_mean; P.g[g].running_var = d[g].running_var;
     P.g[g].momentum = d[g].momentum; P.g[g].eps = d[g].eps;
   }
-  bn_finalize_kernel<<<cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(P, C);
+  bn_finalize_kernel<<<cdiv(C, 16), 256 * n, 0, (hipStream_t)stream>>>(P, C);
   return drn_launch_status(who);
 }
 
@@ -336,39 +342,48 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams P)
   }
 }
 
-// dgamma/dbeta (+)= level sums;  coef: dRaw = A*g + B*raw + Cc.   256 threads = 16 channels x 16 lanes over the partials.
-// Levels are handled in order by the same thread, so shared dgamma/dbeta accumulate deterministically.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdParams P) {
-  __shared__ double sh[2][16][17];
+// dgamma/dbeta (+)= level sums;  coef: dRaw = A*g + B*raw + Cc.   256 threads per level (16 channels x 16 lanes over the
+// partial blocks), one slice of the workgroup per level; dgamma / dbeta are then applied level after level by the thread
+// that owns the channel, so levels sharing one module accumulate in a fixed order.
+__global__ __launch_bounds__(256 * DRN_MAX_GROUPS) void bn_bwd_finalize_kernel(const BnBwdParams P) {
+  __shared__ double sh[DRN_MAX_GROUPS][2][16][17];
+  __shared__ float s_dg[DRN_MAX_GROUPS][16], s_db[DRN_MAX_GROUPS][16];
   const int C = P.C;
-  const int ci = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const int li = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int ci = t & 15, j = t >> 4;
   const int c = blockIdx.x * 16 + ci;
-  for (int li = 0; li < P.n; ++li) {
-    const BnBwdLv& G = P.lv[li];
-    double sg = 0.0, sx = 0.0;
-    if (c < C)
-      for (int b = j; b < G.nblk; b += 16) {
-        sg += (double)G.partial[((long)b * 2 + 0) * C + c];
-        sx += (double)G.partial[((long)b * 2 + 1) * C + c];
-      }
-    __syncthreads();
-    sh[0][ci][j] = sg;
-    sh[1][ci][j] = sx;
-    __syncthreads();
-    if (c >= C || j != 0) continue;
+  const bool live = c < C;
+  const BnBwdLv& G = P.lv[li];                      // blockDim.x = 256 * n
+  double sg = 0.0, sx = 0.0;
+  if (live)
+    for (int b = j; b < G.nblk; b += 16) {
+      sg += (double)G.partial[((long)b * 2 + 0) * C + c];
+      sx += (double)G.partial[((long)b * 2 + 1) * C + c];
+    }
+  sh[li][0][ci][j] = sg;
+  sh[li][1][ci][j] = sx;
+  __syncthreads();
+  if (live && j == 0) {
     sg = 0.0; sx = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { sg += sh[0][ci][k]; sx += sh[1][ci][k]; }
+    for (int k = 0; k < 16; ++k) { sg += sh[li][0][ci][k]; sx += sh[li][1][ci][k]; }
     const float mean = G.save[c], istd = G.save[C + c];
     const float s = G.gamma[c] * istd;
     const float dg = (float)sx, db = (float)sg;
-    if (G.dgamma) G.dgamma[c] = G.accumulate ? G.dgamma[c] + dg : dg;
-    if (G.dbeta) G.dbeta[c] = G.accumulate ? G.dbeta[c] + db : db;
     const float invM = 1.f / (float)G.M;
     G.coef[c] = s;
     G.coef[C + c] = -s * dg * istd * invM;
     G.coef[2 * C + c] = -s * db * invM + s * dg * istd * mean * invM;
+    s_dg[li][ci] = dg;
+    s_db[li][ci] = db;
   }
+  __syncthreads();
+  if (threadIdx.x < 16 && live)
+    for (int k = 0; k < P.n; ++k) {
+      const BnBwdLv& H = P.lv[k];
+      if (H.dgamma) H.dgamma[c] = H.accumulate ? H.dgamma[c] + s_dg[k][ci] : s_dg[k][ci];
+      if (H.dbeta) H.dbeta[c] = H.accumulate ? H.dbeta[c] + s_db[k][ci] : s_db[k][ci];
+    }
 }
 
 template <typename T>
@@ -437,7 +452,7 @@ static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* w
   dim3 grid(cdiv(C / vn, 64), yb);
   if (dtype == DRN_BF16) bn_bwd_reduce_kernel<bf16_t><<<grid, 256, 0, stream>>>(P);
   else bn_bwd_reduce_kernel<float><<<grid, 256, 0, stream>>>(P);
-  bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, stream>>>(P);
+  bn_bwd_finalize_kernel<<<cdiv(C, 16), 256 * n, 0, stream>>>(P);
   if (dtype == DRN_BF16) bn_bwd_apply_kernel<bf16_t><<<ab, 256, 0, stream>>>(P);
   else bn_bwd_apply_kernel<float><<<ab, 256, 0, stream>>>(P);
   return drn_launch_status(who);
