@@ -30,10 +30,14 @@ def _w3(w):
 
 def packed(w, perm, code):
     """Weight `w` (fp32 conv (Cout,Cin,k) or linear (N,K) parameter) permuted + cast for the GEMM; cached on the
-    parameter version.  Linear weights come back 2-D."""
+    parameter version.  Linear weights come back 2-D.  A tensor made by `stack_params` is packed straight from its source
+    parameters (row blocks for the forward layout, column blocks for the data-gradient layout) and cached like them."""
     two_d = w.dim() == 2
+    srcs = getattr(w, "_drn_stack_of", None)
+    if srcs is not None and not two_d:
+        return _packed_stack(srcs, perm, code)
     if not isinstance(w, torch.nn.Parameter):
-        # temporaries (e.g. stacked tower weights) may reuse an address with version 0: never cache them
+        # temporaries may reuse an address with version 0: never cache them
         out = ops.pack_weight(_w3(w), perm, code)
         return out.view(out.shape[0], -1) if two_d else out
     key = (id(w), w.data_ptr(), perm, code)
@@ -48,6 +52,38 @@ def packed(w, perm, code):
             _pack_cache.clear()
         _pack_cache[key] = (ver, out, weakref.ref(w))
     return out.view(out.shape[0], -1) if two_d else out
+
+
+_pstack_cache = {}
+
+
+def _pstack_items(out, params, perm):
+    """Pack items writing conv weights (Cout_i, Cin, k) into their block of the stacked operand `out`."""
+    items, o = [], 0
+    for p in params:
+        n = p.shape[0]
+        dst = out[o:o + n] if perm[0] == 0 else out[:, :, o:o + n]      # (Cout,k,Cin) rows / (Cin,k,Cout) columns
+        items.append((p.detach(), perm, dst))
+        o += n
+    return items
+
+
+def _packed_stack(params, perm, code):
+    key = (tuple((id(p), p.data_ptr()) for p in params), perm, code)
+    ver = (tuple(p._version for p in params), _weights_epoch)
+    hit = _pstack_cache.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == params[0].device and all(r() is p for r, p in zip(hit[2], params)):
+        return hit[1]
+    total = sum(p.shape[0] for p in params)
+    _, Cin, k = params[0].shape
+    shape = (total, k, Cin) if perm[0] == 0 else (Cin, k, total)
+    out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
+        torch.empty(shape, dtype=ops.TORCH_DT[code], device=params[0].device)
+    ops.pack_weights_into(_pstack_items(out, params, perm), code)
+    if len(_pstack_cache) > 64:
+        _pstack_cache.clear()
+    _pstack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
+    return out
 
 
 _stack_cache = {}
@@ -80,6 +116,31 @@ def stacked(params):
         _stack_cache.clear()
     _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
+
+
+class _StackFn(torch.autograd.Function):
+    """cat(params, dim 0) without a copy per step: forward hands out a view of the cached stack (`stacked`), backward
+    splits the gradient into views.  The view remembers its sources so `packed` can build the GEMM operand from them."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.sizes = [p.shape[0] for p in params]
+        buf = stacked(list(params))
+        out = buf.view(buf.shape)
+        out._drn_stack_of = list(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for n in ctx.sizes:
+            outs.append(g[o:o + n])
+            o += n
+        return tuple(outs)
+
+
+def stack_params(params):
+    return _StackFn.apply(*params)
 
 
 def _stack_t_items(out, params):
@@ -120,6 +181,14 @@ def repack_all():
             del _pack_cache[key]
             continue
         by_code.setdefault(key[3], []).append((key, w, out))
+    for key, (ver, out, refs) in list(_pstack_cache.items()):
+        ps = [r() for r in refs]
+        if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key[0] or out.device != ps[0].device:
+            del _pstack_cache[key]
+            continue
+        by_code.setdefault(key[2], [])
+        by_code.setdefault(("stack", key[2]), []).extend(_pstack_items(out, ps, key[1]))
+        _pstack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
     stack_items = []
     for key, (ver, out, refs) in list(_stack_cache.items()):
         ps = [r() for r in refs]
@@ -131,8 +200,11 @@ def repack_all():
         stack_items += _stack_t_items(out, ps) if transposed else _stack_items(out, ps)
         _stack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
     for code, items in by_code.items():
-        extra = stack_items if code == ops.F32 else []
-        ops.pack_weights_into([(_w3(w), key[2], out) for key, w, out in items] + extra, code)
+        if isinstance(code, tuple):
+            continue
+        extra = (stack_items if code == ops.F32 else []) + by_code.get(("stack", code), [])
+        if items or extra:
+            ops.pack_weights_into([(_w3(w), key[2], out) for key, w, out in items] + extra, code)
         for key, w, out in items:
             _pack_cache[key] = ((w._version, _weights_epoch), out, weakref.ref(w))
     if stack_items and ops.F32 not in by_code:
@@ -312,6 +384,7 @@ class _ConvBlockFn(torch.autograd.Function):
             outs.append(out)
         ops.bn_apply_multi(levels, Cout, code, relu=meta.relu)            # all pyramid levels in one launch
         ctx.meta, ctx.nl, ctx.geo, ctx.k = meta, nl, geo, k
+        ctx.weight_obj = weight          # the Python object (a stack_params view carries its sources; saved tensors do not)
         ctx.has_gate, ctx.has_up, ctx.has_cbias = gate is not None, up is not None, cbias is not None
         ctx.beta_ref = beta
         ctx.save_for_backward(weight, gamma, gate if gate is not None else weight.new_empty(0), *xs, *raws, *sss, *saves, *outs)
@@ -373,7 +446,7 @@ class _ConvBlockFn(torch.autograd.Function):
             ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[7 + l] for l in range(nl)):
-            wd = packed(weight, (1, 2, 0), code)                       # (Cin, k, Cout)
+            wd = packed(ctx.weight_obj, (1, 2, 0), code)               # (Cin, k, Cout)
             descs = []
             for l in range(nl):
                 B, L, Lo, M, ld = geo[l]

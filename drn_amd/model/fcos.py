@@ -73,21 +73,33 @@ class FCOSHead(torch.nn.Module):
                 bt, _ = DF.conv_block(bt, self.bbox_tower[3 * i], self.bbox_tower[3 * i + 1], self.training, dt)
             return [torch.cat([c, b], dim=2) for c, b in zip(ct, bt)]
         cc, cb, bc, bb = self.cls_tower[0], self.cls_tower[1], self.bbox_tower[0], self.bbox_tower[1]
-        conv = types.SimpleNamespace(weight=torch.cat([cc.weight, bc.weight], 0), bias=torch.cat([cc.bias, bc.bias], 0),
+        # stacked operands come from caches refreshed once per optimizer step (DF.stack_params / DF.packed): no cat kernels
+        conv = types.SimpleNamespace(weight=DF.stack_params([cc.weight, bc.weight]), bias=DF.stack_params([cc.bias, bc.bias]),
                                      stride=(1,))
-        rm = torch.cat([cb.running_mean, bb.running_mean]) if cb.running_mean is not None else None
-        rv = torch.cat([cb.running_var, bb.running_var]) if cb.running_var is not None else None
-        bn = types.SimpleNamespace(weight=torch.cat([cb.weight, bb.weight]), bias=torch.cat([cb.bias, bb.bias]),
+        track = cb.running_mean is not None
+        rm, rv = self._stacked_running(cb, bb) if track else (None, None)
+        bn = types.SimpleNamespace(weight=DF.stack_params([cb.weight, bb.weight]), bias=DF.stack_params([cb.bias, bb.bias]),
                                    running_mean=rm, running_var=rv, num_batches_tracked=None, momentum=cb.momentum,
                                    eps=cb.eps, track_running_stats=cb.track_running_stats)
         out, _ = DF.conv_block(xs, conv, bn, self.training, dt)
-        if self.training and rm is not None:
+        if self.training and track:
             C = cb.num_features
             with torch.no_grad():
-                cb.running_mean.copy_(rm[:C]); bb.running_mean.copy_(rm[C:])
-                cb.running_var.copy_(rv[:C]); bb.running_var.copy_(rv[C:])
+                dsts = [cb.running_mean, bb.running_mean, cb.running_var, bb.running_var]
+                torch._foreach_copy_(dsts, [rm[:C], rm[C:], rv[:C], rv[C:]])
+                self._tower_stats = (rm, rv, [t._version for t in dsts], [t.data_ptr() for t in dsts])
                 DF.bump_bn_counter(cb.num_batches_tracked, len(xs)); DF.bump_bn_counter(bb.num_batches_tracked, len(xs))
         return out
+
+    def _stacked_running(self, cb, bb):
+        """[cls ; bbox] running statistics in one buffer the BN kernels update; rebuilt only when somebody else touched
+        the modules' own buffers (load_state_dict, .to(), ...) since the last copy-back."""
+        srcs = [cb.running_mean, bb.running_mean, cb.running_var, bb.running_var]
+        st = getattr(self, "_tower_stats", None)
+        if st is not None and st[2] == [t._version for t in srcs] and st[3] == [t.data_ptr() for t in srcs] \
+                and st[0].device == srcs[0].device:
+            return st[0], st[1]
+        return torch.cat(srcs[:2]), torch.cat(srcs[2:])
 
     def forward_nlc(self, xs):
         """xs: channels-last (B, L_l, C) pyramid levels.  Returns flat fp32 buffers
