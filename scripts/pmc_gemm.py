@@ -17,6 +17,12 @@ if shape == "wgrad":
     for _ in range(5):
         ops.gemm_wgrad([ops.wgrad_desc(dY, X, B * 256)], dW, 4096, 4096, dtype=code)
     torch.cuda.synchronize(); sys.exit()
+if shape == "wgrad_nt":      # the prop_fc weight gradient as it runs in the step: NT product of the K-major copies, fp32 output
+    dZT = torch.randn(4096, B * 256, device=dev).to(dt); xT = torch.randn(4096, B * 256, device=dev).to(dt)
+    dW = torch.empty(4096, 4096, device=dev)
+    for _ in range(5):
+        ops.gemm_nt([ops.gemm_desc(dZT, xT, dW, 4096, 4096, B * 256, out_f32=True)], code)
+    torch.cuda.synchronize(); sys.exit()
 if shape == "prop_fc": d, k, W = mk([(B, 256)], 4096, 4096)
 elif shape == "l3": d, k, W = mk([(B, 64)], 512, 512, 3)
 else: d, k, W = mk([(B, 256), (B, 128), (B, 64)], 1024, 512, 3)
