@@ -115,7 +115,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     if (i < P.ngroups && bid >= P.p[i].tile_start) g = i;
   const GemmProb& pr = P.p[g];
   const int t_local = bid - pr.tile_start;
-  const int tm = t_local / pr.tiles_n, tn = t_local - tm * pr.tiles_n;
+  int tm = t_local / pr.tiles_n, tn = t_local - tm * pr.tiles_n;
+  if (P.xcd_swizzle & 2) {
+    // grouped order: walk 8 tile rows down one tile column before moving to the next column, so the ~32 tiles an XCD runs
+    // at a time form an 8 x 4 block (each A panel shared by 4 workgroups, each B panel by 8) instead of 2 x 16
+    const int tiles_m = (pr.M + TM - 1) / TM;
+    const int per_group = 8 * pr.tiles_n;
+    const int gid = t_local / per_group;
+    const int first_m = gid * 8;
+    const int gsm = min(tiles_m - first_m, 8);
+    const int r = t_local - gid * per_group;
+    tm = first_m + r % gsm;
+    tn = r / gsm;
+  }
   const int m0 = tm * TM, n0 = tn * TN;
   const int M = pr.M, N = pr.N, K = pr.K, Cin = pr.Cin, taps = pr.taps;
   const int stride = pr.stride, pad = pr.pad, mode = pr.mode, Lsrc = pr.Lsrc;
@@ -594,7 +606,8 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   P.ngroups = ngroups;
   P.ksplit = ksplit;
   P.ws = ws;
-  P.xcd_swizzle = getenv("DRN_NO_XCD_SWIZZLE") ? 0 : 1;
+  P.xcd_swizzle = getenv("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
+  if (const char* e = getenv("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);      // bit 0: XCD-contiguous runs, bit 1: 8-row grouped order
   if (ksplit > 1) tile = 128;
   int total = 0;
   for (int g = 0; g < ngroups; ++g) {
