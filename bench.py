@@ -202,8 +202,20 @@ def main():
         avg_ms = tot_ms / n
         achieved = flops / (avg_ms * 1e-3) / 1e12
         gemm_ms = sum(a[0] for a in agg.values()) / timed_steps
+        # HBM/fabric bytes per launch of that kernel: not measurable from inside the process; taken from the committed
+        # rocprofv3 --pmc passes of the same launch (profiles/pmc_traffic.json) when there is one, else null
+        traffic, traffic_note = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                ent = json.load(f).get(tag)
+            if ent:
+                traffic = ent["read_bytes"] + ent["write_bytes"]
+                traffic_note = "bytes/launch from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes); %s" % ent["served_by"]
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic, "traffic_note": traffic_note,
+                "avg_launch_ms": round(avg_ms, 4),
                 "launches_per_step": n // timed_steps, "mfma_kernels_ms_per_step": round(gemm_ms, 3),
                 "note": "dominant kernel by total time; flops = 2*M*N*K of that launch; HIP events on the launch stream"}
 
