@@ -4,7 +4,8 @@ Each `torch.autograd.Function` below owns one fused stage of the DRN hot path; f
 backward are sequences of libdrn_hip.so launches (drn_amd/ops.py) on torch's current stream.
 Activations are channels-last ("NLC", shape (B, L, C), C contiguous, row stride may exceed C for
 column slices of a wider buffer) in the compute dtype (float32 = exact-f32 MFMA parity mode,
-bfloat16 = storage with fp32 accumulation).  Parameters stay fp32 and are re-laid / cast per use.
+bfloat16 = storage with fp32 accumulation).  Parameters stay fp32; their GEMM-layout copies (`packed`, `stacked`,
+`stacked_t`) are cached and refreshed in one launch after the optimizer step (`repack_all`).
 """
 import weakref
 

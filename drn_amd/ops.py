@@ -51,9 +51,7 @@ def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Ls
 # Optional per-launch timing of the MFMA kernels (bench.py): a list collecting (tag, flops, start_event, end_event),
 # the events recorded on the same stream the kernels run on.
 kernel_timer = None
-# Split-K of under-filled NT GEMMs is implemented (drn_gemm_nt_splitk) but OFF by default: on MI355X it bought 0.4 % of a
-# step (those launches are bound by operand traffic, not by idle CUs) while changing the fp32 summation order.
-# split-K only pays for long-K problems that cannot fill the chip (conv0 forward: 128 tiles x 204 K-steps -> 2.2x faster);
+# Split-K (drn_gemm_nt_splitk) only pays for long-K problems that cannot fill the chip (conv0 forward: 128 tiles x 204 K-steps -> 2.2x faster);
 # short-K ones lose more to the extra reduce launch than they gain.  DRN_SPLITK=0 disables, =all uses the old wide rule.
 SPLITK = __import__("os").environ.get("DRN_SPLITK", "1")
 
