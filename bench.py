@@ -99,7 +99,10 @@ def main():
     model.train()
     # N>1 with hipGraph: forward+backward replay as a graph, so the collectives are issued after it (no overlap);
     # eager mode overlaps bucket all-reduces with backward from post-accumulate-grad hooks.
-    reducer = ddist.GradReducer(params, world_size=world, overlap=not (args.graph and world > 1))
+    # ... so there is nothing to overlap with and the gradients travel as ONE 153 MB message (xGMI rings are per-link
+    # bound: fewer, larger collectives); 32 MB buckets are for the overlapped eager mode.
+    deferred = args.graph and world > 1
+    reducer = ddist.GradReducer(params, world_size=world, overlap=not deferred, bucket_bytes=(1 << 30) if deferred else (32 << 20))
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-3)                      # main.py:140
     else:
