@@ -35,6 +35,11 @@ struct WgradParams {
   int direct;     // 1: out is the final dW (nsplit==1)
   int w_layout;   // direct only: 0 = [N][taps][Cin], 1 = [N][Cin][taps]
   int accumulate; // direct only
+  // multi != 0: every group is an INDEPENDENT problem of the same N / Cin / taps with its own output (the FPN level convs):
+  // group g owns gridDim.z slices [z_start[g], z_start[g+1]), its rows are split into bps[g]-block pieces
+  int multi;
+  int z_start[DRN_MAX_GROUPS + 1], bps[DRN_MAX_GROUPS], gdirect[DRN_MAX_GROUPS];
+  float* gout[DRN_MAX_GROUPS];
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -116,9 +121,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   const int tap = blockIdx.y / P.ctiles;
   const int c0 = (blockIdx.y - tap * P.ctiles) * TC;
   const int n0 = tn * TNn;
-  const int split = blockIdx.z;
-  const int blk_lo = split * P.blks_per_split;
-  const int blk_hi = min(blk_lo + P.blks_per_split, P.total_blks);
+  int split = blockIdx.z;
+  int blk_lo = split * P.blks_per_split;
+  int blk_hi = min(blk_lo + P.blks_per_split, P.total_blks);
+  float* out_ptr = P.out;
+  int direct = P.direct;
+  if (P.multi) {
+    int pg = 0;
+#pragma unroll
+    for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+      if (i < P.ngroups && (int)blockIdx.z >= P.z_start[i]) pg = i;
+    split = blockIdx.z - P.z_start[pg];
+    const int blk_end = pg + 1 < P.ngroups ? P.g[pg + 1].blk_start : P.total_blks;
+    blk_lo = P.g[pg].blk_start + split * P.bps[pg];
+    blk_hi = min(blk_lo + P.bps[pg], blk_end);
+    out_ptr = P.gout[pg];
+    direct = P.gdirect[pg];
+  }
   const T* zero = (const T*)g_zero_page;
 
   // lane-constant piece of the staging map: instr q = w*4+i covers chunks p = q*64 + l
@@ -216,8 +235,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
 
   // epilogue: acc[mi][ni][r] -> n = n0 + wr*MI*16 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*NI*16 + ni*16 + (l&15)
   const int KW = P.taps * P.Cin;
-  const bool rowmajor = !P.direct || (P.w_layout == 0 && !P.accumulate);   // destination rows contiguous along c
-  float* obase = P.direct ? P.out : P.out + (long)split * P.N * KW;
+  const bool rowmajor = !direct || (P.w_layout == 0 && !P.accumulate);   // destination rows contiguous along c
+  float* obase = direct ? out_ptr : out_ptr + (long)split * P.N * KW;
   if (rowmajor && (KW % 4 == 0) && (P.Cin % 4 == 0) && (((uintptr_t)obase & 15) == 0)) {
     // coalesced: each wave transposes its 64-column slab through a private LDS patch (32 rows at a time) and writes
     // 16-byte row segments instead of 64 scattered 4-byte stores per lane
@@ -259,16 +278,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
         const int c = c0 + wc * (NI * 16) + ni * 16 + (l & 15);
         if (c >= P.Cin) continue;
         float v = acc[mi][ni][r];
-        if (P.direct) {
-          float* dst = P.w_layout == 0 ? P.out + ((long)n * KW + tap * P.Cin + c)
-                                       : P.out + ((long)n * KW + (long)c * P.taps + tap);
+        if (direct) {
+          float* dst = P.w_layout == 0 ? out_ptr + ((long)n * KW + tap * P.Cin + c)
+                                       : out_ptr + ((long)n * KW + (long)c * P.taps + tap);
           if (P.accumulate) v += *dst;
           *dst = v;
         } else {
-          P.out[((long)split * P.N + n) * KW + tap * P.Cin + c] = v;
+          out_ptr[((long)split * P.N + n) * KW + tap * P.Cin + c] = v;
         }
       }
     }
+}
+
+struct WgradReduceMulti {
+  const float* ws[DRN_MAX_GROUPS];
+  float* out[DRN_MAX_GROUPS];
+  int nsplit[DRN_MAX_GROUPS];
+};
+// out[n][...] = (accumulate ? out : 0) + sum_z ws[z][n][tap*Cin+c], in the requested parameter layout; blockIdx.y = problem
+__global__ void wgrad_reduce_multi_kernel(const WgradReduceMulti R, int N, int Cin, int taps, int w_layout, int accumulate) {
+  const long KW = (long)taps * Cin;
+  const long total = (long)N * KW;
+  const float* __restrict__ ws = R.ws[blockIdx.y];
+  float* __restrict__ out = R.out[blockIdx.y];
+  const int nsplit = R.nsplit[blockIdx.y];
+  if (nsplit <= 1) return;                       // written directly by the GEMM
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
+    long o = idx;
+    if (w_layout == 1) {
+      const long n = idx / KW;
+      const int rem = (int)(idx - n * KW);
+      const int tap = rem / Cin, c = rem - tap * Cin;
+      o = n * KW + (long)c * taps + tap;
+    }
+    if (accumulate) s += out[o];
+    out[o] = s;
+  }
 }
 
 // out[n][...] = (accumulate ? out : 0) + sum_z ws[z][n][tap*Cin+c], in the requested parameter layout
@@ -383,4 +430,74 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
     rc = drn_launch_status("drn_gemm_wgrad(reduce)");
   }
   return rc;
+}
+
+// n INDEPENDENT weight gradients of equal N / Cin / taps / stride (the three FPN level convs: different weights, different
+// row counts) in ONE launch + one reduce launch; problem i: dWs[i] = dY_i^T x im2col(X_i).  ws >= n * drn_wgrad_ws_elems(max M).
+extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* dWs, int N, int Cin, int taps, int stride, int pad,
+                                    int w_layout, int accumulate, float* ws, int dtype, void* stream_) {
+  drn_clear_status();
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(d && dWs && n >= 1 && n <= DRN_MAX_GROUPS, "drn_gemm_wgrad_multi: n=%d out of range", n);
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_wgrad_multi: bad dtype %d", dtype);
+  DRN_CHECK_ARG(N > 0 && Cin > 0 && taps >= 1 && stride >= 1, "drn_gemm_wgrad_multi: bad dims");
+  const int ch = dtype == DRN_BF16 ? 8 : 4;
+  const int R = dtype == DRN_BF16 ? 64 : 32;
+  const int tile = 128;
+  WgradParams P;
+  WgradReduceMulti RM;
+  memset(&P, 0, sizeof(P));
+  memset(&RM, 0, sizeof(RM));
+  P.ngroups = n;
+  P.multi = 1;
+  const long per = (long)N * taps * Cin;
+  int blks = 0, z = 0, mmax = 0;
+  bool any_split = false;
+  for (int g = 0; g < n; ++g) mmax = d[g].M > mmax ? d[g].M : mmax;
+  const long ws_per = drn_wgrad_ws_elems(mmax, N, Cin, taps);
+  for (int g = 0; g < n; ++g) {
+    const DrnWgradDesc& s = d[g];
+    DRN_CHECK_ARG(s.dY && s.X && dWs[g] && s.M > 0 && s.Lout > 0 && s.Lsrc > 0 && s.M % s.Lout == 0, "drn_gemm_wgrad_multi: bad problem %d", g);
+    DRN_CHECK_ARG(s.ldy % ch == 0 && s.ldx % ch == 0 && N % ch == 0 && Cin % ch == 0,
+                  "drn_gemm_wgrad_multi: N/Cin/ldy/ldx must be multiples of %d elements", ch);
+    DRN_CHECK_ARG(((uintptr_t)s.dY & 15) == 0 && ((uintptr_t)s.X & 15) == 0, "drn_gemm_wgrad_multi: operands must be 16-byte aligned");
+    P.g[g].dY = s.dY; P.g[g].X = s.X; P.g[g].M = s.M; P.g[g].Lout = s.Lout; P.g[g].Lsrc = s.Lsrc;
+    P.g[g].ldy = s.ldy; P.g[g].ldx = s.ldx; P.g[g].blk_start = blks;
+    const int gb = cdiv(s.M, R);
+    blks += gb;
+    int ns = wgrad_nsplit(total_blocks_upper(s.M, 1), N, Cin, taps);
+    if (ns > gb) ns = gb;
+    P.bps[g] = cdiv(gb, ns);
+    ns = cdiv(gb, P.bps[g]);
+    DRN_CHECK_ARG(ns == 1 || ws, "drn_gemm_wgrad_multi: workspace required");
+    P.z_start[g] = z;
+    z += ns;
+    P.gdirect[g] = ns == 1;
+    P.gout[g] = ns == 1 ? dWs[g] : ws + (long)g * ws_per;
+    RM.ws[g] = ws + (long)g * ws_per; RM.out[g] = dWs[g]; RM.nsplit[g] = ns;
+    any_split |= ns > 1;
+    DRN_CHECK_ARG(ns == 1 || (long)ns * per <= ws_per, "drn_gemm_wgrad_multi: workspace slice too small");
+  }
+  P.z_start[n] = z;
+  P.total_blks = blks;
+  P.blks_per_split = blks;
+  P.N = N; P.Cin = Cin; P.taps = taps; P.stride = stride; P.pad = pad;
+  P.ctiles = cdiv(Cin, tile);
+  P.w_layout = w_layout;
+  P.accumulate = accumulate;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(N, tile), taps * P.ctiles, z);
+  if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+  else conv_wgrad_tn_kernel<float, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+  int rc = drn_launch_status("drn_gemm_wgrad_multi");
+  if (rc || !any_split) return rc;
+  int nb = (int)((per + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  wgrad_reduce_multi_kernel<<<dim3(nb, n), 256, 0, stream>>>(RM, N, Cin, taps, w_layout, accumulate);
+  return drn_launch_status("drn_gemm_wgrad_multi(reduce)");
 }

@@ -592,13 +592,18 @@ class _MultiConvFn(torch.autograd.Function):
             dxs[l] = dx
         if descs:
             ops.gemm_nt(descs, code)
-        dWs = []
-        for l in range(n):
-            B, L, Lo, M, ld, Cout, Cin, k, pad = geo[l]
-            dW = grad_buffer(weights[l])
-            ops.gemm_wgrad([ops.wgrad_desc(draws[l], xs[l], M, Lout=Lo, Lsrc=L, ldy=Cout, ldx=ld)], dW, Cout, Cin, taps=k,
-                           stride=strides[l], pad=pad, w_layout=1, dtype=code)
-            dWs.append(dW)
+        dWs = [grad_buffer(weights[l]) for l in range(n)]
+        wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=geo[l][5], ldx=geo[l][4])
+                  for l in range(n)]
+        same = all(geo[l][5:9] == geo[0][5:9] and strides[l] == strides[0] for l in range(n))
+        if same and n > 1 and n * max(g[3] for g in geo) <= 4 * sum(g[3] for g in geo):
+            # same (Cout, Cin, k): one launch (+ one reduce) for all levels' weight gradients instead of one pair per level
+            ops.gemm_wgrad_multi(wdescs, dWs, geo[0][5], geo[0][6], taps=geo[0][7], stride=strides[0], pad=geo[0][8], w_layout=1,
+                                 dtype=code)
+        else:
+            for l in range(n):
+                B, L, Lo, M, ld, Cout, Cin, k, pad = geo[l]
+                ops.gemm_wgrad([wdescs[l]], dWs[l], Cout, Cin, taps=k, stride=strides[l], pad=pad, w_layout=1, dtype=code)
         return (None,) + tuple(dWs) + tuple(dgammas) + tuple(dbetas) + tuple(dxs)
 
 

@@ -114,6 +114,22 @@ def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulat
                                               _p(ws), dtype, _stream()), "drn_gemm_wgrad"))
 
 
+def gemm_wgrad_multi(descs, dWs, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulate=False, dtype=F32):
+    """len(descs) independent weight gradients of equal shape (different weights / row counts) in one launch."""
+    for dW in dWs:
+        _need_gpu(dW)
+        assert dW.dtype == torch.float32 and dW.is_contiguous()
+    n_ws = len(descs) * int(lib().drn_wgrad_ws_elems(max(d.M for d in descs), N, Cin, taps))
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dWs[0].device)
+    arr = (WgradDesc * len(descs))(*descs)
+    ptrs = (ctypes.c_void_p * len(dWs))(*[dW.data_ptr() for dW in dWs])
+    m_total = sum(d.M for d in descs)
+    tag = "gemm_wgrad_multi[%s] n=%d M=%d N=%d K=%d" % ("bf16" if dtype == BF16 else "f32", len(descs), m_total, N, taps * Cin)
+    _timed(tag, 2.0 * m_total * N * taps * Cin,
+           lambda: check(lib().drn_gemm_wgrad_multi(arr, len(descs), ptrs, N, Cin, taps, stride, pad, w_layout, int(accumulate),
+                                                    _p(ws), dtype, _stream()), "drn_gemm_wgrad_multi"))
+
+
 # ---------------------------------------------------------------------------------------------
 # HBM-bound helpers
 # ---------------------------------------------------------------------------------------------

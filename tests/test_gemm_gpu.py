@@ -275,3 +275,27 @@ def test_prop_fc_weight_gradient_nt_path_matches_tn_kernel():
     want = dZ.double().t() @ X.double()
     assert float((a.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
     assert float((b.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_wgrad_multi_equals_separate_launches(dt):
+    """drn_gemm_wgrad_multi: independent problems (different weights and row counts, FPN levels) in one launch."""
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, Cout, Cin, k = 4, 136, 72, 3
+    code = ops.dtype_code(torch.empty(1, dtype=dt))
+    descs, keep, want, outs = [], [], [], []
+    for L in (256, 64, 20):
+        dY = torch.randn(B * L, Cout, generator=g).to(dev()).to(dt)
+        X = torch.randn(B * L, Cin, generator=g).to(dev()).to(dt)
+        keep.append((dY, X))
+        d = ops.wgrad_desc(dY, X, B * L, Lout=L, Lsrc=L)
+        descs.append(d)
+        ref = torch.empty(Cout, Cin, k, device=dev())
+        ops.gemm_wgrad([d], ref, Cout, Cin, taps=k, pad=1, w_layout=1, dtype=code)
+        want.append(ref)
+        outs.append(torch.full((Cout, Cin, k), float("nan"), device=dev()))
+    ops.gemm_wgrad_multi(descs, outs, Cout, Cin, taps=k, pad=1, w_layout=1, dtype=code)
+    for a, b in zip(outs, want):
+        assert torch.isfinite(a).all()
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-4 * float(b.abs().max()))
