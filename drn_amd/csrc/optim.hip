@@ -64,6 +64,7 @@ struct AdamArgs {
   float* const* p_ptr;      // [nseg] parameter base pointers (device)
   int nseg;
   const float* total_sumsq; // squared global gradient norm over ALL buckets (drn_sumsq_finalize)
+  const int* blk_seg;       // [blocks] tensor index of each block's first element (host-precomputed), or NULL
   const int* step_counter;
   float lr, beta1, beta2, eps, max_norm;
 };
@@ -71,22 +72,59 @@ struct AdamArgs {
 __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs A) {
   __shared__ int first_seg;
   const float total_norm = sqrtf(A.total_sumsq[0]);
+  const bool have_tab = A.blk_seg != nullptr;
   float clip = A.max_norm > 0.f ? A.max_norm / (total_norm + 1e-6f) : 1.f;   // torch.nn.utils.clip_grad_norm_
   clip = fminf(clip, 1.f);
   const int t = *A.step_counter;
   const float bc1 = 1.f - powf(A.beta1, (float)t), bc2 = 1.f - powf(A.beta2, (float)t);
   const float step_size = A.lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   const long base = (long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
-  if (threadIdx.x == 0) {   // binary search: last segment with start <= base
-    int lo = 0, hi = A.nseg - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (A.seg_start[mid] <= base) lo = mid; else hi = mid - 1;
+  if (!have_tab) {
+    if (threadIdx.x == 0) {   // binary search: last segment with start <= base
+      int lo = 0, hi = A.nseg - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (A.seg_start[mid] <= base) lo = mid; else hi = mid - 1;
+      }
+      first_seg = lo;
     }
-    first_seg = lo;
+    __syncthreads();
   }
-  __syncthreads();
-  int seg = first_seg;
+  int seg = have_tab ? A.blk_seg[blockIdx.x] : first_seg;
+  // Fast path (almost every block of the large tensors): the whole 4096-element block lies inside ONE 16-byte-aligned
+  // tensor, so there are no per-quad table lookups and all 16 loads of the four trips are issued before the first use.
+  {
+    const long s0 = A.seg_start[seg], s1 = A.seg_start[seg + 1];
+    float* pbase = A.p_ptr[seg];
+    if (pbase != nullptr && base + OPT_ELEMS_PER_BLOCK <= s1 && base + OPT_ELEMS_PER_BLOCK <= A.n &&
+        ((((uintptr_t)(pbase + (base - s0))) & 15) == 0)) {
+      float* p = pbase + (base - s0);
+      f32x4 g4[4], m4[4], v4[4], p4[4];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int i = threadIdx.x * 4 + t4 * OPT_THREADS * 4;
+        g4[t4] = *(const f32x4*)(A.g + base + i);
+        m4[t4] = *(const f32x4*)(A.m + base + i);
+        v4[t4] = *(const f32x4*)(A.v + base + i);
+        p4[t4] = *(const f32x4*)(p + i);
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int i = threadIdx.x * 4 + t4 * OPT_THREADS * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = g4[t4][e] * clip;
+          m4[t4][e] = A.beta1 * m4[t4][e] + (1.f - A.beta1) * g;
+          v4[t4][e] = A.beta2 * v4[t4][e] + (1.f - A.beta2) * g * g;
+          p4[t4][e] -= step_size * m4[t4][e] / (sqrtf(v4[t4][e]) * inv_sqrt_bc2 + A.eps);
+        }
+        *(f32x4*)(A.m + base + i) = m4[t4];
+        *(f32x4*)(A.v + base + i) = v4[t4];
+        *(f32x4*)(p + i) = p4[t4];
+      }
+      return;
+    }
+  }
   // 4 elements per thread per trip.  Segment starts are 4-aligned in the flat buffers (drn_amd.dist pads them), so a
   // quad never straddles two tensors; only a tensor's last (partial) quad takes the scalar path.
   for (int i = threadIdx.x * 4; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS * 4) {
@@ -124,14 +162,14 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
 }
 
 extern "C" int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev,
-                               int nseg, const float* total_sumsq, const int* step_counter, float lr, float beta1,
-                               float beta2, float eps, float max_norm, void* stream) {
+                               int nseg, const int* blk_seg, const float* total_sumsq, const int* step_counter, float lr,
+                               float beta1, float beta2, float eps, float max_norm, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(g && m && v && n > 0 && seg_start_dev && p_ptr_dev && nseg > 0 && total_sumsq && step_counter,
                 "drn_adam_bucket: bad args");
   AdamArgs A;
   A.g = g; A.m = m; A.v = v; A.n = n; A.seg_start = (const long*)seg_start_dev; A.p_ptr = p_ptr_dev; A.nseg = nseg;
-  A.total_sumsq = total_sumsq; A.step_counter = step_counter;
+  A.total_sumsq = total_sumsq; A.step_counter = step_counter; A.blk_seg = blk_seg;
   A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.max_norm = max_norm;
   adam_bucket_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_adam_bucket");

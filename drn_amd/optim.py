@@ -31,10 +31,14 @@ class FusedAdam(object):
                     ptrs.append(0)
             offs.append(n)
             nb = int(L.drn_opt_nblocks(ctypes.c_int64(n)))
+            import numpy as np
+            starts = np.asarray(offs[:-1], dtype=np.int64)
+            blk_seg = (np.searchsorted(starts, np.arange(nb, dtype=np.int64) * 4096, side="right") - 1).astype(np.int32)
             self.state.append({"m": torch.zeros_like(b.flat), "v": torch.zeros_like(b.flat),
                                "seg": torch.tensor(offs, dtype=torch.int64, device=dev),
                                "ptr": torch.tensor(ptrs, dtype=torch.int64, device=dev),
-                               "nseg": len(ptrs), "part_off": nparts, "nb": nb})
+                               "nseg": len(ptrs), "part_off": nparts, "nb": nb,
+                               "blk_seg": torch.from_numpy(blk_seg).to(dev)})
             nparts += nb
         self.partials = torch.zeros(nparts, dtype=torch.float32, device=dev)
         self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -56,7 +60,7 @@ class FusedAdam(object):
         check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), s), "drn_sumsq_finalize")
         for b, st in zip(self.reducer.buckets, self.state):
             check(L.drn_adam_bucket(P(b.flat), P(st["m"]), P(st["v"]), ctypes.c_int64(b.flat.numel()), P(st["seg"]), P(st["ptr"]),
-                                    st["nseg"], P(self.total_sumsq), P(self.step_counter),
+                                    st["nseg"], P(st["blk_seg"]), P(self.total_sumsq), P(self.step_counter),
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                                     ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
         DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
