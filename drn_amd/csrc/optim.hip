@@ -65,6 +65,7 @@ struct AdamArgs {
   int nseg;
   const float* total_sumsq; // squared global gradient norm over ALL buckets (drn_sumsq_finalize)
   const int* blk_seg;       // [blocks] tensor index of each block's first element (host-precomputed), or NULL
+  bf16_t* const* mirror;    // [nseg] bf16 copy of the tensor in the SAME element order (Linear / 1x1-conv GEMM operand), or NULL
   const int* step_counter;
   float lr, beta1, beta2, eps, max_norm;
 };
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
     if (pbase != nullptr && base + OPT_ELEMS_PER_BLOCK <= s1 && base + OPT_ELEMS_PER_BLOCK <= A.n &&
         ((((uintptr_t)(pbase + (base - s0))) & 15) == 0)) {
       float* p = pbase + (base - s0);
+      bf16_t* mp = A.mirror ? A.mirror[seg] : nullptr;
+      if (mp) mp += base - s0;
       f32x4 g4[4], m4[4], v4[4], p4[4];
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) {
@@ -121,6 +124,12 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
         *(f32x4*)(A.m + base + i) = m4[t4];
         *(f32x4*)(A.v + base + i) = v4[t4];
         *(f32x4*)(p + i) = p4[t4];
+        if (mp) {                                   // the GEMM's bf16 operand, refreshed in the same pass
+          bf16x4 b;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = (bf16_t)p4[t4][e];
+          *(bf16x4*)(mp + i) = b;
+        }
       }
       return;
     }
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
     float* pbase = A.p_ptr[seg];
     if (pbase == nullptr) continue;                       // padding between tensors
     float* p = pbase + (k - s0);
+    bf16_t* mq = (A.mirror && A.mirror[seg]) ? A.mirror[seg] + (k - s0) : nullptr;
     if (k + 4 <= s1 && k + 4 <= A.n && (((uintptr_t)p) & 15) == 0) {
       const f32x4 g4 = *(const f32x4*)(A.g + k);
       f32x4 m4 = *(const f32x4*)(A.m + k), v4 = *(const f32x4*)(A.v + k), p4 = *(const f32x4*)p;
@@ -148,6 +158,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
       *(f32x4*)(A.m + k) = m4;
       *(f32x4*)(A.v + k) = v4;
       *(f32x4*)p = p4;
+      if (mq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mq[e] = (bf16_t)p4[e];
     } else {
       for (int e = 0; e < 4 && k + e < s1 && k + e < A.n; ++e) {
         const float g = A.g[k + e] * clip;
@@ -156,20 +169,21 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
         A.m[k + e] = m;
         A.v[k + e] = v;
         p[e] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + A.eps);
+        if (mq) mq[e] = (bf16_t)p[e];
       }
     }
   }
 }
 
 extern "C" int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev,
-                               int nseg, const int* blk_seg, const float* total_sumsq, const int* step_counter, float lr,
-                               float beta1, float beta2, float eps, float max_norm, void* stream) {
+                               int nseg, const int* blk_seg, void* const* mirror_dev, const float* total_sumsq,
+                               const int* step_counter, float lr, float beta1, float beta2, float eps, float max_norm, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(g && m && v && n > 0 && seg_start_dev && p_ptr_dev && nseg > 0 && total_sumsq && step_counter,
                 "drn_adam_bucket: bad args");
   AdamArgs A;
   A.g = g; A.m = m; A.v = v; A.n = n; A.seg_start = (const long*)seg_start_dev; A.p_ptr = p_ptr_dev; A.nseg = nseg;
-  A.total_sumsq = total_sumsq; A.step_counter = step_counter; A.blk_seg = blk_seg;
+  A.total_sumsq = total_sumsq; A.step_counter = step_counter; A.blk_seg = blk_seg; A.mirror = (bf16_t* const*)mirror_dev;
   A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.max_norm = max_norm;
   adam_bucket_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_adam_bucket");

@@ -171,15 +171,32 @@ def stacked_t(params):
     return out
 
 
-def repack_all():
+def identity_bf16_copies():
+    """{parameter data_ptr: (cache key, bf16 copy)} for cached GEMM operands that keep the parameter's element order (Linear
+    weights, 1x1 convs in the forward layout): the fused optimizer rewrites those itself while it has the value in registers."""
+    out = {}
+    for key, (ver, buf, ref) in _pack_cache.items():
+        w = ref()
+        if w is None or key[3] != ops.BF16 or key[2] != (0, 2, 1) or w.data_ptr() != key[1]:
+            continue
+        if w.dim() == 2 or w.shape[2] == 1:
+            out[w.data_ptr()] = (key, buf)
+    return out
+
+
+def repack_all(skip=()):
     """Refresh every cached re-laid weight IN PLACE with one launch per dtype (drn_pack_weights) and mark it current:
     an optimizer that has just updated all parameters calls this instead of leaving ~20 small per-use launches to
-    the next forward pass.  The copies keep their addresses, so captured hipGraphs stay valid."""
+    the next forward pass.  The copies keep their addresses, so captured hipGraphs stay valid.  `skip`: cache keys the
+    caller has already refreshed itself (identity_bf16_copies)."""
     by_code = {}
     for key, (ver, out, ref) in list(_pack_cache.items()):
         w = ref()
         if w is None or w.data_ptr() != key[1] or out.device != w.device:
             del _pack_cache[key]
+            continue
+        if key in skip:
+            _pack_cache[key] = ((w._version, _weights_epoch), out, ref)
             continue
         by_code.setdefault(key[3], []).append((key, w, out))
     for key, (ver, out, refs) in list(_pstack_cache.items()):

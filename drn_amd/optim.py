@@ -40,6 +40,7 @@ class FusedAdam(object):
                                "nseg": len(ptrs), "part_off": nparts, "nb": nb,
                                "blk_seg": torch.from_numpy(blk_seg).to(dev)})
             nparts += nb
+        self._mirror_sig, self._mirror_keys = None, ()
         self.partials = torch.zeros(nparts, dtype=torch.float32, device=dev)
         self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -52,19 +53,40 @@ class FusedAdam(object):
     def step(self):
         L = lib()
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         for i, (b, st) in enumerate(zip(self.reducer.buckets, self.state)):
             part = self.partials[st["part_off"]:]
             check(L.drn_sumsq_partials(P(b.flat), ctypes.c_int64(b.flat.numel()), P(part),
                                        P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials")
         check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), s), "drn_sumsq_finalize")
+        self._refresh_mirrors()
         for b, st in zip(self.reducer.buckets, self.state):
             check(L.drn_adam_bucket(P(b.flat), P(st["m"]), P(st["v"]), ctypes.c_int64(b.flat.numel()), P(st["seg"]), P(st["ptr"]),
-                                    st["nseg"], P(st["blk_seg"]), P(self.total_sumsq), P(self.step_counter),
+                                    st["nseg"], P(st["blk_seg"]), P(st.get("mirror")), P(self.total_sumsq), P(self.step_counter),
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                                     ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
         DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
-        DF.repack_all()               # refresh the GEMM-layout copies of all weights in one launch
+        DF.repack_all(skip=self._mirror_keys)     # refresh the other GEMM-layout copies of the weights in one launch
+
+    def _refresh_mirrors(self):
+        """Device tables of the bf16 GEMM operands that keep their parameter's element order (drn_adam_bucket rewrites them
+        in place).  Rebuilt only when the set of cached copies changes, and never while a hipGraph is being captured (the
+        table upload is a host->device copy): copies that appear later are simply left to repack_all()."""
+        copies = DF.identity_bf16_copies()
+        sig = tuple(sorted((ptr, buf.data_ptr()) for ptr, (key, buf) in copies.items()))
+        if sig == self._mirror_sig or torch.cuda.is_current_stream_capturing():
+            return
+        keys = []
+        for st in self.state:
+            tab = []
+            for ptr in st["ptr"].tolist():
+                hit = copies.get(ptr) if ptr else None
+                tab.append(hit[1].data_ptr() if hit else 0)
+                if hit:
+                    keys.append(hit[0])
+            st["mirror_bufs"] = [copies[p][1] for p in st["ptr"].tolist() if p and p in copies]      # keep them alive
+            st["mirror"] = torch.tensor(tab, dtype=torch.int64, device=st["ptr"].device) if any(tab) else None
+        self._mirror_sig, self._mirror_keys = sig, frozenset(keys)
 
     def total_norm(self):
         return self.total_sumsq[0].sqrt()

@@ -299,10 +299,12 @@ int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_cou
 int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream);
 /* One bucket: g/m/v flat [n]; tensor i covers [seg_start[i], seg_start[i+1]) and lives at p_ptr[i] (both tables on the
  * device).  blk_seg (device, drn_opt_nblocks(n) ints, or NULL): index of the tensor holding element 4096*b, so a block
- * does not search the table.  clip coef = min(1, max_norm/(sqrt(total_sumsq)+1e-6)) (max_norm<=0: off). */
+ * does not search the table.  mirror_dev (device table of nseg pointers, or NULL; entries may be NULL): a bf16 copy of tensor
+ * i in the same element order (the GEMM operand of a Linear / 1x1 conv), rewritten from the updated value in the same pass.
+ * clip coef = min(1, max_norm/(sqrt(total_sumsq)+1e-6)) (max_norm<=0: off). */
 int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev, int nseg,
-                    const int32_t* blk_seg, const float* total_sumsq, const int* step_counter, float lr, float beta1, float beta2,
-                    float eps, float max_norm, void* stream);
+                    const int32_t* blk_seg, void* const* mirror_dev, const float* total_sumsq, const int* step_counter, float lr,
+                    float beta1, float beta2, float eps, float max_norm, void* stream);
 
 #ifdef __cplusplus
 }
