@@ -325,6 +325,24 @@ def _grad_nlc(g, like_shape, dtype):
     return g
 
 
+class _CastActFn(torch.autograd.Function):
+    """Activation dtype change between two stages that run in different compute dtypes (see mainModel.forward_core: an
+    unaligned feature dimension keeps the input stage and conv0 on the exact-f32 kernels inside a bf16 model)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return x.to(dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.src), None
+
+
+def cast_act(x, dtype):
+    return x if x.dtype == dtype else _CastActFn.apply(x, dtype)
+
+
 class ConvMeta(object):
     """Static (non-tensor) description of one conv+BN(+ReLU) block call."""
 

@@ -19,13 +19,17 @@ class Backbone(nn.Module):
 
     def forward_from_stage(self, g0, gates):
         """g0: (B, T, D+P) channels-last = cat(q0 * prop_fc(x), position feats) (drn_amd.functional.input_stage);
-        gates[i]: (B, C_i) fp32.  The gate of level i+1 is fused into level i's BN-apply pass."""
+        gates[i]: (B, C_i) fp32.  The gate of level i+1 is fused into level i's BN-apply pass.  g0 may arrive in float32
+        inside a bfloat16 model (feature dim not a 16-byte multiple in bf16): conv0 then runs on the exact-f32 kernels
+        and its outputs are cast to the model's compute dtype."""
         outs, x = [], g0
+        dt = self.compute_dtype
         for idx in range(self.num_layers):
             nxt = gates[idx + 1] if idx + 1 < self.num_layers else None
-            out, gated = getattr(self, self.blocks[idx]).forward_nlc([x], gate=nxt)
-            outs.append(out[0])
-            x = gated
+            blk = getattr(self, self.blocks[idx])
+            out, gated = DF.conv_block([x], blk[0], blk[1], self.training, x.dtype if idx == 0 else dt, gate=nxt)
+            outs.append(DF.cast_act(out[0], dt))
+            x = DF.cast_act(gated, dt) if gated is not None else None
         return outs
 
     def forward(self, x, query_fts, position_fts):

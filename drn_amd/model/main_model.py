@@ -60,7 +60,10 @@ class mainModel(nn.Module):
         # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
         duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
         position_feat = torch.cat((props_start_end, duration), dim=-1).float()
-        g0 = DF.input_stage(props_features, position_feat, self.prop_fc, gates[0], self.position_transform, dt)
+        # bf16 rows must be 16-byte multiples for the MFMA kernels' LDS staging; a feature dim that is not (D = 500, the
+        # ActivityNet C3D-PCA convention) keeps the two layers that see D -- prop_fc and conv0 -- on the exact-f32 kernels
+        front_dt = torch.float32 if (dt == torch.bfloat16 and props_features.shape[2] % 8) else dt
+        g0 = DF.input_stage(props_features, position_feat, self.prop_fc, gates[0], self.position_transform, front_dt)
         backbone_feats = self.backbone_net.forward_from_stage(g0, gates)
         feats = self.fpn.forward_nlc(backbone_feats)
         head = self.fcos.head

@@ -65,10 +65,11 @@ def test_fp32_parity_at_config_shapes(name, B, T, D, stage):
     check_outputs(lh, hh, lo, ho, 1e-4)
 
 
-@pytest.mark.parametrize("name,B,T,D,stage", SHAPES[:3])
+@pytest.mark.parametrize("name,B,T,D,stage", SHAPES)
 def test_bf16_tolerance_sweep(name, B, T, D, stage):
     """bf16 storage / fp32 accumulation vs the exact-f32 path (configs[4]'s sweep): losses within 3e-2 relative,
-    head outputs within 6e-2 of their scale (13 stacked conv+BN layers in bf16)."""
+    head outputs within 6e-2 of their scale (13 stacked conv+BN layers in bf16).  D = 500 is not a 16-byte multiple in
+    bf16: prop_fc and conv0 stay on the exact-f32 kernels there, the rest of the model runs in bf16."""
     from drn_amd.model import mainModel
     cfg = default_cfg("C3D" if D == 4096 else "SYN", D, stage)
     batch = synthetic_batch(B, T, D, seed=3)
@@ -84,14 +85,31 @@ def test_bf16_tolerance_sweep(name, B, T, D, stage):
             assert float((x - y).abs().max()) <= 6e-2 * max(1.0, float(y.abs().max())), (j, l)
 
 
-def test_bf16_rejects_unaligned_feature_dim_loudly():
-    """D=500 (configs[4]) is not a 16-byte multiple in bf16: the GEMM refuses instead of computing something else."""
-    from drn_amd import _lib
+def test_bf16_unaligned_feature_dim_trains():
+    """D=500 in a bf16 model: forward + backward run (f32 front, bf16 trunk) and every trainable parameter gets a finite
+    gradient close to the all-f32 model's."""
     from drn_amd.model import mainModel
     cfg = default_cfg("SYN", 500, 1)
-    m = build(mainModel, cfg, DEV, compute_dtype=torch.bfloat16)
-    with pytest.raises(_lib.DrnError):
-        m(*[x.to(DEV) for x in synthetic_batch(2, 64, 500, seed=1)])
+    batch = [x.to(DEV) for x in synthetic_batch(2, 64, 500, seed=1)]
+    grads = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = build(mainModel, cfg, DEV, compute_dtype=dt)
+        m.train()
+        _, losses = m(*batch)
+        sum(losses.values()).backward()
+        grads[dt] = {k: p.grad.float().clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert set(grads[torch.float32]) == set(grads[torch.bfloat16])
+    num = den = 0.0
+    for k, g32 in grads[torch.float32].items():
+        g16 = grads[torch.bfloat16][k]
+        assert torch.isfinite(g16).all(), k
+        num += float((g16 - g32).double().pow(2).sum())
+        den += float(g32.double().pow(2).sum())
+    # two clips, 13 bf16 layers: individual small gradients are noisy; the whole gradient vector must agree
+    assert (num / den) ** 0.5 <= 0.15, (num / den) ** 0.5
+    for k in ("prop_fc.weight", "backbone_net.forward_conv0.0.weight"):          # the layers that ran in f32
+        g32, g16 = grads[torch.float32][k], grads[torch.bfloat16][k]
+        assert float((g16 - g32).norm()) <= 0.2 * float(g32.norm()), k
 
 
 def test_clip_permutation_invariance_full_size():
