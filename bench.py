@@ -145,13 +145,13 @@ def main():
                     reducer.zero()
                     _, losses = model(*batch)
                     loss_of(losses).backward()
+                    reducer.collect()                 # foreign gradients -> flat buckets: device copies, part of the graph
                     return losses
                 core = GraphedStep(fwd_bwd, warmup=0)
 
                 def run():
                     losses = core()
-                    for b_ in reducer.buckets:        # re-arm: hooks only run eagerly / at capture time
-                        b_.launched, b_.handle = False, None
+                    reducer.rearm()                   # hooks only run eagerly / at capture time
                     opt_step()
                     return losses
                 for _ in range(max(args.warmup, 2)):

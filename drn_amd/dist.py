@@ -123,32 +123,56 @@ class GradReducer(object):
                     if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                         p.grad = v.view_as(p)
 
-    def finish(self):
-        """Call after backward: reduce the buckets whose parameters got no gradient this step (unused / frozen
-        branches contribute zeros), wait for all collectives and turn sums into means."""
+    def collect(self):
+        """After backward: make every flat bucket hold this step's gradients -- slices of parameters that got no gradient
+        read as zero, gradients produced outside the sinks (stock autograd ops, hand-set) are copied in with one
+        multi-tensor launch per bucket.  Device work only, so it can sit inside a captured hipGraph: call it at the end
+        of the captured forward+backward and `reduce()` after the replay."""
         for b in self.buckets:
-            if self.steal:
-                dsts, srcs = [], []
-                for p, v in zip(b.params, b.views):
-                    if p.grad is None:                          # no gradient this step: the slice must read as zero
-                        if self._dirty.get(p, False):
-                            v.zero_()
-                            self._dirty[p] = False
-                        p.grad = v.view_as(p)
-                    elif p.grad.data_ptr() != v.data_ptr():     # produced by stock autograd ops / set by hand: move it in
-                        dsts.append(v)
-                        srcs.append(p.grad.detach().reshape(-1))
-                        p.grad = v.view_as(p)
-                        self._dirty[p] = True
-                if dsts:
-                    with torch.no_grad():
-                        torch._foreach_copy_(dsts, srcs)        # one multi-tensor launch per bucket
+            if not self.steal:
+                continue
+            dsts, srcs = [], []
+            for p, v in zip(b.params, b.views):
+                if p.grad is None:                          # no gradient this step: the slice must read as zero
+                    if self._dirty.get(p, False):
+                        v.zero_()
+                        self._dirty[p] = False
+                    p.grad = v.view_as(p)
+                elif p.grad.data_ptr() != v.data_ptr():     # produced by stock autograd ops / set by hand: move it in
+                    dsts.append(v)
+                    srcs.append(p.grad.detach().reshape(-1))
+                    p.grad = v.view_as(p)
+                    self._dirty[p] = True
+            if dsts:
+                with torch.no_grad():
+                    torch._foreach_copy_(dsts, srcs)        # one multi-tensor launch per bucket
+
+    def reduce(self, buckets=None):
+        """Launch the collectives that are not in flight yet (all buckets, or the given ones) without waiting."""
+        for b in (self.buckets if buckets is None else buckets):
             if not b.launched:
                 self._launch(b)
+
+    def wait(self):
+        """Wait for all collectives and turn sums into means."""
         if self.world > 1:
             for b in self.buckets:
-                b.handle.wait()
-                b.flat.div_(self.world)
+                if b.handle is not None:
+                    b.handle.wait()
+                    b.handle = None
+                    b.flat.div_(self.world)
+
+    def rearm(self):
+        """Deferred (hipGraph) mode: hooks only run at capture time, so mark every bucket as not yet reduced."""
+        for b in self.buckets:
+            b.launched, b.handle = False, None
+
+    def finish(self):
+        """Call after backward: collect(), reduce the buckets that are not in flight yet (those whose parameters got no
+        gradient this step contribute zeros), wait for all collectives and turn sums into means."""
+        self.collect()
+        self.reduce()
+        self.wait()
 
     def remove(self):
         for h in self._hooks:

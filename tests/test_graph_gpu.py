@@ -52,3 +52,58 @@ def test_graph_replay_matches_eager():
     for (k1, p1), (k2, p2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         if p1.is_floating_point():
             assert torch.allclose(p1, p2, atol=2e-3, rtol=2e-3), (k1, float((p1 - p2).abs().max()))
+
+
+def test_deferred_mode_graph_carries_foreign_gradients():
+    """Multi-GPU graph mode (bench.py N>1): forward+backward+collect() replay as a hipGraph, the collectives and the
+    optimizer run after it.  Gradients that reach the flat buckets through a copy (Scale parameters, the stacked tower
+    parameters) must be this step's on EVERY replay, not the capture step's."""
+    from drn_amd.dist import GradReducer
+    from drn_amd.graph import GraphedStep
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    dev = "cuda:0"
+
+    def build():
+        m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", 64, 3)), compute_dtype=torch.float32)
+        m.load_state_dict(seeded_state_dict(m, 0))
+        return m.to(dev).train()
+
+    bA = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=1)]
+    other = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=2)]
+    bB = list(bA)                                            # same queries (token shapes are seed dependent) ...
+    bB[2], bB[4] = other[2], other[4]                        # ... different clip features and ground truth
+    assert all(a.shape == b.shape for a, b in zip(bA, bB))
+    # reference: plain eager gradients on batch B
+    mr = build()
+    _, losses = mr(*bB)
+    sum(losses.values()).backward()
+    want = {k: p.grad.clone() for k, p in mr.named_parameters() if p.grad is not None}
+    # deferred mode: capture on batch A, then replay on batch B (inputs refreshed in place)
+    m = build()
+    red = GradReducer([p for p in m.parameters() if p.requires_grad], world_size=1, overlap=False)
+    static = [b.clone() for b in bA]
+
+    def fwd_bwd():
+        red.zero()
+        _, ls = m(*static)
+        sum(ls.values()).backward()
+        red.collect()
+        return ls
+
+    g = GraphedStep(fwd_bwd, warmup=2).capture()
+    g(); red.rearm(); red.finish()
+    for s, b in zip(static, bB):
+        s.copy_(b)
+    g(); red.rearm(); red.finish()
+    torch.cuda.synchronize()
+    checked = 0
+    for k, p in m.named_parameters():
+        if k in want:
+            ref = want[k]
+            tol = 1e-4 * max(float(ref.abs().max()), 1e-6) + 1e-7
+            assert float((p.grad - ref).abs().max()) <= tol, (k, float((p.grad - ref).abs().max()), tol)
+            checked += 1
+    assert checked > 40
+    for k in ("fcos.head.scales.0.scale", "fcos.head.cls_tower.0.weight", "fcos.head.bbox_tower.1.weight"):
+        assert k in want and float(want[k].abs().max()) > 0
