@@ -97,12 +97,16 @@ def main():
     model = build(mainModel, cfg, dev, compute_dtype=cdt)
     params = stage_params(model, stage)
     model.train()
-    # N>1 with hipGraph: forward+backward replay as a graph, so the collectives are issued after it (no overlap);
-    # eager mode overlaps bucket all-reduces with backward from post-accumulate-grad hooks.
-    # ... so there is nothing to overlap with and the gradients travel as ONE 153 MB message (xGMI rings are per-link
-    # bound: fewer, larger collectives); 32 MB buckets are for the overlapped eager mode.
+    # N>1 with hipGraph: forward+backward replay as TWO graphs split where backward leaves the trunk (drn_amd.graph.
+    # TwoPhaseStep); the trunk's gradients are all-reduced while the front's backward (prop_fc's 67 MB gradient, the query
+    # encoder) replays, the front's afterwards.  One bucket per part: xGMI rings are per-link bound, so few large messages.
+    # Eager mode overlaps 32 MB bucket all-reduces with backward from post-accumulate-grad hooks.
     deferred = args.graph and world > 1
-    reducer = ddist.GradReducer(params, world_size=world, overlap=not deferred, bucket_bytes=(1 << 30) if deferred else (32 << 20))
+    if deferred:
+        reducer = ddist.GradReducer(params, world_size=world, overlap=False, bucket_bytes=1 << 30,
+                                    groups=[model.trunk_parameters(), model.front_parameters()])
+    else:
+        reducer = ddist.GradReducer(params, world_size=world, overlap=True)
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-3)                      # main.py:140
     else:
@@ -140,24 +144,20 @@ def main():
                 run = GraphedStep(step, warmup=max(args.warmup, 2)).capture()
                 mode = "hipGraph replay of the full step"
             else:
-                # forward+backward replay as one hipGraph per rank; RCCL all-reduce + fused optimizer stay outside it
-                def fwd_bwd():
-                    reducer.zero()
-                    _, losses = model(*batch)
-                    loss_of(losses).backward()
-                    reducer.collect()                 # foreign gradients -> flat buckets: device copies, part of the graph
-                    return losses
-                core = GraphedStep(fwd_bwd, warmup=0)
+                # forward+backward replay as two hipGraphs per rank; RCCL all-reduces + fused optimizer stay outside them
+                from drn_amd.graph import TwoPhaseStep
+                core = TwoPhaseStep(model, batch[:5], loss_of, reducer,
+                                    between=lambda: reducer.reduce(reducer.group_buckets[0]))
 
                 def run():
-                    losses = core()
                     reducer.rearm()                   # hooks only run eagerly / at capture time
-                    opt_step()
+                    losses = core()
+                    opt_step()                        # reduces the front's bucket, waits for both, clip + Adam
                     return losses
                 for _ in range(max(args.warmup, 2)):
                     run()
                 core.capture()
-                mode = "hipGraph replay of forward+backward; RCCL all-reduce + optimizer eager"
+                mode = "hipGraph replay of forward+backward in two phases; trunk all-reduce overlaps the front's backward; optimizer eager"
             run()
         except Exception as e:                                          # keep the eager path measurable
             print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).split(chr(10))[0]), file=sys.stderr)

@@ -46,9 +46,11 @@ class GradReducer(object):
     in 32 MB buckets = 5 collectives per step.
     """
 
-    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True, steal=True):
+    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True, steal=True, groups=None):
         """overlap=False defers every collective to finish() (required when backward is replayed from a hipGraph:
-        hooks only run at capture time and collectives must stay outside the captured region)."""
+        hooks only run at capture time and collectives must stay outside the captured region).
+        groups: optional list of parameter lists, each bucketed on its own and in the given order (`group_buckets[i]`
+        lists group i's buckets): lets a caller reduce one part of the model while another part is still in backward."""
         self.group = group
         self.overlap = overlap
         # steal=True: p.grad is None at the start of backward; backward kernels that know the sink write straight into
@@ -57,16 +59,22 @@ class GradReducer(object):
         self._dirty = {}
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
-        self.buckets, self._of = [], {}
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):                       # roughly the order backward produces gradients
-            cur.append(p)
-            cur_bytes += p.numel() * p.element_size()
-            if cur_bytes >= bucket_bytes:
+        self.buckets, self._of, self.group_buckets = [], {}, []
+        wanted = set(id(p) for p in self.params)
+        plan = [self.params] if groups is None else [[p for p in g if id(p) in wanted] for g in groups]
+        assert sum(len(g) for g in plan) == len(self.params), "groups must partition the trainable parameters"
+        for part in plan:
+            first = len(self.buckets)
+            cur, cur_bytes = [], 0
+            for p in reversed(part):                          # roughly the order backward produces gradients
+                cur.append(p)
+                cur_bytes += p.numel() * p.element_size()
+                if cur_bytes >= bucket_bytes:
+                    self._make_bucket(cur)
+                    cur, cur_bytes = [], 0
+            if cur:
                 self._make_bucket(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            self._make_bucket(cur)
+            self.group_buckets.append(self.buckets[first:])
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     @staticmethod
@@ -123,12 +131,12 @@ class GradReducer(object):
                     if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                         p.grad = v.view_as(p)
 
-    def collect(self):
-        """After backward: make every flat bucket hold this step's gradients -- slices of parameters that got no gradient
+    def collect(self, buckets=None):
+        """After backward (all buckets, or the given ones): make every flat bucket hold this step's gradients -- slices of parameters that got no gradient
         read as zero, gradients produced outside the sinks (stock autograd ops, hand-set) are copied in with one
         multi-tensor launch per bucket.  Device work only, so it can sit inside a captured hipGraph: call it at the end
         of the captured forward+backward and `reduce()` after the replay."""
-        for b in self.buckets:
+        for b in (self.buckets if buckets is None else buckets):
             if not self.steal:
                 continue
             dsts, srcs = [], []

@@ -326,7 +326,7 @@ def _grad_nlc(g, like_shape, dtype):
 
 
 class _CastActFn(torch.autograd.Function):
-    """Activation dtype change between two stages that run in different compute dtypes (see mainModel.forward_core: an
+    """Activation dtype change between two stages that run in different compute dtypes (see mainModel.forward_front: an
     unaligned feature dimension keeps the input stage and conv0 on the exact-f32 kernels inside a bf16 model)."""
 
     @staticmethod

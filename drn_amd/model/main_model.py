@@ -52,10 +52,24 @@ class mainModel(nn.Module):
         query_features = self.query_encoder(query_tokens, query_length)
         return [DF.linear(query_features[i], getattr(self, "qInput%d" % i)) for i in range(len(query_features))]
 
-    def forward_core(self, gates, props_features, props_start_end, gt_start_end):
-        """Everything downstream of the gates: the HIP path proper (no host-side data dependence, hipGraph-capturable)."""
+    # The step splits at the tensors that leave the "front" (query encoder, gate projections, prop_fc, position
+    # embedding): g0 and the gates of levels 1.. .  Backward runs the trunk (backbone, FPN, heads, losses) first, so its
+    # gradients can be all-reduced while the front's backward -- which holds the largest gradient, prop_fc.weight -- is
+    # still running (drn_amd.graph.TwoPhaseStep).
+    def front_parameters(self):
+        mods = [self.query_encoder, self.prop_fc, self.position_transform] + \
+               [getattr(self, "qInput%d" % t) for t in range(len(self.backbone_net.blocks))]
+        return [p for m in mods for p in m.parameters()]
+
+    def trunk_parameters(self):
+        front = set(id(p) for p in self.front_parameters())
+        return [p for p in self.parameters() if id(p) not in front]
+
+    def forward_front(self, query_tokens, query_length, props_features, props_start_end):
+        """-> (g0 (B, T, D+P) channels-last, gates): query encoder, gate projections, prop_fc + gating + position embedding."""
         if not props_features.is_cuda:
             raise DrnError("drn_amd.mainModel runs on an MI355X only (inputs on %s); no CPU fallback" % props_features.device)
+        gates = self.encode_query(query_tokens, query_length)
         dt = self.compute_dtype
         # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
         duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
@@ -64,6 +78,10 @@ class mainModel(nn.Module):
         # ActivityNet C3D-PCA convention) keeps the two layers that see D -- prop_fc and conv0 -- on the exact-f32 kernels
         front_dt = torch.float32 if (dt == torch.bfloat16 and props_features.shape[2] % 8) else dt
         g0 = DF.input_stage(props_features, position_feat, self.prop_fc, gates[0], self.position_transform, front_dt)
+        return g0, gates
+
+    def forward_trunk(self, g0, gates, gt_start_end):
+        """Backbone (gates[1:] only: level 0 is already applied), FPN, heads, losses / post-processor."""
         backbone_feats = self.backbone_net.forward_from_stage(g0, gates)
         feats = self.fpn.forward_nlc(backbone_feats)
         head = self.fcos.head
@@ -85,5 +103,5 @@ class mainModel(nn.Module):
 
     def forward(self, query_tokens, query_length, props_features, props_start_end, gt_start_end, props_num=None,
                 num_frames=None):
-        gates = self.encode_query(query_tokens, query_length)
-        return self.forward_core(gates, props_features, props_start_end, gt_start_end)
+        g0, gates = self.forward_front(query_tokens, query_length, props_features, props_start_end)
+        return self.forward_trunk(g0, gates, gt_start_end)

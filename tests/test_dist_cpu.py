@@ -75,3 +75,59 @@ def test_grad_reducer_single_process_is_identity():
     red.finish()
     assert torch.allclose(net.weight.grad, torch.full((3, 4), 2.0))
     assert net.weight.grad.data_ptr() == red.buckets[0].flat.data_ptr() or net.bias.grad.data_ptr() == red.buckets[0].flat.data_ptr()
+
+
+def _worker_two_phase(rank, world, port, q):
+    """Deferred mode as bench.py N>1 uses it: bucket groups [trunk, front], backward in two parts with the trunk's
+    all-reduce launched (reduce(group)) while the front's backward still runs, then finish()."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from drn_amd.dist import GradReducer, init_from_env
+    init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    front = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU())
+    trunk = torch.nn.Sequential(torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+    params = list(front.parameters()) + list(trunk.parameters())
+    red = GradReducer(params, world_size=world, overlap=False, bucket_bytes=1 << 30,
+                      groups=[list(trunk.parameters()), list(front.parameters())])
+    assert [len(g) for g in red.group_buckets] == [1, 1]
+    for it in range(2):
+        g = torch.Generator().manual_seed(100 * it + rank)
+        x = torch.randn(5, 16, generator=g)
+        red.zero()
+        red.rearm()
+        h = front(x)
+        hd = h.detach().requires_grad_()
+        trunk(hd).pow(2).sum().backward()
+        red.collect(red.group_buckets[0])
+        red.reduce(red.group_buckets[0])                  # in flight while the front's backward runs
+        assert red.group_buckets[0][0].launched and not red.group_buckets[1][0].launched
+        torch.autograd.backward([h], [hd.grad])
+        red.finish()
+        got = [p.grad.clone() for p in params]
+        acc = None
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 * it + r)
+            x = torch.randn(5, 16, generator=g)
+            for p in params:
+                p.grad = None
+            trunk(front(x)).pow(2).sum().backward()
+            gs = [p.grad.clone() for p in params]
+            acc = gs if acc is None else [a + b for a, b in zip(acc, gs)]
+        for a, b in zip(acc, got):
+            assert torch.allclose(a / world, b, atol=1e-6), (it, float((a / world - b).abs().max()))
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_groups_two_phase_world2_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_two_phase, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]

@@ -107,3 +107,77 @@ def test_deferred_mode_graph_carries_foreign_gradients():
     assert checked > 40
     for k in ("fcos.head.scales.0.scale", "fcos.head.cls_tower.0.weight", "fcos.head.bbox_tower.1.weight"):
         assert k in want and float(want[k].abs().max()) > 0
+
+
+@pytest.mark.parametrize("stage", [1, 3])
+def test_two_phase_step_equals_single_backward(stage):
+    """drn_amd.graph.TwoPhaseStep (trunk backward, then front backward, two hipGraphs sharing a pool, bucket groups
+    [trunk, front]) must leave exactly the gradients of one plain backward in the flat buckets -- eagerly and on replay
+    with refreshed inputs."""
+    from drn_amd.dist import GradReducer
+    from drn_amd.graph import TwoPhaseStep
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    dev = "cuda:0"
+
+    def build():
+        m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", 64, stage)), compute_dtype=torch.float32)
+        m.load_state_dict(seeded_state_dict(m, 0))
+        m = m.to(dev).train()
+        if stage == 1:
+            for n, p in m.named_parameters():
+                if "iou_scores" in n or "mix_fc" in n:
+                    p.requires_grad_(False)
+        return m
+
+    loss_of = lambda ls: sum(ls.values())
+    bA = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=1)]
+    other = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=2)]
+    bB = list(bA)
+    bB[2], bB[4] = other[2], other[4]
+    mr = build()
+    _, ls = mr(*bB)
+    loss_of(ls).backward()
+    want = {k: p.grad.clone() for k, p in mr.named_parameters() if p.grad is not None}
+
+    m = build()
+    assert set(map(id, m.trunk_parameters())) | set(map(id, m.front_parameters())) == set(map(id, m.parameters()))
+    params = [p for p in m.parameters() if p.requires_grad]
+    red = GradReducer(params, world_size=1, overlap=False, bucket_bytes=1 << 30,
+                      groups=[m.trunk_parameters(), m.front_parameters()])
+    assert len(red.group_buckets) == 2 and len(red.buckets) == 2
+    static = [b.clone() for b in bA[:5]]
+    calls = []
+    two = TwoPhaseStep(m, static, loss_of, red, between=lambda: (calls.append(1), red.reduce(red.group_buckets[0])))
+
+    def run():
+        red.rearm()
+        out = two()
+        red.finish()
+        return out
+
+    def check(tag):
+        torch.cuda.synchronize()
+        n = 0
+        for k, p in m.named_parameters():
+            if k in want:
+                ref = want[k]
+                tol = 1e-4 * max(float(ref.abs().max()), 1e-6) + 1e-7
+                assert float((p.grad - ref).abs().max()) <= tol, (tag, k, float((p.grad - ref).abs().max()), tol)
+                n += 1
+        assert n == len(want)
+
+    for s, b in zip(static, bB[:5]):
+        s.copy_(b)
+    run()                                     # eager two-phase on batch B
+    check("eager")
+    for s, b in zip(static, bA[:5]):
+        s.copy_(b)
+    run()
+    two.capture()                             # captured on batch A ...
+    run()
+    for s, b in zip(static, bB[:5]):
+        s.copy_(b)
+    l = run()                                 # ... replayed on batch B
+    check("replay")
+    assert len(calls) >= 4 and torch.isfinite(l["loss_cls"]).all()
