@@ -97,14 +97,15 @@ def main():
     model = build(mainModel, cfg, dev, compute_dtype=cdt)
     params = stage_params(model, stage)
     model.train()
-    # N>1 with hipGraph: forward+backward replay as TWO graphs split where backward leaves the trunk (drn_amd.graph.
-    # TwoPhaseStep); the trunk's gradients are all-reduced while the front's backward (prop_fc's 67 MB gradient, the query
-    # encoder) replays, the front's afterwards.  One bucket per part: xGMI rings are per-link bound, so few large messages.
+    # N>1 with hipGraph: forward+backward replay as THREE graphs split where backward leaves one part of the model
+    # (drn_amd.graph.TwoPhaseStep): the trunk's gradients are all-reduced while the input stage's backward replays, prop_fc's
+    # 67 MB while the query side's backward replays, the query side's 26 MB afterwards.  One bucket per part: xGMI rings are
+    # per-link bound, so few large messages.
     # Eager mode overlaps 32 MB bucket all-reduces with backward from post-accumulate-grad hooks.
     deferred = args.graph and world > 1
     if deferred:
         reducer = ddist.GradReducer(params, world_size=world, overlap=False, bucket_bytes=1 << 30,
-                                    groups=[model.trunk_parameters(), model.front_parameters()])
+                                    groups=[model.trunk_parameters(), model.input_parameters(), model.query_parameters()])
     else:
         reducer = ddist.GradReducer(params, world_size=world, overlap=True)
     if args.torch_adam:
@@ -144,20 +145,20 @@ def main():
                 run = GraphedStep(step, warmup=max(args.warmup, 2)).capture()
                 mode = "hipGraph replay of the full step"
             else:
-                # forward+backward replay as two hipGraphs per rank; RCCL all-reduces + fused optimizer stay outside them
+                # forward+backward replay as three hipGraphs per rank; RCCL all-reduces + fused optimizer stay outside them
                 from drn_amd.graph import TwoPhaseStep
                 core = TwoPhaseStep(model, batch[:5], loss_of, reducer,
-                                    between=lambda: reducer.reduce(reducer.group_buckets[0]))
+                                    between=lambda k: reducer.reduce(reducer.group_buckets[k]))
 
                 def run():
                     reducer.rearm()                   # hooks only run eagerly / at capture time
                     losses = core()
-                    opt_step()                        # reduces the front's bucket, waits for both, clip + Adam
+                    opt_step()                        # reduces the query side's bucket, waits for all, clip + Adam
                     return losses
                 for _ in range(max(args.warmup, 2)):
                     run()
                 core.capture()
-                mode = "hipGraph replay of forward+backward in two phases; trunk all-reduce overlaps the front's backward; optimizer eager"
+                mode = "hipGraph replay of forward+backward in three phases; trunk / prop_fc all-reduces overlap the next phase; optimizer eager"
             run()
         except Exception as e:                                          # keep the eager path measurable
             print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).split(chr(10))[0]), file=sys.stderr)

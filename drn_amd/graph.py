@@ -47,46 +47,54 @@ class GraphedStep(object):
 
 
 class TwoPhaseStep(object):
-    """Forward + backward of drn_amd.model.mainModel as TWO hipGraphs that share one memory pool, split where backward
-    leaves the trunk: phase 1 = front forward, trunk forward, trunk backward (stops at g0 and the gates of levels 1..);
-    phase 2 = backward of the front (prop_fc, position embedding, gate projections, query encoder).  Between the two
-    replays the caller launches the all-reduce of the trunk's gradient buckets, which then overlaps phase 2 -- the
-    multi-GPU counterpart of overlapping collectives with backward when backward is a replayed graph.
+    """Forward + backward of drn_amd.model.mainModel as THREE hipGraphs that share one memory pool, split where backward
+    leaves one part of the model for the next (the class keeps its first name):
+      phase 1  forward of everything + backward of the trunk (backbone, FPN, heads, losses); stops at g0 and the gates;
+      phase 2  backward of the input stage (prop_fc, position embedding): its 67 MB weight gradient is the largest;
+      phase 3  backward of the gate projections and the query encoder.
+    After phase k the caller's `between(k)` launches the all-reduce of that part's gradient bucket, which then overlaps
+    the next phase's replay -- the multi-GPU counterpart of overlapping collectives with backward when backward is a
+    replayed graph.  Only the query side's bucket (26 MB) is left exposed.
 
     model: mainModel; batch: its 5 device-resident arguments; loss_of: loss dict -> scalar; reducer: GradReducer built
-    with groups=[model.trunk_parameters(), model.front_parameters()]; between(): called after phase 1 (launch
-    collectives there)."""
+    with groups=[model.trunk_parameters(), model.input_parameters(), model.query_parameters()]."""
+
+    NPHASES = 3
 
     def __init__(self, model, batch, loss_of, reducer, between=None):
         self.model, self.batch, self.loss_of, self.reducer, self.between = model, batch, loss_of, reducer, between
         self.stream = torch.cuda.Stream()
-        self.g1 = self.g2 = None
+        self.graphs = None
         self.out = None
         self._carry = None
 
-    def _phase1(self):
-        m, (tok, qlen, feats, pse, gt) = self.model, self.batch
-        self.reducer.zero()
-        g0, gates = m.forward_front(tok, qlen, feats, pse)
-        g0d = g0.detach().requires_grad_()
-        gd = [gates[0].detach()] + [g.detach().requires_grad_() for g in gates[1:]]
-        _, losses = m.forward_trunk(g0d, gd, gt)
-        self.loss_of(losses).backward()
-        self.reducer.collect(self.reducer.group_buckets[0])
-        self._carry = ([g0] + list(gates[1:]), [g0d.grad] + [g.grad for g in gd[1:]])
-        return losses
-
-    def _phase2(self):
-        outs, grads = self._carry
-        torch.autograd.backward(outs, grads)
-        self.reducer.collect(self.reducer.group_buckets[1])
-        self._carry = None
+    def _phase(self, k):
+        m, red = self.model, self.reducer
+        if k == 0:
+            tok, qlen, feats, pse, gt = self.batch
+            red.zero()
+            gates = m.encode_query(tok, qlen)
+            gd = [g.detach().requires_grad_() for g in gates]
+            g0, _ = m.forward_front(tok, qlen, feats, pse, gates=gd)
+            g0d = g0.detach().requires_grad_()
+            _, losses = m.forward_trunk(g0d, gd, gt)
+            self.loss_of(losses).backward()                       # trunk parameters, g0d.grad, gd[1:].grad
+            self._carry = (g0, g0d, gates, gd)
+            self.out = losses
+        elif k == 1:
+            g0, g0d, gates, gd = self._carry
+            torch.autograd.backward([g0], [g0d.grad])             # prop_fc, position_transform, gd[0].grad
+        else:
+            g0, g0d, gates, gd = self._carry
+            torch.autograd.backward(list(gates), [g.grad for g in gd])     # gate projections, query encoder
+            self._carry = None
+        red.collect(red.group_buckets[k])
 
     def _eager(self):
-        self.out = self._phase1()
-        if self.between is not None:
-            self.between()
-        self._phase2()
+        for k in range(self.NPHASES):
+            self._phase(k)
+            if self.between is not None and k + 1 < self.NPHASES:
+                self.between(k)
 
     def warm(self, n):
         s = self.stream
@@ -99,19 +107,21 @@ class TwoPhaseStep(object):
         return self
 
     def capture(self):
-        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1, stream=self.stream):
-            self.out = self._phase1()
-        with torch.cuda.graph(self.g2, stream=self.stream, pool=self.g1.pool()):
-            self._phase2()
+        self.graphs = []
+        for k in range(self.NPHASES):
+            g = torch.cuda.CUDAGraph()
+            kw = {} if k == 0 else {"pool": self.graphs[0].pool()}
+            with torch.cuda.graph(g, stream=self.stream, **kw):
+                self._phase(k)
+            self.graphs.append(g)
         return self
 
     def __call__(self):
-        if self.g1 is None:
+        if self.graphs is None:
             self.warm(1)
             return self.out
-        self.g1.replay()
-        if self.between is not None:
-            self.between()
-        self.g2.replay()
+        for k, g in enumerate(self.graphs):
+            g.replay()
+            if self.between is not None and k + 1 < self.NPHASES:
+                self.between(k)
         return self.out

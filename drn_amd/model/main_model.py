@@ -56,20 +56,29 @@ class mainModel(nn.Module):
     # embedding): g0 and the gates of levels 1.. .  Backward runs the trunk (backbone, FPN, heads, losses) first, so its
     # gradients can be all-reduced while the front's backward -- which holds the largest gradient, prop_fc.weight -- is
     # still running (drn_amd.graph.TwoPhaseStep).
-    def front_parameters(self):
-        mods = [self.query_encoder, self.prop_fc, self.position_transform] + \
-               [getattr(self, "qInput%d" % t) for t in range(len(self.backbone_net.blocks))]
+    def query_parameters(self):
+        """Query encoder + the per-level gate projections (main_model.py:36-40,47-50)."""
+        mods = [self.query_encoder] + [getattr(self, "qInput%d" % t) for t in range(len(self.backbone_net.blocks))]
         return [p for m in mods for p in m.parameters()]
+
+    def input_parameters(self):
+        """prop_fc + position_transform: the input stage (main_model.py:33-34,51-59)."""
+        return list(self.prop_fc.parameters()) + list(self.position_transform.parameters())
+
+    def front_parameters(self):
+        return self.query_parameters() + self.input_parameters()
 
     def trunk_parameters(self):
         front = set(id(p) for p in self.front_parameters())
         return [p for p in self.parameters() if id(p) not in front]
 
-    def forward_front(self, query_tokens, query_length, props_features, props_start_end):
-        """-> (g0 (B, T, D+P) channels-last, gates): query encoder, gate projections, prop_fc + gating + position embedding."""
+    def forward_front(self, query_tokens, query_length, props_features, props_start_end, gates=None):
+        """-> (g0 (B, T, D+P) channels-last, gates): query encoder, gate projections, prop_fc + gating + position embedding.
+        `gates`: reuse already computed gate tensors (e.g. detached ones) instead of running the query encoder."""
         if not props_features.is_cuda:
             raise DrnError("drn_amd.mainModel runs on an MI355X only (inputs on %s); no CPU fallback" % props_features.device)
-        gates = self.encode_query(query_tokens, query_length)
+        if gates is None:
+            gates = self.encode_query(query_tokens, query_length)
         dt = self.compute_dtype
         # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
         duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)

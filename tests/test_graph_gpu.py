@@ -111,9 +111,9 @@ def test_deferred_mode_graph_carries_foreign_gradients():
 
 @pytest.mark.parametrize("stage", [1, 3])
 def test_two_phase_step_equals_single_backward(stage):
-    """drn_amd.graph.TwoPhaseStep (trunk backward, then front backward, two hipGraphs sharing a pool, bucket groups
-    [trunk, front]) must leave exactly the gradients of one plain backward in the flat buckets -- eagerly and on replay
-    with refreshed inputs."""
+    """drn_amd.graph.TwoPhaseStep (trunk backward, input-stage backward, query-side backward: three hipGraphs sharing a
+    pool, bucket groups [trunk, input, query]) must leave exactly the gradients of one plain backward in the flat buckets
+    -- eagerly and on replay with refreshed inputs."""
     from drn_amd.dist import GradReducer
     from drn_amd.graph import TwoPhaseStep
     from drn_amd.model import mainModel
@@ -143,12 +143,13 @@ def test_two_phase_step_equals_single_backward(stage):
     m = build()
     assert set(map(id, m.trunk_parameters())) | set(map(id, m.front_parameters())) == set(map(id, m.parameters()))
     params = [p for p in m.parameters() if p.requires_grad]
+    assert set(map(id, m.input_parameters())) | set(map(id, m.query_parameters())) == set(map(id, m.front_parameters()))
     red = GradReducer(params, world_size=1, overlap=False, bucket_bytes=1 << 30,
-                      groups=[m.trunk_parameters(), m.front_parameters()])
-    assert len(red.group_buckets) == 2 and len(red.buckets) == 2
+                      groups=[m.trunk_parameters(), m.input_parameters(), m.query_parameters()])
+    assert len(red.group_buckets) == 3 and len(red.buckets) == 3
     static = [b.clone() for b in bA[:5]]
     calls = []
-    two = TwoPhaseStep(m, static, loss_of, red, between=lambda: (calls.append(1), red.reduce(red.group_buckets[0])))
+    two = TwoPhaseStep(m, static, loss_of, red, between=lambda k: (calls.append(k), red.reduce(red.group_buckets[k])))
 
     def run():
         red.rearm()
@@ -180,4 +181,4 @@ def test_two_phase_step_equals_single_backward(stage):
         s.copy_(b)
     l = run()                                 # ... replayed on batch B
     check("replay")
-    assert len(calls) >= 4 and torch.isfinite(l["loss_cls"]).all()
+    assert calls[-2:] == [0, 1] and len(calls) >= 8 and torch.isfinite(l["loss_cls"]).all()
