@@ -52,6 +52,10 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Ordering point for LDS traffic that stays inside ONE wavefront (a per-wave staging patch): the LDS unit executes a
+// wave's DS instructions in issue order, so only the compiler must be kept from reordering -- no workgroup barrier.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   typedef bf16x8 frag;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCHF) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
-      __syncthreads();
+      wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
 #pragma unroll
       for (int it = 0; it < 8; ++it) {          // 16 lanes per 64-float row, 4 rows per instruction
         const int rl = it * 4 + (l >> 4), cv = l & 15;
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
           }
         }
       }
-      __syncthreads();
+      wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
     }
     return;
   }
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
               DT<T>::st((T*)(wbuf + rl * PITCH) + ni * 16 + (l & 15), v);
             }
           }
-        __syncthreads();
+        wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
           const int rl = it * RPI + l / LPR, cv = l % LPR;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
             }
           }
         }
-        __syncthreads();
+        wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
       }
     }
     return;

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCH) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // per-wave patch: in-order LDS, no workgroup barrier needed
 #pragma unroll
       for (int it = 0; it < 8; ++it) {          // 16 lanes per 64-float row, 4 rows per instruction
         const int rl = it * 4 + (l >> 4), cv = l & 15;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
           *(f32x4*)(obase + ((long)n * KW + tap * P.Cin + c)) = v;
         }
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // per-wave patch: in-order LDS, no workgroup barrier needed
     }
     return;
   }
