@@ -14,6 +14,7 @@
 // The row range (all groups concatenated) is split over gridDim.z; partial tiles go to an fp32
 // workspace and are summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/drn_hip.h"
 
@@ -290,6 +291,321 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
     }
 }
 
+// ---- fused 3-tap weight gradient (k = 3, stride 1, pad 1, bf16) ---------------------------------------------------------
+// The per-tap kernel above re-reads dY for every tap and X three times (each tap is the same rows shifted by one).  Here one
+// workgroup owns a 128 (n) x 128 (c) tile for ALL THREE taps: per 64-row block it stages dY once (16 KB) and X once plus one
+// halo row on each side (16.5 KB) and feeds 3 x the MFMAs -- a third of the staged bytes per MAC.
+// Sequence ends need no masks: the reduction runs over a PADDED row space with Lout+1 rows per sequence whose extra row is
+// zero in both operands (staged from the zero page), so the +-1 row shifts of taps 0 / 2 meet a zero row at either end of
+// a sequence and the padding row itself contributes nothing.  p = seq*(Lout+1) + t  <->  source row m = p - seq.
+// 8 waves as 2 (n) x 4 (c): 64 x 32 per wave and tap = 4 x 2 MFMA tiles x 3 taps = 96 accumulator registers.
+// LDS per stage: dY [2 halves][64 rows][128 B] | X [2 halves][64 rows][128 B] | X halo [2 rows][2 halves][128 B] (row -1, 64).
+// A half is 64 columns = four 32-byte column-block pieces per row; piece cb of row r sits at position cb ^ ((r>>1)&3), so
+// the 8 rows x 4 eight-byte pieces a transposing read touches per 32-lane group fall on 64 distinct banks.  Staging:
+// one global_load_lds covers 8 rows x 128 contiguous bytes (whole cache lines; the swizzle permutes the SOURCE chunks of a
+// row among its 8 lanes).
+// What bounds it (ablation on the conv0 shape, us per 64-row block and workgroup): MFMAs + fragment reads alone 0.89,
+// the block's 33 KB of global_load_lds alone 0.71, together 1.6 -- the LDS-DMA issue (~46 GB/s per CU) does not overlap
+// the matrix pipe when all eight waves enter it together; ring depth, register double-buffering of the fragments and
+// cheaper address arithmetic each changed nothing.  Spreading the loads between the MFMA groups is worth 5 %.
+__device__ __forceinline__ bf16x8 tr_frag(const char* lo_addr, const char* hi_addr) {
+  typedef __attribute__((address_space(3))) s16x4* lp;
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)lo_addr);
+  u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)hi_addr);
+  return u.v;
+}
+
+template <int NSTG>
+__global__ __launch_bounds__(512, 2) void conv_wgrad3_tn_kernel(const WgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int R = 64, MI = 4, NI = 2;
+  constexpr int IMG = 16384, HALO_B = 512, STAGE_B = 2 * IMG + HALO_B;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  int split = blockIdx.z;
+  int blk_lo = split * P.blks_per_split;
+  int blk_hi = min(blk_lo + P.blks_per_split, P.total_blks);
+  float* out_ptr = P.out;
+  int direct = P.direct;
+  if (P.multi) {
+    int pg = 0;
+#pragma unroll
+    for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+      if (i < P.ngroups && (int)blockIdx.z >= P.z_start[i]) pg = i;
+    split = blockIdx.z - P.z_start[pg];
+    const int blk_end = pg + 1 < P.ngroups ? P.g[pg + 1].blk_start : P.total_blks;
+    blk_lo = P.g[pg].blk_start + split * P.bps[pg];
+    blk_hi = min(blk_lo + P.bps[pg], blk_end);
+    out_ptr = P.gout[pg];
+    direct = P.gdirect[pg];
+  }
+  const T* zero = (const T*)g_zero_page;
+
+  // staging map.  Main pieces: wave w owns rows w*8 + (l>>3) of both images, instruction j = column half j; lane chunk
+  // position pc = l&7 inside the 128-byte row holds source column block (pc>>1) ^ ((row>>1)&3), 16-byte half pc&1.
+  // Halo: lanes 0..31 of wave 0: halo row l>>4 (row -1 / row 64), half (l>>3)&1, chunk l&7, unswizzled.
+  const int srow = w * 8 + (l >> 3);
+  const int scol = (((l & 7) >> 1) ^ ((srow >> 1) & 3)) * 16 + (l & 1) * 8;     // inside a 64-column half
+  long y_off[2], x_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    y_off[j] = n0 + j * 64 + scol < P.N ? n0 + j * 64 + scol : -1;
+    x_off[j] = c0 + j * 64 + scol < P.Cin ? c0 + j * 64 + scol : -1;
+  }
+  const bool is_halo = (w == 0) & (l < 32);
+  const int hcol = ((l >> 3) & 1) * 64 + (l & 7) * 8;
+  const long xh_off = c0 + hcol < P.Cin ? c0 + hcol : -1;
+  const int rowoff[2] = {srow, (l >> 4) ? R : -1};          // [1]: the halo row of this lane
+  int s_blk = blk_lo, s_g = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.ngroups && blk_lo >= P.g[i].blk_start) s_g = i;
+  int s_seq[2], s_t[2];             // padded coordinates of the thread's rows in the current group (floor division: p = -1 -> (-1, Lout))
+  auto locate = [&]() {
+    const WgradGroup& G = P.g[s_g];
+    const int Lp = G.Lout + 1;
+    const int pbase = (s_blk - G.blk_start) * R;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = pbase + rowoff[j] + Lp;       // >= 0
+      const int q = p / Lp;
+      s_seq[j] = q - 1;
+      s_t[j] = p - q * Lp;
+    }
+  };
+  locate();
+
+  // Source row m = seq*Lout + t and element offsets m*ld fit 32 bits (checked on the host), so a row address is one 24-bit
+  // multiply-add on top of a scalar base; rows outside the sequence / group read the zero page.
+  auto row_ptr = [&](const T* base, int m, int ld, long coff, bool ok) -> const T* {
+    const unsigned off = __umul24((unsigned)m, (unsigned)ld) + (unsigned)coff;
+    return ok ? base + off : zero;
+  };
+  // part 0..3: one global_load_lds each (the caller spreads them between the MFMA groups); part 3 also carries the halo
+  // rows; part 4 advances to the next block.
+  auto stage_part = [&](int buf, int part) {
+    char* Ys = smem + buf * STAGE_B;
+    char* Xs = Ys + IMG;
+    char* Hs = Xs + IMG;
+    const bool live = s_blk < blk_hi;
+    const WgradGroup& G = P.g[s_g];
+    const T* __restrict__ Yg = (const T*)G.dY;
+    const T* __restrict__ Xg = (const T*)G.X;
+    const int L = G.Lout, nseq = G.M / G.Lout;
+    const bool ok = live & ((unsigned)s_seq[0] < (unsigned)nseq) & (s_t[0] < L);
+    const int m = s_seq[0] * L + s_t[0];
+    if (part == 0) glds16(row_ptr(Yg, m, G.ldy, y_off[0], ok & (y_off[0] >= 0)), Ys + w * 1024);
+    if (part == 1) glds16(row_ptr(Xg, m, G.ldx, x_off[0], ok & (x_off[0] >= 0)), Xs + w * 1024);
+    if (part == 2) glds16(row_ptr(Yg, m, G.ldy, y_off[1], ok & (y_off[1] >= 0)), Ys + 8192 + w * 1024);
+    if (part == 3) {
+      glds16(row_ptr(Xg, m, G.ldx, x_off[1], ok & (x_off[1] >= 0)), Xs + 8192 + w * 1024);
+      if (is_halo) {
+        const bool okh = live & ((unsigned)s_seq[1] < (unsigned)nseq) & (s_t[1] < L) & (xh_off >= 0);
+        glds16(row_ptr(Xg, s_seq[1] * L + s_t[1], G.ldx, xh_off, okh), Hs);
+      }
+    }
+    if (part != 4) return;
+    ++s_blk;
+    if (s_g + 1 < P.ngroups && s_blk >= P.g[s_g + 1].blk_start) {
+      ++s_g;
+      locate();
+    } else {
+      const int Lp = L + 1;
+      if (Lp > R) {                 // at most one sequence end per step
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          s_t[j] += R;
+          const bool wrap = s_t[j] >= Lp;
+          s_t[j] -= wrap ? Lp : 0;
+          s_seq[j] += wrap ? 1 : 0;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          s_t[j] += R;
+          while (s_t[j] >= Lp) {
+            s_t[j] -= Lp;
+            ++s_seq[j];
+          }
+        }
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int part = 0; part < 5; ++part) stage_part(buf, part);
+  };
+
+  f32x4 acc[3][MI][NI];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[t][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wr = w >> 2, wc = w & 3;
+
+  // fragment addresses (bytes from the stage base).  Lane (g = l>>4, i = l&15) of a transposing read supplies the 8-byte
+  // piece (i&3) of row ks*32 + [16 +] fr, fr = g*4 + (i>>2), of one 16-column block; a tap shifts the row by -1 / 0 / +1,
+  // and the two rows that leave the block (row -1: ks 0 "lo" part, row 64: ks 1 "hi" part) come from the halo image.
+  // ks / hi add multiples of 16 rows, which leave the swizzle term ((row>>1)&3) unchanged -> immediates.
+  const int fr = (l >> 4) * 4 + ((l & 15) >> 2);            // 0..15
+  const int fb = (l & 3) * 8;
+  int ya[MI], xa[3][NI], x_first[NI], x_last[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) ya[mi] = wr * 8192 + fr * 128 + ((mi ^ ((fr >> 1) & 3)) * 32) + fb;   // n-blocks wr*4 + mi
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int half = wc >> 1, cb = (wc & 1) * 2 + ni;       // c-block wc*2 + ni
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int rr = fr + t - 1;
+      xa[t][ni] = IMG + half * 8192 + rr * 128 + ((cb ^ ((rr >> 1) & 3)) * 32) + fb;
+    }
+    x_first[ni] = fr == 0 ? 2 * IMG + half * 128 + cb * 32 + fb : xa[0][ni];                       // tap 0 / ks 0 / lo
+    x_last[ni] = fr == 15 ? 2 * IMG + 256 + half * 128 + cb * 32 + fb : xa[2][ni] + 4096 + 2048;   // tap 2 / ks 1 / hi
+  }
+
+  struct Frags {
+    bf16x8 a[MI], b[3][NI];
+  };
+  auto load_frags = [&](Frags& F, const char* S, auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const char* q = S + ya[mi] + ks * 4096;
+      F.a[mi] = tr_frag(q, q + 2048);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const char* q0 = S + xa[0][ni] + ks * 4096;
+      const char* q1 = S + xa[1][ni] + ks * 4096;
+      const char* q2 = S + xa[2][ni] + ks * 4096;
+      F.b[1][ni] = tr_frag(q1, q1 + 2048);
+      F.b[0][ni] = tr_frag(ks == 0 ? S + x_first[ni] : q0, q0 + 2048);
+      F.b[2][ni] = tr_frag(q2, ks == 1 ? S + x_last[ni] : q2 + 2048);
+    }
+  };
+  auto mfma_frags = [&](const Frags& F, int mi0) {      // rows [mi0, mi0 + 2) of the 4 x 2 x 3 grid: 12 MFMAs
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[t][mi0 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.a[mi0 + mi], F.b[t][ni], acc[t][mi0 + mi][ni], 0, 0, 0);
+  };
+  typedef std::integral_constant<int, 0> K0;
+  typedef std::integral_constant<int, 1> K1;
+
+  // NSTG-deep ring + register double buffering of the fragments.  Iteration b: blocks b and b+1 have landed (NSTG-3 younger
+  // ones stay in flight: 4 loads per block and wave, wave 0 one more for the halo rows), one barrier, refill the slot block
+  // b-1 used; the fragments of (b, k-step 1) are read while the MFMAs of (b, k-step 0) run, and those of (b+1, k-step 0)
+  // while the MFMAs of (b, k-step 1) run.
+  auto wait_landed = [&](int younger) {       // `younger` whole blocks may stay in flight
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) { if (w == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else { if (w == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+  };
+#pragma unroll
+  for (int st = 0; st < NSTG - 1; ++st) stage(st);
+  wait_landed(NSTG - 2);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frags F0, F1;
+  load_frags(F0, smem, K0());
+  int cur = 0;
+  for (int blk = blk_lo; blk < blk_hi; ++blk) {
+    wait_landed(NSTG - 3);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int nxt = cur + NSTG - 1;
+    if (nxt >= NSTG) nxt -= NSTG;
+    const int cn = cur + 1 == NSTG ? 0 : cur + 1;
+    load_frags(F1, smem + cur * STAGE_B, K1());
+    stage_part(nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags(F0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_part(nxt, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags(F0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(F0, smem + cn * STAGE_B, K0());
+    stage_part(nxt, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags(F1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_part(nxt, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags(F1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_part(nxt, 4);
+    cur = cn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // epilogue: acc[t][mi][ni][r] -> n = n0 + wr*64 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*32 + ni*16 + (l&15)
+  const int KW = 3 * P.Cin;
+  const bool rowmajor = !direct || (P.w_layout == 0 && !P.accumulate);
+  float* obase = direct ? out_ptr : out_ptr + (long)split * P.N * KW;
+  if (rowmajor && (P.Cin % 4 == 0) && (((uintptr_t)obase & 15) == 0)) {
+    // each wave transposes 32 rows x 32 columns of one tap at a time through a private LDS patch and writes 16-byte segments
+    constexpr int PITCH = 32 * 4 + 16;
+    __syncthreads();
+    char* wbuf = smem + w * (32 * PITCH);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ch = 0; ch < MI / 2; ++ch) {
+        const int nrow0 = n0 + wr * 64 + ch * 32;
+#pragma unroll
+        for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCH) + ni * 16 + (l & 15)) = acc[t][ch * 2 + mi2][ni][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // per-wave patch: in-order LDS, no workgroup barrier needed
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {          // 8 lanes per 32-float row, 8 rows per instruction
+          const int rl = it * 8 + (l >> 3), cv = l & 7;
+          const int n = nrow0 + rl, c = c0 + wc * 32 + cv * 4;
+          if (n < P.N && c < P.Cin) {
+            const f32x4 v = *(const f32x4*)(wbuf + rl * PITCH + cv * 16);
+            *(f32x4*)(obase + ((long)n * KW + t * P.Cin + c)) = v;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 64 + mi * 16 + (l >> 4) * 4 + r;
+        if (n >= P.N) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int c = c0 + wc * 32 + ni * 16 + (l & 15);
+          if (c >= P.Cin) continue;
+          float v = acc[t][mi][ni][r];
+          if (direct) {
+            float* dst = P.w_layout == 0 ? out_ptr + ((long)n * KW + t * P.Cin + c) : out_ptr + ((long)n * KW + (long)c * 3 + t);
+            if (P.accumulate) v += *dst;
+            *dst = v;
+          } else {
+            out_ptr[((long)split * P.N + n) * KW + t * P.Cin + c] = v;
+          }
+        }
+      }
+}
+
 struct WgradReduceMulti {
   const float* ws[DRN_MAX_GROUPS];
   float* out[DRN_MAX_GROUPS];
@@ -361,8 +677,55 @@ static int total_blocks_upper(int M_total, int ngroups_max) {
   return cdiv(M_total, 32) + ngroups_max;
 }
 
+// fused 3-tap kernel (conv_wgrad3_tn_kernel): one 8-wave workgroup per CU; row splits fill the chip once.
+static int wgrad3_nsplit(int m_total, int N, int Cin) {
+  int target = 256;
+  if (const char* e = getenv("DRN_TN3_TARGET")) target = atoi(e);
+  const int tiles = cdiv(N, 128) * cdiv(Cin, 128);
+  int ns = target / tiles;
+  const int cap = cdiv(m_total, 64) / 8;      // every split owns >= 8 row blocks
+  if (ns > cap) ns = cap;
+  if (ns < 1) ns = 1;
+  if (ns > 64) ns = 64;
+  return ns;
+}
+static bool wgrad3_enabled() {
+  const char* e = getenv("DRN_TN_FUSED");
+  return !(e && atoi(e) == 0);
+}
+// stride-1 geometry, enough rows to amortise the wider tile, 32-bit element offsets (rows are addressed with a 24-bit multiply)
+static bool wgrad3_group_ok(const DrnWgradDesc& s) {
+  return s.Lsrc == s.Lout && s.M < (1 << 24) && s.ldy < (1 << 24) && s.ldx < (1 << 24) &&
+         (long)s.M * s.ldy < (1L << 31) && (long)s.M * s.ldx < (1L << 31);
+}
+static int wgrad3_min_rows() {
+  if (const char* e = getenv("DRN_TN3_MINROWS")) return atoi(e);
+  return 4096;
+}
+static void wgrad3_attr() {
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad3_tn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad3_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    set = true;
+  }
+}
+#define WGRAD3_STAGE (2 * 16384 + 512)
+static int wgrad3_stages() {
+  int st = 3;
+  if (const char* e = getenv("DRN_TN3_STAGES")) st = atoi(e);
+  return st < 3 ? 3 : (st > 4 ? 4 : st);
+}
+#define WGRAD3_LAUNCH(GRID, P) do { const int st_ = wgrad3_stages(); \
+    if (st_ == 3) conv_wgrad3_tn_kernel<3><<<GRID, 512, 3 * WGRAD3_STAGE, stream>>>(P); \
+    else conv_wgrad3_tn_kernel<4><<<GRID, 512, 4 * WGRAD3_STAGE, stream>>>(P); } while (0)
+
 extern "C" int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps) {
-  const int ns = wgrad_nsplit(total_blocks_upper(M_total, DRN_MAX_GROUPS), N, Cin, taps);
+  int ns = wgrad_nsplit(total_blocks_upper(M_total, DRN_MAX_GROUPS), N, Cin, taps);
+  if (taps == 3) {
+    const int ns3 = wgrad3_nsplit(M_total, N, Cin);
+    if (ns3 > ns) ns = ns3;
+  }
   return ns > 1 ? (int64_t)ns * N * taps * Cin : 0;
 }
 
@@ -389,6 +752,40 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
     P.g[g].ldy = s.ldy; P.g[g].ldx = s.ldx; P.g[g].blk_start = blks;
     blks += cdiv(s.M, R);
     m_total += s.M;
+  }
+  bool fused = dtype == DRN_BF16 && taps == 3 && stride == 1 && pad == 1 && wgrad3_enabled() && m_total >= wgrad3_min_rows();
+  for (int g = 0; g < ngroups; ++g) fused = fused && wgrad3_group_ok(d[g]);
+  if (fused) {
+    // row blocks of the PADDED row space (Lout + 1 rows per sequence), see conv_wgrad3_tn_kernel
+    blks = 0;
+    for (int g = 0; g < ngroups; ++g) {
+      P.g[g].blk_start = blks;
+      blks += cdiv((d[g].M / d[g].Lout) * (d[g].Lout + 1), 64);
+    }
+    int ns = wgrad3_nsplit(m_total, N, Cin);
+    if (ns > blks) ns = blks;
+    DRN_CHECK_ARG(ns == 1 || ws, "drn_gemm_wgrad: workspace required (drn_wgrad_ws_elems)");
+    P.total_blks = blks;
+    P.blks_per_split = cdiv(blks, ns);
+    ns = cdiv(blks, P.blks_per_split);
+    P.N = N; P.Cin = Cin; P.taps = taps; P.stride = stride; P.pad = pad;
+    P.ctiles = cdiv(Cin, 128);
+    P.direct = ns == 1;
+    P.out = P.direct ? dW : ws;
+    P.w_layout = w_layout;
+    P.accumulate = accumulate;
+    wgrad3_attr();
+    WGRAD3_LAUNCH(dim3(cdiv(N, 128), cdiv(Cin, 128), ns), P);
+    int rc = drn_launch_status("drn_gemm_wgrad(fused taps)");
+    if (rc) return rc;
+    if (!P.direct) {
+      const long total = (long)N * taps * Cin;
+      int nb = (int)((total + 255) / 256);
+      if (nb > 2048) nb = 2048;
+      wgrad_reduce_kernel<<<nb, 256, 0, stream>>>(ws, dW, ns, N, Cin, taps, w_layout, accumulate);
+      rc = drn_launch_status("drn_gemm_wgrad(reduce)");
+    }
+    return rc;
   }
   // the split count must not exceed what drn_wgrad_ws_elems() promised for this M_total
   int ns = wgrad_nsplit(total_blocks_upper(m_total, DRN_MAX_GROUPS), N, Cin, taps);
@@ -455,6 +852,8 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
   bool any_split = false;
   for (int g = 0; g < n; ++g) mmax = d[g].M > mmax ? d[g].M : mmax;
   const long ws_per = drn_wgrad_ws_elems(mmax, N, Cin, taps);
+  bool fused = dtype == DRN_BF16 && taps == 3 && stride == 1 && pad == 1 && wgrad3_enabled() && mmax >= wgrad3_min_rows();
+  for (int g = 0; g < n; ++g) fused = fused && wgrad3_group_ok(d[g]);
   for (int g = 0; g < n; ++g) {
     const DrnWgradDesc& s = d[g];
     DRN_CHECK_ARG(s.dY && s.X && dWs[g] && s.M > 0 && s.Lout > 0 && s.Lsrc > 0 && s.M % s.Lout == 0, "drn_gemm_wgrad_multi: bad problem %d", g);
@@ -463,9 +862,16 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
     DRN_CHECK_ARG(((uintptr_t)s.dY & 15) == 0 && ((uintptr_t)s.X & 15) == 0, "drn_gemm_wgrad_multi: operands must be 16-byte aligned");
     P.g[g].dY = s.dY; P.g[g].X = s.X; P.g[g].M = s.M; P.g[g].Lout = s.Lout; P.g[g].Lsrc = s.Lsrc;
     P.g[g].ldy = s.ldy; P.g[g].ldx = s.ldx; P.g[g].blk_start = blks;
-    const int gb = cdiv(s.M, R);
+    const int gb = fused ? cdiv((s.M / s.Lout) * (s.Lout + 1), 64) : cdiv(s.M, R);
     blks += gb;
     int ns = wgrad_nsplit(total_blocks_upper(s.M, 1), N, Cin, taps);
+    if (fused) {
+      // the problems share the chip: each gets its share of the one-workgroup-per-CU budget by row count
+      ns = (int)((long)wgrad3_nsplit(mmax, N, Cin) * s.M / mmax);
+      const int cap = gb / 4;
+      if (ns > cap) ns = cap;
+      if (ns < 1) ns = 1;
+    }
     if (ns > gb) ns = gb;
     P.bps[g] = cdiv(gb, ns);
     ns = cdiv(gb, P.bps[g]);
@@ -492,7 +898,10 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
     attr_set = true;
   }
   dim3 grid(cdiv(N, tile), taps * P.ctiles, z);
-  if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+  if (fused) {
+    wgrad3_attr();
+    WGRAD3_LAUNCH(dim3(cdiv(N, 128), cdiv(Cin, 128), z), P);
+  } else if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
   else conv_wgrad_tn_kernel<float, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
   int rc = drn_launch_status("drn_gemm_wgrad_multi");
   if (rc || !any_split) return rc;

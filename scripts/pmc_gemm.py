@@ -23,6 +23,12 @@ if shape == "wgrad_nt":      # the prop_fc weight gradient as it runs in the ste
     for _ in range(5):
         ops.gemm_nt([ops.gemm_desc(dZT, xT, dW, 4096, 4096, B * 256, out_f32=True)], code)
     torch.cuda.synchronize(); sys.exit()
+if shape == "wgrad3":        # conv0 weight gradient through the fused 3-tap kernel
+    dY = torch.randn(B * 256, 256, device=dev).to(dt); X = torch.randn(B * 256, 4352, device=dev).to(dt)
+    dW = torch.empty(256, 4352, 3, device=dev)
+    for _ in range(5):
+        ops.gemm_wgrad([ops.wgrad_desc(dY, X, B * 256, Lout=256, Lsrc=256)], dW, 256, 4352, taps=3, stride=1, pad=1, w_layout=1, dtype=code)
+    torch.cuda.synchronize(); sys.exit()
 if shape == "prop_fc": d, k, W = mk([(B, 256)], 4096, 4096)
 elif shape == "l3": d, k, W = mk([(B, 64)], 512, 512, 3)
 else: d, k, W = mk([(B, 256), (B, 128), (B, 64)], 1024, 512, 3)
