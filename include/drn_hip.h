@@ -76,6 +76,9 @@ typedef struct DrnWgradDesc {
   int32_t M, Lout, Lsrc;
   int32_t ldy, ldx;
 } DrnWgradDesc;
+/* bf16, taps == 3, stride == 1, pad == 1, Lsrc == Lout and >= 4096 rows run the fused-tap kernel (one staged X block
+ * feeds all three taps); everything else the per-tap kernel.  Same results to fp32 rounding (the split points differ).
+ * Environment (experiments): DRN_TN_FUSED=0 disables, DRN_TN3_MINROWS, DRN_TN3_TARGET, DRN_TN3_STAGES=3|4. */
 int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps);
 int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, int N, int Cin, int taps, int stride,
                    int pad, int w_layout, int accumulate, float* ws, int dtype, void* stream);

@@ -54,6 +54,7 @@ def case(name, levels, N, Cin, layout=1, multi=False, bench=True):
 
 
 B = 32
+os.environ["DRN_TN3_MINROWS"] = "0"
 case("tiny 2x20 N=24 Cin=40", [(2, 20)], 24, 40, bench=False)
 case("ragged 3x33 N=136 Cin=200", [(3, 33)], 136, 200, layout=0, bench=False)
 case("grouped 4x(64,32,16)", [(4, 64), (4, 32), (4, 16)], 128, 128, bench=False)

@@ -299,3 +299,60 @@ def test_wgrad_multi_equals_separate_launches(dt):
     for a, b in zip(outs, want):
         assert torch.isfinite(a).all()
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-4 * float(b.abs().max()))
+
+
+# ---- fused 3-tap weight gradient (conv_wgrad3_tn_kernel): k = 3, stride 1, pad 1, bf16 ------------------------------------
+@pytest.mark.parametrize("B,L,Cin,Cout,layout", [(3, 50, 72, 136, 1), (2, 64, 64, 128, 0), (5, 20, 40, 24, 1), (8, 256, 320, 256, 1),
+                                                 (1, 63, 128, 128, 0), (4, 65, 136, 200, 1), (7, 3, 64, 64, 1), (2, 1000, 64, 96, 0)])
+def test_conv_wgrad_fused_taps(monkeypatch, B, L, Cin, Cout, layout):
+    """All three taps from one staged X block (padded row space, halo rows): against the fp64 autograd gradient, plus
+    accumulate; sequence lengths below / at / above the 64-row block, ragged channel counts, one sequence."""
+    from drn_amd import ops
+    monkeypatch.setenv("DRN_TN3_MINROWS", "0")
+    x, w = conv_case("bf16", B, L, Cin, Cout, 3, 1)
+    wr = w.double().requires_grad_()
+    y = F.conv1d(x.double(), wr, stride=1, padding=1)
+    dy = rnd(tuple(y.shape), 9, DT["bf16"])
+    y.backward(dy.double())
+    ref = wr.grad if layout == 1 else wr.grad.permute(0, 2, 1)
+    xd, dyd = nlc(x).to(dev()), nlc(dy).to(dev())
+    d = ops.wgrad_desc(dyd, xd, B * L, Lout=L, Lsrc=L)
+    for fused in ("1", "0"):                      # the per-tap kernel on the same inputs keeps the comparison honest
+        monkeypatch.setenv("DRN_TN_FUSED", fused)
+        dW = torch.full(tuple(ref.shape), float("nan"), dtype=torch.float32, device=dev())
+        ops.gemm_wgrad([d], dW, Cout, Cin, taps=3, stride=1, pad=1, w_layout=layout, dtype=ops.dtype_code(xd))
+        torch.cuda.synchronize()
+        close(dW, ref, TOL["bf16"] * np.sqrt(B * L / 64 + 1), "wgrad fused=%s" % fused)
+        ops.gemm_wgrad([d], dW, Cout, Cin, taps=3, stride=1, pad=1, w_layout=layout, accumulate=True, dtype=ops.dtype_code(xd))
+        torch.cuda.synchronize()
+        close(dW, 2 * ref, TOL["bf16"] * 2 * np.sqrt(B * L / 64 + 1), "wgrad accumulate fused=%s" % fused)
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_conv_wgrad_fused_taps_levels(monkeypatch, multi):
+    """Pyramid levels through the fused kernel: summed into one gradient (shared tower weights) and as independent problems
+    (the FPN level convs); must agree with the per-tap kernel to fp32 rounding."""
+    from drn_amd import ops
+    monkeypatch.setenv("DRN_TN3_MINROWS", "0")
+    g = torch.Generator().manual_seed(33)
+    B, Cout, Cin = 4, 136, 200
+    descs, keep = [], []
+    for L in (256, 64, 20):
+        dY = torch.randn(B * L, Cout, generator=g).to(dev()).to(torch.bfloat16)
+        X = torch.randn(B * L, Cin, generator=g).to(dev()).to(torch.bfloat16)
+        keep.append((dY, X))
+        descs.append(ops.wgrad_desc(dY, X, B * L, Lout=L, Lsrc=L))
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("DRN_TN_FUSED", fused)
+        if multi:
+            outs = [torch.full((Cout, Cin, 3), float("nan"), device=dev()) for _ in descs]
+            ops.gemm_wgrad_multi(descs, outs, Cout, Cin, taps=3, pad=1, w_layout=1, dtype=ops.BF16)
+        else:
+            outs = [torch.full((Cout, Cin, 3), float("nan"), device=dev())]
+            ops.gemm_wgrad(descs, outs[0], Cout, Cin, taps=3, pad=1, w_layout=1, dtype=ops.BF16)
+        torch.cuda.synchronize()
+        res[fused] = outs
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.isfinite(a).all()
+        assert torch.allclose(a, b, rtol=1e-5, atol=2e-6 * float(b.abs().max()) * np.sqrt(B * 256 / 64))
