@@ -45,8 +45,13 @@ struct WgradParams {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+// LDS-DMA load as an asm statement, NOT the builtin: the compiler tracks builtin LDS-DMA stores and puts an
+// `s_waitcnt vmcnt(0)` in front of every later LDS read whose memory operand is in the LDS address space (the transposing
+// reads below are) -- which serialises each block's loads with its MFMAs.  The kernels order LDS-DMA against LDS reads
+// themselves (counted vmcnt + barrier), exactly as the ring protocol needs.
 __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
 }
 
 template <typename T> struct TnMma;
@@ -712,7 +717,7 @@ static void wgrad3_attr() {
 }
 #define WGRAD3_STAGE (2 * 16384 + 512)
 static int wgrad3_stages() {
-  int st = 3;
+  int st = 4;
   if (const char* e = getenv("DRN_TN3_STAGES")) st = atoi(e);
   return st < 3 ? 3 : (st > 4 ? 4 : st);
 }
