@@ -624,6 +624,30 @@ __global__ void wgrad_reduce_multi_kernel(const WgradReduceMulti R, int N, int C
   float* __restrict__ out = R.out[blockIdx.y];
   const int nsplit = R.nsplit[blockIdx.y];
   if (nsplit <= 1) return;                       // written directly by the GEMM
+  if (w_layout == 1 && taps == 3) {
+    const long pairs = (long)N * Cin;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (long)gridDim.x * blockDim.x) {
+      const long n = idx / Cin;
+      const int c = (int)(idx - n * Cin);
+      const float* p = ws + n * KW + c;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      for (int z = 0; z < nsplit; ++z) {
+        s0 += p[(long)z * total];
+        s1 += p[(long)z * total + Cin];
+        s2 += p[(long)z * total + 2 * Cin];
+      }
+      float* o = out + n * KW + (long)c * 3;
+      if (accumulate) {
+        s0 += o[0];
+        s1 += o[1];
+        s2 += o[2];
+      }
+      o[0] = s0;
+      o[1] = s1;
+      o[2] = s2;
+    }
+    return;
+  }
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
@@ -644,6 +668,32 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
                                     int taps, int w_layout, int accumulate) {
   const long KW = (long)taps * Cin;
   const long total = (long)N * KW;
+  if (w_layout == 1 && taps == 3) {
+    // nn.Conv1d layout (Cout, Cin, 3): one thread per (n, c) sums its three taps (each read coalesced across the wave) and
+    // writes 12 contiguous bytes -- the generic loop below writes every element at a 12-byte stride
+    const long pairs = (long)N * Cin;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (long)gridDim.x * blockDim.x) {
+      const long n = idx / Cin;
+      const int c = (int)(idx - n * Cin);
+      const float* p = ws + n * KW + c;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      for (int z = 0; z < nsplit; ++z) {
+        s0 += p[(long)z * total];
+        s1 += p[(long)z * total + Cin];
+        s2 += p[(long)z * total + 2 * Cin];
+      }
+      float* o = out + n * KW + (long)c * 3;
+      if (accumulate) {
+        s0 += o[0];
+        s1 += o[1];
+        s2 += o[2];
+      }
+      o[0] = s0;
+      o[1] = s1;
+      o[2] = s2;
+    }
+    return;
+  }
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
