@@ -922,7 +922,9 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
     int ns = wgrad_nsplit(total_blocks_upper(s.M, 1), N, Cin, taps);
     if (fused) {
       // the problems share the chip: each gets its share of the one-workgroup-per-CU budget by row count
-      ns = (int)((long)wgrad3_nsplit(mmax, N, Cin) * s.M / mmax);
+      long m_all = 0;
+      for (int k = 0; k < n; ++k) m_all += d[k].M;
+      ns = (int)((long)wgrad3_nsplit(mmax, N, Cin) * s.M / m_all);
       const int cap = gb / 4;
       if (ns > cap) ns = cap;
       if (ns < 1) ns = 1;
