@@ -166,8 +166,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   for (int i = 1; i < DRN_MAX_GROUPS; ++i)
     if (i < P.ngroups && blk_lo >= P.g[i].blk_start) s_g = i;
   int s_seq[4], s_t[4];             // of row (block base + s_r[i]) in the current group
+  // the current group's fields live in registers (see conv_wgrad3_tn_kernel: run-time indexing of P.g[] inside the block
+  // loop costs scalar loads whose lgkmcnt(0) waits also drain the LDS reads in flight)
+  const T* g_Y;
+  const T* g_X;
+  int g_M, g_Lout, g_Lsrc, g_ldy, g_ldx, g_start, g_next;
   auto locate = [&]() {
     const WgradGroup& G = P.g[s_g];
+    g_Y = (const T*)G.dY;
+    g_X = (const T*)G.X;
+    g_M = G.M; g_Lout = G.Lout; g_Lsrc = G.Lsrc; g_ldy = G.ldy; g_ldx = G.ldx; g_start = G.blk_start;
+    g_next = s_g + 1 < P.ngroups ? P.g[s_g + 1].blk_start : 0x7fffffff;
     const int mbase = (s_blk - G.blk_start) * R;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -183,29 +192,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
     char* Ys = smem + buf * STAGE_B;
     char* Xs = Ys + IMG_Y;
     const bool live = s_blk < blk_hi;
-    const WgradGroup& G = P.g[s_g];
-    const int mbase = (s_blk - G.blk_start) * R;
-    const T* __restrict__ Yg = (const T*)G.dY;
-    const T* __restrict__ Xg = (const T*)G.X;
+    const int mbase = (s_blk - g_start) * R;
+    const T* __restrict__ Yg = g_Y;
+    const T* __restrict__ Xg = g_X;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mbase + s_r[i];
-      const bool min_ = live & (m < G.M);
+      const bool min_ = live & (m < g_M);
       const bool oky = min_ & (y_off[i] >= 0);
-      const T* ys = oky ? Yg + ((long)m * G.ldy + y_off[i]) : zero;
+      const T* ys = oky ? Yg + ((long)m * g_ldy + y_off[i]) : zero;
       const int st = s_t[i] * P.stride + tap - P.pad;
-      const bool okx = min_ & (x_off[i] >= 0) & (st >= 0) & (st < G.Lsrc);
-      const T* xs = okx ? Xg + ((long)(s_seq[i] * G.Lsrc + st) * G.ldx + x_off[i]) : zero;
+      const bool okx = min_ & (x_off[i] >= 0) & (st >= 0) & (st < g_Lsrc);
+      const T* xs = okx ? Xg + ((long)(s_seq[i] * g_Lsrc + st) * g_ldx + x_off[i]) : zero;
       glds16(ys, Ys + (w * 4 + i) * 1024);
       glds16(xs, Xs + (w * 4 + i) * 1024);
     }
     // advance to the next row block
     ++s_blk;
-    if (s_g + 1 < P.ngroups && s_blk >= P.g[s_g + 1].blk_start) {
+    if (s_blk >= g_next) {
       ++s_g;
       locate();
     } else {
-      const int Lout = G.Lout;
+      const int Lout = g_Lout;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s_t[i] += R;
@@ -368,8 +376,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_tn_kernel(const WgradParam
   for (int i = 1; i < DRN_MAX_GROUPS; ++i)
     if (i < P.ngroups && blk_lo >= P.g[i].blk_start) s_g = i;
   int s_seq[2], s_t[2];             // padded coordinates of the thread's rows in the current group (floor division: p = -1 -> (-1, Lout))
+  // the current group's fields live in registers: indexing P.g[] with a run-time group number inside the block loop costs
+  // scalar loads whose lgkmcnt(0) waits also drain the LDS fragment reads in flight
+  const T* g_Y;
+  const T* g_X;
+  int g_L, g_nseq, g_ldy, g_ldx, g_next;     // g_next: first row block of the next group (or past the end)
   auto locate = [&]() {
     const WgradGroup& G = P.g[s_g];
+    g_Y = (const T*)G.dY;
+    g_X = (const T*)G.X;
+    g_L = G.Lout;
+    g_nseq = G.M / G.Lout;
+    g_ldy = G.ldy;
+    g_ldx = G.ldx;
+    g_next = s_g + 1 < P.ngroups ? P.g[s_g + 1].blk_start : 0x7fffffff;
     const int Lp = G.Lout + 1;
     const int pbase = (s_blk - G.blk_start) * R;
 #pragma unroll
@@ -383,10 +403,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_tn_kernel(const WgradParam
   locate();
 
   // Source row m = seq*Lout + t and element offsets m*ld fit 32 bits (checked on the host), so a row address is one 24-bit
-  // multiply-add on top of a scalar base; rows outside the sequence / group read the zero page.
+  // multiply-add on top of a scalar base; rows outside the sequence / group read the zero page (a select, no branch).
   auto row_ptr = [&](const T* base, int m, int ld, long coff, bool ok) -> const T* {
     const unsigned off = __umul24((unsigned)m, (unsigned)ld) + (unsigned)coff;
-    return ok ? base + off : zero;
+    const T* p = base + off;
+    return ok ? p : zero;
   };
   // part 0..3: one global_load_lds each (the caller spreads them between the MFMA groups); part 3 also carries the halo
   // rows; part 4 advances to the next block.
@@ -395,25 +416,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_tn_kernel(const WgradParam
     char* Xs = Ys + IMG;
     char* Hs = Xs + IMG;
     const bool live = s_blk < blk_hi;
-    const WgradGroup& G = P.g[s_g];
-    const T* __restrict__ Yg = (const T*)G.dY;
-    const T* __restrict__ Xg = (const T*)G.X;
-    const int L = G.Lout, nseq = G.M / G.Lout;
-    const bool ok = live & ((unsigned)s_seq[0] < (unsigned)nseq) & (s_t[0] < L);
+    const int L = g_L;
+    const bool ok = live & ((unsigned)s_seq[0] < (unsigned)g_nseq) & (s_t[0] < L);
     const int m = s_seq[0] * L + s_t[0];
-    if (part == 0) glds16(row_ptr(Yg, m, G.ldy, y_off[0], ok & (y_off[0] >= 0)), Ys + w * 1024);
-    if (part == 1) glds16(row_ptr(Xg, m, G.ldx, x_off[0], ok & (x_off[0] >= 0)), Xs + w * 1024);
-    if (part == 2) glds16(row_ptr(Yg, m, G.ldy, y_off[1], ok & (y_off[1] >= 0)), Ys + 8192 + w * 1024);
+    if (part == 0) glds16(row_ptr(g_Y, m, g_ldy, y_off[0], ok & (y_off[0] >= 0)), Ys + w * 1024);
+    if (part == 1) glds16(row_ptr(g_X, m, g_ldx, x_off[0], ok & (x_off[0] >= 0)), Xs + w * 1024);
+    if (part == 2) glds16(row_ptr(g_Y, m, g_ldy, y_off[1], ok & (y_off[1] >= 0)), Ys + 8192 + w * 1024);
     if (part == 3) {
-      glds16(row_ptr(Xg, m, G.ldx, x_off[1], ok & (x_off[1] >= 0)), Xs + 8192 + w * 1024);
+      glds16(row_ptr(g_X, m, g_ldx, x_off[1], ok & (x_off[1] >= 0)), Xs + 8192 + w * 1024);
       if (is_halo) {
-        const bool okh = live & ((unsigned)s_seq[1] < (unsigned)nseq) & (s_t[1] < L) & (xh_off >= 0);
-        glds16(row_ptr(Xg, s_seq[1] * L + s_t[1], G.ldx, xh_off, okh), Hs);
+        const bool okh = live & ((unsigned)s_seq[1] < (unsigned)g_nseq) & (s_t[1] < L) & (xh_off >= 0);
+        glds16(row_ptr(g_X, s_seq[1] * L + s_t[1], g_ldx, xh_off, okh), Hs);
       }
     }
     if (part != 4) return;
     ++s_blk;
-    if (s_g + 1 < P.ngroups && s_blk >= P.g[s_g + 1].blk_start) {
+    if (s_blk >= g_next) {
       ++s_g;
       locate();
     } else {
