@@ -144,6 +144,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   const int div = mode ? stride : 1;
   const long lda = pr.lda;
   const int sh = div == 2 ? 1 : 0;
+  const int tsgn = mode ? -1 : 1;
   int a_s[PA];           // mode 0: t*stride - pad ; mode 1: t + pad ; hugely negative when the row is out of range
   const T* pA[PA];       // A + (seq*Lsrc)*lda + lane chunk offset
   const T* pB[PB];       // B + n*ldb + lane chunk offset
@@ -188,21 +189,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     char* As = smem + buf * STAGE_B;
     char* Bs = As + A_BYTES;
     if constexpr (FAST) {
+      // one branch-free form for both modes (mode 0: sh = 0, div = 1): no control flow inside the MFMA stream
       const bool kin = s_kt < nkt;
       const long koff = (long)s_kt * BK;
-      int st;
-      bool ok;
-      if (mode == 0) {
-        st = a_s[i] + s_tap;
-        ok = kin & ((unsigned)st < (unsigned)Lsrc);
-      } else {
-        const int num = a_s[i] - s_tap;
-        st = num >> sh;
-        ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
-      }
-      const T* src = ok ? pA[i] + ((long)st * lda + s_c0) : zero;
+      const int num = a_s[i] + tsgn * s_tap;
+      const int st = num >> sh;
+      const bool ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
+      const T* cand = pA[i] + ((long)st * lda + s_c0);
+      const T* src = ok ? cand : zero;
       glds16(src, As + (w * 4 + i) * 1024);
-      const T* bsrc = (kin & okb[i]) ? pB[i] + koff : zero;
+      const T* bcand = pB[i] + koff;
+      const T* bsrc = (kin & okb[i]) ? bcand : zero;
       glds16(bsrc, Bs + (w * 4 + i) * 1024);
     } else {
       const int h = i & 1;
