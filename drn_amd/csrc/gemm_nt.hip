@@ -45,6 +45,7 @@ struct GemmParams {
   GemmProb p[DRN_MAX_GROUPS];
 };
 
+constexpr bool getenv_free_scalar_w = false;   // flip to try the scalar wave index on the 8-wave tile as well
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -103,7 +104,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   constexpr int PMAX = PA > PB ? PA : PB;
   constexpr int A_BYTES = TM * 128, STAGE_B = (TM + TN) * 128;
   static_assert(PA * 8 * NW == TM && PB * 8 * NW == TN && PMAX == 4, "staging assumes 4 pieces per wave");
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  // wave index as a scalar for the 4-wave tiles (LDS-DMA bases / M0 stay in SGPRs: +5-10 % on the pyramid-level GEMMs);
+  // the 8-wave 256x256 tile measured 3 % slower with it, so it keeps the per-lane value
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = (WM * WN == 8 && !getenv_free_scalar_w) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness), so give each
   // XCD a CONTIGUOUS run of logical tiles (same A row-panels, all B column-panels) instead of every 8th one -- the A panel

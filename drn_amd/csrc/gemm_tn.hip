@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   static_assert(TNn == TC && TNn * 128 == NW * 4 * 1024, "square tiles, 4 one-KB staging pieces per wave and operand");
   constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int CPR = (int)sizeof(T);       // 16-byte chunks per 16-column row piece
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;   // wave index as a scalar: LDS-DMA bases (M0) stay in SGPRs
   const int tn = blockIdx.x;                // 128-wide block of output channels n
   const int tap = blockIdx.y / P.ctiles;
   const int c0 = (blockIdx.y - tap * P.ctiles) * TC;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_tn_kernel(const WgradParam
   typedef bf16_t T;
   constexpr int R = 64, MI = 4, NI = 2;
   constexpr int IMG = 16384, HALO_B = 512, STAGE_B = 2 * IMG + HALO_B;
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;   // wave index as a scalar: LDS-DMA bases (M0) stay in SGPRs
   const int n0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
   int split = blockIdx.z;
   int blk_lo = split * P.blks_per_split;
