@@ -11,7 +11,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdrn_hip.so")
+LIB_PATH = os.environ.get("DRN_LIB_PATH") or os.path.join(_HERE, "libdrn_hip.so")     # DRN_LIB_PATH: instrumented builds (scripts/experiments)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "drn_hip.h")
 _lib = None
 

@@ -84,6 +84,15 @@ template <> struct Mma<float> {
   }
 };
 
+// Optional per-wave timeline (build with -DDRN_NT_TRACE, scripts/experiments/nt_trace.py): workgroup 0 stamps s_memtime at
+// seven points of every K-step into P.ws (pass a buffer through drn_gemm_nt_splitk with ksplit = 1).
+#ifdef DRN_NT_TRACE
+#define NT_STAMP(slot) do { if (P.ws && P.ksplit == 1 && blockIdx.x == 0 && l == 0 && kt - kt_lo < 64) \
+    ((long long*)P.ws)[((w * 64) + (kt - kt_lo)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NT_STAMP(slot) do { } while (0)
+#endif
+
 // STAGES-deep LDS ring (STAGES x 32 KB).  Iteration kt: wait until tile kt's global_load_lds have landed with a COUNTED
 // vmcnt (the STAGES-2 younger tiles stay in flight across the barrier), one raw s_barrier, issue tile kt+STAGES-1 into the
 // slot everybody just finished reading, then MFMA on tile kt.  Past-the-end tiles read the zero page so the count is uniform.
@@ -92,6 +101,9 @@ template <> struct Mma<float> {
 // global_load_lds instead of a per-lane integer division and 64-bit multiply.  The generic path keeps those.
 // Tile shape: WM x WN waves, each owning MI x NI MFMA tiles of 16x16 -> TM = WM*MI*16 rows, TN = WN*NI*16 columns.
 //   <2,2,4,4>: 128x128, 4 waves, 32 KB/stage (2 workgroups per CU at 2 stages)    -- general purpose
+//   <2,4,4,2>: 128x128, 8 waves (2 per SIMD)                                       -- launches of <= 256 tiles (one
+//              workgroup per CU): with 4 waves each wave spends ~800 cycles per K-step just ISSUING its 8 global_load_lds
+//              (per-wave timeline: 2300 cycles per K-step for 512 cycles of MFMA); 8 waves halve that and overlap it
 //   <2,4,8,4>: 256x256, 8 waves (2 per SIMD), 64 KB/stage, 2 stages               -- large GEMMs: half the operand
 //              traffic and half the global_load_lds / ds_read per MFMA
 template <typename T, int STAGES, bool FAST, int WM, int WN, int MI, int NI>
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   constexpr int PA = TM / (8 * NW), PB = TN / (8 * NW);      // 1-KB staging pieces per wave and operand
   constexpr int PMAX = PA > PB ? PA : PB;
   constexpr int A_BYTES = TM * 128, STAGE_B = (TM + TN) * 128;
-  static_assert(PA * 8 * NW == TM && PB * 8 * NW == TN && PMAX == 4, "staging assumes 4 pieces per wave");
+  static_assert(PA * 8 * NW == TM && PB * 8 * NW == TN && PA == PB && (PMAX == 4 || PMAX == 2), "square tiles: 4 or 2 staging pieces per wave and operand");
   // wave index as a scalar for the 4-wave tiles (LDS-DMA bases / M0 stay in SGPRs: +5-10 % on the pyramid-level GEMMs);
   // the 8-wave 256x256 tile measured 3 % slower with it, so it keeps the per-lane value
   const int tid = threadIdx.x, l = tid & 63;
@@ -201,10 +213,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
       const bool ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
       const T* cand = pA[i] + ((long)st * lda + s_c0);
       const T* src = ok ? cand : zero;
-      glds16(src, As + (w * 4 + i) * 1024);
+      glds16(src, As + (w * PMAX + i) * 1024);
       const T* bcand = pB[i] + koff;
       const T* bsrc = (kin & okb[i]) ? bcand : zero;
-      glds16(bsrc, Bs + (w * 4 + i) * 1024);
+      glds16(bsrc, Bs + (w * PMAX + i) * 1024);
     } else {
       const int h = i & 1;
       const int c = pch ^ ((h << 2) + (l >> 4));
@@ -217,10 +229,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
       const bool ok = kin & (num >= 0) & (st * div == num) & (st < Lsrc);
       const long aoff = (long)(a_base[i] + st) * lda + cc;
       const T* src = ok ? Ag + aoff : zero;
-      glds16(src, As + (w * 4 + i) * 1024);
+      glds16(src, As + (w * PMAX + i) * 1024);
       const bool okb2 = kin & (b_off[i] >= 0);
       const T* bsrc = okb2 ? Bg + (b_off[i] + kk) : zero;
-      glds16(bsrc, Bs + (w * 4 + i) * 1024);
+      glds16(bsrc, Bs + (w * PMAX + i) * 1024);
     }
   };
   auto advance = [&]() {
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   };
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) piece(buf, i);
+    for (int i = 0; i < PMAX; ++i) piece(buf, i);
     advance();
   };
 
@@ -253,10 +265,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   int cur = 0;
   for (int kt = kt_lo; kt < nkt; ++kt) {
     // each thread issues 8 loads per tile; tiles kt+1 .. kt+STAGES-2 may still be in flight
+    NT_STAMP(0);
     if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if constexpr (STAGES == 4 && PMAX == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if constexpr (STAGES == 4 && PMAX == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    NT_STAMP(1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    NT_STAMP(2);
     int nxt = cur + STAGES - 1;
     if (nxt >= STAGES) nxt -= STAGES;
     const char* As = smem + cur * STAGE_B;
@@ -273,14 +289,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * (NI * 16) + ni * 16 + (l & 15)) * 128 + pc);
-      piece(nxt, ks * 2);
+      if constexpr (PMAX == 4) piece(nxt, ks * 2); else piece(nxt, ks);    // 2-piece waves: one pair of loads per k-slice
       __builtin_amdgcn_sched_barrier(0);
+#ifdef DRN_NT_TRACE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      NT_STAMP(3 + ks * 2);                    // fragments of this k-slice arrived (first piece issued)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, 0);
       __builtin_amdgcn_sched_barrier(0);
-      piece(nxt, ks * 2 + 1);
+      if constexpr (PMAX == 4) piece(nxt, ks * 2 + 1);
       __builtin_amdgcn_sched_barrier(0);
       Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, MI / 2);
       __builtin_amdgcn_sched_barrier(0);
+      NT_STAMP(4 + ks * 2);                    // this k-slice's MFMAs and both pieces issued
     }
     advance();
     cur = cur + 1 == STAGES ? 0 : cur + 1;
@@ -306,10 +328,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     return;
   }
   if (pr.out_f32) {
-    // fp32 destination (a weight gradient): each wave transposes its 64-column slab through a private LDS patch, 32 rows
+    // fp32 destination (a weight gradient): each wave transposes its slab (NI*16 columns) through a private LDS patch, 32 rows
     // at a time, and writes 16-byte row segments.  Only bias / accumulate apply here.
     float* __restrict__ Cf = (float*)pr.C;
-    constexpr int PITCHF = 64 * 4 + 16;
+    constexpr int WCOLS = NI * 16;           // columns owned by one wave
+    constexpr int PITCHF = WCOLS * 4 + 16;
+    constexpr int LPRF = WCOLS / 4;          // lanes per staged row in the 16-byte read-back
+    constexpr int RPIF = 64 / LPRF;          // rows per read-back instruction
     char* wbuf = smem + w * (32 * PITCHF);
     const bool vec4 = (pr.ldc % 4 == 0) && (((uintptr_t)Cf & 15) == 0);
 #pragma unroll
@@ -324,8 +349,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
             *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCHF) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
       wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {          // 16 lanes per 64-float row, 4 rows per instruction
-        const int rl = it * 4 + (l >> 4), cv = l & 15;
+      for (int it = 0; it < 32 / RPIF; ++it) {  // LPRF lanes per row, RPIF rows per instruction
+        const int rl = it * RPIF + l / LPRF, cv = l % LPRF;
         const int m = mrow0 + rl, n = n0 + wc * (NI * 16) + cv * 4;
         if (m < M && n < N) {
           f32x4 v = *(const f32x4*)(wbuf + rl * PITCHF + cv * 16);
@@ -416,11 +441,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   const bool vec_ok = (pr.ldc % VEC == 0) && (((uintptr_t)Cg & 15) == 0) &&
                       (!C2g || ((pr.ldc2 % VEC == 0) && (((uintptr_t)C2g & 15) == 0)));
   if (vec_ok) {
-    // Coalesced epilogue: every wave transposes its 64-column slab through a private LDS patch, 32 rows at a time, and
+    // Coalesced epilogue: every wave transposes its slab (NI*16 columns) through a private LDS patch, 32 rows at a time, and
     // writes it out as 16-byte row segments (8 store instructions per wave and 64x64 bf16 tile instead of 64 two-byte
     // ones -- the narrow stores were ~8 us of issue-bound tail per launch).
-    constexpr int PITCH = 64 * (int)sizeof(T) + 16;          // bytes per staged row (+16: conflict-free column writes)
-    constexpr int LPR = 64 * (int)sizeof(T) / 16;            // lanes per staged row in the 16-byte read-back
+    constexpr int WCOLS = NI * 16;                           // columns owned by one wave
+    constexpr int PITCH = WCOLS * (int)sizeof(T) + 16;       // bytes per staged row (+16: conflict-free column writes)
+    constexpr int LPR = WCOLS * (int)sizeof(T) / 16;         // lanes per staged row in the 16-byte read-back
     constexpr int RPI = 64 / LPR;                            // rows per read-back instruction
     __syncthreads();                                         // stats (if any) are done with LDS
     char* wbuf = smem + w * (32 * PITCH);
@@ -632,6 +658,11 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   int stages = (long)total * ksplit > 256 ? 2 : 4;
   if (const char* e = getenv("DRN_NT_STAGES")) stages = atoi(e) == 2 ? 2 : 4;
   if (tile == 256) stages = 2;
+  // 128x128 tiles: 8 waves per workgroup, 2-slot ring (measured 20-30 % faster than 4 waves at one workgroup per CU, 8 % at
+  // two; DRN_NT_WAVES=4 brings the 4-wave variants back for experiments)
+  bool waves8 = tile == 128;
+  if (const char* e = getenv("DRN_NT_WAVES")) waves8 = tile == 128 && atoi(e) == 8;
+  if (waves8 && !getenv("DRN_NT_STAGES")) stages = 2;
   static bool attr_set = false;
   if (!attr_set) {
 #define NT_ATTR(TT, SS, ...) \
@@ -639,6 +670,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)
     NT_ATTR(float, 2, 2, 2, 4, 4); NT_ATTR(bf16_t, 2, 2, 2, 4, 4); NT_ATTR(float, 4, 2, 2, 4, 4); NT_ATTR(bf16_t, 4, 2, 2, 4, 4);
     NT_ATTR(float, 2, 2, 4, 8, 4); NT_ATTR(bf16_t, 2, 2, 4, 8, 4);
+    NT_ATTR(float, 2, 2, 4, 4, 2); NT_ATTR(bf16_t, 2, 2, 4, 4, 2); NT_ATTR(float, 4, 2, 4, 4, 2); NT_ATTR(bf16_t, 4, 2, 4, 4, 2);
 #undef NT_ATTR
     attr_set = true;
   }
@@ -647,6 +679,9 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
   if (tile == 256) {
     if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 65536, 2, 4, 8, 4); else NT_LAUNCH(float, 2, 512, 2 * 65536, 2, 4, 8, 4);
+  } else if (waves8) {
+    if (dtype == DRN_BF16) { if (stages == 2) NT_LAUNCH(bf16_t, 2, 512, 2 * 32768, 2, 4, 4, 2); else NT_LAUNCH(bf16_t, 4, 512, 4 * 32768, 2, 4, 4, 2); }
+    else { if (stages == 2) NT_LAUNCH(float, 2, 512, 2 * 32768, 2, 4, 4, 2); else NT_LAUNCH(float, 4, 512, 4 * 32768, 2, 4, 4, 2); }
   } else if (dtype == DRN_BF16) {
     if (stages == 2) NT_LAUNCH(bf16_t, 2, 256, 2 * 32768, 2, 2, 4, 4); else NT_LAUNCH(bf16_t, 4, 256, 4 * 32768, 2, 2, 4, 4);
   } else {
