@@ -15,21 +15,22 @@ from drn_amd._lib import lib, check
 
 dev = "cuda:0"
 dt = torch.bfloat16
-B, L, N, Cin = 32, 64, 512, 512
+big = len(sys.argv) > 1 and sys.argv[1] == "prop_fc"       # the 256x256-tile prop_fc forward instead of a pyramid-level conv
+B, L, N, Cin, taps = (32, 256, 4096, 4096, 1) if big else (32, 64, 512, 512, 3)
 M = B * L
-W = torch.randn(N, 3 * Cin, device=dev).to(dt)
+W = torch.randn(N, taps * Cin, device=dev).to(dt)
 A = torch.randn(M, Cin, device=dev).to(dt)
 C = torch.empty(M, N, device=dev, dtype=dt)
-d = ops.gemm_desc(A, W, C, M, N, Cin, taps=3, stride=1, pad=1, Lout=L, Lsrc=L)
+d = ops.gemm_desc(A, W, C, M, N, Cin, taps=taps, stride=1, pad=(taps - 1) // 2, Lout=L, Lsrc=L)
 arr = (type(d) * 1)(d)
-for stages in ("2", "4"):
+for stages in (("2",) if big else ("2", "4")):
     os.environ["DRN_NT_STAGES"] = stages
-    trace = torch.zeros(4 * 64 * 8, dtype=torch.int64, device=dev)
+    trace = torch.zeros(8 * 64 * 8, dtype=torch.int64, device=dev)
     for _ in range(3):
         check(lib().drn_gemm_nt_splitk(arr, 1, ctypes.c_void_p(trace.data_ptr()), ops.BF16, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "trace")
     torch.cuda.synchronize()
-    t = trace.view(4, 64, 8).cpu()
-    nk = 3 * Cin // 64
+    t = trace.view(8, 64, 8).cpu()
+    nk = min(64, taps * Cin // 64)
     print("stages=%s: %d K-steps; wave 0 deltas (ticks) per K-step: wait | barrier | frags0 | mfma0 | frags1 | mfma1 | total" % (stages, nk))
     for w in range(2):
         for k in range(4, min(nk, 14)):
