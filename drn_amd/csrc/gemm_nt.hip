@@ -282,20 +282,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int pc = ((ks * 4 + (l >> 4)) ^ swz) * 16;
-      // B fragments and the first half of the A fragments first; the second half of A is read while the first half of the
-      // MFMAs runs (per-wave timeline: the wave sat ~550 cycles per k-slice waiting for all 12 reads before its first MFMA)
       typename Mma<T>::frag a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *(const typename Mma<T>::frag*)(As + (wr * (MI * 16) + mi * 16 + (l & 15)) * 128 + pc);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * (NI * 16) + ni * 16 + (l & 15)) * 128 + pc);
-#pragma unroll
-      for (int mi = 0; mi < MI / 2; ++mi)
-        a[mi] = *(const typename Mma<T>::frag*)(As + (wr * (MI * 16) + mi * 16 + (l & 15)) * 128 + pc);
       if constexpr (PMAX == 4) piece(nxt, ks * 2); else piece(nxt, ks);    // 2-piece waves: one pair of loads per k-slice
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mi = MI / 2; mi < MI; ++mi)
-        a[mi] = *(const typename Mma<T>::frag*)(As + (wr * (MI * 16) + mi * 16 + (l & 15)) * 128 + pc);
 #ifdef DRN_NT_TRACE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       NT_STAMP(3 + ks * 2);                    // fragments of this k-slice arrived (first piece issued)
