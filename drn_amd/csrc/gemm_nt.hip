@@ -84,43 +84,9 @@ template <> struct Mma<float> {
   }
 };
 
-// Optional per-wave timeline (build with -DDRN_NT_TRACE, scripts/experiments/nt_trace.py): workgroup 0 stamps s_memtime at
-// seven points of every K-step into P.ws (pass a buffer through drn_gemm_nt_splitk with ksplit = 1).
-#ifdef DRN_NT_TRACE
-#define NT_STAMP(slot) do { if (P.ws && P.ksplit == 1 && blockIdx.x == 0 && l == 0 && kt - kt_lo < 64) \
-    ((long long*)P.ws)[((w * 64) + (kt - kt_lo)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define NT_STAMP(slot) do { } while (0)
-#endif
-
-// STAGES-deep LDS ring (STAGES x 32 KB).  Iteration kt: wait until tile kt's global_load_lds have landed with a COUNTED
-// vmcnt (the STAGES-2 younger tiles stay in flight across the barrier), one raw s_barrier, issue tile kt+STAGES-1 into the
-// slot everybody just finished reading, then MFMA on tile kt.  Past-the-end tiles read the zero page so the count is uniform.
-// FAST (every group has Cin % BK == 0, so a K-tile never straddles two taps): the tap and channel offset of a tile are
-// wave-uniform scalars advanced incrementally, and each thread keeps 4+4 precomputed row pointers -- ~10 VALU per
-// global_load_lds instead of a per-lane integer division and 64-bit multiply.  The generic path keeps those.
-// Tile shape: WM x WN waves, each owning MI x NI MFMA tiles of 16x16 -> TM = WM*MI*16 rows, TN = WN*NI*16 columns.
-//   <2,2,4,4>: 128x128, 4 waves, 32 KB/stage (2 workgroups per CU at 2 stages)    -- general purpose
-//   <2,4,4,2>: 128x128, 8 waves (2 per SIMD)                                       -- launches of <= 256 tiles (one
-//              workgroup per CU): with 4 waves each wave spends ~800 cycles per K-step just ISSUING its 8 global_load_lds
-//              (per-wave timeline: 2300 cycles per K-step for 512 cycles of MFMA); 8 waves halve that and overlap it
-//   <2,4,8,4>: 256x256, 8 waves (2 per SIMD), 64 KB/stage, 2 stages               -- large GEMMs: half the operand
-//              traffic and half the global_load_lds / ds_read per MFMA
-template <typename T, int STAGES, bool FAST, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 : 1))) void conv_gemm_nt_kernel(const GemmParams P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-byte chunk
-  constexpr int BK = 8 * CH;               // elements per K-step (128 bytes)
-  constexpr int NW = WM * WN, TM = WM * MI * 16, TN = WN * NI * 16;
-  constexpr int PA = TM / (8 * NW), PB = TN / (8 * NW);      // 1-KB staging pieces per wave and operand
-  constexpr int PMAX = PA > PB ? PA : PB;
-  constexpr int A_BYTES = TM * 128, STAGE_B = (TM + TN) * 128;
-  static_assert(PA * 8 * NW == TM && PB * 8 * NW == TN && PA == PB && (PMAX == 4 || PMAX == 2), "square tiles: 4 or 2 staging pieces per wave and operand");
-  // wave index as a scalar for the 4-wave tiles (LDS-DMA bases / M0 stay in SGPRs: +5-10 % on the pyramid-level GEMMs);
-  // the 8-wave 256x256 tile measured 3 % slower with it, so it keeps the per-lane value
-  const int tid = threadIdx.x, l = tid & 63;
-  const int w = (WM * WN == 8 && !getenv_free_scalar_w) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
-
+// Workgroup -> (group, tile row, tile column).
+template <int TM>
+__device__ __forceinline__ void nt_locate(const GemmParams& P, int& g_out, int& tm_out, int& tn_out) {
   // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness), so give each
   // XCD a CONTIGUOUS run of logical tiles (same A row-panels, all B column-panels) instead of every 8th one -- the A panel
   // of a tile row is then fetched into one L2 instead of eight.  Bijective for any grid size.
@@ -148,169 +114,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     tm = first_m + r % gsm;
     tn = r / gsm;
   }
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int M = pr.M, N = pr.N, K = pr.K, Cin = pr.Cin, taps = pr.taps;
-  const int stride = pr.stride, pad = pr.pad, mode = pr.mode, Lsrc = pr.Lsrc;
-  const T* __restrict__ Ag = (const T*)pr.A;
-  const T* __restrict__ Bg = (const T*)pr.B;
-  const T* zero = (const T*)g_zero_page;
+  g_out = g;
+  tm_out = tm;
+  tn_out = tn;
+}
 
-  // ---- per-thread staging state: 4 A rows + 4 B rows (one 16-byte chunk each per K-step)
-  const int pch = l & 7;
-  const int div = mode ? stride : 1;
-  const long lda = pr.lda;
-  const int sh = div == 2 ? 1 : 0;
-  const int tsgn = mode ? -1 : 1;
-  int a_s[PA];           // mode 0: t*stride - pad ; mode 1: t + pad ; hugely negative when the row is out of range
-  const T* pA[PA];       // A + (seq*Lsrc)*lda + lane chunk offset
-  const T* pB[PB];       // B + n*ldb + lane chunk offset
-  bool okb[PB];
-  int a_base[PA];        // generic path
-  long b_off[PB];
-#pragma unroll
-  for (int i = 0; i < PMAX; ++i) {
-    const int row = (w * PMAX + i) * 8 + (l >> 3);
-    const int m = m0 + row;
-    const int coff = (pch ^ (((i & 1) << 2) + (l >> 4))) * CH;
-    int seq = 0, t = -(1 << 28);
-    if (m < M) {
-      seq = m / pr.Lout;
-      t = m - seq * pr.Lout;
-    }
-    a_s[i] = m < M ? (mode ? t + pad : t * stride - pad) : -(1 << 28);
-    a_base[i] = seq * Lsrc;
-    pA[i] = Ag + ((long)seq * Lsrc * lda + coff);
-    const int n = n0 + row;
-    okb[i] = n < N;
-    b_off[i] = n < N ? (long)n * pr.ldb : -1;
-    pB[i] = Bg + ((long)(n < N ? n : 0) * pr.ldb + coff);
-  }
-
-  // tiles are staged strictly in order; these advance by one tile per stage() call.  Split-K: this workgroup owns
-  // K-tiles [kt_lo, nkt) of the problem.
-  const int nkt_all = (K + BK - 1) / BK;
-  const int kt_per = (nkt_all + P.ksplit - 1) / P.ksplit;
-  const int kt_lo = (int)blockIdx.y * kt_per;
-  const int nkt = min(nkt_all, kt_lo + kt_per);
-  int s_kt = kt_lo, s_tap = 0, s_c0 = 0;
-  if (FAST && kt_lo > 0) {
-    s_tap = (kt_lo * BK) / Cin;
-    s_c0 = kt_lo * BK - s_tap * Cin;
-  }
-
-  // Every thread issues exactly 8 global_load_lds per tile (the counted vmcnt below depends on it); masked lanes and
-  // past-the-end tiles read the zero page.
-  // piece(buf, i): the A and B loads of staging row-group i (2 of the 8 global_load_lds of a tile); advance(): next tile.
-  auto piece = [&](int buf, int i) {
-    char* As = smem + buf * STAGE_B;
-    char* Bs = As + A_BYTES;
-    if constexpr (FAST) {
-      // one branch-free form for both modes (mode 0: sh = 0, div = 1): no control flow inside the MFMA stream
-      const bool kin = s_kt < nkt;
-      const long koff = (long)s_kt * BK;
-      const int num = a_s[i] + tsgn * s_tap;
-      const int st = num >> sh;
-      const bool ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
-      const T* cand = pA[i] + ((long)st * lda + s_c0);
-      const T* src = ok ? cand : zero;
-      glds16(src, As + (w * PMAX + i) * 1024);
-      const T* bcand = pB[i] + koff;
-      const T* bsrc = (kin & okb[i]) ? bcand : zero;
-      glds16(bsrc, Bs + (w * PMAX + i) * 1024);
-    } else {
-      const int h = i & 1;
-      const int c = pch ^ ((h << 2) + (l >> 4));
-      const int kk = s_kt * BK + c * CH;
-      const int tp = taps == 1 ? 0 : kk / Cin;
-      const int cc = kk - tp * Cin;
-      const bool kin = kk < K;
-      const int num = mode ? a_s[i] - tp : a_s[i] + tp;
-      const int st = div == 1 ? num : (div == 2 ? num >> 1 : num / div);
-      const bool ok = kin & (num >= 0) & (st * div == num) & (st < Lsrc);
-      const long aoff = (long)(a_base[i] + st) * lda + cc;
-      const T* src = ok ? Ag + aoff : zero;
-      glds16(src, As + (w * PMAX + i) * 1024);
-      const bool okb2 = kin & (b_off[i] >= 0);
-      const T* bsrc = okb2 ? Bg + (b_off[i] + kk) : zero;
-      glds16(bsrc, Bs + (w * PMAX + i) * 1024);
-    }
-  };
-  auto advance = [&]() {
-    if constexpr (FAST) {
-      s_c0 += BK;
-      if (s_c0 >= Cin) {
-        s_c0 -= Cin;
-        ++s_tap;
-      }
-    }
-    ++s_kt;
-  };
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < PMAX; ++i) piece(buf, i);
-    advance();
-  };
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+// Epilogue shared by the NT kernels.  acc[mi][ni][r]: m = wr*MI*16 + mi*16 + (l>>4)*4 + r, n = wc*NI*16 + ni*16 + (l&15).
+// Enter after a workgroup barrier that follows the last LDS read of the main loop (it reuses `smem`).
+template <typename T, int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void nt_epilogue(const GemmParams& P, const GemmProb& pr, f32x4 (&acc)[MI][NI], char* smem,
+                                            const int m0, const int n0, const int tm) {
+  constexpr int NW = WM * WN, TM = WM * MI * 16, TN = WN * NI * 16;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int wr = w / WN, wc = w % WN;
-  const int swz = (l >> 1) & 7;
-
-#pragma unroll
-  for (int st = 0; st < STAGES - 1; ++st) stage(st);
-  int cur = 0;
-  for (int kt = kt_lo; kt < nkt; ++kt) {
-    // each thread issues 8 loads per tile; tiles kt+1 .. kt+STAGES-2 may still be in flight
-    NT_STAMP(0);
-    if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (STAGES == 4 && PMAX == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    if constexpr (STAGES == 4 && PMAX == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    NT_STAMP(1);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    NT_STAMP(2);
-    int nxt = cur + STAGES - 1;
-    if (nxt >= STAGES) nxt -= STAGES;
-    const char* As = smem + cur * STAGE_B;
-    const char* Bs = As + A_BYTES;
-    // The 8 loads of tile kt+STAGES-1 are issued in 4 pairs BETWEEN the MFMA groups of tile kt, so their issue cost
-    // (~100 cycles each) overlaps the matrix pipe instead of preceding it.
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int pc = ((ks * 4 + (l >> 4)) ^ swz) * 16;
-      typename Mma<T>::frag a[MI], b[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        a[mi] = *(const typename Mma<T>::frag*)(As + (wr * (MI * 16) + mi * 16 + (l & 15)) * 128 + pc);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * (NI * 16) + ni * 16 + (l & 15)) * 128 + pc);
-      if constexpr (PMAX == 4) piece(nxt, ks * 2); else piece(nxt, ks);    // 2-piece waves: one pair of loads per k-slice
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef DRN_NT_TRACE
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      NT_STAMP(3 + ks * 2);                    // fragments of this k-slice arrived (first piece issued)
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PMAX == 4) piece(nxt, ks * 2 + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, MI / 2);
-      __builtin_amdgcn_sched_barrier(0);
-      NT_STAMP(4 + ks * 2);                    // this k-slice's MFMAs and both pieces issued
-    }
-    advance();
-    cur = cur + 1 == STAGES ? 0 : cur + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- epilogue.  acc[mi][ni][r]: m = wr*MI*16 + mi*16 + (l>>4)*4 + r, n = wc*NI*16 + ni*16 + (l&15)
+  const int M = pr.M, N = pr.N;
+  (void)TM; (void)NW;
   if (P.ksplit > 1) {   // raw partial tile; bias / gate / stats / conversion happen in splitk_reduce_kernel
     float* wsp = P.ws + (long)blockIdx.y * M * N;
 #pragma unroll
@@ -526,6 +344,211 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
       }
     }
   }
+}
+
+// Optional per-wave timeline (build with -DDRN_NT_TRACE, scripts/experiments/nt_trace.py): workgroup 0 stamps s_memtime at
+// seven points of every K-step into P.ws (pass a buffer through drn_gemm_nt_splitk with ksplit = 1).
+#ifdef DRN_NT_TRACE
+#define NT_STAMP(slot) do { if (P.ws && P.ksplit == 1 && blockIdx.x == 0 && l == 0 && kt - kt_lo < 64) \
+    ((long long*)P.ws)[((w * 64) + (kt - kt_lo)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NT_STAMP(slot) do { } while (0)
+#endif
+
+// STAGES-deep LDS ring (STAGES x 32 KB).  Iteration kt: wait until tile kt's global_load_lds have landed with a COUNTED
+// vmcnt (the STAGES-2 younger tiles stay in flight across the barrier), one raw s_barrier, issue tile kt+STAGES-1 into the
+// slot everybody just finished reading, then MFMA on tile kt.  Past-the-end tiles read the zero page so the count is uniform.
+// FAST (every group has Cin % BK == 0, so a K-tile never straddles two taps): the tap and channel offset of a tile are
+// wave-uniform scalars advanced incrementally, and each thread keeps 4+4 precomputed row pointers -- ~10 VALU per
+// global_load_lds instead of a per-lane integer division and 64-bit multiply.  The generic path keeps those.
+// Tile shape: WM x WN waves, each owning MI x NI MFMA tiles of 16x16 -> TM = WM*MI*16 rows, TN = WN*NI*16 columns.
+//   <2,2,4,4>: 128x128, 4 waves, 32 KB/stage (2 workgroups per CU at 2 stages)    -- general purpose
+//   <2,4,4,2>: 128x128, 8 waves (2 per SIMD)                                       -- launches of <= 256 tiles (one
+//              workgroup per CU): with 4 waves each wave spends ~800 cycles per K-step just ISSUING its 8 global_load_lds
+//              (per-wave timeline: 2300 cycles per K-step for 512 cycles of MFMA); 8 waves halve that and overlap it
+//   <2,4,8,4>: 256x256, 8 waves (2 per SIMD), 64 KB/stage, 2 stages               -- large GEMMs: half the operand
+//              traffic and half the global_load_lds / ds_read per MFMA
+template <typename T, int STAGES, bool FAST, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 : 1))) void conv_gemm_nt_kernel(const GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int BK = 8 * CH;               // elements per K-step (128 bytes)
+  constexpr int NW = WM * WN, TM = WM * MI * 16, TN = WN * NI * 16;
+  constexpr int PA = TM / (8 * NW), PB = TN / (8 * NW);      // 1-KB staging pieces per wave and operand
+  constexpr int PMAX = PA > PB ? PA : PB;
+  constexpr int A_BYTES = TM * 128, STAGE_B = (TM + TN) * 128;
+  static_assert(PA * 8 * NW == TM && PB * 8 * NW == TN && PA == PB && (PMAX == 4 || PMAX == 2), "square tiles: 4 or 2 staging pieces per wave and operand");
+  // wave index as a scalar for the 4-wave tiles (LDS-DMA bases / M0 stay in SGPRs: +5-10 % on the pyramid-level GEMMs);
+  // the 8-wave 256x256 tile measured 3 % slower with it, so it keeps the per-lane value
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = (WM * WN == 8 && !getenv_free_scalar_w) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int g, tm, tn;
+  nt_locate<TM>(P, g, tm, tn);
+  const GemmProb& pr = P.p[g];
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int M = pr.M, N = pr.N, K = pr.K, Cin = pr.Cin, taps = pr.taps;
+  const int stride = pr.stride, pad = pr.pad, mode = pr.mode, Lsrc = pr.Lsrc;
+  const T* __restrict__ Ag = (const T*)pr.A;
+  const T* __restrict__ Bg = (const T*)pr.B;
+  const T* zero = (const T*)g_zero_page;
+
+  // ---- per-thread staging state: 4 A rows + 4 B rows (one 16-byte chunk each per K-step)
+  const int pch = l & 7;
+  const int div = mode ? stride : 1;
+  const long lda = pr.lda;
+  const int sh = div == 2 ? 1 : 0;
+  const int tsgn = mode ? -1 : 1;
+  int a_s[PA];           // mode 0: t*stride - pad ; mode 1: t + pad ; hugely negative when the row is out of range
+  const T* pA[PA];       // A + (seq*Lsrc)*lda + lane chunk offset
+  const T* pB[PB];       // B + n*ldb + lane chunk offset
+  bool okb[PB];
+  int a_base[PA];        // generic path
+  long b_off[PB];
+#pragma unroll
+  for (int i = 0; i < PMAX; ++i) {
+    const int row = (w * PMAX + i) * 8 + (l >> 3);
+    const int m = m0 + row;
+    const int coff = (pch ^ (((i & 1) << 2) + (l >> 4))) * CH;
+    int seq = 0, t = -(1 << 28);
+    if (m < M) {
+      seq = m / pr.Lout;
+      t = m - seq * pr.Lout;
+    }
+    a_s[i] = m < M ? (mode ? t + pad : t * stride - pad) : -(1 << 28);
+    a_base[i] = seq * Lsrc;
+    pA[i] = Ag + ((long)seq * Lsrc * lda + coff);
+    const int n = n0 + row;
+    okb[i] = n < N;
+    b_off[i] = n < N ? (long)n * pr.ldb : -1;
+    pB[i] = Bg + ((long)(n < N ? n : 0) * pr.ldb + coff);
+  }
+
+  // tiles are staged strictly in order; these advance by one tile per stage() call.  Split-K: this workgroup owns
+  // K-tiles [kt_lo, nkt) of the problem.
+  const int nkt_all = (K + BK - 1) / BK;
+  const int kt_per = (nkt_all + P.ksplit - 1) / P.ksplit;
+  const int kt_lo = (int)blockIdx.y * kt_per;
+  const int nkt = min(nkt_all, kt_lo + kt_per);
+  int s_kt = kt_lo, s_tap = 0, s_c0 = 0;
+  if (FAST && kt_lo > 0) {
+    s_tap = (kt_lo * BK) / Cin;
+    s_c0 = kt_lo * BK - s_tap * Cin;
+  }
+
+  // Every thread issues exactly 8 global_load_lds per tile (the counted vmcnt below depends on it); masked lanes and
+  // past-the-end tiles read the zero page.
+  // piece(buf, i): the A and B loads of staging row-group i (2 of the 8 global_load_lds of a tile); advance(): next tile.
+  auto piece = [&](int buf, int i) {
+    char* As = smem + buf * STAGE_B;
+    char* Bs = As + A_BYTES;
+    if constexpr (FAST) {
+      // one branch-free form for both modes (mode 0: sh = 0, div = 1): no control flow inside the MFMA stream
+      const bool kin = s_kt < nkt;
+      const long koff = (long)s_kt * BK;
+      const int num = a_s[i] + tsgn * s_tap;
+      const int st = num >> sh;
+      const bool ok = kin & (num >= 0) & ((num & (div - 1)) == 0) & (st < Lsrc);
+      const T* cand = pA[i] + ((long)st * lda + s_c0);
+      const T* src = ok ? cand : zero;
+      glds16(src, As + (w * PMAX + i) * 1024);
+      const T* bcand = pB[i] + koff;
+      const T* bsrc = (kin & okb[i]) ? bcand : zero;
+      glds16(bsrc, Bs + (w * PMAX + i) * 1024);
+    } else {
+      const int h = i & 1;
+      const int c = pch ^ ((h << 2) + (l >> 4));
+      const int kk = s_kt * BK + c * CH;
+      const int tp = taps == 1 ? 0 : kk / Cin;
+      const int cc = kk - tp * Cin;
+      const bool kin = kk < K;
+      const int num = mode ? a_s[i] - tp : a_s[i] + tp;
+      const int st = div == 1 ? num : (div == 2 ? num >> 1 : num / div);
+      const bool ok = kin & (num >= 0) & (st * div == num) & (st < Lsrc);
+      const long aoff = (long)(a_base[i] + st) * lda + cc;
+      const T* src = ok ? Ag + aoff : zero;
+      glds16(src, As + (w * PMAX + i) * 1024);
+      const bool okb2 = kin & (b_off[i] >= 0);
+      const T* bsrc = okb2 ? Bg + (b_off[i] + kk) : zero;
+      glds16(bsrc, Bs + (w * PMAX + i) * 1024);
+    }
+  };
+  auto advance = [&]() {
+    if constexpr (FAST) {
+      s_c0 += BK;
+      if (s_c0 >= Cin) {
+        s_c0 -= Cin;
+        ++s_tap;
+      }
+    }
+    ++s_kt;
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) piece(buf, i);
+    advance();
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wr = w / WN, wc = w % WN;
+  const int swz = (l >> 1) & 7;
+
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st) stage(st);
+  int cur = 0;
+  for (int kt = kt_lo; kt < nkt; ++kt) {
+    // each thread issues 8 loads per tile; tiles kt+1 .. kt+STAGES-2 may still be in flight
+    NT_STAMP(0);
+    if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STAGES == 4 && PMAX == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if constexpr (STAGES == 4 && PMAX == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    NT_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    NT_STAMP(2);
+    int nxt = cur + STAGES - 1;
+    if (nxt >= STAGES) nxt -= STAGES;
+    const char* As = smem + cur * STAGE_B;
+    const char* Bs = As + A_BYTES;
+    // The 8 loads of tile kt+STAGES-1 are issued in 4 pairs BETWEEN the MFMA groups of tile kt, so their issue cost
+    // (~100 cycles each) overlaps the matrix pipe instead of preceding it.
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int pc = ((ks * 4 + (l >> 4)) ^ swz) * 16;
+      typename Mma<T>::frag a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *(const typename Mma<T>::frag*)(As + (wr * (MI * 16) + mi * 16 + (l & 15)) * 128 + pc);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = *(const typename Mma<T>::frag*)(Bs + (wc * (NI * 16) + ni * 16 + (l & 15)) * 128 + pc);
+      if constexpr (PMAX == 4) piece(nxt, ks * 2); else piece(nxt, ks);    // 2-piece waves: one pair of loads per k-slice
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef DRN_NT_TRACE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      NT_STAMP(3 + ks * 2);                    // fragments of this k-slice arrived (first piece issued)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PMAX == 4) piece(nxt, ks * 2 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      Mma<T>::template part<MI, NI, MI / 2>(a, b, acc, MI / 2);
+      __builtin_amdgcn_sched_barrier(0);
+      NT_STAMP(4 + ks * 2);                    // this k-slice's MFMAs and both pieces issued
+    }
+    advance();
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  nt_epilogue<T, WM, WN, MI, NI>(P, pr, acc, smem, m0, n0, tm);
 }
 
 // Sum the split-K partial tiles in a fixed order and run the epilogue the GEMM skipped: bias, pre-gate copy, gate,
