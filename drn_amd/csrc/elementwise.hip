@@ -271,6 +271,25 @@ extern "C" int drn_pos_embed_fwd(const float* feat, const float* W, const float*
   return drn_launch_status("drn_pos_embed_fwd");
 }
 
+// feat[m] = (float)[start, end, end - start] from the proposal boundaries (model/main_model.py:51-55 builds it with a
+// subtraction, a cat and a cast: three launches of a few hundred elements each)
+template <typename S>
+__global__ void pos_feat_kernel(const S* __restrict__ se, float* __restrict__ feat, int M) {
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+    const S s0 = se[m * 2], e0 = se[m * 2 + 1];
+    feat[m * 3 + 0] = (float)s0;
+    feat[m * 3 + 1] = (float)e0;
+    feat[m * 3 + 2] = (float)(e0 - s0);          // difference in the input precision, then the cast: as the reference
+  }
+}
+extern "C" int drn_pos_feat(const void* start_end, int is_f64, float* feat, int M, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(start_end && feat && M > 0, "drn_pos_feat: bad args");
+  if (is_f64) pos_feat_kernel<double><<<ew_blocks(M, 256), 256, 0, (hipStream_t)stream>>>((const double*)start_end, feat, M);
+  else pos_feat_kernel<float><<<ew_blocks(M, 256), 256, 0, (hipStream_t)stream>>>((const float*)start_end, feat, M);
+  return drn_launch_status("drn_pos_feat");
+}
+
 // partial[blk][k][j], k<4: sum_m dOut[m][j] * {f0,f1,f2,1}; block = 32 rows x all channels, 8 row lanes per channel vector
 template <typename T>
 __global__ __launch_bounds__(256) void pos_embed_bwd_kernel(const T* __restrict__ dout, int ld, const float* __restrict__ feat, int M,

@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as DF
+from .. import ops
 from .._lib import DrnError
 from .backbone import Backbone
 from .basic_blocks import conv_with_kaiming_uniform
@@ -81,8 +82,11 @@ class mainModel(nn.Module):
             gates = self.encode_query(query_tokens, query_length)
         dt = self.compute_dtype
         # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
-        duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
-        position_feat = torch.cat((props_start_end, duration), dim=-1).float()
+        if props_start_end.dtype in (torch.float64, torch.float32):
+            position_feat = ops.pos_feat(props_start_end)                 # one launch instead of sub + cat + cast
+        else:
+            duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
+            position_feat = torch.cat((props_start_end, duration), dim=-1).float()
         # bf16 rows must be 16-byte multiples for the MFMA kernels' LDS staging; a feature dim that is not (D = 500, the
         # ActivityNet C3D-PCA convention) keeps the two layers that see D -- prop_fc and conv0 -- on the exact-f32 kernels
         front_dt = torch.float32 if (dt == torch.bfloat16 and props_features.shape[2] % 8) else dt

@@ -235,6 +235,15 @@ def skinny_ok(M, N, K):
     return SKINNY and M <= 64 and N % 16 == 0 and K % 64 == 0
 
 
+def pos_feat(start_end):
+    """(B, T, 2) fp64 / fp32 proposal boundaries -> (B, T, 3) fp32 [start, end, end - start] (main_model.py:51-55)."""
+    _need_gpu(start_end)
+    se = start_end.contiguous()
+    out = torch.empty(se.shape[:-1] + (3,), dtype=torch.float32, device=se.device)
+    check(lib().drn_pos_feat(_p(se), int(se.dtype == torch.float64), _p(out), se.numel() // 2, _stream()), "drn_pos_feat")
+    return out
+
+
 def pos_embed_fwd(feat, W, b, out2d, ld_out, M, C, dtype):
     check(lib().drn_pos_embed_fwd(_p(feat), _p(W), _p(b), _p(out2d), ld_out, M, C, dtype, _stream()), "drn_pos_embed_fwd")
 

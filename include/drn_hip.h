@@ -109,6 +109,9 @@ typedef struct {
   int64_t ldo; /* elements between consecutive (a,b) rows of out; 0 = contiguous (C) */
 } DrnPackDesc;
 int drn_pack_weights(const DrnPackDesc* items /*host*/, int n, int dtype, void* stream);
+/* feat[m][3] = (float)[start, end, end - start] from props_start_end (M x 2, fp64 or fp32): the position features of
+ * model/main_model.py:51-55 in one launch (the reference: subtraction, torch.cat, .float()). */
+int drn_pos_feat(const void* start_end, int is_f64, float* feat, int M, void* stream);
 /* position_transform = nn.Linear(3,256) on [start,end,duration] (model/main_model.py:34,51-55), written straight
  * into the channel slice of conv0's input (replaces torch.cat at model/backbone.py:31-32). */
 int drn_pos_embed_fwd(const float* feat /*[M][3]*/, const float* W /*[C][3]*/, const float* b, void* out, int ld_out, int M, int C,
