@@ -107,7 +107,7 @@ class FCOSHead(torch.nn.Module):
         dt = self.compute_dtype
         C = xs[0].shape[2]
         ctbt = self._towers(xs)                                            # (B, L, 2C) per level
-        scales = torch.cat([s.scale for s in self.scales[:len(xs)]])
+        scales = DF.stack_params([s.scale for s in self.scales[:len(xs)]])     # cached stack: no cat launch per step
         logits, reg = DF.head_out(ctbt, [(self.cls_logits, None), (self.bbox_pred, scales)], cols=[0, C], dtype=dt)
         mix, _ = DF.conv_block(ctbt, self.mix_fc[0], self.mix_fc[1], self.training, dt)
         iouf, _ = DF.conv_block(mix, self.iou_scores[0], self.iou_scores[1], self.training, dt)
