@@ -77,6 +77,7 @@ def main():
     args = ap.parse_args()
 
     from drn_amd import dist as ddist
+    from drn_amd import functional as DF
     from drn_amd import ops
     from drn_amd.model import mainModel
     # DRN_DIST_BACKEND=gloo + DRN_FORCE_DEVICE=0 lets several ranks share one GPU to exercise the N>1 code path on a
@@ -115,7 +116,7 @@ def main():
         opt = FusedAdam(reducer, lr=1e-3, max_norm=0.5)              # clip_grad_norm_(0.5) + Adam in two HIP kernels/bucket
     batch = [b.to(dev) for b in synthetic_batch(B, T, D, seed=1 + rank)]     # everything resident in HBM, lengths included
 
-    loss_of = lambda losses: losses["loss_iou"] if stage == 2 else sum(l for l in losses.values())   # main.py:222-225
+    loss_of = lambda losses: losses["loss_iou"] if stage == 2 else DF.loss_total(losses)             # main.py:222-225
 
     def opt_step():
         reducer.finish()

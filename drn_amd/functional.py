@@ -813,8 +813,9 @@ def head_out(xs, heads, cols, dtype):
 
 class _FCOSLossFn(torch.autograd.Function):
     """Target assignment + focal / IoU / IoU-score losses (model/loss.py:40-239) in one kernel each way.
-    Returns (loss_cls, loss_reg, loss_iou, counts2), each loss of shape (1,), counts2 = [n_pos, n_iou_pos]; all four are
-    views of one 5-float result buffer (no per-loss slicing kernels in either direction)."""
+    Returns (loss_cls, loss_reg, loss_iou, counts2, all3), each loss of shape (1,), counts2 = [n_pos, n_iou_pos], all3 the
+    three losses as one (3,) view; all are views of one 5-float result buffer (no per-loss slicing kernels in either
+    direction)."""
 
     @staticmethod
     def forward(ctx, meta, logits, reg, iou, gt):
@@ -830,10 +831,13 @@ class _FCOSLossFn(torch.autograd.Function):
         ctx.save_for_backward(logits, reg, iou if iou is not None else logits.new_empty(0), gt, out5)
         counts = out5[3:5]
         ctx.mark_non_differentiable(counts)
-        return out5[0:1], out5[1:2], out5[2:3], counts
+        return out5[0:1], out5[1:2], out5[2:3], counts, out5[0:3]       # [4]: the three losses as one view (loss_total)
 
     @staticmethod
-    def backward(ctx, g_cls, g_reg, g_iou, _gc):
+    def backward(ctx, g_cls, g_reg, g_iou, _gc, g_all):
+        if g_all is not None:                      # gradient of loss_total(): a (3,) tensor (usually an expanded scalar)
+            parts = [g_all[k:k + 1] for k in range(3)]
+            g_cls, g_reg, g_iou = (p if g is None else g + p for g, p in zip((g_cls, g_reg, g_iou), parts))
         meta = ctx.meta
         logits, reg, iou, gt, out5 = ctx.saved_tensors
         levels = ops.loss_levels(meta["levels"])
@@ -845,6 +849,19 @@ class _FCOSLossFn(torch.autograd.Function):
                           meta["target_scale"], meta["iou_stage"], out5,
                           [None if g is None else g.contiguous().float() for g in (g_cls, g_reg, g_iou)], dlogits, dreg, diou)
         return None, dlogits, dreg, diou, None
+
+
+class LossDict(dict):
+    """The reference's loss dict (same keys) that also carries the three losses as one tensor, so that their sum
+    (main.py:222-225) is one reduction instead of a chain of scalar adds."""
+    all3 = None
+
+
+def loss_total(losses):
+    """sum(loss_dict.values()) of the reference's training loop (main.py:225) in one launch when the dict came from this
+    package; any other mapping is summed the reference's way."""
+    a = getattr(losses, "all3", None)
+    return a.sum() if a is not None else sum(l for l in losses.values())
 
 
 def fcos_loss(logits, reg, iou, gt, levels, B, gamma, alpha, target_scale, iou_stage):

@@ -154,13 +154,18 @@ class FCOSModule(torch.nn.Module):
     def _forward_train(self, locations, box_cls, box_regression, targets, iou_scores):
         loss_box_cls, loss_box_reg, loss_iou = self.loss_evaluator(
             locations, box_cls, box_regression, targets, iou_scores, self.is_first_stage)
-        return None, {"loss_cls": loss_box_cls, "loss_reg": loss_box_reg, "loss_iou": loss_iou}
+        return None, self._loss_dict(loss_box_cls, loss_box_reg, loss_iou)
 
     def _forward_test(self, locations, box_cls, box_regression, targets, iou_scores):
         boxes = self.box_selector_test(locations, box_cls, box_regression, iou_scores)
         loss_box_cls, loss_box_reg, loss_iou = self.loss_evaluator(
             locations, box_cls, box_regression, targets, iou_scores, self.is_first_stage)
-        return boxes, {"loss_cls": loss_box_cls, "loss_reg": loss_box_reg, "loss_iou": loss_iou}
+        return boxes, self._loss_dict(loss_box_cls, loss_box_reg, loss_iou)
+
+    def _loss_dict(self, loss_box_cls, loss_box_reg, loss_iou):
+        d = DF.LossDict(loss_cls=loss_box_cls, loss_reg=loss_box_reg, loss_iou=loss_iou)      # model/fcos.py:150-157 keys
+        d.all3 = getattr(self.loss_evaluator, "last_all3", None)
+        return d
 
     def compute_locations(self, features):
         return [self.compute_locations_per_level(f.size(-1), self.fpn_strides[l], f.device) for l, f in enumerate(features)]

@@ -38,7 +38,7 @@ def stage_plan(model, stage, lr):
 
 
 def select_loss(loss_dict, which):
-    return loss_dict["loss_iou"] if which == "loss_iou" else sum(l for l in loss_dict.values())       # main.py:222-225
+    return loss_dict["loss_iou"] if which == "loss_iou" else DF.loss_total(loss_dict)                 # main.py:222-225
 
 
 def to_device(batch, device):

@@ -46,7 +46,7 @@ def test_loss_fwd_bwd(B, T, stage, matched, seed):
     dev = torch.device("cuda:0")
     L_, R_, I_ = (flat(x).to(dev).requires_grad_() for x in (logits, reg, iou))
     levels = [(Ls[i], float(strides[i]), float(O.SIZES_OF_INTEREST[i][0]), float(O.SIZES_OF_INTEREST[i][1])) for i in range(3)]
-    l_cls, l_reg, l_iou, counts = DF.fcos_loss(L_, R_, I_, gt.to(dev), levels, B, 2.0, 0.25, 32.0, stage != 1)
+    l_cls, l_reg, l_iou, counts, all3 = DF.fcos_loss(L_, R_, I_, gt.to(dev), levels, B, 2.0, 0.25, 32.0, stage != 1)
     assert l_cls.shape == l_reg.shape == l_iou.shape == (1,)
     losses = torch.cat([l_cls, l_reg, l_iou])
     (losses * w.to(dev)).sum().backward()
@@ -64,3 +64,32 @@ def test_loss_fwd_bwd(B, T, stage, matched, seed):
     if stage != 1 and ir[0].grad is not None:
         gi = flat([x.grad for x in ir])
         np.testing.assert_allclose(I_.grad.cpu().numpy(), gi.numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_loss_total_matches_python_sum():
+    """DF.loss_total (one reduction over the (3,) view) vs sum(loss_dict.values()) of the reference loop (main.py:225):
+    same value, same input gradients; a plain dict falls back to the python sum."""
+    from drn_amd import functional as DF
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, Ls, strides = 3, (16, 8, 4), (2, 4, 8)
+    R = B * sum(Ls)
+    gt = torch.tensor([[3.0, 20.0], [0.0, 9.0], [11.0, 30.0]])
+    levels = [(Ls[i], float(strides[i]), float(O.SIZES_OF_INTEREST[i][0]), float(O.SIZES_OF_INTEREST[i][1])) for i in range(3)]
+    base = [torch.randn(R, 1, generator=g), torch.randn(R, 2, generator=g).abs() + 0.1, torch.randn(R, 1, generator=g)]
+    grads = []
+    for fused in (True, False):
+        L_, R_, I_ = (x.clone().to(dev).requires_grad_() for x in base)
+        l_cls, l_reg, l_iou, _, all3 = DF.fcos_loss(L_, R_, I_, gt.to(dev), levels, B, 2.0, 0.25, 32.0, True)
+        d = DF.LossDict(loss_cls=l_cls, loss_reg=l_reg, loss_iou=l_iou)
+        if fused:
+            d.all3 = all3
+            total = DF.loss_total(d)
+        else:
+            total = DF.loss_total(dict(d))
+        (2.5 * total).sum().backward()
+        grads.append((float(total.reshape(-1)[0]), L_.grad.clone(), R_.grad.clone(), I_.grad.clone()))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * max(1.0, abs(grads[1][0]))
+    for a, b in zip(grads[0][1:], grads[1][1:]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
