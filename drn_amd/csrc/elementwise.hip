@@ -358,7 +358,7 @@ extern "C" int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, in
 // ---------------------------------------------------------------- FPN top-down backward: dst[s,t] += src[s,2t] + src[s,2t+1]
 template <typename T>
 __global__ void pairsum_add_kernel(T* __restrict__ dst, int ld_dst, const T* __restrict__ src, int ld_src, int Mdst, int C,
-                                   int accumulate) {
+                                   int accumulate, const T* __restrict__ base = nullptr, int ld_base = 0) {
   constexpr int N = V16<T>::N;
   const int nvec = C / N;
   const long total = (long)Mdst * nvec;
@@ -366,11 +366,12 @@ __global__ void pairsum_add_kernel(T* __restrict__ dst, int ld_dst, const T* __r
     const int v = (int)(i % nvec);
     const long m = i / nvec;  // rows of src are exactly 2m, 2m+1 (sequence lengths are even)
     float d[N], a[N], b[N];
-    if (accumulate) V16<T>::load(dst + m * ld_dst + v * N, d);
+    if (base) V16<T>::load(base + m * ld_base + v * N, d);           // out of place: dst = base + pair sums
+    else if (accumulate) V16<T>::load(dst + m * ld_dst + v * N, d);
     V16<T>::load(src + (2 * m) * ld_src + v * N, a);
     V16<T>::load(src + (2 * m + 1) * ld_src + v * N, b);
 #pragma unroll
-    for (int k = 0; k < N; ++k) d[k] = accumulate ? d[k] + (a[k] + b[k]) : a[k] + b[k];
+    for (int k = 0; k < N; ++k) d[k] = (accumulate || base) ? d[k] + (a[k] + b[k]) : a[k] + b[k];
     V16<T>::store(dst + m * ld_dst + v * N, d);
   }
 }
@@ -383,6 +384,20 @@ extern "C" int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_sr
     pairsum_add_kernel<T><<<ew_blocks((long)Mdst * (C / V16<T>::N), 256), 256, 0, (hipStream_t)stream>>>((T*)dst, ld_dst, (const T*)src, ld_src, Mdst, C, accumulate);
   });
   return drn_launch_status("drn_pairsum_add");
+}
+
+// dst = base + pair sums (the same backward when the incoming gradient `base` must stay untouched: no clone + in-place add)
+extern "C" int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int ld_base, const void* src, int ld_src, int Mdst,
+                                  int C, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(dst && base && src && Mdst > 0 && C > 0, "drn_pairsum_add_to: bad args");
+  DISPATCH_DT(dtype, "drn_pairsum_add_to", {
+    DRN_CHECK_ARG(C % V16<T>::N == 0 && ld_dst % V16<T>::N == 0 && ld_src % V16<T>::N == 0 && ld_base % V16<T>::N == 0,
+                  "drn_pairsum_add_to: C/ld must be 16-byte multiples");
+    pairsum_add_kernel<T><<<ew_blocks((long)Mdst * (C / V16<T>::N), 256), 256, 0, (hipStream_t)stream>>>(
+        (T*)dst, ld_dst, (const T*)src, ld_src, Mdst, C, 0, (const T*)base, ld_base);
+  });
+  return drn_launch_status("drn_pairsum_add_to");
 }
 
 // ---------------------------------------------------------------- query-gate backward

@@ -594,8 +594,12 @@ class _MultiConvFn(torch.autograd.Function):
             B, L, Lo, M, ld, Cout = geo[l][:6]
             d = _grad_nlc(gouts[l], None, dt)
             if chain_up and l > 0:
-                d = d.clone() if d is not None else torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
-                ops.pairsum_add(d, Cout, dtot[l - 1], Cout, M, Cout, code)
+                if d is not None:                 # the incoming gradient stays untouched: out-of-place add, no clone
+                    own, d = d, torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+                    ops.pairsum_add_to(d, Cout, own, Cout, dtot[l - 1], Cout, M, Cout, code)
+                else:
+                    d = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+                    ops.pairsum_add(d, Cout, dtot[l - 1], Cout, M, Cout, code, accumulate=False)
             elif d is None:
                 d = torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
             dtot[l] = d

@@ -258,6 +258,10 @@ def pairsum_add(dst, ld_dst, src, ld_src, Mdst, C, dtype, accumulate=True):
     check(lib().drn_pairsum_add(_p(dst), ld_dst, _p(src), ld_src, Mdst, C, int(accumulate), dtype, _stream()), "drn_pairsum_add")
 
 
+def pairsum_add_to(dst, ld_dst, base, ld_base, src, ld_src, Mdst, C, dtype):
+    check(lib().drn_pairsum_add_to(_p(dst), ld_dst, _p(base), ld_base, _p(src), ld_src, Mdst, C, dtype, _stream()), "drn_pairsum_add_to")
+
+
 def gate_bwd(dG, ld_dg, act, ld_act, gate, dC, ld_dc, add, ld_add, dgate, nseq, L, C, dtype, dsum=None):
     """dC = (add or 0) + dG * gate; dgate = sum_t dG * act; dsum (nseq, C) fp32 = sum_t dG * gate."""
     check(lib().drn_gate_bwd(_p(dG), ld_dg, _p(act), ld_act, _p(gate), gate.stride(0), _p(add), ld_add, _p(dC), ld_dc, _p(dgate),

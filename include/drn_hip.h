@@ -120,6 +120,9 @@ int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, int M, int C,
                       float* ws /* >= 1024*C floats */, int dtype, void* stream);
 /* backward of F.interpolate(nearest, x2) + add (model/FPN.py:63-68): dst[s,t] += src[s,2t] + src[s,2t+1] */
 int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int accumulate, int dtype, void* stream);
+/* out-of-place form: dst[s,t] = base[s,t] + src[s,2t] + src[s,2t+1] (base = the level's own incoming gradient) */
+int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int ld_base, const void* src, int ld_src, int Mdst, int C,
+                       int dtype, void* stream);
 /* backward of the query gating x = q[:, :, None] * x (model/backbone.py:28-30):
  * dC = (add ? add : 0) + dG * gate[seq] (skipped when dC is NULL); dgate[seq][c] = sum_t dG*act;
  * dsum (optional, [nseq][C]) = sum_t dG * gate[seq]: per-clip column sums of dC's gated term (bias-gradient partials) */
