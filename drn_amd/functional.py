@@ -835,6 +835,7 @@ class _FCOSLossFn(torch.autograd.Function):
         ctx.save_for_backward(logits, reg, iou if iou is not None else logits.new_empty(0), gt, out5)
         counts = out5[3:5]
         ctx.mark_non_differentiable(counts)
+        ctx.set_materialize_grads(False)           # unused outputs arrive as None in backward, not as zero-filled tensors
         return out5[0:1], out5[1:2], out5[2:3], counts, out5[0:3]       # [4]: the three losses as one view (loss_total)
 
     @staticmethod
