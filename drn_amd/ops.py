@@ -54,6 +54,9 @@ kernel_timer = None
 # Split-K (drn_gemm_nt_splitk) only pays for long-K problems that cannot fill the chip (conv0 forward: 128 tiles x 204 K-steps -> 2.2x faster);
 # short-K ones lose more to the extra reduce launch than they gain.  DRN_SPLITK=0 disables, =all uses the old wide rule.
 SPLITK = __import__("os").environ.get("DRN_SPLITK", "1")
+# with the 8-wave 128x128 tile an unsplit launch of 48 K-steps (conv2's data gradient) beats its 4-way split + reduce;
+# the split pays from ~96 K-steps (conv0 forward: 204)
+SPLITK_MIN_KSTEPS = int(__import__("os").environ.get("DRN_SPLITK_MIN_KSTEPS", "96"))
 
 
 def _timed(tag, flops, launch):
@@ -70,7 +73,7 @@ def _ksplit(d, dtype):
     """Split-K factor for a single problem that cannot fill 256 CUs with 128x128 tiles."""
     tiles = ((d.M + 127) // 128) * ((d.N + 127) // 128)
     nkt = (d.taps * d.Cin) // (64 if dtype == BF16 else 32)
-    if tiles > 160 or nkt < (12 if SPLITK == "all" else 48):
+    if tiles > 160 or nkt < (12 if SPLITK == "all" else SPLITK_MIN_KSTEPS):
         return 1
     return max(1, min(8, 512 // tiles, nkt // 6))
 
