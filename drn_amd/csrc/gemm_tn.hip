@@ -119,7 +119,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   constexpr int R = TnMma<T>::R;
   constexpr int NW = WM * WN, TNn = WM * MI * 16, TC = WN * NI * 16;
   constexpr int IMG_Y = TNn * 128, IMG_X = TC * 128, STAGE_B = IMG_Y + IMG_X;   // bytes (R rows x 2 B or 32 rows x 4 B = 128 B/col)
-  static_assert(TNn == TC && TNn * 128 == NW * 4 * 1024, "square tiles, 4 one-KB staging pieces per wave and operand");
+  constexpr int PMAX = TNn * 128 / (NW * 1024);   // one-KB staging pieces per wave and operand
+  static_assert(TNn == TC && PMAX * NW * 1024 == TNn * 128 && (PMAX == 4 || PMAX == 2), "square tiles, 4 or 2 staging pieces per wave and operand");
   constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int CPR = (int)sizeof(T);       // 16-byte chunks per 16-column row piece
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;   // wave index as a scalar: LDS-DMA bases (M0) stay in SGPRs
@@ -147,11 +148,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   const T* zero = (const T*)g_zero_page;
 
   // lane-constant piece of the staging map: instr q = w*4+i covers chunks p = q*64 + l
-  int s_r[4];
-  long y_off[4], x_off[4];          // column offsets inside a row (or -1 when the 16-column block is out of range)
+  int s_r[PMAX];
+  long y_off[PMAX], x_off[PMAX];          // column offsets inside a row (or -1 when the 16-column block is out of range)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = w * 4 + i;
+  for (int i = 0; i < PMAX; ++i) {
+    const int q = w * PMAX + i;
     const int within = (q & 1) * 64 + l;
     const int col = (q >> 1) * 16 + (within % CPR) * CH;
     s_r[i] = within / CPR;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
 #pragma unroll
   for (int i = 1; i < DRN_MAX_GROUPS; ++i)
     if (i < P.ngroups && blk_lo >= P.g[i].blk_start) s_g = i;
-  int s_seq[4], s_t[4];             // of row (block base + s_r[i]) in the current group
+  int s_seq[PMAX], s_t[PMAX];             // of row (block base + s_r[i]) in the current group
   // the current group's fields live in registers (see conv_wgrad3_tn_kernel: run-time indexing of P.g[] inside the block
   // loop costs scalar loads whose lgkmcnt(0) waits also drain the LDS reads in flight)
   const T* g_Y;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
     g_next = s_g + 1 < P.ngroups ? P.g[s_g + 1].blk_start : 0x7fffffff;
     const int mbase = (s_blk - G.blk_start) * R;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PMAX; ++i) {
       const int m = mbase + s_r[i];
       s_seq[i] = m / G.Lout;
       s_t[i] = m - s_seq[i] * G.Lout;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
     const T* __restrict__ Yg = g_Y;
     const T* __restrict__ Xg = g_X;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PMAX; ++i) {
       const int m = mbase + s_r[i];
       const bool min_ = live & (m < g_M);
       const bool oky = min_ & (y_off[i] >= 0);
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
       const int st = s_t[i] * P.stride + tap - P.pad;
       const bool okx = min_ & (x_off[i] >= 0) & (st >= 0) & (st < g_Lsrc);
       const T* xs = okx ? Xg + ((long)(s_seq[i] * g_Lsrc + st) * g_ldx + x_off[i]) : zero;
-      glds16(ys, Ys + (w * 4 + i) * 1024);
-      glds16(xs, Xs + (w * 4 + i) * 1024);
+      glds16(ys, Ys + (w * PMAX + i) * 1024);
+      glds16(xs, Xs + (w * PMAX + i) * 1024);
     }
     // advance to the next row block
     ++s_blk;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
     } else {
       const int Lout = g_Lout;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < PMAX; ++i) {
         s_t[i] += R;
         while (s_t[i] >= Lout) {
           s_t[i] -= Lout;
@@ -254,7 +255,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   if (rowmajor && (KW % 4 == 0) && (P.Cin % 4 == 0) && (((uintptr_t)obase & 15) == 0)) {
     // coalesced: each wave transposes its 64-column slab through a private LDS patch (32 rows at a time) and writes
     // 16-byte row segments instead of 64 scattered 4-byte stores per lane
-    constexpr int PITCH = 64 * 4 + 16;
+    constexpr int WCOLS = NI * 16;            // columns owned by one wave
+    constexpr int PITCH = WCOLS * 4 + 16;
+    constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;
     __syncthreads();
     char* wbuf = smem + w * (32 * PITCH);
 #pragma unroll
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
             *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCH) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // per-wave patch: in-order LDS, no workgroup barrier needed
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {          // 16 lanes per 64-float row, 4 rows per instruction
-        const int rl = it * 4 + (l >> 4), cv = l & 15;
+      for (int it = 0; it < 32 / RPI; ++it) {   // LPR lanes per row, RPI rows per instruction
+        const int rl = it * RPI + l / LPR, cv = l % LPR;
         const int n = nrow0 + rl, c = c0 + wc * (NI * 16) + cv * 4;
         if (n < P.N && c < P.Cin) {             // Cin % 4 == 0: a quad never crosses the row end
           const f32x4 v = *(const f32x4*)(wbuf + rl * PITCH + cv * 16);
@@ -880,6 +883,8 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
     (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float, 2, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
   dim3 grid(cdiv(N, tile), taps * P.ctiles, ns);
@@ -887,7 +892,11 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
     if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 4, 8, 4><<<grid, 512, 2 * 65536, stream>>>(P);
     else conv_wgrad_tn_kernel<float, 2, 4, 8, 4><<<grid, 512, 2 * 65536, stream>>>(P);
   } else {
-    if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+    const bool w8 = !(getenv("DRN_TN_WAVES") && atoi(getenv("DRN_TN_WAVES")) == 4);     // 8 waves per 128x128 tile (default)
+    if (w8) {
+      if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
+      else conv_wgrad_tn_kernel<float, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
+    } else if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
     else conv_wgrad_tn_kernel<float, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
   }
   int rc = drn_launch_status("drn_gemm_wgrad");
