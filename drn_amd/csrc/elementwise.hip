@@ -271,6 +271,28 @@ extern "C" int drn_pos_embed_fwd(const float* feat, const float* W, const float*
   return drn_launch_status("drn_pos_embed_fwd");
 }
 
+// Stream `bytes` of a buffer through the caches at HBM speed (16-byte loads, nothing written): the bf16 copy of the
+// prop_fc weight is 2.9 ms old when the next forward needs it and long evicted from the 256 MB Infinity Cache; pulling its
+// 32 MB back in right before the GEMM costs ~8 us and saves the GEMM ~29 us of first-touch latency (296 -> 267 us).
+__global__ __launch_bounds__(256) void touch_kernel(const uint4* __restrict__ p, long n16, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;      // keeps the loads alive; practically never stores
+}
+extern "C" int drn_touch(const void* p, int64_t bytes, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(p && bytes >= 0 && (((uintptr_t)p) & 15) == 0, "drn_touch: bad args (16-byte aligned buffer expected)");
+  if (bytes < 16) return DRN_OK;
+  static unsigned* sink = nullptr;
+  if (!sink) (void)hipMalloc(&sink, 16);
+  const long n16 = bytes / 16;
+  touch_kernel<<<ew_blocks(n16, 256), 256, 0, (hipStream_t)stream>>>((const uint4*)p, n16, sink);
+  return drn_launch_status("drn_touch");
+}
+
 // feat[m] = (float)[start, end, end - start] from the proposal boundaries (model/main_model.py:51-55 builds it with a
 // subtraction, a cat and a cast: three launches of a few hundred elements each)
 template <typename S>

@@ -255,6 +255,7 @@ import os
 
 # prop_fc weight gradient through the NT kernel on transposed operands (bf16 only); DRN_NT_WGRAD=0 keeps the TN kernel
 NT_WGRAD = os.environ.get("DRN_NT_WGRAD", "1") == "1"
+TOUCH_W = os.environ.get("DRN_TOUCH_W", "1") == "1"          # warm the prop_fc weight copy right before its GEMM
 
 # BatchNorm `num_batches_tracked` increments are collected during a forward pass and applied by ONE multi-tensor add
 # (flush_bn_counters) instead of one tiny launch per BN call.
@@ -678,6 +679,8 @@ class _InputStageFn(torch.autograd.Function):
         elif xc.dtype != dtype:
             xc = ops.cast(xc.float(), code)
         wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
+        if TOUCH_W and code == ops.BF16:
+            ops.touch(wfc)                                 # 2.9 ms old and evicted: ~8 us here saves the GEMM ~29 us
         G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
         Z = torch.empty((B, T, D), dtype=dtype, device=dev)
         ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),
@@ -713,6 +716,7 @@ class _InputStageFn(torch.autograd.Function):
                 dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
                 ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
                 dZT = ops.transpose2d(dZ.view(B * T, D), code)
+            # (warming x^T the same way -- 64 MB, 13 us -- buys this GEMM exactly those 13 us back: not done)
             ops.gemm_nt([ops.gemm_desc(dZT, xcT, dW, D, D, B * T, out_f32=True)], code)
         else:
             dZ = torch.empty((B, T, D), dtype=dtype, device=dev)

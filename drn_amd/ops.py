@@ -238,6 +238,11 @@ def skinny_ok(M, N, K):
     return SKINNY and M <= 64 and N % 16 == 0 and K % 64 == 0
 
 
+def touch(t):
+    """Stream a tensor through the caches (drn_touch)."""
+    check(lib().drn_touch(_p(t), ctypes.c_int64(t.numel() * t.element_size()), _stream()), "drn_touch")
+
+
 def pos_feat(start_end):
     """(B, T, 2) fp64 / fp32 proposal boundaries -> (B, T, 3) fp32 [start, end, end - start] (main_model.py:51-55)."""
     _need_gpu(start_end)

@@ -109,6 +109,9 @@ typedef struct {
   int64_t ldo; /* elements between consecutive (a,b) rows of out; 0 = contiguous (C) */
 } DrnPackDesc;
 int drn_pack_weights(const DrnPackDesc* items /*host*/, int n, int dtype, void* stream);
+/* Read `bytes` (16-byte aligned buffer) through the caches and discard: warms an operand that was written long ago (the
+ * bf16 weight copy of prop_fc) right before the GEMM that streams it. */
+int drn_touch(const void* p, int64_t bytes, void* stream);
 /* feat[m][3] = (float)[start, end, end - start] from props_start_end (M x 2, fp64 or fp32): the position features of
  * model/main_model.py:51-55 in one launch (the reference: subtraction, torch.cat, .float()). */
 int drn_pos_feat(const void* start_end, int is_f64, float* feat, int M, void* stream);
