@@ -681,6 +681,7 @@ class _InputStageFn(torch.autograd.Function):
         wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
         if TOUCH_W and code == ops.BF16:
             ops.touch(wfc)                                 # 2.9 ms old and evicted: ~8 us here saves the GEMM ~29 us
+            # (doing the same for the other forward weight copies -- 20 MB in a handful of launches -- measured 10 us SLOWER)
         G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
         Z = torch.empty((B, T, D), dtype=dtype, device=dev)
         ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),
