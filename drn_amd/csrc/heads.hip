@@ -33,8 +33,27 @@ __device__ __forceinline__ int head_group_of(const HeadParams& P, int r) {
 // in registers), a wavefront owns a run of consecutive rows of the level-concatenated row space.
 #define HEAD_RPW 8     // rows per wavefront (forward / data gradient)
 
+#define HEAD_LDS_C 1024   // channel counts up to this stage the weights through LDS
+
+// A lane's N x taps x VN weights.  W is the parameter layout [N][C][taps]: gathered straight from global memory that is
+// N*taps*VN four-byte loads at a stride of `taps` floats PER LANE (48 load instructions per wave for 8 rows of work -- the
+// dominant cost of these GEMV-shaped kernels).  Instead the workgroup copies W once, coalesced, into LDS re-laid as
+// [N][taps][C] (head_stage_w, called by every thread before any early return); a lane then reads VN consecutive floats
+// per (n, tap).
+__device__ __forceinline__ void head_stage_w(const float* __restrict__ W, int C, int taps, int N, float* sW) {
+  if (C <= HEAD_LDS_C) {
+    const int total = N * C * taps;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int tp = i % taps, nc = i / taps;          // i = (n*C + c)*taps + tp
+      const int c = nc % C, n = nc / C;
+      sW[(n * taps + tp) * C + c] = W[i];
+    }
+  }
+  __syncthreads();
+}
+
 template <typename T>
-__device__ __forceinline__ void head_load_w(const float* __restrict__ W, int C, int taps, int N, int c0, bool live,
+__device__ __forceinline__ void head_load_w(const float* __restrict__ W, const float* sW, int C, int taps, int N, int c0, bool live,
                                             float (&wr)[HEAD_MAX_N][HEAD_MAX_TAPS][V16<T>::N]) {
   constexpr int VN = V16<T>::N;
 #pragma unroll
@@ -42,7 +61,11 @@ __device__ __forceinline__ void head_load_w(const float* __restrict__ W, int C, 
 #pragma unroll
     for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp)
 #pragma unroll
-      for (int k = 0; k < VN; ++k) wr[n][tp][k] = (live && n < N && tp < taps) ? W[((long)n * C + c0 + k) * taps + tp] : 0.f;
+      for (int k = 0; k < VN; ++k) {
+        float v = 0.f;
+        if (live && n < N && tp < taps) v = C <= HEAD_LDS_C ? sW[(n * taps + tp) * C + c0 + k] : W[((long)n * C + c0 + k) * taps + tp];
+        wr[n][tp][k] = v;
+      }
 }
 
 // dz[r][n] = exp_mode ? scale_l * out[r][n] * dout[r][n] : dout[r][n]   (chain rule of exp(scale * z))
@@ -61,6 +84,8 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
   const int N = P.N, C = P.C, taps = P.taps;
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * HEAD_RPW;
+  __shared__ float sW[HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C];
+  head_stage_w(W, C, taps, N, sW);
   if (r0 >= P.total_rows) return;
   const int nvec = C / VN;
   float acc[HEAD_RPW][HEAD_MAX_N];
@@ -72,7 +97,7 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
     const int v = vb + lane;
     const bool live = v < nvec;
     float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
-    head_load_w<T>(W, C, taps, N, v * VN, live, wr);
+    head_load_w<T>(W, sW, C, taps, N, v * VN, live, wr);
     if (!live) continue;
     // four rows at a time: all 12 source addresses first, then 12 independent 16-byte loads, then the FMAs (a masked tap
     // re-reads the row itself and is skipped in the arithmetic) -- no control flow between the loads
@@ -139,9 +164,11 @@ __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadParams
   const int N = P.N, C = P.C, taps = P.taps;
   const int v = blockIdx.x * 64 + (threadIdx.x & 63);
   const int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * HEAD_RPW;
+  __shared__ float sW[HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C];
+  head_stage_w(W, C, taps, N, sW);
   if (v * VN >= C || r0 >= P.total_rows) return;
   float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
-  head_load_w<T>(W, C, taps, N, v * VN, true, wr);
+  head_load_w<T>(W, sW, C, taps, N, v * VN, true, wr);
   // four rows at a time: the 4 x taps x N gradient scalars are fetched together (independent loads), then the FMAs
 #pragma unroll
   for (int h = 0; h < HEAD_RPW; h += 4) {
