@@ -99,6 +99,35 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
     float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
     head_load_w<T>(W, sW, C, taps, N, v * VN, live, wr);
     if (!live) continue;
+    // Sliding window (k = 3, the wave's 8 rows inside one level): rows r0-1 .. r0+8 are loaded ONCE (10 loads instead of
+    // 24: consecutive rows share two of their three taps) and every (row, tap) picks its window slot; sequence ends are
+    // handled by the same per-(row, tap) mask as below.
+    const int g_first = head_group_of(P, r0), g_last = head_group_of(P, min(r0 + HEAD_RPW, P.total_rows) - 1);
+    if (taps == 3 && P.pad == 1 && g_first == g_last && r0 + HEAD_RPW <= P.total_rows) {
+      const HeadGroup& G = P.g[g_first];
+      const int m0 = r0 - G.row_start;
+      float x[HEAD_RPW + 2][VN];
+#pragma unroll
+      for (int j = 0; j < HEAD_RPW + 2; ++j) {
+        const int m = min(max(m0 - 1 + j, 0), G.M - 1);       // clamped rows are masked below
+        V16<T>::load((const T*)G.X + (long)m * G.ldx + v * VN, x[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < HEAD_RPW; ++i) {
+        const int m = m0 + i;
+        const int t = m % G.L;
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+          const int st = t + tp - 1;
+          if (st >= 0 && st < G.L)
+#pragma unroll
+            for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+              for (int k = 0; k < VN; ++k) acc[i][n] = fmaf(x[i + tp][k], wr[n][tp][k], acc[i][n]);
+        }
+      }
+      continue;
+    }
     // four rows at a time: all 12 source addresses first, then 12 independent 16-byte loads, then the FMAs (a masked tap
     // re-reads the row itself and is skipped in the arithmetic) -- no control flow between the loads
 #pragma unroll
@@ -135,23 +164,43 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
               for (int k = 0; k < VN; ++k) acc[h + i][n] = fmaf(x[i][tp][k], wr[n][tp][k], acc[h + i][n]);
     }
   }
+  // All HEAD_RPW x HEAD_MAX_N dot products are reduced over the 64 lanes TOGETHER: at offsets 32, 16, 8, 4 a lane hands the
+  // half of its values the partner will own to it and adds what it receives (8 + 4 + 2 + 1 shuffles), then offsets 2, 1
+  // finish the single remaining value: 17 shuffles instead of 6 per value (96), same pairwise summation tree as wave_sum.
+  // Value (i, n) = index i*HEAD_MAX_N + n ends in the four lanes with (lane >> 2) == index.
+  float red[HEAD_RPW * HEAD_MAX_N];
 #pragma unroll
-  for (int i = 0; i < HEAD_RPW; ++i) {
-    const int r = r0 + i;
-    if (r >= P.total_rows) break;
-    const HeadGroup& G = P.g[head_group_of(P, r)];
+  for (int i = 0; i < HEAD_RPW; ++i)
 #pragma unroll
-    for (int n = 0; n < HEAD_MAX_N; ++n)
-      if (n < N) {
-        float v = wave_sum(acc[i][n]) + bias[n];
-        if (lane == 0) {
-          if (P.exp_mode) {
-            z[(long)r * N + n] = v;
-            v = expf(G.scale[0] * v);
-          }
-          out[(long)r * N + n] = v;
-        }
+    for (int n = 0; n < HEAD_MAX_N; ++n) red[i * HEAD_MAX_N + n] = acc[i][n];
+  static_assert(HEAD_RPW * HEAD_MAX_N == 16, "the multi-value reduction below is written for 16 values");
+#pragma unroll
+  for (int stage = 0; stage < 4; ++stage) {
+    const int off = 32 >> stage, half = 8 >> stage;
+    const bool upper = (lane & off) != 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < half) {
+        const float send = upper ? red[k] : red[k + half];
+        const float keep = upper ? red[k + half] : red[k];
+        red[k] = keep + __shfl_xor(send, off, 64);
       }
+  }
+  float tot = red[0];
+  tot += __shfl_xor(tot, 2, 64);
+  tot += __shfl_xor(tot, 1, 64);
+  if ((lane & 3) == 0) {
+    const int idx = lane >> 2, i = idx / HEAD_MAX_N, n = idx % HEAD_MAX_N;
+    const int r = r0 + i;
+    if (r < P.total_rows && n < N) {
+      const HeadGroup& G = P.g[head_group_of(P, r)];
+      float v = tot + bias[n];
+      if (P.exp_mode) {
+        z[(long)r * N + n] = v;
+        v = expf(G.scale[0] * v);
+      }
+      out[(long)r * N + n] = v;
+    }
   }
 }
 
