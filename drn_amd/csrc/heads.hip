@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
   constexpr int VN = V16<T>::N;
   const int N = P.N, C = P.C, taps = P.taps;
   const int lane = threadIdx.x & 63;
-  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * HEAD_RPW;
+  const int r0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: row bookkeeping on the scalar unit
   __shared__ float sW[HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C];
   head_stage_w(W, C, taps, N, sW);
   if (r0 >= P.total_rows) return;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadParams
   constexpr int VN = V16<T>::N;
   const int N = P.N, C = P.C, taps = P.taps;
   const int v = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * HEAD_RPW;
+  const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: the dz scalars come through the scalar cache
   __shared__ float sW[HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C];
   head_stage_w(W, C, taps, N, sW);
   if (v * VN >= C || r0 >= P.total_rows) return;
