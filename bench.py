@@ -106,9 +106,10 @@ def main():
     deferred = args.graph and world > 1
     if deferred:
         reducer = ddist.GradReducer(params, world_size=world, overlap=False, bucket_bytes=1 << 30,
-                                    groups=[model.trunk_parameters(), model.input_parameters(), model.query_parameters()])
+                                    groups=[model.trunk_parameters(), model.input_parameters(), model.query_parameters()],
+                                    adjacent=model.grad_stack_groups())
     else:
-        reducer = ddist.GradReducer(params, world_size=world, overlap=True)
+        reducer = ddist.GradReducer(params, world_size=world, overlap=True, adjacent=model.grad_stack_groups())
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-3)                      # main.py:140
     else:

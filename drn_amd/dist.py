@@ -46,11 +46,15 @@ class GradReducer(object):
     in 32 MB buckets = 5 collectives per step.
     """
 
-    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True, steal=True, groups=None):
+    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True, steal=True, groups=None,
+                 adjacent=None):
         """overlap=False defers every collective to finish() (required when backward is replayed from a hipGraph:
         hooks only run at capture time and collectives must stay outside the captured region).
         groups: optional list of parameter lists, each bucketed on its own and in the given order (`group_buckets[i]`
-        lists group i's buckets): lets a caller reduce one part of the model while another part is still in backward."""
+        lists group i's buckets): lets a caller reduce one part of the model while another part is still in backward.
+        adjacent: optional list of parameter lists that must lie back to back, in that order, inside one bucket (the
+        sources of a stacked GEMM operand, `mainModel.grad_stack_groups()`): the stacked gradient is then one slice of the
+        flat buffer and is written there directly (functional.grad_buffer)."""
         self.group = group
         self.overlap = overlap
         # steal=True: p.grad is None at the start of backward; backward kernels that know the sink write straight into
@@ -63,12 +67,25 @@ class GradReducer(object):
         wanted = set(id(p) for p in self.params)
         plan = [self.params] if groups is None else [[p for p in g if id(p) in wanted] for g in groups]
         assert sum(len(g) for g in plan) == len(self.params), "groups must partition the trainable parameters"
+        adj_of = {}
+        for grp in (adjacent or []):
+            grp = [p for p in grp if id(p) in wanted]
+            if len(grp) > 1 and all(p.numel() % 4 == 0 for p in grp[:-1]):      # 4-element alignment padding would split them
+                for p in grp:
+                    adj_of[id(p)] = grp
         for part in plan:
             first = len(self.buckets)
             cur, cur_bytes = [], 0
+            in_part, placed = set(id(p) for p in part), set()
             for p in reversed(part):                          # roughly the order backward produces gradients
-                cur.append(p)
-                cur_bytes += p.numel() * p.element_size()
+                if id(p) in placed:
+                    continue
+                grp = adj_of.get(id(p))
+                run = grp if grp is not None and all(id(q) in in_part for q in grp) else [p]
+                for q in run:
+                    placed.add(id(q))
+                    cur.append(q)
+                    cur_bytes += q.numel() * q.element_size()
                 if cur_bytes >= bucket_bytes:
                     self._make_bucket(cur)
                     cur, cur_bytes = [], 0

@@ -244,10 +244,25 @@ def clear_grad_sinks():
 
 
 def grad_buffer(param, dtype=torch.float32):
-    """Uninitialised fp32 buffer shaped like `param` for its gradient: the registered sink when there is one."""
+    """Uninitialised fp32 buffer shaped like `param` for its gradient: the registered sink when there is one.  For a
+    `stack_params` view: the sinks of its sources when they lie back to back in that order (drn_amd.dist.GradReducer puts
+    `adjacent=` groups that way), so the stacked gradient is written straight into the flat bucket and the per-source
+    views autograd hands to the parameters ARE their sinks (no copy into the bucket afterwards)."""
     sink = _grad_sinks.get(param.data_ptr())
     if sink is not None and sink.numel() == param.numel() and sink.dtype == dtype and sink.device == param.device:
         return sink.view(param.shape)
+    srcs = getattr(param, "_drn_stack_of", None)
+    if srcs:
+        sinks = [_grad_sinks.get(p.data_ptr()) for p in srcs]
+        if all(s is not None and s.numel() == p.numel() and s.dtype == dtype and s.device == param.device
+               for s, p in zip(sinks, srcs)) and \
+                all(a.data_ptr() + a.numel() * a.element_size() == b.data_ptr() for a, b in zip(sinks, sinks[1:])) and \
+                sum(s.numel() for s in sinks) == param.numel():
+            strides, acc = [], 1
+            for d in reversed(param.shape):
+                strides.append(acc)
+                acc *= d
+            return sinks[0].as_strided(tuple(param.shape), tuple(reversed(strides)), sinks[0].storage_offset())
     return torch.empty(param.shape, dtype=dtype, device=param.device)
 
 
@@ -477,7 +492,7 @@ class _ConvBlockFn(torch.autograd.Function):
         side = side_stream(dev) if FORK_WGRAD else main
         side.wait_stream(main) if side is not main else None
         with torch.cuda.stream(side):
-            dW = grad_buffer(weight)
+            dW = grad_buffer(ctx.weight_obj if getattr(ctx.weight_obj, "_drn_stack_of", None) else weight)
             wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
                       for l in range(nl)]
             ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)

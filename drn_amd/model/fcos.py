@@ -59,6 +59,14 @@ class FCOSHead(torch.nn.Module):
         if num_classes != 1:
             raise NotImplementedError("DRN uses a single foreground class (fcos_num_class=2)")
 
+    def grad_stack_groups(self):
+        """Parameter groups whose gradients are produced as ONE stacked tensor (the towers' first convs, see _towers): hand
+        them to GradReducer(adjacent=...) so that stack is a slice of the flat gradient bucket."""
+        if len(self.cls_tower) // 3 != 1:
+            return []
+        cc, cb, bc, bb = self.cls_tower[0], self.cls_tower[1], self.bbox_tower[0], self.bbox_tower[1]
+        return [[cc.weight, bc.weight], [cc.bias, bc.bias], [cb.weight, bb.weight], [cb.bias, bb.bias]]
+
     # -- towers -----------------------------------------------------------------------------------------
     def _towers(self, xs):
         """cat(cls_tower(x), bbox_tower(x)) per level as ONE implicit GEMM with N = 2C: the two towers' first

@@ -69,6 +69,10 @@ class mainModel(nn.Module):
     def front_parameters(self):
         return self.query_parameters() + self.input_parameters()
 
+    def grad_stack_groups(self):
+        """For GradReducer(adjacent=...): parameters whose gradients are computed as one stacked tensor."""
+        return self.fcos.head.grad_stack_groups()
+
     def trunk_parameters(self):
         front = set(id(p) for p in self.front_parameters())
         return [p for p in self.parameters() if id(p) not in front]

@@ -131,3 +131,21 @@ def test_grad_reducer_groups_two_phase_world2_gloo():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_adjacent_groups_are_contiguous_in_the_bucket():
+    """GradReducer(adjacent=[[a, b], ...]): the members of a group occupy consecutive slices of one flat bucket in the given
+    order (no alignment padding between them), whatever their position in the parameter list; everything is still
+    covered exactly once."""
+    from drn_amd.dist import GradReducer
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(*shape)) for shape in [(8, 4), (3,), (16, 4, 3), (5,), (16, 4, 3), (12,), (12,)]]
+    groups = [[ps[4], ps[2]], [ps[6], ps[5]]]
+    red = GradReducer(ps, world_size=1, bucket_bytes=64, adjacent=groups)
+    for a, b in groups:
+        (ba, ia), (bb, ib) = red._of[a], red._of[b]
+        assert ba is bb and ib == ia + 1
+        assert ba.offsets[ia] + a.numel() == ba.offsets[ib]
+    seen = [id(p) for b in red.buckets for p in b.params]
+    assert sorted(seen) == sorted(id(p) for p in ps) and len(seen) == len(set(seen))
+    red.remove()

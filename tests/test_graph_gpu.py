@@ -182,3 +182,38 @@ def test_two_phase_step_equals_single_backward(stage):
     l = run()                                 # ... replayed on batch B
     check("replay")
     assert calls[-2:] == [0, 1] and len(calls) >= 8 and torch.isfinite(l["loss_cls"]).all()
+
+
+def test_adjacent_stack_groups_write_gradients_in_place():
+    """GradReducer(adjacent=mainModel.grad_stack_groups()): the sources of the stacked tower conv lie back to back in the
+    flat bucket, so the stacked weight gradient is written there directly (functional.grad_buffer) instead of being copied
+    in afterwards.  Every parameter gradient must equal the default layout's, bit for bit (same kernels, same inputs)."""
+    from drn_amd.dist import GradReducer
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    dev = "cuda:0"
+    grads = []
+    for adjacent in (False, True):
+        m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", 64, 3)), compute_dtype=torch.bfloat16)
+        m.load_state_dict(seeded_state_dict(m, 0))
+        m = m.to(dev).train()
+        params = [p for p in m.parameters() if p.requires_grad]
+        groups = m.grad_stack_groups()
+        assert groups and all(len(g) == 2 for g in groups)
+        red = GradReducer(params, world_size=1, adjacent=groups if adjacent else None)
+        batch = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=1)]
+        red.zero()
+        _, losses = m(*batch)
+        sum(losses.values()).backward()
+        if adjacent:       # the conv weights of the two towers: gradient views already inside the bucket, back to back
+            a, b = groups[0]
+            assert a.grad.data_ptr() + a.grad.numel() * 4 == b.grad.data_ptr()
+            sink = red._of[a][0].views[red._of[a][1]]
+            assert a.grad.data_ptr() == sink.data_ptr()
+        red.finish()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        red.remove()
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
