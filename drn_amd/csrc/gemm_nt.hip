@@ -566,12 +566,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   T* Cg = (T*)pr.C;
   T* C2g = (T*)pr.C2;
+  // vector path: N, the output row strides and bases allow aligned 4-element accesses for every quad
+  const bool vec = (N % 4 == 0) && (pr.ldc % 4 == 0) && (((uintptr_t)Cg) % 16 == 0) && (((uintptr_t)ws) % 16 == 0) &&
+                   (!C2g || ((pr.ldc2 % 4 == 0) && (((uintptr_t)C2g) % 16 == 0)));
+  auto st4 = [](T* dst, const float (&v)[4]) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 b;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) b[k] = (bf16_t)v[k];
+      *(bf16x4*)dst = b;
+    } else {
+      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+    }
+  };
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int m = mbase + ry + 16 * j;
 #pragma unroll
     for (int k = 0; k < 4; ++k) vals[j][k] = 0.f;
     if (n < N && m < M) {
+      if (vec) {                                  // whole quads, 16-byte aligned: one load per split (same z order)
+        for (int z = 0; z < ksplit; ++z) {
+          const f32x4 q = *(const f32x4*)(ws + ((long)z * M + m) * N + n);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) vals[j][k] += q[k];
+        }
+      } else
       for (int z = 0; z < ksplit; ++z) {
         const float* p = ws + ((long)z * M + m) * N + n;
 #pragma unroll
@@ -579,6 +599,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
           if (n + k < N) vals[j][k] += p[k];
       }
       const float* grow = pr.gate ? pr.gate + (long)(m / pr.Lout) * pr.ldg : nullptr;
+      if (vec && !pr.accumulate) {
+        // packed stores: 4 outputs per lane in one 8-byte (bf16) / 16-byte (f32) store instead of four scalar ones
+        float o[4], o2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          cs[k] += vals[j][k];
+          o2[k] = vals[j][k] + (pr.bias ? pr.bias[n + k] : 0.f);
+          o[k] = grow ? o2[k] * grow[n + k] : o2[k];
+        }
+        if (C2g) st4(C2g + ((long)m * pr.ldc2 + n), o2);
+        st4(Cg + ((long)m * pr.ldc + n), o);
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (n + k >= N) continue;
