@@ -433,9 +433,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
                                                        T* __restrict__ dC, int ld_dc, float* __restrict__ dgate, int ld_dgate,
                                                        float* __restrict__ dsum, int L, int C) {
   constexpr int N = V16<T>::N;
-  __shared__ float red[8][32 * N + 1];
-  const int vx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int v = blockIdx.x * 32 + vx;
+  // 16 channel vectors x 16 row lanes per workgroup (was 32 x 8): twice the workgroups and half the sequential row trips --
+  // at 64-128 workgroups of 16 dependent trips each the launch was pure latency (21 us for 8 MB)
+  constexpr int VX = 16, RY = 16;
+  __shared__ float red[RY][VX * N + 1];
+  const int vx = threadIdx.x & (VX - 1), ry = threadIdx.x / VX;
+  const int v = blockIdx.x * VX + vx;
   const int s = blockIdx.y;
   const int c0 = v * N;
   const bool live = c0 < C;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
   }
   if (live) {
 #pragma unroll 4
-    for (int t = ry; t < L; t += 8) {
+    for (int t = ry; t < L; t += RY) {
       const long m = (long)s * L + t;
       float g[N], a[N];
       V16<T>::load(dG + m * ld_dg + c0, g);
@@ -470,12 +473,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
 #pragma unroll
   for (int k = 0; k < N; ++k) red[ry][vx * N + k] = acc[k];
   __syncthreads();
-  for (int i = threadIdx.x; i < 32 * N; i += 256) {
-    const int c = blockIdx.x * 32 * N + i;
+  for (int i = threadIdx.x; i < VX * N; i += 256) {
+    const int c = blockIdx.x * VX * N + i;
     if (c < C) {
       float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) sum += red[r][i];
+      for (int r = 0; r < RY; ++r) sum += red[r][i];
       dgate[(long)s * ld_dgate + c] = sum;
     }
   }
@@ -484,12 +487,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
 #pragma unroll
     for (int k = 0; k < N; ++k) red[ry][vx * N + k] = cs[k] * gt[k];
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * N; i += 256) {
-      const int c = blockIdx.x * 32 * N + i;
+    for (int i = threadIdx.x; i < VX * N; i += 256) {
+      const int c = blockIdx.x * VX * N + i;
       if (c < C) {
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) sum += red[r][i];
+        for (int r = 0; r < RY; ++r) sum += red[r][i];
         dsum[(long)s * C + c] = sum;
       }
     }
@@ -504,7 +507,7 @@ extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_a
     constexpr int N = V16<T>::N;
     DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && (!dC || ld_dc % N == 0) && (!add || ld_add % N == 0),
                   "drn_gate_bwd: C/ld must be 16-byte multiples");
-    dim3 grid(cdiv(C / N, 32), nseq);
+    dim3 grid(cdiv(C / N, 16), nseq);
     gate_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (const T*)add,
                                                                 ld_add, (T*)dC, ld_dc, dgate, ld_dgate, dsum, L, C);
   });
