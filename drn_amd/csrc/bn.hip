@@ -42,22 +42,55 @@ __global__ __launch_bounds__(256 * DRN_MAX_GROUPS) void bn_finalize_kernel(const
   const bool live = c < C;
   const BnFinGroup& G = P.g[g];                     // blockDim.x = 256 * ngroups
   // slab k holds (sum, M2 about the slab mean) of n_k = min(128, M - 128 k) rows; merge in double (Chan et al.)
+  // Up to 128 slabs (16384 rows): a thread's <= 8 (sum, M2) pairs are loaded ONCE, all loads in flight together, and kept in
+  // registers for the second pass (the kernel is a pure latency chain: two dependent trips to memory cost ~2 us of its 8).
+  constexpr int KMAX = 8;
+  const int tiles = G.tiles, Mrows = G.M;
+  const float* __restrict__ st = G.stats;
+  const bool cached = tiles <= 16 * KMAX;
+  float c0[KMAX], c1[KMAX];
   double s = 0.0;
-  if (live)
-    for (int k = j; k < G.tiles; k += 16) s += (double)G.stats[((long)k * 2 + 0) * C + c];
+  if (live) {
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        const int k = j + 16 * i;
+        c0[i] = k < tiles ? st[((long)k * 2 + 0) * C + c] : 0.f;
+        c1[i] = k < tiles ? st[((long)k * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i)
+        if (j + 16 * i < tiles) s += (double)c0[i];
+    } else {
+      for (int k = j; k < tiles; k += 16) s += (double)st[((long)k * 2 + 0) * C + c];
+    }
+  }
   sh[g][ci][j] = s;
   __syncthreads();
   double mean = 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) mean += sh[g][ci][k];
-  mean /= G.M;
+  mean /= Mrows;
   double q = 0.0;
-  if (live)
-    for (int k = j; k < G.tiles; k += 16) {
-      const int nt = min(128, G.M - k * 128);
-      const double d = (double)G.stats[((long)k * 2 + 0) * C + c] / nt - mean;
-      q += (double)G.stats[((long)k * 2 + 1) * C + c] + nt * d * d;
+  if (live) {
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        const int k = j + 16 * i;
+        if (k < tiles) {
+          const int nt = min(128, Mrows - k * 128);
+          const double d = (double)c0[i] / nt - mean;
+          q += (double)c1[i] + nt * d * d;
+        }
+      }
+    } else {
+      for (int k = j; k < tiles; k += 16) {
+        const int nt = min(128, Mrows - k * 128);
+        const double d = (double)st[((long)k * 2 + 0) * C + c] / nt - mean;
+        q += (double)st[((long)k * 2 + 1) * C + c] + nt * d * d;
+      }
     }
+  }
   __syncthreads();
   sh[g][ci][j] = q;
   __syncthreads();
