@@ -388,11 +388,28 @@ __global__ __launch_bounds__(256 * DRN_MAX_GROUPS) void bn_bwd_finalize_kernel(c
   const bool live = c < C;
   const BnBwdLv& G = P.lv[li];                      // blockDim.x = 256 * n
   double sg = 0.0, sx = 0.0;
-  if (live)
-    for (int b = j; b < G.nblk; b += 16) {
-      sg += (double)G.partial[((long)b * 2 + 0) * C + c];
-      sx += (double)G.partial[((long)b * 2 + 1) * C + c];
+  if (live) {
+    const int nblk = G.nblk;
+    const float* __restrict__ pp = G.partial;
+    int b = j;
+    for (; b + 16 * 3 < nblk; b += 16 * 4) {          // four independent pairs of loads in flight per trip
+      float v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v0[u] = pp[((long)(b + 16 * u) * 2 + 0) * C + c];
+        v1[u] = pp[((long)(b + 16 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sg += (double)v0[u];
+        sx += (double)v1[u];
+      }
     }
+    for (; b < nblk; b += 16) {
+      sg += (double)pp[((long)b * 2 + 0) * C + c];
+      sx += (double)pp[((long)b * 2 + 1) * C + c];
+    }
+  }
   sh[li][0][ci][j] = sg;
   sh[li][1][ci][j] = sx;
   __syncthreads();
