@@ -652,6 +652,7 @@ __global__ void wgrad_reduce_multi_kernel(const WgradReduceMulti R, int N, int C
       const int c = (int)(idx - n * Cin);
       const float* p = ws + n * KW + c;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
       for (int z = 0; z < nsplit; ++z) {
         s0 += p[(long)z * total];
         s1 += p[(long)z * total + Cin];
@@ -698,6 +699,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
       const int c = (int)(idx - n * Cin);
       const float* p = ws + n * KW + c;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
       for (int z = 0; z < nsplit; ++z) {
         s0 += p[(long)z * total];
         s1 += p[(long)z * total + Cin];

@@ -367,8 +367,17 @@ __global__ __launch_bounds__(256) void head_out_bwd_w_final_kernel(const float* 
   const int oi = threadIdx.x & 15, j = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + oi;
   float s = 0.f;
-  if (i < total)
-    for (int b = j; b < nblk; b += 16) s += partial[(long)b * total + i];
+  if (i < total) {
+    int b = j;
+    for (; b + 16 * 3 < nblk; b += 16 * 4) {      // four independent loads in flight per trip
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = partial[(long)(b + 16 * u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u];
+    }
+    for (; b < nblk; b += 16) s += partial[(long)b * total + i];
+  }
   sh[oi][j] = s;
   __syncthreads();
   if (j != 0 || i >= total) return;
