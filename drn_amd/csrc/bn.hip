@@ -349,12 +349,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams P)
     sg[k] = 0.f;
     sx[k] = 0.f;
   }
-  if (live)
-#pragma unroll 2
-    for (int m = r0 + ry; m < r1; m += 4) {
+  if (live) {
+    const long ldd = G.ld_dout, ldr = G.ld_raw;       // (kept in registers: G is indexed by a run-time level number)
+    int m = r0 + ry;
+    for (; m + 12 < r1; m += 16) {                    // four rows = eight 16-byte loads in flight per trip
+      float g[4][N], x[4][N];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        V16<T>::load(dout + (long)(m + 4 * u) * ldd + c0, g[u]);
+        V16<T>::load(raw + (long)(m + 4 * u) * ldr + c0, x[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const float gg = (relu && !(fmaf(x[u][k], sc[k], sh[k]) > 0.f)) ? 0.f : g[u][k];
+          sg[k] += gg;
+          sx[k] = fmaf(gg, (x[u][k] - mean[k]) * istd[k], sx[k]);
+        }
+    }
+    for (; m < r1; m += 4) {
       float g[N], x[N];
-      V16<T>::load(dout + (long)m * G.ld_dout + c0, g);
-      V16<T>::load(raw + (long)m * G.ld_raw + c0, x);
+      V16<T>::load(dout + (long)m * ldd + c0, g);
+      V16<T>::load(raw + (long)m * ldr + c0, x);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams P)
         sx[k] = fmaf(gg, (x[k] - mean[k]) * istd[k], sx[k]);
       }
     }
+  }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     red[0][ry][vx * N + k] = sg[k];
@@ -483,6 +501,8 @@ static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* w
   memset(&P, 0, sizeof(P));
   P.n = n; P.C = C; P.relu = relu;
   int yb = 0, ab = 0;
+  long m_all = 0;
+  for (int i = 0; i < n; ++i) m_all += d[i].M;
   for (int i = 0; i < n; ++i) {
     const DrnBnBwdDesc& s = d[i];
     DRN_CHECK_ARG(s.dout && s.raw && s.scale_shift && s.save && s.gamma && s.draw && s.M > 0, "%s: bad level %d", who, i);
@@ -491,7 +511,11 @@ static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* w
     G.dout = s.dout; G.raw = s.raw; G.draw = s.draw; G.ss = s.scale_shift; G.save = s.save; G.gamma = s.gamma;
     G.dgamma = s.dgamma; G.dbeta = s.dbeta; G.ld_dout = s.ld_dout; G.ld_raw = s.ld_raw; G.ld_draw = s.ld_draw; G.M = s.M;
     G.accumulate = s.accumulate;
-    G.nblk = s.M >= 256 * 16 ? 256 : (s.M >= 16 ? s.M / 16 : 1);
+    // row blocks: 16 rows each (4 per row lane), 64 when the launch has two or more column blocks and many rows -- the shared
+    // head's 14336 x 1024 gradient went as 1280 workgroups of 4-8 rows per thread and took 31 us for 59 MB
+    const long cbk = cdiv(C / vn, 64);
+    const int rows_blk = cbk * (m_all / 64) >= 256 ? 64 : (cbk * (m_all / 32) >= 256 ? 32 : 16);   // (the coarsest that still fills the chip)
+    G.nblk = s.M >= 256 * rows_blk ? 256 : (s.M >= rows_blk ? s.M / rows_blk : 1);
     G.partial = ws + (long)i * (2 * 256 + 3) * C;
     G.coef = G.partial + (long)2 * 256 * C;
     G.yblk0 = yb; G.ablk0 = ab;
