@@ -109,7 +109,9 @@ def main():
                                     groups=[model.trunk_parameters(), model.input_parameters(), model.query_parameters()],
                                     adjacent=model.grad_stack_groups())
     else:
-        reducer = ddist.GradReducer(params, world_size=world, overlap=True, adjacent=model.grad_stack_groups())
+        # one process: nothing to overlap, so ONE bucket (one norm pass + one Adam launch instead of one pair per 32 MB)
+        reducer = ddist.GradReducer(params, world_size=world, overlap=True, adjacent=model.grad_stack_groups(),
+                                    **({"bucket_bytes": 1 << 30} if world == 1 else {}))
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-3)                      # main.py:140
     else:

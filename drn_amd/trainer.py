@@ -57,7 +57,8 @@ class Trainer(object):
         if self.fused:
             from .dist import GradReducer
             from .optim import FusedAdam
-            self.reducer = GradReducer(self.params, world_size=world_size, adjacent=model.grad_stack_groups())
+            self.reducer = GradReducer(self.params, world_size=world_size, adjacent=model.grad_stack_groups(),
+                                       **({"bucket_bytes": 1 << 30} if world_size == 1 else {}))   # one process: one bucket
             self.opt = FusedAdam(self.reducer, lr=self.lr, max_norm=clip_gradient if clip_gradient is not None else 0.0)
         else:
             DF.clear_grad_sinks()
