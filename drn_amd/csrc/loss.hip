@@ -246,3 +246,68 @@ extern "C" int drn_fcos_loss_bwd(const DrnLossLevel* levels, int nlevels, int B,
                                                                                  dreg, diou);
   return drn_launch_status("drn_fcos_loss_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Class-general sigmoid focal loss with the call shape of the reference's only FFI, fcos_core._C.sigmoid_focalloss_forward /
+// _backward (model/layers/sigmoid_focal_loss.py:18-20,31-33): per-element losses over logits (N, C) with int32 class
+// targets (0 = background, c in 1..C = foreground class c, negative = ignored).  Same function as the in-repo formula
+// (sigmoid_focal_loss.py:40-52), written through softplus so that |logit| > 88 stays finite: -log p = softplus(-x),
+// -log(1-p) = softplus(x).
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ targets, long total,
+                                                        int C, float gamma, float alpha, float* __restrict__ losses) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / C;
+    const int cls = (int)(i - n * C) + 1;
+    const int t = targets[n];
+    const float x = logits[i];
+    const float p = 1.f / (1.f + expf(-x));
+    float v = 0.f;
+    if (t == cls) v = alpha * powf(1.f - p, gamma) * softplus(-x);
+    else if (t >= 0) v = (1.f - alpha) * powf(p, gamma) * softplus(x);
+    losses[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
+                                                        const float* __restrict__ d_losses, long total, int C, float gamma, float alpha,
+                                                        float* __restrict__ d_logits) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / C;
+    const int cls = (int)(i - n * C) + 1;
+    const int t = targets[n];
+    const float x = logits[i];
+    const float p = 1.f / (1.f + expf(-x));
+    float dx = 0.f;
+    if (t == cls) {
+      const float om = 1.f - p;
+      dx = alpha * powf(om, gamma) * (-gamma * p * softplus(-x) - om);
+    } else if (t >= 0) {
+      dx = (1.f - alpha) * powf(p, gamma) * (gamma * (1.f - p) * softplus(x) + p);
+    }
+    d_logits[i] = dx * d_losses[i];
+  }
+}
+
+extern "C" int drn_focal_fwd(const float* logits, const int32_t* targets, int64_t N, int num_classes, float gamma, float alpha,
+                             float* losses, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(N >= 0 && num_classes >= 1, "drn_focal_fwd: bad shape N=%lld C=%d", (long long)N, num_classes);
+  if (N == 0) return DRN_OK;
+  DRN_CHECK_ARG(logits && targets && losses, "drn_focal_fwd: null pointer");
+  const long total = (long)N * num_classes;
+  const int nblk = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  focal_fwd_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(logits, targets, total, num_classes, gamma, alpha, losses);
+  return drn_launch_status("drn_focal_fwd");
+}
+
+extern "C" int drn_focal_bwd(const float* logits, const int32_t* targets, const float* d_losses, int64_t N, int num_classes, float gamma,
+                             float alpha, float* d_logits, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(N >= 0 && num_classes >= 1, "drn_focal_bwd: bad shape N=%lld C=%d", (long long)N, num_classes);
+  if (N == 0) return DRN_OK;
+  DRN_CHECK_ARG(logits && targets && d_losses && d_logits, "drn_focal_bwd: null pointer");
+  const long total = (long)N * num_classes;
+  const int nblk = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  focal_bwd_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(logits, targets, d_losses, total, num_classes, gamma, alpha, d_logits);
+  return drn_launch_status("drn_focal_bwd");
+}

@@ -138,6 +138,7 @@ def gemm_wgrad_multi(descs, dWs, N, Cin, taps=1, stride=1, pad=0, w_layout=0, ac
 # ---------------------------------------------------------------------------------------------
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 _ws_cache = {}
+_ws_retired = []          # outgrown buffers stay allocated: a hipGraph captured earlier still writes to them on replay
 
 
 def workspace(n_floats, device):
@@ -145,6 +146,8 @@ def workspace(n_floats, device):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < n_floats:
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf
@@ -391,6 +394,27 @@ def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, i
     check(lib().drn_fcos_loss_bwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
                                   ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(g3[0]), _p(g3[1]), _p(g3[2]),
                                   _p(dlogits), _p(dreg), _p(diou), _stream()), "drn_fcos_loss_bwd")
+
+
+def focal_fwd(logits, targets, gamma, alpha):
+    """Per-element sigmoid focal losses (N, C); the reference's fcos_core._C.sigmoid_focalloss_forward."""
+    _need_gpu(logits, targets)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 2
+    assert targets.dtype == torch.int32 and targets.is_contiguous() and targets.numel() == logits.shape[0]
+    out = torch.empty_like(logits)
+    check(lib().drn_focal_fwd(_p(logits), _p(targets), ctypes.c_int64(logits.shape[0]), logits.shape[1], ctypes.c_float(gamma),
+                              ctypes.c_float(alpha), _p(out), _stream()), "drn_focal_fwd")
+    return out
+
+
+def focal_bwd(logits, targets, d_losses, gamma, alpha):
+    """d_logits (N, C) = d_losses * d loss / d logit; the reference's fcos_core._C.sigmoid_focalloss_backward."""
+    _need_gpu(logits, targets, d_losses)
+    assert d_losses.dtype == torch.float32 and d_losses.is_contiguous() and d_losses.shape == logits.shape
+    out = torch.empty_like(logits)
+    check(lib().drn_focal_bwd(_p(logits), _p(targets), _p(d_losses), ctypes.c_int64(logits.shape[0]), logits.shape[1],
+                              ctypes.c_float(gamma), ctypes.c_float(alpha), _p(out), _stream()), "drn_focal_bwd")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

@@ -45,12 +45,16 @@ class FusedAdam(object):
         self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
 
+        self._ptr_sig = tuple(p.data_ptr() for b in reducer.buckets for p in b.params)
+
     def _check_ptrs(self):
-        for b, st in zip(self.reducer.buckets, self.state):
-            if [p.data_ptr() for p in b.params] != [x for x in st["ptr"].tolist() if x]:
-                raise RuntimeError("parameter storage moved after FusedAdam was built")
+        """The kernels reach the parameters through raw pointers baked into device tables: refuse to step if a parameter's
+        storage moved since construction (model.to(), .float(), load_state_dict(assign=True) ...).  Host-only comparison."""
+        if tuple(p.data_ptr() for b in self.reducer.buckets for p in b.params) != self._ptr_sig:
+            raise RuntimeError("parameter storage moved after FusedAdam was built; build a new GradReducer + FusedAdam")
 
     def step(self):
+        self._check_ptrs()
         L = lib()
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None

@@ -54,6 +54,7 @@ class Trainer(object):
         self.params, self.lr, self.default_epochs, self.which = stage_plan(model, stage, lr)
         self.device = next(model.parameters()).device
         self.fused = fused and stage != 2 and self.device.type == "cuda"
+        self.world_size = world_size
         if self.fused:
             from .dist import GradReducer
             from .optim import FusedAdam
@@ -77,13 +78,33 @@ class Trainer(object):
             self.reducer.finish()
             self.opt.step()
         else:
+            if self.world_size > 1:
+                self._average_grads()
             if self.clip is not None:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)     # over ALL parameters (main.py:238-239)
             self.opt.step()
             self.opt.zero_grad()                                                          # only the optimizer's (main.py:243)
         return loss_dict
 
-    def train_epoch(self, loader):
+    def _average_grads(self):
+        """Un-fused path under one-process-per-GPU: all-reduce(sum)/world of EVERY existing gradient -- the frozen trunk's
+        too, because the clip below runs over all parameters (main.py:238-239).  Those accumulate from step to step and
+        the averaging is linear and idempotent on the already-averaged part, so the stage-2 quirk is preserved."""
+        import torch.distributed as td
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch._utils._flatten_dense_tensors(grads)
+        td.all_reduce(flat)
+        flat.div_(self.world_size)
+        for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(r)
+
+    def train_epoch(self, loader, epoch=None):
+        # one process per GPU: the DistributedSampler reshuffles (and re-shards) per epoch only when told the epoch
+        sampler = getattr(loader, "sampler", None)
+        if epoch is not None and hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
         total, n = None, 0
         for batch in loader:
             _, args = to_device(batch, self.device)
@@ -119,7 +140,7 @@ class Trainer(object):
         best1 = best5 = 0.0
         history = []
         for epoch in range(start_epoch, n_epoch):
-            train_loss = self.train_epoch(train_loader)
+            train_loss = self.train_epoch(train_loader, epoch)
             rec = {"epoch": epoch, "train_loss": train_loss}
             if (epoch + 1) % eval_freq == 0 or epoch == n_epoch - 1:
                 val_loss, topks, accs, _ = self.evaluate(test_loader, id2word)
@@ -137,10 +158,11 @@ class Trainer(object):
         return history
 
 
-    def fit_train_only(self, train_loader, n_epoch):
-        """Ranks other than 0 of a multi-GPU run: same number of training steps, no evaluation / checkpoints."""
+    def fit_train_only(self, train_loader, n_epoch, start_epoch=0):
+        """Ranks other than 0 of a multi-GPU run: the SAME epochs as rank 0's fit() (every step holds a collective), no
+        evaluation / checkpoints."""
         n_epoch = self.default_epochs if self.default_epochs is not None else n_epoch
-        return [{"epoch": e, "train_loss": self.train_epoch(train_loader)} for e in range(n_epoch)]
+        return [{"epoch": e, "train_loss": self.train_epoch(train_loader, e)} for e in range(start_epoch, n_epoch)]
 
 
 # ---------------------------------------------------------------------------------------------- checkpoints

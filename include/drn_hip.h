@@ -234,6 +234,16 @@ int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, c
                       const float* fwd_out5, const float* g_cls, const float* g_reg, const float* g_iou /* 1 float each, NULL = 0 */,
                       float* dlogits, float* dreg, float* diou, void* stream);
 
+/* The reference's ONE real FFI on this path, 1:1: fcos_core._C.sigmoid_focalloss_forward(logits, targets, num_classes, gamma,
+ * alpha) -> losses and sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, alpha) -> d_logits
+ * (model/layers/sigmoid_focal_loss.py:18-20,31-33).  logits / losses / d_losses / d_logits are fp32 [N][num_classes],
+ * targets int32 [N]: 0 = background, c in 1..num_classes = foreground class c, negative = ignored (loss and gradient 0).
+ * Element-wise (the caller sums, sigmoid_focal_loss.py:68); any num_classes; finite for any finite logit. */
+int drn_focal_fwd(const float* logits, const int32_t* targets, int64_t N, int num_classes, float gamma, float alpha, float* losses,
+                  void* stream);
+int drn_focal_bwd(const float* logits, const int32_t* targets, const float* d_losses, int64_t N, int num_classes, float gamma,
+                  float alpha, float* d_logits, void* stream);
+
 /* ---- eval post-processor (drn_amd/csrc/postproc.hip; model/inference.py:51-120,166-199) ------------------------
  * Per clip and level: candidates sigmoid(logit) > thr, score = sigmoid(logit)[*sigmoid(iou)] (iou NULL in the first stage),
  * top_n per level, segments ((loc-reg0)/downsample, (loc+reg1)/downsample) clamped to [0,1], score = sqrt(.), loc/32.

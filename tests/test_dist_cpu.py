@@ -149,3 +149,109 @@ def test_adjacent_groups_are_contiguous_in_the_bucket():
     seen = [id(p) for b in red.buckets for p in b.params]
     assert sorted(seen) == sorted(id(p) for p in ps) and len(seen) == len(set(seen))
     red.remove()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Trainer under one process per GPU, torch-optimizer path (stage 2 / fused=False): gradients of ALL parameters are averaged
+# before the all-parameter clip (drn_amd/trainer.py:_average_grads); every rank runs the same epochs; the sampler is told
+# the epoch.
+def _worker_trainer_stage2(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from drn_amd.dist import init_from_env
+    from drn_amd import trainer as T
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    from oracle import drn_oracle as O
+    init_from_env(backend="gloo")
+    torch.set_num_threads(2)
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traj_s2.npz"))
+
+    def model():
+        m = O.mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", int(g["D"]), 2)))
+        m.load_state_dict(seeded_state_dict(m, 0))
+        return m
+
+    # the reference trajectory's two batches (GT matched to a prediction, so tIoU > 0.9 positives exist and loss_iou has a
+    # gradient); rank r takes batch (it + r) % 2
+    two = []
+    for i, seed in enumerate((1, 2)):
+        b = list(synthetic_batch(int(g["B"]), int(g["T"]), int(g["D"]), seed=seed))
+        b[4] = torch.from_numpy(g["gt%d" % i])
+        two.append(b)
+    batches = [[two[(it + r) % 2] for r in range(world)] for it in range(3)]
+    m = model()
+    tr = T.Trainer(m, 2, lr=1e-3, clip_gradient=0.5, world_size=world, fused=False)
+    for it in range(3):
+        tr.train_step(batches[it][rank])
+    # single-process emulation: per step, average the two ranks' local gradients by hand (the frozen trunk's accumulate)
+    e = model()
+    params, lr, _, which = T.stage_plan(e, 2, 1e-3)
+    opt = torch.optim.Adam(params, lr)
+    opt.zero_grad()
+    replicas = [model() for _ in range(world)]
+    for it in range(3):
+        for rep in replicas:
+            rep.load_state_dict(e.state_dict())
+            rep.train()
+        local = []
+        for r, rep in enumerate(replicas):
+            rep.zero_grad(set_to_none=True)
+            _, ld = rep(*batches[it][r])
+            T.select_loss(ld, which).backward()
+            local.append([p.grad for p in rep.parameters()])
+        for i, p in enumerate(e.parameters()):
+            gs = [l[i] for l in local if l[i] is not None]
+            if gs:
+                avg = sum(gs) / world
+                p.grad = avg if p.grad is None else p.grad + avg
+        e.load_state_dict(replicas[0].state_dict())            # rank 0's BN buffers (no SyncBN)
+        torch.nn.utils.clip_grad_norm_(e.parameters(), 0.5)
+        opt.step()
+        opt.zero_grad()
+    worst = 0.0
+    for (n, a), b in zip(m.named_parameters(), e.parameters()):
+        worst = max(worst, float((a - b).abs().max()))
+    mine = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    same = all(torch.equal(o, mine) for o in other)
+    q.put((rank, "ok" if (worst <= 2e-6 and same) else "mismatch worst=%g same=%s" % (worst, same)))
+    dist.destroy_process_group()
+
+
+def test_trainer_stage2_world2_averages_all_gradients():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_trainer_stage2, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert got == [(0, "ok"), (1, "ok")], got
+
+
+def test_fit_train_only_runs_the_same_epochs_and_sets_sampler_epoch():
+    from drn_amd import trainer as T
+
+    class Sampler(object):
+        def __init__(self):
+            self.epochs = []
+
+        def set_epoch(self, e):
+            self.epochs.append(e)
+
+    class Loader(list):
+        pass
+
+    tr = T.Trainer.__new__(T.Trainer)
+    tr.default_epochs = None
+    seen = []
+    tr.train_step = lambda args: seen.append(1)
+    loader = Loader()
+    loader.sampler = Sampler()
+    hist = tr.fit_train_only(loader, 7, start_epoch=4)
+    assert [h["epoch"] for h in hist] == [4, 5, 6] and loader.sampler.epochs == [4, 5, 6]
+    tr.default_epochs = 10                                    # stage 1: fixed 10 epochs (main.py:126), resumed at 8
+    assert [h["epoch"] for h in tr.fit_train_only(loader, 50, start_epoch=8)] == [8, 9]

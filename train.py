@@ -74,10 +74,13 @@ def main():
             for k, a in zip(topks, accs):
                 print("R@{}: {:.1f}".format(k, a * 100))
         return
-    hist = tr.fit(train_loader, test_loader if rank == 0 else [], n_epoch=args.n_epoch or cfg.get("n_epoch", 50),
-                  eval_freq=cfg.get("eval_freq", 1), snapshot_pref=args.snapshot_pref if rank == 0 else None, dataset=args.dataset,
-                  id2word=id2word, start_epoch=0 if args.stage > 1 else start_epoch) if rank == 0 else tr.fit_train_only(
-        train_loader, args.n_epoch or cfg.get("n_epoch", 50))
+    n_epoch = args.n_epoch or cfg.get("n_epoch", 50)
+    first = 0 if args.stage > 1 else start_epoch                     # the same epoch range on every rank
+    if rank == 0:
+        hist = tr.fit(train_loader, test_loader, n_epoch=n_epoch, eval_freq=cfg.get("eval_freq", 1),
+                      snapshot_pref=args.snapshot_pref, dataset=args.dataset, id2word=id2word, start_epoch=first)
+    else:
+        hist = tr.fit_train_only(train_loader, n_epoch, start_epoch=first)
     if rank == 0:
         print(json.dumps(hist[-1] if hist else {}))
 
