@@ -17,6 +17,7 @@ _lib = None
 
 c_int, c_void_p, c_float, c_int64, c_int32 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64, ctypes.c_int32
 MAX_GROUPS = 4
+QD_MAX, QD_COUNTERS = 16, 2048
 
 
 class DrnError(RuntimeError):
@@ -42,6 +43,17 @@ class WgradDesc(ctypes.Structure):
 class PackDesc(ctypes.Structure):
     _fields_ = [("in_", c_void_p), ("out", c_void_p), ("sa", ctypes.c_int64), ("sb", ctypes.c_int64), ("sc", ctypes.c_int64),
                 ("A", c_int32), ("B", c_int32), ("C", c_int32), ("ldo", ctypes.c_int64)]
+
+
+class SkinnyDesc(ctypes.Structure):
+    _fields_ = [("X", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("mask", c_void_p), ("Y", c_void_p),
+                ("ldx", c_int32), ("ldy", c_int32), ("ldm", c_int32), ("M", c_int32), ("N", c_int32), ("K", c_int32),
+                ("relu", c_int32)]
+
+
+class OuterDesc(ctypes.Structure):
+    _fields_ = [("dY", c_void_p), ("X", c_void_p), ("dW", c_void_p), ("db", c_void_p), ("db2", c_void_p),
+                ("ldy", c_int32), ("ldx", c_int32), ("ldw", c_int32), ("M", c_int32), ("N", c_int32), ("K", c_int32)]
 
 
 class ColSeg(ctypes.Structure):
@@ -87,8 +99,9 @@ def lib():
                            "Run __graft_entry__.build() or `make -C drn_amd/csrc`." % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.drn_last_error.restype = ctypes.c_char_p
-        if hasattr(_lib, "drn_wgrad_ws_elems"):
-            _lib.drn_wgrad_ws_elems.restype = c_int64
+        for fn in ("drn_wgrad_ws_elems", "drn_skinny_group_ws_elems", "drn_opt_nblocks"):
+            if hasattr(_lib, fn):
+                getattr(_lib, fn).restype = c_int64
     return _lib
 
 

@@ -1,0 +1,300 @@
+// Dense layers of the query side (model/language_module.py:13-23,38-63; model/main_model.py:36-50), fp32 throughout.
+//
+// Every product on this side has a "batch" dimension of 32 clips (or 32 clips x <= 8 words for the LSTM input projection):
+//   forward / input gradients   Y[M][N]  = X[M][K] * W[N][K]^T (+ bias)(ReLU)(* mask)      M <= 64 rows per problem
+//   weight / bias gradients     dW[N][K] = sum_m dY[m][N] * X[m][K],  db[N] = sum_m dY[m][N]  M <= a few hundred rows
+// i.e. weight-streaming problems with a tiny reduction or a tiny row count: a library GEMM puts 16-32 workgroups on each and
+// takes 5-25 us, and there are ~25 of them per step.  Here they are GROUPED (one launch serves up to DRN_QD_MAX problems)
+// and run on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) with operands straight from global memory (everything is L2
+// resident).  Long-K problems are split over workgroups; the last-arriving workgroup of an output tile adds the partial
+// tiles in a fixed order (deterministic) and applies the epilogue -- no second launch.
+#include "common.h"
+#include "../../include/drn_hip.h"
+
+#define QD_THREADS 256
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grouped skinny NT product
+// ---------------------------------------------------------------------------------------------------------------------
+struct SkProb {
+  const float* X;
+  const float* W;
+  const float* bias;
+  const float* mask;   // optional [M][ldm]: output zeroed where mask <= 0 (ReLU backward of the layer in front)
+  float* Y;
+  float* part;         // [ksplit][M][N] partial tiles (ksplit > 1)
+  int* counters;       // [ceil(N/16)] arrival counters of this problem (self-resetting)
+  int ldx, ldy, ldm, M, N, K;
+  int kslice, ksplit, relu;
+  int blk0;            // first workgroup of this problem; a problem owns ceil(N/16) * ksplit workgroups
+};
+struct SkGroupArgs {
+  SkProb p[DRN_QD_MAX];
+  int n;
+};
+
+// These are weight-streaming problems whose weights come from HBM (Adam rewrote them ~2 ms earlier): what matters is that
+// the whole matrix is requested at once, i.e. >= ~256 workgroups with every operand of a wave's K range in flight.  So a
+// long K is split over workgroups; the LAST-ARRIVING workgroup of a column tile adds the partial tiles in a fixed order
+// (deterministic) and applies the epilogue -- no second launch.  The partial tiles are exchanged with agent-scope relaxed
+// atomic stores / loads (write-through / L2-bypassing accesses): ordinary stores + __threadfence() cost 25 us per launch
+// here, because a device-scope release writes back the whole L2 of the XCD.
+template <int NBT>
+__global__ __launch_bounds__(QD_THREADS) void skinny_group_kernel(const SkGroupArgs G) {
+  __shared__ float red[4][NBT][64][4];
+  __shared__ int is_last;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_QD_MAX; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.p[i].blk0) g = i;
+  const SkProb& P = G.p[g];
+  const int rel = blockIdx.x - P.blk0;
+  const int ks = rel % P.ksplit, tile = rel / P.ksplit;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int n0 = tile * 16;
+  const int row = l & 15, kc = (l >> 4) * 4;
+  const int kq = P.kslice >> 2;                          // per wave, a multiple of 16
+  const int kbeg = ks * P.kslice + w * kq;
+  const int kend = min(kbeg + kq, P.K);
+  f32x4 acc[NBT];
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool nok = n0 + row < P.N;
+  const float* wrow = P.W + (long)(n0 + row) * P.K;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int KU = 4;                                  // 16-wide K steps whose operands are all requested up front
+  for (int k0 = kbeg; k0 < kend; k0 += 16 * KU) {
+    f32x4 a[KU][NBT], b[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k = k0 + u * 16 + kc;
+      const bool kok = k < kend;                         // K % 4 == 0 and kc % 4 == 0: a quad is in or out as a whole
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) {
+        const int m = bt * 16 + row;
+        a[u][bt] = (kok && m < P.M) ? *(const f32x4*)(P.X + (long)m * P.ldx + k) : zero4;
+      }
+      b[u] = (kok && nok) ? *(const f32x4*)(wrow + k) : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (k0 + u * 16 >= kend) break;                    // wave-uniform: no MFMAs on an all-zero (masked) K step
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][bt][e], b[u][e], acc[bt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][bt][l][r] = acc[bt][r];
+  __syncthreads();
+  // D layout: m = bt*16 + (l>>4)*4 + r, n = n0 + (l&15); wave w finishes register r = w of every lane
+  const int r = w, n = n0 + (l & 15);
+  float v[NBT];
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) v[bt] = red[0][bt][l][r] + red[1][bt][l][r] + red[2][bt][l][r] + red[3][bt][l][r];
+  if (P.ksplit > 1) {
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) {
+      const int m = bt * 16 + (l >> 4) * 4 + r;
+      if (m < P.M && n < P.N)
+        __hip_atomic_store(P.part + ((long)ks * P.M + m) * P.N + n, v[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's write-through stores are complete ...
+    __syncthreads();                                          // ... and so are the other waves' before thread 0 counts us in
+    if (threadIdx.x == 0) {
+      const int prev = __hip_atomic_fetch_add(P.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = prev == P.ksplit - 1;
+      if (is_last) __hip_atomic_store(P.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+    }
+    __syncthreads();
+    if (!is_last) return;
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) {
+      const int m = bt * 16 + (l >> 4) * 4 + r;
+      float s = 0.f;
+      if (m < P.M && n < P.N)
+        for (int q = 0; q < P.ksplit; ++q)
+          s += __hip_atomic_load(P.part + ((long)q * P.M + m) * P.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[bt] = s;
+    }
+  }
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) {
+    const int m = bt * 16 + (l >> 4) * 4 + r;
+    if (m >= P.M || n >= P.N) continue;
+    float o = v[bt];
+    if (P.bias) o += P.bias[n];
+    if (P.relu) o = fmaxf(o, 0.f);
+    if (P.mask && !(P.mask[(long)m * P.ldm + n] > 0.f)) o = 0.f;
+    P.Y[(long)m * P.ldy + n] = o;
+  }
+}
+
+// K >= 1024 is cut into slices of >= 256 until ~256 workgroups work on the long-K problems of the launch together
+// (`tiles_long` = their column tiles): fewer, longer slices when the group already has many tiles (less partial-tile traffic).
+static int qd_ksplit(int tiles_long, int K) {
+  if (K < 1024) return 1;
+  int ks = 1;
+  while (ks < 16 && tiles_long * ks < 256 && K / (2 * ks) >= 256) ks *= 2;
+  return ks;
+}
+static int qd_tiles_long(const DrnSkinnyDesc* d, int n) {
+  int t = 0;
+  for (int i = 0; i < n; ++i)
+    if (d[i].K >= 1024) t += cdiv(d[i].N, 16);
+  return t;
+}
+
+extern "C" int64_t drn_skinny_group_ws_elems(const DrnSkinnyDesc* d, int n) {
+  int64_t tot = 0;
+  const int tl = qd_tiles_long(d, n);
+  for (int i = 0; i < n; ++i) {
+    const int ks = qd_ksplit(tl, d[i].K);
+    if (ks > 1) tot += (int64_t)ks * d[i].M * d[i].N;
+  }
+  return tot;
+}
+
+extern "C" int drn_skinny_group(const DrnSkinnyDesc* d, int n, float* ws, int32_t* counters, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(d && n >= 1 && n <= DRN_QD_MAX, "drn_skinny_group: 1..%d problems", DRN_QD_MAX);
+  SkGroupArgs G;
+  memset(&G, 0, sizeof(G));
+  G.n = n;
+  int blocks = 0, nbt = 1, cnt = 0;
+  int64_t wsoff = 0;
+  const int tiles_long = qd_tiles_long(d, n);
+  for (int i = 0; i < n; ++i) {
+    const DrnSkinnyDesc& s = d[i];
+    DRN_CHECK_ARG(s.X && s.W && s.Y && s.M > 0 && s.M <= 64 && s.N > 0 && s.K > 0, "drn_skinny_group: problem %d: bad shape (M <= 64)", i);
+    DRN_CHECK_ARG(s.K % 4 == 0 && s.ldx % 4 == 0 && (((uintptr_t)s.X | (uintptr_t)s.W) & 15) == 0,
+                  "drn_skinny_group: problem %d: need K %% 4 == 0, ldx %% 4 == 0, 16-byte aligned X / W", i);
+    SkProb& P = G.p[i];
+    P.X = s.X; P.W = s.W; P.bias = s.bias; P.mask = s.mask; P.Y = s.Y;
+    P.ldx = s.ldx; P.ldy = s.ldy; P.ldm = s.ldm; P.M = s.M; P.N = s.N; P.K = s.K; P.relu = s.relu;
+    P.ksplit = qd_ksplit(tiles_long, s.K);
+    P.kslice = cdiv(cdiv(s.K, P.ksplit), 64) * 64;       // 4 waves x 16-wide steps
+    P.blk0 = blocks;
+    blocks += cdiv(s.N, 16) * P.ksplit;
+    if (P.ksplit > 1) {
+      DRN_CHECK_ARG(ws && counters, "drn_skinny_group: problem %d is K-split: workspace (drn_skinny_group_ws_elems) and counters required", i);
+      P.part = ws + wsoff;
+      wsoff += (int64_t)P.ksplit * s.M * s.N;
+      P.counters = counters + cnt;
+      cnt += cdiv(s.N, 16);
+      DRN_CHECK_ARG(cnt <= DRN_QD_COUNTERS, "drn_skinny_group: more than %d K-split column tiles", DRN_QD_COUNTERS);
+    }
+    nbt = nbt > cdiv(s.M, 16) ? nbt : cdiv(s.M, 16);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (nbt == 1) skinny_group_kernel<1><<<blocks, QD_THREADS, 0, st>>>(G);
+  else if (nbt == 2) skinny_group_kernel<2><<<blocks, QD_THREADS, 0, st>>>(G);
+  else skinny_group_kernel<4><<<blocks, QD_THREADS, 0, st>>>(G);
+  return drn_launch_status("drn_skinny_group");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grouped weight / bias gradients of batch-sized layers: dW[N][K] = dY^T X over M rows, db[N] = column sums of dY
+// ---------------------------------------------------------------------------------------------------------------------
+struct OwProb {
+  const float* dY;
+  const float* X;
+  float* dW;
+  float* db;           // optional
+  float* db2;          // optional second destination of the same sums (LSTM: b_ih and b_hh share their gradient)
+  int ldy, ldx, ldw, M, N, K;
+  int ntk;             // workgroup tiles along K (64 wide)
+  int blk0;
+};
+struct OwGroupArgs {
+  OwProb p[DRN_QD_MAX];
+  int n;
+};
+
+// workgroup: 64 rows of dW (n) x 64 columns (k); wave w owns 16 of the rows as four 16x16 MFMA tiles.  The four waves read
+// the same X columns (they meet in the CU's vector cache) and each dY / X panel is re-read N/64 resp. K/64 times from L2.
+__global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupArgs G) {
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_QD_MAX; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.p[i].blk0) g = i;
+  const OwProb& P = G.p[g];
+  const int rel = blockIdx.x - P.blk0;
+  const int tk = rel % P.ntk, tn = rel / P.ntk;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int n0 = tn * 64 + w * 16, k0 = tk * 64;
+  const int li = l & 15, lq = l >> 4;                    // A: (i = n, kk = m) ; B: (kk = m, j = k)
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool nok = n0 + li < P.N;
+  bool kok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kok[j] = k0 + j * 16 + li < P.K;
+  const bool want_db = (P.db != nullptr) && tk == 0;
+  float bsum = 0.f;
+  if (P.dW == nullptr) {                                 // column sums only
+    if (!want_db) return;
+    for (int m = lq; m < P.M; m += 4) bsum += nok ? P.dY[(long)m * P.ldy + n0 + li] : 0.f;
+  } else
+  for (int m0 = 0; m0 < P.M; m0 += 32) {                // 8 MFMA k-steps per trip, all 40 operands requested up front
+    float a[8], b[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int m = m0 + u * 4 + lq;
+      const bool mok = m < P.M;
+      a[u] = (mok && nok) ? P.dY[(long)m * P.ldy + n0 + li] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[u][j] = (mok && kok[j]) ? P.X[(long)m * P.ldx + k0 + j * 16 + li] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bsum += a[u];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][j], acc[j], 0, 0, 0);
+    }
+  }
+  // D: n = n0 + lq*4 + r, k = k0 + j*16 + li
+  if (P.dW != nullptr)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!kok[j]) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + lq * 4 + r;
+        if (n < P.N) P.dW[(long)n * P.ldw + k0 + j * 16 + li] = acc[j][r];
+      }
+    }
+  if (want_db) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lq == 0 && nok) {
+      P.db[n0 + li] = bsum;
+      if (P.db2) P.db2[n0 + li] = bsum;
+    }
+  }
+}
+
+extern "C" int drn_outer_wgrad(const DrnOuterDesc* d, int n, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(d && n >= 1 && n <= DRN_QD_MAX, "drn_outer_wgrad: 1..%d problems", DRN_QD_MAX);
+  OwGroupArgs G;
+  memset(&G, 0, sizeof(G));
+  G.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const DrnOuterDesc& s = d[i];
+    DRN_CHECK_ARG(s.dY && s.M > 0 && s.N > 0 && ((s.dW && s.X && s.K > 0) || (!s.dW && s.db)), "drn_outer_wgrad: problem %d: bad args", i);
+    OwProb& P = G.p[i];
+    P.dY = s.dY; P.X = s.X; P.dW = s.dW; P.db = s.db; P.db2 = s.db2;
+    P.ldy = s.ldy; P.ldx = s.ldx; P.ldw = s.ldw; P.M = s.M; P.N = s.N; P.K = s.K;
+    P.ntk = s.dW ? cdiv(s.K, 64) : 1;
+    P.blk0 = blocks;
+    blocks += cdiv(s.N, 64) * P.ntk;
+  }
+  outer_wgrad_kernel<<<blocks, QD_THREADS, 0, (hipStream_t)stream>>>(G);
+  return drn_launch_status("drn_outer_wgrad");
+}

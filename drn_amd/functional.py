@@ -293,22 +293,6 @@ def flush_bn_counters():
             torch._foreach_add_([t for t, _ in items], [n for _, n in items])
 
 
-_side_streams = {}
-# Forking the weight-gradient GEMM of a block onto a second stream (parallel hipGraph branches) measured SLOWER on
-# MI355X/ROCm 7.2 (6.05 vs 4.7 ms per step): cross-queue dependencies cost more than the idle CUs they fill.
-FORK_WGRAD = os.environ.get("DRN_FORK_WGRAD", "0") == "1"
-
-
-def side_stream(device):
-    """A second HIP stream per device: independent kernels of one backward node (weight gradient vs data gradient)
-    are forked onto it, so under-filled launches share the 256 CUs; the fork/join is captured into the hipGraph."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
-    return st
-
-
 def code_of(dtype):
     return ops.BF16 if dtype == torch.bfloat16 else ops.F32
 
@@ -487,15 +471,10 @@ class _ConvBlockFn(torch.autograd.Function):
                                 ld_draw=Cout, dgamma=dgamma, dbeta=dbeta, accumulate=l > 0, M=M))
             draws.append(draw)
         ops.bn_bwd_multi(blevels, Cout, code, relu=meta.relu)             # reduce / finalize / apply once for all levels
-        # weight gradient on the side stream, data gradient on the main one: both only read `draws`
-        main = torch.cuda.current_stream()
-        side = side_stream(dev) if FORK_WGRAD else main
-        side.wait_stream(main) if side is not main else None
-        with torch.cuda.stream(side):
-            dW = grad_buffer(ctx.weight_obj if getattr(ctx.weight_obj, "_drn_stack_of", None) else weight)
-            wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
-                      for l in range(nl)]
-            ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
+        dW = grad_buffer(ctx.weight_obj if getattr(ctx.weight_obj, "_drn_stack_of", None) else weight)
+        wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
+                  for l in range(nl)]
+        ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[7 + l] for l in range(nl)):
             wd = packed(ctx.weight_obj, (1, 2, 0), code)               # (Cin, k, Cout)
@@ -507,8 +486,6 @@ class _ConvBlockFn(torch.autograd.Function):
                                            Lout=L, Lsrc=Lo))
                 dxs[l] = dx
             ops.gemm_nt(descs, code)
-        if side is not main:
-            main.wait_stream(side)
         dcb = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_cbias else None   # cancels in train-mode BN
         return (None, dW, dcb, dgamma, dbeta, dgate, dup) + tuple(dxs)
 
@@ -671,37 +648,64 @@ def multi_conv_block(xs, blocks, training, dtype, chain_up=False):
     return list(_MultiConvFn.apply(meta, *args))
 
 
+class InputPrep(object):
+    """Everything the input stage needs that does not depend on the query: the feature tensor in the compute dtype (and, for
+    the bf16 weight-gradient product, its transpose), the proposal position features, the GEMM copy of the prop_fc weight
+    (warmed into the caches).  Non-differentiable."""
+    __slots__ = ("xc", "xcT", "pf", "wfc", "dtype", "dims")
+
+
+def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True):
+    """props_start_end: (B, T, 2) proposal boundaries, or the (B, T, 3) position features themselves."""
+    code = code_of(dtype)
+    B, T, D = feats.shape
+    pr = InputPrep()
+    pr.dtype, pr.dims = dtype, (B, T, D)
+    xc = feats.contiguous()
+    # bf16 training: the prop_fc weight gradient runs as an NT product of K-major operands (see backward); the
+    # transposed copy of the features is written by the same pass that casts them
+    nt_wgrad = (code == ops.BF16 and NT_WGRAD and (B * T) % 8 == 0 and D % 8 == 0 and xc.dtype == torch.float32 and want_wgrad)
+    pr.xcT = None
+    if nt_wgrad:
+        xc2, pr.xcT = ops.cast_transpose(xc.view(B * T, D), code)
+        xc = xc2.view(B, T, D)
+    elif xc.dtype != dtype:
+        xc = ops.cast(xc.float(), code)
+    pr.xc = xc
+    Wfc = prop_fc.weight
+    pr.wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
+    if TOUCH_W and code == ops.BF16:
+        ops.touch(pr.wfc)                                  # 2.9 ms old and evicted: ~8 us here saves the GEMM ~29 us
+        # (doing the same for the other forward weight copies -- 20 MB in a handful of launches -- measured 10 us SLOWER)
+    # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
+    if props_start_end.shape[-1] == 3:                     # already [start, end, end-start]
+        pf = props_start_end.float()
+    elif props_start_end.dtype in (torch.float64, torch.float32):
+        pf = ops.pos_feat(props_start_end)                 # one launch instead of sub + cat + cast
+    else:
+        duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
+        pf = torch.cat((props_start_end, duration), dim=-1).float()
+    pr.pf = pf.reshape(B * T, 3).contiguous()
+    return pr
+
+
 class _InputStageFn(torch.autograd.Function):
     """prop_fc + level-0 query gating + position embedding, written into one (B, T, D+P) buffer that is conv0's
     input (model/main_model.py:51-59,67 + model/backbone.py:28-32: Linear, `q * x`, cat) -- one MFMA GEMM whose
     epilogue adds the bias, keeps the pre-gate value for backward and applies the gate, plus one tiny kernel."""
 
     @staticmethod
-    def forward(ctx, dtype, feats, posfeat, Wfc, bfc, gate0, Wpos, bpos):
+    def forward(ctx, prep, Wfc, bfc, gate0, Wpos, bpos):
+        dtype = prep.dtype
         code = code_of(dtype)
-        B, T, D = feats.shape
+        B, T, D = prep.dims
         P = Wpos.shape[0]
-        dev = feats.device
-        xc = feats.contiguous()
-        # bf16 training: the prop_fc weight gradient runs as an NT product of K-major operands (see backward); the
-        # transposed copy of the features is written by the same pass that casts them
-        nt_wgrad = (code == ops.BF16 and NT_WGRAD and (B * T) % 8 == 0 and D % 8 == 0 and xc.dtype == torch.float32
-                    and ctx.needs_input_grad[3])
-        xcT = None
-        if nt_wgrad:
-            xc2, xcT = ops.cast_transpose(xc.view(B * T, D), code)
-            xc = xc2.view(B, T, D)
-        elif xc.dtype != dtype:
-            xc = ops.cast(xc.float(), code)
-        wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
-        if TOUCH_W and code == ops.BF16:
-            ops.touch(wfc)                                 # 2.9 ms old and evicted: ~8 us here saves the GEMM ~29 us
-            # (doing the same for the other forward weight copies -- 20 MB in a handful of launches -- measured 10 us SLOWER)
+        xc, xcT, pf, wfc = prep.xc, prep.xcT, prep.pf, prep.wfc
+        dev = xc.device
         G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
         Z = torch.empty((B, T, D), dtype=dtype, device=dev)
         ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),
                                    C2=Z, ldc2=D)], code)
-        pf = posfeat.reshape(B * T, 3).contiguous().float()
         pos_slice = G0.view(B * T, D + P)[:, D:]
         ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
         ctx.dtype, ctx.dims = dtype, (B, T, D, P)
@@ -720,35 +724,32 @@ class _InputStageFn(torch.autograd.Function):
         dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
         dsum = torch.empty((B, D), dtype=torch.float32, device=dev)      # per-clip column sums of dZ: prop_fc bias gradient
         Wfc, bfc, Wpos, bpos = ctx.param_refs
-        dW = grad_buffer(Wfc)
-        if xcT.numel():
+        dW, db, dWp, dbp = grad_buffer(Wfc), grad_buffer(bfc), grad_buffer(Wpos), grad_buffer(bpos)
+        dZ = dZT = None
+        if xcT.numel() and T % 32 == 0:
             # dW[n][c] = sum_m dZ[m][n] * x[m][c] as an NT product of the K-major copies dZ^T (D, B*T) and x^T (D, B*T):
             # the NT kernel streams both operands with 16-byte LDS reads (1.1 PFLOP/s on this shape), while the TN
             # kernel's transposing ds_read_b64_tr_b16 fragments hold it to ~0.7.  dZ is only ever needed transposed.
-            if T % 32 == 0:
-                dZT = torch.empty((D, B * T), dtype=dtype, device=dev)
-                ops.gate_bwd_t(dG0, D + P, Z, D, gate0, dZT, dgate, B, T, D, code, dsum=dsum)
-            else:
-                dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
-                ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
-                dZT = ops.transpose2d(dZ.view(B * T, D), code)
-            # (warming x^T the same way -- 64 MB, 13 us -- buys this GEMM exactly those 13 us back: not done)
-            ops.gemm_nt([ops.gemm_desc(dZT, xcT, dW, D, D, B * T, out_f32=True)], code)
+            dZT = torch.empty((D, B * T), dtype=dtype, device=dev)
+            ops.gate_bwd_t(dG0, D + P, Z, D, gate0, dZT, dgate, B, T, D, code, dsum=dsum)
         else:
             dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
             ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
+
+        # 2. the parameter gradients
+        if dZT is not None:
+            ops.gemm_nt([ops.gemm_desc(dZT, xcT, dW, D, D, B * T, out_f32=True)], code)
+        elif xcT.numel():
+            ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ.view(B * T, D), code), xcT, dW, D, D, B * T, out_f32=True)], code)
+        else:
             ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
-        db = grad_buffer(bfc)
         ops.colsum(dsum, D, B, D, db, ops.F32)
-        dWp = grad_buffer(Wpos)
-        dbp = grad_buffer(bpos)
         ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, dWp, dbp, code)
-        return None, None, None, dW, db, dgate, dWp, dbp
+        return None, dW, db, dgate, dWp, dbp
 
 
-def input_stage(feats, posfeat, prop_fc, gate0, position_transform, dtype):
-    return _InputStageFn.apply(dtype, feats, posfeat, prop_fc.weight, prop_fc.bias, gate0, position_transform.weight,
-                               position_transform.bias)
+def input_stage(prep, prop_fc, gate0, position_transform):
+    return _InputStageFn.apply(prep, prop_fc.weight, prop_fc.bias, gate0, position_transform.weight, position_transform.bias)
 
 
 class _HeadOutFn(torch.autograd.Function):
@@ -895,13 +896,18 @@ def fcos_loss(logits, reg, iou, gt, levels, B, gamma, alpha, target_scale, iou_s
     return _FCOSLossFn.apply(meta, logits, reg, iou if iou_stage else None, gt)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Query side (model/language_module.py:38-63, model/main_model.py:36-50).  Every dense product here has a 32-clip batch
+# dimension: forward / input gradients go through the grouped skinny kernel, all weight / bias gradients of one backward
+# node through ONE grouped outer-product launch (drn_amd/csrc/qdense.hip) -- no library GEMM, no per-bias reduction launch.
+# ---------------------------------------------------------------------------------------------------------------------
 def _lstm_forward(emb_tm, lens, lstm_params, B, L):
     """emb_tm (L*B, E) time-major fp32.  Returns out (B, L, 2H) and the tensors backward needs."""
     w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = lstm_params
     H = w_hh_f.shape[1]
     dev = emb_tm.device
     wih_s = stacked([w_ih_f, w_ih_r])                                    # (8H, E): one input projection for both directions
-    xproj = torch.mm(emb_tm, wih_s.t())                                  # (L*B, 8H) = [L][B][2][4H]
+    xproj = ops.skinny_rows(emb_tm, wih_s)                               # (L*B, 8H) = [L][B][2][4H]
     hseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
     cseq = torch.empty((2, L + 1, B, H), dtype=torch.float32, device=dev)
     gates = torch.empty((L, B, 2, 4 * H), dtype=torch.float32, device=dev)
@@ -914,9 +920,10 @@ def _lstm_forward(emb_tm, lens, lstm_params, B, L):
     return out, (cseq, gates, hprev)
 
 
-def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L):
-    """dout (B, L, 2H) contiguous fp32.  Returns (demb_tm (L*B, E), the eight parameter gradients); weight gradients
-    land in the reducer's flat buckets when sinks are registered."""
+def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L, leaves):
+    """dout (B, L, 2H) contiguous fp32.  Returns (demb_tm (L*B, E), the eight parameter gradients); the weight / bias
+    gradient products are appended to `leaves` (the caller launches them with its own, ops.outer_wgrad); they land in the
+    reducer's flat buckets when sinks are registered."""
     w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = lstm_params
     cseq, gates, hprev = saved
     H = w_hh_f.shape[1]
@@ -929,56 +936,37 @@ def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L):
         ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], lens, B, L, H, s)
     dg = dgates.view(L * B, 8 * H)
     hp = hprev.view(L * B, 2 * H)
-    dwih_f = torch.mm(dg[:, :4 * H].t(), emb_tm, out=grad_buffer(w_ih_f))
-    dwih_r = torch.mm(dg[:, 4 * H:].t(), emb_tm, out=grad_buffer(w_ih_r))
-    dwhh_f = torch.mm(dg[:, :4 * H].t(), hp[:, :H], out=grad_buffer(w_hh_f))
-    dwhh_r = torch.mm(dg[:, 4 * H:].t(), hp[:, H:], out=grad_buffer(w_hh_r))
-    dbs = [grad_buffer(b) for b in (b_ih_f, b_hh_f, b_ih_r, b_hh_r)]
-    ops.colsum_segs(dg, 8 * H, L * B, [(dbs[0], 0, 4 * H), (dbs[1], 0, 4 * H), (dbs[2], 4 * H, 4 * H), (dbs[3], 4 * H, 4 * H)])
-    demb_tm = torch.mm(dg, stacked([w_ih_f, w_ih_r]))
-    return demb_tm, (dwih_f, dwhh_f, dbs[0], dbs[1], dwih_r, dwhh_r, dbs[2], dbs[3])
-
-
-def _linear_fwd(x, W, b, relu=False, Ws=None):
-    """y = x W^T + b (ReLU) for batch-sized fp32 x; W is a Parameter (or pass the stacked copy as Ws)."""
-    Wm = W.detach() if Ws is None else Ws
-    if ops.skinny_ok(x.shape[0], Wm.shape[0], Wm.shape[1]) and x.stride(1) == 1 and x.stride(0) % 4 == 0:
-        return ops.skinny_linear(x, Wm, b, relu)
-    y = torch.addmm(b, x, Wm.t())
-    return y.relu_() if relu else y
-
-
-def _linear_dx(dy, Wt):
-    """dx = dy W given the cached transposed copy Wt = W^T (K, N) (fp32)."""
-    if ops.skinny_ok(dy.shape[0], Wt.shape[0], Wt.shape[1]) and dy.stride(1) == 1 and dy.stride(0) % 4 == 0:
-        return ops.skinny_linear(dy, Wt)
-    return torch.mm(dy, Wt.t())
+    demb_tm = ops.skinny_rows(dg, stacked_t([w_ih_f, w_ih_r]))           # dg [W_f; W_r]: (L*B, E)
+    gr = [grad_buffer(p) for p in lstm_params]
+    leaves += [dict(dY=dg[:, :4 * H], X=emb_tm, dW=gr[0], db=gr[2], db2=gr[3]), dict(dY=dg[:, :4 * H], X=hp[:, :H], dW=gr[1]),
+               dict(dY=dg[:, 4 * H:], X=emb_tm, dW=gr[4], db=gr[6], db2=gr[7]), dict(dY=dg[:, 4 * H:], X=hp[:, H:], dW=gr[5])]
+    return demb_tm, tuple(gr)
 
 
 class _LinearFn(torch.autograd.Function):
-    """nn.Linear on a batch-sized fp32 input (the per-level gate projections qInput{t}, model/main_model.py:37-50):
-    forward / input gradient on the skinny MFMA kernel, weight gradient (an outer product over the batch) by the
-    library, bias gradient by drn_colsum_segs; parameter gradients land in the reducer's buckets."""
+    """nn.Linear on a batch-sized fp32 input: forward / input gradient on the skinny MFMA kernel, weight + bias gradient in
+    one outer-product launch; parameter gradients land in the reducer's buckets."""
 
     @staticmethod
     def forward(ctx, x, W, b):
         x = x.float().contiguous()
         ctx.save_for_backward(x, W, b)
-        return _linear_fwd(x, W, b.detach())
+        return ops.skinny_linear(x, W.detach(), b.detach())
 
     @staticmethod
     def backward(ctx, dy):
         x, W, b = ctx.saved_tensors
         dy = dy.float().contiguous()
-        dx = _linear_dx(dy, packed(W, (1, 2, 0), ops.F32)) if ctx.needs_input_grad[0] else None
-        dW = torch.mm(dy.t(), x, out=grad_buffer(W))
-        db = grad_buffer(b)
-        ops.colsum_segs(dy, dy.shape[1], dy.shape[0], [(db, 0, dy.shape[1])])
+        dx = ops.skinny_linear(dy, packed(W, (1, 2, 0), ops.F32)) if ctx.needs_input_grad[0] else None
+        dW, db = grad_buffer(W), grad_buffer(b)
+        ops.outer_wgrad([dict(dY=dy, X=x, dW=dW, db=db)])
         return dx, dW, db
 
 
 def linear(x, lin):
     """lin: nn.Linear parameter holder; x (M <= 64, K) fp32 on the GPU."""
+    if x.shape[0] > 64 or lin.weight.shape[1] % 4:
+        raise DrnError("drn_amd.functional.linear serves batch-sized inputs (<= 64 rows, K %% 4 == 0); got %s" % (tuple(x.shape),))
     return _LinearFn.apply(x, lin.weight, lin.bias)
 
 
@@ -990,8 +978,8 @@ def _dev_lengths(lengths, dev):
 
 class _BiLSTMFn(torch.autograd.Function):
     """Bidirectional 1-layer LSTM over padded sequences with device-side lengths (model/language_module.py:38-45:
-    pack_padded_sequence -> nn.LSTM -> pad_packed_sequence).  The input projection and the weight-gradient products
-    are plain library GEMMs (tiny); the recurrence runs in drn_amd/csrc/lstm.hip, one launch per time step."""
+    pack_padded_sequence -> nn.LSTM -> pad_packed_sequence).  The recurrence runs in drn_amd/csrc/lstm.hip, one launch per
+    time step; the input projection and the weight gradients in drn_amd/csrc/qdense.hip."""
 
     @staticmethod
     def forward(ctx, emb, lengths, *lstm_params):
@@ -1008,7 +996,9 @@ class _BiLSTMFn(torch.autograd.Function):
     def backward(ctx, dout):
         B, L, E = ctx.dims
         emb_tm, lens = ctx.saved_tensors[:2]
-        demb_tm, grads = _lstm_backward(dout.contiguous().float(), emb_tm, lens, ctx.lstm_params, ctx.saved_tensors[2:], B, L)
+        leaves = []
+        demb_tm, grads = _lstm_backward(dout.contiguous().float(), emb_tm, lens, ctx.lstm_params, ctx.saved_tensors[2:], B, L, leaves)
+        ops.outer_wgrad(leaves)
         return (demb_tm.view(L, B, E).transpose(0, 1), None) + grads
 
 
@@ -1023,14 +1013,16 @@ def _lstm_param_list(lstm):
 
 
 class _QueryEncoderFn(torch.autograd.Function):
-    """The whole query encoder (model/language_module.py:38-63 + 17-36) as one autograd node: embedding lookup, BiLSTM,
-    [first ; last] sentence vector, qInput + ReLU, the three qInput{t} projections and the three attention commands.
-    Dense products are library GEMMs on stacked weights; everything else is drn_amd/csrc/{lstm,qenc}.hip.  Every
-    parameter gradient is written by a kernel straight into its final buffer (no autograd glue kernels)."""
+    """The whole query side as one autograd node: embedding lookup, BiLSTM, [first ; last] sentence vector, qInput + ReLU,
+    the three qInput{t} projections, the three attention commands (model/language_module.py:38-63 + 17-36) and -- when
+    their parameters are passed -- mainModel's per-level gate projections qInput{t} (model/main_model.py:47-50), whose
+    outputs then replace the commands as the node's outputs.  Forward: 8 + L launches; backward: 8 + L on the critical path
+    plus ONE launch for all 13 (10) weight / bias gradient products.  Every parameter gradient is written by a kernel
+    straight into its final buffer."""
 
     @staticmethod
     def forward(ctx, tokens, lengths, table, *params):
-        lstm_params, (Wq, bq, W0, b0, W1, b1, W2, b2, wl, bl) = params[:8], params[8:]
+        lstm_params, (Wq, bq, W0, b0, W1, b1, W2, b2, wl, bl), gate_params = params[:8], params[8:18], params[18:]
         B, L = tokens.shape
         E = table.shape[1]
         H = lstm_params[1].shape[1]
@@ -1043,60 +1035,84 @@ class _QueryEncoderFn(torch.autograd.Function):
         out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L)
         qvec = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
         ops.qe_qvec_fwd(out, lens, qvec, B, L, C)                          # language_module.py:48-54
-        base = _linear_fwd(qvec, Wq, bq.detach(), relu=True)               # language_module.py:55-56
-        qcmd = _linear_fwd(base, None, stacked([b0, b1, b2]), Ws=stacked([W0, W1, W2]))    # (B, 3*C): all three qInput{t}
+        base = ops.skinny_linear(qvec, Wq.detach(), bq.detach(), relu=True)               # language_module.py:55-56
+        qcmd = ops.skinny_linear(base, stacked([W0, W1, W2]), stacked([b0, b1, b2]))      # (B, 3*C): all three qInput{t}
         att = torch.empty((B, 3, L), dtype=torch.float32, device=dev)
         cmds = torch.empty((3, B, C), dtype=torch.float32, device=dev)
         ops.qe_attn_fwd(out, qcmd, wl.detach(), bl.detach(), lens, att, cmds, B, L, C)
         ctx.dims = (B, L, E, H)
         ctx.params = params
         ctx.table = table
-        ctx.save_for_backward(tokens, lens, emb_tm, out, qvec, base, qcmd, att, *saved)
-        return cmds[0], cmds[1], cmds[2]
+        ctx.save_for_backward(tokens, lens, emb_tm, out, qvec, base, qcmd, att, cmds, *saved)
+        if not gate_params:
+            return cmds[0], cmds[1], cmds[2]
+        # main_model.py:47-50: gate_t = qInput{t}(cmd_t), the three levels in one launch
+        return tuple(ops.skinny_group([dict(X=cmds[t], W=gate_params[2 * t].detach(), bias=gate_params[2 * t + 1].detach())
+                                       for t in range(3)]))
 
     @staticmethod
     def backward(ctx, d0, d1, d2):
         B, L, E, H = ctx.dims
         C = 2 * H
-        tokens, lens, emb_tm, out, qvec, base, qcmd, att = ctx.saved_tensors[:8]
+        tokens, lens, emb_tm, out, qvec, base, qcmd, att, cmds = ctx.saved_tensors[:9]
         params = ctx.params
-        lstm_params, (Wq, bq, W0, b0, W1, b1, W2, b2, wl, bl) = params[:8], params[8:]
+        lstm_params, (Wq, bq, W0, b0, W1, b1, W2, b2, wl, bl), gate_params = params[:8], params[8:18], params[18:]
         dev = out.device
         f32 = dict(dtype=torch.float32, device=dev)
-        dcmds = [None if d is None else d.contiguous().float() for d in (d0, d1, d2)]
+        douts = [None if d is None else d.contiguous().float() for d in (d0, d1, d2)]
+        leaves, gate_grads = [], ()
+        if gate_params:
+            live = [t for t in range(3) if douts[t] is not None]
+            dc = ops.skinny_group([dict(X=douts[t], W=packed(gate_params[2 * t], (1, 2, 0), ops.F32)) for t in live])
+            dcmds = [None] * 3
+            for t, d in zip(live, dc):
+                dcmds[t] = d
+            gg = []
+            for t in range(3):
+                Wg, bg = gate_params[2 * t], gate_params[2 * t + 1]
+                if douts[t] is None:
+                    gg += [torch.zeros_like(Wg), torch.zeros_like(bg)]
+                else:
+                    dWg, dbg = grad_buffer(Wg), grad_buffer(bg)
+                    leaves.append(dict(dY=douts[t], X=cmds[t], dW=dWg, db=dbg))
+                    gg += [dWg, dbg]
+            gate_grads = tuple(gg)
+        else:
+            dcmds = douts
         dqcmd, dout = torch.empty((B, 3 * C), **f32), torch.empty((B, L, C), **f32)
         dw_part, db_part = torch.empty((B, C), **f32), torch.empty((B, 1), **f32)
         ops.qe_attn_bwd(dcmds, att, out, qcmd, wl.detach(), lens, dqcmd, dout, dw_part, db_part, B, L, C)
         dwl, dbl = grad_buffer(wl), grad_buffer(bl)
-        ops.colsum_segs(dw_part, C, B, [(dwl, 0, C)])
-        ops.colsum_segs(db_part, 1, B, [(dbl, 0, 1)])
-        # qInput{t}: q_cmd_t = base W_t^T + b_t
-        dbase = _linear_dx(dqcmd, stacked_t([W0, W1, W2]))
-        dW = [torch.mm(dqcmd[:, t * C:(t + 1) * C].t(), base, out=grad_buffer(W)) for t, W in enumerate((W0, W1, W2))]
+        leaves += [dict(dY=dw_part, db=dwl.view(-1)), dict(dY=db_part, db=dbl.view(-1))]
+        # qInput{t}: q_cmd_t = base W_t^T + b_t ; then qInput's ReLU as the mask of the same launch
+        dpre = ops.skinny_linear(dqcmd, stacked_t([W0, W1, W2]), mask=base)
+        dW = [grad_buffer(W) for W in (W0, W1, W2)]
         db = [grad_buffer(b) for b in (b0, b1, b2)]
-        ops.colsum_segs(dqcmd, 3 * C, B, [(db[t], t * C, C) for t in range(3)])
-        # qInput + ReLU
-        dpre = torch.ops.aten.threshold_backward(dbase, base, 0)
-        dqvec = _linear_dx(dpre, packed(Wq, (1, 2, 0), ops.F32))
-        dWq = torch.mm(dpre.t(), qvec, out=grad_buffer(Wq))
-        dbq = grad_buffer(bq)
-        ops.colsum_segs(dpre, H, B, [(dbq, 0, H)])
+        leaves += [dict(dY=dqcmd[:, t * C:(t + 1) * C], X=base, dW=dW[t], db=db[t]) for t in range(3)]
+        dqvec = ops.skinny_linear(dpre, packed(Wq, (1, 2, 0), ops.F32))
+        dWq, dbq = grad_buffer(Wq), grad_buffer(bq)
+        leaves.append(dict(dY=dpre, X=qvec, dW=dWq, db=dbq))
         ops.qe_qvec_bwd(dqvec, lens, dout, B, L, C)
-        demb_tm, lstm_grads = _lstm_backward(dout, emb_tm, lens, lstm_params, ctx.saved_tensors[8:], B, L)
+        demb_tm, lstm_grads = _lstm_backward(dout, emb_tm, lens, lstm_params, ctx.saved_tensors[9:], B, L, leaves)
         table = ctx.table
         dtable = grad_buffer(table)
         ops.qe_embed_bwd(tokens, demb_tm, dtable, B, L, E, table.shape[0], 0)      # nn.Embedding(padding_idx=0)
-        return (None, None, dtable) + lstm_grads + (dWq, dbq, dW[0], db[0], dW[1], db[1], dW[2], db[2], dwl, dbl)
+        ops.outer_wgrad(leaves)                                                    # every weight / bias gradient of the node
+        return (None, None, dtable) + lstm_grads + (dWq, dbq, dW[0], db[0], dW[1], db[1], dW[2], db[2], dwl, dbl) + gate_grads
 
 
-def query_encoder(tokens, lengths, enc):
-    """enc: drn_amd.model.language_module.QueryEncoder (parameter holder).  Returns the three (B, 2H) commands."""
+def query_encoder(tokens, lengths, enc, gate_linears=None):
+    """enc: drn_amd.model.language_module.QueryEncoder (parameter holder).  Returns the three (B, 2H) commands, or -- with
+    gate_linears = mainModel's three qInput{t} nn.Linear holders -- the three per-level gate tensors (B, C_t)."""
     if enc.embedding.padding_idx != 0:
         raise DrnError("query encoder kernels assume nn.Embedding(padding_idx=0) (model/language_module.py:13)")
+    extra = []
+    for lin in (gate_linears or []):
+        extra += [lin.weight, lin.bias]
     return _QueryEncoderFn.apply(tokens, lengths, enc.embedding.weight, *_lstm_param_list(enc.biLSTM),
                                  enc.qInput.weight, enc.qInput.bias, enc.qInput0.weight, enc.qInput0.bias,
                                  enc.qInput1.weight, enc.qInput1.bias, enc.qInput2.weight, enc.qInput2.bias,
-                                 enc.cmd_inter2logits.weight, enc.cmd_inter2logits.bias)
+                                 enc.cmd_inter2logits.weight, enc.cmd_inter2logits.bias, *extra)
 
 
 class _LGPFn(torch.autograd.Function):

@@ -50,8 +50,12 @@ class mainModel(nn.Module):
 
     def encode_query(self, query_tokens, query_length):
         """Query encoder + per-level gate projections (model/main_model.py:47-50): three (B, C_l) fp32 gate tensors."""
+        n = len(self.backbone_net.blocks)
+        if n == 3:          # the whole query side, gate projections included, as one autograd node
+            return list(DF.query_encoder(query_tokens, query_length, self.query_encoder,
+                                         [getattr(self, "qInput%d" % i) for i in range(n)]))
         query_features = self.query_encoder(query_tokens, query_length)
-        return [DF.linear(query_features[i], getattr(self, "qInput%d" % i)) for i in range(len(query_features))]
+        return [DF.linear(query_features[i], getattr(self, "qInput%d" % i)) for i in range(n)]
 
     # The step splits at the tensors that leave the "front" (query encoder, gate projections, prop_fc, position
     # embedding): g0 and the gates of levels 1.. .  Backward runs the trunk (backbone, FPN, heads, losses) first, so its
@@ -82,19 +86,15 @@ class mainModel(nn.Module):
         `gates`: reuse already computed gate tensors (e.g. detached ones) instead of running the query encoder."""
         if not props_features.is_cuda:
             raise DrnError("drn_amd.mainModel runs on an MI355X only (inputs on %s); no CPU fallback" % props_features.device)
-        if gates is None:
-            gates = self.encode_query(query_tokens, query_length)
         dt = self.compute_dtype
-        # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
-        if props_start_end.dtype in (torch.float64, torch.float32):
-            position_feat = ops.pos_feat(props_start_end)                 # one launch instead of sub + cat + cast
-        else:
-            duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
-            position_feat = torch.cat((props_start_end, duration), dim=-1).float()
         # bf16 rows must be 16-byte multiples for the MFMA kernels' LDS staging; a feature dim that is not (D = 500, the
         # ActivityNet C3D-PCA convention) keeps the two layers that see D -- prop_fc and conv0 -- on the exact-f32 kernels
         front_dt = torch.float32 if (dt == torch.bfloat16 and props_features.shape[2] % 8) else dt
-        g0 = DF.input_stage(props_features, position_feat, self.prop_fc, gates[0], self.position_transform, front_dt)
+        want_wgrad = self.prop_fc.weight.requires_grad and torch.is_grad_enabled()
+        if gates is None:
+            gates = self.encode_query(query_tokens, query_length)
+        prep = DF.input_prep(props_features, props_start_end, self.prop_fc, front_dt, want_wgrad)
+        g0 = DF.input_stage(prep, self.prop_fc, gates[0], self.position_transform)
         return g0, gates
 
     def forward_trunk(self, g0, gates, gt_start_end):

@@ -218,27 +218,80 @@ def pack_weights_into(items, dtype):
     check(lib().drn_pack_weights(arr, len(items), dtype, _stream()), "drn_pack_weights")
 
 
-def skinny_linear(x, W, bias=None, relu=False):
-    """y = x W^T (+ bias)(ReLU) for batch-sized x (M <= 64 rows), fp32, exact-fp32 MFMA (drn_amd/csrc/skinny.hip)."""
-    _need_gpu(x, W)
-    M, K = x.shape
-    N = W.shape[0]
-    assert W.shape[1] == K and x.stride(1) == 1 and W.is_contiguous()
-    L = lib()
-    L.drn_skinny_ws_elems.restype = ctypes.c_int64
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    n_ws = int(L.drn_skinny_ws_elems(M, N, K))
-    ws = workspace(n_ws, x.device) if n_ws else None
-    check(L.drn_skinny_linear(_p(x), x.stride(0), _p(W), _p(bias), _p(y), N, M, N, K, int(relu), _p(ws), _stream()),
-          "drn_skinny_linear")
-    return y
+_qd_counters = {}
 
 
-SKINNY = __import__("os").environ.get("DRN_SKINNY", "1") == "1"     # 0: library GEMMs for the batch-sized linears
+def _counters(device):
+    """DRN_QD_COUNTERS zeroed int32 arrival counters per device for the K-split dense kernels (they re-arm themselves)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    c = _qd_counters.get(key)
+    if c is None:
+        c = _qd_counters[key] = torch.zeros(_lib.QD_COUNTERS, dtype=torch.int32, device=device)
+    return c
+
+
+def skinny_group(probs):
+    """probs: list of dict(X (M<=64, K) fp32 [row stride % 4 == 0], W (N, K) contiguous, bias=None, mask=None, relu=False,
+    Y=None): Y = X W^T (+bias)(ReLU)(zero where mask <= 0) for all problems in ONE launch (per DRN_QD_MAX problems).
+    Returns the outputs.  Exact-fp32 MFMA, deterministic (drn_amd/csrc/qdense.hip)."""
+    outs = []
+    for c0 in range(0, len(probs), _lib.QD_MAX):
+        chunk = probs[c0:c0 + _lib.QD_MAX]
+        arr = (_lib.SkinnyDesc * len(chunk))()
+        dev = chunk[0]["X"].device
+        for d, q in zip(arr, chunk):
+            X, W = q["X"], q["W"]
+            _need_gpu(X, W)
+            M, K = X.shape
+            N = W.shape[0]
+            assert W.shape[1] == K and W.is_contiguous() and X.stride(1) == 1 and X.dtype == W.dtype == torch.float32
+            Y = q.get("Y")
+            if Y is None:
+                Y = torch.empty((M, N), dtype=torch.float32, device=dev)
+            mask = q.get("mask")
+            d.X, d.W, d.bias, d.mask, d.Y = _p(X), _p(W), _p(q.get("bias")), _p(mask), _p(Y)
+            d.ldx, d.ldy, d.ldm = X.stride(0), Y.stride(0), (mask.stride(0) if mask is not None else 0)
+            d.M, d.N, d.K, d.relu = M, N, K, int(bool(q.get("relu")))
+            outs.append(Y)
+        n_ws = int(lib().drn_skinny_group_ws_elems(arr, len(chunk)))
+        ws = workspace(n_ws, dev) if n_ws else None
+        check(lib().drn_skinny_group(arr, len(chunk), _p(ws), _p(_counters(dev)), _stream()), "drn_skinny_group")
+    return outs
+
+
+def skinny_linear(x, W, bias=None, relu=False, mask=None):
+    """y = x W^T (+ bias)(ReLU) for batch-sized x (M <= 64 rows), fp32."""
+    return skinny_group([dict(X=x, W=W, bias=bias, relu=relu, mask=mask)])[0]
+
+
+def skinny_rows(X, W, bias=None):
+    """Y = X W^T for a taller X (e.g. clips x words rows): 64-row blocks of X as the problems of grouped launches."""
+    M = X.shape[0]
+    Y = torch.empty((M, W.shape[0]), dtype=torch.float32, device=X.device)
+    skinny_group([dict(X=X[r:r + 64], W=W, bias=bias, Y=Y[r:r + 64]) for r in range(0, M, 64)])
+    return Y
+
+
+def outer_wgrad(probs):
+    """probs: list of dict(dY (M, N), X (M, K) or None, dW (N, K) or None, db=None, db2=None): dW = dY^T X, db = db2 = column
+    sums of dY, all problems in one launch per DRN_QD_MAX (drn_amd/csrc/qdense.hip)."""
+    for c0 in range(0, len(probs), _lib.QD_MAX):
+        chunk = probs[c0:c0 + _lib.QD_MAX]
+        arr = (_lib.OuterDesc * len(chunk))()
+        for d, q in zip(arr, chunk):
+            dY, X, dW = q["dY"], q.get("X"), q.get("dW")
+            _need_gpu(dY, X, dW)
+            assert dY.stride(1) == 1 and dY.dtype == torch.float32
+            d.dY, d.X, d.dW, d.db, d.db2 = _p(dY), _p(X), _p(dW), _p(q.get("db")), _p(q.get("db2"))
+            d.ldy, d.M, d.N = dY.stride(0), dY.shape[0], dY.shape[1]
+            if dW is not None:
+                assert X.stride(1) == 1 and X.shape[0] == dY.shape[0] and dW.stride(1) == 1 and dW.shape == (dY.shape[1], X.shape[1])
+                d.ldx, d.ldw, d.K = X.stride(0), dW.stride(0), X.shape[1]
+        check(lib().drn_outer_wgrad(arr, len(chunk), _stream()), "drn_outer_wgrad")
 
 
 def skinny_ok(M, N, K):
-    return SKINNY and M <= 64 and N % 16 == 0 and K % 64 == 0
+    return M <= 64 and K % 4 == 0
 
 
 def touch(t):

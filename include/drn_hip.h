@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 1
+#define DRN_ABI_VERSION 2
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
@@ -277,13 +277,38 @@ typedef struct {
 } DrnColSeg;
 int drn_colsum_segs(const float* X, int ld, int M, const DrnColSeg* segs /*host*/, int nsegs, void* stream);
 
-/* ---- batch-sized dense layers (drn_amd/csrc/skinny.hip; model/language_module.py:20-23,55-56, model/main_model.py:37-50)
- * Y[M][N] = X[M][K] * W[N][K]^T (+ bias[N]) (ReLU), fp32, M <= 64 rows (clips per GPU), N % 16 == 0, K % 64 == 0: the
- * qInput* / gate projections forward, and their input gradients through transposed weight copies.  Exact-fp32 MFMA,
- * K split over workgroups with a deterministic second pass; ws >= drn_skinny_ws_elems() floats (may be 0). */
-int64_t drn_skinny_ws_elems(int M, int N, int K);
-int drn_skinny_linear(const float* X, int ldx, const float* W, const float* bias /*or NULL*/, float* Y, int ldy, int M, int N, int K,
-                      int relu, float* ws, void* stream);
+/* ---- batch-sized dense layers of the query side (drn_amd/csrc/qdense.hip; model/language_module.py:13-23,38-63,
+ * model/main_model.py:36-50), fp32, exact-fp32 MFMA, GROUPED: one launch serves up to DRN_QD_MAX problems.
+ * drn_skinny_group:  Y[M][N] = X[M][K] * W[N][K]^T (+ bias[N]) (ReLU) (zeroed where mask[m][n] <= 0), M <= 64 rows, any N,
+ *   K % 4 == 0: qInput* / the gate projections / the LSTM input projection forward, and -- through cached transposed
+ *   weight copies -- their input gradients (mask = the ReLU of the layer in front).  Long K is split over workgroups; the
+ *   last-arriving workgroup of a column tile adds the partial tiles in a fixed order (deterministic, no second launch):
+ *   ws >= drn_skinny_group_ws_elems() floats, counters = DRN_QD_COUNTERS int32 zeros owned by the caller (the kernel
+ *   leaves them zero).
+ * drn_outer_wgrad:  dW[N][K] = sum_m dY[m][N] * X[m][K] (row stride ldw), db[N] = db2[N] = sum_m dY[m][N] (optional):
+ *   the weight / bias gradients of the same layers (M = clips, or clips x words for the LSTM weights).  A problem with
+ *   dW == NULL only produces the column sums. */
+#define DRN_QD_MAX 16
+#define DRN_QD_COUNTERS 2048
+typedef struct DrnSkinnyDesc {
+  const float* X;
+  const float* W;
+  const float* bias; /* or NULL */
+  const float* mask; /* or NULL; [M][ldm] */
+  float* Y;
+  int32_t ldx, ldy, ldm, M, N, K, relu;
+} DrnSkinnyDesc;
+int64_t drn_skinny_group_ws_elems(const DrnSkinnyDesc* descs /*host*/, int n);
+int drn_skinny_group(const DrnSkinnyDesc* descs /*host*/, int n, float* ws, int32_t* counters, void* stream);
+typedef struct DrnOuterDesc {
+  const float* dY;
+  const float* X;
+  float* dW;
+  float* db;  /* or NULL */
+  float* db2; /* or NULL */
+  int32_t ldy, ldx, ldw, M, N, K;
+} DrnOuterDesc;
+int drn_outer_wgrad(const DrnOuterDesc* descs /*host*/, int n, void* stream);
 
 /* ---- language-guided pooling (drn_amd/csrc/lgp.hip; model/LGP.py:29-51) ---------------------------------------
  * x (B, t, C) channels-last, qn (B, C) fp32 = BN(conv1x1(query)) prepared by the caller, out (B, t/2, C),

@@ -148,7 +148,8 @@ def test_input_stage_fwd_bwd(dt):
         fch.weight.copy_(fc.weight.float()); fch.bias.copy_(fc.bias.float())
         pth.weight.copy_(pt.weight.float()); pth.bias.copy_(pt.bias.float())
     qh = q.detach().float().to(DEV).requires_grad_()
-    g0 = DF.input_stage(feats.float().to(DEV), pos.float().to(DEV), fch, qh, pth, dt)
+    prep = DF.input_prep(feats.float().to(DEV), pos.float().to(DEV), fch, dt)
+    g0 = DF.input_stage(prep, fch, qh, pth)
     (g0.float() * w.float().to(DEV)).sum().backward()
     tol = TOL[dt]
     close(g0, ref, tol, "G0")

@@ -49,6 +49,9 @@ def test_repack_all_refreshes_cached_weight_layouts_in_place(dt):
     perms = [(0, 2, 1), (1, 2, 0)]
     copies = [(p, perm, DF.packed(p, perm, code)) for p in params for perm in (perms if p.dim() == 3 else perms[:1])]
     ptrs = [c.data_ptr() for _, _, c in copies]
+    # fp32 concatenations (rewritten by the Adam kernel itself: same element order) and a transposed stack (repack_all)
+    stack, stack_t = DF.stacked([params[0], params[6]]), DF.stacked_t([params[28]])
+    sptr, tptr = stack.data_ptr(), stack_t.data_ptr()
     red = GradReducer(params, world_size=1)
     opt = FusedAdam(red, lr=1e-1, max_norm=1e9)
     red.zero()
@@ -65,3 +68,7 @@ def test_repack_all_refreshes_cached_weight_layouts_in_place(dt):
         want = w3.permute(*perm).contiguous().to(dt)
         want = want.view(want.shape[0], -1) if p.dim() == 2 else want
         assert torch.equal(again, want)
+    again = DF.stacked([params[0], params[6]])
+    assert again.data_ptr() == sptr and torch.equal(again, torch.cat([params[0].detach(), params[6].detach()]))
+    again = DF.stacked_t([params[28]])
+    assert again.data_ptr() == tptr and torch.equal(again, params[28].detach().t().contiguous())

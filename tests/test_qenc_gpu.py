@@ -1,4 +1,4 @@
-"""Fused query encoder (drn_amd.functional._QueryEncoderFn: drn_qe_* + drn_lstm_step_* kernels + library GEMMs) against
+"""Fused query encoder (drn_amd.functional._QueryEncoderFn: drn_qe_* + drn_lstm_step_* + drn_skinny_group + drn_outer_wgrad kernels) against
 the oracle's QueryEncoder (oracle/drn_oracle.py, model/language_module.py:9-62) in fp64 on the CPU: the three attention
 commands and the gradient of every parameter, including the dense embedding gradient with its zero padding row."""
 import pytest
@@ -114,7 +114,7 @@ def test_skinny_linear(M, N, K, relu, bias):
 def test_gate_linear_function_matches_torch():
     from drn_amd import functional as DF
     g = torch.Generator().manual_seed(3)
-    for N, K in [(4096, 1024), (500, 1024), (256, 1024)]:          # 500: not a multiple of 16 -> library path
+    for N, K in [(4096, 1024), (500, 1024), (256, 1024)]:          # 500: not a multiple of 16 (ragged last column tile)
         lin = torch.nn.Linear(K, N).to("cuda:0")
         ref = torch.nn.Linear(K, N).double()
         ref.load_state_dict({k: v.double().cpu() for k, v in lin.state_dict().items()})
@@ -127,3 +127,114 @@ def test_gate_linear_function_matches_torch():
         _close(xh.grad, xr.grad, 1e-5, "dx")
         _close(lin.weight.grad, ref.weight.grad, 1e-5, "dW")
         _close(lin.bias.grad, ref.bias.grad, 1e-5, "db")
+
+
+def test_skinny_group_ragged_and_masked():
+    """drn_skinny_group: several problems of different shapes in one launch -- N not a multiple of 16, K = 300 (a multiple
+    of 4 only), long-K ones (split over workgroups, last-arriver reduce) next to short ones, bias / ReLU / mask epilogues, a strided X -- against
+    fp64, bit-identical from launch to launch; a short-K-only group as well."""
+    from drn_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    shapes = [(32, 4096, 300, False, False, False), (64, 300, 4096, False, False, False), (32, 512, 3072, False, False, True),
+              (7, 50, 2048, True, True, False), (32, 1024, 4096, True, False, False), (1, 1, 4, False, True, False)]
+    probs, wants = [], []
+    for M, N, K, bias, relu, mask in shapes:
+        wide = torch.randn(M, K + 8, generator=g).to(dev)
+        x = wide[:, 4:4 + K]                                        # row stride K + 8, 16-byte aligned start
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=g).to(dev) if bias else None
+        mk = torch.randn(M, N, generator=g).to(dev) if mask else None
+        want = x.double() @ W.double().t() + (b.double() if bias else 0)
+        want = want.clamp_min(0) if relu else want
+        if mask:
+            want = want * (mk.double() > 0)
+        probs.append(dict(X=x, W=W, bias=b, relu=relu, mask=mk))
+        wants.append(want.cpu())
+    first = None
+    for rep in range(4):                                  # repeated: the K-split tiles' arrival counters re-arm themselves
+        outs = ops.skinny_group(probs)
+        for o, wnt, sh in zip(outs, wants, shapes):
+            _close(o, wnt, 3e-6, "skinny_group %s rep %d" % (sh, rep))
+        if first is None:
+            first = [o.clone() for o in outs]
+        assert all(torch.equal(a, b) for a, b in zip(first, outs)), "K-split reduce must be order-independent (deterministic)"
+    assert int(ops._counters(torch.device(dev)).abs().sum()) == 0
+    short = [0, 5]
+    outs = ops.skinny_group([probs[i] for i in short])
+    for o, i in zip(outs, short):
+        _close(o, wants[i], 3e-6, "skinny_group short-K %s" % (shapes[i],))
+    y = ops.skinny_rows(torch.randn(200, 300, generator=g).to(dev), probs[0]["W"])
+    assert y.shape == (200, 4096)
+
+
+def test_outer_wgrad_group():
+    """drn_outer_wgrad: dW = dY^T X and db = db2 = column sums for a group of problems (M = 32 and M = 256 rows, K = 300,
+    column-sliced dY / X views, a bias-only problem) against fp64."""
+    from drn_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(12)
+    probs, checks = [], []
+    big = torch.randn(256, 4096, generator=g).to(dev)
+    emb = torch.randn(256, 300, generator=g).to(dev)
+    hp = torch.randn(256, 1024, generator=g).to(dev)
+    for dY, X in [(big[:, :2048], emb), (big[:, 2048:], hp[:, 512:]), (torch.randn(32, 4096, generator=g).to(dev), torch.randn(32, 1024, generator=g).to(dev)),
+                  (torch.randn(32, 50, generator=g).to(dev), torch.randn(32, 20, generator=g).to(dev)), (torch.randn(5, 1, generator=g).to(dev), None)]:
+        N = dY.shape[1]
+        dW = torch.full((N, X.shape[1]), float("nan"), device=dev) if X is not None else None
+        db, db2 = torch.full((N,), float("nan"), device=dev), torch.full((N,), float("nan"), device=dev)
+        probs.append(dict(dY=dY, X=X, dW=dW, db=db, db2=db2))
+        checks.append((dY, X, dW, db, db2))
+    probs.append(dict(dY=probs[2]["dY"], X=probs[2]["X"], dW=torch.empty(4096, 1024, device=dev)))      # no bias requested
+    ops.outer_wgrad(probs)
+    for dY, X, dW, db, db2 in checks:
+        if X is not None:
+            _close(dW, (dY.double().t() @ X.double()).cpu(), 3e-6, "dW %s" % (tuple(dW.shape),))
+        want = dY.double().sum(0).cpu()
+        _close(db, want, 3e-6, "db")
+        assert torch.equal(db, db2)
+    _close(probs[-1]["dW"], (checks[2][0].double().t() @ checks[2][1].double()).cpu(), 3e-6, "dW without bias")
+
+
+def test_query_side_with_gate_projections_matches_oracle():
+    """mainModel.encode_query: the query encoder and the three per-level gate projections qInput{t} (main_model.py:47-50)
+    as ONE autograd node, against the oracle's modules in fp64 -- gates and every parameter gradient."""
+    from drn_amd import functional as DF
+    from drn_amd.model.language_module import QueryEncoder
+    from oracle import drn_oracle as O
+    B, L, H, E, V = 32, 8, 512, 300, 60
+    Cs = [4096, 256, 512]
+    g = torch.Generator().manual_seed(21)
+    lens = sorted(torch.randint(3, L + 1, (B,), generator=g).tolist(), reverse=True)
+    lens[0] = L
+    lengths = torch.tensor(lens, dtype=torch.int64)
+    tokens = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        tokens[b, :lens[b]] = torch.randint(1, V + 1, (lens[b],), generator=g)
+    ref = O.QueryEncoder(V, hidden_dim=H, embed_dim=E).double()
+    lin_r = [torch.nn.Linear(2 * H, c).double() for c in Cs]
+    with torch.no_grad():
+        for p in list(ref.parameters()) + [p for l in lin_r for p in l.parameters()]:
+            p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float64) * (p.shape[-1] ** -0.5 if p.dim() > 1 else 0.1))
+        ref.embedding.weight.mul_(E ** 0.5)
+        ref.embedding.weight[0].zero_()
+    w = [torch.randn(B, c, generator=g, dtype=torch.float64) for c in Cs]
+    gr = [lin_r[t](c) for t, c in enumerate(ref(tokens, lengths))]
+    sum((a * wi).sum() for a, wi in zip(gr, w)).backward()
+    dev = "cuda:0"
+    mod = QueryEncoder(V, hidden_dim=H, embed_dim=E)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mod = mod.to(dev)
+    lin_h = [torch.nn.Linear(2 * H, c).to(dev) for c in Cs]
+    for lh, lr in zip(lin_h, lin_r):
+        lh.load_state_dict({k: v.float() for k, v in lr.state_dict().items()})
+    gh = DF.query_encoder(tokens.to(dev), lengths.to(dev), mod, lin_h)
+    sum((a * wi.float().to(dev)).sum() for a, wi in zip(gh, w)).backward()
+    for t in range(3):
+        _close(gh[t], gr[t], 3e-5, "gate%d" % t)
+        _close(lin_h[t].weight.grad, lin_r[t].weight.grad, 2e-4, "qInput%d.weight" % t)
+        _close(lin_h[t].bias.grad, lin_r[t].bias.grad, 2e-4, "qInput%d.bias" % t)
+    refp = dict(ref.named_parameters())
+    for k, p in mod.named_parameters():
+        if not k.startswith("textualAttention"):
+            _close(p.grad, refp[k].grad, 2e-4, k)
