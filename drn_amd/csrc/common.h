@@ -45,6 +45,21 @@ static inline int drn_launch_status(const char* what) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Experiment switches: the shipped library carries the measured-best kernel variants only and never reads the environment.
+// `make EXPERIMENTS=1` (-DDRN_EXPERIMENTS) compiles the alternative variants back in and lets DRN_* variables select them
+// (DESIGN.md section 9).
+#ifdef DRN_EXPERIMENTS
+#include <stdlib.h>
+static inline const char* drn_exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* drn_exp_env(const char*) { return nullptr; }
+#endif
+// Two tuning values tests need (force the fused-tap weight-gradient kernel on small shapes / switch it off): set explicitly
+// through drn_tune(), process-wide, not read from the environment.
+int drn_tuning(int key);
+#define DRN_TUNE_TN3_MINROWS 0
+#define DRN_TUNE_TN_FUSED 1
+
 // ---- device helpers -------------------------------------------------------
 // zero-initialised source for masked 16-byte global_load_lds (one copy per translation unit)
 static __device__ uint4 g_zero_page[4];

@@ -686,15 +686,15 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     if (s.Cin % (8 * ch) != 0 || (s.mode == 1 && s.stride > 2)) fast = false;
   }
   int tile = big_tiles >= 200 ? 256 : 128;
-  if (const char* e = getenv("DRN_NT_TILE")) tile = atoi(e) == 256 ? 256 : 128;
-  if (getenv("DRN_NT_GENERIC")) fast = false;
+  if (const char* e = drn_exp_env("DRN_NT_TILE")) tile = atoi(e) == 256 ? 256 : 128;
+  if (drn_exp_env("DRN_NT_GENERIC")) fast = false;
   GemmParams P;
   memset(&P, 0, sizeof(P));
   P.ngroups = ngroups;
   P.ksplit = ksplit;
   P.ws = ws;
-  P.xcd_swizzle = getenv("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
-  if (const char* e = getenv("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);      // bit 0: XCD-contiguous runs, bit 1: 8-row grouped order
+  P.xcd_swizzle = drn_exp_env("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
+  if (const char* e = drn_exp_env("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);      // bit 0: XCD-contiguous runs, bit 1: 8-row grouped order
   if (ksplit > 1) tile = 128;
   int total = 0;
   for (int g = 0; g < ngroups; ++g) {
@@ -712,21 +712,24 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   // Pipeline depth for the 128x128 tile: 2 stages leave room for two workgroups per CU (best when the grid
   // oversubscribes the chip); 4 stages (one workgroup per CU) otherwise.  DRN_NT_STAGES overrides for experiments.
   int stages = (long)total * ksplit > 256 ? 2 : 4;
-  if (const char* e = getenv("DRN_NT_STAGES")) stages = atoi(e) == 2 ? 2 : 4;
+  if (const char* e = drn_exp_env("DRN_NT_STAGES")) stages = atoi(e) == 2 ? 2 : 4;
   if (tile == 256) stages = 2;
   // 128x128 tiles: 8 waves per workgroup, 2-slot ring (measured 20-30 % faster than 4 waves at one workgroup per CU, 8 % at
   // two; DRN_NT_WAVES=4 brings the 4-wave variants back for experiments)
   bool waves8 = tile == 128;
-  if (const char* e = getenv("DRN_NT_WAVES")) waves8 = tile == 128 && atoi(e) == 8;
-  if (waves8 && !getenv("DRN_NT_STAGES")) stages = 2;
+  if (const char* e = drn_exp_env("DRN_NT_WAVES")) waves8 = tile == 128 && atoi(e) == 8;
+  if (waves8 && !drn_exp_env("DRN_NT_STAGES")) stages = 2;
   static bool attr_set = false;
   if (!attr_set) {
 #define NT_ATTR(TT, SS, ...) \
     (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
     (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)
-    NT_ATTR(float, 2, 2, 2, 4, 4); NT_ATTR(bf16_t, 2, 2, 2, 4, 4); NT_ATTR(float, 4, 2, 2, 4, 4); NT_ATTR(bf16_t, 4, 2, 2, 4, 4);
     NT_ATTR(float, 2, 2, 4, 8, 4); NT_ATTR(bf16_t, 2, 2, 4, 8, 4);
-    NT_ATTR(float, 2, 2, 4, 4, 2); NT_ATTR(bf16_t, 2, 2, 4, 4, 2); NT_ATTR(float, 4, 2, 4, 4, 2); NT_ATTR(bf16_t, 4, 2, 4, 4, 2);
+    NT_ATTR(float, 2, 2, 4, 4, 2); NT_ATTR(bf16_t, 2, 2, 4, 4, 2);
+#ifdef DRN_EXPERIMENTS
+    NT_ATTR(float, 2, 2, 2, 4, 4); NT_ATTR(bf16_t, 2, 2, 2, 4, 4); NT_ATTR(float, 4, 2, 2, 4, 4); NT_ATTR(bf16_t, 4, 2, 2, 4, 4);
+    NT_ATTR(float, 4, 2, 4, 4, 2); NT_ATTR(bf16_t, 4, 2, 4, 4, 2);
+#endif
 #undef NT_ATTR
     attr_set = true;
   }
@@ -735,13 +738,18 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
   if (tile == 256) {
     if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 65536, 2, 4, 8, 4); else NT_LAUNCH(float, 2, 512, 2 * 65536, 2, 4, 8, 4);
-  } else if (waves8) {
-    if (dtype == DRN_BF16) { if (stages == 2) NT_LAUNCH(bf16_t, 2, 512, 2 * 32768, 2, 4, 4, 2); else NT_LAUNCH(bf16_t, 4, 512, 4 * 32768, 2, 4, 4, 2); }
-    else { if (stages == 2) NT_LAUNCH(float, 2, 512, 2 * 32768, 2, 4, 4, 2); else NT_LAUNCH(float, 4, 512, 4 * 32768, 2, 4, 4, 2); }
-  } else if (dtype == DRN_BF16) {
+  }
+#ifdef DRN_EXPERIMENTS
+  else if (waves8 && stages == 4) {
+    if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 4, 512, 4 * 32768, 2, 4, 4, 2); else NT_LAUNCH(float, 4, 512, 4 * 32768, 2, 4, 4, 2);
+  } else if (!waves8 && dtype == DRN_BF16) {
     if (stages == 2) NT_LAUNCH(bf16_t, 2, 256, 2 * 32768, 2, 2, 4, 4); else NT_LAUNCH(bf16_t, 4, 256, 4 * 32768, 2, 2, 4, 4);
-  } else {
+  } else if (!waves8) {
     if (stages == 2) NT_LAUNCH(float, 2, 256, 2 * 32768, 2, 2, 4, 4); else NT_LAUNCH(float, 4, 256, 4 * 32768, 2, 2, 4, 4);
+  }
+#endif
+  else {      // 128x128 tile, 8 waves, 2-slot ring
+    if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 32768, 2, 4, 4, 2); else NT_LAUNCH(float, 2, 512, 2 * 32768, 2, 4, 4, 2);
   }
 #undef NT_LAUNCH
   if (ksplit > 1) {

@@ -734,7 +734,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 
 // 256x256 tiles only when they alone fill half the chip (the 4096x4096 prop_fc gradient: 256 tiles)
 static int wgrad_tile(int N, int Cin, int taps) {
-  if (const char* e = getenv("DRN_TN_TILE")) return atoi(e) == 256 ? 256 : 128;
+  if (const char* e = drn_exp_env("DRN_TN_TILE")) return atoi(e) == 256 ? 256 : 128;
   return (long)cdiv(N, 256) * taps * cdiv(Cin, 256) >= 128 ? 256 : 128;
 }
 
@@ -758,7 +758,7 @@ static int total_blocks_upper(int M_total, int ngroups_max) {
 // fused 3-tap kernel (conv_wgrad3_tn_kernel): one 8-wave workgroup per CU; row splits fill the chip once.
 static int wgrad3_nsplit(int m_total, int N, int Cin) {
   int target = 256;
-  if (const char* e = getenv("DRN_TN3_TARGET")) target = atoi(e);
+  if (const char* e = drn_exp_env("DRN_TN3_TARGET")) target = atoi(e);
   const int tiles = cdiv(N, 128) * cdiv(Cin, 128);
   int ns = target / tiles;
   const int cap = cdiv(m_total, 64) / 8;      // every split owns >= 8 row blocks
@@ -768,8 +768,7 @@ static int wgrad3_nsplit(int m_total, int N, int Cin) {
   return ns;
 }
 static bool wgrad3_enabled() {
-  const char* e = getenv("DRN_TN_FUSED");
-  return !(e && atoi(e) == 0);
+  return drn_tuning(DRN_TUNE_TN_FUSED) != 0;
 }
 // stride-1 geometry, enough rows to amortise the wider tile, 32-bit element offsets (rows are addressed with a 24-bit multiply)
 static bool wgrad3_group_ok(const DrnWgradDesc& s) {
@@ -777,13 +776,14 @@ static bool wgrad3_group_ok(const DrnWgradDesc& s) {
          (long)s.M * s.ldy < (1L << 31) && (long)s.M * s.ldx < (1L << 31);
 }
 static int wgrad3_min_rows() {
-  if (const char* e = getenv("DRN_TN3_MINROWS")) return atoi(e);
-  return 4096;
+  return drn_tuning(DRN_TUNE_TN3_MINROWS);        // 4096 unless a test forces the kernel onto small shapes (drn_tune)
 }
 static void wgrad3_attr() {
   static bool set = false;
   if (!set) {
+#ifdef DRN_EXPERIMENTS
     (void)hipFuncSetAttribute((const void*)conv_wgrad3_tn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+#endif
     (void)hipFuncSetAttribute((const void*)conv_wgrad3_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     set = true;
   }
@@ -791,12 +791,16 @@ static void wgrad3_attr() {
 #define WGRAD3_STAGE (2 * 16384 + 512)
 static int wgrad3_stages() {
   int st = 4;
-  if (const char* e = getenv("DRN_TN3_STAGES")) st = atoi(e);
+  if (const char* e = drn_exp_env("DRN_TN3_STAGES")) st = atoi(e);
   return st < 3 ? 3 : (st > 4 ? 4 : st);
 }
+#ifdef DRN_EXPERIMENTS
 #define WGRAD3_LAUNCH(GRID, P) do { const int st_ = wgrad3_stages(); \
     if (st_ == 3) conv_wgrad3_tn_kernel<3><<<GRID, 512, 3 * WGRAD3_STAGE, stream>>>(P); \
     else conv_wgrad3_tn_kernel<4><<<GRID, 512, 4 * WGRAD3_STAGE, stream>>>(P); } while (0)
+#else
+#define WGRAD3_LAUNCH(GRID, P) conv_wgrad3_tn_kernel<4><<<GRID, 512, 4 * WGRAD3_STAGE, stream>>>(P)      // 4-deep ring
+#endif
 
 extern "C" int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps) {
   int ns = wgrad_nsplit(total_blocks_upper(M_total, DRN_MAX_GROUPS), N, Cin, taps);
@@ -894,12 +898,14 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
     if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 4, 8, 4><<<grid, 512, 2 * 65536, stream>>>(P);
     else conv_wgrad_tn_kernel<float, 2, 4, 8, 4><<<grid, 512, 2 * 65536, stream>>>(P);
   } else {
-    const bool w8 = !(getenv("DRN_TN_WAVES") && atoi(getenv("DRN_TN_WAVES")) == 4);     // 8 waves per 128x128 tile (default)
-    if (w8) {
-      if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
-      else conv_wgrad_tn_kernel<float, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
-    } else if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
-    else conv_wgrad_tn_kernel<float, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+#ifdef DRN_EXPERIMENTS
+    if (drn_exp_env("DRN_TN_WAVES") && atoi(drn_exp_env("DRN_TN_WAVES")) == 4) {
+      if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+      else conv_wgrad_tn_kernel<float, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+    } else
+#endif
+    if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);      // 8 waves per 128x128 tile
+    else conv_wgrad_tn_kernel<float, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
   }
   int rc = drn_launch_status("drn_gemm_wgrad");
   if (rc) return rc;

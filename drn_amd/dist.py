@@ -202,4 +202,4 @@ class GradReducer(object):
     def remove(self):
         for h in self._hooks:
             h.remove()
-        DF.clear_grad_sinks()
+        DF.unregister_grad_sinks(self.params)          # this reducer's parameters only: other models keep their sinks

@@ -92,10 +92,11 @@ _stack_cache = {}
 
 def _stack_items(out, params):
     items, r = [], 0
+    flat = out.view(out.shape[0], -1)                   # rows of the stack, whatever the parameters' trailing dims
     for p in params:
         n = p.shape[0]
         src = p.detach().reshape(n, 1, -1) if p.dim() > 1 else p.detach().view(1, 1, n)
-        items.append((src, (0, 1, 2), out[r:r + n]))
+        items.append((src, (0, 1, 2), flat[r:r + n] if p.dim() > 1 else out[r:r + n]))
         r += n
     return items
 
@@ -239,6 +240,12 @@ def register_grad_sink(param, flat_slice):
     _grad_sinks[param.data_ptr()] = flat_slice
 
 
+def unregister_grad_sinks(params):
+    """Forget the sinks of these parameters only (another model's reducer in the same process keeps its own)."""
+    for p in params:
+        _grad_sinks.pop(p.data_ptr(), None)
+
+
 def clear_grad_sinks():
     _grad_sinks.clear()
 
@@ -268,9 +275,8 @@ def grad_buffer(param, dtype=torch.float32):
 
 import os
 
-# prop_fc weight gradient through the NT kernel on transposed operands (bf16 only); DRN_NT_WGRAD=0 keeps the TN kernel
-NT_WGRAD = os.environ.get("DRN_NT_WGRAD", "1") == "1"
-TOUCH_W = os.environ.get("DRN_TOUCH_W", "1") == "1"          # warm the prop_fc weight copy right before its GEMM
+NT_WGRAD = True      # prop_fc weight gradient through the NT kernel on transposed operands (bf16): 250 vs 410 us for the TN kernel
+TOUCH_W = True       # warm the prop_fc weight copy right before its GEMM
 
 # BatchNorm `num_batches_tracked` increments are collected during a forward pass and applied by ONE multi-tensor add
 # (flush_bn_counters) instead of one tiny launch per BN call.
@@ -341,6 +347,22 @@ class _CastActFn(torch.autograd.Function):
 
 def cast_act(x, dtype):
     return x if x.dtype == dtype else _CastActFn.apply(x, dtype)
+
+
+# Debug tap (tests/test_parity_grad_gpu.py): a list that receives (weight tensor object, level, bool mask (B, L, C)) -- which
+# ReLU outputs were passed -- for every conv->BN->ReLU call and for the query encoder's qInput ReLU, so that a reference run can
+# be given this run's discrete decisions.  None (the default) costs nothing.
+relu_tap = None
+
+
+def _tap_relu(weight, level, out, up=None):
+    if relu_tap is None:
+        return
+    if up is None:
+        mask = out > 0
+    else:             # out = relu(y) + nearest_x2(up): passed <=> the sum moved (a y below half an ulp of `up` reads as blocked)
+        mask = out != up.repeat_interleave(2, dim=1)
+    relu_tap.append((weight, level, mask))
 
 
 class ConvMeta(object):
@@ -419,6 +441,9 @@ class _ConvBlockFn(torch.autograd.Function):
                                ld_up=upl.stride(1) if upl is not None else 0, gate=gate, gated=gated, ld_gated=Cout))
             outs.append(out)
         ops.bn_apply_multi(levels, Cout, code, relu=meta.relu)            # all pyramid levels in one launch
+        if relu_tap is not None and meta.relu:
+            for l in range(nl):
+                _tap_relu(weight, l, outs[l], up)
         ctx.meta, ctx.nl, ctx.geo, ctx.k = meta, nl, geo, k
         ctx.weight_obj = weight          # the Python object (a stack_params view carries its sources; saved tensors do not)
         ctx.has_gate, ctx.has_up, ctx.has_cbias = gate is not None, up is not None, cbias is not None
@@ -567,6 +592,9 @@ class _MultiConvFn(torch.autograd.Function):
             outs[l] = out
         if levels:
             ops.bn_apply_multi(levels, geo[0][5], code)
+        if relu_tap is not None:
+            for l in range(n):
+                _tap_relu(weights[l], 0, outs[l], outs[l + 1] if (chain_up and l + 1 < n) else None)
         ctx.meta, ctx.geo = meta, geo
         ctx.save_for_backward(*weights, *gammas, *xs, *raws, *sss, *saves)
         return tuple(outs)
@@ -1036,6 +1064,7 @@ class _QueryEncoderFn(torch.autograd.Function):
         qvec = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
         ops.qe_qvec_fwd(out, lens, qvec, B, L, C)                          # language_module.py:48-54
         base = ops.skinny_linear(qvec, Wq.detach(), bq.detach(), relu=True)               # language_module.py:55-56
+        _tap_relu(Wq, 0, base)
         qcmd = ops.skinny_linear(base, stacked([W0, W1, W2]), stacked([b0, b1, b2]))      # (B, 3*C): all three qInput{t}
         att = torch.empty((B, 3, L), dtype=torch.float32, device=dev)
         cmds = torch.empty((3, B, C), dtype=torch.float32, device=dev)

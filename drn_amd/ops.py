@@ -51,12 +51,10 @@ def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Ls
 # Optional per-launch timing of the MFMA kernels (bench.py): a list collecting (tag, flops, start_event, end_event),
 # the events recorded on the same stream the kernels run on.
 kernel_timer = None
-# Split-K (drn_gemm_nt_splitk) only pays for long-K problems that cannot fill the chip (conv0 forward: 128 tiles x 204 K-steps -> 2.2x faster);
-# short-K ones lose more to the extra reduce launch than they gain.  DRN_SPLITK=0 disables, =all uses the old wide rule.
-SPLITK = __import__("os").environ.get("DRN_SPLITK", "1")
-# with the 8-wave 128x128 tile an unsplit launch of 48 K-steps (conv2's data gradient) beats its 4-way split + reduce;
-# the split pays from ~96 K-steps (conv0 forward: 204)
-SPLITK_MIN_KSTEPS = int(__import__("os").environ.get("DRN_SPLITK_MIN_KSTEPS", "96"))
+# Split-K (drn_gemm_nt_splitk) only pays for long-K problems that cannot fill the chip (conv0 forward: 128 tiles x 204 K-steps
+# -> 2.2x faster); short-K ones lose more to the reduce pass than they gain: with the 8-wave 128x128 tile an unsplit launch
+# of 48 K-steps (conv2's data gradient) beats its 4-way split; the split pays from ~96 K-steps (conv0 forward: 204).
+SPLITK_MIN_KSTEPS = 96
 
 
 def _timed(tag, flops, launch):
@@ -73,7 +71,7 @@ def _ksplit(d, dtype):
     """Split-K factor for a single problem that cannot fill 256 CUs with 128x128 tiles."""
     tiles = ((d.M + 127) // 128) * ((d.N + 127) // 128)
     nkt = (d.taps * d.Cin) // (64 if dtype == BF16 else 32)
-    if tiles > 160 or nkt < (12 if SPLITK == "all" else SPLITK_MIN_KSTEPS):
+    if tiles > 160 or nkt < SPLITK_MIN_KSTEPS:
         return 1
     return max(1, min(8, 512 // tiles, nkt // 6))
 
@@ -81,7 +79,7 @@ def _ksplit(d, dtype):
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
-    if len(descs) == 1 and SPLITK != "0":
+    if len(descs) == 1:
         ks = _ksplit(descs[0], dtype)
         if ks > 1:
             d0 = descs[0]

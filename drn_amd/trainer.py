@@ -62,7 +62,7 @@ class Trainer(object):
                                        **({"bucket_bytes": 1 << 30} if world_size == 1 else {}))   # one process: one bucket
             self.opt = FusedAdam(self.reducer, lr=self.lr, max_norm=clip_gradient if clip_gradient is not None else 0.0)
         else:
-            DF.clear_grad_sinks()
+            DF.unregister_grad_sinks(model.parameters())   # autograd owns this model's gradients (other models keep their sinks)
             self.reducer = None
             self.opt = torch.optim.Adam(self.params, self.lr)
             self.opt.zero_grad()

@@ -26,6 +26,10 @@ extern "C" {
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
+/* Process-wide tuning values that tests use to reach kernels their shapes would not select: "tn3_minrows" (fewest rows for
+ * the fused-tap weight-gradient kernel, default 4096), "tn_fused" (0 switches that kernel off).  The library never reads the
+ * environment (the experiment build `make EXPERIMENTS=1` does). */
+int drn_tune(const char* key, int value);
 const char* drn_last_error(void); /* thread-local, valid until the next failing call on this thread */
 
 /* One problem of a grouped implicit-GEMM launch:  C[M][N] (+)= A'(M x K) * B[N][K]^T

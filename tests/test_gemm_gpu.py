@@ -12,6 +12,27 @@ DT = {"f32": torch.float32, "bf16": torch.bfloat16}
 TOL = {"f32": 2e-5, "bf16": 1e-2}
 
 
+
+def tune(monkeypatch, key, value):
+    """drn_tune(key, value) for the duration of one test (defaults restored afterwards)."""
+    from drn_amd import _lib
+    defaults = {"tn3_minrows": 4096, "tn_fused": 1}
+    _lib.check(_lib.lib().drn_tune(key.encode(), int(value)), "drn_tune")
+    _RESTORE.append((key, defaults[key]))
+
+
+_RESTORE = []
+
+
+@pytest.fixture(autouse=True)
+def _restore_tuning():
+    yield
+    if _RESTORE:
+        from drn_amd import _lib
+        while _RESTORE:
+            k, v = _RESTORE.pop()
+            _lib.lib().drn_tune(k.encode(), v)
+
 def dev():
     return torch.device("cuda:0")
 
@@ -308,7 +329,7 @@ def test_conv_wgrad_fused_taps(monkeypatch, B, L, Cin, Cout, layout):
     """All three taps from one staged X block (padded row space, halo rows): against the fp64 autograd gradient, plus
     accumulate; sequence lengths below / at / above the 64-row block, ragged channel counts, one sequence."""
     from drn_amd import ops
-    monkeypatch.setenv("DRN_TN3_MINROWS", "0")
+    tune(monkeypatch, "tn3_minrows", 0)
     x, w = conv_case("bf16", B, L, Cin, Cout, 3, 1)
     wr = w.double().requires_grad_()
     y = F.conv1d(x.double(), wr, stride=1, padding=1)
@@ -318,7 +339,7 @@ def test_conv_wgrad_fused_taps(monkeypatch, B, L, Cin, Cout, layout):
     xd, dyd = nlc(x).to(dev()), nlc(dy).to(dev())
     d = ops.wgrad_desc(dyd, xd, B * L, Lout=L, Lsrc=L)
     for fused in ("1", "0"):                      # the per-tap kernel on the same inputs keeps the comparison honest
-        monkeypatch.setenv("DRN_TN_FUSED", fused)
+        tune(monkeypatch, "tn_fused", int(fused))
         dW = torch.full(tuple(ref.shape), float("nan"), dtype=torch.float32, device=dev())
         ops.gemm_wgrad([d], dW, Cout, Cin, taps=3, stride=1, pad=1, w_layout=layout, dtype=ops.dtype_code(xd))
         torch.cuda.synchronize()
@@ -333,7 +354,7 @@ def test_conv_wgrad_fused_taps_levels(monkeypatch, multi):
     """Pyramid levels through the fused kernel: summed into one gradient (shared tower weights) and as independent problems
     (the FPN level convs); must agree with the per-tap kernel to fp32 rounding."""
     from drn_amd import ops
-    monkeypatch.setenv("DRN_TN3_MINROWS", "0")
+    tune(monkeypatch, "tn3_minrows", 0)
     g = torch.Generator().manual_seed(33)
     B, Cout, Cin = 4, 136, 200
     descs, keep = [], []
@@ -344,7 +365,7 @@ def test_conv_wgrad_fused_taps_levels(monkeypatch, multi):
         descs.append(ops.wgrad_desc(dY, X, B * L, Lout=L, Lsrc=L))
     res = {}
     for fused in ("0", "1"):
-        monkeypatch.setenv("DRN_TN_FUSED", fused)
+        tune(monkeypatch, "tn_fused", int(fused))
         if multi:
             outs = [torch.full((Cout, Cin, 3), float("nan"), device=dev()) for _ in descs]
             ops.gemm_wgrad_multi(descs, outs, Cout, Cin, taps=3, pad=1, w_layout=1, dtype=ops.BF16)
