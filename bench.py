@@ -23,6 +23,37 @@ sys.path.insert(0, ROOT)
 from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0
+
+
+def path_flops(T, D, stage):
+    """Algorithmic FLOPs per clip of the path (2 x multiply-adds of every contraction, query encoder excluded):
+    forward by component, and what one training step executes = 3 x forward - the prop_fc input gradient (the features need
+    no gradient, as in the reference's autograd) - in stage 1 the backward of the frozen IoU branch."""
+    SL = T + T // 2 + T // 4
+    f = {"prop_fc": 2.0 * T * D * D, "conv0": 2.0 * T * (D + 256) * 3 * 256,
+         "conv1": 2.0 * (T // 2) * 256 * 3 * 512, "conv2": 2.0 * (T // 4) * 512 * 3 * 1024,
+         "fpn": 2.0 * (T * 256 + (T // 2) * 512 + (T // 4) * 1024) * 512 + 2.0 * SL * 512 * 3 * 512,
+         "towers": 2.0 * SL * 512 * 3 * 1024, "outs": 2.0 * SL * 512 * 3 * 3,
+         "iou_branch": 2.0 * SL * (1024 * 512 + 512 * 3 * 256 + 256)}
+    fwd = sum(f.values())
+    step = 3.0 * fwd - f["prop_fc"] - (2.0 * f["iou_branch"] if stage == 1 else 0.0)
+    return {"fwd": fwd, "step": step, "fpn_heads_fwd": f["fpn"] + f["towers"] + f["outs"] + f["iou_branch"]}
+
+
+def time_graph(fn, reps=20):
+    """Median-free mean time (ms) of `reps` replays of a hipGraph of fn(), HIP events on the replay stream."""
+    from drn_amd.graph import GraphedStep
+    g = GraphedStep(fn, warmup=2).capture()
+    g()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def build(model_cls, cfg, device, **kw):
@@ -70,6 +101,8 @@ def main():
     ap.add_argument("--stage", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed oracle steps for cpu_baseline (~1 s each on 32 threads); 0 disables")
+    ap.add_argument("--no-f32", dest="f32_line", action="store_false",
+                    help="skip the extra exact-f32 (1e-4 parity mode) timing of the same workload reported as `f32`")
     ap.add_argument("--verbose", action="store_true", help="per-kernel MFMA timing table on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from Python instead of replaying a hipGraph")
@@ -121,8 +154,17 @@ def main():
 
     loss_of = lambda losses: losses["loss_iou"] if stage == 2 else DF.loss_total(losses)             # main.py:222-225
 
+    ar_events = None                 # N>1: HIP events around the exchange wait of every timed step (exposed all-reduce time)
+
     def opt_step():
-        reducer.finish()
+        if ar_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reducer.finish()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            reducer.finish()
         if args.torch_adam:
             torch.nn.utils.clip_grad_norm_(params, 0.5)              # main.py:238-239
         opt.step()
@@ -173,11 +215,15 @@ def main():
         for _ in range(args.warmup):
             step()
     barrier()
+    if world > 1:
+        ar_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = run()
     barrier()
     dt = time.perf_counter() - t0
+    exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
+    ar_events = None
     # per-kernel timing of the MFMA GEMMs for the roofline object: HIP events around each launch, on the launch
     # stream, over a few extra eager steps of the same workload (events cannot sit inside a replayed graph)
     timers = None
@@ -188,12 +234,67 @@ def main():
         torch.cuda.synchronize()
         ops.kernel_timer = None
         timed_steps = max(3, min(args.steps, 5))
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt, exposed_ms], device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = {"clips_per_s": [round(B * args.steps / float(t[0]), 1) for t in allr],
+                    "allreduce_exposed_ms_per_step": [round(float(t[1]), 4) for t in allr],
+                    "note": "exposed = GPU time the step's stream waits in GradReducer.finish() (query-side bucket + whatever of the "
+                            "trunk / prop_fc exchanges the next phase did not hide), HIP events"}
+        dt = max(float(t[0]) for t in allr)
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
+    fl = path_flops(T, D, stage)
+
+    # FPN + heads forward (north_star's named region) as its own hipGraph on the backbone outputs of this workload
+    fpn_heads = None
+    if rank == 0 and args.graph and not args.no_kernel_timing:
+        try:
+            with torch.no_grad():
+                g0, gates = model.forward_front(*batch[:4])
+                bb = model.backbone_net.forward_from_stage(g0, gates)
+
+                def fpn_heads_fwd():
+                    model.fcos.head.forward_nlc(model.fpn.forward_nlc(bb))
+                    DF.flush_bn_counters()
+                t_fh = time_graph(fpn_heads_fwd)
+            gf = fl["fpn_heads_fwd"] * B / 1e9
+            fpn_heads = {"GFLOP": round(gf, 1), "us": round(t_fh * 1e3, 1), "TFLOP/s": round(gf / t_fh, 1),
+                         "frac": round(gf / t_fh / PEAK_TFLOPS[args.dtype], 4),
+                         "note": "fpn.forward_nlc + fcos.head.forward_nlc (laterals, level convs, towers, cls/reg heads, mix_fc, IoU "
+                                 "head, train-mode BN) replayed as one hipGraph on this workload's C1..C3, HIP events over 20 replays"}
+        except Exception as e:
+            print("fpn+heads timing failed: %s" % e, file=sys.stderr)
+
+    # the same workload in the exact-f32 mode (the reference's own arithmetic, the <=1e-4 parity mode)
+    f32_line = None
+    if rank == 0 and world == 1 and args.f32_line and args.dtype == "bf16" and args.graph and not args.torch_adam:
+        try:
+            from drn_amd.optim import FusedAdam
+            m32 = build(mainModel, cfg, dev, compute_dtype=torch.float32)
+            p32 = stage_params(m32, stage)
+            m32.train()
+            r32 = ddist.GradReducer(p32, world_size=1, overlap=True, adjacent=m32.grad_stack_groups(), bucket_bytes=1 << 30)
+            o32 = FusedAdam(r32, lr=1e-3, max_norm=0.5)
+
+            def step32():
+                r32.zero()
+                _, ls = m32(*batch)
+                loss_of(ls).backward()
+                r32.finish()
+                o32.step()
+                return ls
+            t32 = time_graph(step32, reps=min(args.steps, 10))
+            f32_line = {"value": round(B / (t32 * 1e-3), 2), "unit": "clips/s", "ms_per_step": round(t32, 3), "dtype": "f32",
+                        "path_frac": round(fl["step"] * B / (t32 * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], 4),
+                        "note": "same step with compute_dtype=float32 (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak): the mode "
+                                "tests/test_parity_grad_gpu.py holds to 1e-4 against the oracle"}
+            r32.remove()
+            del m32, o32, r32
+        except Exception as e:
+            print("f32 timing failed: %s" % e, file=sys.stderr)
 
     roof = None
     if timers:
@@ -226,6 +327,20 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4),
                 "launches_per_step": n // timed_steps, "mfma_kernels_ms_per_step": round(gemm_ms, 3),
                 "note": "dominant kernel by total time; flops = 2*M*N*K of that launch; HIP events on the launch stream"}
+    # t_bound / t_measured with t_bound = max(FLOPs / peak_mfma, compulsory bytes / peak_hbm) over the WHOLE step
+    step_flops = fl["step"] * B * world
+    bytes_in = 4.0 * B * world * T * D                       # the feature tensor, read once (fp32 in HBM)
+    t_mfma, t_hbm = step_flops / (PEAK_TFLOPS[args.dtype] * 1e12 * world), bytes_in / (PEAK_HBM_TBS * 1e12 * world)
+    path = {"TFLOP_per_step": round(step_flops / 1e12, 4), "TFLOP/s": round(step_flops / (ms * 1e-3) / 1e12, 1),
+            "path_frac": round(max(t_mfma, t_hbm) / (ms * 1e-3), 4), "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+            "compulsory_input_bytes": int(bytes_in),
+            "note": "executed FLOPs = 3 x forward - prop_fc input gradient (- frozen IoU branch backward in stage 1), SURVEY 8d table"}
+    if roof is not None:
+        roof["path"] = path
+        roof["path_frac"] = path["path_frac"]
+        roof["fpn_heads_fwd"] = fpn_heads
+    else:
+        roof = {"bound": "mfma", "path": path, "path_frac": path["path_frac"], "fpn_heads_fwd": fpn_heads}
 
     out = {"metric": "clips/sec fwd+bwd (BxT=256x4096 C3D feats)", "value": round(value, 2), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -235,6 +350,10 @@ def main():
                       "global_batch": B * world, "T": T, "D": D, "parallelism": "dp%d" % world, "launch": mode,
                       "loss_cls": float(losses["loss_cls"].detach().reshape(-1)[0])},
            "roofline": roof}
+    if per_rank is not None:
+        out["per_rank"] = per_rank
+    if f32_line is not None:
+        out["f32"] = f32_line
     if rank == 0:
         if world == 1 and args.cpu_steps > 0:
             # stock PyTorch oversubscribes badly on these small convs beyond ~32 threads
