@@ -86,6 +86,12 @@ class HeadGroup(ctypes.Structure):
     _fields_ = [("X", c_void_p), ("dX", c_void_p), ("ldx", c_int32), ("M", c_int32), ("L", c_int32), ("scale", c_void_p)]
 
 
+class HeadCall(ctypes.Structure):
+    _fields_ = [("groups", c_void_p), ("ngroups", c_int32), ("N", c_int32), ("C", c_int32), ("taps", c_int32), ("exp_mode", c_int32),
+                ("accumulate_dx", c_int32), ("accumulate_dw", c_int32), ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+                ("z", c_void_p), ("dout", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("dscale", c_void_p), ("ws", c_void_p)]
+
+
 class LossLevel(ctypes.Structure):
     _fields_ = [("L", c_int32), ("stride", c_float), ("lo", c_float), ("hi", c_float)]
 

@@ -21,6 +21,27 @@ struct HeadParams {
   int N, C, taps, pad, exp_mode;
 };
 
+// Up to HEAD_MAX_SETS independent heads (own weights, own column slice of the level tensors, own outputs) share one launch:
+// blockIdx.z selects the set.  cls_logits and bbox_pred read the two halves of the same tower output; launched together
+// their workgroups fill the chip side by side instead of one half-empty launch after the other.
+#define HEAD_MAX_SETS 2
+struct HeadSet {
+  HeadParams P;
+  const float* W;      // [N][C][taps]
+  const float* bias;
+  float* out;
+  float* z;
+  const float* dout;
+  float* partial;      // backward: per-row-block partial sums
+  float* dW;
+  float* dbias;
+  float* dscale;
+  int accumulate_dx, accumulate_dw, nblk;
+};
+struct HeadMulti {
+  HeadSet s[HEAD_MAX_SETS];
+};
+
 __device__ __forceinline__ int head_group_of(const HeadParams& P, int r) {
   int g = 0;
 #pragma unroll
@@ -77,10 +98,14 @@ __device__ __forceinline__ float head_dz(const HeadParams& P, const HeadGroup& G
 
 // out[r][n] (and z[r][n] in exp mode); r = concatenated row over levels.  grid = ceil(rows / (4*HEAD_RPW)), block 256.
 template <typename T>
-__global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, const float* __restrict__ W /*[N][C][taps]*/,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           float* __restrict__ z) {
+__global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
   constexpr int VN = V16<T>::N;
+  const HeadSet& S = MS.s[blockIdx.z];
+  const HeadParams& P = S.P;
+  const float* __restrict__ W = S.W;
+  const float* __restrict__ bias = S.bias;
+  float* __restrict__ out = S.out;
+  float* __restrict__ z = S.z;
   const int N = P.N, C = P.C, taps = P.taps;
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: row bookkeeping on the scalar unit
@@ -206,10 +231,14 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadParams P, c
 
 // dX[m][c] (+)= sum_n sum_tap dz[row(s, t - tap + pad)][n] * W[n][c][tap].  grid (ceil(nvec/64), ceil(rows/(4*HEAD_RPW)))
 template <typename T>
-__global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadParams P, const float* __restrict__ W,
-                                                                const float* __restrict__ dout, const float* __restrict__ out,
-                                                                int accumulate) {
+__global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadMulti MS) {
   constexpr int VN = V16<T>::N;
+  const HeadSet& S = MS.s[blockIdx.z];
+  const HeadParams& P = S.P;
+  const float* __restrict__ W = S.W;
+  const float* __restrict__ dout = S.dout;
+  const float* __restrict__ out = S.out;
+  const int accumulate = S.accumulate_dx;
   const int N = P.N, C = P.C, taps = P.taps;
   const int v = blockIdx.x * 64 + (threadIdx.x & 63);
   const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: the dz scalars come through the scalar cache
@@ -269,16 +298,21 @@ __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadParams
 // grid (ceil(nvec/64), nblk); block 1024 = 64 channel vectors x 16 row lanes
 #define HEAD_EXTRA 8
 template <typename T>
-__global__ __launch_bounds__(1024) void head_out_bwd_w_kernel(const HeadParams P, const float* __restrict__ dout,
-                                                              const float* __restrict__ out, const float* __restrict__ z,
-                                                              float* __restrict__ partial) {
+__global__ __launch_bounds__(1024) void head_out_bwd_w_kernel(const HeadMulti MS) {
   constexpr int VN = V16<T>::N;
+  const HeadSet& S = MS.s[blockIdx.z];
+  const HeadParams& P = S.P;
+  const float* __restrict__ dout = S.dout;
+  const float* __restrict__ out = S.out;
+  const float* __restrict__ z = S.z;
+  float* __restrict__ partial = S.partial;
+  if ((int)blockIdx.y >= S.nblk) return;
   __shared__ float red[16][64 * VN + 1];
   const int N = P.N, C = P.C, taps = P.taps;
   const int vx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int v = blockIdx.x * 64 + vx;
   const bool live = v * VN < C;
-  const int rows_per = (P.total_rows + gridDim.y - 1) / gridDim.y;
+  const int rows_per = (P.total_rows + S.nblk - 1) / S.nblk;
   const int r0 = blockIdx.y * rows_per, r1 = min(P.total_rows, r0 + rows_per);
   const long pstride = (long)N * taps * C + HEAD_EXTRA;
   float* prow = partial + (long)blockIdx.y * pstride;
@@ -358,11 +392,15 @@ __global__ __launch_bounds__(1024) void head_out_bwd_w_kernel(const HeadParams P
 }
 
 // dW[n][c][tap] / dbias[n] / dscale[l] (+)= sum_blk partial[blk][...];  256 threads = 16 outputs x 16 lanes over the row blocks
-__global__ __launch_bounds__(256) void head_out_bwd_w_final_kernel(const float* __restrict__ partial, int nblk, int N, int C, int taps,
-                                                                   int ngroups, int exp_mode, float* __restrict__ dW,
-                                                                   float* __restrict__ dbias, float* __restrict__ dscale,
-                                                                   int accumulate) {
+__global__ __launch_bounds__(256) void head_out_bwd_w_final_kernel(const HeadMulti MS) {
   __shared__ float sh[16][17];
+  const HeadSet& S = MS.s[blockIdx.z];
+  const float* __restrict__ partial = S.partial;
+  const int nblk = S.nblk, N = S.P.N, C = S.P.C, taps = S.P.taps, ngroups = S.P.ngroups, exp_mode = S.P.exp_mode;
+  float* __restrict__ dW = S.dW;
+  float* __restrict__ dbias = S.dbias;
+  float* __restrict__ dscale = S.dscale;
+  const int accumulate = S.accumulate_dw;
   const int nw = N * taps * C, total = nw + HEAD_EXTRA;
   const int oi = threadIdx.x & 15, j = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + oi;
@@ -423,37 +461,79 @@ static int fill_head_params(HeadParams& P, const DrnHeadGroup* groups, int ngrou
   return DRN_OK;
 }
 
+static int fill_head_set(HeadSet& S, const DrnHeadCall& c, int dtype, bool backward, const char* who) {
+  int rc = fill_head_params(S.P, c.groups, c.ngroups, c.N, c.C, c.taps, c.exp_mode, dtype, backward, who);
+  if (rc) return rc;
+  S.W = c.W; S.bias = c.bias; S.out = c.out; S.z = c.z; S.dout = c.dout; S.partial = c.ws; S.dW = c.dW; S.dbias = c.dbias;
+  S.dscale = c.dscale; S.accumulate_dx = c.accumulate_dx; S.accumulate_dw = c.accumulate_dw;
+  S.nblk = S.P.total_rows >= 256 * 16 ? 256 : (S.P.total_rows >= 16 ? S.P.total_rows / 16 : 1);
+  if (!backward) DRN_CHECK_ARG(c.W && c.bias && c.out && (!c.exp_mode || c.z), "%s: null pointer", who);
+  else DRN_CHECK_ARG(c.W && c.dout && c.dW && c.dbias && c.ws && (!c.exp_mode || (c.out && c.z && c.dscale)), "%s: null pointer", who);
+  return DRN_OK;
+}
+
+extern "C" int drn_heads_fwd(const DrnHeadCall* calls, int ncalls, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(calls && ncalls >= 1 && ncalls <= HEAD_MAX_SETS, "drn_heads_fwd: 1..%d heads per launch", HEAD_MAX_SETS);
+  HeadMulti MS;
+  memset(&MS, 0, sizeof(MS));
+  int rows = 0;
+  for (int i = 0; i < ncalls; ++i) {
+    int rc = fill_head_set(MS.s[i], calls[i], dtype, false, "drn_heads_fwd");
+    if (rc) return rc;
+    rows = rows > MS.s[i].P.total_rows ? rows : MS.s[i].P.total_rows;
+  }
+  dim3 grid(cdiv(rows, 4 * HEAD_RPW), 1, ncalls);
+  DISPATCH_DT(dtype, "drn_heads_fwd", { head_out_fwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(MS); });
+  return drn_launch_status("drn_heads_fwd");
+}
+
+extern "C" int drn_heads_bwd(const DrnHeadCall* calls, int ncalls, int dtype, void* stream_) {
+  drn_clear_status();
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(calls && ncalls >= 1 && ncalls <= HEAD_MAX_SETS, "drn_heads_bwd: 1..%d heads per launch", HEAD_MAX_SETS);
+  HeadMulti MS;
+  memset(&MS, 0, sizeof(MS));
+  int rows = 0, cmax = 0, nblk = 0, tot = 0;
+  for (int i = 0; i < ncalls; ++i) {
+    int rc = fill_head_set(MS.s[i], calls[i], dtype, true, "drn_heads_bwd");
+    if (rc) return rc;
+    const HeadSet& S = MS.s[i];
+    rows = rows > S.P.total_rows ? rows : S.P.total_rows;
+    cmax = cmax > S.P.C ? cmax : S.P.C;
+    nblk = nblk > S.nblk ? nblk : S.nblk;
+    const int t = S.P.N * S.P.taps * S.P.C + HEAD_EXTRA;
+    tot = tot > t ? tot : t;
+  }
+  DISPATCH_DT(dtype, "drn_heads_bwd", {
+    constexpr int VN = V16<T>::N;
+    dim3 dgrid(cdiv(cmax / VN, 64), cdiv(rows, 4 * HEAD_RPW), ncalls);
+    head_out_bwd_data_kernel<T><<<dgrid, 256, 0, stream>>>(MS);
+    dim3 grid(cdiv(cmax / VN, 64), nblk, ncalls);
+    head_out_bwd_w_kernel<T><<<grid, 1024, 0, stream>>>(MS);
+  });
+  head_out_bwd_w_final_kernel<<<dim3(cdiv(tot, 16), 1, ncalls), 256, 0, stream>>>(MS);
+  return drn_launch_status("drn_heads_bwd");
+}
+
+// single-head entry points (one set per launch)
 extern "C" int drn_head_out_fwd(const DrnHeadGroup* groups, int ngroups, const float* W, const float* bias, int N, int C, int taps,
                                 int exp_mode, float* out, float* z, int dtype, void* stream) {
-  drn_clear_status();
-  HeadParams P;
-  int rc = fill_head_params(P, groups, ngroups, N, C, taps, exp_mode, dtype, false, "drn_head_out_fwd");
-  if (rc) return rc;
-  DRN_CHECK_ARG(W && bias && out && (!exp_mode || z), "drn_head_out_fwd: null pointer");
-  const int nb = cdiv(P.total_rows, 4 * HEAD_RPW);
-  DISPATCH_DT(dtype, "drn_head_out_fwd", { head_out_fwd_kernel<T><<<nb, 256, 0, (hipStream_t)stream>>>(P, W, bias, out, z); });
-  return drn_launch_status("drn_head_out_fwd");
+  DrnHeadCall c;
+  memset(&c, 0, sizeof(c));
+  c.groups = groups; c.ngroups = ngroups; c.W = W; c.bias = bias; c.N = N; c.C = C; c.taps = taps; c.exp_mode = exp_mode;
+  c.out = out; c.z = z;
+  return drn_heads_fwd(&c, 1, dtype, stream);
 }
 
 extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const float* W, const float* dout, const float* out,
                                 const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
                                 float* dscale, int accumulate_dw, float* ws /* >= 256*(N*taps*C + 8) floats */, int dtype,
-                                void* stream_) {
-  drn_clear_status();
-  hipStream_t stream = (hipStream_t)stream_;
-  HeadParams P;
-  int rc = fill_head_params(P, groups, ngroups, N, C, taps, exp_mode, dtype, true, "drn_head_out_bwd");
-  if (rc) return rc;
-  DRN_CHECK_ARG(W && dout && dW && dbias && ws && (!exp_mode || (out && z && dscale)), "drn_head_out_bwd: null pointer");
-  const int nblk = P.total_rows >= 256 * 16 ? 256 : (P.total_rows >= 16 ? P.total_rows / 16 : 1);
-  DISPATCH_DT(dtype, "drn_head_out_bwd", {
-    constexpr int VN = V16<T>::N;
-    dim3 dgrid(cdiv(C / VN, 64), cdiv(P.total_rows, 4 * HEAD_RPW));
-    head_out_bwd_data_kernel<T><<<dgrid, 256, 0, stream>>>(P, W, dout, out, accumulate_dx);
-    dim3 grid(cdiv(C / VN, 64), nblk);
-    head_out_bwd_w_kernel<T><<<grid, 1024, 0, stream>>>(P, dout, out, z, ws);
-  });
-  head_out_bwd_w_final_kernel<<<cdiv(N * taps * C + HEAD_EXTRA, 16), 256, 0, stream>>>(ws, nblk, N, C, taps, ngroups, exp_mode, dW,
-                                                                                          dbias, dscale, accumulate_dw);
-  return drn_launch_status("drn_head_out_bwd");
+                                void* stream) {
+  DrnHeadCall c;
+  memset(&c, 0, sizeof(c));
+  c.groups = groups; c.ngroups = ngroups; c.W = W; c.dout = dout; c.out = (float*)out; c.z = (float*)z; c.N = N; c.C = C; c.taps = taps;
+  c.exp_mode = exp_mode; c.accumulate_dx = accumulate_dx; c.dW = dW; c.dbias = dbias; c.dscale = dscale; c.accumulate_dw = accumulate_dw;
+  c.ws = ws;
+  return drn_heads_bwd(&c, 1, dtype, stream);
 }

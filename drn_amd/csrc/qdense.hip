@@ -214,9 +214,15 @@ struct OwGroupArgs {
   int n;
 };
 
-// workgroup: 64 rows of dW (n) x 64 columns (k); wave w owns 16 of the rows as four 16x16 MFMA tiles.  The four waves read
-// the same X columns (they meet in the CU's vector cache) and each dY / X panel is re-read N/64 resp. K/64 times from L2.
+// workgroup: 64 rows of dW (n) x 64 columns (k); wave w owns 16 of the rows as four 16x16 MFMA tiles.  The M rows are
+// consumed 32 at a time: the 32 x 64 slabs of dY and X are fetched with coalesced 16-byte loads (256 B per row), parked in
+// LDS (row pitch 80 floats: the four row groups of an MFMA operand read land on disjoint bank quarters) and the next
+// slab's loads are already in flight while the current one feeds the MFMAs -- operand loads straight in MFMA layout (4 B per
+// lane, every panel re-read by each wave) held this kernel to ~1.2 TB/s of L2 traffic.
+#define OW_MB 32
+#define OW_PITCH 80
 __global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupArgs G) {
+  __shared__ float Ys[OW_MB][OW_PITCH], Xs[OW_MB][OW_PITCH];
   int g = 0;
 #pragma unroll
   for (int i = 1; i < DRN_QD_MAX; ++i)
@@ -225,49 +231,75 @@ __global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupAr
   const int rel = blockIdx.x - P.blk0;
   const int tk = rel % P.ntk, tn = rel / P.ntk;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int n0 = tn * 64 + w * 16, k0 = tk * 64;
+  const int nb = tn * 64, k0 = tk * 64;
+  const int n0 = nb + w * 16;
   const int li = l & 15, lq = l >> 4;                    // A: (i = n, kk = m) ; B: (kk = m, j = k)
-  f32x4 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool nok = n0 + li < P.N;
-  bool kok[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) kok[j] = k0 + j * 16 + li < P.K;
   const bool want_db = (P.db != nullptr) && tk == 0;
   float bsum = 0.f;
   if (P.dW == nullptr) {                                 // column sums only
     if (!want_db) return;
     for (int m = lq; m < P.M; m += 4) bsum += nok ? P.dY[(long)m * P.ldy + n0 + li] : 0.f;
-  } else
-  for (int m0 = 0; m0 < P.M; m0 += 32) {                // 8 MFMA k-steps per trip, all 40 operands requested up front
-    float a[8], b[8][4];
+  } else {
+    f32x4 acc[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int m = m0 + u * 4 + lq;
-      const bool mok = m < P.M;
-      a[u] = (mok && nok) ? P.dY[(long)m * P.ldy + n0 + li] : 0.f;
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging map: thread t loads rows (t >> 4) and (t >> 4) + 16 of the slab, columns 4 * (t & 15) .. + 3 of both panels
+    const int sr = threadIdx.x >> 4, sc = (threadIdx.x & 15) * 4;
+    const bool yvec = (P.ldy % 4 == 0) && ((((uintptr_t)P.dY) & 15) == 0) && (nb + sc + 3 < P.N);
+    const bool xvec = (P.ldx % 4 == 0) && ((((uintptr_t)P.X) & 15) == 0) && (k0 + sc + 3 < P.K);
+    auto fetch = [&](const float* base, int ld, int m, int c, int cmax, bool vec) -> f32x4 {
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < P.M) {
+        const float* p = base + (long)m * ld + c;
+        if (vec) v = *(const f32x4*)p;
+        else
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[u][j] = (mok && kok[j]) ? P.X[(long)m * P.ldx + k0 + j * 16 + li] : 0.f;
+          for (int e = 0; e < 4; ++e)
+            if (c + e < cmax) v[e] = p[e];
+      }
+      return v;
+    };
+    f32x4 ry[2], rx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ry[h] = fetch(P.dY, P.ldy, sr + 16 * h, nb + sc, P.N, yvec);
+      rx[h] = fetch(P.X, P.ldx, sr + 16 * h, k0 + sc, P.K, xvec);
     }
+    for (int m0 = 0; m0 < P.M; m0 += OW_MB) {
+      __syncthreads();                                   // the previous slab's MFMA operand reads are done
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      bsum += a[u];
+      for (int h = 0; h < 2; ++h) {
+        *(f32x4*)&Ys[sr + 16 * h][sc] = ry[h];
+        *(f32x4*)&Xs[sr + 16 * h][sc] = rx[h];
+      }
+      __syncthreads();
+      if (m0 + OW_MB < P.M) {                            // next slab in flight while this one is multiplied
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][j], acc[j], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+          ry[h] = fetch(P.dY, P.ldy, m0 + OW_MB + sr + 16 * h, nb + sc, P.N, yvec);
+          rx[h] = fetch(P.X, P.ldx, m0 + OW_MB + sr + 16 * h, k0 + sc, P.K, xvec);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < OW_MB / 4; ++u) {
+        const float a = Ys[u * 4 + lq][w * 16 + li];
+        bsum += a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[u * 4 + lq][j * 16 + li], acc[j], 0, 0, 0);
+      }
     }
-  }
-  // D: n = n0 + lq*4 + r, k = k0 + j*16 + li
-  if (P.dW != nullptr)
+    // D: n = n0 + lq*4 + r, k = k0 + j*16 + li
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!kok[j]) continue;
+      if (k0 + j * 16 + li >= P.K) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + lq * 4 + r;
         if (n < P.N) P.dW[(long)n * P.ldw + k0 + j * 16 + li] = acc[j][r];
       }
     }
+  }
   if (want_db) {
     bsum += __shfl_xor(bsum, 16, 64);
     bsum += __shfl_xor(bsum, 32, 64);

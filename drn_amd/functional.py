@@ -795,7 +795,7 @@ class _HeadOutFn(torch.autograd.Function):
         dev = xs[0].device
         geo = [geom(x) for x in xs]
         R = sum(g[0] * g[1] for g in geo)
-        outs, zs = [], []
+        outs, zs, calls = [], [], []
         for h, (W, bias, scales) in enumerate(heads):
             N, C, taps = W.shape
             c0 = meta["cols"][h]
@@ -803,9 +803,10 @@ class _HeadOutFn(torch.autograd.Function):
             groups = ops.head_groups(xsl, scales=scales)
             out = torch.empty((R, N), dtype=torch.float32, device=dev)
             z = torch.empty((R, N), dtype=torch.float32, device=dev) if scales is not None else None
-            ops.head_out_fwd(groups, W, bias, N, C, taps, scales is not None, out, z, code)
+            calls.append(dict(groups=groups, W=W, bias=bias, N=N, C=C, taps=taps, exp_mode=scales is not None, out=out, z=z))
             outs.append(out)
             zs.append(z if z is not None else out.new_empty(0))
+        ops.heads_fwd(calls, code)                       # the heads of one call share launches (two per launch)
         ctx.meta, ctx.geo, ctx.R = meta, geo, R
         ctx.save_for_backward(*args, *outs, *zs)
         return tuple(outs)
@@ -826,7 +827,7 @@ class _HeadOutFn(torch.autograd.Function):
                                                                       for i in range(len(covered) - 1))
         alloc = torch.empty if full else torch.zeros
         dxs = [alloc((g[0], g[1], g[2]), dtype=dtype, device=dev) for g in geo]
-        grads = []
+        grads, calls = [], []
         for h in range(nheads):
             W, bias, scales = args[3 * h:3 * h + 3]
             N, C, taps = W.shape
@@ -846,12 +847,14 @@ class _HeadOutFn(torch.autograd.Function):
                 # dX geometry must match X's: both are slices of equally wide buffers
                 for x, dx in zip(xs, dxs):
                     assert x.stride(1) == dx.stride(1), "head input must be contiguous in backward"
-                ops.head_out_bwd(groups, W, dout, outs[h], zs[h] if scales is not None else None, N, C, taps,
-                                 scales is not None, False, dW, db, dsc, R, code)
+                calls.append(dict(groups=groups, W=W, dout=dout, out=outs[h], z=zs[h] if scales is not None else None, N=N, C=C,
+                                  taps=taps, exp_mode=scales is not None, accumulate_dx=False, dW=dW, dbias=db, dscale=dsc))
             elif full:
                 for dx in dxs:
                     dx[:, :, c0:c0 + C].zero_()
             grads += [dW, db, dsc]
+        if calls:
+            ops.heads_bwd(calls, code)
         return (None,) + tuple(grads) + tuple(dxs)
 
 

@@ -416,16 +416,45 @@ def head_groups(xs, dxs=None, scales=None):
     return (_lib.HeadGroup * len(gs))(*gs)
 
 
+def _head_calls(calls):
+    """calls: list of dicts(groups (HeadGroup array), W, N, C, taps, exp_mode, + bias/out/z (forward) or dout/out/z/dW/dbias/
+    dscale/ws (backward)).  Up to 2 heads share one launch (drn_amd/csrc/heads.hip)."""
+    arr = (_lib.HeadCall * len(calls))()
+    for d, c in zip(arr, calls):
+        d.groups = ctypes.cast(c["groups"], ctypes.c_void_p)
+        d.ngroups, d.N, d.C, d.taps, d.exp_mode = len(c["groups"]), c["N"], c["C"], c["taps"], int(c["exp_mode"])
+        d.accumulate_dx, d.accumulate_dw = int(c.get("accumulate_dx", 0)), 0
+        d.W, d.bias, d.out, d.z = _p(c["W"]), _p(c.get("bias")), _p(c.get("out")), _p(c.get("z"))
+        d.dout, d.dW, d.dbias, d.dscale, d.ws = _p(c.get("dout")), _p(c.get("dW")), _p(c.get("dbias")), _p(c.get("dscale")), _p(c.get("ws"))
+    return arr
+
+
+def heads_fwd(calls, dtype):
+    for c0 in range(0, len(calls), 2):
+        chunk = calls[c0:c0 + 2]
+        check(lib().drn_heads_fwd(_head_calls(chunk), len(chunk), dtype, _stream()), "drn_heads_fwd")
+
+
+def heads_bwd(calls, dtype):
+    """Each call gets its own slice of the per-device workspace (256*(N*taps*C + 8) floats)."""
+    for c0 in range(0, len(calls), 2):
+        chunk = calls[c0:c0 + 2]
+        sizes = [256 * (c["N"] * c["taps"] * c["C"] + 8) for c in chunk]
+        ws = workspace(sum(sizes), chunk[0]["dW"].device)
+        off = 0
+        for c, n in zip(chunk, sizes):
+            c["ws"] = ws[off:off + n]
+            off += n
+        check(lib().drn_heads_bwd(_head_calls(chunk), len(chunk), dtype, _stream()), "drn_heads_bwd")
+
+
 def head_out_fwd(groups, W, bias, N, C, taps, exp_mode, out, z, dtype):
-    check(lib().drn_head_out_fwd(groups, len(groups), _p(W), _p(bias), N, C, taps, int(exp_mode), _p(out), _p(z), dtype,
-                                 _stream()), "drn_head_out_fwd")
+    heads_fwd([dict(groups=groups, W=W, bias=bias, N=N, C=C, taps=taps, exp_mode=exp_mode, out=out, z=z)], dtype)
 
 
 def head_out_bwd(groups, W, dout, out, z, N, C, taps, exp_mode, accumulate_dx, dW, dbias, dscale, R, dtype):
-    ws = workspace(256 * (N * taps * C + 8), dW.device)
-    check(lib().drn_head_out_bwd(groups, len(groups), _p(W), _p(dout), _p(out), _p(z), N, C, taps, int(exp_mode),
-                                 int(accumulate_dx), _p(dW), _p(dbias), _p(dscale), 0, _p(ws), dtype, _stream()),
-          "drn_head_out_bwd")
+    heads_bwd([dict(groups=groups, W=W, dout=dout, out=out, z=z, N=N, C=C, taps=taps, exp_mode=exp_mode,
+                    accumulate_dx=accumulate_dx, dW=dW, dbias=dbias, dscale=dscale)], dtype)
 
 
 def loss_levels(levels):

@@ -220,6 +220,25 @@ int drn_head_out_bwd(const DrnHeadGroup* groups /*host*/, int ngroups, const flo
                      const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
                      float* dscale, int accumulate_dw, float* ws /* >= 256*(N*taps*C + 8) floats */, int dtype, void* stream);
 
+/* Up to 2 heads per launch (cls_logits + bbox_pred read the two halves of one tower output: side by side they fill the chip).
+ * One DrnHeadCall = the arguments of drn_head_out_fwd / _bwd for one head; forward uses groups, W, bias, out, z; backward
+ * groups (with dX), W, dout, out, z, dW, dbias, dscale, ws (>= 256*(N*taps*C + 8) floats each), accumulate flags. */
+typedef struct DrnHeadCall {
+  const DrnHeadGroup* groups; /* host */
+  int32_t ngroups, N, C, taps, exp_mode, accumulate_dx, accumulate_dw;
+  const float* W;
+  const float* bias;
+  float* out;
+  float* z;
+  const float* dout;
+  float* dW;
+  float* dbias;
+  float* dscale;
+  float* ws;
+} DrnHeadCall;
+int drn_heads_fwd(const DrnHeadCall* calls /*host*/, int ncalls, int dtype, void* stream);
+int drn_heads_bwd(const DrnHeadCall* calls /*host*/, int ncalls, int dtype, void* stream);
+
 /* ---- losses (drn_amd/csrc/loss.hip; model/loss.py:40-239, model/layers/{iou_loss,sigmoid_focal_loss}.py) -- */
 typedef struct DrnLossLevel {
   int32_t L;    /* locations per clip on this level */
