@@ -172,7 +172,7 @@ def main():
     def step():
         reducer.zero()
         _, losses = model(*batch)
-        loss_of(losses).backward()
+        DF.backward(loss_of(losses))
         opt_step()
         return losses
 
@@ -282,7 +282,7 @@ def main():
             def step32():
                 r32.zero()
                 _, ls = m32(*batch)
-                loss_of(ls).backward()
+                DF.backward(loss_of(ls))
                 r32.finish()
                 o32.step()
                 return ls

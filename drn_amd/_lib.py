@@ -18,6 +18,7 @@ _lib = None
 c_int, c_void_p, c_float, c_int64, c_int32 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64, ctypes.c_int32
 MAX_GROUPS = 4
 QD_MAX, QD_COUNTERS = 16, 2048
+LOSS_MAX_BUMPS = 32
 
 
 class DrnError(RuntimeError):
@@ -88,8 +89,12 @@ class HeadGroup(ctypes.Structure):
 
 class HeadCall(ctypes.Structure):
     _fields_ = [("groups", c_void_p), ("ngroups", c_int32), ("N", c_int32), ("C", c_int32), ("taps", c_int32), ("exp_mode", c_int32),
-                ("accumulate_dx", c_int32), ("accumulate_dw", c_int32), ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+                ("accumulate_dx", c_int32), ("accumulate_dw", c_int32), ("dscale_stride", c_int32), ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p),
                 ("z", c_void_p), ("dout", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("dscale", c_void_p), ("ws", c_void_p)]
+
+
+class CounterBump(ctypes.Structure):
+    _fields_ = [("counter", c_void_p), ("inc", c_int32)]
 
 
 class LossLevel(ctypes.Structure):

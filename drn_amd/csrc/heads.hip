@@ -36,7 +36,7 @@ struct HeadSet {
   float* dW;
   float* dbias;
   float* dscale;
-  int accumulate_dx, accumulate_dw, nblk;
+  int accumulate_dx, accumulate_dw, nblk, dscale_stride;
 };
 struct HeadMulti {
   HeadSet s[HEAD_MAX_SETS];
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void head_out_bwd_w_final_kernel(const HeadMul
       dst = dbias + e;
     } else {
       if (!exp_mode || e - 2 >= ngroups) return;
-      dst = dscale + (e - 2);
+      dst = dscale + (long)(e - 2) * S.dscale_stride;
     }
   }
   *dst = accumulate ? *dst + s : s;
@@ -466,6 +466,7 @@ static int fill_head_set(HeadSet& S, const DrnHeadCall& c, int dtype, bool backw
   if (rc) return rc;
   S.W = c.W; S.bias = c.bias; S.out = c.out; S.z = c.z; S.dout = c.dout; S.partial = c.ws; S.dW = c.dW; S.dbias = c.dbias;
   S.dscale = c.dscale; S.accumulate_dx = c.accumulate_dx; S.accumulate_dw = c.accumulate_dw;
+  S.dscale_stride = c.dscale_stride > 0 ? c.dscale_stride : 1;
   S.nblk = S.P.total_rows >= 256 * 16 ? 256 : (S.P.total_rows >= 16 ? S.P.total_rows / 16 : 1);
   if (!backward) DRN_CHECK_ARG(c.W && c.bias && c.out && (!c.exp_mode || c.z), "%s: null pointer", who);
   else DRN_CHECK_ARG(c.W && c.dout && c.dW && c.dbias && c.ws && (!c.exp_mode || (c.out && c.z && c.dscale)), "%s: null pointer", who);

@@ -21,7 +21,18 @@ struct LossParams {
   float stride[DRN_MAX_GROUPS], lo[DRN_MAX_GROUPS], hi[DRN_MAX_GROUPS];
   float gamma, alpha, target_scale;  // 2.0, 0.25, 32
   int iou_stage;                     // 0: first stage (no IoU-score loss)
+  int gt_f64;                        // ground truth arrives as float64 (the reference casts with .float(), main_model.py:74)
 };
+// counters (BatchNorm num_batches_tracked, int64) the forward pass owes an increment: applied by the loss's final kernel
+// instead of a launch of their own
+struct LossBumps {
+  long long* ptr[DRN_LOSS_MAX_BUMPS];
+  int inc[DRN_LOSS_MAX_BUMPS];
+  int n;
+};
+__device__ __forceinline__ float load_gt(const LossParams& P, const void* gt, int i) {
+  return P.gt_f64 ? (float)((const double*)gt)[i] : ((const float*)gt)[i];
+}
 
 struct Loc {
   int level, b, t;
@@ -86,14 +97,14 @@ __device__ __forceinline__ bool assign_label(const LossParams& P, const Loc& q, 
 // Phase 1: one location per thread, per-block partial sums partial[blk][5] = {focal, iou-loss, smooth-l1, n_pos, n_iou}.
 __global__ __launch_bounds__(256) void fcos_loss_fwd_partial_kernel(const LossParams P, const float* __restrict__ logits,
                                                                     const float* __restrict__ reg, const float* __restrict__ iou,
-                                                                    const float* __restrict__ gt, float* __restrict__ partial,
+                                                                    const void* __restrict__ gt, float* __restrict__ partial,
                                                                     float* __restrict__ labels) {
   __shared__ float sh[17];
   float s_focal = 0.f, s_ioul = 0.f, s_sl1 = 0.f, n_pos = 0.f, n_iou = 0.f;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < P.total_rows) {
     const Loc q = locate(P, r);
-    const float gs = gt[q.b * 2], ge = gt[q.b * 2 + 1];
+    const float gs = load_gt(P, gt, q.b * 2), ge = load_gt(P, gt, q.b * 2 + 1);
     float tl, tr;
     const bool pos = assign_label(P, q, gs, ge, tl, tr);
     if (labels) labels[r] = pos ? 1.f : 0.f;
@@ -129,9 +140,12 @@ __global__ __launch_bounds__(256) void fcos_loss_fwd_partial_kernel(const LossPa
   }
 }
 
-// Phase 2 (one workgroup, fixed order): out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ; out[4] = n_iou_pos
-__global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ out) {
+// Phase 2 (one workgroup, fixed order): out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ; out[4] = n_iou_pos ;
+// out[5] = their sum (main.py:225)
+__global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ out,
+                                                                  const LossBumps U) {
   __shared__ float sh[17];
+  if ((int)threadIdx.x < U.n) *U.ptr[threadIdx.x] += U.inc[threadIdx.x];
   float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int b = threadIdx.x; b < nblk; b += blockDim.x)
 #pragma unroll
@@ -144,13 +158,14 @@ __global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* _
     out[2] = v[4] > 0.f ? v[2] / v[4] : 0.f;          // loss.py:194-197
     out[3] = v[3];
     out[4] = v[4];
+    out[5] = out[0] + out[1] + out[2];
   }
 }
 
 // g_cls / g_reg / g_iou: upstream gradients (one float each, NULL = 0) of (loss_cls, loss_reg, loss_iou).  Outputs: dlogits[r], dreg[r][2], diou[r].
 __global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, const float* __restrict__ logits,
                                                                      const float* __restrict__ reg, const float* __restrict__ iou,
-                                                                     const float* __restrict__ gt, const float* __restrict__ fwd_out,
+                                                                     const void* __restrict__ gt, const float* __restrict__ fwd_out,
                                                                      const float* __restrict__ g_cls, const float* __restrict__ g_reg,
                                                                      const float* __restrict__ g_iou, float* __restrict__ dlogits,
                                                                      float* __restrict__ dreg, float* __restrict__ diou) {
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, 
   const float k_iou = (P.iou_stage && n_iou > 0.f) ? (g_iou ? g_iou[0] : 0.f) / n_iou : 0.f;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P.total_rows; r += gridDim.x * blockDim.x) {
     const Loc q = locate(P, r);
-    const float gs = gt[q.b * 2], ge = gt[q.b * 2 + 1];
+    const float gs = load_gt(P, gt, q.b * 2), ge = load_gt(P, gt, q.b * 2 + 1);
     float tl, tr;
     const bool pos = assign_label(P, q, gs, ge, tl, tr);
     const float x = logits[r];
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, 
 }
 
 static int fill_loss_params(LossParams& P, const DrnLossLevel* levels, int nlevels, int B, float gamma, float alpha, float target_scale,
-                            int iou_stage, const char* who) {
+                            int iou_stage, int gt_f64, const char* who) {
   DRN_CHECK_ARG(levels && nlevels >= 1 && nlevels <= DRN_MAX_GROUPS && B > 0, "%s: bad level table", who);
   memset(&P, 0, sizeof(P));
   P.nlevels = nlevels; P.B = B;
@@ -213,32 +228,38 @@ static int fill_loss_params(LossParams& P, const DrnLossLevel* levels, int nleve
     rows += B * levels[l].L;
   }
   P.total_rows = rows;
-  P.gamma = gamma; P.alpha = alpha; P.target_scale = target_scale; P.iou_stage = iou_stage;
+  P.gamma = gamma; P.alpha = alpha; P.target_scale = target_scale; P.iou_stage = iou_stage; P.gt_f64 = gt_f64;
   return DRN_OK;
 }
 
 extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg, const float* iou,
-                                 const float* gt, float gamma, float alpha, float target_scale, int iou_stage, float* out5,
-                                 float* labels, float* ws, void* stream) {
+                                 const void* gt, int gt_f64, float gamma, float alpha, float target_scale, int iou_stage, float* out6,
+                                 float* labels, float* ws, const DrnCounterBump* bumps, int nbumps, void* stream) {
   drn_clear_status();
   LossParams P;
-  int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_fwd");
+  int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, gt_f64, "drn_fcos_loss_fwd");
   if (rc) return rc;
-  DRN_CHECK_ARG(logits && reg && gt && out5 && (!iou_stage || iou), "drn_fcos_loss_fwd: null pointer");
+  DRN_CHECK_ARG(logits && reg && gt && out6 && (!iou_stage || iou), "drn_fcos_loss_fwd: null pointer");
+  DRN_CHECK_ARG(nbumps >= 0 && nbumps <= DRN_LOSS_MAX_BUMPS && (nbumps == 0 || bumps), "drn_fcos_loss_fwd: at most %d counter bumps",
+                DRN_LOSS_MAX_BUMPS);
   const int nblk = cdiv(P.total_rows, 256);
   DRN_CHECK_ARG(ws, "drn_fcos_loss_fwd: workspace (5*ceil(R/256) floats) required");
+  LossBumps U;
+  memset(&U, 0, sizeof(U));
+  U.n = nbumps;
+  for (int i = 0; i < nbumps; ++i) { U.ptr[i] = (long long*)bumps[i].counter; U.inc[i] = bumps[i].inc; }
   fcos_loss_fwd_partial_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, ws, labels);
-  fcos_loss_fwd_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, nblk, B, out5);
+  fcos_loss_fwd_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, nblk, B, out6, U);
   return drn_launch_status("drn_fcos_loss_fwd");
 }
 
 extern "C" int drn_fcos_loss_bwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg,
-                                 const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
+                                 const float* iou, const void* gt, int gt_f64, float gamma, float alpha, float target_scale, int iou_stage,
                                  const float* fwd_out5, const float* g_cls, const float* g_reg, const float* g_iou, float* dlogits,
                                  float* dreg, float* diou, void* stream) {
   drn_clear_status();
   LossParams P;
-  int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, "drn_fcos_loss_bwd");
+  int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, gt_f64, "drn_fcos_loss_bwd");
   if (rc) return rc;
   DRN_CHECK_ARG(logits && reg && gt && fwd_out5 && dlogits && dreg && (!iou_stage || (iou && diou)),
                 "drn_fcos_loss_bwd: null pointer");

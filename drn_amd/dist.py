@@ -70,7 +70,9 @@ class GradReducer(object):
         adj_of = {}
         for grp in (adjacent or []):
             grp = [p for p in grp if id(p) in wanted]
-            if len(grp) > 1 and all(p.numel() % 4 == 0 for p in grp[:-1]):      # 4-element alignment padding would split them
+            # back to back only when no 4-element alignment padding falls between them; one-element parameters are kept
+            # together too (equal 4-element spacing: functional.grad_buffer hands out a strided view)
+            if len(grp) > 1 and (all(p.numel() % 4 == 0 for p in grp[:-1]) or all(p.numel() == 1 for p in grp)):
                 for p in grp:
                     adj_of[id(p)] = grp
         for part in plan:
@@ -129,7 +131,8 @@ class GradReducer(object):
             with torch.no_grad():
                 sink.copy_(p.grad.reshape(-1))          # gradient produced elsewhere (stock autograd ops): move it in
             p.grad = sink.view_as(p)                    # (single process / deferred mode: finish() batches these copies)
-        self._dirty[p] = True
+        if p.grad is not None:                          # (the engine also runs the hook of a parameter whose gradient came back undefined)
+            self._dirty[p] = True
         b.pending -= 1
         if self.overlap and b.pending == 0 and not b.launched:
             self._launch(b)

@@ -127,6 +127,7 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *params):
         ctx.sizes = [p.shape[0] for p in params]
+        ctx.set_materialize_grads(False)             # an absent gradient stays absent for every source
         buf = stacked(list(params))
         out = buf.view(buf.shape)
         out._drn_stack_of = list(params)
@@ -134,6 +135,8 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * len(ctx.sizes)
         outs, o = [], 0
         for n in ctx.sizes:
             outs.append(g[o:o + n])
@@ -270,6 +273,13 @@ def grad_buffer(param, dtype=torch.float32):
                 strides.append(acc)
                 acc *= d
             return sinks[0].as_strided(tuple(param.shape), tuple(reversed(strides)), sinks[0].storage_offset())
+        # one-element sources (the Scale parameters) at a fixed spacing inside the bucket (each slice starts on a 16-byte
+        # boundary): a strided 1-D view, element l = source l's sink
+        if all(s is not None and s.numel() == 1 and p.numel() == 1 and s.dtype == dtype and s.device == param.device
+               for s, p in zip(sinks, srcs)) and param.dim() == 1 and len(sinks) > 1:
+            step = (sinks[1].data_ptr() - sinks[0].data_ptr()) // sinks[0].element_size()
+            if step > 0 and all(b.data_ptr() - a.data_ptr() == step * a.element_size() for a, b in zip(sinks, sinks[1:])):
+                return sinks[0].as_strided((len(sinks),), (step,), sinks[0].storage_offset())
     return torch.empty(param.shape, dtype=dtype, device=param.device)
 
 
@@ -289,6 +299,19 @@ def bump_bn_counter(t, n=1):
         _bn_pending[key][1] += n
     else:
         _bn_pending[key] = [t, n]
+
+
+def take_bn_counters(device):
+    """Hand the pending increments to a kernel that applies them itself (the loss's final kernel); [] when there are none or
+    too many / foreign ones (those stay for flush_bn_counters)."""
+    from ._lib import LOSS_MAX_BUMPS
+    if not _bn_pending or len(_bn_pending) > LOSS_MAX_BUMPS:
+        return []
+    items = list(_bn_pending.values())
+    if any(t.device != device or t.dtype != torch.int64 for t, _ in items):
+        return []
+    _bn_pending.clear()
+    return items
 
 
 def flush_bn_counters():
@@ -511,8 +534,9 @@ class _ConvBlockFn(torch.autograd.Function):
                                            Lout=L, Lsrc=Lo))
                 dxs[l] = dx
             ops.gemm_nt(descs, code)
-        dcb = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_cbias else None   # cancels in train-mode BN
-        return (None, dW, dcb, dgamma, dbeta, dgate, dup) + tuple(dxs)
+        # a conv bias in front of a train-mode BN cancels: its gradient is exactly zero -> None (no fill, no copy into the
+        # bucket: the reducer's slice of a parameter without gradient reads as zero)
+        return (None, dW, None, dgamma, dbeta, dgate, dup) + tuple(dxs)
 
 
 def conv_block(xs, conv, bn, training, dtype, gate=None, up=None, relu=True):
@@ -596,6 +620,7 @@ class _MultiConvFn(torch.autograd.Function):
             for l in range(n):
                 _tap_relu(weights[l], 0, outs[l], outs[l + 1] if (chain_up and l + 1 < n) else None)
         ctx.meta, ctx.geo = meta, geo
+        ctx.beta_refs = betas
         ctx.save_for_backward(*weights, *gammas, *xs, *raws, *sss, *saves)
         return tuple(outs)
 
@@ -628,7 +653,7 @@ class _MultiConvFn(torch.autograd.Function):
         for l in range(n):
             B, L, Lo, M, ld, Cout = geo[l][:6]
             draw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
-            dg, db = grad_buffer(gammas[l]), torch.empty_like(gammas[l])
+            dg, db = grad_buffer(gammas[l]), grad_buffer(ctx.beta_refs[l])
             blevels.append(dict(dout=dtot[l], ld_dout=Cout, raw=raws[l], ld_raw=Cout, ss=sss[l], save=saves[l], gamma=gammas[l],
                                 draw=draw, ld_draw=Cout, dgamma=dg, dbeta=db, accumulate=False, M=M))
             draws.append(draw)
@@ -835,7 +860,7 @@ class _HeadOutFn(torch.autograd.Function):
             dout = douts[h]
             if dout is not None:                         # the kernels write every element of the three gradients
                 dW, db = grad_buffer(W), grad_buffer(bias)
-                dsc = torch.empty(nl, dtype=torch.float32, device=dev) if scales is not None else None
+                dsc = grad_buffer(scales) if scales is not None else None      # (nl,), possibly strided: the sinks themselves
             else:
                 dW, db = torch.zeros_like(W), torch.zeros_like(bias)
                 dsc = torch.zeros(nl, dtype=torch.float32, device=dev) if scales is not None else None
@@ -869,56 +894,69 @@ def head_out(xs, heads, cols, dtype):
 
 class _FCOSLossFn(torch.autograd.Function):
     """Target assignment + focal / IoU / IoU-score losses (model/loss.py:40-239) in one kernel each way.
-    Returns (loss_cls, loss_reg, loss_iou, counts2, all3), each loss of shape (1,), counts2 = [n_pos, n_iou_pos], all3 the
-    three losses as one (3,) view; all are views of one 5-float result buffer (no per-loss slicing kernels in either
-    direction)."""
+    Returns (loss_cls, loss_reg, loss_iou, counts2, total): each loss of shape (1,), counts2 = [n_pos, n_iou_pos], total =
+    the sum of the three losses (main.py:225), shape (1,); all are views of one 6-float result buffer (no per-loss slicing or
+    summing kernels in either direction).  The BatchNorm step counters the forward pass owes (bump_bn_counter) ride along."""
 
     @staticmethod
     def forward(ctx, meta, logits, reg, iou, gt):
         levels = ops.loss_levels(meta["levels"])
         B = meta["B"]
-        out5 = torch.empty(5, dtype=torch.float32, device=logits.device)
+        out6 = torch.empty(6, dtype=torch.float32, device=logits.device)
         logits, reg = logits.contiguous(), reg.contiguous()
         iou = iou.contiguous() if iou is not None else None
-        gt = gt.contiguous().float()
+        gt = gt.contiguous()
+        if gt.dtype not in (torch.float32, torch.float64):
+            gt = gt.float()
         ops.fcos_loss_fwd(levels, B, logits, reg, iou, gt, meta["gamma"], meta["alpha"], meta["target_scale"],
-                          meta["iou_stage"], out5)
+                          meta["iou_stage"], out6, bumps=take_bn_counters(logits.device))
         ctx.meta = meta
-        ctx.save_for_backward(logits, reg, iou if iou is not None else logits.new_empty(0), gt, out5)
-        counts = out5[3:5]
+        ctx.save_for_backward(logits, reg, iou if iou is not None else logits.new_empty(0), gt, out6)
+        counts = out6[3:5]
         ctx.mark_non_differentiable(counts)
         ctx.set_materialize_grads(False)           # unused outputs arrive as None in backward, not as zero-filled tensors
-        return out5[0:1], out5[1:2], out5[2:3], counts, out5[0:3]       # [4]: the three losses as one view (loss_total)
+        return out6[0:1], out6[1:2], out6[2:3], counts, out6[5:6]
 
     @staticmethod
-    def backward(ctx, g_cls, g_reg, g_iou, _gc, g_all):
-        if g_all is not None:                      # gradient of loss_total(): a (3,) tensor (usually an expanded scalar)
-            parts = [g_all[k:k + 1] for k in range(3)]
-            g_cls, g_reg, g_iou = (p if g is None else g + p for g, p in zip((g_cls, g_reg, g_iou), parts))
+    def backward(ctx, g_cls, g_reg, g_iou, _gc, g_tot):
+        if g_tot is not None:                      # gradient of the total: the same scalar for each of the three losses
+            g_cls, g_reg, g_iou = (g_tot if g is None else g + g_tot for g in (g_cls, g_reg, g_iou))
         meta = ctx.meta
-        logits, reg, iou, gt, out5 = ctx.saved_tensors
+        logits, reg, iou, gt, out6 = ctx.saved_tensors
         levels = ops.loss_levels(meta["levels"])
         has_iou = bool(meta["iou_stage"])
         dlogits = torch.empty_like(logits)
         dreg = torch.empty_like(reg)
         diou = torch.empty_like(iou) if has_iou else None
         ops.fcos_loss_bwd(levels, meta["B"], logits, reg, iou if has_iou else None, gt, meta["gamma"], meta["alpha"],
-                          meta["target_scale"], meta["iou_stage"], out5,
+                          meta["target_scale"], meta["iou_stage"], out6,
                           [None if g is None else g.contiguous().float() for g in (g_cls, g_reg, g_iou)], dlogits, dreg, diou)
         return None, dlogits, dreg, diou, None
 
 
 class LossDict(dict):
-    """The reference's loss dict (same keys) that also carries the three losses as one tensor, so that their sum
-    (main.py:222-225) is one reduction instead of a chain of scalar adds."""
-    all3 = None
+    """The reference's loss dict (same keys) that also carries the sum of the three losses as computed by the loss kernel
+    (main.py:222-225), so that the trainer's `sum(loss_dict.values())` costs no launch."""
+    total = None
 
 
 def loss_total(losses):
-    """sum(loss_dict.values()) of the reference's training loop (main.py:225) in one launch when the dict came from this
+    """sum(loss_dict.values()) of the reference's training loop (main.py:225) without a launch when the dict came from this
     package; any other mapping is summed the reference's way."""
-    a = getattr(losses, "all3", None)
-    return a.sum() if a is not None else sum(l for l in losses.values())
+    t = getattr(losses, "total", None)
+    return t.reshape(()) if t is not None else sum(l for l in losses.values())
+
+
+_ones = {}
+
+
+def backward(loss):
+    """loss.backward() with a cached unit gradient (autograd otherwise fills a fresh ones_like(loss) per step)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ones.get(key)
+    if one is None:
+        one = _ones[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    loss.backward(gradient=one)
 
 
 def fcos_loss(logits, reg, iou, gt, levels, B, gamma, alpha, target_scale, iou_stage):

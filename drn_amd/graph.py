@@ -12,6 +12,8 @@ would run -- uncaptured and unordered -- outside the graph.  So do not run `step
 """
 import torch
 
+from . import functional as DF
+
 
 class GraphedStep(object):
     def __init__(self, step_fn, warmup=3):
@@ -78,7 +80,7 @@ class TwoPhaseStep(object):
             g0, _ = m.forward_front(tok, qlen, feats, pse, gates=gd)
             g0d = g0.detach().requires_grad_()
             _, losses = m.forward_trunk(g0d, gd, gt)
-            self.loss_of(losses).backward()                       # trunk parameters, g0d.grad, gd[1:].grad
+            DF.backward(self.loss_of(losses))                     # trunk parameters, g0d.grad, gd[1:].grad
             self._carry = (g0, g0d, gates, gd)
             self.out = losses
         elif k == 1:

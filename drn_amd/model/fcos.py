@@ -62,10 +62,11 @@ class FCOSHead(torch.nn.Module):
     def grad_stack_groups(self):
         """Parameter groups whose gradients are produced as ONE stacked tensor (the towers' first convs, see _towers): hand
         them to GradReducer(adjacent=...) so that stack is a slice of the flat gradient bucket."""
+        scales = [[s.scale for s in self.scales]]          # one-element slices at a fixed spacing: a strided gradient view
         if len(self.cls_tower) // 3 != 1:
-            return []
+            return scales
         cc, cb, bc, bb = self.cls_tower[0], self.cls_tower[1], self.bbox_tower[0], self.bbox_tower[1]
-        return [[cc.weight, bc.weight], [cc.bias, bc.bias], [cb.weight, bb.weight], [cb.bias, bb.bias]]
+        return [[cc.weight, bc.weight], [cc.bias, bc.bias], [cb.weight, bb.weight], [cb.bias, bb.bias]] + scales
 
     # -- towers -----------------------------------------------------------------------------------------
     def _towers(self, xs):
@@ -91,23 +92,27 @@ class FCOSHead(torch.nn.Module):
                                    eps=cb.eps, track_running_stats=cb.track_running_stats)
         out, _ = DF.conv_block(xs, conv, bn, self.training, dt)
         if self.training and track:
-            C = cb.num_features
-            with torch.no_grad():
-                dsts = [cb.running_mean, bb.running_mean, cb.running_var, bb.running_var]
-                torch._foreach_copy_(dsts, [rm[:C], rm[C:], rv[:C], rv[C:]])
-                self._tower_stats = (rm, rv, [t._version for t in dsts], [t.data_ptr() for t in dsts])
-                DF.bump_bn_counter(cb.num_batches_tracked, len(xs)); DF.bump_bn_counter(bb.num_batches_tracked, len(xs))
+            DF.bump_bn_counter(cb.num_batches_tracked, len(xs)); DF.bump_bn_counter(bb.num_batches_tracked, len(xs))
         return out
 
     def _stacked_running(self, cb, bb):
-        """[cls ; bbox] running statistics in one buffer the BN kernels update; rebuilt only when somebody else touched
-        the modules' own buffers (load_state_dict, .to(), ...) since the last copy-back."""
-        srcs = [cb.running_mean, bb.running_mean, cb.running_var, bb.running_var]
+        """[cls ; bbox] running statistics in one buffer each, which the BN kernels update in place; the two modules' own
+        `running_mean` / `running_var` buffers are VIEWS of its halves (same names, same state_dict), so nothing is copied
+        back per step.  Re-established whenever somebody replaced the modules' buffers (`.to()`, `.float()`, ...)."""
+        C = cb.num_features
         st = getattr(self, "_tower_stats", None)
-        if st is not None and st[2] == [t._version for t in srcs] and st[3] == [t.data_ptr() for t in srcs] \
-                and st[0].device == srcs[0].device:
-            return st[0], st[1]
-        return torch.cat(srcs[:2]), torch.cat(srcs[2:])
+        if st is not None:
+            rm, rv = st
+            if cb.running_mean.data_ptr() == rm.data_ptr() and bb.running_mean.data_ptr() == rm[C:].data_ptr() and \
+                    cb.running_var.data_ptr() == rv.data_ptr() and bb.running_var.data_ptr() == rv[C:].data_ptr():
+                return rm, rv
+        with torch.no_grad():
+            rm = torch.cat([cb.running_mean, bb.running_mean])
+            rv = torch.cat([cb.running_var, bb.running_var])
+            cb.running_mean, bb.running_mean = rm[:C], rm[C:]
+            cb.running_var, bb.running_var = rv[:C], rv[C:]
+        self._tower_stats = (rm, rv)
+        return rm, rv
 
     def forward_nlc(self, xs):
         """xs: channels-last (B, L_l, C) pyramid levels.  Returns flat fp32 buffers
@@ -172,7 +177,7 @@ class FCOSModule(torch.nn.Module):
 
     def _loss_dict(self, loss_box_cls, loss_box_reg, loss_iou):
         d = DF.LossDict(loss_cls=loss_box_cls, loss_reg=loss_box_reg, loss_iou=loss_iou)      # model/fcos.py:150-157 keys
-        d.all3 = getattr(self.loss_evaluator, "last_all3", None)
+        d.total = getattr(self.loss_evaluator, "last_total", None)         # their sum, from the same kernel (DF.loss_total)
         return d
 
     def compute_locations(self, features):

@@ -41,10 +41,10 @@ class FCOSLossComputation(object):
                    float(self.object_sizes_of_interest[i][1])) for i, c in enumerate(box_cls)]
         logits, reg = self._flat(box_cls), self._flat(box_regression)
         iou = None if is_first_stage else self._flat(iou_scores)
-        l_cls, l_reg, l_iou, counts, all3 = DF.fcos_loss(logits, reg, iou, targets, levels, B, self.gamma, self.alpha, TARGET_SCALE,
+        l_cls, l_reg, l_iou, counts, total = DF.fcos_loss(logits, reg, iou, targets, levels, B, self.gamma, self.alpha, TARGET_SCALE,
                                       not is_first_stage)
         self.last_counts = counts
-        self.last_all3 = all3
+        self.last_total = total
         if is_first_stage:
             return l_cls, l_reg, l_iou.detach()    # stage 1: the kernel writes 0 there (loss.py:239, `torch.tensor([0])`)
         return l_cls, l_reg, l_iou

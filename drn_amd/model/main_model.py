@@ -112,11 +112,15 @@ class mainModel(nn.Module):
             self.taps["head"] = (box_cls, box_reg, [], iou_scores)
         fc = self.fcos
         locations = [fc.compute_locations_per_level(L, fc.fpn_strides[l], logits.device) for l, (_, L) in enumerate(geo)]
-        targets = gt_start_end.float()
-        DF.flush_bn_counters()
+        # main_model.py:74 casts the ground truth with .float(): the loss kernel does that on load (fp64 or fp32 in)
+        targets = gt_start_end if gt_start_end.dtype in (torch.float32, torch.float64) else gt_start_end.float()
+        # the BatchNorm step counters owed by this forward pass are applied by the loss's own launch (DF.take_bn_counters)
         if self.training:
-            return fc._forward_train(locations, box_cls, box_reg, targets, iou_scores)
-        return fc._forward_test(locations, box_cls, box_reg, targets, iou_scores)
+            res = fc._forward_train(locations, box_cls, box_reg, targets, iou_scores)
+        else:
+            res = fc._forward_test(locations, box_cls, box_reg, targets, iou_scores)
+        DF.flush_bn_counters()
+        return res
 
     def forward(self, query_tokens, query_length, props_features, props_start_end, gt_start_end, props_num=None,
                 num_frames=None):

@@ -424,6 +424,7 @@ def _head_calls(calls):
         d.groups = ctypes.cast(c["groups"], ctypes.c_void_p)
         d.ngroups, d.N, d.C, d.taps, d.exp_mode = len(c["groups"]), c["N"], c["C"], c["taps"], int(c["exp_mode"])
         d.accumulate_dx, d.accumulate_dw = int(c.get("accumulate_dx", 0)), 0
+        d.dscale_stride = c["dscale"].stride(0) if c.get("dscale") is not None and c["dscale"].numel() > 1 else 1
         d.W, d.bias, d.out, d.z = _p(c["W"]), _p(c.get("bias")), _p(c.get("out")), _p(c.get("z"))
         d.dout, d.dW, d.dbias, d.dscale, d.ws = _p(c.get("dout")), _p(c.get("dW")), _p(c.get("dbias")), _p(c.get("dscale")), _p(c.get("ws"))
     return arr
@@ -462,18 +463,23 @@ def loss_levels(levels):
     return (_lib.LossLevel * len(levels))(*[_lib.LossLevel(L=L, stride=s, lo=lo, hi=hi) for (L, s, lo, hi) in levels])
 
 
-def fcos_loss_fwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, labels=None):
+def fcos_loss_fwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out6, labels=None, bumps=None):
+    """out6 (6 floats) = loss_cls, loss_reg, loss_iou, n_pos, n_iou_pos, sum of the three losses.  gt (B, 2) fp32 or fp64.
+    bumps: [(int64 device counter, increment)] applied by the same launch (BatchNorm num_batches_tracked)."""
+    assert out6.numel() >= 6 and gt.dtype in (torch.float32, torch.float64) and gt.is_contiguous()
     ws = workspace(5 * ((logits.shape[0] + 255) // 256), logits.device)
-    check(lib().drn_fcos_loss_fwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
-                                  ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(labels),
-                                  _p(ws), _stream()), "drn_fcos_loss_fwd")
+    nb = len(bumps) if bumps else 0
+    arr = (_lib.CounterBump * nb)(*[_lib.CounterBump(counter=_p(t), inc=int(n)) for t, n in bumps]) if nb else None
+    check(lib().drn_fcos_loss_fwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), int(gt.dtype == torch.float64),
+                                  ctypes.c_float(gamma), ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out6),
+                                  _p(labels), _p(ws), arr, nb, _stream()), "drn_fcos_loss_fwd")
 
 
-def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out5, g3, dlogits, dreg, diou):
+def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out6, g3, dlogits, dreg, diou):
     """g3: upstream gradients (1-element fp32 tensors or None) of loss_cls, loss_reg, loss_iou."""
-    check(lib().drn_fcos_loss_bwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), ctypes.c_float(gamma),
-                                  ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out5), _p(g3[0]), _p(g3[1]), _p(g3[2]),
-                                  _p(dlogits), _p(dreg), _p(diou), _stream()), "drn_fcos_loss_bwd")
+    check(lib().drn_fcos_loss_bwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), int(gt.dtype == torch.float64),
+                                  ctypes.c_float(gamma), ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out6),
+                                  _p(g3[0]), _p(g3[1]), _p(g3[2]), _p(dlogits), _p(dreg), _p(diou), _stream()), "drn_fcos_loss_bwd")
 
 
 def focal_fwd(logits, targets, gamma, alpha):

@@ -73,7 +73,7 @@ class Trainer(object):
         if self.fused:
             self.reducer.zero()
         _, loss_dict = self.model(*args)
-        select_loss(loss_dict, self.which).backward()
+        DF.backward(select_loss(loss_dict, self.which))
         if self.fused:
             self.reducer.finish()
             self.opt.step()

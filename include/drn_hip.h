@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 2
+#define DRN_ABI_VERSION 3
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
@@ -222,10 +222,11 @@ int drn_head_out_bwd(const DrnHeadGroup* groups /*host*/, int ngroups, const flo
 
 /* Up to 2 heads per launch (cls_logits + bbox_pred read the two halves of one tower output: side by side they fill the chip).
  * One DrnHeadCall = the arguments of drn_head_out_fwd / _bwd for one head; forward uses groups, W, bias, out, z; backward
- * groups (with dX), W, dout, out, z, dW, dbias, dscale, ws (>= 256*(N*taps*C + 8) floats each), accumulate flags. */
+ * groups (with dX), W, dout, out, z, dW, dbias, dscale (+ dscale_stride), ws (>= 256*(N*taps*C + 8) floats each), accumulate flags. */
 typedef struct DrnHeadCall {
   const DrnHeadGroup* groups; /* host */
   int32_t ngroups, N, C, taps, exp_mode, accumulate_dx, accumulate_dw;
+  int32_t dscale_stride; /* elements between dscale[l] and dscale[l+1] (0 = 1) */
   const float* W;
   const float* bias;
   float* out;
@@ -246,15 +247,23 @@ typedef struct DrnLossLevel {
   float lo, hi; /* object_sizes_of_interest (model/loss.py:47-51) */
 } DrnLossLevel;
 /* logits [R], reg [R][2], iou [R] are fp32 over R = B*sum(L) rows ordered level-first, clip-major (the reference's
- * flatten order, model/loss.py:150-166).  out5 = {loss_cls, loss_reg, loss_iou, n_pos, n_iou_pos}.
- * Replaces fcos_core._C.sigmoid_focalloss_forward/backward (model/layers/sigmoid_focal_loss.py:18,31) + IOULoss +
+ * flatten order, model/loss.py:150-166).  gt [B][2] is fp32, or fp64 with gt_f64 = 1 (cast on load, main_model.py:74).
+ * out6 = {loss_cls, loss_reg, loss_iou, n_pos, n_iou_pos, loss_cls + loss_reg + loss_iou (main.py:225)}.
+ * bumps (host array, may be NULL): int64 device counters (BatchNorm num_batches_tracked) incremented by the same launch.
+ * Replaces FCOSLossComputation.__call__ incl. fcos_core._C.sigmoid_focalloss_forward/backward + IOULoss +
  * segment_tiou/SmoothL1. */
+#define DRN_LOSS_MAX_BUMPS 32
+typedef struct DrnCounterBump {
+  void* counter; /* int64 on the device */
+  int32_t inc;
+} DrnCounterBump;
 int drn_fcos_loss_fwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg,
-                      const float* iou, const float* gt /*[B][2]*/, float gamma, float alpha, float target_scale, int iou_stage,
-                      float* out5, float* labels /*[R] or NULL*/, float* ws /* >= 5*ceil(R/256) floats */, void* stream);
+                      const float* iou, const void* gt /*[B][2]*/, int gt_f64, float gamma, float alpha, float target_scale,
+                      int iou_stage, float* out6, float* labels /*[R] or NULL*/, float* ws /* >= 5*ceil(R/256) floats */,
+                      const DrnCounterBump* bumps /*host*/, int nbumps, void* stream);
 int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg,
-                      const float* iou, const float* gt, float gamma, float alpha, float target_scale, int iou_stage,
-                      const float* fwd_out5, const float* g_cls, const float* g_reg, const float* g_iou /* 1 float each, NULL = 0 */,
+                      const float* iou, const void* gt, int gt_f64, float gamma, float alpha, float target_scale, int iou_stage,
+                      const float* fwd_out6, const float* g_cls, const float* g_reg, const float* g_iou /* 1 float each, NULL = 0 */,
                       float* dlogits, float* dreg, float* diou, void* stream);
 
 /* The reference's ONE real FFI on this path, 1:1: fcos_core._C.sigmoid_focalloss_forward(logits, targets, num_classes, gamma,

@@ -92,6 +92,8 @@ def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=
             if key not in g:
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, "unexpected grad for " + k
                 continue
+            if k in ZERO_GRADS and p.grad is None:          # analytically zero: the HIP path hands out no gradient at all
+                continue
             assert p.grad is not None, "missing grad for " + k
             seen += 1
             gr = p.grad.detach().double().reshape(-1).cpu()

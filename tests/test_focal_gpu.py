@@ -80,7 +80,7 @@ def test_focal_module_matches_fused_loss_kernel():
     gt = torch.tensor([[0.1, 0.6], [0.3, 0.9], [0.0, 0.4]], device=dev)
     levels = [(Ls[i], float(2 ** i), float(O.SIZES_OF_INTEREST[i][0]), float(O.SIZES_OF_INTEREST[i][1])) for i in range(3)]
     from drn_amd import ops
-    out5 = torch.empty(5, device=dev)
+    out5 = torch.empty(6, device=dev)
     labels = torch.empty(R, device=dev)
     ops.fcos_loss_fwd(ops.loss_levels(levels), B, logits, reg, None, gt, 2.0, 0.25, 32.0, 0, out5, labels=labels)
     n_pos = int(out5[3].item())

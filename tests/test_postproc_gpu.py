@@ -114,7 +114,7 @@ def test_target_labels_match_oracle_bit_exact(B, T):
     logits = torch.randn(R, 1, generator=g).to(dev)
     reg = torch.exp(torch.randn(R, 2, generator=g)).to(dev)
     levels = [(Ls[i], strides[i], float(O.SIZES_OF_INTEREST[i][0]), float(O.SIZES_OF_INTEREST[i][1])) for i in range(3)]
-    out5 = torch.empty(5, device=dev)
+    out5 = torch.empty(6, device=dev)
     labels = torch.empty(R, device=dev)
     ops.fcos_loss_fwd(ops.loss_levels(levels), B, logits, reg, None, gt.to(dev), 2.0, 0.25, 32.0, 0, out5, labels=labels)
     assert torch.equal(labels.cpu(), want.float()), int((labels.cpu() != want.float()).sum())
