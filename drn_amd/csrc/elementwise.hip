@@ -426,16 +426,17 @@ extern "C" int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int l
 // forward was G[s,t,c] = act[s,t,c] * gate[s,c].  Here:
 //   dC[s,t,c] = (add ? add[s,t,c] : 0) + dG[s,t,c] * gate[s,c]        dgate[s,c] = sum_t dG[s,t,c] * act[s,t,c]
 //   dsum[s,c] = sum_t dG[s,t,c] * gate[s,c]   (optional: per-sequence column sums of the gated gradient = bias gradient partials)
-// grid (ceil(nvec/32), nseq); block 256 = 32 channel vectors x 8 row lanes.
+// grid (ceil(nvec/8), nseq); block 256 = 8 channel vectors x 32 row lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG, int ld_dg, const T* __restrict__ act, int ld_act,
                                                        const float* __restrict__ gate, int ldg, const T* __restrict__ add, int ld_add,
                                                        T* __restrict__ dC, int ld_dc, float* __restrict__ dgate, int ld_dgate,
                                                        float* __restrict__ dsum, int L, int C) {
   constexpr int N = V16<T>::N;
-  // 16 channel vectors x 16 row lanes per workgroup (was 32 x 8): twice the workgroups and half the sequential row trips --
-  // at 64-128 workgroups of 16 dependent trips each the launch was pure latency (21 us for 8 MB)
-  constexpr int VX = 16, RY = 16;
+  // 8 channel vectors (one 128-byte line of bf16) x 32 row lanes per workgroup (was 32 x 8, then 16 x 16): every halving of
+  // the sequential row trips halved the launch -- at 64-128 workgroups of 16 dependent trips it was pure latency (19 us
+  // for 4 MB at C = 256)
+  constexpr int VX = 8, RY = 32;
   __shared__ float red[RY][VX * N + 1];
   const int vx = threadIdx.x & (VX - 1), ry = threadIdx.x / VX;
   const int v = blockIdx.x * VX + vx;
@@ -507,7 +508,7 @@ extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_a
     constexpr int N = V16<T>::N;
     DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && (!dC || ld_dc % N == 0) && (!add || ld_add % N == 0),
                   "drn_gate_bwd: C/ld must be 16-byte multiples");
-    dim3 grid(cdiv(C / N, 16), nseq);
+    dim3 grid(cdiv(C / N, 8), nseq);
     gate_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (const T*)add,
                                                                 ld_add, (T*)dC, ld_dc, dgate, ld_dgate, dsum, L, C);
   });
