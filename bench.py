@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="per-kernel MFMA timing table on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="N=1: replay the step as ONE linear hipGraph instead of the two-stream schedule (drn_amd.graph.DualStreamStep)")
     ap.add_argument("--torch-adam", action="store_true", help="torch clip_grad_norm_ + optim.Adam instead of the fused HIP step")
     args = ap.parse_args()
 
@@ -186,7 +188,13 @@ def main():
         # all warm-up steps run on the capture stream (see drn_amd/graph.py), then the step is captured once
         from drn_amd.graph import GraphedStep
         try:
-            if world == 1:
+            if world == 1 and not args.single_stream and not args.torch_adam:
+                # seven linear hipGraphs on two streams: the query side (small latency-bound launches) runs beside the
+                # input preparation forward and beside the deferred weight gradients backward
+                from drn_amd.graph import DualStreamStep
+                run = DualStreamStep(model, batch[:5], loss_of, reducer, opt).warm(max(args.warmup, 2)).capture()
+                mode = "hipGraph replay of the full step: 7 linear graphs on 2 streams (query side beside input prep / deferred weight gradients)"
+            elif world == 1:
                 # the whole step (query encoder, HIP path forward+backward, fused clip+Adam) replays as ONE hipGraph
                 run = GraphedStep(step, warmup=max(args.warmup, 2)).capture()
                 mode = "hipGraph replay of the full step"

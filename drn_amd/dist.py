@@ -151,6 +151,15 @@ class GradReducer(object):
                     if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                         p.grad = v.view_as(p)
 
+    def adopt(self, params, grads):
+        """Gradients computed outside the engine's accumulation (torch.autograd.grad on a second stream,
+        drn_amd.graph.DualStreamStep): install them as p.grad the way AccumulateGrad + the hook would have; collect() then
+        moves in whatever is not already its sink."""
+        for p, g in zip(params, grads):
+            if g is not None and p in self._of:
+                p.grad = g if g.shape == p.shape else g.view_as(p)
+                self._dirty[p] = True
+
     def collect(self, buckets=None):
         """After backward (all buckets, or the given ones): make every flat bucket hold this step's gradients -- slices of parameters that got no gradient
         read as zero, gradients produced outside the sinks (stock autograd ops, hand-set) are copied in with one

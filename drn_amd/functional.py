@@ -24,6 +24,15 @@ def bump_weights_epoch():
     _weights_epoch += 1
 
 
+def _purge_dead(cache, limit, refs_of):
+    """Bound a weight-copy cache by dropping the entries of parameters that no longer exist -- and ONLY those: a copy of a
+    live parameter may be referenced by raw pointer from a launch descriptor being assembled right now (the levels of a
+    grouped launch are packed one after the other) or from a captured hipGraph, so it is never evicted."""
+    if len(cache) > limit:
+        for k in [k for k, e in cache.items() if any(r() is None for r in refs_of(e))]:
+            del cache[k]
+
+
 def _w3(w):
     """A Linear weight (N, K) packs like a k=1 conv weight (N, K, 1)."""
     return w.detach().unsqueeze(-1) if w.dim() == 2 else w.detach()
@@ -49,8 +58,7 @@ def packed(w, perm, code):
         out = hit[1]
     else:
         out = ops.pack_weight(_w3(w), perm, code)
-        if len(_pack_cache) > 256:
-            _pack_cache.clear()
+        _purge_dead(_pack_cache, 256, lambda e: (e[2],))
         _pack_cache[key] = (ver, out, weakref.ref(w))
     return out.view(out.shape[0], -1) if two_d else out
 
@@ -81,8 +89,7 @@ def _packed_stack(params, perm, code):
     out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
         torch.empty(shape, dtype=ops.TORCH_DT[code], device=params[0].device)
     ops.pack_weights_into(_pstack_items(out, params, perm), code)
-    if len(_pstack_cache) > 64:
-        _pstack_cache.clear()
+    _purge_dead(_pstack_cache, 64, lambda e: e[2])
     _pstack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
 
@@ -114,8 +121,7 @@ def stacked(params):
     out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
         torch.empty(shape, dtype=torch.float32, device=params[0].device)
     ops.pack_weights_into(_stack_items(out, params), ops.F32)
-    if len(_stack_cache) > 64:
-        _stack_cache.clear()
+    _purge_dead(_stack_cache, 64, lambda e: e[2])
     _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
 
@@ -169,8 +175,7 @@ def stacked_t(params):
     out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
         torch.empty(shape, dtype=torch.float32, device=params[0].device)
     ops.pack_weights_into(_stack_t_items(out, params), ops.F32)
-    if len(_stack_cache) > 64:
-        _stack_cache.clear()
+    _purge_dead(_stack_cache, 64, lambda e: e[2])
     _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
 
@@ -188,16 +193,20 @@ def identity_bf16_copies():
     return out
 
 
-def repack_all(skip=()):
+def repack_all(skip=(), codes=None):
     """Refresh every cached re-laid weight IN PLACE with one launch per dtype (drn_pack_weights) and mark it current:
     an optimizer that has just updated all parameters calls this instead of leaving ~20 small per-use launches to
     the next forward pass.  The copies keep their addresses, so captured hipGraphs stay valid.  `skip`: cache keys the
-    caller has already refreshed itself (identity_bf16_copies)."""
+    caller has already refreshed itself (identity_bf16_copies).  `codes`: only the copies of these dtypes (ops.F32 holds
+    the query side's stacks, ops.BF16 the conv / linear operands of a bf16 model) -- the rest stay stale until their call."""
+    want = lambda code: codes is None or code in codes
     by_code = {}
     for key, (ver, out, ref) in list(_pack_cache.items()):
         w = ref()
         if w is None or w.data_ptr() != key[1] or out.device != w.device:
             del _pack_cache[key]
+            continue
+        if not want(key[3]):
             continue
         if key in skip:
             _pack_cache[key] = ((w._version, _weights_epoch), out, ref)
@@ -207,6 +216,8 @@ def repack_all(skip=()):
         ps = [r() for r in refs]
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key[0] or out.device != ps[0].device:
             del _pstack_cache[key]
+            continue
+        if not want(key[2]):
             continue
         by_code.setdefault(key[2], [])
         by_code.setdefault(("stack", key[2]), []).extend(_pstack_items(out, ps, key[1]))
@@ -218,6 +229,8 @@ def repack_all(skip=()):
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != (key[1:] if transposed else key) \
                 or out.device != ps[0].device:
             del _stack_cache[key]
+            continue
+        if not want(ops.F32):
             continue
         stack_items += _stack_t_items(out, ps) if transposed else _stack_items(out, ps)
         _stack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
@@ -240,17 +253,37 @@ _grad_sinks = {}
 
 
 def register_grad_sink(param, flat_slice):
-    _grad_sinks[param.data_ptr()] = flat_slice
+    _grad_sinks[param.data_ptr()] = (weakref.ref(param), flat_slice)
+
+
+def _sink_of(ptr):
+    """The registered sink for the parameter storage at `ptr` -- None once the parameter that registered it is gone (a new
+    tensor at a recycled address must not inherit a dead model's bucket)."""
+    ent = _grad_sinks.get(ptr)
+    if ent is None:
+        return None
+    owner = ent[0]()
+    if owner is None or owner.data_ptr() != ptr:
+        del _grad_sinks[ptr]
+        _sink_handed.discard(ent[1].data_ptr())
+        return None
+    return ent[1]
 
 
 def unregister_grad_sinks(params):
     """Forget the sinks of these parameters only (another model's reducer in the same process keeps its own)."""
     for p in params:
-        _grad_sinks.pop(p.data_ptr(), None)
+        ent = _grad_sinks.pop(p.data_ptr(), None)
+        if ent is not None:
+            _sink_handed.discard(ent[1].data_ptr())
 
 
 def clear_grad_sinks():
     _grad_sinks.clear()
+    _sink_handed.clear()
+
+
+_sink_handed = set()     # data_ptr of every buffer grad_buffer() handed out that IS (part of) a reducer's flat bucket
 
 
 def grad_buffer(param, dtype=torch.float32):
@@ -258,12 +291,13 @@ def grad_buffer(param, dtype=torch.float32):
     `stack_params` view: the sinks of its sources when they lie back to back in that order (drn_amd.dist.GradReducer puts
     `adjacent=` groups that way), so the stacked gradient is written straight into the flat bucket and the per-source
     views autograd hands to the parameters ARE their sinks (no copy into the bucket afterwards)."""
-    sink = _grad_sinks.get(param.data_ptr())
+    sink = _sink_of(param.data_ptr())
     if sink is not None and sink.numel() == param.numel() and sink.dtype == dtype and sink.device == param.device:
+        _sink_handed.add(sink.data_ptr())
         return sink.view(param.shape)
     srcs = getattr(param, "_drn_stack_of", None)
     if srcs:
-        sinks = [_grad_sinks.get(p.data_ptr()) for p in srcs]
+        sinks = [_sink_of(p.data_ptr()) for p in srcs]
         if all(s is not None and s.numel() == p.numel() and s.dtype == dtype and s.device == param.device
                for s, p in zip(sinks, srcs)) and \
                 all(a.data_ptr() + a.numel() * a.element_size() == b.data_ptr() for a, b in zip(sinks, sinks[1:])) and \
@@ -272,6 +306,7 @@ def grad_buffer(param, dtype=torch.float32):
             for d in reversed(param.shape):
                 strides.append(acc)
                 acc *= d
+            _sink_handed.add(sinks[0].data_ptr())
             return sinks[0].as_strided(tuple(param.shape), tuple(reversed(strides)), sinks[0].storage_offset())
         # one-element sources (the Scale parameters) at a fixed spacing inside the bucket (each slice starts on a 16-byte
         # boundary): a strided 1-D view, element l = source l's sink
@@ -283,7 +318,39 @@ def grad_buffer(param, dtype=torch.float32):
     return torch.empty(param.shape, dtype=dtype, device=param.device)
 
 
-import os
+# Deferred weight gradients.  A weight gradient feeds nothing but the optimizer, so a backward node may hand its launch
+# to the caller instead of issuing it in line: drn_amd.graph.DualStreamStep collects them (`begin_defer` / `take_deferred`)
+# and runs them on the main stream WHILE the query side's backward -- a long chain of small, latency-bound launches --
+# runs on a second stream.  Only gradients written straight into a reducer's flat bucket qualify (autograd then merely
+# adopts the view; nothing reads the values before the optimizer); anything else is launched in line as before.
+_deferred = None
+
+
+def begin_defer():
+    global _deferred
+    _deferred = []
+
+
+def take_deferred():
+    """The jobs collected since begin_defer(), in issue order; deferral is switched off."""
+    global _deferred
+    jobs, _deferred = (_deferred or []), None
+    return jobs
+
+
+def _alias(t):
+    """Another tensor object on the same memory.  A deferred job must not hold the very tensor its node returns to autograd:
+    AccumulateGrad adopts an incoming gradient only while nobody else references it -- otherwise it CLONES it, here before
+    the deferred kernel has written it."""
+    return t.view(t.shape)
+
+
+def _defer(job, *grad_bufs):
+    if _deferred is not None and all(b.data_ptr() in _sink_handed for b in grad_bufs):
+        _deferred.append(job)
+    else:
+        job()
+
 
 NT_WGRAD = True      # prop_fc weight gradient through the NT kernel on transposed operands (bf16): 250 vs 410 us for the TN kernel
 TOUCH_W = True       # warm the prop_fc weight copy right before its GEMM
@@ -522,7 +589,9 @@ class _ConvBlockFn(torch.autograd.Function):
         dW = grad_buffer(ctx.weight_obj if getattr(ctx.weight_obj, "_drn_stack_of", None) else weight)
         wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=Cout, ldx=geo[l][4])
                   for l in range(nl)]
-        ops.gemm_wgrad(wdescs, dW, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)
+        keep = (draws, xs)          # (the descriptors hold raw pointers: a deferred job keeps the operands alive)
+        dWj = _alias(dW)
+        _defer(lambda: (keep, ops.gemm_wgrad(wdescs, dWj, Cout, Cin, taps=k, stride=meta.stride, pad=pad, w_layout=1, dtype=code)), dWj)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[7 + l] for l in range(nl)):
             wd = packed(ctx.weight_obj, (1, 2, 0), code)               # (Cin, k, Cout)
@@ -681,14 +750,20 @@ class _MultiConvFn(torch.autograd.Function):
         wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=geo[l][5], ldx=geo[l][4])
                   for l in range(n)]
         same = all(geo[l][5:9] == geo[0][5:9] and strides[l] == strides[0] for l in range(n))
-        if same and n > 1 and n * max(g[3] for g in geo) <= 4 * sum(g[3] for g in geo):
-            # same (Cout, Cin, k): one launch (+ one reduce) for all levels' weight gradients instead of one pair per level
-            ops.gemm_wgrad_multi(wdescs, dWs, geo[0][5], geo[0][6], taps=geo[0][7], stride=strides[0], pad=geo[0][8], w_layout=1,
-                                 dtype=code)
-        else:
-            for l in range(n):
-                B, L, Lo, M, ld, Cout, Cin, k, pad = geo[l]
-                ops.gemm_wgrad([wdescs[l]], dWs[l], Cout, Cin, taps=k, stride=strides[l], pad=pad, w_layout=1, dtype=code)
+        keep = (draws, xs)
+        dWj = [_alias(w) for w in dWs]
+
+        def wgrads():
+            if same and n > 1 and n * max(g[3] for g in geo) <= 4 * sum(g[3] for g in geo):
+                # same (Cout, Cin, k): one launch (+ one reduce) for all levels' weight gradients instead of one pair per level
+                ops.gemm_wgrad_multi(wdescs, dWj, geo[0][5], geo[0][6], taps=geo[0][7], stride=strides[0], pad=geo[0][8],
+                                     w_layout=1, dtype=code)
+            else:
+                for l in range(n):
+                    B, L, Lo, M, ld, Cout, Cin, k, pad = geo[l]
+                    ops.gemm_wgrad([wdescs[l]], dWj[l], Cout, Cin, taps=k, stride=strides[l], pad=pad, w_layout=1, dtype=code)
+            return keep
+        _defer(wgrads, *dWj)
         return (None,) + tuple(dWs) + tuple(dgammas) + tuple(dbetas) + tuple(dxs)
 
 
@@ -789,15 +864,19 @@ class _InputStageFn(torch.autograd.Function):
             dZ = torch.empty((B, T, D), dtype=dtype, device=dev)
             ops.gate_bwd(dG0, D + P, Z, D, gate0, dZ, D, None, 0, dgate, B, T, D, code, dsum=dsum)
 
-        # 2. the parameter gradients
-        if dZT is not None:
-            ops.gemm_nt([ops.gemm_desc(dZT, xcT, dW, D, D, B * T, out_f32=True)], code)
-        elif xcT.numel():
-            ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ.view(B * T, D), code), xcT, dW, D, D, B * T, out_f32=True)], code)
-        else:
-            ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], dW, D, D, taps=1, w_layout=0, dtype=code)
-        ops.colsum(dsum, D, B, D, db, ops.F32)
-        ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, dWp, dbp, code)
+        # 2. the parameter gradients (deferrable: only the optimizer reads them)
+        jW, jb, jWp, jbp = _alias(dW), _alias(db), _alias(dWp), _alias(dbp)
+
+        def wgrads():
+            if dZT is not None:
+                ops.gemm_nt([ops.gemm_desc(dZT, xcT, jW, D, D, B * T, out_f32=True)], code)
+            elif xcT.numel():
+                ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ.view(B * T, D), code), xcT, jW, D, D, B * T, out_f32=True)], code)
+            else:
+                ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], jW, D, D, taps=1, w_layout=0, dtype=code)
+            ops.colsum(dsum, D, B, D, jb, ops.F32)
+            ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, jWp, jbp, code)
+        _defer(wgrads, jW, jb, jWp, jbp)
         return None, dW, db, dgate, dWp, dbp
 
 

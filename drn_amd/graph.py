@@ -73,7 +73,7 @@ class TwoPhaseStep(object):
     def _phase(self, k):
         m, red = self.model, self.reducer
         if k == 0:
-            tok, qlen, feats, pse, gt = self.batch
+            tok, qlen, feats, pse, gt = self.batch[:5]
             red.zero()
             gates = m.encode_query(tok, qlen)
             gd = [g.detach().requires_grad_() for g in gates]
@@ -126,4 +126,138 @@ class TwoPhaseStep(object):
             g.replay()
             if self.between is not None and k + 1 < self.NPHASES:
                 self.between(k)
+        return self.out
+
+
+class DualStreamStep(object):
+    """One training step of drn_amd.model.mainModel on ONE GPU as seven linear hipGraphs on two streams, so that the query
+    side -- ~35 small, latency-bound launches each way that use a fraction of the chip -- runs BESIDE bandwidth- / MFMA-bound
+    work it does not depend on (a single hipGraph with parallel branches leaves ROCm 7.2's fast submission path, see
+    DESIGN.md; separate linear graphs joined by events do not):
+
+        main stream                                              side stream
+        prep     cast / transpose of the features, weight warm   q_fwd   query encoder + gate projections
+        trunk    prop_fc .. losses, backward down to the gates   (waits for q_fwd)
+                 (weight gradients deferred, functional._defer)
+        wgrads   the deferred weight gradients                   q_bwd   gate projections + query encoder backward
+        opt      clip + Adam + fp32 weight copies                (waits for q_bwd)
+        repack   bf16 weight copies                              q_fwd of the NEXT step starts after `opt`
+
+    Results are bit-identical to the single-stream step: deferral only reorders independent launches and every kernel is
+    deterministic (tests/test_graph_gpu.py).  model: mainModel; batch: its 5 device-resident arguments; loss_of: loss dict ->
+    scalar; reducer: GradReducer over the trainable parameters (steal mode); opt: FusedAdam on that reducer."""
+
+    PHASES = ("q_fwd", "prep", "trunk", "q_bwd", "wgrads", "opt", "repack")
+    SIDE = ("q_fwd", "q_bwd")
+
+    def __init__(self, model, batch, loss_of, reducer, opt, wgrads_first=True):
+        self.model, self.batch, self.loss_of, self.reducer, self.opt = model, batch, loss_of, reducer, opt
+        self.main, self.side = torch.cuda.Stream(), torch.cuda.Stream()
+        self.wgrads_first = wgrads_first       # small weight gradients before the prop_fc one (it owns every CU while it runs)
+        self.graphs = None
+        self.out = None
+        self._c = {}
+        self._ev = dict((k, torch.cuda.Event()) for k in ("q_fwd", "trunk", "q_bwd", "opt", "start"))
+        self._fresh = True
+        have = set(id(p) for p in reducer.params)
+        self._qparams = [p for p in model.query_parameters() if id(p) in have]
+
+    # ---- the phases (each runs on the stream its row in the table says)
+    def _phase(self, name):
+        m, red, c = self.model, self.reducer, self._c
+        tok, qlen, feats, pse, gt = self.batch[:5]
+        if name == "q_fwd":
+            c["gates"] = m.encode_query(tok, qlen)
+        elif name == "prep":
+            c["prep"] = m.prepare_input(feats, pse)
+        elif name == "trunk":
+            red.zero()
+            gd = c["gd"] = [g.detach().requires_grad_() for g in c["gates"]]
+            DF.begin_defer()
+            try:
+                g0, _ = m.forward_front(tok, qlen, feats, pse, gates=gd, prep=c.pop("prep"))
+                _, losses = m.forward_trunk(g0, gd, gt)
+                DF.backward(self.loss_of(losses))            # trunk + input stage; the gates' gradients land in gd[i].grad
+            finally:
+                c["jobs"] = DF.take_deferred()
+            self.out = losses
+        elif name == "q_bwd":
+            grads = torch.autograd.grad(c["gates"], self._qparams, [g.grad for g in c["gd"]], allow_unused=True)
+            red.adopt(self._qparams, grads)
+        elif name == "wgrads":
+            jobs = c.pop("jobs")
+            if not self.wgrads_first:
+                jobs = jobs[::-1]
+            for job in jobs:
+                job()
+        elif name == "opt":
+            red.finish()
+            self.opt.step(repack=False)
+            self.opt.repack(codes=(0,))                      # ops.F32: the query side's stacks, needed by the next q_fwd
+        else:
+            self.opt.repack(codes=(1,))                      # ops.BF16
+
+    def _schedule(self, run, M, Q):
+        """Issue the seven phases with their cross-stream dependencies; run(name) launches phase `name` on the current stream."""
+        ev = self._ev
+        if self._fresh:                       # first step on these streams: the side stream starts behind everything queued so far
+            ev["start"].record(M)
+            Q.wait_event(ev["start"])
+            self._fresh = False
+        else:
+            Q.wait_event(ev["opt"])           # the previous step's parameters
+        with torch.cuda.stream(Q):
+            run("q_fwd")
+            ev["q_fwd"].record(Q)
+        with torch.cuda.stream(M):
+            run("prep")
+            M.wait_event(ev["q_fwd"])
+            run("trunk")
+            ev["trunk"].record(M)
+        with torch.cuda.stream(Q):
+            Q.wait_event(ev["trunk"])
+            run("q_bwd")
+            ev["q_bwd"].record(Q)
+        with torch.cuda.stream(M):
+            run("wgrads")
+            M.wait_event(ev["q_bwd"])
+            run("opt")
+            ev["opt"].record(M)
+            run("repack")
+
+    def warm(self, n):
+        """Eager two-stream steps on the capture streams (see GraphedStep.warm for why these streams and no others)."""
+        cur = torch.cuda.current_stream()
+        self.main.wait_stream(cur)
+        self._fresh = True
+        for _ in range(n):
+            self._schedule(self._phase, self.main, self.side)
+        cur.wait_stream(self.main)
+        cur.wait_stream(self.side)
+        torch.cuda.synchronize()
+        return self
+
+    def capture(self):
+        graphs, pools = {}, {}
+        for name in self.PHASES:
+            side = name in self.SIDE
+            g = torch.cuda.CUDAGraph()
+            kw = {"pool": pools[side]} if side in pools else {}
+            with torch.cuda.graph(g, stream=self.side if side else self.main, **kw):
+                self._phase(name)
+            pools.setdefault(side, g.pool())
+            graphs[name] = g
+        self._c.clear()                       # (the graphs' private pools keep every block they captured)
+        self.graphs = graphs
+        self._fresh = True
+        return self
+
+    def __call__(self):
+        if self.graphs is None:
+            self.warm(1)
+            return self.out
+        M = torch.cuda.current_stream()
+        if getattr(self, "_last_main", None) != M.cuda_stream:
+            self._fresh, self._last_main = True, M.cuda_stream
+        self._schedule(lambda name: self.graphs[name].replay(), M, self.side)
         return self.out

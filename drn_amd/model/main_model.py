@@ -81,9 +81,9 @@ class mainModel(nn.Module):
         front = set(id(p) for p in self.front_parameters())
         return [p for p in self.parameters() if id(p) not in front]
 
-    def forward_front(self, query_tokens, query_length, props_features, props_start_end, gates=None):
-        """-> (g0 (B, T, D+P) channels-last, gates): query encoder, gate projections, prop_fc + gating + position embedding.
-        `gates`: reuse already computed gate tensors (e.g. detached ones) instead of running the query encoder."""
+    def prepare_input(self, props_features, props_start_end):
+        """The part of the input stage that does not depend on the query (cast / transposed copy of the features, position
+        features, the warmed GEMM copy of the prop_fc weight): drn_amd.graph.DualStreamStep runs it beside the query encoder."""
         if not props_features.is_cuda:
             raise DrnError("drn_amd.mainModel runs on an MI355X only (inputs on %s); no CPU fallback" % props_features.device)
         dt = self.compute_dtype
@@ -91,9 +91,16 @@ class mainModel(nn.Module):
         # ActivityNet C3D-PCA convention) keeps the two layers that see D -- prop_fc and conv0 -- on the exact-f32 kernels
         front_dt = torch.float32 if (dt == torch.bfloat16 and props_features.shape[2] % 8) else dt
         want_wgrad = self.prop_fc.weight.requires_grad and torch.is_grad_enabled()
+        return DF.input_prep(props_features, props_start_end, self.prop_fc, front_dt, want_wgrad)
+
+    def forward_front(self, query_tokens, query_length, props_features, props_start_end, gates=None, prep=None):
+        """-> (g0 (B, T, D+P) channels-last, gates): query encoder, gate projections, prop_fc + gating + position embedding.
+        `gates`: reuse already computed gate tensors (e.g. detached ones) instead of running the query encoder; `prep`: the
+        result of prepare_input() on the same features."""
+        if prep is None:
+            prep = self.prepare_input(props_features, props_start_end)
         if gates is None:
             gates = self.encode_query(query_tokens, query_length)
-        prep = DF.input_prep(props_features, props_start_end, self.prop_fc, front_dt, want_wgrad)
         g0 = DF.input_stage(prep, self.prop_fc, gates[0], self.position_transform)
         return g0, gates
 

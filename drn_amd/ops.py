@@ -140,8 +140,9 @@ _ws_retired = []          # outgrown buffers stay allocated: a hipGraph captured
 
 
 def workspace(n_floats, device):
-    """A grow-only fp32 scratch buffer per device (stream-ordered reuse on torch's current stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """A grow-only fp32 scratch buffer per device AND stream (stream-ordered reuse on torch's current stream; two streams
+    that run side by side -- drn_amd.graph.DualStreamStep -- never share one)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < n_floats:
         if buf is not None:
@@ -220,8 +221,9 @@ _qd_counters = {}
 
 
 def _counters(device):
-    """DRN_QD_COUNTERS zeroed int32 arrival counters per device for the K-split dense kernels (they re-arm themselves)."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """DRN_QD_COUNTERS zeroed int32 arrival counters per device and stream for the K-split dense kernels (they re-arm
+    themselves)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     c = _qd_counters.get(key)
     if c is None:
         c = _qd_counters[key] = torch.zeros(_lib.QD_COUNTERS, dtype=torch.int32, device=device)

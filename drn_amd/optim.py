@@ -53,7 +53,9 @@ class FusedAdam(object):
         if tuple(p.data_ptr() for b in self.reducer.buckets for p in b.params) != self._ptr_sig:
             raise RuntimeError("parameter storage moved after FusedAdam was built; build a new GradReducer + FusedAdam")
 
-    def step(self):
+    def step(self, repack=True):
+        """repack=False leaves the refresh of the re-laid weight copies to the caller (`repack(codes)`), who may split it
+        over two points of its schedule (drn_amd.graph.DualStreamStep)."""
         self._check_ptrs()
         L = lib()
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -70,7 +72,12 @@ class FusedAdam(object):
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                                     ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
         DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
-        DF.repack_all(skip=self._mirror_keys)     # refresh the other GEMM-layout copies of the weights in one launch
+        if repack:
+            self.repack()
+
+    def repack(self, codes=None):
+        """Refresh the other GEMM-layout copies of the weights (one launch per dtype; `codes`: only these dtypes)."""
+        DF.repack_all(skip=self._mirror_keys, codes=codes)
 
     def _refresh_mirrors(self):
         """Device tables of the bf16 GEMM operands that keep their parameter's element order (drn_adam_bucket rewrites them
