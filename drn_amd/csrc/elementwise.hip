@@ -85,38 +85,53 @@ extern "C" int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out,
 // ---------------------------------------------------------------- cast + transpose in one pass over the fp32 input
 // out[m][k] = (T) in[m][k]  and  outT[k][m] = (T) in[m][k]: the proposal features are cast once per step anyway; writing
 // the K-major copy from the same tile saves re-reading them for the prop_fc weight gradient (NT product of transposes).
+// Tile: 128 rows (m) x 64 columns (k) per 256-thread workgroup.  A thread owns 8 consecutive source floats at a time (four
+// such units, all eight 16-byte loads requested before the first use): they become one 16-byte store of `out` (bf16) or two
+// (f32) and eight 2-byte column writes of the LDS tile [k][m]; the tile is then flushed as 16-byte pieces of outT rows
+// (256-byte segments).  134 MB in, 2 x 67 MB out at B*T = 8192, D = 4096.
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ outT,
                                                              int M, int K) {
-  constexpr int VN = V16<T>::N;
-  constexpr int CPR = 64 / VN;
-  __shared__ T tile[64][64 + 2 * VN / 4 + 2];  // [k][m]
-  const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
-  for (int q = threadIdx.x; q < 64 * 16; q += 256) {          // 64 rows x 16 float4 chunks
-    const int r = q >> 4, cv = q & 15;
-    const int m = m0 + r, k = k0 + cv * 4;
-    if (m < M && k < K) {                                      // K % 4 == 0
-      const f32x4 v = *(const f32x4*)(in + (long)m * K + k);
-      T t[4];
+  constexpr int VN = V16<T>::N;              // elements per 16-byte piece of the outputs
+  constexpr int TM = 128, TK = 64;
+  constexpr int PITCH = TM + 16 / (int)sizeof(T);          // [k][m] tile, rows stay 16-byte aligned
+  constexpr int CPR = TM / VN;                               // 16-byte pieces per tile row (a power of two)
+  __shared__ __attribute__((aligned(16))) T tile[TK][PITCH];
+  const int m0 = blockIdx.y * TM, k0 = blockIdx.x * TK;
+  f32x4 v[4][2];
+  int mm[4], kk[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        DT<T>::st(&t[e], v[e]);
-        tile[cv * 4 + e][r] = t[e];
-      }
-      if (sizeof(T) == 2) *(uint2*)(out + (long)m * K + k) = *(const uint2*)t;
-      else *(uint4*)(out + (long)m * K + k) = *(const uint4*)t;
+  for (int u = 0; u < 4; ++u) {                             // unit = 8 floats: 128 rows x 8 units per row
+    const int q = threadIdx.x + 256 * u;
+    mm[u] = q >> 3;
+    kk[u] = (q & 7) * 8;
+    const int m = m0 + mm[u], k = k0 + kk[u];
+    const bool ok = m < M && k < K;                         // K % 8 == 0 (checked by the host)
+    const float* src = in + (long)m * K + k;
+    v[u][0] = ok ? *(const f32x4*)src : (f32x4){0.f, 0.f, 0.f, 0.f};
+    v[u][1] = ok ? *(const f32x4*)(src + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int m = m0 + mm[u], k = k0 + kk[u];
+    T t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      DT<T>::st(&t[e], v[u][e >> 2][e & 3]);
+      // (16-byte piece index XOR row group: the 8 lanes of a source row write tile rows a multiple of 128 bytes apart)
+      tile[kk[u] + e][((((mm[u] / VN) ^ (kk[u] >> 3)) & (CPR - 1)) * VN) + (mm[u] % VN)] = t[e];
+    }
+    if (m < M && k < K) {
+      T* dst = out + (long)m * K + k;
+#pragma unroll
+      for (int h = 0; h < 8 / VN; ++h) *(uint4*)(dst + h * VN) = *(const uint4*)(t + h * VN);
     }
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < 64 * CPR; q += 256) {
+  for (int q = threadIdx.x; q < TK * CPR; q += 256) {
     const int r = q / CPR, cv = q % CPR;
     const int k = k0 + r, m = m0 + cv * VN;
-    if (k < K && m < M) {
-      T v[VN];
-#pragma unroll
-      for (int e = 0; e < VN; ++e) v[e] = tile[r][cv * VN + e];
-      *(uint4*)(outT + (long)k * M + m) = *(const uint4*)v;
-    }
+    if (k < K && m < M) *(uint4*)(outT + (long)k * M + m) = *(const uint4*)&tile[r][((cv ^ (r >> 3)) & (CPR - 1)) * VN];
   }
 }
 extern "C" int drn_cast_transpose(const float* in, void* out, void* outT, int M, int K, int dtype, void* stream) {
@@ -124,9 +139,9 @@ extern "C" int drn_cast_transpose(const float* in, void* out, void* outT, int M,
   DRN_CHECK_ARG(in && out && outT && M > 0 && K > 0, "drn_cast_transpose: bad args");
   DISPATCH_DT(dtype, "drn_cast_transpose", {
     constexpr int VN = V16<T>::N;
-    DRN_CHECK_ARG(M % VN == 0 && K % VN == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)outT) & 15) == 0,
-                  "drn_cast_transpose: dims must be 16-byte multiples");
-    dim3 grid(cdiv(K, 64), cdiv(M, 64));
+    DRN_CHECK_ARG(M % VN == 0 && K % 8 == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)outT) & 15) == 0,
+                  "drn_cast_transpose: M must be a 16-byte multiple in the output type, K a multiple of 8");
+    dim3 grid(cdiv(K, 64), cdiv(M, 128));
     cast_transpose_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(in, (T*)out, (T*)outT, M, K);
   });
   return drn_launch_status("drn_cast_transpose");
@@ -516,19 +531,24 @@ extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_a
 }
 
 // Variant for the input stage: the gated gradient is only ever consumed as the K-major operand of the prop_fc weight
-// gradient, so it is written TRANSPOSED, dCT[c][s*L + t] = dG[s,t,c] * gate[s,c], 32 rows at a time through an LDS tile
-// (64-byte row segments), and never in its natural layout.  Requires L % 32 == 0.
-template <typename T>
+// gradient, so it is written TRANSPOSED, dCT[c][s*L + t] = dG[s,t,c] * gate[s,c], RI rows at a time through an LDS tile, and
+// never in its natural layout.  A workgroup owns one clip and CV channel vectors (CV * N channels); 256 / CV row lanes.
+//   <32, 32>: 256 (bf16) channels x 32 rows per pass -- any L % 32 == 0
+//   <16, 128>: 128 channels x 128 rows per pass: 256-byte segments on BOTH sides (row reads and transposed row writes) and
+//              16 row loads in flight per thread -- L % 128 == 0 (the benchmarked T = 256)
+template <typename T, int CV, int RI>
 __global__ __launch_bounds__(256) void gate_bwd_t_kernel(const T* __restrict__ dG, int ld_dg, const T* __restrict__ act, int ld_act,
                                                          const float* __restrict__ gate, int ldg, T* __restrict__ dCT, long ldt,
                                                          float* __restrict__ dgate, int ld_dgate, float* __restrict__ dsum, int L,
                                                          int C) {
   constexpr int N = V16<T>::N;
-  constexpr int TP = 32 * N + 16 / (int)sizeof(T);      // [row][channel] tile, pitch in elements (16-byte aligned rows)
-  __shared__ float red[8][32 * N + 1];
-  __shared__ __attribute__((aligned(16))) T tile[32][TP];
-  const int vx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int v = blockIdx.x * 32 + vx;
+  constexpr int RL = 256 / CV, RPT = RI / RL;            // row lanes, rows per thread and pass
+  constexpr int TP = RI + 16 / (int)sizeof(T);           // [channel][row] tile, pitch in elements (16-byte aligned rows)
+  constexpr int EPC = 16 / (int)sizeof(T), CPR = RI / EPC;   // elements per 16-byte piece, pieces per tile row (a power of two)
+  __shared__ float red[RL][CV * N + 1];
+  __shared__ __attribute__((aligned(16))) T tile[CV * N][TP];
+  const int vx = threadIdx.x % CV, ry = threadIdx.x / CV;
+  const int v = blockIdx.x * CV + vx;
   const int s = blockIdx.y;
   const int c0 = v * N;
   const bool live = c0 < C;
@@ -539,53 +559,53 @@ __global__ __launch_bounds__(256) void gate_bwd_t_kernel(const T* __restrict__ d
     acc[k] = 0.f;
     cs[k] = 0.f;
   }
-  for (int t0 = 0; t0 < L; t0 += 32) {
+  for (int t0 = 0; t0 < L; t0 += RI) {
+    uint4 graw[RPT], araw[RPT];                            // raw 16-byte pieces: every row load of the pass is requested first
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rl = i * 8 + ry;
-      const long m = (long)s * L + t0 + rl;
-      float g[N], a[N];
-      if (live) {
-        V16<T>::load(dG + m * ld_dg + c0, g);
-        V16<T>::load(act + m * ld_act + c0, a);
-      } else {
+    for (int i = 0; i < RPT; ++i) {
+      const long m = (long)s * L + t0 + i * RL + ry;
+      graw[i] = live ? *(const uint4*)(dG + m * ld_dg + c0) : make_uint4(0, 0, 0, 0);
+      araw[i] = live ? *(const uint4*)(act + m * ld_act + c0) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
-        for (int k = 0; k < N; ++k) { g[k] = 0.f; a[k] = 0.f; }
-      }
-      float o[N];
+    for (int i = 0; i < RPT; ++i) {
+      float g[N], a[N], o[N];
+      V16<T>::load((const T*)&graw[i], g);
+      V16<T>::load((const T*)&araw[i], a);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         acc[k] = fmaf(g[k], a[k], acc[k]);
         cs[k] += g[k];
         o[k] = g[k] * gt[k];
       }
-      V16<T>::store(&tile[rl][vx * N], o);              // natural layout: one conflict-free 16-byte LDS write
+      // transposed on the way in; the 16-byte piece index of a row is XORed with the channel group so that the 16 lanes of
+      // a row lane (channels 8 apart = rows of the tile a multiple of 128 bytes apart) spread over all banks
+      const int row = i * RL + ry;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const int ch = vx * N + k;
+        DT<T>::st(&tile[ch][(((row / EPC) ^ (ch >> 3)) & (CPR - 1)) * EPC + (row % EPC)], o[k]);
+      }
     }
     __syncthreads();
-    // flush transposed: a thread gathers EPC consecutive rows of one channel (column reads, neighbouring lanes hit
-    // neighbouring channels) and stores them as one 16-byte piece of dCT's row; 4 (bf16) / 8 (f32) lanes share a row
-    constexpr int EPC = 16 / (int)sizeof(T), CPR = 32 / EPC;
-    for (int q = threadIdx.x; q < 32 * N * CPR; q += 256) {
-      const int ch = q % (32 * N), part = q / (32 * N);
-      const int c = blockIdx.x * 32 * N + ch;
-      if (c < C) {
-        T pk[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) pk[e] = tile[part * EPC + e][ch];
-        *(uint4*)(dCT + (long)c * ldt + (long)s * L + t0 + part * EPC) = *(const uint4*)pk;
-      }
+    // flush: consecutive lanes take consecutive 16-byte pieces of one dCT row (whole 64- / 256-byte segments per request)
+    for (int q = threadIdx.x; q < CV * N * CPR; q += 256) {
+      const int ch = q / CPR, part = q % CPR;
+      const int c = blockIdx.x * CV * N + ch;
+      if (c < C)
+        *(uint4*)(dCT + (long)c * ldt + (long)s * L + t0 + part * EPC) = *(const uint4*)&tile[ch][((part ^ (ch >> 3)) & (CPR - 1)) * EPC];
     }
     __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) red[ry][vx * N + k] = acc[k];
   __syncthreads();
-  for (int i = threadIdx.x; i < 32 * N; i += 256) {
-    const int c = blockIdx.x * 32 * N + i;
+  for (int i = threadIdx.x; i < CV * N; i += 256) {
+    const int c = blockIdx.x * CV * N + i;
     if (c < C) {
       float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) sum += red[r][i];
+      for (int r = 0; r < RL; ++r) sum += red[r][i];
       dgate[(long)s * ld_dgate + c] = sum;
     }
   }
@@ -594,12 +614,12 @@ __global__ __launch_bounds__(256) void gate_bwd_t_kernel(const T* __restrict__ d
 #pragma unroll
     for (int k = 0; k < N; ++k) red[ry][vx * N + k] = cs[k] * gt[k];
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * N; i += 256) {
-      const int c = blockIdx.x * 32 * N + i;
+    for (int i = threadIdx.x; i < CV * N; i += 256) {
+      const int c = blockIdx.x * CV * N + i;
       if (c < C) {
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) sum += red[r][i];
+        for (int r = 0; r < RL; ++r) sum += red[r][i];
         dsum[(long)s * C + c] = sum;
       }
     }
@@ -614,9 +634,12 @@ extern "C" int drn_gate_bwd_t(const void* dG, int ld_dg, const void* act, int ld
     constexpr int N = V16<T>::N;
     DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && ldt % N == 0 && (((uintptr_t)dCT) & 15) == 0,
                   "drn_gate_bwd_t: C/ld must be 16-byte multiples");
-    dim3 grid(cdiv(C / N, 32), nseq);
-    gate_bwd_t_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (T*)dCT, ldt,
-                                                                  dgate, ld_dgate, dsum, L, C);
+    if (L % 128 == 0 && sizeof(T) == 2)
+      gate_bwd_t_kernel<T, 16, 128><<<dim3(cdiv(C / N, 16), nseq), 256, 0, (hipStream_t)stream>>>(
+          (const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (T*)dCT, ldt, dgate, ld_dgate, dsum, L, C);
+    else
+      gate_bwd_t_kernel<T, 32, 32><<<dim3(cdiv(C / N, 32), nseq), 256, 0, (hipStream_t)stream>>>(
+          (const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (T*)dCT, ldt, dgate, ld_dgate, dsum, L, C);
   });
   return drn_launch_status("drn_gate_bwd_t");
 }

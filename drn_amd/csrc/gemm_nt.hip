@@ -40,8 +40,10 @@ struct GemmProb {
 struct GemmParams {
   int ngroups;
   int xcd_swizzle;
-  int ksplit;       // > 1: gridDim.y splits of the K loop, raw fp32 partial tiles go to `ws` (single group only)
-  float* ws;        // [ksplit][M][N]
+  int ksplit;       // > 1: gridDim.y splits of the K loop; partial tiles are exchanged through `ws` and summed by the
+                    // LAST-ARRIVING split of each tile, which then runs the epilogue (single group only)
+  float* ws;        // [tiles][ksplit][TM*TN] fp32, accumulator-native order (one 16-byte piece per thread and MFMA tile)
+  int* counters;    // [tiles] arrival counters, zero on entry, re-armed by the last arriver
   GemmProb p[DRN_MAX_GROUPS];
 };
 
@@ -129,22 +131,6 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams& P, const GemmProb&
   const int wr = w / WN, wc = w % WN;
   const int M = pr.M, N = pr.N;
   (void)TM; (void)NW;
-  if (P.ksplit > 1) {   // raw partial tile; bias / gate / stats / conversion happen in splitk_reduce_kernel
-    float* wsp = P.ws + (long)blockIdx.y * M * N;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * (MI * 16) + mi * 16 + (l >> 4) * 4 + r;
-        if (m >= M) continue;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int n = n0 + wc * (NI * 16) + ni * 16 + (l & 15);
-          if (n < N) wsp[(long)m * N + n] = acc[mi][ni][r];
-        }
-      }
-    return;
-  }
   if (pr.out_f32) {
     // fp32 destination (a weight gradient): each wave transposes its slab (NI*16 columns) through a private LDS patch, 32 rows
     // at a time, and writes 16-byte row segments.  Only bias / accumulate apply here.
@@ -548,124 +534,82 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  if constexpr (MI * NI == 8) {          // (the 128x128 tiles: split launches always use them)
+    if (P.ksplit > 1) {
+      // Split-K without a second launch: every split publishes its partial tile with write-through (sc1) 16-byte stores in
+      // accumulator-native order (lane-contiguous: 1 KB per wave instruction), counts itself in, and the split that arrives
+      // LAST re-reads all partials -- its own included, always in split order, so the sum does not depend on who was last --
+      // and carries on into the epilogue.  Same exchange protocol as skinny_group_kernel (qdense.hip).
+      constexpr int NT = 64 * NW;
+      const int tile_id = blockIdx.x, ks = P.ksplit;
+      f32x4* slab = (f32x4*)P.ws + ((long)tile_id * ks + blockIdx.y) * (MI * NI * NT) + tid;
+      // ONE asm statement for the eight stores and their drain.  As separate statements the compiler recycled a store's
+      // data registers for the next store's address straight after issuing it -- it cannot know the statement is a store, so
+      // its hazard recogniser did not keep the wait states a > 64-bit VMEM store needs before its data VGPRs are
+      // overwritten: rare corrupted partial tiles (scripts/stress_splitk.py).
+      asm volatile(
+          "global_store_dwordx4 %0, %8, off sc1\n\t"
+          "global_store_dwordx4 %1, %9, off sc1\n\t"
+          "global_store_dwordx4 %2, %10, off sc1\n\t"
+          "global_store_dwordx4 %3, %11, off sc1\n\t"
+          "global_store_dwordx4 %4, %12, off sc1\n\t"
+          "global_store_dwordx4 %5, %13, off sc1\n\t"
+          "global_store_dwordx4 %6, %14, off sc1\n\t"
+          "global_store_dwordx4 %7, %15, off sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          :
+          : "v"(slab), "v"(slab + NT), "v"(slab + 2 * NT), "v"(slab + 3 * NT), "v"(slab + 4 * NT), "v"(slab + 5 * NT),
+            "v"(slab + 6 * NT), "v"(slab + 7 * NT), "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[2][0]),
+            "v"(acc[2][1]), "v"(acc[3][0]), "v"(acc[3][1])
+          : "memory");
+      static_assert(MI == 4 && NI == 2, "the exchange is written for the 8-wave 128x128 tile");
+      __syncthreads();
+      int& s_last = *(int*)smem;            // (the ring is idle: everybody is past the main loop's last LDS read)
+      if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(P.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == ks - 1;
+        if (prev == ks - 1) __hip_atomic_store(P.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+      }
+      __syncthreads();
+      if (!s_last) return;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4* src = (const f32x4*)P.ws + (long)tile_id * ks * (MI * NI * NT) + tid;
+      for (int q = 0; q < ks; ++q, src += MI * NI * NT) {
+        // ONE asm statement for the eight loads AND their wait: with a separate wait the compiler, which takes an asm output
+        // as ready when its statement ends, may move a loaded value to another register before the data has landed
+        // (seen as rare garbage tiles).  Early-clobber outputs: no output may share registers with a later load's address.
+        f32x4 p0, p1, p2, p3, p4, p5, p6, p7;
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off sc1\n\t"
+            "global_load_dwordx4 %1, %9, off sc1\n\t"
+            "global_load_dwordx4 %2, %10, off sc1\n\t"
+            "global_load_dwordx4 %3, %11, off sc1\n\t"
+            "global_load_dwordx4 %4, %12, off sc1\n\t"
+            "global_load_dwordx4 %5, %13, off sc1\n\t"
+            "global_load_dwordx4 %6, %14, off sc1\n\t"
+            "global_load_dwordx4 %7, %15, off sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
+            : "v"(src), "v"(src + NT), "v"(src + 2 * NT), "v"(src + 3 * NT), "v"(src + 4 * NT), "v"(src + 5 * NT), "v"(src + 6 * NT),
+              "v"(src + 7 * NT)
+            : "memory");
+        const f32x4 part[8] = {p0, p1, p2, p3, p4, p5, p6, p7};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += part[mi * NI + ni];
+      }
+      __syncthreads();
+    }
+  }
   nt_epilogue<T, WM, WN, MI, NI>(P, pr, acc, smem, m0, n0, tm);
 }
 
-// Sum the split-K partial tiles in a fixed order and run the epilogue the GEMM skipped: bias, pre-gate copy, gate,
-// accumulate, conversion, per-128-row-slab column sums for BatchNorm.  grid (ceil(N/64), ceil(M/128)), 256 threads =
-// 16 column quads x 16 row lanes.
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, const GemmProb pr) {
-  __shared__ float red[16][65];
-  __shared__ float colmean[64];
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-  const int n = blockIdx.x * 64 + cx * 4;
-  const int M = pr.M, N = pr.N;
-  const int mbase = blockIdx.y * 128;
-  float vals[8][4];
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  T* Cg = (T*)pr.C;
-  T* C2g = (T*)pr.C2;
-  // vector path: N, the output row strides and bases allow aligned 4-element accesses for every quad
-  const bool vec = (N % 4 == 0) && (pr.ldc % 4 == 0) && (((uintptr_t)Cg) % 16 == 0) && (((uintptr_t)ws) % 16 == 0) &&
-                   (!C2g || ((pr.ldc2 % 4 == 0) && (((uintptr_t)C2g) % 16 == 0)));
-  auto st4 = [](T* dst, const float (&v)[4]) {
-    if constexpr (sizeof(T) == 2) {
-      bf16x4 b;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) b[k] = (bf16_t)v[k];
-      *(bf16x4*)dst = b;
-    } else {
-      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-    }
-  };
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int m = mbase + ry + 16 * j;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) vals[j][k] = 0.f;
-    if (n < N && m < M) {
-      if (vec) {                                  // whole quads, 16-byte aligned: one load per split (same z order)
-        for (int z = 0; z < ksplit; ++z) {
-          const f32x4 q = *(const f32x4*)(ws + ((long)z * M + m) * N + n);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) vals[j][k] += q[k];
-        }
-      } else
-      for (int z = 0; z < ksplit; ++z) {
-        const float* p = ws + ((long)z * M + m) * N + n;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (n + k < N) vals[j][k] += p[k];
-      }
-      const float* grow = pr.gate ? pr.gate + (long)(m / pr.Lout) * pr.ldg : nullptr;
-      if (vec && !pr.accumulate) {
-        // packed stores: 4 outputs per lane in one 8-byte (bf16) / 16-byte (f32) store instead of four scalar ones
-        float o[4], o2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          cs[k] += vals[j][k];
-          o2[k] = vals[j][k] + (pr.bias ? pr.bias[n + k] : 0.f);
-          o[k] = grow ? o2[k] * grow[n + k] : o2[k];
-        }
-        if (C2g) st4(C2g + ((long)m * pr.ldc2 + n), o2);
-        st4(Cg + ((long)m * pr.ldc + n), o);
-        continue;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (n + k >= N) continue;
-        cs[k] += vals[j][k];
-        float o = vals[j][k];
-        if (pr.bias) o += pr.bias[n + k];
-        if (C2g) DT<T>::st(C2g + ((long)m * pr.ldc2 + n + k), o);
-        if (grow) o *= grow[n + k];
-        const long off = (long)m * pr.ldc + n + k;
-        if (pr.accumulate) o += DT<T>::ld(Cg + off);
-        DT<T>::st(Cg + off, o);
-      }
-    }
-  }
-  if (pr.stats) {   // (sum, centred sum of squares) of this 128-row slab, same format as the GEMM epilogue
-    const int rows = min(128, M - mbase);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) red[ry][cx * 4 + k] = cs[k];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
-      colmean[threadIdx.x] = t / (float)rows;
-      const int nn = blockIdx.x * 64 + threadIdx.x;
-      if (nn < N) pr.stats[((long)blockIdx.y * 2 + 0) * N + nn] = t;
-    }
-    __syncthreads();
-    float cq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = mbase + ry + 16 * j;
-      if (m < M)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float dlt = vals[j][k] - colmean[cx * 4 + k];
-          cq[k] = fmaf(dlt, dlt, cq[k]);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) red[ry][cx * 4 + k] = cq[k];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
-      const int nn = blockIdx.x * 64 + threadIdx.x;
-      if (nn < N) pr.stats[((long)blockIdx.y * 2 + 1) * N + nn] = t;
-    }
-  }
-}
-
-static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr) {
+static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr,
+                     int* counters = nullptr) {
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_nt: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_nt: bad dtype %d", dtype);
   const int ch = dtype == DRN_BF16 ? 8 : 4;
@@ -693,6 +637,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   P.ngroups = ngroups;
   P.ksplit = ksplit;
   P.ws = ws;
+  P.counters = counters;
   P.xcd_swizzle = drn_exp_env("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
   if (const char* e = drn_exp_env("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);      // bit 0: XCD-contiguous runs, bit 1: 8-row grouped order
   if (ksplit > 1) tile = 128;
@@ -752,11 +697,6 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 32768, 2, 4, 4, 2); else NT_LAUNCH(float, 2, 512, 2 * 32768, 2, 4, 4, 2);
   }
 #undef NT_LAUNCH
-  if (ksplit > 1) {
-    dim3 rg(cdiv(P.p[0].N, 64), cdiv(P.p[0].M, 128));
-    if (dtype == DRN_BF16) splitk_reduce_kernel<bf16_t><<<rg, 256, 0, stream>>>(ws, ksplit, P.p[0]);
-    else splitk_reduce_kernel<float><<<rg, 256, 0, stream>>>(ws, ksplit, P.p[0]);
-  }
   return drn_launch_status("drn_gemm_nt");
 }
 
@@ -765,8 +705,14 @@ extern "C" int drn_gemm_nt(const DrnGemmDesc* descs, int ngroups, int dtype, voi
   return launch_nt(descs, ngroups, dtype, (hipStream_t)stream);
 }
 
-extern "C" int drn_gemm_nt_splitk(const DrnGemmDesc* desc, int ksplit, float* ws, int dtype, void* stream) {
+extern "C" int64_t drn_gemm_nt_splitk_ws_elems(int M, int N, int ksplit) {
+  return (int64_t)ksplit * cdiv(M, 128) * cdiv(N, 128) * 128 * 128;
+}
+
+extern "C" int drn_gemm_nt_splitk(const DrnGemmDesc* desc, int ksplit, float* ws, int32_t* counters, int dtype, void* stream) {
   drn_clear_status();
-  DRN_CHECK_ARG(desc && ksplit >= 1 && ksplit <= 64 && (ksplit == 1 || ws), "drn_gemm_nt_splitk: bad ksplit/workspace");
-  return launch_nt(desc, 1, dtype, (hipStream_t)stream, ksplit, ws);
+  DRN_CHECK_ARG(desc && ksplit >= 1 && ksplit <= 64 && (ksplit == 1 || (ws && counters)), "drn_gemm_nt_splitk: bad ksplit/workspace/counters");
+  DRN_CHECK_ARG(ksplit == 1 || (cdiv(desc->M, 128) * cdiv(desc->N, 128) <= DRN_QD_COUNTERS && (((uintptr_t)ws) & 15) == 0),
+                "drn_gemm_nt_splitk: more than %d output tiles or unaligned workspace", DRN_QD_COUNTERS);
+  return launch_nt(desc, 1, dtype, (hipStream_t)stream, ksplit, ws, (int*)counters);
 }

@@ -871,7 +871,8 @@ class _InputStageFn(torch.autograd.Function):
             if dZT is not None:
                 ops.gemm_nt([ops.gemm_desc(dZT, xcT, jW, D, D, B * T, out_f32=True)], code)
             elif xcT.numel():
-                ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ.view(B * T, D), code), xcT, jW, D, D, B * T, out_f32=True)], code)
+                dZt = ops.transpose2d(dZ.view(B * T, D), code)      # (a descriptor holds raw pointers: keep the operand alive)
+                ops.gemm_nt([ops.gemm_desc(dZt, xcT, jW, D, D, B * T, out_f32=True)], code)
             else:
                 ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], jW, D, D, taps=1, w_layout=0, dtype=code)
             ops.colsum(dsum, D, B, D, jb, ops.F32)

@@ -150,9 +150,12 @@ class DualStreamStep(object):
     PHASES = ("q_fwd", "prep", "trunk", "q_bwd", "wgrads", "opt", "repack")
     SIDE = ("q_fwd", "q_bwd")
 
-    def __init__(self, model, batch, loss_of, reducer, opt, wgrads_first=True):
+    def __init__(self, model, batch, loss_of, reducer, opt, wgrads_first=True, side_priority=-1, main_first=False):
         self.model, self.batch, self.loss_of, self.reducer, self.opt = model, batch, loss_of, reducer, opt
-        self.main, self.side = torch.cuda.Stream(), torch.cuda.Stream()
+        self.main_first = main_first
+        # the side stream's launches are few workgroups each and latency-bound: at high priority they get CU slots ahead of the
+        # main stream's thousands of queued workgroups instead of waiting for a whole wave of them to drain
+        self.main, self.side = torch.cuda.Stream(), torch.cuda.Stream(priority=side_priority)
         self.wgrads_first = wgrads_first       # small weight gradients before the prop_fc one (it owns every CU while it runs)
         self.graphs = None
         self.out = None
@@ -206,6 +209,27 @@ class DualStreamStep(object):
             self._fresh = False
         else:
             Q.wait_event(ev["opt"])           # the previous step's parameters
+        if self.main_first:
+            with torch.cuda.stream(M):
+                run("prep")
+            with torch.cuda.stream(Q):
+                run("q_fwd")
+                ev["q_fwd"].record(Q)
+            with torch.cuda.stream(M):
+                M.wait_event(ev["q_fwd"])
+                run("trunk")
+                ev["trunk"].record(M)
+                run("wgrads")
+            with torch.cuda.stream(Q):
+                Q.wait_event(ev["trunk"])
+                run("q_bwd")
+                ev["q_bwd"].record(Q)
+            with torch.cuda.stream(M):
+                M.wait_event(ev["q_bwd"])
+                run("opt")
+                ev["opt"].record(M)
+                run("repack")
+            return
         with torch.cuda.stream(Q):
             run("q_fwd")
             ev["q_fwd"].record(Q)

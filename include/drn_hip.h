@@ -66,9 +66,12 @@ typedef struct DrnGemmDesc {
  * Replaces nn.Linear (model/main_model.py:59), nn.Conv1d (model/basic_blocks.py:9,
  * model/fcos.py:33,37,59,65) forward and their input gradients. */
 int drn_gemm_nt(const DrnGemmDesc* descs /*host*/, int ngroups, int dtype, void* stream);
-/* Same for ONE problem with the K loop split `ksplit` ways (few output tiles, long K: conv0, the coarse pyramid levels):
- * partial tiles go to ws (fp32, ksplit*M*N elements) and a deterministic reduce pass applies the epilogue. */
-int drn_gemm_nt_splitk(const DrnGemmDesc* desc /*host*/, int ksplit, float* ws, int dtype, void* stream);
+/* Same for ONE problem with the K loop split `ksplit` ways (few output tiles: conv0, the coarse pyramid levels), in ONE
+ * launch: every split publishes its fp32 partial tile in ws (drn_gemm_nt_splitk_ws_elems floats, 16-byte aligned), the
+ * split that arrives last at a tile adds them in split order (deterministic) and runs the epilogue.  counters: >= one int32
+ * per 128x128 output tile (<= DRN_QD_COUNTERS), zero on entry, left zero (the buffer drn_skinny_group uses will do). */
+int64_t drn_gemm_nt_splitk_ws_elems(int M, int N, int ksplit);
+int drn_gemm_nt_splitk(const DrnGemmDesc* desc /*host*/, int ksplit, float* ws, int32_t* counters, int dtype, void* stream);
 
 /* Weight gradient:  dW[n][tap][c] (fp32) = sum_m dY[m][n] * X[src(m,tap)][c]   (mode-0 addressing of X).
  * dW is written as [N][taps][Cin] when w_layout==0 or [N][Cin][taps] (the nn.Conv1d parameter layout) when 1.

@@ -234,7 +234,8 @@ def test_wgrad_grouped_levels(dt):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("ksplit", [2, 5])
 def test_conv_fwd_splitk_with_stats_bias_gate(dt, ksplit):
-    """drn_gemm_nt_splitk: K loop split over workgroups, deterministic reduce pass runs the epilogue."""
+    """drn_gemm_nt_splitk: K loop split over workgroups, the last-arriving split of a tile sums the partial tiles in split
+    order (deterministic) and runs the epilogue -- one launch."""
     import ctypes
     from drn_amd import ops, _lib
     B, L, Cin, Cout, k = 3, 40, 192, 136, 3
@@ -250,17 +251,53 @@ def test_conv_fwd_splitk_with_stats_bias_gate(dt, ksplit):
     bias_d, gate_d = bias.to(dev()), gate.to(dev())       # descriptors hold raw pointers: keep the tensors alive
     d = ops.gemm_desc(xd, wp, C, M, Cout, Cin, taps=k, pad=1, Lout=L, Lsrc=L, stats=stats, bias=bias_d,
                       gate=gate_d, ldg=Cout, C2=C2)
-    ws = torch.empty(ksplit * M * Cout, dtype=torch.float32, device=dev())
+    L_ = _lib.lib()
+    L_.drn_gemm_nt_splitk_ws_elems.restype = ctypes.c_int64
+    ws = torch.empty(int(L_.drn_gemm_nt_splitk_ws_elems(M, Cout, ksplit)), dtype=torch.float32, device=dev())
+    counters = torch.zeros(16, dtype=torch.int32, device=dev())
     arr = (_lib.GemmDesc * 1)(d)
-    _lib.check(_lib.lib().drn_gemm_nt_splitk(arr, ksplit, ctypes.c_void_p(ws.data_ptr()), ops.dtype_code(xd),
-                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "splitk")
+    for _ in range(2):                    # twice: the counters must come back re-armed
+        _lib.check(L_.drn_gemm_nt_splitk(arr, ksplit, ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(counters.data_ptr()),
+                                         ops.dtype_code(xd), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "splitk")
     torch.cuda.synchronize()
+    assert int(counters.abs().sum()) == 0
     pre = ref + bias.double()
     close(C2, pre, TOL[dt] * 2, "pre-gate")
     close(C, pre * gate.double().repeat_interleave(L, 0), TOL[dt] * 2, "gated")
     tot, m2 = merged_stats(stats, M)
     close(tot, ref.sum(0), TOL[dt] * 4, "col sum (raw conv)")
     close(m2, ((ref - ref.mean(0)) ** 2).sum(0), TOL[dt] * 4, "col M2")
+
+
+@pytest.mark.parametrize("M,N,K,ksplit", [(8192, 256, 6528, 4), (8192, 256, 13056, 3), (64, 512, 3072, 8)])
+def test_splitk_exchange_under_load(M, N, K, ksplit):
+    """The one-launch split-K exchange with every CU holding two workgroups (512 of them), workspace poisoned before each of
+    many launches: every launch must reproduce the first bit for bit and match an fp32 product.  (A first version issued the
+    partial-tile stores as separate inline-asm statements; the compiler reused a store's data registers two instructions
+    later and the > 64-bit-store hazard corrupted a few tiles per launch -- only at this residency.)"""
+    import ctypes
+    from drn_amd import ops, _lib
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g).to(dev()).to(torch.bfloat16)
+    B = torch.randn(N, K, generator=g).to(dev()).to(torch.bfloat16)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    arr = (_lib.GemmDesc * 1)(ops.gemm_desc(A, B, C, M, N, K))
+    L_ = _lib.lib()
+    ws = torch.empty(int(L_.drn_gemm_nt_splitk_ws_elems(M, N, ksplit)), dtype=torch.float32, device=dev())
+    counters = torch.zeros(2048, dtype=torch.int32, device=dev())
+    want = A.float() @ B.float().t()
+    first = None
+    for it in range(25):
+        ws.fill_(float("nan"))
+        _lib.check(L_.drn_gemm_nt_splitk(arr, ksplit, ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(counters.data_ptr()), ops.BF16,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "splitk")
+        out = C.float()
+        if first is None:
+            first = out.clone()
+            assert float((out - want).abs().max()) <= 1e-2 * float(want.abs().max())
+        else:
+            assert torch.equal(out, first), ("launch", it, float((out - first).abs().max()))
+    assert int(counters.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -292,7 +329,8 @@ def test_prop_fc_weight_gradient_nt_path_matches_tn_kernel():
     a = torch.empty(D, D, device=dev())
     b = torch.empty(D, D, device=dev())
     ops.gemm_wgrad([ops.wgrad_desc(dZ, X, R)], a.view(D, D, 1), D, D, taps=1, w_layout=0, dtype=ops.BF16)
-    ops.gemm_nt([ops.gemm_desc(ops.transpose2d(dZ, ops.BF16), ops.transpose2d(X, ops.BF16), b, D, D, R, out_f32=True)], ops.BF16)
+    dZT, XT = ops.transpose2d(dZ, ops.BF16), ops.transpose2d(X, ops.BF16)      # descriptors hold raw pointers: keep them alive
+    ops.gemm_nt([ops.gemm_desc(dZT, XT, b, D, D, R, out_f32=True)], ops.BF16)
     want = dZ.double().t() @ X.double()
     assert float((a.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
     assert float((b.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
