@@ -106,8 +106,10 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="per-kernel MFMA timing table on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from Python instead of replaying a hipGraph")
-    ap.add_argument("--single-stream", action="store_true",
-                    help="N=1: replay the step as ONE linear hipGraph instead of the two-stream schedule (drn_amd.graph.DualStreamStep)")
+    ap.add_argument("--dual-stream", action="store_true",
+                    help="N=1: replay the step as seven linear hipGraphs on two streams (drn_amd.graph.DualStreamStep: query side beside "
+                         "input prep / deferred weight gradients) instead of ONE linear hipGraph; measured 0.5 %% SLOWER on ROCm 7.2 "
+                         "(DESIGN.md section 5), kept as an experiment")
     ap.add_argument("--torch-adam", action="store_true", help="torch clip_grad_norm_ + optim.Adam instead of the fused HIP step")
     args = ap.parse_args()
 
@@ -188,7 +190,7 @@ def main():
         # all warm-up steps run on the capture stream (see drn_amd/graph.py), then the step is captured once
         from drn_amd.graph import GraphedStep
         try:
-            if world == 1 and not args.single_stream and not args.torch_adam:
+            if world == 1 and args.dual_stream and not args.torch_adam:
                 # seven linear hipGraphs on two streams: the query side (small latency-bound launches) runs beside the
                 # input preparation forward and beside the deferred weight gradients backward
                 from drn_amd.graph import DualStreamStep

@@ -617,6 +617,69 @@ def conv_block(xs, conv, bn, training, dtype, gate=None, up=None, relu=True):
     return list(res), None
 
 
+class _PlainConvFn(torch.autograd.Function):
+    """Conv1d(k, stride, pad=(k-1)//2) [+ bias] [-> ReLU] without BatchNorm: the factory variants of model/basic_blocks.py:5-33
+    that DRN itself never instantiates (use_bn=False) and the FPN top blocks (model/FPN.py:86-103).  Same implicit-GEMM
+    kernels; the bias rides in the GEMM epilogue, the ReLU in one elementwise pass (identity scale/shift through the BN-apply
+    kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, relu, dtype):
+        code = code_of(dtype)
+        Cout, Cin, k = weight.shape
+        pad = (k - 1) // 2
+        B, L, C, ld = geom(x)
+        assert C == Cin and x.dtype == dtype
+        Lo = (L + 2 * pad - k) // stride + 1
+        M = B * Lo
+        dev = x.device
+        raw = torch.empty((B, Lo, Cout), dtype=dtype, device=dev)
+        ops.gemm_nt([ops.gemm_desc(x, packed(weight, (0, 2, 1), code), raw, M, Cout, Cin, taps=k, stride=stride, pad=pad, Lout=Lo,
+                                   Lsrc=L, lda=ld, bias=bias.detach() if bias is not None else None)], code)
+        out = raw
+        if relu:
+            ss = torch.cat([torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)]).view(2, Cout)
+            out = torch.empty_like(raw)
+            ops.bn_apply(raw, Cout, ss, out, Cout, M, Cout, Lo, code, relu=True)
+        ctx.meta = (stride, relu, dtype, (B, L, Lo, M, ld), k)
+        ctx.has_bias = bias is not None
+        ctx.weight_obj, ctx.bias_obj = weight, bias
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        stride, relu, dtype, (B, L, Lo, M, ld), k = ctx.meta
+        code = code_of(dtype)
+        x, weight, out = ctx.saved_tensors
+        Cout, Cin, _ = weight.shape
+        pad = (k - 1) // 2
+        dev = x.device
+        d = _grad_nlc(dout, None, dtype)
+        if relu:
+            d = d * (out > 0)                                   # (off the DRN hot path: one framework elementwise op)
+        db = None
+        if ctx.has_bias:
+            db = grad_buffer(ctx.bias_obj)
+            ops.colsum(d.view(M, Cout), Cout, M, Cout, db, code)
+        dW = grad_buffer(ctx.weight_obj)
+        ops.gemm_wgrad([ops.wgrad_desc(d, x, M, Lout=Lo, Lsrc=L, ldy=Cout, ldx=ld)], dW, Cout, Cin, taps=k, stride=stride, pad=pad,
+                       w_layout=1, dtype=code)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, L, Cin), dtype=dtype, device=dev)
+            ops.gemm_nt([ops.gemm_desc(d, packed(ctx.weight_obj, (1, 2, 0), code), dx, B * L, Cin, Cout, taps=k, stride=stride,
+                                       pad=pad, mode=1, Lout=L, Lsrc=Lo)], code)
+        return dx, dW, db, None, None, None
+
+
+def plain_conv(x, conv, dtype, relu=False):
+    """conv: nn.Conv1d parameter holder (dilation 1, padding (k-1)//2); x channels-last (B, L, Cin)."""
+    if conv.dilation[0] != 1 or conv.padding[0] != (conv.kernel_size[0] - 1) // 2:
+        raise DrnError("plain_conv: dilation 1 and 'same' padding only")
+    return _PlainConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], relu, dtype)
+
+
 class _MultiConvFn(torch.autograd.Function):
     """n INDEPENDENT conv->BN->ReLU blocks (different weights, one input each) launched together: the implicit GEMMs of
     all blocks go through ONE grouped launch forward and ONE for the data gradients, so the coarse pyramid levels (64-128

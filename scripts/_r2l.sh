@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do timeout 1500 python -m pytest tests -q -m gpu --tb=line -rf 2>&1 | grep -E "passed|failed|^FAILED|Error" | cut -c1-300; done
+timeout 900 python -m pytest tests/test_functional_gpu.py -x -q -k "variants or top_blocks" 2>&1 | tail -15 | cut -c1-250

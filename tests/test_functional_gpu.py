@@ -195,3 +195,60 @@ def test_head_out_fwd_bwd(dt):
     close(ch.bias.grad, cls.bias.grad, tol * 3, "db cls")
     close(bh.bias.grad, box.bias.grad, tol * 3, "db box")
     close(sh.grad, scales.grad, tol * 3, "dscale")
+
+
+@pytest.mark.parametrize("use_bn,use_relu", [(True, False), (False, True), (False, False)])
+def test_conv_factory_variants_match_torch(use_bn, use_relu):
+    """The factory combinations DRN never instantiates (model/basic_blocks.py:5-33: no BatchNorm -> biased conv, no ReLU) against
+    the same nn.Sequential in fp64: outputs, input / weight / bias gradients, state_dict keys."""
+    from drn_amd.model.basic_blocks import conv_with_kaiming_uniform
+    torch.manual_seed(3)
+    B, L, Cin, Cout, k, stride = 3, 40, 64, 72, 3, 2
+    blk = conv_with_kaiming_uniform(use_bn, use_relu)(Cin, Cout, k, stride).to(DEV).train()
+    mods = [torch.nn.Conv1d(Cin, Cout, k, stride=stride, padding=1, bias=not use_bn)]
+    if use_bn:
+        mods.append(torch.nn.BatchNorm1d(Cout))
+    if use_relu:
+        mods.append(torch.nn.ReLU())
+    ref = (torch.nn.Sequential(*mods) if len(mods) > 1 else mods[0]).double().train()
+    assert list(ref.state_dict().keys()) == list(blk.state_dict().keys())
+    ref.load_state_dict({k_: v.double().cpu() for k_, v in blk.state_dict().items()})
+    x = torch.randn(B, Cin, L)
+    xd = x.to(DEV).requires_grad_()
+    xr = x.double().requires_grad_()
+    y, yr = blk(xd), ref(xr)
+    g = torch.randn(yr.shape)
+    y.backward(g.to(DEV))
+    yr.backward(g.double())
+    scale = float(yr.abs().max())
+    assert float((y.cpu().double() - yr).abs().max()) <= 3e-5 * scale
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) <= 3e-5 * float(xr.grad.abs().max())
+    for (n1, p1), (n2, p2) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert n1 == n2 and float((p1.grad.cpu().double() - p2.grad).abs().max()) <= 5e-5 * max(float(p2.grad.abs().max()), 1e-3), n1
+
+
+@pytest.mark.parametrize("top", ["maxpool", "p6p7", "p6p7_c5"])
+def test_fpn_top_blocks(top):
+    """model/FPN.py:72-103: the extra pyramid levels of the optional top blocks (unused by DRN's own config)."""
+    from drn_amd.model.FPN import FPN, LastLevelMaxPool, LastLevelP6P7
+    from drn_amd.model.basic_blocks import conv_with_kaiming_uniform
+    torch.manual_seed(4)
+    B, C = 2, 64
+    chans, Ls = [32, 48, 96], [32, 16, 8]
+    tb = LastLevelMaxPool() if top == "maxpool" else LastLevelP6P7(C if top == "p6p7" else chans[-1], C)
+    fpn = FPN(chans, C, conv_with_kaiming_uniform(True, True), top_blocks=tb).to(DEV).train()
+    xs = [torch.randn(B, c, L) for c, L in zip(chans, Ls)]
+    outs = fpn([x.to(DEV) for x in xs])
+    assert len(outs) == (4 if top == "maxpool" else 5)
+    p3 = outs[2].detach().cpu().double()
+    if top == "maxpool":
+        want = torch.nn.functional.max_pool2d(p3, 1, 2, 0)
+        assert outs[3].shape == want.shape and float((outs[3].cpu().double() - want).abs().max()) == 0.0
+    else:
+        src = p3 if top == "p6p7" else xs[-1].double()
+        p6 = torch.nn.functional.conv1d(src, tb.p6.weight.detach().cpu().double(), tb.p6.bias.detach().cpu().double(), 2, 1)
+        p7 = torch.nn.functional.conv1d(torch.relu(p6), tb.p7.weight.detach().cpu().double(), tb.p7.bias.detach().cpu().double(), 2, 1)
+        for got, want in ((outs[3], p6), (outs[4], p7)):
+            assert got.shape == want.shape and float((got.cpu().double() - want).abs().max()) <= 5e-5 * float(want.abs().max())
+        sum(o.float().sum() for o in outs).backward()
+        assert tb.p6.weight.grad is not None and tb.p7.bias.grad is not None
