@@ -93,6 +93,11 @@ class HeadCall(ctypes.Structure):
                 ("z", c_void_p), ("dout", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("dscale", c_void_p), ("ws", c_void_p)]
 
 
+class AdamTiledItem(ctypes.Structure):
+    _fields_ = [("p", c_void_p), ("off", c_int64), ("m1", c_void_p), ("m2", c_void_p), ("ld1", c_int64), ("ld2", c_int64),
+                ("R", c_int32), ("C", c_int32), ("k", c_int32), ("code1", c_int32), ("code2", c_int32), ("tiles_c", c_int32)]
+
+
 class CounterBump(ctypes.Structure):
     _fields_ = [("counter", c_void_p), ("inc", c_int32)]
 

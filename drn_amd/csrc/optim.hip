@@ -188,3 +188,148 @@ extern "C" int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, co
   adam_bucket_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_adam_bucket");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Adam over tensors with re-laid GEMM copies: 64-row x 64-channel tiles (see include/drn_hip.h, drn_adam_tiled).
+// ---------------------------------------------------------------------------------------------------------------------
+#define TILED_MAXK 3
+template <typename T>
+__device__ __forceinline__ void tiled_store_piece(T* dst, const float* v);
+template <>
+__device__ __forceinline__ void tiled_store_piece<float>(float* dst, const float* v) {
+  *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+}
+template <>
+__device__ __forceinline__ void tiled_store_piece<bf16_t>(bf16_t* dst, const float* v) {
+  bf16x8 b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = (bf16_t)v[e];
+  *(bf16x8*)dst = b;
+}
+
+// copy 1: [r][tap][c] -- pieces of VEC consecutive channels; copy 2: [c][tap][r] -- pieces of VEC consecutive rows
+template <typename T>
+__device__ __forceinline__ void tiled_flush(const float (*tile)[64 * TILED_MAXK + 1], const DrnAdamTiledItem& it, int which, int r0, int c0,
+                                            int nr, int nc) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int k = it.k;
+  if (which == 1) {
+    T* out = (T*)it.m1;
+    const bool vec = (nc % VEC == 0) && (it.ld1 % VEC == 0) && ((((uintptr_t)out) & 15) == 0);
+    const int pcs = (nc + VEC - 1) / VEC;
+    for (int q = threadIdx.x; q < nr * k * pcs; q += OPT_THREADS) {
+      const int cv = q % pcs, rt = q / pcs, tap = rt % k, r = rt / k;
+      float vals[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vals[e] = cv * VEC + e < nc ? tile[r][(cv * VEC + e) * k + tap] : 0.f;
+      T* dst = out + ((long)(r0 + r) * k + tap) * it.ld1 + c0 + cv * VEC;
+      if (vec) tiled_store_piece<T>(dst, vals);
+      else
+        for (int e = 0; e < VEC && cv * VEC + e < nc; ++e) DT<T>::st(dst + e, vals[e]);
+    }
+  } else {
+    T* out = (T*)it.m2;
+    const bool vec = (nr % VEC == 0) && (it.ld2 % VEC == 0) && ((((uintptr_t)out) & 15) == 0);
+    const int pcs = (nr + VEC - 1) / VEC;
+    for (int q = threadIdx.x; q < nc * k * pcs; q += OPT_THREADS) {
+      const int rv = q % pcs, ct = q / pcs, tap = ct % k, c = ct / k;
+      float vals[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vals[e] = rv * VEC + e < nr ? tile[rv * VEC + e][c * k + tap] : 0.f;
+      T* dst = out + ((long)(c0 + c) * k + tap) * it.ld2 + r0 + rv * VEC;
+      if (vec) tiled_store_piece<T>(dst, vals);
+      else
+        for (int e = 0; e < VEC && rv * VEC + e < nr; ++e) DT<T>::st(dst + e, vals[e]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __restrict__ G, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                                const DrnAdamTiledItem* __restrict__ items, const int* __restrict__ blk_item,
+                                                                const int* __restrict__ blk_tile, const float* __restrict__ total_sumsq,
+                                                                const int* __restrict__ step_counter, float lr, float beta1, float beta2,
+                                                                float eps, float max_norm) {
+  __shared__ float tile[64][64 * TILED_MAXK + 1];
+  const DrnAdamTiledItem it = items[blk_item[blockIdx.x]];
+  const int t = blk_tile[blockIdx.x];
+  const int tcw = (64 * TILED_MAXK) / it.k;                    // channels per tile: 192 elements of a tensor row whatever k is
+  const int r0 = (t / it.tiles_c) * 64, c0 = (t % it.tiles_c) * tcw;
+  const int nr = min(64, it.R - r0), nc = min(tcw, it.C - c0);
+  const int k = it.k, S = it.C * k, ts = nc * k;            // row length of the tensor, of the tile
+  const float total_norm = sqrtf(total_sumsq[0]);
+  float clip = max_norm > 0.f ? max_norm / (total_norm + 1e-6f) : 1.f;
+  clip = fminf(clip, 1.f);
+  const int tstep = *step_counter;
+  const float bc1 = 1.f - powf(beta1, (float)tstep), bc2 = 1.f - powf(beta2, (float)tstep);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const long tbase = (long)r0 * S + (long)c0 * k;             // first element of the tile inside the tensor
+  const bool vec4 = (ts % 4 == 0) && (S % 4 == 0) && ((((uintptr_t)it.p) & 15) == 0) && (it.off % 4 == 0);
+  if (vec4) {
+    const int qpr = ts / 4, nq = nr * qpr;                    // float4 pieces per tile row, in the tile
+    for (int q0 = threadIdx.x; q0 < nq; q0 += 4 * OPT_THREADS) {
+      f32x4 g4[4], m4[4], v4[4], p4[4];
+      long e0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                           // 16 loads in flight per trip
+        const int q = q0 + u * OPT_THREADS;
+        const int r = q / qpr, c4 = (q - r * qpr) * 4;
+        e0[u] = q < nq ? tbase + (long)r * S + c4 : -1;
+        if (e0[u] >= 0) {
+          g4[u] = *(const f32x4*)(G + it.off + e0[u]);
+          m4[u] = *(const f32x4*)(Mo + it.off + e0[u]);
+          v4[u] = *(const f32x4*)(Vo + it.off + e0[u]);
+          p4[u] = *(const f32x4*)(it.p + e0[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (e0[u] < 0) continue;
+        const int q = q0 + u * OPT_THREADS;
+        const int r = q / qpr, c4 = (q - r * qpr) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = g4[u][e] * clip;
+          m4[u][e] = beta1 * m4[u][e] + (1.f - beta1) * g;
+          v4[u][e] = beta2 * v4[u][e] + (1.f - beta2) * g * g;
+          p4[u][e] -= step_size * m4[u][e] / (sqrtf(v4[u][e]) * inv_sqrt_bc2 + eps);
+          tile[r][c4 + e] = p4[u][e];
+        }
+        *(f32x4*)(Mo + it.off + e0[u]) = m4[u];
+        *(f32x4*)(Vo + it.off + e0[u]) = v4[u];
+        *(f32x4*)(it.p + e0[u]) = p4[u];
+      }
+    }
+  } else {
+    for (int q = threadIdx.x; q < nr * ts; q += OPT_THREADS) {
+      const int r = q / ts, c = q - r * ts;
+      const long e0 = tbase + (long)r * S + c;
+      const float g = G[it.off + e0] * clip;
+      const float mm = beta1 * Mo[it.off + e0] + (1.f - beta1) * g;
+      const float vv = beta2 * Vo[it.off + e0] + (1.f - beta2) * g * g;
+      Mo[it.off + e0] = mm;
+      Vo[it.off + e0] = vv;
+      const float pp = it.p[e0] - step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+      it.p[e0] = pp;
+      tile[r][c] = pp;
+    }
+  }
+  __syncthreads();
+  if (it.m1) {
+    if (it.code1 == DRN_BF16) tiled_flush<bf16_t>(tile, it, 1, r0, c0, nr, nc); else tiled_flush<float>(tile, it, 1, r0, c0, nr, nc);
+  }
+  if (it.m2) {
+    if (it.code2 == DRN_BF16) tiled_flush<bf16_t>(tile, it, 2, r0, c0, nr, nc); else tiled_flush<float>(tile, it, 2, r0, c0, nr, nc);
+  }
+}
+
+extern "C" int drn_adam_tiled(const float* g, float* m, float* v, const DrnAdamTiledItem* items_dev, const int32_t* blk_item_dev,
+                              const int32_t* blk_tile_dev, int nblocks, const float* total_sumsq, const int* step_counter, float lr,
+                              float beta1, float beta2, float eps, float max_norm, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(g && m && v && items_dev && blk_item_dev && blk_tile_dev && nblocks > 0 && total_sumsq && step_counter,
+                "drn_adam_tiled: bad args");
+  adam_tiled_kernel<<<nblocks, OPT_THREADS, 0, (hipStream_t)stream>>>(g, m, v, items_dev, blk_item_dev, blk_tile_dev, total_sumsq,
+                                                                       step_counter, lr, beta1, beta2, eps, max_norm);
+  return drn_launch_status("drn_adam_tiled");
+}

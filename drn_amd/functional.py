@@ -126,6 +126,23 @@ def stacked(params):
     return out
 
 
+_shape_stack_cache = {}
+
+
+def _shape_only_stack(params):
+    """A buffer with the shape of cat(params, dim 0) whose CONTENTS are never read: the stacked conv weight of the two towers
+    only carries its shape and its sources through autograd (the kernels read the re-laid copies `packed` builds from the
+    sources), so it is neither filled nor refreshed after optimizer steps."""
+    key = tuple((id(p), p.data_ptr()) for p in params)
+    hit = _shape_stack_cache.get(key)
+    if hit is not None and all(r() is p for r, p in zip(hit[1], params)) and hit[0].device == params[0].device:
+        return hit[0]
+    out = torch.empty((sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:]), dtype=torch.float32, device=params[0].device)
+    _purge_dead(_shape_stack_cache, 64, lambda e: e[1])
+    _shape_stack_cache[key] = (out, [weakref.ref(p) for p in params])
+    return out
+
+
 class _StackFn(torch.autograd.Function):
     """cat(params, dim 0) without a copy per step: forward hands out a view of the cached stack (`stacked`), backward
     splits the gradient into views.  The view remembers its sources so `packed` can build the GEMM operand from them."""
@@ -134,7 +151,7 @@ class _StackFn(torch.autograd.Function):
     def forward(ctx, *params):
         ctx.sizes = [p.shape[0] for p in params]
         ctx.set_materialize_grads(False)             # an absent gradient stays absent for every source
-        buf = stacked(list(params))
+        buf = _shape_only_stack(list(params)) if params[0].dim() == 3 else stacked(list(params))
         out = buf.view(buf.shape)
         out._drn_stack_of = list(params)
         return out
@@ -193,13 +210,67 @@ def identity_bf16_copies():
     return out
 
 
-def repack_all(skip=(), codes=None):
+def relaid_copies():
+    """Every cached re-laid copy of a live parameter, as the fused optimizer needs it to write the copy itself while it holds
+    the updated value (drn_adam_tiled): {parameter data_ptr: [dict(kind 1|2, base tensor, ld, code, k, skip key)]}.
+    kind 1 = [r][tap][c] order (element (r, c, tap) at base[(r*k + tap)*ld + c]): forward conv / Linear operands, fp32 stacks;
+    kind 2 = [c][tap][r] order: data-gradient operands, transposed Linear weights.  A copy made of several parameters (stacked
+    operands) is listed under each of them with the same skip key."""
+    out = {}
+
+    def add(p, kind, base, ld, code, key):
+        out.setdefault(p.data_ptr(), []).append(dict(param=p, kind=kind, base=base, ld=ld, code=code, key=key,
+                                                     k=p.shape[2] if p.dim() == 3 else 1))
+
+    for key, (ver, buf, ref) in _pack_cache.items():
+        w = ref()
+        if w is None or w.data_ptr() != key[1] or buf.device != w.device or w.dim() not in (2, 3):
+            continue
+        Cout, Cin = w.shape[0], w.shape[1]
+        if key[2] == (0, 2, 1):
+            add(w, 1, buf, Cin, key[3], ("pack", key))
+        elif key[2] == (1, 2, 0):
+            add(w, 2, buf, Cout, key[3], ("pack", key))
+    for key, (ver, buf, refs) in _pstack_cache.items():
+        ps = [r() for r in refs]
+        if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key[0]:
+            continue
+        o, total = 0, sum(p.shape[0] for p in ps)
+        for p in ps:
+            n, Cin = p.shape[0], p.shape[1]
+            if key[1] == (0, 2, 1):
+                add(p, 1, buf[o:o + n], Cin, key[2], ("pstack", key))
+            elif key[1] == (1, 2, 0):
+                add(p, 2, buf[:, :, o:o + n], total, key[2], ("pstack", key))
+            o += n
+    for key, (ver, buf, refs) in _stack_cache.items():
+        ps = [r() for r in refs]
+        transposed = key[0] == "t"
+        if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != (key[1:] if transposed else key):
+            continue
+        if transposed:
+            c, total = 0, sum(p.shape[0] for p in ps)
+            for p in ps:                                     # p (N, K) -> buf[:, c:c+N] = p^T
+                add(p, 2, buf[:, c:c + p.shape[0]], total, ops.F32, ("stack", key))
+                c += p.shape[0]
+        elif all(p.dim() in (1, 2) for p in ps):
+            r = 0
+            for p in ps:                                     # rows [r, r+n) of the stack = p itself
+                add(p, 1, buf[r:r + p.shape[0]], p.shape[1] if p.dim() == 2 else p.shape[0], ops.F32, ("stack", key))
+                r += p.shape[0]
+    return out
+
+
+def repack_all(skip=(), codes=None, updated=None):
     """Refresh every cached re-laid weight IN PLACE with one launch per dtype (drn_pack_weights) and mark it current:
     an optimizer that has just updated all parameters calls this instead of leaving ~20 small per-use launches to
     the next forward pass.  The copies keep their addresses, so captured hipGraphs stay valid.  `skip`: cache keys the
     caller has already refreshed itself (identity_bf16_copies).  `codes`: only the copies of these dtypes (ops.F32 holds
-    the query side's stacks, ops.BF16 the conv / linear operands of a bf16 model) -- the rest stay stale until their call."""
+    the query side's stacks, ops.BF16 the conv / linear operands of a bf16 model) -- the rest stay stale until their call.
+    `updated`: data_ptrs of the parameters the caller has changed; copies of all other parameters (frozen ones: mix_fc and
+    iou_scores in stage 1) are still valid and only marked current."""
     want = lambda code: codes is None or code in codes
+    same = lambda ps: updated is not None and not any(p.data_ptr() in updated for p in ps)
     by_code = {}
     for key, (ver, out, ref) in list(_pack_cache.items()):
         w = ref()
@@ -208,7 +279,7 @@ def repack_all(skip=(), codes=None):
             continue
         if not want(key[3]):
             continue
-        if key in skip:
+        if key in skip or ("pack", key) in skip or same([w]):
             _pack_cache[key] = ((w._version, _weights_epoch), out, ref)
             continue
         by_code.setdefault(key[3], []).append((key, w, out))
@@ -219,8 +290,9 @@ def repack_all(skip=(), codes=None):
             continue
         if not want(key[2]):
             continue
-        by_code.setdefault(key[2], [])
-        by_code.setdefault(("stack", key[2]), []).extend(_pstack_items(out, ps, key[1]))
+        if ("pstack", key) not in skip and not same(ps):
+            by_code.setdefault(key[2], [])
+            by_code.setdefault(("stack", key[2]), []).extend(_pstack_items(out, ps, key[1]))
         _pstack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
     stack_items = []
     for key, (ver, out, refs) in list(_stack_cache.items()):
@@ -232,7 +304,8 @@ def repack_all(skip=(), codes=None):
             continue
         if not want(ops.F32):
             continue
-        stack_items += _stack_t_items(out, ps) if transposed else _stack_items(out, ps)
+        if ("stack", key) not in skip and not same(ps):
+            stack_items += _stack_t_items(out, ps) if transposed else _stack_items(out, ps)
         _stack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
     for code, items in by_code.items():
         if isinstance(code, tuple):

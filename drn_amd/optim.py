@@ -10,8 +10,9 @@ from ._lib import check, lib
 
 
 class FusedAdam(object):
-    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5):
-        self.reducer, self.lr, self.betas, self.eps, self.max_norm = reducer, lr, betas, eps, max_norm
+    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5, tiled=True):
+        """tiled=False keeps every parameter on the linear kernel and leaves the re-laid weight copies to repack_all()."""
+        self.reducer, self.lr, self.betas, self.eps, self.max_norm, self.tiled = reducer, lr, betas, eps, max_norm, tiled
         L = lib()
         L.drn_opt_nblocks.restype = ctypes.c_int64
         dev = reducer.buckets[0].flat.device
@@ -36,7 +37,8 @@ class FusedAdam(object):
             blk_seg = (np.searchsorted(starts, np.arange(nb, dtype=np.int64) * 4096, side="right") - 1).astype(np.int32)
             self.state.append({"m": torch.zeros_like(b.flat), "v": torch.zeros_like(b.flat),
                                "seg": torch.tensor(offs, dtype=torch.int64, device=dev),
-                               "ptr": torch.tensor(ptrs, dtype=torch.int64, device=dev),
+                               "ptr": torch.tensor(ptrs, dtype=torch.int64, device=dev), "ptr_host": list(ptrs),
+                               "ptr_index": dict((q, i) for i, q in enumerate(ptrs) if q),
                                "nseg": len(ptrs), "part_off": nparts, "nb": nb,
                                "blk_seg": torch.from_numpy(blk_seg).to(dev)})
             nparts += nb
@@ -46,6 +48,7 @@ class FusedAdam(object):
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
 
         self._ptr_sig = tuple(p.data_ptr() for b in reducer.buckets for p in b.params)
+        self._updated = frozenset(self._ptr_sig)
 
     def _check_ptrs(self):
         """The kernels reach the parameters through raw pointers baked into device tables: refuse to step if a parameter's
@@ -71,33 +74,93 @@ class FusedAdam(object):
                                     st["nseg"], P(st["blk_seg"]), P(st.get("mirror")), P(self.total_sumsq), P(self.step_counter),
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                                     ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
+        for b, st in zip(self.reducer.buckets, self.state):
+            if st.get("tiled") is not None:
+                raw, bi, bt, nb = st["tiled"]
+                check(L.drn_adam_tiled(P(b.flat), P(st["m"]), P(st["v"]), P(raw), P(bi), P(bt), nb, P(self.total_sumsq),
+                                       P(self.step_counter), ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
+                                       ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s),
+                      "drn_adam_tiled")
         DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
         if repack:
             self.repack()
 
     def repack(self, codes=None):
         """Refresh the other GEMM-layout copies of the weights (one launch per dtype; `codes`: only these dtypes)."""
-        DF.repack_all(skip=self._mirror_keys, codes=codes)
+        DF.repack_all(skip=self._mirror_keys, codes=codes, updated=self._updated)
 
     def _refresh_mirrors(self):
-        """Device tables of the bf16 GEMM operands that keep their parameter's element order (drn_adam_bucket rewrites them
-        in place).  Rebuilt only when the set of cached copies changes, and never while a hipGraph is being captured (the
-        table upload is a host->device copy): copies that appear later are simply left to repack_all()."""
+        """Device tables of the cached GEMM operands the optimizer kernels rewrite themselves while they hold the new value:
+        (a) bf16 copies in the parameter's own element order (Linear / 1x1-conv forward operands without any other copy):
+            drn_adam_bucket's `mirror` table;
+        (b) every parameter with a RE-LAID copy (conv weights as [Cout][k][Cin] / [Cin][k][Cout], transposed Linear weights,
+            fp32 stacks): taken out of drn_adam_bucket (NULL pointer in its table) and updated tile by tile by drn_adam_tiled,
+            which writes up to one copy of each orientation per parameter.
+        Rebuilt only when the set of cached copies changes, and never while a hipGraph is being captured (the table upload is
+        a host->device copy): copies that appear later are simply left to repack_all()."""
         copies = DF.identity_bf16_copies()
-        sig = tuple(sorted((ptr, buf.data_ptr()) for ptr, (key, buf) in copies.items()))
+        relaid = DF.relaid_copies() if self.tiled else {}
+        sig = (tuple(sorted((ptr, buf.data_ptr()) for ptr, (key, buf) in copies.items())),
+               tuple(sorted((ptr, c["kind"], c["base"].data_ptr()) for ptr, lst in relaid.items() for c in lst)))
         if sig == self._mirror_sig or torch.cuda.is_current_stream_capturing():
             return
-        keys = []
-        for st in self.state:
+        from ._lib import AdamTiledItem
+        keys, keep = [], []
+        for b, st in zip(self.reducer.buckets, self.state):
+            dev = st["seg"].device
+            ptrs = list(st["ptr_host"])
+            items, blk_item, blk_tile, used_keys = [], [], [], []
+            for p, off in zip(b.params, b.offsets):
+                lst = relaid.get(p.data_ptr(), [])
+                k = p.shape[2] if p.dim() == 3 else 1
+                # tiled when there is anything but a lone same-order bf16 copy (that one rides in drn_adam_bucket)
+                c1 = [c for c in lst if c["kind"] == 1]
+                c2 = [c for c in lst if c["kind"] == 2]
+                lone_identity = len(lst) == 1 and c1 and k == 1 and c1[0]["code"] == 1 and p.dim() in (2, 3)
+                if not lst or lone_identity or p.dim() not in (1, 2, 3) or k > 3:
+                    continue
+                R, C = (p.shape[0], p.shape[1]) if p.dim() >= 2 else (1, p.shape[0])
+                it = AdamTiledItem(p=p.data_ptr(), off=off, m1=None, m2=None, ld1=0, ld2=0, R=R, C=C, k=k, code1=0, code2=0,
+                                   tiles_c=(C + 192 // k - 1) // (192 // k))
+                if c1:
+                    it.m1, it.ld1, it.code1 = c1[0]["base"].data_ptr(), c1[0]["ld"], c1[0]["code"]
+                    used_keys.append(c1[0]["key"]); keep.append(c1[0]["base"])
+                if c2:
+                    it.m2, it.ld2, it.code2 = c2[0]["base"].data_ptr(), c2[0]["ld"], c2[0]["code"]
+                    used_keys.append(c2[0]["key"]); keep.append(c2[0]["base"])
+                ntiles = ((R + 63) // 64) * it.tiles_c
+                blk_item += [len(items)] * ntiles
+                blk_tile += list(range(ntiles))
+                items.append(it)
+                ptrs[st["ptr_index"][p.data_ptr()]] = 0          # drn_adam_bucket skips it
+            st["tiled"] = None
+            if items:
+                arr = (AdamTiledItem * len(items))(*items)
+                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+                st["tiled"] = (raw, torch.tensor(blk_item, dtype=torch.int32, device=dev),
+                               torch.tensor(blk_tile, dtype=torch.int32, device=dev), len(blk_item))
+            st["ptr"] = torch.tensor(ptrs, dtype=torch.int64, device=dev)
             tab = []
-            for ptr in st["ptr"].tolist():
+            for ptr in ptrs:
                 hit = copies.get(ptr) if ptr else None
                 tab.append(hit[1].data_ptr() if hit else 0)
                 if hit:
                     keys.append(hit[0])
-            st["mirror_bufs"] = [copies[p][1] for p in st["ptr"].tolist() if p and p in copies]      # keep them alive
-            st["mirror"] = torch.tensor(tab, dtype=torch.int64, device=st["ptr"].device) if any(tab) else None
-        self._mirror_sig, self._mirror_keys = sig, frozenset(keys)
+            st["mirror_bufs"] = [copies[q][1] for q in ptrs if q and q in copies]      # keep them alive
+            st["mirror"] = torch.tensor(tab, dtype=torch.int64, device=dev) if any(tab) else None
+            keys += used_keys
+        # a copy made of several parameters is skipped by repack_all only if the tiled kernel writes ALL of its parts
+        need = {}
+        for ptr, lst in relaid.items():
+            for c in lst:
+                need[c["key"]] = need.get(c["key"], 0) + 1
+        done = {}
+        for kk in keys:
+            done[kk] = done.get(kk, 0) + 1
+        self._keep = keep
+        self._mirror_sig = sig
+        self._mirror_keys = frozenset(kk for kk in done if not isinstance(kk, tuple) or kk[0] not in ("pack", "pstack", "stack")
+                                      or done[kk] >= need.get(kk, 1))
 
     def total_norm(self):
         return self.total_sumsq[0].sqrt()

@@ -388,6 +388,25 @@ int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t
                     const int32_t* blk_seg, void* const* mirror_dev, const float* total_sumsq, const int* step_counter, float lr,
                     float beta1, float beta2, float eps, float max_norm, void* stream);
 
+/* The same update for tensors whose GEMM operands are RE-LAID copies (conv weights (Cout, Cin, k) as [Cout][k][Cin] and
+ * [Cin][k][Cout]; Linear weights transposed): the tensor is walked in tiles of 64 rows x 192 row elements instead of linearly, each tile's
+ * updated values pass through LDS and leave as 16-byte pieces of BOTH copies -- the per-step drn_pack_weights launches over
+ * these tensors (76 us per step) disappear.  items: DEVICE array; blk_item / blk_tile: device, one int per workgroup (which
+ * item, which tile of it), nblocks of them.  The caller leaves these tensors out of drn_adam_bucket (NULL in p_ptr_dev). */
+typedef struct DrnAdamTiledItem {
+  float* p;        /* parameter, R x (C*k) row-major fp32 */
+  int64_t off;     /* its offset inside the flat g / m / v buffers */
+  void* m1;        /* copy [r][tap][c]: element (r, c, tap) at m1[(r*k + tap)*ld1 + c], or NULL */
+  void* m2;        /* copy [c][tap][r]: element (r, c, tap) at m2[(c*k + tap)*ld2 + r], or NULL */
+  int64_t ld1, ld2;
+  int32_t R, C, k;
+  int32_t code1, code2; /* dtype of m1 / m2: DRN_F32 or DRN_BF16 */
+  int32_t tiles_c;      /* ceil(C / (192 / k)): a tile is 64 rows x 192 consecutive elements of a tensor row */
+} DrnAdamTiledItem;
+int drn_adam_tiled(const float* g, float* m, float* v, const DrnAdamTiledItem* items_dev, const int32_t* blk_item_dev,
+                   const int32_t* blk_tile_dev, int nblocks, const float* total_sumsq, const int* step_counter, float lr, float beta1,
+                   float beta2, float eps, float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
