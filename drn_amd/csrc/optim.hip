@@ -253,7 +253,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
   __shared__ float tile[64][64 * TILED_MAXK + 1];
   const DrnAdamTiledItem it = items[blk_item[blockIdx.x]];
   const int t = blk_tile[blockIdx.x];
-  const int tcw = (64 * TILED_MAXK) / it.k;                    // channels per tile: 192 elements of a tensor row whatever k is
+  constexpr int tcw = 64;       // channels per tile (192-element tiles for k = 1 -- half as many workgroups -- measured 13 % slower)
   const int r0 = (t / it.tiles_c) * 64, c0 = (t % it.tiles_c) * tcw;
   const int nr = min(64, it.R - r0), nc = min(tcw, it.C - c0);
   const int k = it.k, S = it.C * k, ts = nc * k;            // row length of the tensor, of the tile

@@ -222,7 +222,8 @@ struct OwGroupArgs {
 #define OW_MB 32
 #define OW_PITCH 80
 __global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupArgs G) {
-  __shared__ float Ys[OW_MB][OW_PITCH], Xs[OW_MB][OW_PITCH];
+  __shared__ __attribute__((aligned(16))) float sm[2][OW_MB][OW_PITCH];   // one block: the epilogue re-uses all of it
+  float (*Ys)[OW_PITCH] = sm[0], (*Xs)[OW_PITCH] = sm[1];
   int g = 0;
 #pragma unroll
   for (int i = 1; i < DRN_QD_MAX; ++i)
@@ -289,14 +290,29 @@ __global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupAr
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[u * 4 + lq][j * 16 + li], acc[j], 0, 0, 0);
       }
     }
-    // D: n = n0 + lq*4 + r, k = k0 + j*16 + li
+    // D: n = n0 + lq*4 + r, k = k0 + j*16 + li.  Each wave parks its 16 x 64 tile in LDS (the slabs are spent) and writes it
+    // out as 16-byte pieces of whole 256-byte row segments: 4 store instructions per wave instead of 16 four-byte ones
+    // that touched a 64-byte piece of four different rows each (the launch writes 26 MB: it is store-bound).
+    __syncthreads();                                     // every wave is done reading the last slab
+    float* wt = &sm[0][0][0] + w * (16 * 68);               // 4 waves x 16 rows x pitch 68 floats = 17 KB of the 20 KB
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (k0 + j * 16 + li >= P.K) continue;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + lq * 4 + r;
-        if (n < P.N) P.dW[(long)n * P.ldw + k0 + j * 16 + li] = acc[j][r];
+      for (int r = 0; r < 4; ++r) wt[(lq * 4 + r) * 68 + j * 16 + li] = acc[j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a wave reads back only what it wrote itself)
+    const bool ovec = (P.ldw % 4 == 0) && ((((uintptr_t)P.dW) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = it * 4 + (l >> 4), cc = (l & 15) * 4;
+      const int n = n0 + rr, k = k0 + cc;
+      if (n < P.N && k < P.K) {
+        const f32x4 v = *(const f32x4*)(wt + rr * 68 + cc);
+        float* dst = P.dW + (long)n * P.ldw + k;
+        if (ovec && k + 3 < P.K) *(f32x4*)dst = v;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < P.K) dst[e] = v[e];
       }
     }
   }

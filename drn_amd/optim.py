@@ -121,7 +121,7 @@ class FusedAdam(object):
                     continue
                 R, C = (p.shape[0], p.shape[1]) if p.dim() >= 2 else (1, p.shape[0])
                 it = AdamTiledItem(p=p.data_ptr(), off=off, m1=None, m2=None, ld1=0, ld2=0, R=R, C=C, k=k, code1=0, code2=0,
-                                   tiles_c=(C + 192 // k - 1) // (192 // k))
+                                   tiles_c=(C + 63) // 64)
                 if c1:
                     it.m1, it.ld1, it.code1 = c1[0]["base"].data_ptr(), c1[0]["ld"], c1[0]["code"]
                     used_keys.append(c1[0]["key"]); keep.append(c1[0]["base"])

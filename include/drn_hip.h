@@ -389,7 +389,7 @@ int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t
                     float beta1, float beta2, float eps, float max_norm, void* stream);
 
 /* The same update for tensors whose GEMM operands are RE-LAID copies (conv weights (Cout, Cin, k) as [Cout][k][Cin] and
- * [Cin][k][Cout]; Linear weights transposed): the tensor is walked in tiles of 64 rows x 192 row elements instead of linearly, each tile's
+ * [Cin][k][Cout]; Linear weights transposed): the tensor is walked in 64 x 64-channel tiles instead of linearly, each tile's
  * updated values pass through LDS and leave as 16-byte pieces of BOTH copies -- the per-step drn_pack_weights launches over
  * these tensors (76 us per step) disappear.  items: DEVICE array; blk_item / blk_tile: device, one int per workgroup (which
  * item, which tile of it), nblocks of them.  The caller leaves these tensors out of drn_adam_bucket (NULL in p_ptr_dev). */
@@ -401,7 +401,7 @@ typedef struct DrnAdamTiledItem {
   int64_t ld1, ld2;
   int32_t R, C, k;
   int32_t code1, code2; /* dtype of m1 / m2: DRN_F32 or DRN_BF16 */
-  int32_t tiles_c;      /* ceil(C / (192 / k)): a tile is 64 rows x 192 consecutive elements of a tensor row */
+  int32_t tiles_c;      /* ceil(C / 64) */
 } DrnAdamTiledItem;
 int drn_adam_tiled(const float* g, float* m, float* v, const DrnAdamTiledItem* items_dev, const int32_t* blk_item_dev,
                    const int32_t* blk_tile_dev, int nblocks, const float* total_sumsq, const int* step_counter, float lr, float beta1,
