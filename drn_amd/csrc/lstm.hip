@@ -54,6 +54,26 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
   const int kq = H / 4;
   const int row = l & 15, kc = (l >> 4) * 4;
   const int bb_a = bt * 16 + row;
+  // The cell update's own operands (input projection, biases, previous state, length) are requested BEFORE the recurrent
+  // product: issued in the epilogue they were a second, serial memory round trip of ~1 us in an 8 us kernel.
+  const int e_bb = bt * 16 + (l >> 4) * 4 + w, e_j = j0 + (l & 15);
+  const bool e_own = e_bb < B;
+  float e_x[4], e_bi[4], e_bh[4], e_cp = 0.f, e_hp = 0.f;
+  long long e_len = 0;
+  {
+    const int bq = e_own ? e_bb : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      e_x[g] = A.xproj[(((long)t * B + bq) * 2 + dir) * 4 * H + g * H + e_j];
+      e_bi[g] = A.b_ih[dir][g * H + e_j];
+      e_bh[g] = A.b_hh[dir][g * H + e_j];
+    }
+    const long sp = ((long)(dir * (L + 1) + (s > 0 ? s : 1)) * B + bq) * H + e_j;     // (slot 0 is never written: not read at s = 0)
+    e_cp = A.cseq[sp];
+    e_hp = A.hseq[sp];
+    e_len = A.lengths[bq];
+    if (s == 0) { e_cp = 0.f; e_hp = 0.f; }
+  }
   if (s > 0)                            // zero initial state: the first step has no recurrent term
     for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 16 * KU) {
       f32x4 a[KU], b[KU][4];
@@ -79,22 +99,21 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
   // epilogue: 256 threads = 64 lanes x 4 regs of the D tile; D layout: b = bt*16 + (l>>4)*4 + r, j = j0 + (l&15)
   {
     const int r = w;                    // wave w finishes register r of every lane
-    const int bb = bt * 16 + (l >> 4) * 4 + r;
-    if (bb >= B) return;
-    const int j = j0 + (l & 15);
+    const int bb = e_bb;
+    if (!e_own) return;
+    const int j = e_j;
     float pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float v = red[0][g][l][r] + red[1][g][l][r] + red[2][g][l][r] + red[3][g][l][r];
-      pre[g] = v + A.xproj[(((long)t * B + bb) * 2 + dir) * 4 * H + g * H + j] + A.b_ih[dir][g * H + j] + A.b_hh[dir][g * H + j];
+      pre[g] = v + e_x[g] + e_bi[g] + e_bh[g];
     }
     const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-    const long st_prev = ((long)(dir * (L + 1) + s) * B + bb) * H + j;
     const long st_new = ((long)(dir * (L + 1) + s + 1) * B + bb) * H + j;
-    const float cp = s > 0 ? A.cseq[st_prev] : 0.f, hp = s > 0 ? A.hseq[st_prev] : 0.f;
+    const float cp = e_cp, hp = e_hp;
     const float cn = fg * cp + ig * gg;
     const float hn = og * tanhf(cn);
-    const bool valid = t < A.lengths[bb];
+    const bool valid = t < e_len;
     A.cseq[st_new] = valid ? cn : cp;
     A.hseq[st_new] = valid ? hn : hp;
     float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
@@ -138,20 +157,36 @@ struct LstmBwdArgs {
 };
 
 // Cell backward for one (direction, clip, hidden unit) at step s given dL/dh entering that step: writes dgates for time
-// t(s), the running dL/dc for step s-1, and the part of dh that bypasses the cell at padded positions.
-__device__ __forceinline__ void lstm_cell_bwd(const LstmBwdArgs& A, int dir, int bb, int j, int s, float dh_in) {
+// t(s), the running dL/dc for step s-1, and the part of dh that bypasses the cell at padded positions.  In two halves so that
+// the step kernel can request the cell's operands BEFORE its recurrent product (they were a second, serial memory round trip).
+struct LstmCellIn {
+  float dout, dcn, ig, fg, gg, og, cn, cp;
+  bool valid;
+};
+__device__ __forceinline__ LstmCellIn lstm_cell_bwd_load(const LstmBwdArgs& A, int dir, int bb, int j, int s) {
   const int B = A.B, L = A.L, H = A.H;
   const int t = dir == 0 ? s : L - 1 - s;
-  const bool valid = t < A.lengths[bb];
+  LstmCellIn c;
+  c.valid = t < A.lengths[bb];
+  const long sidx = ((long)dir * B + bb) * H + j;
+  c.dout = A.dout[((long)bb * L + t) * 2 * H + dir * H + j];
+  c.dcn = s == L - 1 ? 0.f : A.dc[sidx];       // nothing flows in from beyond the last step
+  const float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+  c.ig = gs[0]; c.fg = gs[H]; c.gg = gs[2 * H]; c.og = gs[3 * H];
+  c.cn = A.cseq[((long)(dir * (L + 1) + s + 1) * B + bb) * H + j];
+  c.cp = A.cseq[((long)(dir * (L + 1) + (s > 0 ? s : 1)) * B + bb) * H + j];
+  if (s == 0) c.cp = 0.f;
+  return c;
+}
+__device__ __forceinline__ void lstm_cell_bwd_apply(const LstmBwdArgs& A, const LstmCellIn& c, int dir, int bb, int j, int s, float dh_in) {
+  const int B = A.B, L = A.L, H = A.H;
+  const int t = dir == 0 ? s : L - 1 - s;
   const long sidx = ((long)dir * B + bb) * H + j;
   float* dg = A.dgates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
-  const float dh = dh_in + (valid ? A.dout[((long)bb * L + t) * 2 * H + dir * H + j] : 0.f);
-  const float dcn = s == L - 1 ? 0.f : A.dc[sidx];       // nothing flows in from beyond the last step
-  if (valid) {
-    const float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
-    const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
-    const float cn = A.cseq[((long)(dir * (L + 1) + s + 1) * B + bb) * H + j];
-    const float cp = s > 0 ? A.cseq[((long)(dir * (L + 1) + s) * B + bb) * H + j] : 0.f;
+  const float dh = dh_in + (c.valid ? c.dout : 0.f);
+  const float dcn = c.dcn;
+  if (c.valid) {
+    const float ig = c.ig, fg = c.fg, gg = c.gg, og = c.og, cn = c.cn, cp = c.cp;
     const float tc = tanhf(cn);
     const float dcv = dcn + dh * og * (1.f - tc * tc);
     dg[0] = dcv * gg * ig * (1.f - ig);
@@ -165,6 +200,10 @@ __device__ __forceinline__ void lstm_cell_bwd(const LstmBwdArgs& A, int dir, int
     A.dc[sidx] = dcn;
     A.dh_pass[sidx] = dh;
   }
+}
+__device__ __forceinline__ void lstm_cell_bwd(const LstmBwdArgs& A, int dir, int bb, int j, int s, float dh_in) {
+  const LstmCellIn c = lstm_cell_bwd_load(A, dir, bb, j, s);
+  lstm_cell_bwd_apply(A, c, dir, bb, j, s, dh_in);
 }
 
 // first backward step (s = L-1): no recurrent gradient yet
@@ -191,6 +230,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmB
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int row = l & 15, rc = (l >> 4) * 4;
   const int bb_a = bt * 16 + row;
+  // operands of the cell backward this thread will run in the epilogue: requested up front
+  const int e_bb = bt * 16 + (l >> 4) * 4 + w, e_k = k0 + (l & 15);
+  const bool e_own = e_bb < B;
+  const LstmCellIn e_c = lstm_cell_bwd_load(A, dir, e_own ? e_bb : 0, e_k, s - 1);
+  const float e_dhp = A.dh_pass[((long)dir * B + (e_own ? e_bb : 0)) * H + e_k];
   for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 16 * KU) {
     f32x4 a[KU], b[KU];
 #pragma unroll
@@ -208,11 +252,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmB
   for (int r = 0; r < 4; ++r) red[w][l][r] = acc[r];
   __syncthreads();
   const int r = w;
-  const int bb = bt * 16 + (l >> 4) * 4 + r;
-  if (bb >= B) return;
-  const int k = k0 + (l & 15);
-  const float dh = A.dh_pass[((long)dir * B + bb) * H + k] + red[0][l][r] + red[1][l][r] + red[2][l][r] + red[3][l][r];
-  lstm_cell_bwd(A, dir, bb, k, s - 1, dh);
+  if (!e_own) return;
+  const float dh = e_dhp + red[0][l][r] + red[1][l][r] + red[2][l][r] + red[3][l][r];
+  lstm_cell_bwd_apply(A, e_c, dir, e_bb, e_k, s - 1, dh);
 }
 
 extern "C" int drn_lstm_bwd_first(const float* dout, const float* gates, const float* cseq, float* dgates, float* dc, float* dh_pass,
