@@ -46,9 +46,11 @@ def check_outputs(lh, hh, lo, ho, atol, levels=(0, 1, 2)):
             assert err <= atol * max(1.0, float(y.abs().max())), ("head", j, l, err)
 
 
-# (name, B, T, D, stage): configs[1]/[2] per-GPU shape at full size; configs[3] and [4] with a smaller batch
+# (name, B, T, D, stage): every BASELINE.json config at the size ONE GPU runs: configs[1] and configs[3] are single-GPU (B = 32 /
+# B = 64), configs[2] (batch 256) and configs[4] (batch 128) are 8-way data parallel = 32 / 16 clips per GPU (per-rank BatchNorm
+# statistics and loss normalisation, drn_amd/dist.py; the exchange itself: tests/test_dist_cpu.py, tests/test_dist_gpu.py)
 SHAPES = [("cfg1_T256_D4096_stage1", 32, 256, 4096, 1), ("cfg2_T256_D4096_stage3", 32, 256, 4096, 3),
-          ("cfg3_T512_D1024", 8, 512, 1024, 1), ("cfg4_T1024_D500", 4, 1024, 500, 1)]
+          ("cfg3_T512_D1024_B64", 64, 512, 1024, 1), ("cfg4_T1024_D500_B16", 16, 1024, 500, 1)]
 
 
 @pytest.mark.parametrize("name,B,T,D,stage", SHAPES)

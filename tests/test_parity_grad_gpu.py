@@ -146,7 +146,8 @@ def grad_errors(hip_model, oracle_model):
 
 
 # (B, T, D, stage): tiny, the reference's CPU-runnable configs[0] shape, and the benchmarked per-GPU shape of configs[1] / [2]
-CASES = [(2, 32, 64, 3), (2, 64, 4096, 1), (2, 64, 4096, 3), (32, 256, 4096, 1), (32, 256, 4096, 3)]
+CASES = [(2, 32, 64, 3), (2, 64, 4096, 1), (2, 64, 4096, 3), (32, 256, 4096, 1), (32, 256, 4096, 3),
+         (64, 512, 1024, 1), (16, 1024, 500, 1)]        # + configs[3] at full size, configs[4] at its per-GPU size
 
 
 @pytest.mark.parametrize("B,T,D,stage", CASES)
