@@ -17,6 +17,13 @@ from ._lib import DrnError
 
 _pack_cache = {}
 _weights_epoch = 0
+_cache_gen = 0          # bumped whenever a weight-copy cache gains or loses an entry (drn_amd.optim re-reads them only then)
+
+
+def _bump_cache_gen():
+    global _cache_gen
+    _cache_gen += 1
+
 
 
 def bump_weights_epoch():
@@ -32,6 +39,7 @@ def _purge_dead(cache, limit, refs_of):
     if len(cache) > limit:
         for k in [k for k, e in cache.items() if any(r() is None for r in refs_of(e))]:
             del cache[k]
+        _bump_cache_gen()
 
 
 def _w3(w):
@@ -61,6 +69,7 @@ def packed(w, perm, code):
         out = ops.pack_weight(_w3(w), perm, code)
         _purge_dead(_pack_cache, 256, lambda e: (e[2],))
         _pack_cache[key] = (ver, out, weakref.ref(w))
+        _bump_cache_gen()
     return out.view(out.shape[0], -1) if two_d else out
 
 
@@ -91,6 +100,7 @@ def _packed_stack(params, perm, code):
         torch.empty(shape, dtype=ops.TORCH_DT[code], device=params[0].device)
     ops.pack_weights_into(_pstack_items(out, params, perm), code)
     _purge_dead(_pstack_cache, 64, lambda e: e[2])
+    _bump_cache_gen()
     _pstack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
 
@@ -123,6 +133,7 @@ def stacked(params):
         torch.empty(shape, dtype=torch.float32, device=params[0].device)
     ops.pack_weights_into(_stack_items(out, params), ops.F32)
     _purge_dead(_stack_cache, 64, lambda e: e[2])
+    _bump_cache_gen()
     _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
 
@@ -194,6 +205,7 @@ def stacked_t(params):
         torch.empty(shape, dtype=torch.float32, device=params[0].device)
     ops.pack_weights_into(_stack_t_items(out, params), ops.F32)
     _purge_dead(_stack_cache, 64, lambda e: e[2])
+    _bump_cache_gen()
     _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
 
@@ -277,6 +289,7 @@ def repack_all(skip=(), codes=None, updated=None):
         w = ref()
         if w is None or w.data_ptr() != key[1] or out.device != w.device:
             del _pack_cache[key]
+            _bump_cache_gen()
             continue
         if not want(key[3]):
             continue
@@ -288,6 +301,7 @@ def repack_all(skip=(), codes=None, updated=None):
         ps = [r() for r in refs]
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key[0] or out.device != ps[0].device:
             del _pstack_cache[key]
+            _bump_cache_gen()
             continue
         if not want(key[2]):
             continue
@@ -302,6 +316,7 @@ def repack_all(skip=(), codes=None, updated=None):
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != (key[1:] if transposed else key) \
                 or out.device != ps[0].device:
             del _stack_cache[key]
+            _bump_cache_gen()
             continue
         if not want(ops.F32):
             continue

@@ -98,11 +98,15 @@ class FusedAdam(object):
             which writes up to one copy of each orientation per parameter.
         Rebuilt only when the set of cached copies changes, and never while a hipGraph is being captured (the table upload is
         a host->device copy): copies that appear later are simply left to repack_all()."""
+        if DF._cache_gen == getattr(self, "_seen_gen", None) or torch.cuda.is_current_stream_capturing():
+            return                                   # no cache entry came or went since the tables were built
+        gen = DF._cache_gen
         copies = DF.identity_bf16_copies()
         relaid = DF.relaid_copies() if self.tiled else {}
         sig = (tuple(sorted((ptr, buf.data_ptr()) for ptr, (key, buf) in copies.items())),
                tuple(sorted((ptr, c["kind"], c["base"].data_ptr()) for ptr, lst in relaid.items() for c in lst)))
-        if sig == self._mirror_sig or torch.cuda.is_current_stream_capturing():
+        if sig == self._mirror_sig:
+            self._seen_gen = gen
             return
         from ._lib import AdamTiledItem
         keys, keep = [], []
@@ -158,6 +162,7 @@ class FusedAdam(object):
         for kk in keys:
             done[kk] = done.get(kk, 0) + 1
         self._keep = keep
+        self._seen_gen = gen
         self._mirror_sig = sig
         self._mirror_keys = frozenset(kk for kk in done if not isinstance(kk, tuple) or kk[0] not in ("pack", "pstack", "stack")
                                       or done[kk] >= need.get(kk, 1))
