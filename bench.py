@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--torch-adam", action="store_true", help="torch clip_grad_norm_ + optim.Adam instead of the fused HIP step")
     args = ap.parse_args()
 
+    def note(msg):                       # progress on stderr with --verbose (where a multi-rank run stopped, if it did)
+        if args.verbose:
+            print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
     from drn_amd import dist as ddist
     from drn_amd import functional as DF
     from drn_amd import ops
@@ -224,6 +228,7 @@ def main():
     else:
         for _ in range(args.warmup):
             step()
+    note("warm-up / capture done (%s)" % mode)
     barrier()
     if world > 1:
         ar_events = []
@@ -232,6 +237,7 @@ def main():
         losses = run()
     barrier()
     dt = time.perf_counter() - t0
+    note("timed loop done")
     exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
     ar_events = None
     # per-kernel timing of the MFMA GEMMs for the roofline object: HIP events around each launch, on the launch
@@ -243,6 +249,7 @@ def main():
             step()
         torch.cuda.synchronize()
         ops.kernel_timer = None
+        note("kernel timing done")
         timed_steps = max(3, min(args.steps, 5))
     per_rank = None
     if world > 1:
@@ -254,6 +261,7 @@ def main():
                     "note": "exposed = GPU time the step's stream waits in GradReducer.finish() (query-side bucket + whatever of the "
                             "trunk / prop_fc exchanges the next phase did not hide), HIP events"}
         dt = max(float(t[0]) for t in allr)
+        note("per-rank gather done")
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     fl = path_flops(T, D, stage)
@@ -370,8 +378,10 @@ def main():
             torch.set_num_threads(min(32, os.cpu_count() or 1))
             out["cpu_baseline"] = cpu_baseline(cfg, B, T, D, stage, args.cpu_steps)
         print(json.dumps(out), flush=True)
+    note("result printed")
     if world > 1:
         torch.distributed.destroy_process_group()
+    note("exit")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -q -m gpu --tb=line -rf 2>&1 | grep -E "passed|failed|^FAILED|Error" | cut -c1-300
-timeout 300 python bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --steps 60 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['config']['loss_cls'])"
+export DRN_DIST_BACKEND=gloo DRN_FORCE_DEVICE=0
+for i in 1 2; do
+S=$SECONDS
+timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 2951$i bench.py --gpus 2 --steps 6 --warmup 2 --cpu-steps 0 --verbose > gpurun_out/n2_$i.log 2>&1
+echo "run $i rc $? wall $((SECONDS-S)) s"; grep -E "bench rank|Error|Signal" gpurun_out/n2_$i.log | cut -c1-160 | tail -6
+done
