@@ -96,11 +96,18 @@ __global__ __launch_bounds__(QD_THREADS) void skinny_group_kernel(const SkGroupA
 #pragma unroll
   for (int bt = 0; bt < NBT; ++bt) v[bt] = red[0][bt][l][r] + red[1][bt][l][r] + red[2][bt][l][r] + red[3][bt][l][r];
   if (P.ksplit > 1) {
-#pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) {
-      const int m = bt * 16 + (l >> 4) * 4 + r;
-      if (m < P.M && n < P.N)
-        __hip_atomic_store(P.part + ((long)ks * P.M + m) * P.N + n, v[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // partial tiles are exchanged in the lanes' own order: a lane's NBT values (one per 16-row block) are ONE 4 / 8 / 16-byte
+    // write-through store and one load per split, not NBT four-byte ones (a scalar sc1 access is a fabric transaction of its own)
+    const int ntiles = (P.N + 15) >> 4;
+    float* mine = P.part + (((long)ks * ntiles + tile) * QD_THREADS + threadIdx.x) * NBT;
+    if constexpr (NBT == 4) {
+      const f32x4 pv = (f32x4){v[0], v[1], v[2], v[3]};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(mine), "v"(pv) : "memory");
+    } else if constexpr (NBT == 2) {
+      const f32x2 pv = (f32x2){v[0], v[1]};
+      asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(mine), "v"(pv) : "memory");
+    } else {
+      __hip_atomic_store(mine, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's write-through stores are complete ...
     __syncthreads();                                          // ... and so are the other waves' before thread 0 counts us in
@@ -112,13 +119,47 @@ __global__ __launch_bounds__(QD_THREADS) void skinny_group_kernel(const SkGroupA
     __syncthreads();
     if (!is_last) return;
 #pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) {
-      const int m = bt * 16 + (l >> 4) * 4 + r;
-      float s = 0.f;
-      if (m < P.M && n < P.N)
-        for (int q = 0; q < P.ksplit; ++q)
-          s += __hip_atomic_load(P.part + ((long)q * P.M + m) * P.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v[bt] = s;
+    for (int bt = 0; bt < NBT; ++bt) v[bt] = 0.f;
+    // fixed order: deterministic whoever arrives last.  ksplit is a power of two >= 2 (qd_ksplit): four (or the two) partial
+    // tiles per trip are requested together -- one asm statement per trip with its own wait (see gemm_nt.hip on why)
+    const long qstride = (long)ntiles * QD_THREADS * NBT;
+    const float* src = P.part + ((long)tile * QD_THREADS + threadIdx.x) * NBT;
+    if constexpr (NBT == 4) {
+      for (int q = 0; q < P.ksplit; q += 4) {
+        f32x4 p0, p1, p2 = (f32x4){0.f, 0.f, 0.f, 0.f}, p3 = p2;
+        if (P.ksplit >= 4)
+          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                       "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                       : "v"(src + q * qstride), "v"(src + (q + 1) * qstride), "v"(src + (q + 2) * qstride), "v"(src + (q + 3) * qstride)
+                       : "memory");
+        else
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(p0), "=&v"(p1)
+                       : "v"(src + q * qstride), "v"(src + (q + 1) * qstride)
+                       : "memory");
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) v[bt] = (((v[bt] + p0[bt]) + p1[bt]) + p2[bt]) + p3[bt];
+      }
+    } else if constexpr (NBT == 2) {
+      for (int q = 0; q < P.ksplit; q += 4) {
+        f32x2 p0, p1, p2 = (f32x2){0.f, 0.f}, p3 = p2;
+        if (P.ksplit >= 4)
+          asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %5, off sc1\n\t"
+                       "global_load_dwordx2 %2, %6, off sc1\n\tglobal_load_dwordx2 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                       : "v"(src + q * qstride), "v"(src + (q + 1) * qstride), "v"(src + (q + 2) * qstride), "v"(src + (q + 3) * qstride)
+                       : "memory");
+        else
+          asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(p0), "=&v"(p1)
+                       : "v"(src + q * qstride), "v"(src + (q + 1) * qstride)
+                       : "memory");
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) v[bt] = (((v[bt] + p0[bt]) + p1[bt]) + p2[bt]) + p3[bt];
+      }
+    } else {
+      for (int q = 0; q < P.ksplit; ++q) v[0] += __hip_atomic_load(src + q * qstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #pragma unroll
@@ -153,7 +194,7 @@ extern "C" int64_t drn_skinny_group_ws_elems(const DrnSkinnyDesc* d, int n) {
   const int tl = qd_tiles_long(d, n);
   for (int i = 0; i < n; ++i) {
     const int ks = qd_ksplit(tl, d[i].K);
-    if (ks > 1) tot += (int64_t)ks * d[i].M * d[i].N;
+    if (ks > 1) tot += (int64_t)ks * cdiv(d[i].N, 16) * QD_THREADS * 4;      // lane-ordered partial tiles, up to 4 row blocks
   }
   return tot;
 }
@@ -182,7 +223,7 @@ extern "C" int drn_skinny_group(const DrnSkinnyDesc* d, int n, float* ws, int32_
     if (P.ksplit > 1) {
       DRN_CHECK_ARG(ws && counters, "drn_skinny_group: problem %d is K-split: workspace (drn_skinny_group_ws_elems) and counters required", i);
       P.part = ws + wsoff;
-      wsoff += (int64_t)P.ksplit * s.M * s.N;
+      wsoff += (int64_t)P.ksplit * cdiv(s.N, 16) * QD_THREADS * 4;
       P.counters = counters + cnt;
       cnt += cdiv(s.N, 16);
       DRN_CHECK_ARG(cnt <= DRN_QD_COUNTERS, "drn_skinny_group: more than %d K-split column tiles", DRN_QD_COUNTERS);
