@@ -122,9 +122,14 @@ __device__ __forceinline__ void qe_dots(const float* __restrict__ ob, const floa
     for (int c = threadIdx.x; c < C; c += 256) {
       const float wc = BWD ? 1.f : w[c];
       const float q0 = v0 ? v0[c] * wc : 0.f, q1 = v1 ? v1[c] * wc : 0.f, q2 = v2 ? v2[c] * wc : 0.f;
+      // unconditional loads (row index clamped, the value masked): a load under a run-time condition gets its own branch and
+      // its own vmcnt(0), i.e. eight serial memory round trips per channel here
+      float ov[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ov[j] = ob[(long)max(min(l0 + j, len - 1), 0) * C + c];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float o = l0 + j < len ? ob[(long)(l0 + j) * C + c] : 0.f;
+        const float o = l0 + j < len ? ov[j] : 0.f;
         acc[0][j] = fmaf(q0, o, acc[0][j]);
         acc[1][j] = fmaf(q1, o, acc[1][j]);
         acc[2][j] = fmaf(q2, o, acc[2][j]);
@@ -177,12 +182,19 @@ __global__ __launch_bounds__(256) void qe_attn_fwd_kernel(const float* __restric
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 4
-    for (int l = 0; l < len; ++l) {
-      const float o = ob[(long)l * C + c];
-      a0 = fmaf(lg[0][l], o, a0);
-      a1 = fmaf(lg[1][l], o, a1);
-      a2 = fmaf(lg[2][l], o, a2);
+    for (int l0 = 0; l0 < len; l0 += 8) {          // eight independent row loads per trip (clamped: lg is zero beyond len)
+      float ov[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ov[j] = ob[(long)min(l0 + j, len - 1) * C + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int l = l0 + j;
+        if (l < len) {                               // (register-only: lg beyond len is not initialised)
+          a0 = fmaf(lg[0][l], ov[j], a0);
+          a1 = fmaf(lg[1][l], ov[j], a1);
+          a2 = fmaf(lg[2][l], ov[j], a2);
+        }
+      }
     }
     cmds[((long)0 * B + b) * C + c] = a0;
     cmds[((long)1 * B + b) * C + c] = a1;
@@ -246,19 +258,26 @@ __global__ __launch_bounds__(256) void qe_attn_bwd_kernel(const float* __restric
       q[t] = qb[t * C + c];
       d[t] = dc[t] ? dc[t][c] : 0.f;
     }
-#pragma unroll 4
-    for (int l = 0; l < L; ++l) {
-      float g = 0.f;
-      if (l < len) {
-        const float o = ob[(long)l * C + c];
+    for (int l0 = 0; l0 < L; l0 += 8) {              // eight independent row loads per trip (row index clamped)
+      float ov[8];
 #pragma unroll
-        for (int t = 0; t < QE_NCMD; ++t) {
-          S[t] = fmaf(dl[t][l], o, S[t]);
-          g = fmaf(at[t][l], d[t], g);
-          g = fmaf(dl[t][l] * q[t], wc, g);
+      for (int j = 0; j < 8; ++j) ov[j] = ob[(long)max(min(l0 + j, len - 1), 0) * C + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int l = l0 + j;
+        if (l >= L) break;
+        float g = 0.f;
+        if (l < len) {
+          const float o = ov[j];
+#pragma unroll
+          for (int t = 0; t < QE_NCMD; ++t) {
+            S[t] = fmaf(dl[t][l], o, S[t]);
+            g = fmaf(at[t][l], d[t], g);
+            g = fmaf(dl[t][l] * q[t], wc, g);
+          }
         }
+        dout[((long)b * L + l) * C + c] = g;
       }
-      dout[((long)b * L + l) * C + c] = g;
     }
     float dw = 0.f;
 #pragma unroll
