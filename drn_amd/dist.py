@@ -26,6 +26,11 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+            # one node: keep gloo on the loopback interface instead of resolving the host name, which may not resolve
+            # inside a container (a rendezvous that then waits for its 30-minute timeout).  RCCL picks its own interface.
+            if backend == "gloo":
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         elif os.environ.get("DRN_FORCE_DEVICE") is not None and torch.cuda.is_available():
