@@ -663,6 +663,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   // two; DRN_NT_WAVES=4 brings the 4-wave variants back for experiments)
   bool waves8 = tile == 128;
   if (const char* e = drn_exp_env("DRN_NT_WAVES")) waves8 = tile == 128 && atoi(e) == 8;
+  if (ksplit > 1) waves8 = true;       // the in-launch split-K exchange exists for the 8-wave 128x128 tile only
   if (waves8 && !drn_exp_env("DRN_NT_STAGES")) stages = 2;
   static bool attr_set = false;
   if (!attr_set) {

@@ -293,7 +293,9 @@ def repack_all(skip=(), codes=None, updated=None):
             continue
         if not want(key[3]):
             continue
-        if key in skip or ("pack", key) in skip or same([w]):
+        # (a copy somebody else refreshed / an untouched parameter's copy is only marked current -- unless the parameter was
+        # modified in place since the copy was built (load_state_dict, copy_): then it is repacked like the rest)
+        if (key in skip or ("pack", key) in skip or same([w])) and ver[0] == w._version:
             _pack_cache[key] = ((w._version, _weights_epoch), out, ref)
             continue
         by_code.setdefault(key[3], []).append((key, w, out))
@@ -305,7 +307,7 @@ def repack_all(skip=(), codes=None, updated=None):
             continue
         if not want(key[2]):
             continue
-        if ("pstack", key) not in skip and not same(ps):
+        if (("pstack", key) not in skip and not same(ps)) or ver[0] != tuple(p._version for p in ps):
             by_code.setdefault(key[2], [])
             by_code.setdefault(("stack", key[2]), []).extend(_pstack_items(out, ps, key[1]))
         _pstack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
@@ -320,7 +322,7 @@ def repack_all(skip=(), codes=None, updated=None):
             continue
         if not want(ops.F32):
             continue
-        if ("stack", key) not in skip and not same(ps):
+        if (("stack", key) not in skip and not same(ps)) or ver[0] != tuple(p._version for p in ps):
             stack_items += _stack_t_items(out, ps) if transposed else _stack_items(out, ps)
         _stack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
     for code, items in by_code.items():

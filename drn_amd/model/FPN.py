@@ -3,6 +3,7 @@ import torch
 from torch import nn
 
 from .. import functional as DF
+from .basic_blocks import conv_bn
 
 
 class FPN(nn.Module):
@@ -25,8 +26,8 @@ class FPN(nn.Module):
         """feats: channels-last (B, L_l, C_l), highest resolution first.  The three lateral 1x1 convs run as ONE grouped
         implicit-GEMM launch, their BN-apply passes resolve the top-down chain last_l = lateral_l + nearest_x2(last_{l+1})
         coarse to fine (FPN.py:54-68), then the three output convs run as one grouped launch (FPN.py:56,69)."""
-        inner = [(getattr(self, nm)[0], getattr(self, nm)[1]) for nm in self.inner_blocks]
-        layer = [(getattr(self, nm)[0], getattr(self, nm)[1]) for nm in self.layer_blocks]
+        inner = [conv_bn(getattr(self, nm), "FPN." + nm) for nm in self.inner_blocks]
+        layer = [conv_bn(getattr(self, nm), "FPN." + nm) for nm in self.layer_blocks]
         dt = self.compute_dtype
         last = DF.multi_conv_block(list(feats), inner, self.training, dt, chain_up=True)
         results = DF.multi_conv_block(last, layer, self.training, dt, chain_up=False)

@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as DF
+from .basic_blocks import conv_bn
 
 
 class Backbone(nn.Module):
@@ -26,8 +27,8 @@ class Backbone(nn.Module):
         dt = self.compute_dtype
         for idx in range(self.num_layers):
             nxt = gates[idx + 1] if idx + 1 < self.num_layers else None
-            blk = getattr(self, self.blocks[idx])
-            out, gated = DF.conv_block([x], blk[0], blk[1], self.training, x.dtype if idx == 0 else dt, gate=nxt)
+            conv, bn = conv_bn(getattr(self, self.blocks[idx]), "Backbone." + self.blocks[idx])
+            out, gated = DF.conv_block([x], conv, bn, self.training, x.dtype if idx == 0 else dt, gate=nxt)
             outs.append(DF.cast_act(out[0], dt))
             x = DF.cast_act(gated, dt) if gated is not None else None
         return outs

@@ -6,6 +6,21 @@ from .. import functional as DF
 from .._lib import DrnError
 
 
+def conv_bn(block, who):
+    """(conv, BatchNorm1d) of a conv -> BN -> ReLU block, the only kind the channels-last model paths run (DRN builds nothing
+    else, model/main_model.py:28): the no-BN / no-ReLU / Dropout variants of the factory raise here instead of being
+    mis-indexed or silently run without their Dropout."""
+    if not isinstance(block, nn.Sequential) or len(block) < 2 or not isinstance(block[0], nn.Conv1d) \
+            or not isinstance(block[1], nn.BatchNorm1d):
+        raise DrnError("%s: needs conv -> BatchNorm1d -> ReLU blocks (conv_with_kaiming_uniform(True, True)); got %s"
+                       % (who, type(block).__name__))
+    if not getattr(block, "relu", True) or not any(isinstance(m, nn.ReLU) for m in block):
+        raise DrnError("%s: a block without ReLU is only served by its own forward()" % who)
+    if block.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in block):
+        raise DrnError("%s: Dropout is not applied on the channels-last model path; call the block itself" % who)
+    return block[0], block[1]
+
+
 class ConvBlock(nn.Sequential):
     """nn.Sequential(Conv1d(bias=False), BatchNorm1d[, ReLU]) as a parameter holder (keys `0.weight`, `1.*`);
     forward runs the fused implicit-GEMM + BN (+ ReLU) HIP path on channels-last activations."""
@@ -14,7 +29,11 @@ class ConvBlock(nn.Sequential):
     relu = True
 
     def forward_nlc(self, xs, gate=None, up=None):
-        """xs: list of (B, L, Cin) channels-last level inputs -> (list of outputs, gated output or None)."""
+        """xs: list of (B, L, Cin) channels-last level inputs -> (list of outputs, gated output or None).  The channels-last
+        path has no Dropout stage (DRN builds its blocks without one, model/main_model.py:28): a block made with
+        use_dropout=True is served by `forward` only and refuses to run here in training mode rather than skip it silently."""
+        if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self):
+            raise DrnError("ConvBlock.forward_nlc: Dropout is not applied on the channels-last model path; call the block itself")
         return DF.conv_block(xs, self[0], self[1], self.training, self.compute_dtype, gate=gate, up=up, relu=self.relu)
 
     def forward(self, x):
@@ -60,7 +79,9 @@ class PlainConv(nn.Conv1d):
 
 def conv_with_kaiming_uniform(use_bn=True, use_relu=True, use_dropout=False):
     """Same factory signature and module layout (state_dict keys) as the reference (model/basic_blocks.py:5-33): every
-    combination of BatchNorm / ReLU / Dropout.  DRN itself instantiates BN + ReLU only (model/main_model.py:28)."""
+    combination of BatchNorm / ReLU / Dropout.  DRN itself instantiates BN + ReLU only (model/main_model.py:28), and the
+    model paths (Backbone / FPN / FCOSHead `forward_nlc`) accept exactly that kind of block: they index it as (conv, BatchNorm)
+    and raise DrnError for the use_bn=False variants, which -- like Dropout -- are served by the blocks' own `forward`."""
 
     def make_conv(in_channels, out_channels, kernel_size=3, stride=1, dilation=1):
         if dilation != 1:

@@ -109,6 +109,13 @@ class FusedAdam(object):
             self._seen_gen = gen
             return
         from ._lib import AdamTiledItem
+        # A hipGraph captured earlier (GraphedStep, DualStreamStep's "opt" phase) has the ADDRESSES of the current device
+        # tables and of the copies they point to baked into its drn_adam_bucket / drn_adam_tiled nodes: the superseded tables
+        # stay allocated (never freed, like ops._ws_retired) so that such a replay keeps updating what it updated at capture
+        # time instead of reading pointers out of recycled memory.
+        retired = self.__dict__.setdefault("_retired", [])
+        retired.append((getattr(self, "_keep", None),
+                        [(st.get("ptr"), st.get("tiled"), st.get("mirror"), st.get("mirror_bufs")) for st in self.state]))
         keys, keep = [], []
         for b, st in zip(self.reducer.buckets, self.state):
             dev = st["seg"].device

@@ -1,4 +1,4 @@
-"""Micro-benchmark of drn_skinny_linear on the query-side shapes (M = 32 clips)."""
+"""Micro-benchmark of drn_skinny_group (through ops.skinny_linear, one problem per launch) on the query-side shapes (M = 32 clips)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from drn_amd import ops

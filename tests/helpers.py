@@ -74,13 +74,12 @@ def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=
             got = ten[l].detach().float().cpu().numpy()
             ref = g["%s%d" % (nm, l)]
             assert got.shape == ref.shape, (nm, l, got.shape, ref.shape)
-            np.testing.assert_allclose(got, ref, atol=atol * max(1.0, np.abs(ref).max()), rtol=0,
-                                       err_msg="%s%d" % (nm, l))
+            np.testing.assert_allclose(got, ref, atol=atol, rtol=0, err_msg="%s%d" % (nm, l))
     if taps:
         for t in tap_names:
             cs, smp = checksum(caught[t])
             ref = g["smp/" + t]
-            np.testing.assert_allclose(smp, ref, atol=atol * max(1.0, np.abs(ref).max()), rtol=0, err_msg="smp/" + t)
+            np.testing.assert_allclose(smp, ref, atol=atol, rtol=0, err_msg="smp/" + t)
             n = caught[t].numel()
             np.testing.assert_allclose(cs, g["cs/" + t], atol=atol * n * 0.05 + 1e-3, rtol=1e-5, err_msg="cs/" + t)
     if train:
@@ -112,8 +111,7 @@ def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=
             for key in g:
                 if key.startswith("bn/"):
                     got = sd[key[3:]].float().cpu().numpy()
-                    np.testing.assert_allclose(got, g[key], atol=atol * max(1.0, np.abs(g[key]).max()), rtol=0,
-                                               err_msg=key)
+                    np.testing.assert_allclose(got, g[key], atol=atol, rtol=0, err_msg=key)
     else:
         n_det = np.array([len(b["detections"]) for b in boxes])
         np.testing.assert_array_equal(n_det, g["n_det"])

@@ -84,8 +84,9 @@ def test_loss_total_matches_python_sum():
         l_cls, l_reg, l_iou, _, all3 = DF.fcos_loss(L_, R_, I_, gt.to(dev), levels, B, 2.0, 0.25, 32.0, True)
         d = DF.LossDict(loss_cls=l_cls, loss_reg=l_reg, loss_iou=l_iou)
         if fused:
-            d.all3 = all3
+            d.total = all3
             total = DF.loss_total(d)
+            assert total.data_ptr() == all3.data_ptr(), "the fused branch must hand out the kernel's own total"
         else:
             total = DF.loss_total(dict(d))
         (2.5 * total).sum().backward()
