@@ -77,6 +77,14 @@ class BnApplyDesc(ctypes.Structure):
                 ("ld_gated", c_int32), ("M", c_int32), ("L", c_int32)]
 
 
+class BnTrainDesc(ctypes.Structure):
+    _fields_ = [("stats", c_void_p), ("scale_shift", c_void_p), ("save", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("conv_bias", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("raw", c_void_p), ("out", c_void_p),
+                ("up", c_void_p), ("gate", c_void_p), ("gated", c_void_p), ("momentum", ctypes.c_float), ("eps", ctypes.c_float),
+                ("tiles", c_int32), ("ld_raw", c_int32), ("ld_out", c_int32), ("ld_up", c_int32), ("ldg", c_int32),
+                ("ld_gated", c_int32), ("M", c_int32), ("L", c_int32)]
+
+
 class BnBwdDesc(ctypes.Structure):
     _fields_ = [("dout", c_void_p), ("raw", c_void_p), ("scale_shift", c_void_p), ("save", c_void_p), ("gamma", c_void_p),
                 ("draw", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("ld_dout", c_int32), ("ld_raw", c_int32),

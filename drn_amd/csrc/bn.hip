@@ -294,6 +294,227 @@ extern "C" int drn_bn_apply(const void* raw, int ld_raw, const float* scale_shif
   return bn_apply_launch(&d, 1, C, relu, dtype, stream, "drn_bn_apply");
 }
 
+// ---------------------------------------------------------------- train-mode forward in ONE launch
+// The separate finalize launch (5-8 us: a C/16-workgroup kernel that is one memory round trip long) is gone: every workgroup
+// of the apply pass owns a (row block x 64-channel tile) and merges the slab statistics of ITS 64 channels itself -- tiles x
+// 64 x 2 floats out of L2, all loads of a thread in flight together -- before it touches its rows.  All workgroups of a
+// channel tile run the same instructions on the same numbers, so they agree bit for bit.  What must happen once per channel
+// and IN GROUP ORDER -- scale/shift + (mean, invstd) for backward, the running statistics of a BatchNorm module that several
+// groups share (the head towers, applied once per pyramid level: model/fcos.py:93-102) -- is done by C/64 extra "updater"
+// workgroups at the front of the grid, one per channel tile, which walk the groups one after the other.
+struct BnTrainLv {
+  const void* raw;
+  void* out;
+  const void* up;
+  void* gated;
+  const float* gate;
+  const float* stats;
+  float* ss;
+  float* save;
+  const float* gamma;
+  const float* beta;
+  const float* conv_bias;
+  float* running_mean;
+  float* running_var;
+  float momentum, eps;
+  int ld_raw, ld_out, ld_up, ld_gated, ldg, M, L, tiles, blk0, rows_wg;
+};
+struct BnTrainParams {
+  BnTrainLv lv[DRN_MAX_GROUPS];
+  int n, C, relu, nupd, total_blocks;
+};
+
+// (mean, biased variance) of channel cbase + (tid & 63) from the GEMM epilogue's per-128-row-slab (sum, M2) pairs, merged in
+// double with the parallel-variance formula (Chan et al.).  256 threads = 64 channels x 4 slab lanes; the lanes meet in LDS
+// and are added in a fixed order.  Up to 64 slabs (8192 rows) a thread's pairs are loaded once, all in flight together, and
+// kept in registers for the second pass; longer problems re-read them (L2 hits).
+__device__ __forceinline__ void bn_merge64(const float* __restrict__ st, const int tiles, const int Mrows, const int C,
+                                           const int cbase, double (*shd)[64], double& mean_out, double& var_out) {
+  constexpr int KMAX = 16;
+  const int ci = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const float* __restrict__ p = st + cbase + ci;
+  const bool cached = tiles <= 4 * KMAX;
+  float c0[KMAX], c1[KMAX];
+  double s = 0.0;
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      const int k = min(j + 4 * i, tiles - 1);        // clamped index, masked use: no branch around the loads
+      c0[i] = p[((long)k * 2 + 0) * C];
+      c1[i] = p[((long)k * 2 + 1) * C];
+    }
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+      if (j + 4 * i < tiles) s += (double)c0[i];
+  } else {
+    for (int k = j; k < tiles; k += 4) s += (double)p[((long)k * 2 + 0) * C];
+  }
+  shd[j][ci] = s;
+  __syncthreads();
+  const double mean = ((shd[0][ci] + shd[1][ci]) + (shd[2][ci] + shd[3][ci])) / Mrows;
+  double q = 0.0;
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      const int k = j + 4 * i;
+      if (k < tiles) {
+        const int nt = min(128, Mrows - k * 128);
+        const double d = (double)c0[i] / nt - mean;
+        q += (double)c1[i] + nt * d * d;
+      }
+    }
+  } else {
+    for (int k = j; k < tiles; k += 4) {
+      const int nt = min(128, Mrows - k * 128);
+      const double d = (double)p[((long)k * 2 + 0) * C] / nt - mean;
+      q += (double)p[((long)k * 2 + 1) * C] + nt * d * d;
+    }
+  }
+  __syncthreads();
+  shd[j][ci] = q;
+  __syncthreads();
+  q = (shd[0][ci] + shd[1][ci]) + (shd[2][ci] + shd[3][ci]);
+  double var = q / Mrows;
+  if (var < 0.0) var = 0.0;
+  __syncthreads();                       // shd is free again
+  mean_out = mean;
+  var_out = var;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams P) {
+  constexpr int N = V16<T>::N, NV = 64 / N, RP = 256 / NV;      // 16-byte vectors per 64-channel row piece, rows per pass
+  __shared__ double shd[4][64];
+  __shared__ float s_sc[64], s_sh[64];
+  const int C = P.C, tid = threadIdx.x;
+  if ((int)blockIdx.x < P.nupd) {
+    const int cbase = blockIdx.x * 64, c = cbase + (tid & 63);
+    for (int g = 0; g < P.n; ++g) {
+      const BnTrainLv& G = P.lv[g];
+      double mean, var;
+      bn_merge64(G.stats, G.tiles, G.M, C, cbase, shd, mean, var);
+      if (tid < 64) {
+        const float invstd = (float)(1.0 / sqrt(var + (double)G.eps));
+        const float sc = G.gamma[c] * invstd;
+        G.ss[c] = sc;
+        G.ss[C + c] = G.beta[c] - (float)mean * sc;
+        G.save[c] = (float)mean;
+        G.save[C + c] = invstd;
+        const float cb = G.conv_bias ? G.conv_bias[c] : 0.f;
+        const float unb = (float)(G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var);
+        if (G.running_mean) G.running_mean[c] = (1.f - G.momentum) * G.running_mean[c] + G.momentum * ((float)mean + cb);
+        if (G.running_var) G.running_var[c] = (1.f - G.momentum) * G.running_var[c] + G.momentum * unb;
+      }
+    }
+    return;
+  }
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.n && (int)blockIdx.x >= P.lv[i].blk0) li = i;
+  const BnTrainLv& G = P.lv[li];
+  const int ctiles = C >> 6;
+  const int b = blockIdx.x - G.blk0;
+  const int rblk = b / ctiles, cbase = (b - rblk * ctiles) * 64;
+  {
+    double mean, var;
+    bn_merge64(G.stats, G.tiles, G.M, C, cbase, shd, mean, var);
+    if (tid < 64) {
+      const float invstd = (float)(1.0 / sqrt(var + (double)G.eps));
+      const float sc = G.gamma[cbase + tid] * invstd;
+      s_sc[tid] = sc;
+      s_sh[tid] = G.beta[cbase + tid] - (float)mean * sc;
+    }
+    __syncthreads();
+  }
+  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
+  float sc[N], sh[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { sc[k] = s_sc[v * N + k]; sh[k] = s_sh[v * N + k]; }
+  const T* __restrict__ raw = (const T*)G.raw;
+  const T* __restrict__ up = (const T*)G.up;
+  T* __restrict__ out = (T*)G.out;
+  T* __restrict__ gated = (T*)G.gated;
+  const int M = G.M, L = G.L, relu = P.relu;
+  const long ld_raw = G.ld_raw, ld_out = G.ld_out, ld_up = G.ld_up, ld_gated = G.ld_gated, ldg = G.ldg;
+  const float* __restrict__ gate = G.gate;
+  const int row0 = rblk * G.rows_wg, row1 = min(M, row0 + G.rows_wg);
+  constexpr int U = 4;
+  for (int mb = row0 + ry; mb < row1; mb += U * RP) {
+    float x[U][N], uu[U][N];
+    int sq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = min(mb + u * RP, M - 1);           // clamped index, masked store
+      V16<T>::load(raw + (long)m * ld_raw + c0, x[u]);
+      sq[u] = m / L;
+      if (up) {
+        const int t = m - sq[u] * L;
+        V16<T>::load(up + ((long)sq[u] * (L >> 1) + (t >> 1)) * ld_up + c0, uu[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mb + u * RP;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float y = fmaf(x[u][k], sc[k], sh[k]);
+        x[u][k] = relu ? fmaxf(y, 0.f) : y;
+      }
+      if (up) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[u][k] += uu[u][k];
+      }
+      if (m < row1) {
+        V16<T>::store(out + (long)m * ld_out + c0, x[u]);
+        if (gated) {
+          const float* gp = gate + (long)sq[u] * ldg + c0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) x[u][k] *= gp[k];
+          V16<T>::store(gated + (long)m * ld_gated + c0, x[u]);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int drn_bn_train_apply(const DrnBnTrainDesc* d, int n, int C, int relu, int dtype, void* stream) {
+  drn_clear_status();
+  const char* who = "drn_bn_train_apply";
+  DRN_CHECK_ARG(d && n >= 1 && n <= DRN_MAX_GROUPS && C > 0 && C % 64 == 0, "%s: bad args (C must be a multiple of 64)", who);
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "%s: bad dtype %d", who, dtype);
+  const int vn = dtype == DRN_BF16 ? 8 : 4;
+  const int RP = 256 / (64 / vn);
+  BnTrainParams P;
+  memset(&P, 0, sizeof(P));
+  P.n = n; P.C = C; P.relu = relu; P.nupd = C / 64;
+  long m_all = 0;
+  for (int i = 0; i < n; ++i) m_all += d[i].M;
+  // four rows per thread; eight once the launch would pass ~4096 workgroups
+  const int rows_wg = ((m_all + 4 * RP - 1) / (4 * RP)) * (C / 64) > 4096 ? 8 * RP : 4 * RP;
+  int blocks = P.nupd;
+  for (int i = 0; i < n; ++i) {
+    const DrnBnTrainDesc& s = d[i];
+    DRN_CHECK_ARG(s.raw && s.out && s.stats && s.scale_shift && s.save && s.gamma && s.beta && s.M > 0 && s.L > 0 && s.M % s.L == 0 &&
+                  s.tiles == (s.M + 127) / 128, "%s: bad level %d", who, i);
+    DRN_CHECK_ARG(!s.up || (s.L % 2 == 0), "%s: upsample-add needs an even sequence length", who);
+    DRN_CHECK_ARG((s.gate != nullptr) == (s.gated != nullptr), "%s: gate and gated must come together", who);
+    DRN_CHECK_ARG(s.ld_raw % vn == 0 && s.ld_out % vn == 0 && (!s.up || s.ld_up % vn == 0) && (!s.gated || (s.ld_gated % vn == 0 && s.ldg % 4 == 0)),
+                  "%s: ld must be 16-byte multiples", who);
+    BnTrainLv& G = P.lv[i];
+    G.raw = s.raw; G.out = s.out; G.up = s.up; G.gated = s.gated; G.gate = s.gate;
+    G.stats = s.stats; G.ss = s.scale_shift; G.save = s.save; G.gamma = s.gamma; G.beta = s.beta; G.conv_bias = s.conv_bias;
+    G.running_mean = s.running_mean; G.running_var = s.running_var; G.momentum = s.momentum; G.eps = s.eps;
+    G.ld_raw = s.ld_raw; G.ld_out = s.ld_out; G.ld_up = s.ld_up; G.ld_gated = s.ld_gated; G.ldg = s.ldg; G.M = s.M; G.L = s.L;
+    G.tiles = s.tiles; G.blk0 = blocks; G.rows_wg = rows_wg;
+    blocks += cdiv(s.M, rows_wg) * (C / 64);
+  }
+  P.total_blocks = blocks;
+  if (dtype == DRN_BF16) bn_train_apply_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(P);
+  else bn_train_apply_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(P);
+  return drn_launch_status(who);
+}
+
 // ---------------------------------------------------------------- backward
 // The ReLU mask is recomputed as fma(raw, scale, shift) > 0 with the forward's own scale/shift, so it is
 // bit-identical to the forward decision even when `out` had the FPN upsample added on top.
@@ -490,6 +711,252 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams P) 
   }
 }
 
+// ---- backward in TWO launches for C % 64 == 0 (every layer of the model): the same (row block x 64-channel tile) geometry as
+// the forward.  Reduce: 256 threads = NV 16-byte channel vectors x RP row lanes, four rows (eight loads) in flight per thread,
+// the row lanes combined through LDS in a fixed order -> partial[rb][2][C], rb <= 64 row blocks.  Apply: every workgroup sums
+// the <= 64 x 2 partials of its 64 channels itself (double, fixed order) and derives the three coefficients before it touches
+// its rows -- the finalize launch is gone; dgamma / dbeta are written by C/64 updater workgroups that walk the levels in order
+// (levels sharing one module accumulate in that order).
+struct BnBwd2Lv {
+  const void* dout;
+  const void* raw;
+  void* draw;
+  const float* ss;
+  const float* save;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  float* partial;   // [rb][2][C]
+  int ld_dout, ld_raw, ld_draw, M, accumulate, rb, rrows, rblk0, arows, ablk0;
+};
+struct BnBwd2Params {
+  BnBwd2Lv lv[DRN_MAX_GROUPS];
+  int n, C, relu, nupd;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce64_kernel(const BnBwd2Params P) {
+  constexpr int N = V16<T>::N, NV = 64 / N, RP = 256 / NV;
+  __shared__ float red[2][RP][65];
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.n && (int)blockIdx.x >= P.lv[i].rblk0) li = i;
+  const BnBwd2Lv& G = P.lv[li];
+  const int C = P.C, relu = P.relu, M = G.M, tid = threadIdx.x;
+  const int ctiles = C >> 6;
+  const int b = blockIdx.x - G.rblk0;
+  const int rblk = b / ctiles, cbase = (b - rblk * ctiles) * 64;
+  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
+  const T* __restrict__ dout = (const T*)G.dout;
+  const T* __restrict__ raw = (const T*)G.raw;
+  float mean[N], istd[N], sc[N], sh[N], sg[N], sx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    mean[k] = G.save[c0 + k];
+    istd[k] = G.save[C + c0 + k];
+    sc[k] = G.ss[c0 + k];
+    sh[k] = G.ss[C + c0 + k];
+    sg[k] = 0.f;
+    sx[k] = 0.f;
+  }
+  const long ldd = G.ld_dout, ldr = G.ld_raw;
+  const int row0 = rblk * G.rrows, row1 = min(M, row0 + G.rrows);
+  constexpr int U = 4;
+  for (int mb = row0 + ry; mb < row1; mb += U * RP) {
+    float g[U][N], x[U][N];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = min(mb + u * RP, M - 1);           // clamped index, masked use
+      V16<T>::load(dout + (long)m * ldd + c0, g[u]);
+      V16<T>::load(raw + (long)m * ldr + c0, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = mb + u * RP < row1;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float gg = (!in || (relu && !(fmaf(x[u][k], sc[k], sh[k]) > 0.f))) ? 0.f : g[u][k];
+        sg[k] += gg;
+        sx[k] = fmaf(gg, (x[u][k] - mean[k]) * istd[k], sx[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    red[0][ry][v * N + k] = sg[k];
+    red[1][ry][v * N + k] = sx[k];
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int kind = tid >> 6, cc = tid & 63;
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) a += red[kind][r][cc];
+    G.partial[((long)rblk * 2 + kind) * C + cbase + cc] = a;
+  }
+}
+
+// column sums (double) of the rb partial pairs of channel cbase + (tid & 63): 64 channels x 4 lanes, combined in LDS
+__device__ __forceinline__ void bn_bwd_sum64(const float* __restrict__ pp, const int rb, const int C, const int cbase,
+                                             double (*shd)[4][64], double& sg_out, double& sx_out) {
+  constexpr int KMAX = 16;
+  const int ci = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const float* __restrict__ p = pp + cbase + ci;
+  double sg = 0.0, sx = 0.0;
+  if (rb <= 4 * KMAX) {
+    float v0[KMAX], v1[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      const int k = min(j + 4 * i, rb - 1);
+      v0[i] = p[((long)k * 2 + 0) * C];
+      v1[i] = p[((long)k * 2 + 1) * C];
+    }
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+      if (j + 4 * i < rb) {
+        sg += (double)v0[i];
+        sx += (double)v1[i];
+      }
+  } else {
+    for (int k = j; k < rb; k += 4) {
+      sg += (double)p[((long)k * 2 + 0) * C];
+      sx += (double)p[((long)k * 2 + 1) * C];
+    }
+  }
+  shd[0][j][ci] = sg;
+  shd[1][j][ci] = sx;
+  __syncthreads();
+  sg_out = (shd[0][0][ci] + shd[0][1][ci]) + (shd[0][2][ci] + shd[0][3][ci]);
+  sx_out = (shd[1][0][ci] + shd[1][1][ci]) + (shd[1][2][ci] + shd[1][3][ci]);
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply64_kernel(const BnBwd2Params P) {
+  constexpr int N = V16<T>::N, NV = 64 / N, RP = 256 / NV;
+  __shared__ double shd[2][4][64];
+  __shared__ float s_k[3][64];
+  const int C = P.C, tid = threadIdx.x;
+  if ((int)blockIdx.x < P.nupd) {
+    const int cbase = blockIdx.x * 64, c = cbase + (tid & 63);
+    for (int g = 0; g < P.n; ++g) {
+      const BnBwd2Lv& G = P.lv[g];
+      double sg, sx;
+      bn_bwd_sum64(G.partial, G.rb, C, cbase, shd, sg, sx);
+      if (tid < 64) {
+        const float dg = (float)sx, db = (float)sg;
+        if (G.dgamma) G.dgamma[c] = G.accumulate ? G.dgamma[c] + dg : dg;
+        if (G.dbeta) G.dbeta[c] = G.accumulate ? G.dbeta[c] + db : db;
+      }
+    }
+    return;
+  }
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.n && (int)blockIdx.x >= P.lv[i].ablk0) li = i;
+  const BnBwd2Lv& G = P.lv[li];
+  const int relu = P.relu, M = G.M;
+  const int ctiles = C >> 6;
+  const int b = blockIdx.x - G.ablk0;
+  const int rblk = b / ctiles, cbase = (b - rblk * ctiles) * 64;
+  {
+    double sg, sx;
+    bn_bwd_sum64(G.partial, G.rb, C, cbase, shd, sg, sx);
+    if (tid < 64) {
+      const int c = cbase + tid;
+      const float mean = G.save[c], istd = G.save[C + c];
+      const float s = G.gamma[c] * istd;
+      const float dg = (float)sx, db = (float)sg;
+      const float invM = 1.f / (float)M;
+      s_k[0][tid] = s;
+      s_k[1][tid] = -s * dg * istd * invM;
+      s_k[2][tid] = -s * db * invM + s * dg * istd * mean * invM;
+    }
+    __syncthreads();
+  }
+  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
+  float sc[N], sh[N], ka[N], kb[N], kc[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    sc[k] = G.ss[c0 + k];
+    sh[k] = G.ss[C + c0 + k];
+    ka[k] = s_k[0][v * N + k];
+    kb[k] = s_k[1][v * N + k];
+    kc[k] = s_k[2][v * N + k];
+  }
+  const T* __restrict__ dout = (const T*)G.dout;
+  const T* __restrict__ raw = (const T*)G.raw;
+  T* __restrict__ draw = (T*)G.draw;
+  const long ldd = G.ld_dout, ldr = G.ld_raw, ldw = G.ld_draw;
+  const int row0 = rblk * G.arows, row1 = min(M, row0 + G.arows);
+  constexpr int U = 4;
+  for (int mb = row0 + ry; mb < row1; mb += U * RP) {
+    float g[U][N], x[U][N];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = min(mb + u * RP, M - 1);
+      V16<T>::load(dout + (long)m * ldd + c0, g[u]);
+      V16<T>::load(raw + (long)m * ldr + c0, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = mb + u * RP;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float gg = (relu && !(fmaf(x[u][k], sc[k], sh[k]) > 0.f)) ? 0.f : g[u][k];
+        x[u][k] = fmaf(ka[k], gg, fmaf(kb[k], x[u][k], kc[k]));
+      }
+      if (m < row1) V16<T>::store(draw + (long)m * ldw + c0, x[u]);
+    }
+  }
+}
+
+static int bn_bwd_launch64(const DrnBnBwdDesc* d, int n, int C, int relu, float* ws, int dtype, hipStream_t stream, const char* who) {
+  const int vn = dtype == DRN_BF16 ? 8 : 4;
+  const int RP = 256 / (64 / vn);
+  const int ctiles = C / 64;
+  BnBwd2Params P;
+  memset(&P, 0, sizeof(P));
+  P.n = n; P.C = C; P.relu = relu; P.nupd = ctiles;
+  long m_all = 0;
+  for (int i = 0; i < n; ++i) m_all += d[i].M;
+  // reduce: row blocks of a multiple of 4*RP rows (four rows per thread and trip), sized for ~512 workgroups per launch, at most
+  // 64 per level (what an apply workgroup re-reads: 64 x 2 x 64 floats = 32 KB)
+  int rrows = (int)((m_all * ctiles + 511) / 512);
+  rrows = cdiv(rrows < 1 ? 1 : rrows, 4 * RP) * (4 * RP);
+  const int arows = ((m_all + 4 * RP - 1) / (4 * RP)) * ctiles > 4096 ? 8 * RP : 4 * RP;
+  int rb_total = 0, ab = P.nupd;
+  for (int i = 0; i < n; ++i) {
+    const DrnBnBwdDesc& s = d[i];
+    DRN_CHECK_ARG(s.dout && s.raw && s.scale_shift && s.save && s.gamma && s.draw && s.M > 0, "%s: bad level %d", who, i);
+    DRN_CHECK_ARG(s.ld_dout % vn == 0 && s.ld_raw % vn == 0 && s.ld_draw % vn == 0, "%s: ld must be 16-byte multiples", who);
+    BnBwd2Lv& G = P.lv[i];
+    G.dout = s.dout; G.raw = s.raw; G.draw = s.draw; G.ss = s.scale_shift; G.save = s.save; G.gamma = s.gamma;
+    G.dgamma = s.dgamma; G.dbeta = s.dbeta; G.ld_dout = s.ld_dout; G.ld_raw = s.ld_raw; G.ld_draw = s.ld_draw; G.M = s.M;
+    G.accumulate = s.accumulate;
+    int rr = rrows;
+    if (cdiv(s.M, rr) > 64) rr = cdiv(cdiv(s.M, 64), 4 * RP) * (4 * RP);
+    G.rrows = rr;
+    G.rb = cdiv(s.M, rr);
+    G.partial = ws + (long)i * (2 * 256 + 3) * C;
+    G.rblk0 = rb_total;
+    rb_total += G.rb * ctiles;
+    G.arows = arows;
+    G.ablk0 = ab;
+    ab += cdiv(s.M, arows) * ctiles;
+  }
+  if (dtype == DRN_BF16) {
+    bn_bwd_reduce64_kernel<bf16_t><<<rb_total, 256, 0, stream>>>(P);
+    bn_bwd_apply64_kernel<bf16_t><<<ab, 256, 0, stream>>>(P);
+  } else {
+    bn_bwd_reduce64_kernel<float><<<rb_total, 256, 0, stream>>>(P);
+    bn_bwd_apply64_kernel<float><<<ab, 256, 0, stream>>>(P);
+  }
+  return drn_launch_status(who);
+}
+
 // draw may alias dout (in place).  ws >= n * (2*256 + 3) * C floats.
 static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* ws, int dtype, void* stream_, const char* who) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -497,6 +964,7 @@ static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* w
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "%s: bad dtype %d", who, dtype);
   const int vn = dtype == DRN_BF16 ? 8 : 4;
   DRN_CHECK_ARG(C % vn == 0, "%s: C must be a 16-byte multiple", who);
+  if (C % 64 == 0) return bn_bwd_launch64(d, n, C, relu, ws, dtype, stream, who);
   BnBwdParams P;
   memset(&P, 0, sizeof(P));
   P.n = n; P.C = C; P.relu = relu;

@@ -588,6 +588,8 @@ class _ConvBlockFn(torch.autograd.Function):
         ops.gemm_nt(descs, code)
         bn = meta.bn
         sss, saves = [], []
+        fused = meta.training and Cout % 64 == 0       # statistics merge + running statistics + apply in ONE launch
+        track = False
         if meta.training:
             if bn.momentum is None:
                 raise DrnError("cumulative-average BatchNorm (momentum=None) is not supported")
@@ -599,8 +601,9 @@ class _ConvBlockFn(torch.autograd.Function):
                 sss.append(ss)
                 saves.append(sv)
             track = bn.track_running_stats and bn.running_mean is not None
-            ops.bn_finalize(groups, Cout, gamma, beta, cbias, bn.running_mean if track else None,
-                            bn.running_var if track else None, bn.momentum, bn.eps)
+            if not fused:
+                ops.bn_finalize(groups, Cout, gamma, beta, cbias, bn.running_mean if track else None,
+                                bn.running_var if track else None, bn.momentum, bn.eps)
             if track and bn.num_batches_tracked is not None:
                 bump_bn_counter(bn.num_batches_tracked, nl)
         else:
@@ -620,8 +623,15 @@ class _ConvBlockFn(torch.autograd.Function):
                 upl = up
             levels.append(dict(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, L=Lo, up=upl,
                                ld_up=upl.stride(1) if upl is not None else 0, gate=gate, gated=gated, ld_gated=Cout))
+            if fused:
+                levels[-1].update(stats=stats[l], tiles=stats[l].shape[0], save=saves[l], gamma=gamma, beta=beta, conv_bias=cbias,
+                                  running_mean=bn.running_mean if track else None, running_var=bn.running_var if track else None,
+                                  momentum=bn.momentum, eps=bn.eps)
             outs.append(out)
-        ops.bn_apply_multi(levels, Cout, code, relu=meta.relu)            # all pyramid levels in one launch
+        if fused:
+            ops.bn_train_apply(levels, Cout, code, relu=meta.relu)        # all pyramid levels, statistics included, in one launch
+        else:
+            ops.bn_apply_multi(levels, Cout, code, relu=meta.relu)        # all pyramid levels in one launch
         if relu_tap is not None and meta.relu:
             for l in range(nl):
                 _tap_relu(weight, l, outs[l], up)
@@ -822,7 +832,9 @@ class _MultiConvFn(torch.autograd.Function):
                 ops.bn_eval_scale_shift(Cout, gammas[l], betas[l], None, bn.running_mean, bn.running_var, bn.eps, ss)
                 saves.append(ss)
             sss.append(ss)
-        if fin:                                                # every level has its own BatchNorm module: one launch
+        # C % 64 == 0 (every FPN block): the apply launches merge the statistics themselves; otherwise a finalize launch first
+        fused = bool(fin) and all(g[5] % 64 == 0 for g in geo)
+        if fin and not fused:                                  # every level has its own BatchNorm module: one launch
             for grp in ([fin] if same_c else [[f] for f in fin]):
                 ops.bn_finalize_multi(grp, grp[0]["ss"].shape[1])
         outs = [None] * n
@@ -832,13 +844,16 @@ class _MultiConvFn(torch.autograd.Function):
             out = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
             up = outs[l + 1] if (chain_up and l + 1 < n) else None
             lv = dict(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, L=Lo, up=up, ld_up=Cout if up is not None else 0)
+            if fused:
+                lv.update(fin[l])
+            apply = ops.bn_train_apply if fused else ops.bn_apply_multi
             if chain_up or not same_c:
-                ops.bn_apply_multi([lv], Cout, code)          # out_l reads out_{l+1}: one launch per level, in order
+                apply([lv], Cout, code)                       # out_l reads out_{l+1}: one launch per level, in order
             else:
                 levels.append(lv)
             outs[l] = out
         if levels:
-            ops.bn_apply_multi(levels, geo[0][5], code)
+            (ops.bn_train_apply if fused else ops.bn_apply_multi)(levels, geo[0][5], code)
         if relu_tap is not None:
             for l in range(n):
                 _tap_relu(weights[l], 0, outs[l], outs[l + 1] if (chain_up and l + 1 < n) else None)

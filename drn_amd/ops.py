@@ -382,6 +382,24 @@ def bn_apply_multi(levels, C, dtype, relu=True):
     check(lib().drn_bn_apply_multi(arr, len(levels), C, int(relu), dtype, _stream()), "drn_bn_apply_multi")
 
 
+def bn_train_apply(levels, C, dtype, relu=True):
+    """Train-mode BatchNorm (+ReLU) forward of up to DRN_MAX_GROUPS levels in ONE launch (C % 64 == 0): levels = list of dicts
+    with the statistics side (stats, tiles, ss, save, gamma, beta[, conv_bias, running_mean, running_var], momentum, eps) and
+    the apply side (raw, ld_raw, out, ld_out, M, L[, up, ld_up, gate, gated, ld_gated]) of drn_bn_finalize_multi +
+    drn_bn_apply_multi; the groups' running statistics are updated in list order."""
+    arr = (_lib.BnTrainDesc * len(levels))()
+    for d, v in zip(arr, levels):
+        gate = v.get("gate")
+        d.stats, d.scale_shift, d.save, d.gamma, d.beta = _p(v["stats"]), _p(v["ss"]), _p(v["save"]), _p(v["gamma"]), _p(v["beta"])
+        d.conv_bias, d.running_mean, d.running_var = _p(v.get("conv_bias")), _p(v.get("running_mean")), _p(v.get("running_var"))
+        d.raw, d.out, d.up, d.gate, d.gated = _p(v["raw"]), _p(v["out"]), _p(v.get("up")), _p(gate), _p(v.get("gated"))
+        d.momentum, d.eps, d.tiles = v["momentum"], v["eps"], v["tiles"]
+        d.ld_raw, d.ld_out, d.ld_up = v["ld_raw"], v["ld_out"], v.get("ld_up", 0)
+        d.ldg, d.ld_gated = (gate.stride(0) if gate is not None else 0), v.get("ld_gated", 0)
+        d.M, d.L = v["M"], v["L"]
+    check(lib().drn_bn_train_apply(arr, len(levels), C, int(relu), dtype, _stream()), "drn_bn_train_apply")
+
+
 def bn_bwd_multi(levels, C, dtype, relu=True):
     """levels: list of dicts(dout, ld_dout, raw, ld_raw, ss, save, gamma, draw, ld_draw, dgamma, dbeta, accumulate, M)."""
     arr = (_lib.BnBwdDesc * len(levels))()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 3
+#define DRN_ABI_VERSION 4
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
@@ -188,6 +188,28 @@ typedef struct DrnBnApplyDesc {
   int32_t ld_raw, ld_out, ld_up, ldg, ld_gated, M, L;
 } DrnBnApplyDesc;
 int drn_bn_apply_multi(const DrnBnApplyDesc* descs /*host*/, int n, int C, int relu, int dtype, void* stream);
+/* Train-mode forward in ONE launch (C % 64 == 0): statistics merge + running-statistics update + apply.  Each workgroup of the
+ * apply pass merges the slab statistics of its own 64 channels; scale_shift / save / the running statistics are written once
+ * per channel, groups in order (groups may share a BatchNorm module: model/fcos.py:93-102).  Replaces drn_bn_finalize(_multi)
+ * + drn_bn_apply_multi for nn.BatchNorm1d + ReLU in training (model/basic_blocks.py:23-26). */
+typedef struct DrnBnTrainDesc {
+  const float* stats; /* [tiles][2][C] from drn_gemm_nt, tiles = ceil(M/128) */
+  float* scale_shift; /* out [2][C] */
+  float* save;        /* out [2][C]: mean, invstd */
+  const float* gamma;
+  const float* beta;
+  const float* conv_bias; /* or NULL */
+  float* running_mean;    /* or NULL */
+  float* running_var;     /* or NULL */
+  const void* raw;
+  void* out;
+  const void* up;    /* or NULL */
+  const float* gate; /* or NULL (with gated) */
+  void* gated;
+  float momentum, eps;
+  int32_t tiles, ld_raw, ld_out, ld_up, ldg, ld_gated, M, L;
+} DrnBnTrainDesc;
+int drn_bn_train_apply(const DrnBnTrainDesc* descs /*host*/, int n, int C, int relu, int dtype, void* stream);
 /* dRaw, dgamma, dbeta from dOut; ReLU mask recomputed from raw; draw may alias dout. */
 int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld_raw, const float* scale_shift, const float* save,
                const float* gamma, void* draw, int ld_draw, float* dgamma, float* dbeta, int accumulate, int M, int C, int relu,
