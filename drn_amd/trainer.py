@@ -48,17 +48,59 @@ def to_device(batch, device):
     return names, (mv(tok), mv(qlen), mv(feats), mv(pse), mv(gt), nprops, nframes)
 
 
+class _StepSlot(object):
+    """Static device inputs + the captured hipGraph of one training-step geometry (clips, proposals, feature dim, padded query
+    length)."""
+
+    def __init__(self, key, device, pse_dtype, gt_dtype):
+        B, T, D, Lq = key
+        self.key = key
+        self.tok = torch.zeros((B, Lq), dtype=torch.int64, device=device)
+        self.qlen = torch.zeros((B,), dtype=torch.int64, device=device)
+        self.feats = torch.zeros((B, T, D), dtype=torch.float32, device=device)
+        self.pse = torch.zeros((B, T, 2), dtype=pse_dtype, device=device)
+        self.gt = torch.zeros((B, 2), dtype=gt_dtype, device=device)
+        self.args = (self.tok, self.qlen, self.feats, self.pse, self.gt, None, None)
+        self.seen, self.graph, self.out = 0, None, None
+
+    def load(self, tok, qlen, feats, pse, gt):
+        """Copy one batch (host or device tensors) into the static buffers; the token matrix is zero-padded (padding_idx 0)
+        out to the slot's query length -- the kernels read the true lengths from `qlen` on the device."""
+        L = tok.shape[1]
+        self.tok[:, :L].copy_(tok, non_blocking=True)
+        if L < self.tok.shape[1]:
+            self.tok[:, L:].zero_()
+        self.qlen.copy_(qlen, non_blocking=True)
+        self.feats.copy_(feats, non_blocking=True)
+        self.pse.copy_(pse, non_blocking=True)
+        self.gt.copy_(gt, non_blocking=True)
+
+
 class Trainer(object):
-    def __init__(self, model, stage, lr=1e-3, clip_gradient=0.5, world_size=1, fused=True):
+    def __init__(self, model, stage, lr=1e-3, clip_gradient=0.5, world_size=1, fused=True, graph=False, lq_bucket=4,
+                 graph_warmup=2, max_graphs=16):
+        """graph=True (fused stages only): `train_step` replays the step as a hipGraph -- the launch path bench.py measures --
+        one capture per input geometry (clips, proposals, feature dim, query length rounded up to a multiple of `lq_bucket`:
+        the query kernels take the true lengths from the device, so padding changes no value); the first `graph_warmup`
+        steps of a geometry, a ragged last batch beyond `max_graphs` geometries and everything in stage 2 run eagerly.  With
+        world_size > 1 forward + backward replay and the gradient exchange + optimizer run eagerly after them."""
         self.model, self.stage, self.clip = model, stage, clip_gradient
         self.params, self.lr, self.default_epochs, self.which = stage_plan(model, stage, lr)
         self.device = next(model.parameters()).device
         self.fused = fused and stage != 2 and self.device.type == "cuda"
         self.world_size = world_size
+        self.graph = bool(graph) and self.fused
+        self.lq_bucket, self.graph_warmup, self.max_graphs = max(int(lq_bucket), 1), max(int(graph_warmup), 1), max_graphs
+        self._slots = {}
+        # every step of a graph-mode trainer -- eager ones included -- runs on ONE side stream: autograd's AccumulateGrad nodes
+        # remember the stream they were created on, and warm-up, capture and replay must agree on it (drn_amd/graph.py)
+        self.stream = torch.cuda.Stream(device=self.device) if self.graph else None
         if self.fused:
             from .dist import GradReducer
             from .optim import FusedAdam
+            # (hipGraph + several ranks: collectives stay outside the captured region -> no launches from backward hooks)
             self.reducer = GradReducer(self.params, world_size=world_size, adjacent=model.grad_stack_groups(),
+                                       overlap=not (self.graph and world_size > 1),
                                        **({"bucket_bytes": 1 << 30} if world_size == 1 else {}))   # one process: one bucket
             self.opt = FusedAdam(self.reducer, lr=self.lr, max_norm=clip_gradient if clip_gradient is not None else 0.0)
         else:
@@ -67,9 +109,73 @@ class Trainer(object):
             self.opt = torch.optim.Adam(self.params, self.lr)
             self.opt.zero_grad()
 
+    # ------------------------------------------------------------------------------------------ hipGraph mode
+    def _slot_for(self, tok, feats, pse, gt):
+        B, T, D = feats.shape
+        Lq = -(-int(tok.shape[1]) // self.lq_bucket) * self.lq_bucket
+        key = (int(B), int(T), int(D), Lq)
+        slot = self._slots.get(key)
+        if slot is None:
+            if len(self._slots) >= self.max_graphs:
+                return None
+            slot = self._slots[key] = _StepSlot(key, self.device, pse.dtype, gt.dtype)
+        return slot
+
+    def _fwd_bwd(self, args):
+        self.reducer.zero()
+        _, loss_dict = self.model(*args)
+        DF.backward(select_loss(loss_dict, self.which))
+        self.reducer.collect()
+        return loss_dict
+
+    def _exchange_and_update(self):
+        self.reducer.finish()
+        self.opt.step()
+
+    def _graph_step(self, args):
+        tok, qlen, feats, pse, gt = args[:5]
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)                       # inputs produced on the caller's stream
+        whole = self.world_size == 1                       # one process: the optimizer replays with the rest
+        with torch.cuda.stream(self.stream):
+            slot = self._slot_for(tok, feats, pse, gt)
+            if slot is None or pse.dtype != slot.pse.dtype or gt.dtype != slot.gt.dtype:
+                dev_args = tuple(a.to(self.device, non_blocking=True) if torch.is_tensor(a) else a for a in args)
+                out = self._fwd_bwd(dev_args)
+                self._exchange_and_update()
+            else:
+                slot.load(tok, qlen, feats, pse, gt)
+                if slot.graph is None and slot.seen >= self.graph_warmup:
+                    if self.world_size > 1:
+                        self.reducer.rearm()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.stream):
+                        slot.out = self._fwd_bwd(slot.args)
+                        if whole:
+                            self._exchange_and_update()
+                    slot.graph = g
+                if slot.graph is not None:
+                    if self.world_size > 1:
+                        self.reducer.rearm()               # hooks only ran at capture time
+                    slot.graph.replay()
+                    if not whole:
+                        self._exchange_and_update()
+                    out = slot.out
+                else:
+                    slot.seen += 1
+                    out = self._fwd_bwd(slot.args)
+                    self._exchange_and_update()
+        cur.wait_stream(self.stream)
+        return out
+
     def train_step(self, args):
-        """One main.py:218-243 iteration on device-resident arguments.  Returns the loss dict (device tensors, no sync)."""
+        """One main.py:218-243 iteration.  Returns the loss dict (device tensors, no sync).  Arguments: the model's 7
+        positional inputs, device-resident (graph mode also takes host tensors: they are copied straight into the static
+        input buffers of the captured step; the returned losses are then views of replay-owned memory -- read them before the
+        next step)."""
         self.model.train()
+        if self.graph:
+            return self._graph_step(args)
         if self.fused:
             self.reducer.zero()
         _, loss_dict = self.model(*args)
@@ -107,7 +213,11 @@ class Trainer(object):
             sampler.set_epoch(epoch)
         total, n = None, 0
         for batch in loader:
-            _, args = to_device(batch, self.device)
+            if self.graph:                                 # host tensors go straight into the captured step's input buffers
+                names, pse, feats, gt, tok, qlen, nprops, nframes = batch
+                args = (tok, qlen, feats, pse, gt, nprops, nframes)
+            else:
+                _, args = to_device(batch, self.device)
             bs = args[2].size(0)
             loss = select_loss(self.train_step(args), self.which).detach().reshape(-1)[0] * bs
             total = loss if total is None else total + loss
