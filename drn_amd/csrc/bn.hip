@@ -490,8 +490,10 @@ extern "C" int drn_bn_train_apply(const DrnBnTrainDesc* d, int n, int C, int rel
   P.n = n; P.C = C; P.relu = relu; P.nupd = C / 64;
   long m_all = 0;
   for (int i = 0; i < n; ++i) m_all += d[i].M;
-  // four rows per thread; eight once the launch would pass ~4096 workgroups
-  const int rows_wg = ((m_all + 4 * RP - 1) / (4 * RP)) * (C / 64) > 4096 ? 8 * RP : 4 * RP;
+  // four rows per thread and trip; more trips per workgroup once the launch would exceed ~1024 workgroups (what the chip holds at
+  // once): every workgroup pays the statistics merge of its channel tile, so on the big tensors fewer, longer workgroups win
+  const long wg4 = ((m_all + 4 * RP - 1) / (4 * RP)) * (C / 64);
+  const int rows_wg = 4 * RP * (int)(wg4 > 1024 ? (wg4 + 1023) / 1024 : 1);
   int blocks = P.nupd;
   for (int i = 0; i < n; ++i) {
     const DrnBnTrainDesc& s = d[i];

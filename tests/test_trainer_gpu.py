@@ -70,3 +70,55 @@ def test_fit_evaluate_checkpoint_on_mini_dataset(tmp_path):
     if files:                                                                # a best checkpoint exists once R@k > 0
         m2 = hip_model(3, cfg=cfg)
         T.load_checkpoint(m2, os.path.join(str(tmp_path / "snap"), files[0]), map_location="cuda:0")
+
+
+def _varying_batches(n, B, T, D, seed=3):
+    """n synthetic batches whose longest query differs (3, 5, 7 words -> padded lengths 4 and 8), the last one ragged (B - 1 clips)."""
+    from drn_amd.utils.synthetic import VOCAB_SIZE, synthetic_batch
+    out = []
+    for i in range(n):
+        nb = B - 1 if i == n - 1 else B
+        b = list(synthetic_batch(nb, T, D, seed=seed + i))
+        g = torch.Generator().manual_seed(100 + i)
+        lmax = 3 + (i * 2) % 6                                  # 3, 5, 7, 3, ...
+        lens = torch.sort(torch.randint(2, lmax + 1, (nb,), generator=g), descending=True)[0]
+        lens[0] = lmax                                          # (sorted descending: the first clip carries the longest query)
+        tok = torch.zeros((nb, lmax), dtype=torch.int64)
+        for r in range(nb):
+            tok[r, :int(lens[r])] = torch.randint(1, VOCAB_SIZE + 1, (int(lens[r]),), generator=g)
+        b[0], b[1] = tok, lens
+        out.append(b)
+    return out
+
+
+@pytest.mark.parametrize("dtype,stage", [(torch.bfloat16, 1), (torch.float32, 3)])
+def test_graph_trainer_is_bit_identical_to_eager(dtype, stage):
+    """Trainer(graph=True) -- train.py's default -- replays each step as a hipGraph from static input buffers, tokens padded to
+    the geometry's query length; fed batches of varying query length and a ragged last batch it must leave EVERY parameter and
+    buffer bit-identical to the eager trainer, and report the same losses (main.py:198-252 is the loop both implement)."""
+    from drn_amd import functional as DF
+    from drn_amd import trainer as T
+    B, Tp, D, n = 4, 32, 64, 13
+    batches = _varying_batches(n, B, Tp, D)
+    order = [0, 1, 2, 0, 1, 2, 0, 1, 2, 12, 0, 1, 2]           # every geometry passes warm-up, capture and replay; one ragged step
+    runs = []
+    for graph in (False, True):
+        m = hip_model(stage)
+        m.set_compute_dtype(dtype)
+        tr = T.Trainer(m, stage, lr=1e-4 if stage == 1 else 1.0, clip_gradient=0.5, graph=graph, lq_bucket=4)   # (stage 3 divides lr by 1e4)
+        assert tr.graph == graph
+        losses = []
+        for i in order:
+            b = batches[i]
+            args = b if graph else [t.to("cuda:0") for t in b]   # graph mode takes the host batch as the loader yields it
+            ld = tr.train_step(args)
+            losses.append([float(ld[k].detach().reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
+        torch.cuda.synchronize()
+        DF.flush_bn_counters()
+        if graph:
+            assert sum(s.graph is not None for s in tr._slots.values()) >= 2, "no step was ever replayed"
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    (l0, s0), (l1, s1) = runs
+    assert np.array_equal(np.array(l0), np.array(l1)), (l0, l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), (k, float((s0[k].float() - s1[k].float()).abs().max()))

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--snapshot-pref", default="runs/drn")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="launch every kernel of a step from Python instead of replaying it as a hipGraph (stages 1 and 3)")
     args = ap.parse_args()
 
     rank, local, world = ddist.init_from_env()
@@ -67,7 +69,8 @@ def main():
         start_epoch, picked = T.load_checkpoint(model, args.resume, map_location=dev)
         if rank == 0:
             print("resumed %d tensors from %s (epoch %d)" % (len(picked), args.resume, start_epoch))
-    tr = T.Trainer(model, args.stage, lr=args.lr or cfg.get("lr", 1e-3), clip_gradient=cfg.get("clip_gradient", 0.5), world_size=world)
+    tr = T.Trainer(model, args.stage, lr=args.lr or cfg.get("lr", 1e-3), clip_gradient=cfg.get("clip_gradient", 0.5), world_size=world,
+                   graph=args.graph)
     if args.evaluate:
         if rank == 0:
             _, topks, accs, _ = tr.evaluate(test_loader, id2word)
