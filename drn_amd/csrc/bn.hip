@@ -416,6 +416,33 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
   const int ctiles = C >> 6;
   const int b = blockIdx.x - G.blk0;
   const int rblk = b / ctiles, cbase = (b - rblk * ctiles) * 64;
+  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
+  const T* __restrict__ raw = (const T*)G.raw;
+  const T* __restrict__ up = (const T*)G.up;
+  T* __restrict__ out = (T*)G.out;
+  T* __restrict__ gated = (T*)G.gated;
+  const int M = G.M, L = G.L, relu = P.relu;
+  const long ld_raw = G.ld_raw, ld_out = G.ld_out, ld_up = G.ld_up, ld_gated = G.ld_gated, ldg = G.ldg;
+  const float* __restrict__ gate = G.gate;
+  const int row0 = rblk * G.rows_wg, row1 = min(M, row0 + G.rows_wg);
+  constexpr int U = 4;
+  typename V16<T>::raw_t xr[U], ur[U];
+  int sq[U];
+  auto load_batch = [&](int mb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = min(mb + u * RP, M - 1);           // clamped index, masked store
+      xr[u] = V16<T>::ldraw(raw + (long)m * ld_raw + c0);
+      sq[u] = m / L;
+      if (up) {
+        const int t = m - sq[u] * L;
+        ur[u] = V16<T>::ldraw(up + ((long)sq[u] * (L >> 1) + (t >> 1)) * ld_up + c0);
+      }
+    }
+  };
+  // the rows of the first trip are requested BEFORE the statistics merge: every workgroup of a launch reaches its merge at the
+  // same time, and without this the memory system idles through it
+  load_batch(row0 + ry);
   {
     double mean, var;
     bn_merge64(G.stats, G.tiles, G.M, C, cbase, shd, mean, var);
@@ -427,51 +454,34 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
     }
     __syncthreads();
   }
-  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
   float sc[N], sh[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) { sc[k] = s_sc[v * N + k]; sh[k] = s_sh[v * N + k]; }
-  const T* __restrict__ raw = (const T*)G.raw;
-  const T* __restrict__ up = (const T*)G.up;
-  T* __restrict__ out = (T*)G.out;
-  T* __restrict__ gated = (T*)G.gated;
-  const int M = G.M, L = G.L, relu = P.relu;
-  const long ld_raw = G.ld_raw, ld_out = G.ld_out, ld_up = G.ld_up, ld_gated = G.ld_gated, ldg = G.ldg;
-  const float* __restrict__ gate = G.gate;
-  const int row0 = rblk * G.rows_wg, row1 = min(M, row0 + G.rows_wg);
-  constexpr int U = 4;
   for (int mb = row0 + ry; mb < row1; mb += U * RP) {
-    float x[U][N], uu[U][N];
-    int sq[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int m = min(mb + u * RP, M - 1);           // clamped index, masked store
-      V16<T>::load(raw + (long)m * ld_raw + c0, x[u]);
-      sq[u] = m / L;
-      if (up) {
-        const int t = m - sq[u] * L;
-        V16<T>::load(up + ((long)sq[u] * (L >> 1) + (t >> 1)) * ld_up + c0, uu[u]);
-      }
-    }
+    if (mb != row0 + ry) load_batch(mb);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int m = mb + u * RP;
+      float x[N];
+      V16<T>::cvt(xr[u], x);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
-        const float y = fmaf(x[u][k], sc[k], sh[k]);
-        x[u][k] = relu ? fmaxf(y, 0.f) : y;
+        const float y = fmaf(x[k], sc[k], sh[k]);
+        x[k] = relu ? fmaxf(y, 0.f) : y;
       }
       if (up) {
+        float uu[N];
+        V16<T>::cvt(ur[u], uu);
 #pragma unroll
-        for (int k = 0; k < N; ++k) x[u][k] += uu[u][k];
+        for (int k = 0; k < N; ++k) x[k] += uu[k];
       }
       if (m < row1) {
-        V16<T>::store(out + (long)m * ld_out + c0, x[u]);
+        V16<T>::store(out + (long)m * ld_out + c0, x);
         if (gated) {
           const float* gp = gate + (long)sq[u] * ldg + c0;
 #pragma unroll
-          for (int k = 0; k < N; ++k) x[u][k] *= gp[k];
-          V16<T>::store(gated + (long)m * ld_gated + c0, x[u]);
+          for (int k = 0; k < N; ++k) x[k] *= gp[k];
+          V16<T>::store(gated + (long)m * ld_gated + c0, x);
         }
       }
     }
@@ -490,10 +500,9 @@ extern "C" int drn_bn_train_apply(const DrnBnTrainDesc* d, int n, int C, int rel
   P.n = n; P.C = C; P.relu = relu; P.nupd = C / 64;
   long m_all = 0;
   for (int i = 0; i < n; ++i) m_all += d[i].M;
-  // four rows per thread and trip; more trips per workgroup once the launch would exceed ~1024 workgroups (what the chip holds at
-  // once): every workgroup pays the statistics merge of its channel tile, so on the big tensors fewer, longer workgroups win
+  // four rows per thread = ONE trip per workgroup, requested before the statistics merge (more trips only beyond 4096 workgroups)
   const long wg4 = ((m_all + 4 * RP - 1) / (4 * RP)) * (C / 64);
-  const int rows_wg = 4 * RP * (int)(wg4 > 1024 ? (wg4 + 1023) / 1024 : 1);
+  const int rows_wg = 4 * RP * (int)(wg4 > 4096 ? (wg4 + 4095) / 4096 : 1);
   int blocks = P.nupd;
   for (int i = 0; i < n; ++i) {
     const DrnBnTrainDesc& s = d[i];
@@ -863,6 +872,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply64_kernel(const BnBwd2Params 
   const int ctiles = C >> 6;
   const int b = blockIdx.x - G.ablk0;
   const int rblk = b / ctiles, cbase = (b - rblk * ctiles) * 64;
+  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
+  const T* __restrict__ dout = (const T*)G.dout;
+  const T* __restrict__ raw = (const T*)G.raw;
+  T* __restrict__ draw = (T*)G.draw;
+  const long ldd = G.ld_dout, ldr = G.ld_raw, ldw = G.ld_draw;
+  const int row0 = rblk * G.arows, row1 = min(M, row0 + G.arows);
+  constexpr int U = 4;
+  typename V16<T>::raw_t gr[U], xr[U];
+  auto load_batch = [&](int mb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = min(mb + u * RP, M - 1);
+      gr[u] = V16<T>::ldraw(dout + (long)m * ldd + c0);
+      xr[u] = V16<T>::ldraw(raw + (long)m * ldr + c0);
+    }
+  };
+  load_batch(row0 + ry);          // requested before the merge of the partial sums (see bn_train_apply_kernel)
   {
     double sg, sx;
     bn_bwd_sum64(G.partial, G.rb, C, cbase, shd, sg, sx);
@@ -878,7 +904,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply64_kernel(const BnBwd2Params 
     }
     __syncthreads();
   }
-  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
   float sc[N], sh[N], ka[N], kb[N], kc[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -888,29 +913,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply64_kernel(const BnBwd2Params 
     kb[k] = s_k[1][v * N + k];
     kc[k] = s_k[2][v * N + k];
   }
-  const T* __restrict__ dout = (const T*)G.dout;
-  const T* __restrict__ raw = (const T*)G.raw;
-  T* __restrict__ draw = (T*)G.draw;
-  const long ldd = G.ld_dout, ldr = G.ld_raw, ldw = G.ld_draw;
-  const int row0 = rblk * G.arows, row1 = min(M, row0 + G.arows);
-  constexpr int U = 4;
   for (int mb = row0 + ry; mb < row1; mb += U * RP) {
-    float g[U][N], x[U][N];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int m = min(mb + u * RP, M - 1);
-      V16<T>::load(dout + (long)m * ldd + c0, g[u]);
-      V16<T>::load(raw + (long)m * ldr + c0, x[u]);
-    }
+    if (mb != row0 + ry) load_batch(mb);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int m = mb + u * RP;
+      float g[N], x[N];
+      V16<T>::cvt(gr[u], g);
+      V16<T>::cvt(xr[u], x);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
-        const float gg = (relu && !(fmaf(x[u][k], sc[k], sh[k]) > 0.f)) ? 0.f : g[u][k];
-        x[u][k] = fmaf(ka[k], gg, fmaf(kb[k], x[u][k], kc[k]));
+        const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
+        x[k] = fmaf(ka[k], gg, fmaf(kb[k], x[k], kc[k]));
       }
-      if (m < row1) V16<T>::store(draw + (long)m * ldw + c0, x[u]);
+      if (m < row1) V16<T>::store(draw + (long)m * ldw + c0, x);
     }
   }
 }

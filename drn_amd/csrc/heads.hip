@@ -96,7 +96,27 @@ __device__ __forceinline__ float head_dz(const HeadParams& P, const HeadGroup& G
   return P.exp_mode ? G.scale[0] * out[idx] * d : d;
 }
 
+// A wave's run of HEAD_RPW rows [r0, r0 + HEAD_RPW) of the level-concatenated row space takes the WINDOW path when all of them
+// exist and lie in one level: the k = 3 taps of consecutive rows overlap, so rows m0-1 .. m0+HEAD_RPW (clamped into the level;
+// a tap that leaves its sequence is masked per (row, tap)) are fetched once -- HEAD_RPW + 2 loads instead of 3 x HEAD_RPW.
+struct HeadRun {
+  int g, m0;       // level of the run, first row inside it
+  bool window;
+};
+__device__ __forceinline__ HeadRun head_run(const HeadParams& P, int r0) {
+  HeadRun R;
+  R.g = 0; R.m0 = 0; R.window = false;
+  if (r0 >= P.total_rows) return R;
+  R.g = head_group_of(P, r0);
+  R.m0 = r0 - P.g[R.g].row_start;
+  R.window = P.taps == 3 && P.pad == 1 && r0 + HEAD_RPW <= P.total_rows && head_group_of(P, r0 + HEAD_RPW - 1) == R.g;
+  return R;
+}
+
 // out[r][n] (and z[r][n] in exp mode); r = concatenated row over levels.  grid = ceil(rows / (4*HEAD_RPW)), block 256.
+// The activations of a window run are requested BEFORE the workgroup stages the weights through LDS: the launch is one
+// residency wave long, so its duration is one workgroup's dependency chain -- weights -> LDS -> barrier -> activations -> FMAs
+// -> wave reduction -- and the two memory trips at its head now overlap.
 template <typename T>
 __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
   constexpr int VN = V16<T>::N;
@@ -110,9 +130,22 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: row bookkeeping on the scalar unit
   __shared__ float sW[HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C];
+  const int nvec = C / VN;
+  const HeadRun R = head_run(P, r0);
+  const T* __restrict__ Xw = (const T*)P.g[R.g].X;
+  const int Mw = P.g[R.g].M, Lw = P.g[R.g].L;
+  const long ldw = P.g[R.g].ldx;
+  typename V16<T>::raw_t xr[HEAD_RPW + 2];
+  auto fetch_window = [&](int v) {
+#pragma unroll
+    for (int j = 0; j < HEAD_RPW + 2; ++j) {
+      const int m = min(max(R.m0 - 1 + j, 0), Mw - 1);        // clamped rows are masked below
+      xr[j] = V16<T>::ldraw(Xw + (long)m * ldw + v * VN);
+    }
+  };
+  if (R.window && lane < nvec) fetch_window(lane);
   head_stage_w(W, C, taps, N, sW);
   if (r0 >= P.total_rows) return;
-  const int nvec = C / VN;
   float acc[HEAD_RPW][HEAD_MAX_N];
 #pragma unroll
   for (int i = 0; i < HEAD_RPW; ++i)
@@ -124,27 +157,20 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
     float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
     head_load_w<T>(W, sW, C, taps, N, v * VN, live, wr);
     if (!live) continue;
-    // Sliding window (k = 3, the wave's 8 rows inside one level): rows r0-1 .. r0+8 are loaded ONCE (10 loads instead of
-    // 24: consecutive rows share two of their three taps) and every (row, tap) picks its window slot; sequence ends are
-    // handled by the same per-(row, tap) mask as below.
-    const int g_first = head_group_of(P, r0), g_last = head_group_of(P, min(r0 + HEAD_RPW, P.total_rows) - 1);
-    if (taps == 3 && P.pad == 1 && g_first == g_last && r0 + HEAD_RPW <= P.total_rows) {
-      const HeadGroup& G = P.g[g_first];
-      const int m0 = r0 - G.row_start;
+    if (R.window) {
+      if (vb) fetch_window(v);
+      const int t0 = R.m0 % Lw;
       float x[HEAD_RPW + 2][VN];
 #pragma unroll
-      for (int j = 0; j < HEAD_RPW + 2; ++j) {
-        const int m = min(max(m0 - 1 + j, 0), G.M - 1);       // clamped rows are masked below
-        V16<T>::load((const T*)G.X + (long)m * G.ldx + v * VN, x[j]);
-      }
+      for (int j = 0; j < HEAD_RPW + 2; ++j) V16<T>::cvt(xr[j], x[j]);
 #pragma unroll
       for (int i = 0; i < HEAD_RPW; ++i) {
-        const int m = m0 + i;
-        const int t = m % G.L;
+        int t = t0 + i;
+        t = t >= Lw ? t - Lw * (t / Lw) : t;
 #pragma unroll
         for (int tp = 0; tp < 3; ++tp) {
           const int st = t + tp - 1;
-          if (st >= 0 && st < G.L)
+          if (st >= 0 && st < Lw)
 #pragma unroll
             for (int n = 0; n < HEAD_MAX_N; ++n)
 #pragma unroll
@@ -229,11 +255,40 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
   }
 }
 
-// dX[m][c] (+)= sum_n sum_tap dz[row(s, t - tap + pad)][n] * W[n][c][tap].  grid (ceil(nvec/64), ceil(rows/(4*HEAD_RPW)))
+// ---- backward: data gradient and weight-gradient partials in ONE launch (blockIdx.y < nblk_data: data gradient; the rest:
+// weight gradient).  Both walk the same runs of HEAD_RPW rows per wave and read the same HEAD_RPW + 2 gradient rows
+// dz[m0-1 .. m0+HEAD_RPW] (wave-uniform: scalar loads, requested before anything else).
+//   data:   dX[m][c] (+)= sum_n sum_tap dz[row(s, t - tap + 1)][n] * W[n][c][tap]
+//   weight: partial[wg][n][tap][c] = sum over the workgroup's rows of dz[r][n] * X[src(r, tap)][c], X through the same sliding window
+//           as the forward pass (HEAD_RPW + 2 loads per run, the next run's in flight while this one's FMAs run), the four waves
+//           of a workgroup combined through LDS in a fixed order; + HEAD_EXTRA values: [0..1] = sum dz[r][n] (bias gradient),
+//           [2..5] = per level sum z*out*dout (scale gradient, exp mode).
+#define HEAD_EXTRA 8
+#define HEAD_WRUNS 2     // runs per wave in the weight-gradient part: HEAD_WRUNS * HEAD_RPW * 4 rows per workgroup
+
+// dzw[j][n], j = 0 .. HEAD_RPW+1 <-> row m0 - 1 + j of level R.g, zero outside the level
+__device__ __forceinline__ void head_dz_window(const HeadParams& P, const HeadRun& R, const float* __restrict__ dout,
+                                               const float* __restrict__ out, float (&dzw)[HEAD_RPW + 2][HEAD_MAX_N]) {
+  const HeadGroup& G = P.g[R.g];
+  const float sc = P.exp_mode ? G.scale[0] : 1.f;
+#pragma unroll
+  for (int j = 0; j < HEAD_RPW + 2; ++j) {
+    const int m = R.m0 - 1 + j;
+    const bool in = m >= 0 && m < G.M;
+    const long ro = (long)(G.row_start + (in ? m : R.m0)) * P.N;
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) {
+      const long idx = ro + (n < P.N ? n : 0);          // always a valid address; masked afterwards
+      const float d = dout[idx];
+      const float zz = P.exp_mode ? sc * out[idx] * d : d;
+      dzw[j][n] = (in && n < P.N) ? zz : 0.f;
+    }
+  }
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadMulti MS) {
+__device__ __forceinline__ void head_bwd_data_part(const HeadSet& S, float* sW, const int by) {
   constexpr int VN = V16<T>::N;
-  const HeadSet& S = MS.s[blockIdx.z];
   const HeadParams& P = S.P;
   const float* __restrict__ W = S.W;
   const float* __restrict__ dout = S.dout;
@@ -241,13 +296,43 @@ __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadMulti 
   const int accumulate = S.accumulate_dx;
   const int N = P.N, C = P.C, taps = P.taps;
   const int v = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int r0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: the dz scalars come through the scalar cache
-  __shared__ float sW[HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C];
+  const int r0 = (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: the dz scalars come through the scalar cache
+  const HeadRun R = head_run(P, r0);
+  float dzw[HEAD_RPW + 2][HEAD_MAX_N];
+  if (R.window) head_dz_window(P, R, dout, out, dzw);      // before the weights are staged: the two trips overlap
   head_stage_w(W, C, taps, N, sW);
   if (v * VN >= C || r0 >= P.total_rows) return;
   float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
   head_load_w<T>(W, sW, C, taps, N, v * VN, true, wr);
-  // four rows at a time: the 4 x taps x N gradient scalars are fetched together (independent loads), then the FMAs
+  if (R.window) {
+    const HeadGroup& G = P.g[R.g];
+    const int L = G.L;
+    const int t0 = R.m0 % L;
+    T* __restrict__ dX = (T*)G.dX + (long)R.m0 * G.ldx + v * VN;
+#pragma unroll
+    for (int i = 0; i < HEAD_RPW; ++i) {
+      int t = t0 + i;
+      t = t >= L ? t - L * (t / L) : t;
+      float a[VN];
+      if (accumulate) V16<T>::load(dX + (long)i * G.ldx, a);
+      else {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) a[k] = 0.f;
+      }
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) {
+        const int to = t - tp + 1;                         // output position that read this input through tap `tp`
+        if (to >= 0 && to < L)
+#pragma unroll
+          for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+            for (int k = 0; k < VN; ++k) a[k] = fmaf(dzw[i + 2 - tp][n], wr[n][tp][k], a[k]);
+      }
+      V16<T>::store(dX + (long)i * G.ldx, a);
+    }
+    return;
+  }
+  // general path (runs that straddle two levels or the end): four rows at a time
 #pragma unroll
   for (int h = 0; h < HEAD_RPW; h += 4) {
     float dv[4][HEAD_MAX_TAPS][HEAD_MAX_N];
@@ -293,29 +378,20 @@ __global__ __launch_bounds__(256) void head_out_bwd_data_kernel(const HeadMulti 
   }
 }
 
-// partial[blk][...]: per row block, [n][tap][c] = sum_rows dz[r][n] * X[src(r,tap)][c], then 8 extras:
-// [0..1] = sum_rows dz[r][n] (bias gradient), [2..5] = per level sum z*out*dout (scale gradient, exp mode).
-// grid (ceil(nvec/64), nblk); block 1024 = 64 channel vectors x 16 row lanes
-#define HEAD_EXTRA 8
 template <typename T>
-__global__ __launch_bounds__(1024) void head_out_bwd_w_kernel(const HeadMulti MS) {
+__device__ __forceinline__ void head_bwd_w_part(const HeadSet& S, float* sred, const int wb) {
   constexpr int VN = V16<T>::N;
-  const HeadSet& S = MS.s[blockIdx.z];
   const HeadParams& P = S.P;
   const float* __restrict__ dout = S.dout;
   const float* __restrict__ out = S.out;
   const float* __restrict__ z = S.z;
-  float* __restrict__ partial = S.partial;
-  if ((int)blockIdx.y >= S.nblk) return;
-  __shared__ float red[16][64 * VN + 1];
+  if (wb >= S.nblk) return;
   const int N = P.N, C = P.C, taps = P.taps;
-  const int vx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int v = blockIdx.x * 64 + vx;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int v = blockIdx.x * 64 + lane;
   const bool live = v * VN < C;
-  const int rows_per = (P.total_rows + S.nblk - 1) / S.nblk;
-  const int r0 = blockIdx.y * rows_per, r1 = min(P.total_rows, r0 + rows_per);
   const long pstride = (long)N * taps * C + HEAD_EXTRA;
-  float* prow = partial + (long)blockIdx.y * pstride;
+  float* __restrict__ prow = S.partial + (long)wb * pstride;
   float acc[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
 #pragma unroll
   for (int n = 0; n < HEAD_MAX_N; ++n)
@@ -326,37 +402,104 @@ __global__ __launch_bounds__(1024) void head_out_bwd_w_kernel(const HeadMulti MS
   float ex[HEAD_EXTRA];
 #pragma unroll
   for (int k = 0; k < HEAD_EXTRA; ++k) ex[k] = 0.f;
-  for (int r = r0 + ry; r < r1; r += 16) {
-    const int g = head_group_of(P, r);
-    const HeadGroup& G = P.g[g];
-    const int m = r - G.row_start;
-    const int s = m / G.L, t = m - s * G.L;
+  const int rbase = (wb * 4 + w) * (HEAD_WRUNS * HEAD_RPW);
+  typename V16<T>::raw_t xr[2][HEAD_RPW + 2];
+  auto fetch = [&](const HeadRun& R, typename V16<T>::raw_t (&buf)[HEAD_RPW + 2]) {
+    const HeadGroup& G = P.g[R.g];
     const T* __restrict__ X = (const T*)G.X;
-    float d[HEAD_MAX_N];
 #pragma unroll
-    for (int n = 0; n < HEAD_MAX_N; ++n) {
-      d[n] = n < N ? head_dz(P, G, dout, out, (long)r * N + n) : 0.f;
-      ex[n] += d[n];
-      if (P.exp_mode && n < N) {
-        const float zz = z[(long)r * N + n] * out[(long)r * N + n] * dout[(long)r * N + n];
+    for (int j = 0; j < HEAD_RPW + 2; ++j) {
+      const int m = min(max(R.m0 - 1 + j, 0), G.M - 1);
+      buf[j] = V16<T>::ldraw(X + (long)m * G.ldx + v * VN);
+    }
+  };
+  HeadRun Rn = head_run(P, rbase);
+  if (Rn.window && live) fetch(Rn, xr[0]);
 #pragma unroll
-        for (int l = 0; l < DRN_MAX_GROUPS; ++l)
-          if (l == g) ex[2 + l] += zz;
+  for (int run = 0; run < HEAD_WRUNS; ++run) {
+    const int r0 = rbase + run * HEAD_RPW;
+    const HeadRun R = Rn;
+    if (run + 1 < HEAD_WRUNS) {
+      Rn = head_run(P, r0 + HEAD_RPW);
+      if (Rn.window && live) fetch(Rn, xr[(run + 1) & 1]);
+    }
+    if (r0 >= P.total_rows) continue;
+    if (R.window) {
+      const HeadGroup& G = P.g[R.g];
+      const int L = G.L, t0 = R.m0 % L;
+      float dzw[HEAD_RPW + 2][HEAD_MAX_N];
+      head_dz_window(P, R, dout, out, dzw);
+#pragma unroll
+      for (int i = 0; i < HEAD_RPW; ++i)
+#pragma unroll
+        for (int n = 0; n < HEAD_MAX_N; ++n) {
+          ex[n] += dzw[i + 1][n];
+          if (P.exp_mode && n < N) {
+            const long idx = (long)(r0 + i) * N + n;
+            const float zz = z[idx] * out[idx] * dout[idx];
+#pragma unroll
+            for (int l = 0; l < DRN_MAX_GROUPS; ++l)
+              if (l == R.g) ex[2 + l] += zz;
+          }
+        }
+      if (live) {
+        float x[HEAD_RPW + 2][VN];
+#pragma unroll
+        for (int j = 0; j < HEAD_RPW + 2; ++j) V16<T>::cvt(xr[run & 1][j], x[j]);
+#pragma unroll
+        for (int i = 0; i < HEAD_RPW; ++i) {
+          int t = t0 + i;
+          t = t >= L ? t - L * (t / L) : t;
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp) {
+            const int st = t + tp - 1;
+            if (st >= 0 && st < L)
+#pragma unroll
+              for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+                for (int k = 0; k < VN; ++k) acc[n][tp][k] = fmaf(dzw[i + 1][n], x[i + tp][k], acc[n][tp][k]);
+          }
+        }
+      }
+      continue;
+    }
+    // general path: row by row
+    for (int i = 0; i < HEAD_RPW; ++i) {
+      const int r = r0 + i;
+      if (r >= P.total_rows) break;
+      const int g = head_group_of(P, r);
+      const HeadGroup& G = P.g[g];
+      const int m = r - G.row_start;
+      const int s = m / G.L, t = m - s * G.L;
+      const T* __restrict__ X = (const T*)G.X;
+      float d[HEAD_MAX_N];
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n) {
+        d[n] = n < N ? head_dz(P, G, dout, out, (long)r * N + n) : 0.f;
+        ex[n] += d[n];
+        if (P.exp_mode && n < N) {
+          const float zz = z[(long)r * N + n] * out[(long)r * N + n] * dout[(long)r * N + n];
+#pragma unroll
+          for (int l = 0; l < DRN_MAX_GROUPS; ++l)
+            if (l == g) ex[2 + l] += zz;
+        }
+      }
+      if (!live) continue;
+#pragma unroll
+      for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+        const int st = t + tp - P.pad;
+        if (tp >= taps || st < 0 || st >= G.L) continue;
+        float x[VN];
+        V16<T>::load(X + (long)(s * G.L + st) * G.ldx + v * VN, x);
+#pragma unroll
+        for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+          for (int k = 0; k < VN; ++k) acc[n][tp][k] = fmaf(d[n], x[k], acc[n][tp][k]);
       }
     }
-    if (!live) continue;
-#pragma unroll
-    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
-      const int st = t + tp - P.pad;
-      if (tp >= taps || st < 0 || st >= G.L) continue;
-      float x[VN];
-      V16<T>::load(X + (long)(s * G.L + st) * G.ldx + v * VN, x);
-#pragma unroll
-      for (int n = 0; n < HEAD_MAX_N; ++n)
-#pragma unroll
-        for (int k = 0; k < VN; ++k) acc[n][tp][k] = fmaf(d[n], x[k], acc[n][tp][k]);
-    }
   }
+  // the four waves of the workgroup, added in wave order
+  float (*red)[64 * VN + 1] = (float (*)[64 * VN + 1])sred;
 #pragma unroll
   for (int n = 0; n < HEAD_MAX_N; ++n)
 #pragma unroll
@@ -364,31 +507,32 @@ __global__ __launch_bounds__(1024) void head_out_bwd_w_kernel(const HeadMulti MS
       if (n >= N || tp >= taps) continue;          // uniform
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < VN; ++k) red[ry][vx * VN + k] = acc[n][tp][k];
+      for (int k = 0; k < VN; ++k) red[w][lane * VN + k] = acc[n][tp][k];
       __syncthreads();
-      for (int i = threadIdx.x; i < 64 * VN; i += 1024) {
+      for (int i = threadIdx.x; i < 64 * VN; i += 256) {
         const int c = blockIdx.x * 64 * VN + i;
-        if (c < C) {
-          float sum = 0.f;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) sum += red[q][i];
-          prow[((long)n * taps + tp) * C + c] = sum;
-        }
+        if (c < C) prow[((long)n * taps + tp) * C + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
       }
     }
-  if (blockIdx.x == 0) {   // every lane of a row lane saw the same rows: lane 0 of each speaks for it
+  if (blockIdx.x == 0) {   // every lane of a wave saw the same rows: lane 0 speaks for it
     __syncthreads();
-    if (vx == 0)
+    if (lane == 0)
 #pragma unroll
-      for (int k = 0; k < HEAD_EXTRA; ++k) red[ry][k] = ex[k];
+      for (int k = 0; k < HEAD_EXTRA; ++k) red[w][k] = ex[k];
     __syncthreads();
-    if (threadIdx.x < HEAD_EXTRA) {
-      float sum = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) sum += red[q][threadIdx.x];
-      prow[(long)N * taps * C + threadIdx.x] = sum;
-    }
+    if (threadIdx.x < HEAD_EXTRA) prow[(long)N * taps * C + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
+}
+
+// grid (ceil(nvec/64), nblk_data + nblk_w, heads); block 256
+template <typename T>
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadMulti MS, const int nblk_data) {
+  constexpr int VN = V16<T>::N;
+  constexpr int SW_FLOATS = HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C, RED_FLOATS = 4 * (64 * VN + 1);
+  __shared__ float smem[SW_FLOATS > RED_FLOATS ? SW_FLOATS : RED_FLOATS];
+  const HeadSet& S = MS.s[blockIdx.z];
+  if ((int)blockIdx.y < nblk_data) head_bwd_data_part<T>(S, smem, blockIdx.y);
+  else head_bwd_w_part<T>(S, smem, blockIdx.y - nblk_data);
 }
 
 // dW[n][c][tap] / dbias[n] / dscale[l] (+)= sum_blk partial[blk][...];  256 threads = 16 outputs x 16 lanes over the row blocks
@@ -467,10 +611,14 @@ static int fill_head_set(HeadSet& S, const DrnHeadCall& c, int dtype, bool backw
   S.W = c.W; S.bias = c.bias; S.out = c.out; S.z = c.z; S.dout = c.dout; S.partial = c.ws; S.dW = c.dW; S.dbias = c.dbias;
   S.dscale = c.dscale; S.accumulate_dx = c.accumulate_dx; S.accumulate_dw = c.accumulate_dw;
   S.dscale_stride = c.dscale_stride > 0 ? c.dscale_stride : 1;
-  S.nblk = S.P.total_rows >= 256 * 16 ? 256 : (S.P.total_rows >= 16 ? S.P.total_rows / 16 : 1);
+  S.nblk = cdiv(S.P.total_rows, 4 * HEAD_WRUNS * HEAD_RPW);      // weight-gradient workgroups = partial rows (drn_heads_ws_rows)
   if (!backward) DRN_CHECK_ARG(c.W && c.bias && c.out && (!c.exp_mode || c.z), "%s: null pointer", who);
   else DRN_CHECK_ARG(c.W && c.dout && c.dW && c.dbias && c.ws && (!c.exp_mode || (c.out && c.z && c.dscale)), "%s: null pointer", who);
   return DRN_OK;
+}
+
+extern "C" int64_t drn_heads_ws_elems(int total_rows, int N, int C, int taps) {
+  return (int64_t)cdiv(total_rows, 4 * HEAD_WRUNS * HEAD_RPW) * ((int64_t)N * taps * C + HEAD_EXTRA);
 }
 
 extern "C" int drn_heads_fwd(const DrnHeadCall* calls, int ncalls, int dtype, void* stream) {
@@ -508,10 +656,9 @@ extern "C" int drn_heads_bwd(const DrnHeadCall* calls, int ncalls, int dtype, vo
   }
   DISPATCH_DT(dtype, "drn_heads_bwd", {
     constexpr int VN = V16<T>::N;
-    dim3 dgrid(cdiv(cmax / VN, 64), cdiv(rows, 4 * HEAD_RPW), ncalls);
-    head_out_bwd_data_kernel<T><<<dgrid, 256, 0, stream>>>(MS);
-    dim3 grid(cdiv(cmax / VN, 64), nblk, ncalls);
-    head_out_bwd_w_kernel<T><<<grid, 1024, 0, stream>>>(MS);
+    const int nblk_data = cdiv(rows, 4 * HEAD_RPW);
+    dim3 grid(cdiv(cmax / VN, 64), nblk_data + nblk, ncalls);       // data gradient and weight-gradient partials side by side
+    head_out_bwd_kernel<T><<<grid, 256, 0, stream>>>(MS, nblk_data);
   });
   head_out_bwd_w_final_kernel<<<dim3(cdiv(tot, 16), 1, ncalls), 256, 0, stream>>>(MS);
   return drn_launch_status("drn_heads_bwd");
@@ -529,7 +676,7 @@ extern "C" int drn_head_out_fwd(const DrnHeadGroup* groups, int ngroups, const f
 
 extern "C" int drn_head_out_bwd(const DrnHeadGroup* groups, int ngroups, const float* W, const float* dout, const float* out,
                                 const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
-                                float* dscale, int accumulate_dw, float* ws /* >= 256*(N*taps*C + 8) floats */, int dtype,
+                                float* dscale, int accumulate_dw, float* ws /* >= drn_heads_ws_elems() floats */, int dtype,
                                 void* stream) {
   DrnHeadCall c;
   memset(&c, 0, sizeof(c));

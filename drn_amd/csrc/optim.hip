@@ -31,7 +31,56 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_kernel(const float
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// The same with the finalize pass folded in: every workgroup publishes its partial with a write-through (agent-scope) store,
+// drains it and takes a ticket; the workgroup that draws the LAST ticket of the step -- `expected` workgroups over all buckets'
+// launches -- adds ALL partials in index order (agent-scope loads: nothing stale out of its own L1) exactly as
+// sumsq_finalize_kernel does, so the result does not depend on who came last, and re-arms the ticket.  One launch and one
+// kernel boundary less per step (the squared norm of 38 M gradients is 10887 partials: ~2 us of tail for the one workgroup).
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_fin_kernel(const float* __restrict__ g, long n, float* all_partials,
+                                                                          int part_off, int npart_all, int* ticket, int expected,
+                                                                          float* __restrict__ total, int* __restrict__ step_counter) {
+  __shared__ float sh[17];
+  __shared__ int s_last;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
+  const long base = (long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS * 4) {
+    const long k = base + i;
+    if (k + 4 <= n) {
+      const f32x4 v = *(const f32x4*)(g + k);
+      s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+    } else {
+      for (int e = 0; e < 4 && k + e < n; ++e) s = fmaf(g[k + e], g[k + e], s);
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(all_partials + part_off + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == expected - 1;
+    if (prev == expected - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < npart_all; i += OPT_THREADS)
+    t += __hip_atomic_load(all_partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = block_sum(t, sh);
+  if (threadIdx.x == 0) total[0] = t;
+}
+
 extern "C" int64_t drn_opt_nblocks(int64_t n) { return (n + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK; }
+
+extern "C" int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* ticket,
+                                      float* total_sumsq, int* step_counter, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(g && all_partials && ticket && total_sumsq && n > 0 && part_off >= 0 &&
+                part_off + drn_opt_nblocks(n) <= npart_all, "drn_sumsq_partials_fin: bad args");
+  sumsq_partials_fin_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(g, n, all_partials, part_off, npart_all,
+                                                                                              ticket, npart_all, total_sumsq, step_counter);
+  return drn_launch_status("drn_sumsq_partials_fin");
+}
 
 extern "C" int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream) {
   drn_clear_status();

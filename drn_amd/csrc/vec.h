@@ -11,6 +11,13 @@ template <> struct V16<float> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = t[i];
   }
+  // the 16 bytes as loaded (conversion deferred: a prefetched vector costs 4 registers, whatever T is)
+  typedef f32x4 raw_t;
+  static __device__ __forceinline__ raw_t ldraw(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ void cvt(const raw_t& t, float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = t[i];
+  }
   static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
     f32x4 t;
 #pragma unroll
@@ -23,6 +30,12 @@ template <> struct V16<bf16_t> {
   static constexpr int N = 8;
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     const bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  typedef bf16x8 raw_t;
+  static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return *(const bf16x8*)p; }
+  static __device__ __forceinline__ void cvt(const raw_t& t, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
   }

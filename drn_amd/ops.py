@@ -461,10 +461,10 @@ def heads_fwd(calls, dtype):
 
 
 def heads_bwd(calls, dtype):
-    """Each call gets its own slice of the per-device workspace (256*(N*taps*C + 8) floats)."""
+    """Each call gets its own slice of the per-device workspace (drn_heads_ws_elems floats)."""
     for c0 in range(0, len(calls), 2):
         chunk = calls[c0:c0 + 2]
-        sizes = [256 * (c["N"] * c["taps"] * c["C"] + 8) for c in chunk]
+        sizes = [int(lib().drn_heads_ws_elems(sum(int(g.M) for g in c["groups"]), c["N"], c["C"], c["taps"])) for c in chunk]
         ws = workspace(sum(sizes), chunk[0]["dW"].device)
         off = 0
         for c, n in zip(chunk, sizes):

@@ -243,11 +243,12 @@ int drn_head_out_fwd(const DrnHeadGroup* groups /*host*/, int ngroups, const flo
  * dX (+)= conv^T(dz), dW/dbias/dscale (+)= ... over all levels. */
 int drn_head_out_bwd(const DrnHeadGroup* groups /*host*/, int ngroups, const float* W, const float* dout, const float* out,
                      const float* z, int N, int C, int taps, int exp_mode, int accumulate_dx, float* dW, float* dbias,
-                     float* dscale, int accumulate_dw, float* ws /* >= 256*(N*taps*C + 8) floats */, int dtype, void* stream);
+                     float* dscale, int accumulate_dw, float* ws /* >= drn_heads_ws_elems(sum of M, N, C, taps) floats */, int dtype, void* stream);
 
 /* Up to 2 heads per launch (cls_logits + bbox_pred read the two halves of one tower output: side by side they fill the chip).
  * One DrnHeadCall = the arguments of drn_head_out_fwd / _bwd for one head; forward uses groups, W, bias, out, z; backward
- * groups (with dX), W, dout, out, z, dW, dbias, dscale (+ dscale_stride), ws (>= 256*(N*taps*C + 8) floats each), accumulate flags. */
+ * groups (with dX), W, dout, out, z, dW, dbias, dscale (+ dscale_stride), ws (>= drn_heads_ws_elems() floats each), accumulate flags.
+ * Backward is two launches: data gradient + weight-gradient partials side by side, then the reduction of the partials. */
 typedef struct DrnHeadCall {
   const DrnHeadGroup* groups; /* host */
   int32_t ngroups, N, C, taps, exp_mode, accumulate_dx, accumulate_dw;
@@ -262,6 +263,7 @@ typedef struct DrnHeadCall {
   float* dscale;
   float* ws;
 } DrnHeadCall;
+int64_t drn_heads_ws_elems(int total_rows, int N, int C, int taps); /* fp32 workspace of one head's backward */
 int drn_heads_fwd(const DrnHeadCall* calls /*host*/, int ncalls, int dtype, void* stream);
 int drn_heads_bwd(const DrnHeadCall* calls /*host*/, int ncalls, int dtype, void* stream);
 
@@ -399,6 +401,12 @@ int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, 
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */
 /* partials[b] = sum of g^2 over block b; step_counter (device int, or NULL) is incremented once per call. */
 int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream);
+/* drn_sumsq_partials + drn_sumsq_finalize in one launch per bucket: all_partials holds npart_all = sum over ALL buckets of
+ * drn_opt_nblocks(n_b) floats, this bucket's start at part_off; ticket = one int32, zero on entry, left zero.  The workgroup
+ * that arrives last over all the step's launches adds all partials in index order into total_sumsq[0] (same value as the two-launch
+ * form).  Every bucket of the step must go through this call, on one stream. */
+int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* ticket,
+                           float* total_sumsq, int* step_counter, void* stream);
 /* total_sumsq[0] = sum of ALL buckets' partials, one workgroup, fixed order (the squared global gradient norm). */
 int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream);
 /* One bucket: g/m/v flat [n]; tensor i covers [seg_start[i], seg_start[i+1]) and lives at p_ptr[i] (both tables on the

@@ -161,21 +161,23 @@ def test_input_stage_fwd_bwd(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_head_out_fwd_bwd(dt):
-    """cls_logits + exp(scale*bbox_pred) on the two halves of the stacked tower output, 3 levels (model/fcos.py:96-100)."""
+@pytest.mark.parametrize("B,C,Ls", [(2, 64, (32, 16, 8)), (3, 512, (64, 32, 16)), (3, 128, (50, 25, 13))])
+def test_head_out_fwd_bwd(dt, B, C, Ls):
+    """cls_logits + exp(scale*bbox_pred) on the two halves of the stacked tower output, 3 levels (model/fcos.py:96-100); the
+    second shape has the model's channel count (runs of 8 rows inside one level: the sliding-window paths), the third has
+    sequence lengths that are no multiples of 8 (runs across clip and level boundaries: masks and the row-by-row paths)."""
     from drn_amd import functional as DF
-    B, C = 2, 64
     torch.manual_seed(0)
     cls, box = nn.Conv1d(C, 1, 3, padding=1).double(), nn.Conv1d(C, 2, 3, padding=1).double()
     scales = (rnd(3, seed=1) * 0.1 + 1.0).requires_grad_()
-    xs = [rnd(B, 2 * C, L, seed=2 + i) for i, L in enumerate((32, 16, 8))]
+    xs = [rnd(B, 2 * C, L, seed=2 + i) * (8.0 / np.sqrt(C)) for i, L in enumerate(Ls)]
     if dt == torch.bfloat16:
         xs = [x.bfloat16().double() for x in xs]
     xr = [x.clone().requires_grad_() for x in xs]
     lo = [cls(x[:, :C]) for x in xr]
     rg = [torch.exp(scales[l] * box(x[:, C:])) for l, x in enumerate(xr)]
     flat = lambda ts: torch.cat([t.permute(0, 2, 1).reshape(-1, t.size(1)) for t in ts])
-    w1, w2 = rnd(B * 56, 1, seed=8), rnd(B * 56, 2, seed=9)
+    w1, w2 = rnd(B * sum(Ls), 1, seed=8), rnd(B * sum(Ls), 2, seed=9)
     ((flat(lo) * w1).sum() + (flat(rg) * w2).sum()).backward()
     ch, bh = nn.Conv1d(C, 1, 3, padding=1).to(DEV), nn.Conv1d(C, 2, 3, padding=1).to(DEV)
     with torch.no_grad():
