@@ -351,30 +351,35 @@ __device__ __forceinline__ void bn_merge64(const float* __restrict__ st, const i
   }
   shd[j][ci] = s;
   __syncthreads();
-  const double mean = ((shd[0][ci] + shd[1][ci]) + (shd[2][ci] + shd[3][ci])) / Mrows;
+  // (double-precision divisions are ~40-instruction sequences: every slab but the last has 128 rows -- an exact power-of-two
+  // reciprocal -- and the two per-channel ones are multiplications by 1/M)
+  const double inv_m = 1.0 / (double)Mrows;
+  const int n_last = Mrows - (tiles - 1) * 128;
+  const double inv_last = n_last == 128 ? 0.0078125 : 1.0 / (double)n_last;
+  const double mean = ((shd[0][ci] + shd[1][ci]) + (shd[2][ci] + shd[3][ci])) * inv_m;
   double q = 0.0;
   if (cached) {
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
       const int k = j + 4 * i;
       if (k < tiles) {
-        const int nt = min(128, Mrows - k * 128);
-        const double d = (double)c0[i] / nt - mean;
-        q += (double)c1[i] + nt * d * d;
+        const bool last = k == tiles - 1;
+        const double d = (double)c0[i] * (last ? inv_last : 0.0078125) - mean;
+        q += (double)c1[i] + (double)(last ? n_last : 128) * d * d;
       }
     }
   } else {
     for (int k = j; k < tiles; k += 4) {
-      const int nt = min(128, Mrows - k * 128);
-      const double d = (double)p[((long)k * 2 + 0) * C] / nt - mean;
-      q += (double)p[((long)k * 2 + 1) * C] + nt * d * d;
+      const bool last = k == tiles - 1;
+      const double d = (double)p[((long)k * 2 + 0) * C] * (last ? inv_last : 0.0078125) - mean;
+      q += (double)p[((long)k * 2 + 1) * C] + (double)(last ? n_last : 128) * d * d;
     }
   }
   __syncthreads();
   shd[j][ci] = q;
   __syncthreads();
   q = (shd[0][ci] + shd[1][ci]) + (shd[2][ci] + shd[3][ci]);
-  double var = q / Mrows;
+  double var = q * inv_m;
   if (var < 0.0) var = 0.0;
   __syncthreads();                       // shd is free again
   mean_out = mean;

@@ -27,7 +27,7 @@ struct HeadParams {
 #define HEAD_MAX_SETS 2
 struct HeadSet {
   HeadParams P;
-  const float* W;      // [N][C][taps]
+  const float* W;      // [N][taps][C]: the re-laid fp32 copy of the nn.Conv1d weight (N, C, taps)
   const float* bias;
   float* out;
   float* z;
@@ -54,39 +54,26 @@ __device__ __forceinline__ int head_group_of(const HeadParams& P, int r) {
 // in registers), a wavefront owns a run of consecutive rows of the level-concatenated row space.
 #define HEAD_RPW 8     // rows per wavefront (forward / data gradient)
 
-#define HEAD_LDS_C 1024   // channel counts up to this stage the weights through LDS
-
-// A lane's N x taps x VN weights.  W is the parameter layout [N][C][taps]: gathered straight from global memory that is
-// N*taps*VN four-byte loads at a stride of `taps` floats PER LANE (48 load instructions per wave for 8 rows of work -- the
-// dominant cost of these GEMV-shaped kernels).  Instead the workgroup copies W once, coalesced, into LDS re-laid as
-// [N][taps][C] (head_stage_w, called by every thread before any early return); a lane then reads VN consecutive floats
-// per (n, tap).
-__device__ __forceinline__ void head_stage_w(const float* __restrict__ W, int C, int taps, int N, float* sW) {
-  if (C <= HEAD_LDS_C) {
-    const int total = N * C * taps;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const int tp = i % taps, nc = i / taps;          // i = (n*C + c)*taps + tp
-      const int c = nc % C, n = nc / C;
-      sW[(n * taps + tp) * C + c] = W[i];
-    }
-  }
-  __syncthreads();
-}
-
+// A lane's N x taps x VN weights come from `Wt`, the fp32 copy of the nn.Conv1d weight re-laid as [N][taps][C] (kept current by the
+// optimizer like every other GEMM-layout copy: drn_adam_tiled): VN consecutive floats per (n, tap) = one or two 16-byte loads
+// out of a 12 KB, L2-resident table -- no LDS staging pass, no barrier in front of the activations.
 template <typename T>
-__device__ __forceinline__ void head_load_w(const float* __restrict__ W, const float* sW, int C, int taps, int N, int c0, bool live,
+__device__ __forceinline__ void head_load_w(const float* __restrict__ Wt, int C, int taps, int N, int c0, bool live,
                                             float (&wr)[HEAD_MAX_N][HEAD_MAX_TAPS][V16<T>::N]) {
   constexpr int VN = V16<T>::N;
 #pragma unroll
   for (int n = 0; n < HEAD_MAX_N; ++n)
 #pragma unroll
-    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp)
+    for (int tp = 0; tp < HEAD_MAX_TAPS; ++tp) {
+      const bool on = live && n < N && tp < taps;
+      const float* src = Wt + ((long)((on ? n : 0) * taps + (on ? tp : 0)) * C + (live ? c0 : 0));     // always a valid address
 #pragma unroll
-      for (int k = 0; k < VN; ++k) {
-        float v = 0.f;
-        if (live && n < N && tp < taps) v = C <= HEAD_LDS_C ? sW[(n * taps + tp) * C + c0 + k] : W[((long)n * C + c0 + k) * taps + tp];
-        wr[n][tp][k] = v;
+      for (int q = 0; q < VN / 4; ++q) {
+        const f32x4 t = *(const f32x4*)(src + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wr[n][tp][q * 4 + k] = on ? t[k] : 0.f;
       }
+    }
 }
 
 // dz[r][n] = exp_mode ? scale_l * out[r][n] * dout[r][n] : dout[r][n]   (chain rule of exp(scale * z))
@@ -114,9 +101,8 @@ __device__ __forceinline__ HeadRun head_run(const HeadParams& P, int r0) {
 }
 
 // out[r][n] (and z[r][n] in exp mode); r = concatenated row over levels.  grid = ceil(rows / (4*HEAD_RPW)), block 256.
-// The activations of a window run are requested BEFORE the workgroup stages the weights through LDS: the launch is one
-// residency wave long, so its duration is one workgroup's dependency chain -- weights -> LDS -> barrier -> activations -> FMAs
-// -> wave reduction -- and the two memory trips at its head now overlap.
+// The launch is one residency wave long, so its duration is one wave's dependency chain: the activations of a window run and the
+// lane's weights are requested together (one memory trip), then FMAs and the wave reduction.
 template <typename T>
 __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
   constexpr int VN = V16<T>::N;
@@ -129,8 +115,8 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
   const int N = P.N, C = P.C, taps = P.taps;
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: row bookkeeping on the scalar unit
-  __shared__ float sW[HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C];
   const int nvec = C / VN;
+  if (r0 >= P.total_rows) return;
   const HeadRun R = head_run(P, r0);
   const T* __restrict__ Xw = (const T*)P.g[R.g].X;
   const int Mw = P.g[R.g].M, Lw = P.g[R.g].L;
@@ -143,9 +129,7 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
       xr[j] = V16<T>::ldraw(Xw + (long)m * ldw + v * VN);
     }
   };
-  if (R.window && lane < nvec) fetch_window(lane);
-  head_stage_w(W, C, taps, N, sW);
-  if (r0 >= P.total_rows) return;
+  if (R.window && lane < nvec) fetch_window(lane);      // in flight while the weights arrive
   float acc[HEAD_RPW][HEAD_MAX_N];
 #pragma unroll
   for (int i = 0; i < HEAD_RPW; ++i)
@@ -155,7 +139,7 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
     const int v = vb + lane;
     const bool live = v < nvec;
     float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
-    head_load_w<T>(W, sW, C, taps, N, v * VN, live, wr);
+    head_load_w<T>(W, C, taps, N, v * VN, live, wr);
     if (!live) continue;
     if (R.window) {
       if (vb) fetch_window(v);
@@ -287,7 +271,7 @@ __device__ __forceinline__ void head_dz_window(const HeadParams& P, const HeadRu
 }
 
 template <typename T>
-__device__ __forceinline__ void head_bwd_data_part(const HeadSet& S, float* sW, const int by) {
+__device__ __forceinline__ void head_bwd_data_part(const HeadSet& S, const int by) {
   constexpr int VN = V16<T>::N;
   const HeadParams& P = S.P;
   const float* __restrict__ W = S.W;
@@ -297,13 +281,12 @@ __device__ __forceinline__ void head_bwd_data_part(const HeadSet& S, float* sW, 
   const int N = P.N, C = P.C, taps = P.taps;
   const int v = blockIdx.x * 64 + (threadIdx.x & 63);
   const int r0 = (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: the dz scalars come through the scalar cache
+  if (v * VN >= C || r0 >= P.total_rows) return;
   const HeadRun R = head_run(P, r0);
   float dzw[HEAD_RPW + 2][HEAD_MAX_N];
-  if (R.window) head_dz_window(P, R, dout, out, dzw);      // before the weights are staged: the two trips overlap
-  head_stage_w(W, C, taps, N, sW);
-  if (v * VN >= C || r0 >= P.total_rows) return;
+  if (R.window) head_dz_window(P, R, dout, out, dzw);
   float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
-  head_load_w<T>(W, sW, C, taps, N, v * VN, true, wr);
+  head_load_w<T>(W, C, taps, N, v * VN, true, wr);
   if (R.window) {
     const HeadGroup& G = P.g[R.g];
     const int L = G.L;
@@ -528,10 +511,9 @@ __device__ __forceinline__ void head_bwd_w_part(const HeadSet& S, float* sred, c
 template <typename T>
 __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadMulti MS, const int nblk_data) {
   constexpr int VN = V16<T>::N;
-  constexpr int SW_FLOATS = HEAD_MAX_N * HEAD_MAX_TAPS * HEAD_LDS_C, RED_FLOATS = 4 * (64 * VN + 1);
-  __shared__ float smem[SW_FLOATS > RED_FLOATS ? SW_FLOATS : RED_FLOATS];
+  __shared__ float smem[4 * (64 * VN + 1)];
   const HeadSet& S = MS.s[blockIdx.z];
-  if ((int)blockIdx.y < nblk_data) head_bwd_data_part<T>(S, smem, blockIdx.y);
+  if ((int)blockIdx.y < nblk_data) head_bwd_data_part<T>(S, blockIdx.y);
   else head_bwd_w_part<T>(S, smem, blockIdx.y - nblk_data);
 }
 

@@ -32,12 +32,14 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_kernel(const float
 }
 
 // The same with the finalize pass folded in: every workgroup publishes its partial with a write-through (agent-scope) store,
-// drains it and takes a ticket; the workgroup that draws the LAST ticket of the step -- `expected` workgroups over all buckets'
-// launches -- adds ALL partials in index order (agent-scope loads: nothing stale out of its own L1) exactly as
-// sumsq_finalize_kernel does, so the result does not depend on who came last, and re-arms the ticket.  One launch and one
-// kernel boundary less per step (the squared norm of 38 M gradients is 10887 partials: ~2 us of tail for the one workgroup).
+// drains it and takes a ticket; the workgroup that draws the LAST ticket of the step adds ALL partials in index order
+// (agent-scope loads: nothing stale out of its own L1) exactly as sumsq_finalize_kernel does, so the result does not depend on
+// who came last.  Tickets are two-level -- one counter per SUMSQ_GROUP consecutive partials, whose last arriver takes a ticket
+// of the top counter -- because one word takes only ~90 atomics per microsecond: 10887 workgroups on a single counter made this
+// 29 us kernel 144 us long.  tickets[0] = top, tickets[1 + g] = group g; all zero on entry, re-armed by their last arrivers.
+#define SUMSQ_GROUP 32
 __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_fin_kernel(const float* __restrict__ g, long n, float* all_partials,
-                                                                          int part_off, int npart_all, int* ticket, int expected,
+                                                                          int part_off, int npart_all, int* tickets,
                                                                           float* __restrict__ total, int* __restrict__ step_counter) {
   __shared__ float sh[17];
   __shared__ int s_last;
@@ -55,11 +57,20 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_fin_kernel(const f
   }
   s = block_sum(s, sh);
   if (threadIdx.x == 0) {
-    __hip_atomic_store(all_partials + part_off + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int idx = part_off + blockIdx.x, grp = idx / SUMSQ_GROUP;
+    const int ngroups = (npart_all + SUMSQ_GROUP - 1) / SUMSQ_GROUP;
+    const int in_group = min(SUMSQ_GROUP, npart_all - grp * SUMSQ_GROUP);
+    __hip_atomic_store(all_partials + idx, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = prev == expected - 1;
-    if (prev == expected - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+    int last = 0;
+    if (__hip_atomic_fetch_add(tickets + 1 + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1) {
+      __hip_atomic_store(tickets + 1 + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed
+      if (__hip_atomic_fetch_add(tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+        __hip_atomic_store(tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    s_last = last;
   }
   __syncthreads();
   if (!s_last) return;
@@ -72,13 +83,15 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_fin_kernel(const f
 
 extern "C" int64_t drn_opt_nblocks(int64_t n) { return (n + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK; }
 
-extern "C" int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* ticket,
+extern "C" int64_t drn_sumsq_tickets(int npart_all) { return 1 + (npart_all + SUMSQ_GROUP - 1) / SUMSQ_GROUP; }
+
+extern "C" int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* tickets,
                                       float* total_sumsq, int* step_counter, void* stream) {
   drn_clear_status();
-  DRN_CHECK_ARG(g && all_partials && ticket && total_sumsq && n > 0 && part_off >= 0 &&
+  DRN_CHECK_ARG(g && all_partials && tickets && total_sumsq && n > 0 && part_off >= 0 &&
                 part_off + drn_opt_nblocks(n) <= npart_all, "drn_sumsq_partials_fin: bad args");
   sumsq_partials_fin_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(g, n, all_partials, part_off, npart_all,
-                                                                                              ticket, npart_all, total_sumsq, step_counter);
+                                                                                              tickets, total_sumsq, step_counter);
   return drn_launch_status("drn_sumsq_partials_fin");
 }
 

@@ -1077,11 +1077,13 @@ class _HeadOutFn(torch.autograd.Function):
             groups = ops.head_groups(xsl, scales=scales)
             out = torch.empty((R, N), dtype=torch.float32, device=dev)
             z = torch.empty((R, N), dtype=torch.float32, device=dev) if scales is not None else None
-            calls.append(dict(groups=groups, W=W, bias=bias, N=N, C=C, taps=taps, exp_mode=scales is not None, out=out, z=z))
+            calls.append(dict(groups=groups, W=packed(W, (0, 2, 1), ops.F32), bias=bias, N=N, C=C, taps=taps,
+                              exp_mode=scales is not None, out=out, z=z))             # W as [N][taps][C] (cached copy)
             outs.append(out)
             zs.append(z if z is not None else out.new_empty(0))
         ops.heads_fwd(calls, code)                       # the heads of one call share launches (two per launch)
         ctx.meta, ctx.geo, ctx.R = meta, geo, R
+        ctx.head_w = [h[0] for h in heads]           # the Parameter objects (`packed` caches per parameter, not per saved tensor)
         ctx.save_for_backward(*args, *outs, *zs)
         return tuple(outs)
 
@@ -1121,7 +1123,8 @@ class _HeadOutFn(torch.autograd.Function):
                 # dX geometry must match X's: both are slices of equally wide buffers
                 for x, dx in zip(xs, dxs):
                     assert x.stride(1) == dx.stride(1), "head input must be contiguous in backward"
-                calls.append(dict(groups=groups, W=W, dout=dout, out=outs[h], z=zs[h] if scales is not None else None, N=N, C=C,
+                calls.append(dict(groups=groups, W=packed(ctx.head_w[h], (0, 2, 1), ops.F32), dout=dout, out=outs[h],
+                                  z=zs[h] if scales is not None else None, N=N, C=C,
                                   taps=taps, exp_mode=scales is not None, accumulate_dx=False, dW=dW, dbias=db, dscale=dsc))
             elif full:
                 for dx in dxs:

@@ -46,7 +46,8 @@ class FusedAdam(object):
         self.partials = torch.zeros(nparts, dtype=torch.float32, device=dev)
         self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.drn_sumsq_tickets.restype = ctypes.c_int64
+        self.ticket = torch.zeros(int(L.drn_sumsq_tickets(nparts)), dtype=torch.int32, device=dev)
 
         self._ptr_sig = tuple(p.data_ptr() for b in reducer.buckets for p in b.params)
         self._updated = frozenset(self._ptr_sig)

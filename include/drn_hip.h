@@ -236,7 +236,9 @@ typedef struct DrnHeadGroup {
   int32_t ldx, M, L;
   const float* scale; /* exp mode: scales[l].scale (1 float) */
 } DrnHeadGroup;
-/* out[r][n] = bias[n] + conv(X, W)[r][n]; exp_mode: z = that, out = exp(scale_l*z).  W is the nn.Conv1d weight (N,C,taps). */
+/* out[r][n] = bias[n] + conv(X, W)[r][n]; exp_mode: z = that, out = exp(scale_l*z).  `W` is the nn.Conv1d weight (N,C,taps)
+ * RE-LAID as [N][taps][C] fp32 (what drn_pack_weight(perm 0,2,1) / drn_adam_tiled's kind-1 copy produce); dW comes back in the
+ * parameter's own (N,C,taps) layout. */
 int drn_head_out_fwd(const DrnHeadGroup* groups /*host*/, int ngroups, const float* W, const float* bias, int N, int C, int taps,
                      int exp_mode, float* out, float* z, int dtype, void* stream);
 /* dout is the gradient w.r.t. `out`; exp_mode applies d out/d z = scale*out and accumulates dscale[l];
@@ -402,10 +404,12 @@ int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partia
 /* partials[b] = sum of g^2 over block b; step_counter (device int, or NULL) is incremented once per call. */
 int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream);
 /* drn_sumsq_partials + drn_sumsq_finalize in one launch per bucket: all_partials holds npart_all = sum over ALL buckets of
- * drn_opt_nblocks(n_b) floats, this bucket's start at part_off; ticket = one int32, zero on entry, left zero.  The workgroup
- * that arrives last over all the step's launches adds all partials in index order into total_sumsq[0] (same value as the two-launch
- * form).  Every bucket of the step must go through this call, on one stream. */
-int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* ticket,
+ * drn_opt_nblocks(n_b) floats, this bucket's start at part_off; tickets = drn_sumsq_tickets(npart_all) int32, zero on entry,
+ * left zero (two-level arrival counters).  The workgroup that arrives last over all the step's launches adds all partials in
+ * index order into total_sumsq[0] (same value as the two-launch form).  Every bucket of the step must go through this call,
+ * on one stream. */
+int64_t drn_sumsq_tickets(int npart_all);
+int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* tickets,
                            float* total_sumsq, int* step_counter, void* stream);
 /* total_sumsq[0] = sum of ALL buckets' partials, one workgroup, fixed order (the squared global gradient norm). */
 int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream);
