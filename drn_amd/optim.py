@@ -47,7 +47,12 @@ class FusedAdam(object):
         self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         L.drn_sumsq_tickets.restype = ctypes.c_int64
-        self.ticket = torch.zeros(int(L.drn_sumsq_tickets(nparts)), dtype=torch.int32, device=dev)
+        self.ticket = torch.zeros(int(L.drn_sumsq_tickets(len(reducer.buckets))), dtype=torch.int32, device=dev)
+        wg = 0
+        for b, st in zip(reducer.buckets, self.state):
+            st["wg_off"] = wg
+            wg += int(L.drn_sumsq_wgs(ctypes.c_int64(b.flat.numel())))
+        self._wg_all = wg
 
         self._ptr_sig = tuple(p.data_ptr() for b in reducer.buckets for p in b.params)
         self._updated = frozenset(self._ptr_sig)
@@ -68,7 +73,7 @@ class FusedAdam(object):
         # squared global gradient norm: per-block partials; the workgroup that finishes last adds them up (no finalize launch)
         for i, (b, st) in enumerate(zip(self.reducer.buckets, self.state)):
             check(L.drn_sumsq_partials_fin(P(b.flat), ctypes.c_int64(b.flat.numel()), P(self.partials), st["part_off"],
-                                           self.partials.numel(), P(self.ticket), P(self.total_sumsq),
+                                           self.partials.numel(), P(self.ticket), st["wg_off"], self._wg_all, P(self.total_sumsq),
                                            P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials_fin")
         self._refresh_mirrors()
         for b, st in zip(self.reducer.buckets, self.state):
