@@ -3,7 +3,10 @@
 // PyTorch put them and are reached through a small device-resident segment table.  Two launches per bucket:
 //   1. drn_sumsq_partials : per-block sums of g^2 (fixed order -> deterministic norm); the first call of a step
 //      also advances the device-side step counter (no host scalar changes between steps -> hipGraph friendly);
-//   2. drn_sumsq_finalize : ONE workgroup adds all partials of all buckets in a fixed order -> the squared global norm;
+//   2. drn_sumsq_finalize : ONE workgroup adds all partials of all buckets in a fixed order -> the squared global norm
+//      (round 3 tried to fold this 5 us launch into (1) by arrival tickets, three ways: a returning atomic per 4096-element
+//      block made the 29 us pass 144 us long -- one word takes ~90 atomics/us --, two-level tickets 64 us, <= 1024 grid-stride
+//      workgroups with one ticket each 44 us: the streaming pass is at 6 TB/s only as 10887 independent fire-and-forget blocks);
 //   3. drn_adam_bucket    : clip coefficient from that scalar, then m,v,p updates with torch.optim.Adam's formula
 //      (bias-corrected, eps outside the sqrt, no weight decay).
 #include "common.h"
@@ -31,84 +34,6 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_kernel(const float
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-// The same with the finalize pass folded in.  At most SUMSQ_MAX_WGS workgroups walk the 4096-element blocks grid-stride (the
-// next block's loads are requested before the current block is reduced), each block's partial is published with a write-through
-// (agent-scope) store; at its end a workgroup drains its stores and takes a ticket, and the workgroup that draws the LAST ticket
-// of the step adds ALL partials in index order (agent-scope loads: nothing stale out of its own L1) exactly as
-// sumsq_finalize_kernel does -- same partials, same order, same value, whoever came last.  Tickets are two-level (one counter
-// per SUMSQ_GROUP workgroups, whose last arriver takes a ticket of the top counter): a single word takes only ~90 atomics per
-// microsecond, and a returning atomic per 4096-element block (10887 of them) made this 29 us kernel 64-144 us long.
-// tickets[0] = top, tickets[1 + g] = group g; all zero on entry, re-armed by their last arrivers.
-#define SUMSQ_GROUP 32
-#define SUMSQ_MAX_WGS 1024
-__global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_fin_kernel(const float* __restrict__ g, long n, float* all_partials,
-                                                                          int part_off, int npart_all, int nblk, int* tickets,
-                                                                          int wg_off, int wg_all, float* __restrict__ total,
-                                                                          int* __restrict__ step_counter) {
-  __shared__ float sh[17];
-  __shared__ int s_last;
-  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
-  f32x4 cur[4], nxt[4];
-  auto fetch = [&](int b, f32x4 (&v)[4]) {          // whole blocks only (the caller handles the ragged last block)
-    const float* p = g + (long)b * OPT_ELEMS_PER_BLOCK + threadIdx.x * 4;
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) v[t4] = *(const f32x4*)(p + t4 * OPT_THREADS * 4);
-  };
-  auto whole = [&](int b) { return b < nblk && (long)(b + 1) * OPT_ELEMS_PER_BLOCK <= n; };
-  int b = blockIdx.x;
-  if (whole(b)) fetch(b, cur);
-  for (; b < nblk; b += gridDim.x) {
-    const int bn = b + gridDim.x;
-    const bool w = whole(b);
-    if (whole(bn)) fetch(bn, nxt);
-    float s = 0.f;
-    if (w) {
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        s = fmaf(cur[t4][0], cur[t4][0], s); s = fmaf(cur[t4][1], cur[t4][1], s);
-        s = fmaf(cur[t4][2], cur[t4][2], s); s = fmaf(cur[t4][3], cur[t4][3], s);
-      }
-    } else {
-      const long base = (long)b * OPT_ELEMS_PER_BLOCK;
-      for (int i = threadIdx.x * 4; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS * 4) {
-        const long k = base + i;
-        if (k + 4 <= n) {
-          const f32x4 v = *(const f32x4*)(g + k);
-          s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
-        } else {
-          for (int e = 0; e < 4 && k + e < n; ++e) s = fmaf(g[k + e], g[k + e], s);
-        }
-      }
-    }
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) __hip_atomic_store(all_partials + part_off + b, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) cur[t4] = nxt[t4];
-  }
-  if (threadIdx.x == 0) {
-    const int idx = wg_off + blockIdx.x, grp = idx / SUMSQ_GROUP;
-    const int ngroups = (wg_all + SUMSQ_GROUP - 1) / SUMSQ_GROUP;
-    const int in_group = min(SUMSQ_GROUP, wg_all - grp * SUMSQ_GROUP);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int last = 0;
-    if (__hip_atomic_fetch_add(tickets + 1 + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1) {
-      __hip_atomic_store(tickets + 1 + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed
-      if (__hip_atomic_fetch_add(tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
-        __hip_atomic_store(tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
-      }
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  float t = 0.f;
-  for (int i = threadIdx.x; i < npart_all; i += OPT_THREADS)
-    t += __hip_atomic_load(all_partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  t = block_sum(t, sh);
-  if (threadIdx.x == 0) total[0] = t;
-}
-
 extern "C" int64_t drn_opt_nblocks(int64_t n) { return (n + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK; }
 
 extern "C" int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream) {
@@ -117,21 +42,6 @@ extern "C" int drn_sumsq_partials(const float* g, int64_t n, float* partials, in
   sumsq_partials_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(g, n, partials, step_counter);
   return drn_launch_status("drn_sumsq_partials");
 }
-
-static int sumsq_wgs(int64_t nblk) { return (int)(nblk < SUMSQ_MAX_WGS ? nblk : SUMSQ_MAX_WGS); }
-extern "C" int64_t drn_sumsq_tickets(int nbuckets) { return 1 + ((int64_t)nbuckets * SUMSQ_MAX_WGS + SUMSQ_GROUP - 1) / SUMSQ_GROUP; }
-
-extern "C" int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* tickets,
-                                      int wg_off, int wg_all, float* total_sumsq, int* step_counter, void* stream) {
-  drn_clear_status();
-  const int64_t nblk = drn_opt_nblocks(n);
-  DRN_CHECK_ARG(g && all_partials && tickets && total_sumsq && n > 0 && part_off >= 0 && part_off + nblk <= npart_all &&
-                wg_off >= 0 && wg_off + sumsq_wgs(nblk) <= wg_all, "drn_sumsq_partials_fin: bad args");
-  sumsq_partials_fin_kernel<<<sumsq_wgs(nblk), OPT_THREADS, 0, (hipStream_t)stream>>>(g, n, all_partials, part_off, npart_all, (int)nblk,
-                                                                                      tickets, wg_off, wg_all, total_sumsq, step_counter);
-  return drn_launch_status("drn_sumsq_partials_fin");
-}
-extern "C" int drn_sumsq_wgs(int64_t n) { return sumsq_wgs(drn_opt_nblocks(n)); }
 
 __global__ __launch_bounds__(1024) void sumsq_finalize_kernel(const float* __restrict__ partials, int n, float* __restrict__ out) {
   __shared__ float sh[17];

@@ -46,13 +46,6 @@ class FusedAdam(object):
         self.partials = torch.zeros(nparts, dtype=torch.float32, device=dev)
         self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.drn_sumsq_tickets.restype = ctypes.c_int64
-        self.ticket = torch.zeros(int(L.drn_sumsq_tickets(len(reducer.buckets))), dtype=torch.int32, device=dev)
-        wg = 0
-        for b, st in zip(reducer.buckets, self.state):
-            st["wg_off"] = wg
-            wg += int(L.drn_sumsq_wgs(ctypes.c_int64(b.flat.numel())))
-        self._wg_all = wg
 
         self._ptr_sig = tuple(p.data_ptr() for b in reducer.buckets for p in b.params)
         self._updated = frozenset(self._ptr_sig)
@@ -70,11 +63,11 @@ class FusedAdam(object):
         L = lib()
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        # squared global gradient norm: per-block partials; the workgroup that finishes last adds them up (no finalize launch)
         for i, (b, st) in enumerate(zip(self.reducer.buckets, self.state)):
-            check(L.drn_sumsq_partials_fin(P(b.flat), ctypes.c_int64(b.flat.numel()), P(self.partials), st["part_off"],
-                                           self.partials.numel(), P(self.ticket), st["wg_off"], self._wg_all, P(self.total_sumsq),
-                                           P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials_fin")
+            part = self.partials[st["part_off"]:]
+            check(L.drn_sumsq_partials(P(b.flat), ctypes.c_int64(b.flat.numel()), P(part),
+                                       P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials")
+        check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), s), "drn_sumsq_finalize")
         self._refresh_mirrors()
         for b, st in zip(self.reducer.buckets, self.state):
             check(L.drn_adam_bucket(P(b.flat), P(st["m"]), P(st["v"]), ctypes.c_int64(b.flat.numel()), P(st["seg"]), P(st["ptr"]),

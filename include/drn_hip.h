@@ -403,16 +403,6 @@ int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, 
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */
 /* partials[b] = sum of g^2 over block b; step_counter (device int, or NULL) is incremented once per call. */
 int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream);
-/* drn_sumsq_partials + drn_sumsq_finalize in one launch per bucket: all_partials holds npart_all = sum over ALL buckets of
- * drn_opt_nblocks(n_b) floats, this bucket's start at part_off.  A bucket's launch has drn_sumsq_wgs(n_b) workgroups; wg_off =
- * the sum of that over the buckets launched before it this step, wg_all = over all buckets.  tickets = drn_sumsq_tickets(number
- * of buckets) int32, zero on entry, left zero (two-level arrival counters).  The workgroup that arrives last over all the
- * step's launches adds all partials in index order into total_sumsq[0] (same value as the two-launch form).  Every bucket of the
- * step must go through this call, on one stream. */
-int64_t drn_sumsq_tickets(int nbuckets);
-int drn_sumsq_wgs(int64_t n);
-int drn_sumsq_partials_fin(const float* g, int64_t n, float* all_partials, int part_off, int npart_all, int32_t* tickets, int wg_off,
-                           int wg_all, float* total_sumsq, int* step_counter, void* stream);
 /* total_sumsq[0] = sum of ALL buckets' partials, one workgroup, fixed order (the squared global gradient norm). */
 int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream);
 /* One bucket: g/m/v flat [n]; tensor i covers [seg_start[i], seg_start[i+1]) and lives at p_ptr[i] (both tables on the
