@@ -90,6 +90,56 @@ def cpu_baseline(cfg, B, T, D, stage, steps):
                       % (steps, B, T, D, stage)}
 
 
+def collate_like(batch, names):
+    """synthetic_batch's 7 model arguments -> the 8-tuple drn_amd.data.collate_data yields (dataset.py:180-224)."""
+    tok, qlen, feats, pse, gt, nprops, nframes = batch
+    return (names, pse, feats, gt, tok, qlen, nprops, nframes)
+
+
+def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, False)):
+    """Throughput of the TRAINING LOOP a user runs (train.py -> drn_amd.trainer.Trainer.train_epoch, main.py:198-252), not of a
+    hand-built step: a fresh model per line, eight device-resident synthetic batches with different query lengths, `steps` steps
+    through train_epoch after the warm-up epoch that captures the hipGraphs.  T=256 is the benchmarked shape, T=32 the number of
+    proposals Charades-STA really has (model/loss.py:98)."""
+    from drn_amd import trainer as TR
+    from drn_amd.model import mainModel
+    out = {}
+    for T in Ts:
+        batches = [collate_like([t.to(dev) if torch.is_tensor(t) else t for t in synthetic_batch(B, T, D, seed=100 + i)], ["v%d" % i] * B)
+                   for i in range(8)]
+        for graph in graph_modes:
+            m = build(mainModel, cfg, dev, compute_dtype=cdt)
+            tr = TR.Trainer(m, stage, lr=1e-3, clip_gradient=0.5, graph=graph)
+            tr.train_epoch(batches)                          # warm-up: every geometry passes warm-up steps
+            tr.train_epoch(batches)                          # ... and capture
+            torch.cuda.synchronize()
+            n_ep = max(1, steps // len(batches))
+            t0 = time.perf_counter()
+            for _ in range(n_ep):
+                tr.train_epoch(batches)                      # (returns the epoch's mean loss: one host sync per epoch)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            key = "T%d_%s" % (T, "graph" if graph else "eager")
+            out[key] = {"clips_per_s": round(B * len(batches) * n_ep / dt, 1), "ms_per_step": round(dt / (len(batches) * n_ep) * 1e3, 3),
+                        "graphs": len([s for s in tr._slots.values() if s.graph is not None]) if graph else 0}
+            if graph and T == Ts[-1]:
+                # evaluation loop (main.py:270-366): eval-mode forward, post-processor, host-side NMS / R@k
+                ev = batches[:4]
+                tr.evaluate(ev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                tr.evaluate(ev)
+                out["evaluate_T%d" % T] = {"clips_per_s": round(B * len(ev) / (time.perf_counter() - t0), 1),
+                                           "note": "Trainer.evaluate: eval forward + drn_postprocess + host-side result records, temporal NMS, R@1/R@5"}
+            if tr.reducer is not None:
+                tr.reducer.remove()
+            del m, tr
+    out["note"] = ("Trainer.train_epoch (what train.py runs) on 8 device-resident synthetic batches, B=%d, query lengths 3..8 padded to "
+                   "multiples of 4; graph = hipGraph replay per input geometry (Trainer(graph=True), train.py's default), eager = every "
+                   "kernel launched from Python" % B)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +161,11 @@ def main():
                          "input prep / deferred weight gradients) instead of ONE linear hipGraph; measured 0.5 %% SLOWER on ROCm 7.2 "
                          "(DESIGN.md section 5), kept as an experiment")
     ap.add_argument("--torch-adam", action="store_true", help="torch clip_grad_norm_ + optim.Adam instead of the fused HIP step")
+    ap.add_argument("--dump-gemms", default=None, metavar="PATH",
+                    help="write the MFMA launches of one step in launch order [(tag, flops)] as JSON (scripts/gemm_table.py joins them "
+                         "with a rocprofv3 kernel trace of the replayed graph)")
+    ap.add_argument("--no-trainer", dest="trainer_line", action="store_false",
+                    help="skip the `trainer` object (clips/s through drn_amd.trainer.Trainer.train_epoch at T=256 and T=32, graph and eager)")
     args = ap.parse_args()
 
     def note(msg):                       # progress on stderr with --verbose (where a multi-rank run stopped, if it did)
@@ -240,6 +295,17 @@ def main():
     note("timed loop done")
     exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
     ar_events = None
+    # the same step launched kernel by kernel from Python (what the hipGraph replay saves): wall clock over a few steps
+    eager_ms = None
+    if args.graph and world == 1 and not args.no_kernel_timing:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - te) / 10 * 1e3
     # per-kernel timing of the MFMA GEMMs for the roofline object: HIP events around each launch, on the launch
     # stream, over a few extra eager steps of the same workload (events cannot sit inside a replayed graph)
     timers = None
@@ -251,6 +317,10 @@ def main():
         ops.kernel_timer = None
         note("kernel timing done")
         timed_steps = max(3, min(args.steps, 5))
+        if args.dump_gemms and rank == 0:
+            per = len(timers) // timed_steps
+            with open(args.dump_gemms, "w") as f:
+                json.dump([[t[0], t[1]] for t in timers[-per:]], f)
     per_rank = None
     if world > 1:
         mine = torch.tensor([dt, exposed_ms], device=dev, dtype=torch.float64)
@@ -342,9 +412,12 @@ def main():
             pass
         roof = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic, "traffic_note": traffic_note,
-                "avg_launch_ms": round(avg_ms, 4),
-                "launches_per_step": n // timed_steps, "mfma_kernels_ms_per_step": round(gemm_ms, 3),
-                "note": "dominant kernel by total time; flops = 2*M*N*K of that launch; HIP events on the launch stream"}
+                "avg_launch_ms_eager": round(avg_ms, 4),
+                "launches_per_step": n // timed_steps, "mfma_kernels_ms_per_step_eager": round(gemm_ms, 3),
+                "note": "dominant kernel by total time; flops = 2*M*N*K of that launch; `*_eager` figures (and `achieved`, `frac`) are "
+                        "HIP events around each launch of extra EAGER steps on the launch stream (events cannot sit inside a replayed "
+                        "graph); inside the replayed graph the same launches run 5-7 % shorter: profiles/*_step_kernel_sequence.txt, "
+                        "profiles/*_gemm_table.txt"}
     # t_bound / t_measured with t_bound = max(FLOPs / peak_mfma, compulsory bytes / peak_hbm) over the WHOLE step
     step_flops = fl["step"] * B * world
     bytes_in = 4.0 * B * world * T * D                       # the feature tensor, read once (fp32 in HBM)
@@ -368,10 +441,18 @@ def main():
                       "global_batch": B * world, "T": T, "D": D, "parallelism": "dp%d" % world, "launch": mode,
                       "loss_cls": float(losses["loss_cls"].detach().reshape(-1)[0])},
            "roofline": roof}
+    if eager_ms is not None:
+        out["eager_ms_per_step"] = round(eager_ms, 3)
     if per_rank is not None:
         out["per_rank"] = per_rank
     if f32_line is not None:
         out["f32"] = f32_line
+    if rank == 0 and world == 1 and args.trainer_line and args.graph and not args.torch_adam:
+        try:
+            del run
+            out["trainer"] = trainer_lines(cfg, dev, cdt, stage, B, D, (32, T) if T != 32 else (T,), min(args.steps * 2, 48))
+        except Exception as e:
+            print("trainer timing failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
     if rank == 0:
         if world == 1 and args.cpu_steps > 0:
             # stock PyTorch oversubscribes badly on these small convs beyond ~32 threads

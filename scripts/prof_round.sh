@@ -7,15 +7,16 @@ TAG=${1:-r02_a}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --steps 30"
+CMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --no-trainer --steps 30"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/bench_under_trace.json 2> /dev/null
-PMCCMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --steps 4 --warmup 2"
+PMCCMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --no-trainer --steps 4 --warmup 2"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- $PMCCMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- $PMCCMD > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --dump-gemms $OUT/gemms.json > $OUT/bench_default.json 2> $OUT/bench_default.err
 python scripts/rocprof_summary.py $OUT/trace/t_results.db 35 > $OUT/kernel_stats.txt
 python scripts/rocprof_step.py $OUT/trace/t_results.db > $OUT/step_kernel_sequence.txt
+python scripts/gemm_table.py $OUT/trace/t_results.db $OUT/gemms.json > $OUT/gemm_table.txt 2> $OUT/gemm_table.err
 python scripts/pmc_hbm_table.py $OUT/trace/t_results.db $OUT/fetch/f_results.db $OUT/write/w_results.db > $OUT/hbm_kernels.txt 2> $OUT/hbm_kernels.err
 rm -rf $OUT/trace $OUT/fetch $OUT/write
 tail -3 $OUT/step_kernel_sequence.txt; head -30 $OUT/hbm_kernels.txt; cat $OUT/hbm_kernels.err | tail -5; cat $OUT/bench_default.json | head -c 400
