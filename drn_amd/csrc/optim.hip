@@ -43,18 +43,19 @@ extern "C" int drn_sumsq_partials(const float* g, int64_t n, float* partials, in
   return drn_launch_status("drn_sumsq_partials");
 }
 
-__global__ __launch_bounds__(1024) void sumsq_finalize_kernel(const float* __restrict__ partials, int n, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sumsq_finalize_kernel(const float* __restrict__ partials, int n, float* __restrict__ out,
+                                                              float grad_scale) {
   __shared__ float sh[17];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) s += partials[i];
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) out[0] = s;
+  if (threadIdx.x == 0) out[0] = s * grad_scale * grad_scale;       // the norm of grad_scale * g
 }
 
-extern "C" int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream) {
+extern "C" int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, float grad_scale, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(partials && total_sumsq && npartials > 0, "drn_sumsq_finalize: bad args");
-  sumsq_finalize_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partials, npartials, total_sumsq);
+  sumsq_finalize_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partials, npartials, total_sumsq, grad_scale);
   return drn_launch_status("drn_sumsq_finalize");
 }
 
@@ -71,6 +72,7 @@ struct AdamArgs {
   bf16_t* const* mirror;    // [nseg] bf16 copy of the tensor in the SAME element order (Linear / 1x1-conv GEMM operand), or NULL
   const int* step_counter;
   float lr, beta1, beta2, eps, max_norm;
+  float grad_scale;         // g is read as grad_scale * g (1/world: the buckets hold the all-reduced SUM, see drn_amd.dist)
 };
 
 __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs A) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
         const int i = threadIdx.x * 4 + t4 * OPT_THREADS * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float g = g4[t4][e] * clip;
+          const float g = g4[t4][e] * A.grad_scale * clip;
           m4[t4][e] = A.beta1 * m4[t4][e] + (1.f - A.beta1) * g;
           v4[t4][e] = A.beta2 * v4[t4][e] + (1.f - A.beta2) * g * g;
           p4[t4][e] -= step_size * m4[t4][e] / (sqrtf(v4[t4][e]) * inv_sqrt_bc2 + A.eps);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
       f32x4 m4 = *(const f32x4*)(A.m + k), v4 = *(const f32x4*)(A.v + k), p4 = *(const f32x4*)p;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float g = g4[e] * clip;
+        const float g = g4[e] * A.grad_scale * clip;
         m4[e] = A.beta1 * m4[e] + (1.f - A.beta1) * g;
         v4[e] = A.beta2 * v4[e] + (1.f - A.beta2) * g * g;
         p4[e] -= step_size * m4[e] / (sqrtf(v4[e]) * inv_sqrt_bc2 + A.eps);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
         for (int e = 0; e < 4; ++e) mq[e] = (bf16_t)p4[e];
     } else {
       for (int e = 0; e < 4 && k + e < s1 && k + e < A.n; ++e) {
-        const float g = A.g[k + e] * clip;
+        const float g = A.g[k + e] * A.grad_scale * clip;
         const float m = A.beta1 * A.m[k + e] + (1.f - A.beta1) * g;
         const float v = A.beta2 * A.v[k + e] + (1.f - A.beta2) * g * g;
         A.m[k + e] = m;
@@ -180,14 +182,15 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
 
 extern "C" int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev,
                                int nseg, const int* blk_seg, void* const* mirror_dev, const float* total_sumsq,
-                               const int* step_counter, float lr, float beta1, float beta2, float eps, float max_norm, void* stream) {
+                               const int* step_counter, float lr, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                               void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(g && m && v && n > 0 && seg_start_dev && p_ptr_dev && nseg > 0 && total_sumsq && step_counter,
                 "drn_adam_bucket: bad args");
   AdamArgs A;
   A.g = g; A.m = m; A.v = v; A.n = n; A.seg_start = (const long*)seg_start_dev; A.p_ptr = p_ptr_dev; A.nseg = nseg;
   A.total_sumsq = total_sumsq; A.step_counter = step_counter; A.blk_seg = blk_seg; A.mirror = (bf16_t* const*)mirror_dev;
-  A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.max_norm = max_norm;
+  A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.max_norm = max_norm; A.grad_scale = grad_scale;
   adam_bucket_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_adam_bucket");
 }
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
                                                                 const DrnAdamTiledItem* __restrict__ items, const int* __restrict__ blk_item,
                                                                 const int* __restrict__ blk_tile, const float* __restrict__ total_sumsq,
                                                                 const int* __restrict__ step_counter, float lr, float beta1, float beta2,
-                                                                float eps, float max_norm) {
+                                                                float eps, float max_norm, float grad_scale) {
   __shared__ float tile[64][64 * TILED_MAXK + 1];
   const DrnAdamTiledItem it = items[blk_item[blockIdx.x]];
   const int t = blk_tile[blockIdx.x];
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
         const int r = q / qpr, c4 = (q - r * qpr) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float g = g4[u][e] * clip;
+          const float g = g4[u][e] * grad_scale * clip;
           m4[u][e] = beta1 * m4[u][e] + (1.f - beta1) * g;
           v4[u][e] = beta2 * v4[u][e] + (1.f - beta2) * g * g;
           p4[u][e] -= step_size * m4[u][e] / (sqrtf(v4[u][e]) * inv_sqrt_bc2 + eps);
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
     for (int q = threadIdx.x; q < nr * ts; q += OPT_THREADS) {
       const int r = q / ts, c = q - r * ts;
       const long e0 = tbase + (long)r * S + c;
-      const float g = G[it.off + e0] * clip;
+      const float g = G[it.off + e0] * grad_scale * clip;
       const float mm = beta1 * Mo[it.off + e0] + (1.f - beta1) * g;
       const float vv = beta2 * Vo[it.off + e0] + (1.f - beta2) * g * g;
       Mo[it.off + e0] = mm;
@@ -328,11 +331,11 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
 
 extern "C" int drn_adam_tiled(const float* g, float* m, float* v, const DrnAdamTiledItem* items_dev, const int32_t* blk_item_dev,
                               const int32_t* blk_tile_dev, int nblocks, const float* total_sumsq, const int* step_counter, float lr,
-                              float beta1, float beta2, float eps, float max_norm, void* stream) {
+                              float beta1, float beta2, float eps, float max_norm, float grad_scale, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(g && m && v && items_dev && blk_item_dev && blk_tile_dev && nblocks > 0 && total_sumsq && step_counter,
                 "drn_adam_tiled: bad args");
   adam_tiled_kernel<<<nblocks, OPT_THREADS, 0, (hipStream_t)stream>>>(g, m, v, items_dev, blk_item_dev, blk_tile_dev, total_sumsq,
-                                                                       step_counter, lr, beta1, beta2, eps, max_norm);
+                                                                       step_counter, lr, beta1, beta2, eps, max_norm, grad_scale);
   return drn_launch_status("drn_adam_tiled");
 }

@@ -62,6 +62,9 @@ class GradReducer(object):
         flat buffer and is written there directly (functional.grad_buffer)."""
         self.group = group
         self.overlap = overlap
+        # True (set by drn_amd.optim.FusedAdam): wait() leaves the all-reduced SUM in the buckets -- `p.grad` then reads
+        # world x the mean -- and the optimizer kernels apply 1/world themselves (`grad_scale`)
+        self.defer_average = False
         # steal=True: p.grad is None at the start of backward; backward kernels that know the sink write straight into
         # the flat bucket and autograd adopts that view (no zero-fill, no accumulate-add); anything else is copied in.
         self.steal = steal
@@ -196,13 +199,14 @@ class GradReducer(object):
                 self._launch(b)
 
     def wait(self):
-        """Wait for all collectives and turn sums into means."""
+        """Wait for all collectives and turn sums into means (unless the optimizer does that: `defer_average`)."""
         if self.world > 1:
             for b in self.buckets:
                 if b.handle is not None:
                     b.handle.wait()
                     b.handle = None
-                    b.flat.div_(self.world)
+                    if not self.defer_average:
+                        b.flat.div_(self.world)
 
     def rearm(self):
         """Deferred (hipGraph) mode: hooks only run at capture time, so mark every bucket as not yet reduced."""

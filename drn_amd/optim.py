@@ -13,6 +13,10 @@ class FusedAdam(object):
     def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=0.5, tiled=True):
         """tiled=False keeps every parameter on the linear kernel and leaves the re-laid weight copies to repack_all()."""
         self.reducer, self.lr, self.betas, self.eps, self.max_norm, self.tiled = reducer, lr, betas, eps, max_norm, tiled
+        # the kernels read every gradient as grad_scale * g: the reducer leaves the all-reduced SUM in its buckets and the
+        # division by the world size rides here instead of one elementwise launch per bucket and step
+        reducer.defer_average = True
+        self.grad_scale = 1.0 / float(reducer.world)
         L = lib()
         L.drn_opt_nblocks.restype = ctypes.c_int64
         dev = reducer.buckets[0].flat.device
@@ -67,20 +71,22 @@ class FusedAdam(object):
             part = self.partials[st["part_off"]:]
             check(L.drn_sumsq_partials(P(b.flat), ctypes.c_int64(b.flat.numel()), P(part),
                                        P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials")
-        check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), s), "drn_sumsq_finalize")
+        check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), ctypes.c_float(self.grad_scale), s),
+              "drn_sumsq_finalize")
         self._refresh_mirrors()
         for b, st in zip(self.reducer.buckets, self.state):
             check(L.drn_adam_bucket(P(b.flat), P(st["m"]), P(st["v"]), ctypes.c_int64(b.flat.numel()), P(st["seg"]), P(st["ptr"]),
                                     st["nseg"], P(st["blk_seg"]), P(st.get("mirror")), P(self.total_sumsq), P(self.step_counter),
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
-                                    ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s), "drn_adam_bucket")
+                                    ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), ctypes.c_float(self.grad_scale), s),
+                      "drn_adam_bucket")
         for b, st in zip(self.reducer.buckets, self.state):
             if st.get("tiled") is not None:
                 raw, bi, bt, nb = st["tiled"]
                 check(L.drn_adam_tiled(P(b.flat), P(st["m"]), P(st["v"]), P(raw), P(bi), P(bt), nb, P(self.total_sumsq),
                                        P(self.step_counter), ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
-                                       ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), s),
-                      "drn_adam_tiled")
+                                       ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps), ctypes.c_float(self.max_norm),
+                                       ctypes.c_float(self.grad_scale), s), "drn_adam_tiled")
         DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
         if repack:
             self.repack()

@@ -100,3 +100,32 @@ def synthetic_batch(B, T, D, seed=1, device="cpu"):
             torch.from_numpy(feats).to(dev), torch.from_numpy(pse).to(dev),
             torch.from_numpy(gt).to(dev), torch.full((B,), T, dtype=torch.int64),
             torch.full((B,), 16 * T, dtype=torch.int64))
+
+
+def planted_batches(n, B, T, D, seed=0, noise=0.3):
+    """n synthetic batches in drn_amd.data.collate_data's 8-tuple format whose FEATURES CARRY THE ANSWER: every clip has one
+    ground-truth segment, proposals inside it hold a fixed pattern vector (+ noise), the others noise only -- a planted signal a
+    model can learn to localise in a few hundred steps (there is no Charades-STA feature file in this repository: the only R@1
+    evidence obtainable is relative, between two runs of this task).  Uniform proposals (t/T, (t+1)/T) as the reference's
+    MAN-32 props file gives; segment lengths 0.15-0.6 of the clip; random queries (they carry no information)."""
+    g = np.random.default_rng(int(seed))
+    pattern = np.random.default_rng(12345).standard_normal(D).astype(np.float32)
+    t = np.arange(T, dtype=np.float64)
+    pse1 = np.stack([t / T, (t + 1) / T], -1)
+    centres = (t + 0.5) / T
+    out = []
+    for i in range(n):
+        s = g.uniform(0.0, 0.4, size=B)
+        w = g.uniform(0.15, 0.6, size=B)
+        e = np.minimum(s + w, 1.0)
+        inside = ((centres[None, :] >= s[:, None]) & (centres[None, :] <= e[:, None])).astype(np.float32)
+        feats = np.abs(noise * g.standard_normal((B, T, D)).astype(np.float32) + inside[:, :, None] * pattern[None, None, :])
+        lens = np.sort(g.integers(3, 9, size=B))[::-1].copy()
+        tokens = np.zeros((B, int(lens.max())), dtype=np.int64)
+        for b in range(B):
+            tokens[b, :lens[b]] = g.integers(1, VOCAB_SIZE + 1, size=lens[b])
+        names = ["clip%d_%d" % (i, b) for b in range(B)]
+        out.append((names, torch.from_numpy(np.broadcast_to(pse1[None], (B, T, 2)).copy()), torch.from_numpy(feats),
+                    torch.from_numpy(np.stack([s, e], -1)), torch.from_numpy(tokens), torch.from_numpy(lens.astype(np.int64)),
+                    torch.full((B,), T, dtype=torch.int64), torch.full((B,), 16 * T, dtype=torch.int64)))
+    return out

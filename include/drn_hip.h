@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 4
+#define DRN_ABI_VERSION 5
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
@@ -403,16 +403,17 @@ int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, 
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */
 /* partials[b] = sum of g^2 over block b; step_counter (device int, or NULL) is incremented once per call. */
 int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream);
-/* total_sumsq[0] = sum of ALL buckets' partials, one workgroup, fixed order (the squared global gradient norm). */
-int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, void* stream);
+/* total_sumsq[0] = grad_scale^2 * sum of ALL buckets' partials, one workgroup, fixed order: the squared global norm of the
+ * gradients the Adam kernels see, grad_scale * g (grad_scale = 1/world when the buckets hold the all-reduced SUM; 1 otherwise). */
+int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, float grad_scale, void* stream);
 /* One bucket: g/m/v flat [n]; tensor i covers [seg_start[i], seg_start[i+1]) and lives at p_ptr[i] (both tables on the
  * device).  blk_seg (device, drn_opt_nblocks(n) ints, or NULL): index of the tensor holding element 4096*b, so a block
  * does not search the table.  mirror_dev (device table of nseg pointers, or NULL; entries may be NULL): a bf16 copy of tensor
  * i in the same element order (the GEMM operand of a Linear / 1x1 conv), rewritten from the updated value in the same pass.
- * clip coef = min(1, max_norm/(sqrt(total_sumsq)+1e-6)) (max_norm<=0: off). */
+ * Every gradient is read as grad_scale * g; clip coef = min(1, max_norm/(sqrt(total_sumsq)+1e-6)) (max_norm<=0: off). */
 int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, const int64_t* seg_start_dev, float* const* p_ptr_dev, int nseg,
                     const int32_t* blk_seg, void* const* mirror_dev, const float* total_sumsq, const int* step_counter, float lr,
-                    float beta1, float beta2, float eps, float max_norm, void* stream);
+                    float beta1, float beta2, float eps, float max_norm, float grad_scale, void* stream);
 
 /* The same update for tensors whose GEMM operands are RE-LAID copies (conv weights (Cout, Cin, k) as [Cout][k][Cin] and
  * [Cin][k][Cout]; Linear weights transposed): the tensor is walked in 64 x 64-channel tiles instead of linearly, each tile's
@@ -431,7 +432,7 @@ typedef struct DrnAdamTiledItem {
 } DrnAdamTiledItem;
 int drn_adam_tiled(const float* g, float* m, float* v, const DrnAdamTiledItem* items_dev, const int32_t* blk_item_dev,
                    const int32_t* blk_tile_dev, int nblocks, const float* total_sumsq, const int* step_counter, float lr, float beta1,
-                   float beta2, float eps, float max_norm, void* stream);
+                   float beta2, float eps, float max_norm, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -208,3 +208,32 @@ def test_bf16_losses_heads_gradients_vs_oracle(B, T, D, stage, tol_glob, tol_big
                                                                                max(big, key=big.get)))
     assert glob <= tol_glob, glob
     assert max(big.values()) <= tol_big, sorted(big.items(), key=lambda kv: -kv[1])[:5]
+
+
+
+# The same comparison with the ORACLE GIVEN THE bf16 RUN'S ReLU DECISIONS: what is left is bf16 rounding alone (storage of 13
+# stacked conv+BN layers' activations and gradients, unit roundoff 2^-9), no discrete disagreement.  If the 0.14-0.20 of the
+# free comparison above were anything but ReLU flips -- a bf16-only code path gone wrong (the split-K branches only bf16 takes,
+# drn_amd/ops.py:_ksplit) -- it would survive the injection.
+@pytest.mark.parametrize("B,T,D,stage", [(32, 256, 4096, 1), (32, 256, 4096, 3)])
+def test_bf16_gradients_vs_oracle_given_equal_relu_decisions(B, T, D, stage, monkeypatch):
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    cfg, batch, mo = make_case(B, T, D, stage, seed=3)
+    mh, lh, head_h, taps = hip_run(cfg, batch, stage, dtype=torch.bfloat16, tap=True)
+    inject_masks(mo, mh, taps, monkeypatch)
+    _, lo = mo(*batch)
+    loss_of(lo, stage).backward()
+    errs, glob = grad_errors(mh, mo)
+    numel = {k: p.numel() for k, p in mo.named_parameters()}
+    big = {k: e for k, e in errs.items() if numel[k] >= 100000}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("bf16 masked B=%d T=%d stage %d: global %.3e, large-tensor max %.3e (%s), worst %s" %
+          (B, T, stage, glob, max(big.values()), max(big, key=big.get), worst))
+    for k in ("loss_cls", "loss_reg", "loss_iou"):
+        a, b = float(lh[k].reshape(-1)[0]), float(lo[k].reshape(-1)[0])
+        assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), (k, a, b)
+    assert glob <= BF16_MASKED_GLOBAL, glob
+    assert max(big.values()) <= BF16_MASKED_BIG, sorted(big.items(), key=lambda kv: -kv[1])[:5]
+
+
+BF16_MASKED_GLOBAL, BF16_MASKED_BIG = 3e-2, 6e-2        # measured: see DESIGN.md section 4 (round 3)
