@@ -40,6 +40,7 @@ struct WgradParams {
   // group g owns gridDim.z slices [z_start[g], z_start[g+1]), its rows are split into bps[g]-block pieces
   int multi;
   int z_start[DRN_MAX_GROUPS + 1], bps[DRN_MAX_GROUPS], gdirect[DRN_MAX_GROUPS];
+  int gcin[DRN_MAX_GROUPS];   // multi: the problem's own input-channel count (the per-tap kernel only; the FPN laterals differ in Cin)
   float* gout[DRN_MAX_GROUPS];
 };
 
@@ -125,14 +126,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   constexpr int CPR = (int)sizeof(T);       // 16-byte chunks per 16-column row piece
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;   // wave index as a scalar: LDS-DMA bases (M0) stay in SGPRs
   const int tn = blockIdx.x;                // 128-wide block of output channels n
-  const int tap = blockIdx.y / P.ctiles;
-  const int c0 = (blockIdx.y - tap * P.ctiles) * TC;
-  const int n0 = tn * TNn;
   int split = blockIdx.z;
   int blk_lo = split * P.blks_per_split;
   int blk_hi = min(blk_lo + P.blks_per_split, P.total_blks);
   float* out_ptr = P.out;
   int direct = P.direct;
+  int Cin = Cin, ctiles = P.ctiles;
   if (P.multi) {
     int pg = 0;
 #pragma unroll
@@ -144,7 +143,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
     blk_hi = min(blk_lo + P.bps[pg], blk_end);
     out_ptr = P.gout[pg];
     direct = P.gdirect[pg];
+    Cin = P.gcin[pg];
+    ctiles = (Cin + TC - 1) / TC;
+    if ((int)blockIdx.y >= P.taps * ctiles) return;       // the grid is sized for the widest problem
   }
+  const int tap = blockIdx.y / ctiles;
+  const int c0 = (blockIdx.y - tap * ctiles) * TC;
+  const int n0 = tn * TNn;
   const T* zero = (const T*)g_zero_page;
 
   // lane-constant piece of the staging map: instr q = w*4+i covers chunks p = q*64 + l
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
     const int col = (q >> 1) * 16 + (within % CPR) * CH;
     s_r[i] = within / CPR;
     y_off[i] = n0 + col < P.N ? n0 + col : -1;
-    x_off[i] = c0 + col < P.Cin ? c0 + col : -1;
+    x_off[i] = c0 + col < Cin ? c0 + col : -1;
   }
 
   // Row blocks are consumed strictly in order; (group, first row of the block) advance incrementally and the
@@ -249,10 +254,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: acc[mi][ni][r] -> n = n0 + wr*MI*16 + mi*16 + (l>>4)*4 + r ; c = c0 + wc*NI*16 + ni*16 + (l&15)
-  const int KW = P.taps * P.Cin;
+  const int KW = P.taps * Cin;
   const bool rowmajor = !direct || (P.w_layout == 0 && !P.accumulate);   // destination rows contiguous along c
   float* obase = direct ? out_ptr : out_ptr + (long)split * P.N * KW;
-  if (rowmajor && (KW % 4 == 0) && (P.Cin % 4 == 0) && (((uintptr_t)obase & 15) == 0)) {
+  if (rowmajor && (KW % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)obase & 15) == 0)) {
     // coalesced: each wave transposes its 64-column slab through a private LDS patch (32 rows at a time) and writes
     // 16-byte row segments instead of 64 scattered 4-byte stores per lane
     constexpr int WCOLS = NI * 16;            // columns owned by one wave
@@ -275,9 +280,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
       for (int it = 0; it < 32 / RPI; ++it) {   // LPR lanes per row, RPI rows per instruction
         const int rl = it * RPI + l / LPR, cv = l % LPR;
         const int n = nrow0 + rl, c = c0 + wc * (NI * 16) + cv * 4;
-        if (n < P.N && c < P.Cin) {             // Cin % 4 == 0: a quad never crosses the row end
+        if (n < P.N && c < Cin) {             // Cin % 4 == 0: a quad never crosses the row end
           const f32x4 v = *(const f32x4*)(wbuf + rl * PITCH + cv * 16);
-          *(f32x4*)(obase + ((long)n * KW + tap * P.Cin + c)) = v;
+          *(f32x4*)(obase + ((long)n * KW + tap * Cin + c)) = v;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // per-wave patch: in-order LDS, no workgroup barrier needed
@@ -293,15 +298,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int c = c0 + wc * (NI * 16) + ni * 16 + (l & 15);
-        if (c >= P.Cin) continue;
+        if (c >= Cin) continue;
         float v = acc[mi][ni][r];
         if (direct) {
-          float* dst = P.w_layout == 0 ? out_ptr + ((long)n * KW + tap * P.Cin + c)
+          float* dst = P.w_layout == 0 ? out_ptr + ((long)n * KW + tap * Cin + c)
                                        : out_ptr + ((long)n * KW + (long)c * P.taps + tap);
           if (P.accumulate) v += *dst;
           *dst = v;
         } else {
-          out_ptr[((long)split * P.N + n) * KW + tap * P.Cin + c] = v;
+          out_ptr[((long)split * P.N + n) * KW + tap * Cin + c] = v;
         }
       }
     }
@@ -636,9 +641,11 @@ struct WgradReduceMulti {
   const float* ws[DRN_MAX_GROUPS];
   float* out[DRN_MAX_GROUPS];
   int nsplit[DRN_MAX_GROUPS];
+  int cin[DRN_MAX_GROUPS];
 };
 // out[n][...] = (accumulate ? out : 0) + sum_z ws[z][n][tap*Cin+c], in the requested parameter layout; blockIdx.y = problem
-__global__ void wgrad_reduce_multi_kernel(const WgradReduceMulti R, int N, int Cin, int taps, int w_layout, int accumulate) {
+__global__ void wgrad_reduce_multi_kernel(const WgradReduceMulti R, int N, int taps, int w_layout, int accumulate) {
+  const int Cin = R.cin[blockIdx.y];
   const long KW = (long)taps * Cin;
   const long total = (long)N * KW;
   const float* __restrict__ ws = R.ws[blockIdx.y];
@@ -921,8 +928,8 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
 
 // n INDEPENDENT weight gradients of equal N / Cin / taps / stride (the three FPN level convs: different weights, different
 // row counts) in ONE launch + one reduce launch; problem i: dWs[i] = dY_i^T x im2col(X_i).  ws >= n * drn_wgrad_ws_elems(max M).
-extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* dWs, int N, int Cin, int taps, int stride, int pad,
-                                    int w_layout, int accumulate, float* ws, int dtype, void* stream_) {
+extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* dWs, int N, int Cin, const int32_t* Cins, int taps,
+                                    int stride, int pad, int w_layout, int accumulate, float* ws, int dtype, void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(d && dWs && n >= 1 && n <= DRN_MAX_GROUPS, "drn_gemm_wgrad_multi: n=%d out of range", n);
@@ -937,12 +944,18 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
   memset(&RM, 0, sizeof(RM));
   P.ngroups = n;
   P.multi = 1;
-  const long per = (long)N * taps * Cin;
+  // Cins (host, or NULL = every problem has Cin input channels): the problems' own channel counts -- the FPN laterals share N,
+  // taps = 1 and differ in Cin; Cin is then the LARGEST of them (workspace slices, grid)
+  bool varied = false;
+  for (int g = 0; g < n && Cins; ++g) {
+    DRN_CHECK_ARG(Cins[g] > 0 && Cins[g] <= Cin && Cins[g] % ch == 0, "drn_gemm_wgrad_multi: bad Cins[%d]", g);
+    varied |= Cins[g] != Cin;
+  }
   int blks = 0, z = 0, mmax = 0;
   bool any_split = false;
   for (int g = 0; g < n; ++g) mmax = d[g].M > mmax ? d[g].M : mmax;
   const long ws_per = drn_wgrad_ws_elems(mmax, N, Cin, taps);
-  bool fused = dtype == DRN_BF16 && taps == 3 && stride == 1 && pad == 1 && wgrad3_enabled() && mmax >= wgrad3_min_rows();
+  bool fused = !varied && dtype == DRN_BF16 && taps == 3 && stride == 1 && pad == 1 && wgrad3_enabled() && mmax >= wgrad3_min_rows();
   for (int g = 0; g < n; ++g) fused = fused && wgrad3_group_ok(d[g]);
   for (int g = 0; g < n; ++g) {
     const DrnWgradDesc& s = d[g];
@@ -954,7 +967,10 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
     P.g[g].ldy = s.ldy; P.g[g].ldx = s.ldx; P.g[g].blk_start = blks;
     const int gb = fused ? cdiv((s.M / s.Lout) * (s.Lout + 1), 64) : cdiv(s.M, R);
     blks += gb;
-    int ns = wgrad_nsplit(total_blocks_upper(s.M, 1), N, Cin, taps);
+    const int cin_g = Cins ? Cins[g] : Cin;
+    const long per = (long)N * taps * cin_g;
+    P.gcin[g] = cin_g; RM.cin[g] = cin_g;
+    int ns = wgrad_nsplit(total_blocks_upper(s.M, 1), N, cin_g, taps);
     if (fused) {
       // the problems share the chip: each gets its share of the one-workgroup-per-CU budget by row count
       long m_all = 0;
@@ -985,20 +1001,20 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
   P.accumulate = accumulate;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<float, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel<bf16_t, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     attr_set = true;
   }
   dim3 grid(cdiv(N, tile), taps * P.ctiles, z);
   if (fused) {
     wgrad3_attr();
     WGRAD3_LAUNCH(dim3(cdiv(N, 128), cdiv(Cin, 128), z), P);
-  } else if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
-  else conv_wgrad_tn_kernel<float, 2, 2, 4, 4><<<grid, 256, 2 * 32768, stream>>>(P);
+  } else if (dtype == DRN_BF16) conv_wgrad_tn_kernel<bf16_t, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);      // 8 waves per 128x128 tile
+  else conv_wgrad_tn_kernel<float, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
   int rc = drn_launch_status("drn_gemm_wgrad_multi");
   if (rc || !any_split) return rc;
-  int nb = (int)((per + 255) / 256);
+  int nb = (int)(((long)N * taps * Cin + 255) / 256);
   if (nb > 1024) nb = 1024;
-  wgrad_reduce_multi_kernel<<<dim3(nb, n), 256, 0, stream>>>(RM, N, Cin, taps, w_layout, accumulate);
+  wgrad_reduce_multi_kernel<<<dim3(nb, n), 256, 0, stream>>>(RM, N, taps, w_layout, accumulate);
   return drn_launch_status("drn_gemm_wgrad_multi(reduce)");
 }

@@ -918,15 +918,17 @@ class _MultiConvFn(torch.autograd.Function):
         dWs = [grad_buffer(weights[l]) for l in range(n)]
         wdescs = [ops.wgrad_desc(draws[l], xs[l], geo[l][3], Lout=geo[l][2], Lsrc=geo[l][1], ldy=geo[l][5], ldx=geo[l][4])
                   for l in range(n)]
-        same = all(geo[l][5:9] == geo[0][5:9] and strides[l] == strides[0] for l in range(n))
+        # same (Cout, k, stride) -- Cin may differ (the 1x1 laterals: 256 / 512 / 1024 input channels)
+        same = all((geo[l][5], geo[l][7], geo[l][8]) == (geo[0][5], geo[0][7], geo[0][8]) and strides[l] == strides[0] for l in range(n))
         keep = (draws, xs)
         dWj = [_alias(w) for w in dWs]
 
         def wgrads():
             if same and n > 1 and n * max(g[3] for g in geo) <= 4 * sum(g[3] for g in geo):
-                # same (Cout, Cin, k): one launch (+ one reduce) for all levels' weight gradients instead of one pair per level
-                ops.gemm_wgrad_multi(wdescs, dWj, geo[0][5], geo[0][6], taps=geo[0][7], stride=strides[0], pad=geo[0][8],
-                                     w_layout=1, dtype=code)
+                # one launch (+ one reduce) for all levels' weight gradients instead of one pair per level
+                cins = [g[6] for g in geo]
+                ops.gemm_wgrad_multi(wdescs, dWj, geo[0][5], cins[0] if len(set(cins)) == 1 else cins, taps=geo[0][7],
+                                     stride=strides[0], pad=geo[0][8], w_layout=1, dtype=code)
             else:
                 for l in range(n):
                     B, L, Lo, M, ld, Cout, Cin, k, pad = geo[l]

@@ -120,18 +120,24 @@ def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulat
 
 
 def gemm_wgrad_multi(descs, dWs, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulate=False, dtype=F32):
-    """len(descs) independent weight gradients of equal shape (different weights / row counts) in one launch."""
+    """len(descs) independent weight gradients of equal N / taps (different weights / row counts) in one launch.  Cin: one int, or
+    one per problem (the FPN laterals)."""
     for dW in dWs:
         _need_gpu(dW)
         assert dW.dtype == torch.float32 and dW.is_contiguous()
+    cins = None
+    if not isinstance(Cin, int):
+        cins = (ctypes.c_int32 * len(descs))(*[int(c) for c in Cin])
+        Cin = max(int(c) for c in Cin)
     n_ws = len(descs) * int(lib().drn_wgrad_ws_elems(max(d.M for d in descs), N, Cin, taps))
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dWs[0].device)
     arr = (WgradDesc * len(descs))(*descs)
     ptrs = (ctypes.c_void_p * len(dWs))(*[dW.data_ptr() for dW in dWs])
     m_total = sum(d.M for d in descs)
     tag = "gemm_wgrad_multi[%s] n=%d M=%d N=%d K=%d" % ("bf16" if dtype == BF16 else "f32", len(descs), m_total, N, taps * Cin)
-    _timed(tag, 2.0 * m_total * N * taps * Cin,
-           lambda: check(lib().drn_gemm_wgrad_multi(arr, len(descs), ptrs, N, Cin, taps, stride, pad, w_layout, int(accumulate),
+    flops = sum(2.0 * d.M * N * taps * (cins[i] if cins is not None else Cin) for i, d in enumerate(descs))
+    _timed(tag, flops,
+           lambda: check(lib().drn_gemm_wgrad_multi(arr, len(descs), ptrs, N, Cin, cins, taps, stride, pad, w_layout, int(accumulate),
                                                     _p(ws), dtype, _stream()), "drn_gemm_wgrad_multi"))
 
 

@@ -90,10 +90,13 @@ int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps);
 int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, int N, int Cin, int taps, int stride,
                    int pad, int w_layout, int accumulate, float* ws, int dtype, void* stream);
 
-/* n independent weight gradients of equal N / Cin / taps / stride / pad (different weights, different row counts: the FPN
- * level convs) in one launch; dWs is a HOST array of n device pointers; ws >= n * drn_wgrad_ws_elems(max M, N, Cin, taps). */
-int drn_gemm_wgrad_multi(const DrnWgradDesc* problems /*host*/, int n, float* const* dWs /*host*/, int N, int Cin, int taps,
-                         int stride, int pad, int w_layout, int accumulate, float* ws, int dtype, void* stream);
+/* n independent weight gradients of equal N / taps / stride / pad (different weights, different row counts: the FPN level
+ * convs) in one launch; dWs is a HOST array of n device pointers; ws >= n * drn_wgrad_ws_elems(max M, N, Cin, taps).
+ * Cins (host, or NULL): the problems' own input-channel counts when they differ (the FPN 1x1 laterals: 256 / 512 / 1024 -> 512);
+ * Cin is then the largest of them. */
+int drn_gemm_wgrad_multi(const DrnWgradDesc* problems /*host*/, int n, float* const* dWs /*host*/, int N, int Cin,
+                         const int32_t* Cins /*host*/, int taps, int stride, int pad, int w_layout, int accumulate, float* ws,
+                         int dtype, void* stream);
 
 /* ---- HBM-bound helpers (drn_amd/csrc/elementwise.hip) -------------------------------------------------- */
 /* fp32 -> dtype cast of n contiguous elements (feature tensor / weights; the reference is fp32-only). */

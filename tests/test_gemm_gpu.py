@@ -360,6 +360,32 @@ def test_wgrad_multi_equals_separate_launches(dt):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-4 * float(b.abs().max()))
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_wgrad_multi_with_different_input_channels(dt):
+    """The FPN 1x1 laterals (model/FPN.py:36: 256 / 512 / 1024 -> 512 channels on levels of L, L/2, L/4 positions): one launch
+    for problems that share N and taps but not Cin, against one launch per problem."""
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(22)
+    B, Cout = 4, 136
+    code = ops.dtype_code(torch.empty(1, dtype=dt))
+    descs, keep, want, outs, cins = [], [], [], [], []
+    for L, Cin in ((256, 72), (128, 136), (64, 264)):
+        dY = torch.randn(B * L, Cout, generator=g).to(dev()).to(dt)
+        X = torch.randn(B * L, Cin, generator=g).to(dev()).to(dt)
+        keep.append((dY, X))
+        d = ops.wgrad_desc(dY, X, B * L, Lout=L, Lsrc=L)
+        descs.append(d)
+        ref = torch.empty(Cout, Cin, 1, device=dev())
+        ops.gemm_wgrad([d], ref, Cout, Cin, taps=1, w_layout=1, dtype=code)
+        want.append(ref)
+        outs.append(torch.full((Cout, Cin, 1), float("nan"), device=dev()))
+        cins.append(Cin)
+    ops.gemm_wgrad_multi(descs, outs, Cout, cins, taps=1, w_layout=1, dtype=code)
+    for a, b in zip(outs, want):
+        assert torch.isfinite(a).all()
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-4 * float(b.abs().max()))
+
+
 # ---- fused 3-tap weight gradient (conv_wgrad3_tn_kernel): k = 3, stride 1, pad 1, bf16 ------------------------------------
 @pytest.mark.parametrize("B,L,Cin,Cout,layout", [(3, 50, 72, 136, 1), (2, 64, 64, 128, 0), (5, 20, 40, 24, 1), (8, 256, 320, 256, 1),
                                                  (1, 63, 128, 128, 0), (4, 65, 136, 200, 1), (7, 3, 64, 64, 1), (2, 1000, 64, 96, 0)])
