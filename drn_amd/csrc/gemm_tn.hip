@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_tn_kernel(const Wg
   int blk_hi = min(blk_lo + P.blks_per_split, P.total_blks);
   float* out_ptr = P.out;
   int direct = P.direct;
-  int Cin = Cin, ctiles = P.ctiles;
+  int Cin = P.Cin, ctiles = P.ctiles;
   if (P.multi) {
     int pg = 0;
 #pragma unroll
