@@ -200,6 +200,16 @@ extern "C" int drn_adam_bucket(const float* g, float* m, float* v, int64_t n, co
 // Adam over tensors with re-laid GEMM copies: 64-row x 64-channel tiles (see include/drn_hip.h, drn_adam_tiled).
 // ---------------------------------------------------------------------------------------------------------------------
 #define TILED_MAXK 3
+// Division by a small run-time divisor d as one multiply-high: magic = floor(2^32 / d) + 1 is exact for q * d < 2^32 (d >= 2;
+// every quotient here is below 2^16).  The tile index arithmetic below divides by the tile's row length in pieces, by the piece
+// count and by the tap count -- ~150 integer divisions per thread and tile as ~40-instruction sequences made this kernel
+// VALU-bound (3.8 TB/s where the linear kernel streams 5.4): one real division per divisor and thread instead.
+struct FastDiv {
+  unsigned magic;
+  int d;
+  __device__ __forceinline__ explicit FastDiv(int dd) : magic(dd > 1 ? 0xFFFFFFFFu / (unsigned)dd + 1u : 0u), d(dd) {}
+  __device__ __forceinline__ int div(int q) const { return d > 1 ? (int)__umulhi((unsigned)q, magic) : q; }
+};
 template <typename T>
 __device__ __forceinline__ void tiled_store_piece(T* dst, const float* v);
 template <>
@@ -224,8 +234,9 @@ __device__ __forceinline__ void tiled_flush(const float (*tile)[64 * TILED_MAXK 
     T* out = (T*)it.m1;
     const bool vec = (nc % VEC == 0) && (it.ld1 % VEC == 0) && ((((uintptr_t)out) & 15) == 0);
     const int pcs = (nc + VEC - 1) / VEC;
+    const FastDiv dp(pcs), dk(k);
     for (int q = threadIdx.x; q < nr * k * pcs; q += OPT_THREADS) {
-      const int cv = q % pcs, rt = q / pcs, tap = rt % k, r = rt / k;
+      const int rt = dp.div(q), cv = q - rt * pcs, r = dk.div(rt), tap = rt - r * k;
       float vals[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) vals[e] = cv * VEC + e < nc ? tile[r][(cv * VEC + e) * k + tap] : 0.f;
@@ -238,8 +249,9 @@ __device__ __forceinline__ void tiled_flush(const float (*tile)[64 * TILED_MAXK 
     T* out = (T*)it.m2;
     const bool vec = (nr % VEC == 0) && (it.ld2 % VEC == 0) && ((((uintptr_t)out) & 15) == 0);
     const int pcs = (nr + VEC - 1) / VEC;
+    const FastDiv dp(pcs), dk(k);
     for (int q = threadIdx.x; q < nc * k * pcs; q += OPT_THREADS) {
-      const int rv = q % pcs, ct = q / pcs, tap = ct % k, c = ct / k;
+      const int ct = dp.div(q), rv = q - ct * pcs, c = dk.div(ct), tap = ct - c * k;
       float vals[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) vals[e] = rv * VEC + e < nr ? tile[rv * VEC + e][c * k + tap] : 0.f;
@@ -273,13 +285,14 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
   const bool vec4 = (ts % 4 == 0) && (S % 4 == 0) && ((((uintptr_t)it.p) & 15) == 0) && (it.off % 4 == 0);
   if (vec4) {
     const int qpr = ts / 4, nq = nr * qpr;                    // float4 pieces per tile row, in the tile
+    const FastDiv dq(qpr);
     for (int q0 = threadIdx.x; q0 < nq; q0 += 4 * OPT_THREADS) {
       f32x4 g4[4], m4[4], v4[4], p4[4];
       long e0[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {                           // 16 loads in flight per trip
         const int q = q0 + u * OPT_THREADS;
-        const int r = q / qpr, c4 = (q - r * qpr) * 4;
+        const int r = dq.div(q), c4 = (q - r * qpr) * 4;
         e0[u] = q < nq ? tbase + (long)r * S + c4 : -1;
         if (e0[u] >= 0) {
           g4[u] = *(const f32x4*)(G + it.off + e0[u]);
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
       for (int u = 0; u < 4; ++u) {
         if (e0[u] < 0) continue;
         const int q = q0 + u * OPT_THREADS;
-        const int r = q / qpr, c4 = (q - r * qpr) * 4;
+        const int r = dq.div(q), c4 = (q - r * qpr) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float g = g4[u][e] * grad_scale * clip;
@@ -307,8 +320,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
       }
     }
   } else {
+    const FastDiv dt(ts);
     for (int q = threadIdx.x; q < nr * ts; q += OPT_THREADS) {
-      const int r = q / ts, c = q - r * ts;
+      const int r = dt.div(q), c = q - r * ts;
       const long e0 = tbase + (long)r * S + c;
       const float g = G[it.off + e0] * grad_scale * clip;
       const float mm = beta1 * Mo[it.off + e0] + (1.f - beta1) * g;
