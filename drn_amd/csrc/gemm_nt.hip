@@ -710,6 +710,21 @@ extern "C" int64_t drn_gemm_nt_splitk_ws_elems(int M, int N, int ksplit) {
   return (int64_t)ksplit * cdiv(M, 128) * cdiv(N, 128) * 128 * 128;
 }
 
+// The same for a GROUPED launch (pyramid levels / independent problems of one launch): workspace and counters are indexed by the
+// launch-wide tile number, every problem splits its own K range `ksplit` ways.  Short sequences (Charades-STA's 32 proposals:
+// 14-56 tiles per grouped launch on 256 CUs) are where this pays.  ws >= ksplit * (sum of 128x128 tiles) * 16384 floats.
+extern "C" int drn_gemm_nt_splitk_grouped(const DrnGemmDesc* descs, int ngroups, int ksplit, float* ws, int32_t* counters, int dtype,
+                                          void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(descs && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS && ksplit >= 1 && ksplit <= 64 && (ksplit == 1 || (ws && counters)),
+                "drn_gemm_nt_splitk_grouped: bad groups/ksplit/workspace/counters");
+  long tiles = 0;
+  for (int g = 0; g < ngroups; ++g) tiles += (long)cdiv(descs[g].M, 128) * cdiv(descs[g].N, 128);
+  DRN_CHECK_ARG(ksplit == 1 || (tiles <= DRN_QD_COUNTERS && (((uintptr_t)ws) & 15) == 0),
+                "drn_gemm_nt_splitk_grouped: more than %d output tiles or unaligned workspace", DRN_QD_COUNTERS);
+  return launch_nt(descs, ngroups, dtype, (hipStream_t)stream, ksplit, ws, (int*)counters);
+}
+
 extern "C" int drn_gemm_nt_splitk(const DrnGemmDesc* desc, int ksplit, float* ws, int32_t* counters, int dtype, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(desc && ksplit >= 1 && ksplit <= 64 && (ksplit == 1 || (ws && counters)), "drn_gemm_nt_splitk: bad ksplit/workspace/counters");

@@ -68,12 +68,14 @@ def _timed(tag, flops, launch):
     kernel_timer.append((tag, flops, e0, e1))
 
 
-def _ksplit(d, dtype):
-    """Split-K factor for a single problem that cannot fill 256 CUs with 128x128 tiles."""
-    tiles = ((d.M + 127) // 128) * ((d.N + 127) // 128)
-    nkt = (d.taps * d.Cin) // (64 if dtype == BF16 else 32)
-    # exact-f32 (parity) mode keeps round 1's rule -- split only the long-K problems -- so its summation orders, and with
-    # them the ReLU decisions the tolerance tests were calibrated on, stay what they were
+def _ksplit(descs, dtype):
+    """Split-K factor for a launch (one problem, or -- bf16 -- a group of them) that cannot fill 256 CUs with 128x128 tiles."""
+    tiles = sum(((d.M + 127) // 128) * ((d.N + 127) // 128) for d in descs)
+    nkt = min((d.taps * d.Cin) // (64 if dtype == BF16 else 32) for d in descs)
+    # exact-f32 (parity) mode keeps round 1's rule -- split only the long-K single problems -- so its summation orders, and
+    # with them the ReLU decisions the tolerance tests were calibrated on, stay what they were
+    if dtype != BF16 and len(descs) > 1:
+        return 1
     if tiles > 160 or nkt < (SPLITK_MIN_KSTEPS if dtype == BF16 else 96):
         return 1
     return max(1, min(8, 512 // tiles, nkt // (12 if dtype == BF16 else 6)))
@@ -82,16 +84,16 @@ def _ksplit(d, dtype):
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
-    if len(descs) == 1:
-        ks = _ksplit(descs[0], dtype)
-        if ks > 1:
-            d0 = descs[0]
-            dev = torch.device("cuda", torch.cuda.current_device())
-            ws = torch.empty(ks * ((d0.M + 127) // 128) * ((d0.N + 127) // 128) * 128 * 128, dtype=torch.float32, device=dev)
-            tag = "gemm_nt[%s] g=1 M=%d N=%d K=%d mode=%d splitK=%d" % ("bf16" if dtype == BF16 else "f32", d0.M, d0.N,
-                                                                        d0.taps * d0.Cin, d0.mode, ks)
-            return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk(arr, ks, _p(ws), _p(_counters(dev)), dtype, _stream()),
-                                                    "drn_gemm_nt_splitk"))
+    ks = _ksplit(descs, dtype)
+    if ks > 1:
+        d0 = descs[0]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        tiles = sum(((d.M + 127) // 128) * ((d.N + 127) // 128) for d in descs)
+        ws = torch.empty(ks * tiles * 128 * 128, dtype=torch.float32, device=dev)
+        tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=%d splitK=%d" % ("bf16" if dtype == BF16 else "f32", len(descs),
+                                                                     sum(d.M for d in descs), d0.N, d0.taps * d0.Cin, d0.mode, ks)
+        return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk_grouped(arr, len(descs), ks, _p(ws), _p(_counters(dev)),
+                                                                                 dtype, _stream()), "drn_gemm_nt_splitk_grouped"))
     d0 = descs[0]
     tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=%d" % ("bf16" if dtype == BF16 else "f32", len(descs),
                                                       sum(d.M for d in descs), d0.N, d0.taps * d0.Cin, d0.mode)

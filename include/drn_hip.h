@@ -72,6 +72,10 @@ int drn_gemm_nt(const DrnGemmDesc* descs /*host*/, int ngroups, int dtype, void*
  * per 128x128 output tile (<= DRN_QD_COUNTERS), zero on entry, left zero (the buffer drn_skinny_group uses will do). */
 int64_t drn_gemm_nt_splitk_ws_elems(int M, int N, int ksplit);
 int drn_gemm_nt_splitk(const DrnGemmDesc* desc /*host*/, int ksplit, float* ws, int32_t* counters, int dtype, void* stream);
+/* ... and for a grouped launch: every problem's K loop is split ksplit ways; ws >= ksplit * (sum over the problems of their
+ * 128x128 output tiles) * 16384 floats, one counter per tile of the launch. */
+int drn_gemm_nt_splitk_grouped(const DrnGemmDesc* descs /*host*/, int ngroups, int ksplit, float* ws, int32_t* counters, int dtype,
+                               void* stream);
 
 /* Weight gradient:  dW[n][tap][c] (fp32) = sum_m dY[m][n] * X[src(m,tap)][c]   (mode-0 addressing of X).
  * dW is written as [N][taps][Cin] when w_layout==0 or [N][Cin][taps] (the nn.Conv1d parameter layout) when 1.

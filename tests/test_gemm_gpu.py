@@ -269,6 +269,44 @@ def test_conv_fwd_splitk_with_stats_bias_gate(dt, ksplit):
     close(m2, ((ref - ref.mean(0)) ** 2).sum(0), TOL[dt] * 4, "col M2")
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("ksplit", [2, 4])
+def test_grouped_splitk_equals_plain_grouped_launch(dt, ksplit):
+    """drn_gemm_nt_splitk_grouped: three problems of one launch (shared-weight conv on three pyramid levels, BN statistics in the
+    epilogue), each K loop split: same outputs and statistics as the unsplit grouped launch up to fp32 summation order."""
+    import ctypes
+    from drn_amd import ops, _lib
+    B, Cin, Cout, k = 3, 192, 136, 3
+    code = ops.BF16 if dt == "bf16" else ops.F32
+    x0, w = conv_case(dt, B, 40, Cin, Cout, k, 1)
+    wp = w.permute(0, 2, 1).contiguous().to(dev())
+    keep, plain, split = [], [], []
+    for li, L in enumerate((40, 24, 9)):
+        x = rnd((B, Cin, L), 30 + li, DT[dt])
+        xd = nlc(x).to(dev())
+        keep.append(xd)
+        M = B * L
+        for lst in (plain, split):
+            C = torch.full((M, Cout), float("nan"), dtype=DT[dt], device=dev())
+            st = torch.full(((M + 127) // 128, 2, Cout), float("nan"), dtype=torch.float32, device=dev())
+            lst.append((C, st, ops.gemm_desc(xd, wp, C, M, Cout, Cin, taps=k, pad=1, Lout=L, Lsrc=L, stats=st)))
+    L_ = _lib.lib()
+    _lib.check(L_.drn_gemm_nt((_lib.GemmDesc * 3)(*[t[2] for t in plain]), 3, code,
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "grouped")
+    tiles = sum(((t[0].shape[0] + 127) // 128) * ((Cout + 127) // 128) for t in split)
+    ws = torch.full((ksplit * tiles * 128 * 128,), float("nan"), dtype=torch.float32, device=dev())
+    counters = torch.zeros(2048, dtype=torch.int32, device=dev())
+    for _ in range(2):
+        _lib.check(L_.drn_gemm_nt_splitk_grouped((_lib.GemmDesc * 3)(*[t[2] for t in split]), 3, ksplit, ctypes.c_void_p(ws.data_ptr()),
+                                                 ctypes.c_void_p(counters.data_ptr()), code,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "grouped split-K")
+    torch.cuda.synchronize()
+    assert int(counters.abs().sum()) == 0
+    for (Cp, sp, _), (Cs, ss, _) in zip(plain, split):
+        close(Cs, Cp.double(), TOL[dt] * 2, "grouped split-K output")
+        close(ss, sp.double(), TOL[dt] * 4, "grouped split-K statistics")
+
+
 @pytest.mark.parametrize("M,N,K,ksplit", [(8192, 256, 6528, 4), (8192, 256, 13056, 3), (64, 512, 3072, 8)])
 def test_splitk_exchange_under_load(M, N, K, ksplit):
     """The one-launch split-K exchange with every CU holding two workgroups (512 of them), workspace poisoned before each of
