@@ -303,8 +303,8 @@ def test_grouped_splitk_equals_plain_grouped_launch(dt, ksplit):
     torch.cuda.synchronize()
     assert int(counters.abs().sum()) == 0
     for (Cp, sp, _), (Cs, ss, _) in zip(plain, split):
-        close(Cs, Cp.double(), TOL[dt] * 2, "grouped split-K output")
-        close(ss, sp.double(), TOL[dt] * 4, "grouped split-K statistics")
+        close(Cs, Cp.double().cpu(), TOL[dt] * 2, "grouped split-K output")
+        close(ss, sp.double().cpu(), TOL[dt] * 4, "grouped split-K statistics")
 
 
 @pytest.mark.parametrize("M,N,K,ksplit", [(8192, 256, 6528, 4), (8192, 256, 13056, 3), (64, 512, 3072, 8)])
