@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--dump-gemms", default=None, metavar="PATH",
                     help="write the MFMA launches of one step in launch order [(tag, flops)] as JSON (scripts/gemm_table.py joins them "
                          "with a rocprofv3 kernel trace of the replayed graph)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="drn_tune(KEY, VALUE) before anything runs (experiments)")
     ap.add_argument("--no-trainer", dest="trainer_line", action="store_false",
                     help="skip the `trainer` object (clips/s through drn_amd.trainer.Trainer.train_epoch at T=256 and T=32, graph and eager)")
     args = ap.parse_args()
@@ -178,6 +179,10 @@ def main():
     from drn_amd.model import mainModel
     # DRN_DIST_BACKEND=gloo + DRN_FORCE_DEVICE=0 lets several ranks share one GPU to exercise the N>1 code path on a
     # single-GPU box (test only; the real runs use RCCL, one GPU per rank)
+    for kv in args.tune:
+        from drn_amd._lib import check, lib
+        k, v = kv.split("=")
+        check(lib().drn_tune(k.encode(), int(v)), "drn_tune")
     rank, local, world = ddist.init_from_env(backend=os.environ.get("DRN_DIST_BACKEND"))
     if os.environ.get("DRN_FORCE_DEVICE") is not None:
         local = int(os.environ["DRN_FORCE_DEVICE"])

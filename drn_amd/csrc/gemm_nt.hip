@@ -665,6 +665,10 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   if (const char* e = drn_exp_env("DRN_NT_WAVES")) waves8 = tile == 128 && atoi(e) == 8;
   if (ksplit > 1) waves8 = true;       // the in-launch split-K exchange exists for the 8-wave 128x128 tile only
   if (waves8 && !drn_exp_env("DRN_NT_STAGES")) stages = 2;
+  // launches that leave CUs idle anyway (<= 256 workgroups: most of the pyramid GEMMs at T = 256, everything at Charades-STA's
+  // T = 32) run one workgroup per CU with a 4-slot ring -- three K-tiles of loads in flight against the cold operands instead of
+  // one: step 1.51 -> 1.435 ms at T = 32, 2.448 -> 2.434 at T = 256 (512 as the bound: 2.465)
+  const bool deep8 = waves8 && stages == 2 && drn_tuning(DRN_TUNE_NT_DEEP) > 0 && (long)total * ksplit <= drn_tuning(DRN_TUNE_NT_DEEP);
   static bool attr_set = false;
   if (!attr_set) {
 #define NT_ATTR(TT, SS, ...) \
@@ -672,9 +676,9 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)
     NT_ATTR(float, 2, 2, 4, 8, 4); NT_ATTR(bf16_t, 2, 2, 4, 8, 4);
     NT_ATTR(float, 2, 2, 4, 4, 2); NT_ATTR(bf16_t, 2, 2, 4, 4, 2);
+    NT_ATTR(float, 4, 2, 4, 4, 2); NT_ATTR(bf16_t, 4, 2, 4, 4, 2);
 #ifdef DRN_EXPERIMENTS
     NT_ATTR(float, 2, 2, 2, 4, 4); NT_ATTR(bf16_t, 2, 2, 2, 4, 4); NT_ATTR(float, 4, 2, 2, 4, 4); NT_ATTR(bf16_t, 4, 2, 2, 4, 4);
-    NT_ATTR(float, 4, 2, 4, 4, 2); NT_ATTR(bf16_t, 4, 2, 4, 4, 2);
 #endif
 #undef NT_ATTR
     attr_set = true;
@@ -684,6 +688,8 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
   if (tile == 256) {
     if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 65536, 2, 4, 8, 4); else NT_LAUNCH(float, 2, 512, 2 * 65536, 2, 4, 8, 4);
+  } else if (deep8) {     // few workgroups, cold operands: three tiles of loads in flight instead of one
+    if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 4, 512, 4 * 32768, 2, 4, 4, 2); else NT_LAUNCH(float, 4, 512, 4 * 32768, 2, 4, 4, 2);
   }
 #ifdef DRN_EXPERIMENTS
   else if (waves8 && stages == 4) {
