@@ -85,26 +85,27 @@ extern "C" int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out,
 // ---------------------------------------------------------------- cast + transpose in one pass over the fp32 input
 // out[m][k] = (T) in[m][k]  and  outT[k][m] = (T) in[m][k]: the proposal features are cast once per step anyway; writing
 // the K-major copy from the same tile saves re-reading them for the prop_fc weight gradient (NT product of transposes).
-// Tile: 128 rows (m) x 64 columns (k) per 256-thread workgroup.  A thread owns 8 consecutive source floats at a time (four
-// such units, all eight 16-byte loads requested before the first use): they become one 16-byte store of `out` (bf16) or two
+// Tile: TM rows (m) x TK columns (k) per NT-thread workgroup.  A thread owns 8 consecutive source floats at a time (TM*TK/8/NT
+// such units, all their 16-byte loads requested before the first use): they become one 16-byte store of `out` (bf16) or two
 // (f32) and eight 2-byte column writes of the LDS tile [k][m]; the tile is then flushed as 16-byte pieces of outT rows
-// (256-byte segments).  134 MB in, 2 x 67 MB out at B*T = 8192, D = 4096.
-template <typename T>
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ outT,
-                                                             int M, int K) {
+// (TM x 2-byte segments).  134 MB in, 2 x 67 MB out at B*T = 8192, D = 4096.
+template <typename T, int TM, int TK, int NT>
+__global__ __launch_bounds__(NT) void cast_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ outT,
+                                                            int M, int K) {
   constexpr int VN = V16<T>::N;              // elements per 16-byte piece of the outputs
-  constexpr int TM = 128, TK = 64;
   constexpr int PITCH = TM + 16 / (int)sizeof(T);          // [k][m] tile, rows stay 16-byte aligned
   constexpr int CPR = TM / VN;                               // 16-byte pieces per tile row (a power of two)
+  constexpr int UPR = TK / 8;                                // 8-float units per source row of the tile
+  constexpr int NU = TM * UPR / NT;                          // units per thread
   __shared__ __attribute__((aligned(16))) T tile[TK][PITCH];
   const int m0 = blockIdx.y * TM, k0 = blockIdx.x * TK;
-  f32x4 v[4][2];
-  int mm[4], kk[4];
+  f32x4 v[NU][2];
+  int mm[NU], kk[NU];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {                             // unit = 8 floats: 128 rows x 8 units per row
-    const int q = threadIdx.x + 256 * u;
-    mm[u] = q >> 3;
-    kk[u] = (q & 7) * 8;
+  for (int u = 0; u < NU; ++u) {                            // unit = 8 floats; all 2*NU 16-byte loads requested before the first use
+    const int q = threadIdx.x + NT * u;
+    mm[u] = q / UPR;
+    kk[u] = (q % UPR) * 8;
     const int m = m0 + mm[u], k = k0 + kk[u];
     const bool ok = m < M && k < K;                         // K % 8 == 0 (checked by the host)
     const float* src = in + (long)m * K + k;
@@ -112,13 +113,13 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     v[u][1] = ok ? *(const f32x4*)(src + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int m = m0 + mm[u], k = k0 + kk[u];
     T t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       DT<T>::st(&t[e], v[u][e >> 2][e & 3]);
-      // (16-byte piece index XOR row group: the 8 lanes of a source row write tile rows a multiple of 128 bytes apart)
+      // (16-byte piece index XOR row group: the lanes of a source row write tile rows a multiple of 128 bytes apart)
       tile[kk[u] + e][((((mm[u] / VN) ^ (kk[u] >> 3)) & (CPR - 1)) * VN) + (mm[u] % VN)] = t[e];
     }
     if (m < M && k < K) {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < TK * CPR; q += 256) {
+  for (int q = threadIdx.x; q < TK * CPR; q += NT) {
     const int r = q / CPR, cv = q % CPR;
     const int k = k0 + r, m = m0 + cv * VN;
     if (k < K && m < M) *(uint4*)(outT + (long)k * M + m) = *(const uint4*)&tile[r][((cv ^ (r >> 3)) & (CPR - 1)) * VN];
@@ -141,8 +142,9 @@ extern "C" int drn_cast_transpose(const float* in, void* out, void* outT, int M,
     constexpr int VN = V16<T>::N;
     DRN_CHECK_ARG(M % VN == 0 && K % 8 == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)outT) & 15) == 0,
                   "drn_cast_transpose: M must be a 16-byte multiple in the output type, K a multiple of 8");
-    dim3 grid(cdiv(K, 64), cdiv(M, 128));
-    cast_transpose_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(in, (T*)out, (T*)outT, M, K);
+    // 64 x 128 tiles: 512-byte source row segments.  Measured at B*T = 8192, D = 4096 with cold caches (scripts/bench_ew.py):
+    // 128 x 64 tiles (256-byte segments) 60 us, 64 x 128 53.5, 128 x 128 54, 64 x 256 56.5, 32 x 128 (64-byte outT pieces) 84
+    cast_transpose_kernel<T, 64, 128, 256><<<dim3(cdiv(K, 128), cdiv(M, 64)), 256, 0, (hipStream_t)stream>>>(in, (T*)out, (T*)outT, M, K);
   });
   return drn_launch_status("drn_cast_transpose");
 }

@@ -4,9 +4,9 @@
 //
 // The input projection x_t W_ih^T + b_ih + b_hh for all t is a plain GEMM done by the caller; these kernels do the
 // recurrent part, which is latency-bound: per step and direction a (B=32..64) x 2048 x 512 product plus the cell
-// update.  It runs on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) straight from L2-resident operands: a workgroup
-// owns 16 hidden units (all four gates), its 4 waves split K, partial tiles meet in LDS and the cell update is fused
-// into the epilogue.  Padded positions (t >= len[b]) keep the state and emit zeros, which reproduces
+// update.  It runs on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) -- or, with the optimizer-maintained bf16 copies of
+// W_hh / W_hh^T (the bf16 model), on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- straight from L2-resident operands:
+// the waves of a workgroup split K, partial tiles meet in LDS and the cell update is fused into the epilogue.  Padded positions (t >= len[b]) keep the state and emit zeros, which reproduces
 // pack_padded_sequence / pad_packed_sequence semantics for both directions.
 //
 // Layouts (fp32): xproj / gates / dgates [L][B][2][4H] indexed by TIME t and direction (gate order i,f,g,o as in
@@ -15,6 +15,7 @@
 // is never read, the initial state is zero); hprev_t [L][B][2][H] = hidden state that entered time t (operand of the
 // W_hh gradient); out [B][L][2H].  Step s handles t = s for the forward direction and t = L-1-s for the reverse one.
 // xproj holds x_t W_ih^T only: both bias vectors are added here.
+#include <type_traits>
 #include "common.h"
 #include "../../include/drn_hip.h"
 
@@ -25,38 +26,42 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 struct LstmFwdArgs {
   const float* xproj;
-  const float* Whh[2];
+  const void* Whh[2];         // [4H][H], fp32 or (w_bf16) the optimizer-maintained bf16 copy in the same element order
   float* hseq;
   float* cseq;
   float* gates;
   float* out;
   float* hprev_t;
+  float* qvec;                // optional [B][4H]: [out[b][0][:], out[b][len_b-1][:]] (language_module.py:48-54), written by the steps that produce those rows
   const float* b_ih[2];
   const float* b_hh[2];
   const long long* lengths;   // [B] int64 (the dtype the data layer hands over)
   int B, L, H, s;
 };
 
-// grid (H/16, 2 dirs, batch tiles of 16); block 256 = 4 waves, wave w reduces k in [w*H/4, (w+1)*H/4).  The step is
-// latency-bound, so every operand of a wave's K range is requested before the first MFMA (KU iterations of 16 at a time).
-template <int KU>
+// grid (H/4, 2 dirs); block 256 = 4 waves.  A workgroup owns FOUR hidden units -- their i,f,g,o gates are the 16 columns of one MFMA
+// tile, column c = unit * 4 + gate -- for ALL batch rows (MT tiles of 16), its waves split K; the partial tiles meet in LDS and
+// thread (clip, unit) runs the cell update.  256 workgroups of H = 512 fill the chip and each pulls 32 KB of W_hh (16 KB in
+// bf16) + the 64 KB of h through its L1 per step; round 3's first layout (16 units x 16 clips per workgroup, 128 workgroups,
+// 160 KB and 128 fp32 MFMAs per wave) took 7.9 us per step hot and alone (scripts/bench_nodes.py), ~6 of them in the kernel.
+// Every operand of a wave's K range -- and the cell update's own operands -- is requested before the first MFMA.
+//   WT = float : v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode), KU iterations of 16 k at a time
+//   WT = bf16_t: v_mfma_f32_16x16x32_bf16 on the bf16 weight copy; h is rounded to bf16 as it is loaded, accumulation in fp32
+//                (the benchmarked bf16 mode: same precision contract as the rest of the model), KU iterations of 32 k
+template <typename WT, int MT, int KU>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmFwdArgs A) {
-  __shared__ float red[4][4][64][4];   // [wave][gate][lane][reg]
+  __shared__ float red[4][MT][64][4];   // [wave][batch tile][lane][reg]
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int dir = blockIdx.y, j0 = blockIdx.x * 16, bt = blockIdx.z;
+  const int dir = blockIdx.y, j0 = blockIdx.x * 4;
   const int B = A.B, L = A.L, H = A.H, s = A.s;
   const int t = dir == 0 ? s : L - 1 - s;
   const float* hprev = A.hseq + ((long)(dir * (L + 1) + s) * B) * H;
-  const float* W = A.Whh[dir];
-  f32x4 acc[4];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int kq = H / 4;
-  const int row = l & 15, kc = (l >> 4) * 4;
-  const int bb_a = bt * 16 + row;
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // The cell update's own operands (input projection, biases, previous state, length) are requested BEFORE the recurrent
-  // product: issued in the epilogue they were a second, serial memory round trip of ~1 us in an 8 us kernel.
-  const int e_bb = bt * 16 + (l >> 4) * 4 + w, e_j = j0 + (l & 15);
+  // product: issued in the epilogue they were a second, serial memory round trip of ~1 us.
+  const int e_bb = threadIdx.x >> 2, e_j = j0 + (threadIdx.x & 3);
   const bool e_own = e_bb < B;
   float e_x[4], e_bi[4], e_bh[4], e_cp = 0.f, e_hp = 0.f;
   long long e_len = 0;
@@ -74,38 +79,78 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
     e_len = A.lengths[bq];
     if (s == 0) { e_cp = 0.f; e_hp = 0.f; }
   }
-  if (s > 0)                            // zero initial state: the first step has no recurrent term
-    for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 16 * KU) {
-      f32x4 a[KU], b[KU][4];
+  if (s > 0) {                          // zero initial state: the first step has no recurrent term
+    const int kq = H / 4;
+    const int col = l & 15;
+    const long wrow = (long)((col & 3) * H + j0 + (col >> 2)) * H;     // W_hh row of MFMA column c: gate c & 3 of unit c >> 2
+    if constexpr (std::is_same<WT, float>::value) {
+      const float* W = (const float*)A.Whh[dir];
+      const int kc = (l >> 4) * 4;
+      for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 16 * KU) {
+        f32x4 a[KU][MT], b[KU];
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const int k = k0 + u * 16 + kc;
-        a[u] = bb_a < B ? *(const f32x4*)(hprev + (long)bb_a * H + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < KU; ++u) {
+          const int k = k0 + u * 16 + kc;
+          b[u] = *(const f32x4*)(W + wrow + k);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b[u][g] = *(const f32x4*)(W + (long)(g * H + j0 + row) * H + k);
+          for (int mt = 0; mt < MT; ++mt) {
+            const int bb = mt * 16 + col;
+            a[u][mt] = *(const f32x4*)(hprev + (long)(bb < B ? bb : 0) * H + k);
+            if (bb >= B) a[u][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt][e], b[u][e], acc[mt], 0, 0, 0);
       }
+    } else {
+      const bf16_t* W = (const bf16_t*)A.Whh[dir];
+      const int kc = (l >> 4) * 8;
+      for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 32 * KU) {
+        f32x4 alo[KU][MT], ahi[KU][MT];
+        bf16x8 b[KU];
 #pragma unroll
-      for (int u = 0; u < KU; ++u)
+        for (int u = 0; u < KU; ++u) {
+          const int k = k0 + u * 32 + kc;
+          b[u] = *(const bf16x8*)(W + wrow + k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int mt = 0; mt < MT; ++mt) {
+            const int bb = mt * 16 + col;
+            const float* hp = hprev + (long)(bb < B ? bb : 0) * H + k;
+            alo[u][mt] = *(const f32x4*)hp;
+            ahi[u][mt] = *(const f32x4*)(hp + 4);
+            if (bb >= B) { alo[u][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ahi[u][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+          }
+        }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][g][e], acc[g], 0, 0, 0);
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 av;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { av[e] = (bf16_t)alo[u][mt][e]; av[4 + e] = (bf16_t)ahi[u][mt][e]; }
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc[mt], 0, 0, 0);
+          }
+      }
     }
+  }
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[w][g][l][r] = acc[g][r];
+    for (int r = 0; r < 4; ++r) red[w][mt][l][r] = acc[mt][r];
   __syncthreads();
-  // epilogue: 256 threads = 64 lanes x 4 regs of the D tile; D layout: b = bt*16 + (l>>4)*4 + r, j = j0 + (l&15)
+  // epilogue: thread (clip bb, unit u).  D layout of tile mt: clip = mt*16 + (lane>>4)*4 + reg, column = lane & 15.
+  if (!e_own) return;
   {
-    const int r = w;                    // wave w finishes register r of every lane
-    const int bb = e_bb;
-    if (!e_own) return;
-    const int j = e_j;
+    const int bb = e_bb, j = e_j;
+    const int mt = bb >> 4, r16 = bb & 15, ln = (r16 >> 2) * 16 + (threadIdx.x & 3) * 4, rg = r16 & 3;
     float pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float v = red[0][g][l][r] + red[1][g][l][r] + red[2][g][l][r] + red[3][g][l][r];
+      const float v = red[0][mt][ln + g][rg] + red[1][mt][ln + g][rg] + red[2][mt][ln + g][rg] + red[3][mt][ln + g][rg];
       pre[g] = v + e_x[g] + e_bi[g] + e_bh[g];
     }
     const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
@@ -120,26 +165,46 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
     gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
     A.hprev_t[(((long)t * B + bb) * 2 + dir) * H + j] = hp;
     A.out[((long)bb * L + t) * 2 * H + dir * H + j] = valid ? hn : 0.f;
+    if (A.qvec) {                       // the [first ; last] sentence vector: each half-row is produced by exactly one step
+      float* qv = A.qvec + (long)bb * 4 * H + dir * H + j;
+      if (t == 0) qv[0] = valid ? hn : 0.f;
+      if (t == e_len - 1) qv[2 * H] = hn;
+    }
   }
 }
 
-extern "C" int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, const float* b_ih_f, const float* b_hh_f,
-                                 const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out,
-                                 float* hprev_t, const int64_t* lengths, int B, int L, int H, int s, void* stream) {
+template <typename WT, int MT>
+static void lstm_fwd_launch(const LstmFwdArgs& A, hipStream_t stream) {
+  dim3 grid(A.H / 4, 2);
+  const int per = std::is_same<WT, float>::value ? 16 : 32;       // k per iteration
+  const int it = A.H / 4 / per;                                   // iterations per wave
+  if (it % 8 == 0 && std::is_same<WT, float>::value) lstm_step_fwd_kernel<WT, MT, 8><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  else if (it % 4 == 0) lstm_step_fwd_kernel<WT, MT, 4><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  else if (it % 2 == 0) lstm_step_fwd_kernel<WT, MT, 2><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  else lstm_step_fwd_kernel<WT, MT, 1><<<grid, LSTM_THREADS, 0, stream>>>(A);
+}
+
+extern "C" int drn_lstm_step_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, int w_dtype, const float* b_ih_f,
+                                 const float* b_hh_f, const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates,
+                                 float* out, float* hprev_t, float* qvec, const int64_t* lengths, int B, int L, int H, int s, void* stream_) {
   drn_clear_status();
+  hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(xproj && Whh_f && Whh_r && b_ih_f && b_hh_f && b_ih_r && b_hh_r && hseq && cseq && gates && out && hprev_t && lengths,
                 "drn_lstm_step_fwd: null pointer");
   DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0 && s >= 0 && s < L, "drn_lstm_step_fwd: need B<=64, H%%64==0");
+  DRN_CHECK_ARG(w_dtype == DRN_F32 || (w_dtype == DRN_BF16 && H % 128 == 0), "drn_lstm_step_fwd: bf16 weights need H %% 128 == 0");
   LstmFwdArgs A;
   A.xproj = xproj; A.Whh[0] = Whh_f; A.Whh[1] = Whh_r; A.hseq = hseq; A.cseq = cseq; A.gates = gates; A.out = out;
-  A.hprev_t = hprev_t; A.b_ih[0] = b_ih_f; A.b_hh[0] = b_hh_f; A.b_ih[1] = b_ih_r; A.b_hh[1] = b_hh_r;
+  A.hprev_t = hprev_t; A.qvec = qvec; A.b_ih[0] = b_ih_f; A.b_hh[0] = b_hh_f; A.b_ih[1] = b_ih_r; A.b_hh[1] = b_hh_r;
   A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
-  dim3 grid(H / 16, 2, cdiv(B, 16));
-  const int kq16 = H / 64;               // 16-wide K iterations per wave
-  if (kq16 % 8 == 0) lstm_step_fwd_kernel<8><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
-  else if (kq16 % 4 == 0) lstm_step_fwd_kernel<4><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
-  else if (kq16 % 2 == 0) lstm_step_fwd_kernel<2><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
-  else lstm_step_fwd_kernel<1><<<grid, LSTM_THREADS, 0, (hipStream_t)stream>>>(A);
+  const int mt = cdiv(B, 16);
+  if (w_dtype == DRN_BF16) {
+    if (mt == 1) lstm_fwd_launch<bf16_t, 1>(A, stream); else if (mt == 2) lstm_fwd_launch<bf16_t, 2>(A, stream);
+    else if (mt == 3) lstm_fwd_launch<bf16_t, 3>(A, stream); else lstm_fwd_launch<bf16_t, 4>(A, stream);
+  } else {
+    if (mt == 1) lstm_fwd_launch<float, 1>(A, stream); else if (mt == 2) lstm_fwd_launch<float, 2>(A, stream);
+    else if (mt == 3) lstm_fwd_launch<float, 3>(A, stream); else lstm_fwd_launch<float, 4>(A, stream);
+  }
   return drn_launch_status("drn_lstm_step_fwd");
 }
 
@@ -148,10 +213,11 @@ struct LstmBwdArgs {
   const float* dout;     // [B][L][2H]
   const float* gates;    // activated i,f,g,o
   const float* cseq;
-  const float* WhhT[2];  // [H][4H] = Whh^T (contiguous along the gate row index)
+  const void* WhhT[2];   // [H][4H] = Whh^T (contiguous along the gate row index), fp32 or bf16
   float* dgates;         // [L][B][2][4H] by time
   float* dc;             // [2][B][H]
   float* dh_pass;        // [2][B][H]  dL/dh that bypasses the cell at padded positions (in/out)
+  const float* dqvec;    // optional [B][4H]: gradient of the [first ; last] sentence vector, added to dout rows 0 and len_b-1 on load
   const long long* lengths;
   int B, L, H, s;
 };
@@ -167,9 +233,16 @@ __device__ __forceinline__ LstmCellIn lstm_cell_bwd_load(const LstmBwdArgs& A, i
   const int B = A.B, L = A.L, H = A.H;
   const int t = dir == 0 ? s : L - 1 - s;
   LstmCellIn c;
-  c.valid = t < A.lengths[bb];
+  const long long len = A.lengths[bb];
+  c.valid = t < len;
   const long sidx = ((long)dir * B + bb) * H + j;
   c.dout = A.dout[((long)bb * L + t) * 2 * H + dir * H + j];
+  if (A.dqvec) {                        // (same order as the former in-place pass: row 0's half first, then row len-1's)
+    const float* dq = A.dqvec + (long)bb * 4 * H + dir * H + j;
+    const float d0 = dq[0], d1 = dq[2 * H];
+    if (t == 0) c.dout += d0;
+    if (t == len - 1) c.dout += d1;
+  }
   c.dcn = s == L - 1 ? 0.f : A.dc[sidx];       // nothing flows in from beyond the last step
   const float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
   c.ig = gs[0]; c.fg = gs[H]; c.gg = gs[2 * H]; c.og = gs[3 * H];
@@ -216,8 +289,10 @@ __global__ void lstm_bwd_first_kernel(const LstmBwdArgs A) {
 
 // dh[dir][b][k] = dh_pass + sum_r dgates[t(s)][b][dir][r] * Whh[dir][r][k], immediately consumed by the cell backward of
 // step s-1 for the same (b, k) -- dh itself never goes to memory.  grid (H/16, 2, batch tiles), 4 waves split r (K = 4H),
-// KU iterations of 16 prefetched at a time.
-template <int KU>
+// KU iterations prefetched at a time.  WT = float: exact-fp32 MFMA, 16 r per iteration; WT = bf16_t: the bf16 copy of Whh^T,
+// dgates rounded to bf16 as they are loaded, v_mfma_f32_16x16x32_bf16 with fp32 accumulation, 32 r per iteration -- half the
+// weight bytes through the L1 and 1/16 of the MFMA cycles (the fp32 step is 9.8 us hot and alone, scripts/bench_nodes.py).
+template <typename WT, int KU>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmBwdArgs A) {
   __shared__ float red[4][64][4];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -226,27 +301,54 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmB
   const int K = 4 * H, kq = K / 4;
   const int t = dir == 0 ? s : L - 1 - s;
   const float* dg = A.dgates + ((long)t * B * 2 + dir) * K;      // row bb at dg + bb * 2K
-  const float* WT = A.WhhT[dir];
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int row = l & 15, rc = (l >> 4) * 4;
+  const int row = l & 15;
   const int bb_a = bt * 16 + row;
   // operands of the cell backward this thread will run in the epilogue: requested up front
   const int e_bb = bt * 16 + (l >> 4) * 4 + w, e_k = k0 + (l & 15);
   const bool e_own = e_bb < B;
   const LstmCellIn e_c = lstm_cell_bwd_load(A, dir, e_own ? e_bb : 0, e_k, s - 1);
   const float e_dhp = A.dh_pass[((long)dir * B + (e_own ? e_bb : 0)) * H + e_k];
-  for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 16 * KU) {
-    f32x4 a[KU], b[KU];
+  const float* arow = dg + (long)(bb_a < B ? bb_a : 0) * 2 * K;
+  if constexpr (std::is_same<WT, float>::value) {
+    const float* WT_ = (const float*)A.WhhT[dir];
+    const int rc = (l >> 4) * 4;
+    for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 16 * KU) {
+      f32x4 a[KU], b[KU];
 #pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const int r = r0 + u * 16 + rc;
-      a[u] = bb_a < B ? *(const f32x4*)(dg + (long)bb_a * 2 * K + r) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      b[u] = *(const f32x4*)(WT + (long)(k0 + row) * K + r);
+      for (int u = 0; u < KU; ++u) {
+        const int r = r0 + u * 16 + rc;
+        a[u] = *(const f32x4*)(arow + r);
+        if (bb_a >= B) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        b[u] = *(const f32x4*)(WT_ + (long)(k0 + row) * K + r);
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
     }
+  } else {
+    const bf16_t* WT_ = (const bf16_t*)A.WhhT[dir];
+    const int rc = (l >> 4) * 8;
+    for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 32 * KU) {
+      f32x4 alo[KU], ahi[KU];
+      bf16x8 b[KU];
 #pragma unroll
-    for (int u = 0; u < KU; ++u)
+      for (int u = 0; u < KU; ++u) {
+        const int r = r0 + u * 32 + rc;
+        alo[u] = *(const f32x4*)(arow + r);
+        ahi[u] = *(const f32x4*)(arow + r + 4);
+        if (bb_a >= B) { alo[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; ahi[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        b[u] = *(const bf16x8*)(WT_ + (long)(k0 + row) * K + r);
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
+      for (int u = 0; u < KU; ++u) {
+        bf16x8 av;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { av[e] = (bf16_t)alo[u][e]; av[4 + e] = (bf16_t)ahi[u][e]; }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc, 0, 0, 0);
+      }
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[w][l][r] = acc[r];
@@ -258,21 +360,21 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmB
 }
 
 extern "C" int drn_lstm_bwd_first(const float* dout, const float* gates, const float* cseq, float* dgates, float* dc, float* dh_pass,
-                                  const int64_t* lengths, int B, int L, int H, void* stream) {
+                                  const float* dqvec, const int64_t* lengths, int B, int L, int H, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(dout && gates && cseq && dgates && dc && dh_pass && lengths, "drn_lstm_bwd_first: null pointer");
   DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0, "drn_lstm_bwd_first: need B<=64, H%%64==0");
   LstmBwdArgs A;
   memset(&A, 0, sizeof(A));
-  A.dout = dout; A.gates = gates; A.cseq = cseq; A.dgates = dgates; A.dc = dc; A.dh_pass = dh_pass;
+  A.dout = dout; A.gates = gates; A.cseq = cseq; A.dgates = dgates; A.dc = dc; A.dh_pass = dh_pass; A.dqvec = dqvec;
   A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = L - 1;
   lstm_bwd_first_kernel<<<cdiv(2 * B * H, 256), 256, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_lstm_bwd_first");
 }
 
-extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const float* WhhT_f, const float* WhhT_r,
-                                 float* dgates, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s,
-                                 void* stream_) {
+extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const void* WhhT_f, const void* WhhT_r,
+                                 int w_dtype, float* dgates, float* dc, float* dh_pass, const float* dqvec, const int64_t* lengths, int B, int L,
+                                 int H, int s, void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(dout && gates && cseq && WhhT_f && WhhT_r && dgates && dc && dh_pass && lengths, "drn_lstm_step_bwd: null pointer");
@@ -280,10 +382,17 @@ extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const fl
   LstmBwdArgs A;
   memset(&A, 0, sizeof(A));
   A.dout = dout; A.gates = gates; A.cseq = cseq; A.WhhT[0] = WhhT_f; A.WhhT[1] = WhhT_r; A.dgates = dgates; A.dc = dc;
-  A.dh_pass = dh_pass; A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
+  A.dh_pass = dh_pass; A.dqvec = dqvec; A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
+  DRN_CHECK_ARG(w_dtype == DRN_F32 || (w_dtype == DRN_BF16 && H % 128 == 0), "drn_lstm_step_bwd: bf16 weights need H %% 128 == 0");
   dim3 grid(H / 16, 2, cdiv(B, 16));
-  const int kq16 = H / 16;               // 16-wide K iterations per wave (K = 4H over 4 waves)
-  if (kq16 % 8 == 0) lstm_step_bwd_kernel<8><<<grid, LSTM_THREADS, 0, stream>>>(A);
-  else lstm_step_bwd_kernel<4><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  if (w_dtype == DRN_BF16) {
+    const int it = H / 32;               // 32-wide K iterations per wave (K = 4H over 4 waves)
+    if (it % 8 == 0) lstm_step_bwd_kernel<bf16_t, 8><<<grid, LSTM_THREADS, 0, stream>>>(A);
+    else lstm_step_bwd_kernel<bf16_t, 4><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  } else {
+    const int kq16 = H / 16;             // 16-wide K iterations per wave
+    if (kq16 % 8 == 0) lstm_step_bwd_kernel<float, 8><<<grid, LSTM_THREADS, 0, stream>>>(A);
+    else lstm_step_bwd_kernel<float, 4><<<grid, LSTM_THREADS, 0, stream>>>(A);
+  }
   return drn_launch_status("drn_lstm_step_bwd");
 }

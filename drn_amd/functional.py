@@ -1224,8 +1224,14 @@ def fcos_loss(logits, reg, iou, gt, levels, B, gamma, alpha, target_scale, iou_s
 # dimension: forward / input gradients go through the grouped skinny kernel, all weight / bias gradients of one backward
 # node through ONE grouped outer-product launch (drn_amd/csrc/qdense.hip) -- no library GEMM, no per-bias reduction launch.
 # ---------------------------------------------------------------------------------------------------------------------
-def _lstm_forward(emb_tm, lens, lstm_params, B, L):
-    """emb_tm (L*B, E) time-major fp32.  Returns out (B, L, 2H) and the tensors backward needs."""
+def _lstm_lowp(lowp, H):
+    """bf16 recurrent weights (drn_lstm_step_*'s DRN_BF16 mode) need H % 128 == 0; smaller test models stay on the fp32 kernels."""
+    return bool(lowp) and H % 128 == 0
+
+
+def _lstm_forward(emb_tm, lens, lstm_params, B, L, qvec=None, lowp=False):
+    """emb_tm (L*B, E) time-major fp32.  Returns out (B, L, 2H) and the tensors backward needs.  qvec (B, 4H) or None: filled
+    with [out[b][0] ; out[b][len_b - 1]] by the step kernels (language_module.py:48-54)."""
     w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = lstm_params
     H = w_hh_f.shape[1]
     dev = emb_tm.device
@@ -1237,26 +1243,31 @@ def _lstm_forward(emb_tm, lens, lstm_params, B, L):
     hprev = torch.empty((L, B, 2, H), dtype=torch.float32, device=dev)
     out = torch.empty((B, L, 2 * H), dtype=torch.float32, device=dev)
     biases = (b_ih_f.detach(), b_hh_f.detach(), b_ih_r.detach(), b_hh_r.detach())
-    whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
+    if _lstm_lowp(lowp, H):               # bf16 copies in the parameter's own element order, kept current by the optimizer kernels
+        whf, whr = packed(w_hh_f, (0, 2, 1), ops.BF16), packed(w_hh_r, (0, 2, 1), ops.BF16)
+    else:
+        whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
     for s in range(L):
-        ops.lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev, lens, B, L, H, s)
+        ops.lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev, lens, B, L, H, s, qvec=qvec)
     return out, (cseq, gates, hprev)
 
 
-def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L, leaves):
-    """dout (B, L, 2H) contiguous fp32.  Returns (demb_tm (L*B, E), the eight parameter gradients); the weight / bias
+def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L, leaves, dqvec=None, lowp=False):
+    """dout (B, L, 2H) contiguous fp32; dqvec (B, 4H) or None: gradient of the [first ; last] sentence vector, added to rows 0 and
+    len_b - 1 of dout as the kernels read them.  Returns (demb_tm (L*B, E), the eight parameter gradients); the weight / bias
     gradient products are appended to `leaves` (the caller launches them with its own, ops.outer_wgrad); they land in the
     reducer's flat buckets when sinks are registered."""
     w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r = lstm_params
     cseq, gates, hprev = saved
     H = w_hh_f.shape[1]
     dev = dout.device
-    wtf, wtr = packed(w_hh_f, (1, 2, 0), ops.F32), packed(w_hh_r, (1, 2, 0), ops.F32)      # W_hh^T, cached
+    wcode = ops.BF16 if _lstm_lowp(lowp, H) else ops.F32
+    wtf, wtr = packed(w_hh_f, (1, 2, 0), wcode), packed(w_hh_r, (1, 2, 0), wcode)          # W_hh^T, cached
     dgates = torch.empty((L, B, 2, 4 * H), dtype=torch.float32, device=dev)
     scratch = torch.empty((2, 2, B, H), dtype=torch.float32, device=dev)
-    ops.lstm_bwd_first(dout, gates, cseq, dgates, scratch[0], scratch[1], lens, B, L, H)
+    ops.lstm_bwd_first(dout, gates, cseq, dgates, scratch[0], scratch[1], lens, B, L, H, dqvec=dqvec)
     for s in range(L - 1, 0, -1):           # W_hh product of step s + cell backward of step s-1 in one launch
-        ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], lens, B, L, H, s)
+        ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], lens, B, L, H, s, dqvec=dqvec)
     dg = dgates.view(L * B, 8 * H)
     hp = hprev.view(L * B, 2 * H)
     demb_tm = ops.skinny_rows(dg, stacked_t([w_ih_f, w_ih_r]))           # dg [W_f; W_r]: (L*B, E)
@@ -1305,11 +1316,12 @@ class _BiLSTMFn(torch.autograd.Function):
     time step; the input projection and the weight gradients in drn_amd/csrc/qdense.hip."""
 
     @staticmethod
-    def forward(ctx, emb, lengths, *lstm_params):
+    def forward(ctx, lowp, emb, lengths, *lstm_params):
         B, L, E = emb.shape
         emb_tm = emb.detach().transpose(0, 1).reshape(L * B, E).float()
         lens = _dev_lengths(lengths, emb.device)
-        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L)
+        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L, lowp=lowp)
+        ctx.lowp = lowp
         ctx.dims = (B, L, E)
         ctx.lstm_params = lstm_params
         ctx.save_for_backward(emb_tm, lens, *saved)
@@ -1320,14 +1332,16 @@ class _BiLSTMFn(torch.autograd.Function):
         B, L, E = ctx.dims
         emb_tm, lens = ctx.saved_tensors[:2]
         leaves = []
-        demb_tm, grads = _lstm_backward(dout.contiguous().float(), emb_tm, lens, ctx.lstm_params, ctx.saved_tensors[2:], B, L, leaves)
+        demb_tm, grads = _lstm_backward(dout.contiguous().float(), emb_tm, lens, ctx.lstm_params, ctx.saved_tensors[2:], B, L, leaves,
+                                        lowp=ctx.lowp)
         ops.outer_wgrad(leaves)
-        return (demb_tm.view(L, B, E).transpose(0, 1), None) + grads
+        return (None, demb_tm.view(L, B, E).transpose(0, 1), None) + grads
 
 
-def bilstm(emb, lengths, lstm):
-    """lstm: an nn.LSTM(num_layers=1, bidirectional=True, batch_first=True) used as a parameter holder."""
-    return _BiLSTMFn.apply(emb, lengths, *_lstm_param_list(lstm))
+def bilstm(emb, lengths, lstm, lowp=False):
+    """lstm: an nn.LSTM(num_layers=1, bidirectional=True, batch_first=True) used as a parameter holder.  lowp: recurrent
+    products on the bf16 MFMA with bf16 copies of W_hh (needs hidden_size % 128 == 0, else the fp32 kernels run)."""
+    return _BiLSTMFn.apply(bool(lowp), emb, lengths, *_lstm_param_list(lstm))
 
 
 def _lstm_param_list(lstm):
@@ -1344,8 +1358,9 @@ class _QueryEncoderFn(torch.autograd.Function):
     straight into its final buffer."""
 
     @staticmethod
-    def forward(ctx, tokens, lengths, table, *params):
+    def forward(ctx, lowp, tokens, lengths, table, *params):
         lstm_params, (Wq, bq, W0, b0, W1, b1, W2, b2, wl, bl), gate_params = params[:8], params[8:18], params[18:]
+        ctx.lowp = lowp
         B, L = tokens.shape
         E = table.shape[1]
         H = lstm_params[1].shape[1]
@@ -1355,9 +1370,10 @@ class _QueryEncoderFn(torch.autograd.Function):
         lens = _dev_lengths(lengths, dev)
         emb_tm = torch.empty((L * B, E), dtype=torch.float32, device=dev)
         ops.qe_embed_fwd(tokens, table.detach(), emb_tm, B, L, E)
-        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L)
         qvec = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
-        ops.qe_qvec_fwd(out, lens, qvec, B, L, C)                          # language_module.py:48-54
+        # (the forward recurrence stays on the exact-fp32 MFMA in the bf16 model too: it is only 0.5 us per step slower than the
+        # bf16 variant and keeps the gates -- which scale every feature channel -- free of a second rounding; backward uses bf16)
+        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L, qvec=qvec)            # qvec: language_module.py:48-54
         base = ops.skinny_linear(qvec, Wq.detach(), bq.detach(), relu=True)               # language_module.py:55-56
         _tap_relu(Wq, 0, base)
         qcmd = ops.skinny_linear(base, stacked([W0, W1, W2]), stacked([b0, b1, b2]))      # (B, 3*C): all three qInput{t}
@@ -1416,24 +1432,26 @@ class _QueryEncoderFn(torch.autograd.Function):
         dqvec = ops.skinny_linear(dpre, packed(Wq, (1, 2, 0), ops.F32))
         dWq, dbq = grad_buffer(Wq), grad_buffer(bq)
         leaves.append(dict(dY=dpre, X=qvec, dW=dWq, db=dbq))
-        ops.qe_qvec_bwd(dqvec, lens, dout, B, L, C)
-        demb_tm, lstm_grads = _lstm_backward(dout, emb_tm, lens, lstm_params, ctx.saved_tensors[9:], B, L, leaves)
+        demb_tm, lstm_grads = _lstm_backward(dout, emb_tm, lens, lstm_params, ctx.saved_tensors[9:], B, L, leaves, dqvec=dqvec,
+                                             lowp=ctx.lowp)
         table = ctx.table
         dtable = grad_buffer(table)
         ops.qe_embed_bwd(tokens, demb_tm, dtable, B, L, E, table.shape[0], 0)      # nn.Embedding(padding_idx=0)
         ops.outer_wgrad(leaves)                                                    # every weight / bias gradient of the node
-        return (None, None, dtable) + lstm_grads + (dWq, dbq, dW[0], db[0], dW[1], db[1], dW[2], db[2], dwl, dbl) + gate_grads
+        return (None, None, None, dtable) + lstm_grads + (dWq, dbq, dW[0], db[0], dW[1], db[1], dW[2], db[2], dwl, dbl) + gate_grads
 
 
-def query_encoder(tokens, lengths, enc, gate_linears=None):
+def query_encoder(tokens, lengths, enc, gate_linears=None, lowp=False):
     """enc: drn_amd.model.language_module.QueryEncoder (parameter holder).  Returns the three (B, 2H) commands, or -- with
-    gate_linears = mainModel's three qInput{t} nn.Linear holders -- the three per-level gate tensors (B, C_t)."""
+    gate_linears = mainModel's three qInput{t} nn.Linear holders -- the three per-level gate tensors (B, C_t).  lowp (the bf16
+    model): the recurrent products of the BiLSTM's BACKWARD pass use the bf16 copy of W_hh^T on the bf16 MFMA (fp32 accumulation);
+    the forward pass is fp32 in either mode."""
     if enc.embedding.padding_idx != 0:
         raise DrnError("query encoder kernels assume nn.Embedding(padding_idx=0) (model/language_module.py:13)")
     extra = []
     for lin in (gate_linears or []):
         extra += [lin.weight, lin.bias]
-    return _QueryEncoderFn.apply(tokens, lengths, enc.embedding.weight, *_lstm_param_list(enc.biLSTM),
+    return _QueryEncoderFn.apply(bool(lowp), tokens, lengths, enc.embedding.weight, *_lstm_param_list(enc.biLSTM),
                                  enc.qInput.weight, enc.qInput.bias, enc.qInput0.weight, enc.qInput0.bias,
                                  enc.qInput1.weight, enc.qInput1.bias, enc.qInput2.weight, enc.qInput2.bias,
                                  enc.cmd_inter2logits.weight, enc.cmd_inter2logits.bias, *extra)

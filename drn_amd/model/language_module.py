@@ -35,6 +35,10 @@ class TextualAttention(nn.Module):
 
 
 class QueryEncoder(nn.Module):
+    # torch.bfloat16 (set by mainModel.set_compute_dtype): the recurrent products of the BiLSTM's backward pass run on the bf16
+    # MFMA with the optimizer-maintained bf16 copy of W_hh^T (fp32 accumulation); the forward pass and everything else stay fp32
+    compute_dtype = torch.float32
+
     def __init__(self, vocab_size, hidden_dim=512, embed_dim=300, num_layers=1, bidirection=True):
         super(QueryEncoder, self).__init__()
         self.hidden_dim = hidden_dim
@@ -51,4 +55,4 @@ class QueryEncoder(nn.Module):
     def forward(self, query_tokens, query_length):
         """language_module.py:38-63 -> the three attention commands [(B, 2H)] * 3, as one fused autograd node
         (drn_amd.functional._QueryEncoderFn: embedding, BiLSTM, sentence vector, qInput*, attention)."""
-        return list(DF.query_encoder(query_tokens, query_length, self))
+        return list(DF.query_encoder(query_tokens, query_length, self, lowp=self.compute_dtype == torch.bfloat16))

@@ -53,7 +53,8 @@ class mainModel(nn.Module):
         n = len(self.backbone_net.blocks)
         if n == 3:          # the whole query side, gate projections included, as one autograd node
             return list(DF.query_encoder(query_tokens, query_length, self.query_encoder,
-                                         [getattr(self, "qInput%d" % i) for i in range(n)]))
+                                         [getattr(self, "qInput%d" % i) for i in range(n)],
+                                         lowp=self.compute_dtype == torch.bfloat16))
         query_features = self.query_encoder(query_tokens, query_length)
         return [DF.linear(query_features[i], getattr(self, "qInput%d" % i)) for i in range(n)]
 

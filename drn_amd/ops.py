@@ -459,6 +459,7 @@ def _head_calls(calls):
         d.dscale_stride = c["dscale"].stride(0) if c.get("dscale") is not None and c["dscale"].numel() > 1 else 1
         d.W, d.bias, d.out, d.z = _p(c["W"]), _p(c.get("bias")), _p(c.get("out")), _p(c.get("z"))
         d.dout, d.dW, d.dbias, d.dscale, d.ws = _p(c.get("dout")), _p(c.get("dW")), _p(c.get("dbias")), _p(c.get("dscale")), _p(c.get("ws"))
+    arr._groups = [c["groups"] for c in calls]        # the nested host arrays live as long as the descriptor array that points to them
     return arr
 
 
@@ -538,21 +539,24 @@ def focal_bwd(logits, targets, d_losses, gamma, alpha):
 # ---------------------------------------------------------------------------------------------
 # query-encoder LSTM recurrence
 # ---------------------------------------------------------------------------------------------
-def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens, B, L, H, s):
-    """biases = (b_ih_f, b_hh_f, b_ih_r, b_hh_r); lens int64 on the device; layouts in include/drn_hip.h."""
+def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens, B, L, H, s, qvec=None):
+    """biases = (b_ih_f, b_hh_f, b_ih_r, b_hh_r); lens int64 on the device; layouts in include/drn_hip.h.  qvec (B, 4H) or None:
+    the [first ; last] sentence vector, written by the steps that produce its rows.  whf / whr: W_hh (4H, H) fp32, or bf16 copies."""
     _need_gpu(xproj, out)
-    check(lib().drn_lstm_step_fwd(_p(xproj), _p(whf), _p(whr), _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(biases[3]),
-                                  _p(hseq), _p(cseq), _p(gates), _p(out), _p(hprev_t), _p(lens), B, L, H, s, _stream()),
+    assert whf.dtype == whr.dtype and whf.is_contiguous() and whr.is_contiguous()
+    check(lib().drn_lstm_step_fwd(_p(xproj), _p(whf), _p(whr), BF16 if whf.dtype == torch.bfloat16 else F32, _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(biases[3]),
+                                  _p(hseq), _p(cseq), _p(gates), _p(out), _p(hprev_t), _p(qvec), _p(lens), B, L, H, s, _stream()),
           "drn_lstm_step_fwd")
 
 
-def lstm_bwd_first(dout, gates, cseq, dgates, dc, dh_pass, lens, B, L, H):
-    check(lib().drn_lstm_bwd_first(_p(dout), _p(gates), _p(cseq), _p(dgates), _p(dc), _p(dh_pass), _p(lens), B, L, H, _stream()),
-          "drn_lstm_bwd_first")
+def lstm_bwd_first(dout, gates, cseq, dgates, dc, dh_pass, lens, B, L, H, dqvec=None):
+    check(lib().drn_lstm_bwd_first(_p(dout), _p(gates), _p(cseq), _p(dgates), _p(dc), _p(dh_pass), _p(dqvec), _p(lens), B, L, H,
+                                   _stream()), "drn_lstm_bwd_first")
 
 
-def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dc, dh_pass, lens, B, L, H, s):
-    check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), _p(dgates), _p(dc), _p(dh_pass),
+def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dc, dh_pass, lens, B, L, H, s, dqvec=None):
+    assert wtf.dtype == wtr.dtype and wtf.is_contiguous() and wtr.is_contiguous()
+    check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), BF16 if wtf.dtype == torch.bfloat16 else F32, _p(dgates), _p(dc), _p(dh_pass), _p(dqvec),
                                   _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")
 
 

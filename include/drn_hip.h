@@ -393,18 +393,23 @@ int drn_lgp_bwd(const void* x, int ldx, const float* qn, const float* att, const
  * direction (one (L*B) x 8H matrix); xproj = x_t W_ih^T without biases (b_ih + b_hh are added here); hseq/cseq
  * [2][L+1][B][H] by step (slot 0 is never read: zero initial state); hprev_t [L][B][2][H] = hidden state that entered
  * time t (operand of the W_hh gradient); out [B][L][2H].  Step s handles t = s (forward direction) and t = L-1-s
- * (reverse).  B <= 64, H % 64 == 0. */
-int drn_lstm_step_fwd(const float* xproj, const float* Whh_f, const float* Whh_r, const float* b_ih_f, const float* b_hh_f,
+ * (reverse).  B <= 64, H % 64 == 0.  w_dtype: DRN_F32 (exact-fp32 MFMA, the parity mode) or DRN_BF16 (Whh_* / WhhT_* are bf16
+ * copies in the same element order, H % 128 == 0: the hidden state / gate gradients are rounded to bf16 as they are loaded,
+ * products accumulate in fp32; states, gates and every output stay fp32).  qvec (optional, [B][4H]): the sentence vector [out[b][0][:] ; out[b][len_b-1][:]]
+ * (language_module.py:48-54), each half-row written by the step that produces it -- no gather launch after the recurrence. */
+int drn_lstm_step_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, int w_dtype, const float* b_ih_f, const float* b_hh_f,
                       const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out, float* hprev_t,
-                      const int64_t* lengths, int B, int L, int H, int s, void* stream);
+                      float* qvec, const int64_t* lengths, int B, int L, int H, int s, void* stream);
 /* Backward: drn_lstm_bwd_first does the cell backward of the last step (s = L-1) from dout [B][L][2H] alone; then
  * drn_lstm_step_bwd for s = L-1 .. 1 propagates through W_hh of step s (dgates[t(s)] x Whh) and applies the cell backward
  * of step s-1 in its epilogue (the recurrent dL/dh never goes to memory).  dgates is the operand of the weight-gradient
- * GEMMs; dc / dh_pass are [2][B][H] running state.  WhhT_* = Whh^T as [H][4H]. */
+ * GEMMs; dc / dh_pass are [2][B][H] running state.  WhhT_* = Whh^T as [H][4H].  dqvec (optional, [B][4H]): gradient of the
+ * sentence vector, added to dout rows 0 and len_b-1 as they are read (dout itself is not modified). */
 int drn_lstm_bwd_first(const float* dout, const float* gates, const float* cseq, float* dgates, float* dc, float* dh_pass,
-                       const int64_t* lengths, int B, int L, int H, void* stream);
-int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const float* WhhT_f, const float* WhhT_r,
-                      float* dgates, float* dc, float* dh_pass, const int64_t* lengths, int B, int L, int H, int s, void* stream);
+                       const float* dqvec, const int64_t* lengths, int B, int L, int H, void* stream);
+int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const void* WhhT_f, const void* WhhT_r, int w_dtype,
+                      float* dgates, float* dc, float* dh_pass, const float* dqvec, const int64_t* lengths, int B, int L, int H, int s,
+                      void* stream);
 
 /* ---- fused clip_grad_norm_ + Adam over flat gradient buckets (drn_amd/csrc/optim.hip; main.py:140,238-243) ---- */
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */

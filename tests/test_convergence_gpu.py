@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 T_PROPS, D, B = 32, 64, 32          # Charades-STA's 32 proposals (model/loss.py:98), a small feature dim, the reference's batch size
-STEPS, EVAL_CLIPS = 400, 1024
+STEPS, EVAL_CLIPS = 400, 8192     # 8192 held-out clips: one clip = 0.012 pt, binomial sigma at 99.5 % = 0.08 pt (1024 clips: 0.22 pt -- the 0.3 pt band was 1.4 sigma)
 
 
 def run(dtype, jitter=0.0):

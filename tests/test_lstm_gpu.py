@@ -42,3 +42,67 @@ def test_bilstm_matches_packed_nn_lstm(B, L, E, H, lens):
     close(xh.grad, xr.grad, 1e-4, "dx")
     for k, p in mod.named_parameters():
         close(p.grad, dict(ref.named_parameters())[k].grad, 1e-4, k)
+
+
+def test_sentence_vector_rides_in_the_step_kernels():
+    """qvec = [out[b][0] ; out[b][len_b-1]] written by the forward steps, and its gradient added to dout rows 0 / len_b-1 as
+    the backward steps read them: bit-identical to the separate gather / scatter-add kernels (language_module.py:48-54)."""
+    from drn_amd import functional as DF
+    from drn_amd import ops
+    torch.manual_seed(1)
+    dev = "cuda:0"
+    B, L, E, H = 6, 5, 20, 64
+    lens = torch.tensor([5, 4, 3, 2, 1, 1], dtype=torch.int64, device=dev)
+    mod = nn.LSTM(E, H, 1, batch_first=True, bidirectional=True).to(dev)
+    params = DF._lstm_param_list(mod)
+    emb_tm = torch.randn(L * B, E, device=dev)
+    qvec = torch.full((B, 4 * H), float("nan"), device=dev)
+    out, saved = DF._lstm_forward(emb_tm, lens, params, B, L, qvec=qvec)
+    want = torch.empty_like(qvec)
+    ops.qe_qvec_fwd(out, lens, want, B, L, 2 * H)
+    assert torch.equal(qvec, want)
+    dout = torch.randn(B, L, 2 * H, device=dev)
+    dqvec = torch.randn(B, 4 * H, device=dev)
+    leaves = []
+    d_a, _ = DF._lstm_backward(dout, emb_tm, lens, params, saved, B, L, leaves, dqvec=dqvec)
+    dgates_a = leaves[0]["dY"].clone()
+    dout_b = dout.clone()
+    ops.qe_qvec_bwd(dqvec, lens, dout_b, B, L, 2 * H)
+    leaves_b = []
+    d_b, _ = DF._lstm_backward(dout_b, emb_tm, lens, params, saved, B, L, leaves_b)
+    assert torch.equal(d_a, d_b) and torch.equal(dgates_a, leaves_b[0]["dY"])
+
+
+@pytest.mark.parametrize("B,L,lens", [(32, 8, None), (7, 5, [5, 5, 4, 3, 2, 1, 1]), (40, 3, None)])
+def test_bf16_recurrent_weights_track_the_fp32_kernels(B, L, lens):
+    """The bf16 model's BiLSTM: W_hh / W_hh^T as bf16 copies on v_mfma_f32_16x16x32_bf16 (h and the gate gradients rounded to bf16
+    on load, fp32 accumulation, fp32 states) against the exact-fp32 kernels on the same inputs: bf16 rounding of two operands
+    (2^-9 each) through <= 8 recurrent steps."""
+    from drn_amd import functional as DF
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    E, H = 300, 512
+    if lens is None:
+        lens = sorted(torch.randint(1, L + 1, (B,)).tolist(), reverse=True)
+        lens[0] = L
+    lengths = torch.tensor(lens, dtype=torch.int64, device=dev)
+    mod = nn.LSTM(E, H, 1, batch_first=True, bidirectional=True).to(dev)
+    x = torch.randn(B, L, E, device=dev)
+    w = torch.randn(B, L, 2 * H, device=dev)
+    res = {}
+    for lowp in (False, True):
+        mod.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        o = DF.bilstm(xi, lengths, mod, lowp=lowp)
+        (o * w).sum().backward()
+        res[lowp] = (o.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in mod.named_parameters()})
+    o32, dx32, g32 = res[False]
+    o16, dx16, g16 = res[True]
+    assert not torch.equal(o32, o16)                                  # the bf16 path really ran
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    assert rel(o16, o32) <= 1e-2, rel(o16, o32)
+    assert rel(dx16, dx32) <= 2e-2, rel(dx16, dx32)
+    for k in g32:
+        assert rel(g16[k], g32[k]) <= 2e-2, (k, rel(g16[k], g32[k]))
+    for b in range(B):                                                # padded positions stay exact zeros
+        assert float(o16[b, lens[b]:].abs().max() if lens[b] < L else 0.0) == 0.0
