@@ -23,6 +23,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--T", type=int, default=256)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--min-us", type=float, default=0.0)
+ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="drn_tune(KEY, VALUE) before the replays (experiments)")
+ap.add_argument("--only", default=None, help="only entry points whose name contains this")
 ap.add_argument("--lstm-f32", action="store_true", help="keep the BiLSTM's recurrent products on the fp32 kernels in the bf16 model")
 args = ap.parse_args()
 if args.lstm_f32:
@@ -70,11 +72,16 @@ L._lib = Recorder()
 step()
 torch.cuda.synchronize()
 L._lib = real
+for kv in args.tune:
+    k, v = kv.split("=")
+    L.check(real.drn_tune(k.encode(), int(v)), "drn_tune")
 keep = list(calls)                      # (the argument tuples keep host descriptor arrays alive; device tensors live in the autograd graph
 print("%d C-ABI calls in one step" % len(keep))                                           # of the last step, which we never free)
 s = torch.cuda.Stream()
 rows = []
 for i, (name, fn, a) in enumerate(keep):
+    if args.only and args.only not in name:
+        continue
     a = list(a)
     if os.environ.get("BENCH_NODES_DEBUG"):
         print("call %d %s%r" % (i, name, tuple(x.value if hasattr(x, "value") else x for x in a)), flush=True)
