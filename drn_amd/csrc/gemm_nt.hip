@@ -334,6 +334,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams& P, const GemmProb&
 
 // Optional per-wave timeline (build with -DDRN_NT_TRACE, scripts/experiments/nt_trace.py): workgroup 0 stamps s_memtime at
 // seven points of every K-step into P.ws (pass a buffer through drn_gemm_nt_splitk with ksplit = 1).
+// -DDRN_NT_PHASES (scripts/experiments/nt_phases.py): wall_clock64() (100 MHz) per workgroup at entry / staging state ready /
+// first K-tile landed / K loop done / exit, read back with drn_debug_nt_phases() -- the fixed part of a small launch.
+#ifdef DRN_NT_PHASES
+__device__ long long g_nt_phases[4096 * 8];
+#define NT_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) g_nt_phases[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int drn_debug_nt_phases(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_phases), (size_t)n * 8); }
+#else
+#define NT_PHASE(i) do { } while (0)
+#endif
 #ifdef DRN_NT_TRACE
 #define NT_STAMP(slot) do { if (P.ws && P.ksplit == 1 && blockIdx.x == 0 && l == 0 && kt - kt_lo < 64) \
     ((long long*)P.ws)[((w * 64) + (kt - kt_lo)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   // the 8-wave 256x256 tile measured 3 % slower with it, so it keeps the per-lane value
   const int tid = threadIdx.x, l = tid & 63;
   const int w = (WM * WN == 8 && !getenv_free_scalar_w) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
+  NT_PHASE(0);
 
   int g, tm, tn;
   nt_locate<TM>(P, g, tm, tn);
@@ -484,6 +494,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   const int wr = w / WN, wc = w % WN;
   const int swz = (l >> 1) & 7;
 
+  NT_PHASE(1);
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st) stage(st);
   int cur = 0;
@@ -497,6 +508,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     NT_STAMP(2);
+    if (kt == kt_lo) NT_PHASE(2);
     int nxt = cur + STAGES - 1;
     if (nxt >= STAGES) nxt -= STAGES;
     const char* As = smem + cur * STAGE_B;
@@ -533,6 +545,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  NT_PHASE(3);
 
   if constexpr (MI * NI == 8) {          // (the 128x128 tiles: split launches always use them)
     if (P.ksplit > 1) {
@@ -606,6 +619,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
     }
   }
   nt_epilogue<T, WM, WN, MI, NI>(P, pr, acc, smem, m0, n0, tm);
+  NT_PHASE(4);
 }
 
 static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr,

@@ -130,6 +130,10 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
     }
   };
   if (R.window && lane < nvec) fetch_window(lane);      // in flight while the weights arrive
+  // the output stage's own operands (bias, the level's scale) are requested here as well: fetched after the wave reduction they
+  // were one more serial trip through caches that start every kernel cold
+  const float b_pre = bias[(lane >> 2) % HEAD_MAX_N < N ? (lane >> 2) % HEAD_MAX_N : 0];
+  const float sc_pre = (P.exp_mode && R.window) ? P.g[R.g].scale[0] : 1.f;
   float acc[HEAD_RPW][HEAD_MAX_N];
 #pragma unroll
   for (int i = 0; i < HEAD_RPW; ++i)
@@ -228,11 +232,10 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
     const int idx = lane >> 2, i = idx / HEAD_MAX_N, n = idx % HEAD_MAX_N;
     const int r = r0 + i;
     if (r < P.total_rows && n < N) {
-      const HeadGroup& G = P.g[head_group_of(P, r)];
-      float v = tot + bias[n];
+      float v = tot + b_pre;
       if (P.exp_mode) {
         z[(long)r * N + n] = v;
-        v = expf(G.scale[0] * v);
+        v = expf((R.window ? sc_pre : P.g[head_group_of(P, r)].scale[0]) * v);
       }
       out[(long)r * N + n] = v;
     }
@@ -250,23 +253,41 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
 #define HEAD_EXTRA 8
 #define HEAD_WRUNS 2     // runs per wave in the weight-gradient part: HEAD_WRUNS * HEAD_RPW * 4 rows per workgroup
 
-// dzw[j][n], j = 0 .. HEAD_RPW+1 <-> row m0 - 1 + j of level R.g, zero outside the level
+// dzw[j][n], j = 0 .. HEAD_RPW+1 <-> row m0 - 1 + j of level R.g, zero outside the level.  The window is wave-uniform, but it is
+// FETCHED by the lanes -- lane 2j + n loads the operands of dz[j][n], one memory round trip for the whole window -- and then
+// broadcast with v_readlane.  (As scalar loads -- round 2 -- the compiler put a branch and an `s_waitcnt lgkmcnt(0)` behind almost
+// every one of the ~40 s_load_dword of a window: dozens of SERIAL trips through a scalar cache and an L2 that start every kernel
+// cold, the bulk of the 33 us this launch took.)  zsum (w part, exp mode): sum over the run's rows of z * out * dout, per n.
 __device__ __forceinline__ void head_dz_window(const HeadParams& P, const HeadRun& R, const float* __restrict__ dout,
-                                               const float* __restrict__ out, float (&dzw)[HEAD_RPW + 2][HEAD_MAX_N]) {
+                                               const float* __restrict__ out, const float* __restrict__ z,
+                                               float (&dzw)[HEAD_RPW + 2][HEAD_MAX_N], float (&zsum)[HEAD_MAX_N]) {
+  static_assert(HEAD_MAX_N == 2 && (HEAD_RPW + 2) * HEAD_MAX_N <= 64, "one lane per (row, n) of the window");
   const HeadGroup& G = P.g[R.g];
-  const float sc = P.exp_mode ? G.scale[0] : 1.f;
+  const int lane = threadIdx.x & 63;
+  const int j = lane >> 1, n = lane & 1;
+  const int m = R.m0 - 1 + j;
+  const bool in = j < HEAD_RPW + 2 && m >= 0 && m < G.M && n < P.N;
+  const long idx = (long)(G.row_start + (in ? m : R.m0)) * P.N + (n < P.N ? n : 0);     // always a valid address; masked afterwards
+  const float d = dout[idx];
+  float v = d, zv = 0.f;
+  if (P.exp_mode) {                                       // (uniform)
+    const float od = out[idx] * d;
+    v = G.scale[0] * od;
+    if (z) zv = (in && j >= 1 && j <= HEAD_RPW) ? z[idx] * od : 0.f;
+  }
+  v = in ? v : 0.f;
 #pragma unroll
-  for (int j = 0; j < HEAD_RPW + 2; ++j) {
-    const int m = R.m0 - 1 + j;
-    const bool in = m >= 0 && m < G.M;
-    const long ro = (long)(G.row_start + (in ? m : R.m0)) * P.N;
+  for (int jj = 0; jj < HEAD_RPW + 2; ++jj)
 #pragma unroll
-    for (int n = 0; n < HEAD_MAX_N; ++n) {
-      const long idx = ro + (n < P.N ? n : 0);          // always a valid address; masked afterwards
-      const float d = dout[idx];
-      const float zz = P.exp_mode ? sc * out[idx] * d : d;
-      dzw[j][n] = (in && n < P.N) ? zz : 0.f;
-    }
+    for (int nn = 0; nn < HEAD_MAX_N; ++nn)
+      dzw[jj][nn] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj * HEAD_MAX_N + nn));
+#pragma unroll
+  for (int nn = 0; nn < HEAD_MAX_N; ++nn) {
+    float sacc = 0.f;
+    if (z)
+#pragma unroll
+      for (int jj = 1; jj <= HEAD_RPW; ++jj) sacc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zv), jj * HEAD_MAX_N + nn));
+    zsum[nn] = sacc;
   }
 }
 
@@ -281,10 +302,11 @@ __device__ __forceinline__ void head_bwd_data_part(const HeadSet& S, const int b
   const int N = P.N, C = P.C, taps = P.taps;
   const int v = blockIdx.x * 64 + (threadIdx.x & 63);
   const int r0 = (by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * HEAD_RPW;   // wave-uniform: the dz scalars come through the scalar cache
-  if (v * VN >= C || r0 >= P.total_rows) return;
+  if (r0 >= P.total_rows) return;                    // (wave-uniform)
   const HeadRun R = head_run(P, r0);
-  float dzw[HEAD_RPW + 2][HEAD_MAX_N];
-  if (R.window) head_dz_window(P, R, dout, out, dzw);
+  float dzw[HEAD_RPW + 2][HEAD_MAX_N], zs_unused[HEAD_MAX_N];
+  if (R.window) head_dz_window(P, R, dout, out, nullptr, dzw, zs_unused);     // all 64 lanes fetch: before any lane leaves
+  if (v * VN >= C) return;
   float wr[HEAD_MAX_N][HEAD_MAX_TAPS][VN];
   head_load_w<T>(W, C, taps, N, v * VN, true, wr);
   if (R.window) {
@@ -410,21 +432,17 @@ __device__ __forceinline__ void head_bwd_w_part(const HeadSet& S, float* sred, c
     if (R.window) {
       const HeadGroup& G = P.g[R.g];
       const int L = G.L, t0 = R.m0 % L;
-      float dzw[HEAD_RPW + 2][HEAD_MAX_N];
-      head_dz_window(P, R, dout, out, dzw);
+      float dzw[HEAD_RPW + 2][HEAD_MAX_N], zsum[HEAD_MAX_N];
+      head_dz_window(P, R, dout, out, P.exp_mode ? z : nullptr, dzw, zsum);
 #pragma unroll
       for (int i = 0; i < HEAD_RPW; ++i)
 #pragma unroll
-        for (int n = 0; n < HEAD_MAX_N; ++n) {
-          ex[n] += dzw[i + 1][n];
-          if (P.exp_mode && n < N) {
-            const long idx = (long)(r0 + i) * N + n;
-            const float zz = z[idx] * out[idx] * dout[idx];
+        for (int n = 0; n < HEAD_MAX_N; ++n) ex[n] += dzw[i + 1][n];
 #pragma unroll
-            for (int l = 0; l < DRN_MAX_GROUPS; ++l)
-              if (l == R.g) ex[2 + l] += zz;
-          }
-        }
+      for (int n = 0; n < HEAD_MAX_N; ++n)
+#pragma unroll
+        for (int l = 0; l < DRN_MAX_GROUPS; ++l)
+          if (l == R.g) ex[2 + l] += zsum[n];
       if (live) {
         float x[HEAD_RPW + 2][VN];
 #pragma unroll

@@ -6,7 +6,9 @@
 FETCH_SIZE / WRITE_SIZE are in KiB-ish units of 1024 B per the rocprofv3 derived-metric definition; FETCH_SIZE is DOUBLED (gfx950:
 128-B requests tallied at 64 B for wide coalesced reads, MI355X_MICROARCH.md "HBM").  Infinity-Cache hits are counted: the
 figure is fabric traffic behind the L2, an upper bound of HBM traffic.
-usage: python scripts/pmc_hbm_table.py trace.db fetch.db write.db [steps_in_trace] > profiles/rNN_hbm_kernels.txt"""
+usage: python scripts/pmc_hbm_table.py trace.db fetch.db write.db [pmc_traffic.json] > profiles/rNN_hbm_kernels.txt
+With a 4th argument the per-launch bytes of the two prop_fc GEMMs (the 256x256-tile kernel's 512- and 256-workgroup launches) are
+written there in the format bench.py reads for roofline.traffic."""
 import collections
 import sqlite3
 import sys
@@ -43,8 +45,48 @@ def pmc(dbpath, counter):
     return agg
 
 
+def by_grid(dbpath, counter, name_part):
+    """{workgroups per launch: mean counter value} over the dispatches whose kernel name contains name_part."""
+    db = sqlite3.connect(dbpath)
+    cur = db.cursor()
+    cur.execute("select * from counters_collection limit 1")
+    cols = [d[0] for d in cur.description]
+    ki, ci, vi = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value")
+    gcol = [c for c in cols if c in ("grid_size", "grid_size_x", "grid_x")]
+    wcol = [c for c in cols if c in ("workgroup_size", "workgroup_size_x", "workgroup_x")]
+    if not gcol or not wcol:
+        sys.stderr.write("counters_collection has no grid / workgroup size columns: %s\n" % cols)
+        return {}
+    gi, wi = cols.index(gcol[0]), cols.index(wcol[0])
+    agg = collections.defaultdict(list)
+    for r in cur.execute("select * from counters_collection"):
+        if r[ci] == counter and name_part in r[ki]:
+            agg[int(r[gi]) // max(int(r[wi]), 1)].append(float(r[vi]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def write_traffic_json(path, fetch, write):
+    import json
+    big = "2, 4, 8, 4>"                     # the 256x256-tile NT kernel
+    F, W = by_grid(fetch, "FETCH_SIZE", big), by_grid(write, "WRITE_SIZE", big)
+    out = {"_comment": "Fabric traffic per launch of the two prop_fc GEMMs INSIDE the replayed step, from this round's rocprofv3 --pmc passes "
+                       "(FETCH_SIZE and WRITE_SIZE in separate passes, only --kernel-trace beside them; FETCH_SIZE doubled per the gfx950 "
+                       "correction of MI355X_MICROARCH.md), scripts/prof_round.sh -> scripts/pmc_hbm_table.py.  bench.py copies the entry of "
+                       "its dominant kernel into roofline.traffic."}
+    for wgs, tag, alg in ((512, "gemm_nt[bf16] g=1 M=8192 N=4096 K=4096 mode=0", 2 * (8192 * 4096 + 4096 * 4096 + 2 * 8192 * 4096)),   # x, W; gated output + pre-gate copy
+                          (256, "gemm_nt[bf16] g=1 M=4096 N=4096 K=8192 mode=0", 2 * 2 * 4096 * 8192 + 4 * 4096 * 4096)):
+        if wgs in F and wgs in W:
+            out[tag] = {"read_bytes": int(2 * 1024 * F[wgs]), "write_bytes": int(1024 * W[wgs]), "algorithmic_bytes": alg,
+                        "served_by": "Infinity Cache + HBM behind the eight private L2s (32 tiles per XCD at a time touch >= 24 MB of operand "
+                                     "panels, i.e. >= 384 MB per launch, DESIGN.md section 5); compulsory HBM bytes = algorithmic"}
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     trace, fetch, write = sys.argv[1:4]
+    if len(sys.argv) > 4:
+        write_traffic_json(sys.argv[4], fetch, write)
     db = sqlite3.connect(trace)
     dur = collections.defaultdict(list)
     for name, s, e in db.execute("select name, start, end from kernels"):
