@@ -67,7 +67,9 @@ def stage_params(model, stage):
     for n, p in model.named_parameters():
         if stage == 1 and ("iou_scores" in n or "mix_fc" in n):
             p.requires_grad_(False)
-    return [p for p in model.parameters() if p.requires_grad]
+    # (mainModel.learned_parameters drops QueryEncoder.textualAttention, which the reference declares and never calls: its
+    # gradients stay None there and torch's clip_grad_norm_ / Adam skip such parameters, main.py:140,238-243)
+    return model.learned_parameters() if hasattr(model, "learned_parameters") else [p for p in model.parameters() if p.requires_grad]
 
 
 def cpu_baseline(cfg, B, T, D, stage, steps):

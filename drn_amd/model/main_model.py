@@ -67,6 +67,18 @@ class mainModel(nn.Module):
         mods = [self.query_encoder] + [getattr(self, "qInput%d" % t) for t in range(len(self.backbone_net.blocks))]
         return [p for m in mods for p in m.parameters()]
 
+    def unused_parameters(self):
+        """Parameters the reference constructs but never calls: QueryEncoder.textualAttention (language_module.py:16,65-74;
+        6.3 M of them).  Their .grad stays None, so in the reference clip_grad_norm_ and Adam.step never touch them
+        (main.py:140,238-243: both skip parameters without a gradient).  `learned_parameters` leaves them out of the flat
+        gradient buckets -- same semantics, but no zero gradients to all-reduce and no Adam pass over zero moments."""
+        return list(self.query_encoder.textualAttention.parameters())
+
+    def learned_parameters(self):
+        """What an optimizer should hold: every parameter with requires_grad that the forward pass can reach."""
+        dead = set(id(p) for p in self.unused_parameters())
+        return [p for p in self.parameters() if p.requires_grad and id(p) not in dead]
+
     def input_parameters(self):
         """prop_fc + position_transform: the input stage (main_model.py:33-34,51-59)."""
         return list(self.prop_fc.parameters()) + list(self.position_transform.parameters())

@@ -23,17 +23,20 @@ from .metrics import PostProcessRunner, results_entry
 
 
 def stage_plan(model, stage, lr):
-    """(learned parameters, lr, default n_epoch, loss selector) per main.py:124-138.  Mutates requires_grad in stage 1."""
+    """(learned parameters, lr, default n_epoch, loss selector) per main.py:124-138.  Mutates requires_grad in stage 1.
+    Parameters the forward pass never reaches (mainModel.unused_parameters: the reference's dead TextualAttention) are left out:
+    their gradient is None in the reference, where clip_grad_norm_ and Adam skip them -- same result, nothing to exchange/update."""
+    dead = set(id(p) for p in model.unused_parameters()) if hasattr(model, "unused_parameters") else set()
     if stage == 1:
         for name, p in model.named_parameters():
             if "iou_scores" in name or "mix_fc" in name:
                 p.requires_grad = False
-        return [p for p in model.parameters() if p.requires_grad], lr, 10, "sum"
+        return [p for p in model.parameters() if p.requires_grad and id(p) not in dead], lr, 10, "sum"
     if stage == 2:
         head = model.fcos.head
         return list(head.iou_scores.parameters()) + list(head.mix_fc.parameters()), lr / 100, None, "loss_iou"
     if stage == 3:
-        return list(model.parameters()), lr / 10000, None, "sum"
+        return [p for p in model.parameters() if id(p) not in dead], lr / 10000, None, "sum"
     raise ValueError("stage must be 1, 2 or 3")
 
 
