@@ -42,6 +42,7 @@ struct GemmParams {
   int xcd_swizzle;
   int ksplit;       // > 1: gridDim.y splits of the K loop; partial tiles are exchanged through `ws` and summed by the
                     // LAST-ARRIVING split of each tile, which then runs the epilogue (single group only)
+  int nblocks;      // gridDim.x (the XCD-aware tile order needs it; read from here it arrives with the one descriptor fetch)
   float* ws;        // [tiles][ksplit][TM*TN] fp32, accumulator-native order (one 16-byte piece per thread and MFMA tile)
   int* counters;    // [tiles] arrival counters, zero on entry, re-armed by the last arriver
   GemmProb p[DRN_MAX_GROUPS];
@@ -86,25 +87,67 @@ template <> struct Mma<float> {
   }
 };
 
-// Workgroup -> (group, tile row, tile column).
+// The launch descriptor (GemmParams, 576 bytes of kernel arguments) is fetched by the LANES in one memory trip -- lane i takes
+// dword i of the header and of each group's GemmProb -- and handed to the scalar unit with v_readlane.  Left to the compiler the
+// fields arrive through a chain of ~8 DEPENDENT scalar loads (group lookup, then fields as they are first used, each behind its own
+// s_waitcnt), and the scalar cache starts every kernel cold: 1.6-2.0 us before a workgroup issued its first operand load
+// (-DDRN_NT_PHASES), in every one of the ~25 launches of a step.
+constexpr int NT_HDR_DW = (int)offsetof(GemmParams, p) / 4;
+constexpr int NT_PROB_DW = (int)sizeof(GemmProb) / 4;
+static_assert(NT_HDR_DW <= 64 && NT_PROB_DW <= 64 && sizeof(GemmProb) % 4 == 0 && offsetof(GemmParams, p) % 4 == 0, "one lane per dword");
+struct NtHeader {
+  int ngroups, xcd_swizzle, ksplit, nblocks;
+  float* ws;
+  int* counters;
+};
+__device__ __forceinline__ unsigned nt_rl(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ void nt_fetch(const GemmParams& P, NtHeader& H, GemmProb& pr, int& g_out, int bid_for_group) {
+  const unsigned* kp = (const unsigned*)&P;
+  const int l = threadIdx.x & 63;
+  const unsigned hv = kp[l < NT_HDR_DW ? l : 0];
+  unsigned gv[DRN_MAX_GROUPS];
+#pragma unroll
+  for (int i = 0; i < DRN_MAX_GROUPS; ++i) gv[i] = kp[NT_HDR_DW + i * NT_PROB_DW + (l < NT_PROB_DW ? l : 0)];
+  __builtin_amdgcn_sched_barrier(0);            // all five loads are in flight before the first v_readlane waits for one
+  H.ngroups = (int)nt_rl(hv, (int)offsetof(GemmParams, ngroups) / 4);
+  H.xcd_swizzle = (int)nt_rl(hv, (int)offsetof(GemmParams, xcd_swizzle) / 4);
+  H.ksplit = (int)nt_rl(hv, (int)offsetof(GemmParams, ksplit) / 4);
+  H.nblocks = (int)nt_rl(hv, (int)offsetof(GemmParams, nblocks) / 4);
+  H.ws = (float*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, ws) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, ws) / 4));
+  H.counters = (int*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, counters) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, counters) / 4));
+  int bid = bid_for_group;
+  if (H.xcd_swizzle) {
+    const int nb = H.nblocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  int g = 0;
+  unsigned sel = gv[0];
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < H.ngroups && bid >= (int)nt_rl(gv[i], (int)offsetof(GemmProb, tile_start) / 4)) {
+      g = i;
+      sel = gv[i];
+    }
+  unsigned* q = (unsigned*)&pr;
+#pragma unroll
+  for (int i = 0; i < NT_PROB_DW; ++i) q[i] = nt_rl(sel, i);
+  g_out = g;
+}
+
+// Workgroup -> (tile row, tile column) inside its group.
 template <int TM>
-__device__ __forceinline__ void nt_locate(const GemmParams& P, int& g_out, int& tm_out, int& tn_out) {
+__device__ __forceinline__ void nt_locate(const NtHeader& H, const GemmProb& pr, int& tm_out, int& tn_out) {
   // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness), so give each
   // XCD a CONTIGUOUS run of logical tiles (same A row-panels, all B column-panels) instead of every 8th one -- the A panel
   // of a tile row is then fetched into one L2 instead of eight.  Bijective for any grid size.
   int bid = blockIdx.x;
-  if (P.xcd_swizzle) {
-    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+  if (H.xcd_swizzle) {
+    const int nb = H.nblocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  int g = 0;
-#pragma unroll
-  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
-    if (i < P.ngroups && bid >= P.p[i].tile_start) g = i;
-  const GemmProb& pr = P.p[g];
   const int t_local = bid - pr.tile_start;
   int tm = t_local / pr.tiles_n, tn = t_local - tm * pr.tiles_n;
-  if (P.xcd_swizzle & 2) {
+  if (H.xcd_swizzle & 2) {
     // grouped order: walk 8 tile rows down one tile column before moving to the next column, so the ~32 tiles an XCD runs
     // at a time form an 8 x 4 block (each A panel shared by 4 workgroups, each B panel by 8) instead of 2 x 16
     const int tiles_m = (pr.M + TM - 1) / TM;
@@ -116,7 +159,6 @@ __device__ __forceinline__ void nt_locate(const GemmParams& P, int& g_out, int& 
     tm = first_m + r % gsm;
     tn = r / gsm;
   }
-  g_out = g;
   tm_out = tm;
   tn_out = tn;
 }
@@ -124,7 +166,7 @@ __device__ __forceinline__ void nt_locate(const GemmParams& P, int& g_out, int& 
 // Epilogue shared by the NT kernels.  acc[mi][ni][r]: m = wr*MI*16 + mi*16 + (l>>4)*4 + r, n = wc*NI*16 + ni*16 + (l&15).
 // Enter after a workgroup barrier that follows the last LDS read of the main loop (it reuses `smem`).
 template <typename T, int WM, int WN, int MI, int NI>
-__device__ __forceinline__ void nt_epilogue(const GemmParams& P, const GemmProb& pr, f32x4 (&acc)[MI][NI], char* smem,
+__device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& pr, f32x4 (&acc)[MI][NI], char* smem,
                                             const int m0, const int n0, const int tm) {
   constexpr int NW = WM * WN, TM = WM * MI * 16, TN = WN * NI * 16;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -364,7 +406,7 @@ extern "C" int drn_debug_nt_phases(long long* out, int n) { return (int)hipMemcp
 //   <2,4,8,4>: 256x256, 8 waves (2 per SIMD), 64 KB/stage, 2 stages               -- large GEMMs: half the operand
 //              traffic and half the global_load_lds / ds_read per MFMA
 template <typename T, int STAGES, bool FAST, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 : 1))) void conv_gemm_nt_kernel(const GemmParams P) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 : 1))) void conv_gemm_nt_kernel(const GemmParams P_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 8 * CH;               // elements per K-step (128 bytes)
@@ -379,9 +421,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 2 : (STAGES <= 2 ? 2 
   const int w = (WM * WN == 8 && !getenv_free_scalar_w) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
   NT_PHASE(0);
 
+  NtHeader P;
+  GemmProb pr;
   int g, tm, tn;
-  nt_locate<TM>(P, g, tm, tn);
-  const GemmProb& pr = P.p[g];
+  nt_fetch(P_arg, P, pr, g, blockIdx.x);
+  nt_locate<TM>(P, pr, tm, tn);
   const int m0 = tm * TM, n0 = tn * TN;
   const int M = pr.M, N = pr.N, K = pr.K, Cin = pr.Cin, taps = pr.taps;
   const int stride = pr.stride, pad = pr.pad, mode = pr.mode, Lsrc = pr.Lsrc;
@@ -698,6 +742,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     attr_set = true;
   }
 #define NT_LAUNCH(TT, SS, THREADS, LDS, ...) do { \
+    P.nblocks = total; \
     if (fast) conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); \
     else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
   if (tile == 256) {
