@@ -5,7 +5,8 @@ backward are sequences of libdrn_hip.so launches (drn_amd/ops.py) on torch's cur
 Activations are channels-last ("NLC", shape (B, L, C), C contiguous, row stride may exceed C for
 column slices of a wider buffer) in the compute dtype (float32 = exact-f32 MFMA parity mode,
 bfloat16 = storage with fp32 accumulation).  Parameters stay fp32; their GEMM-layout copies (`packed`, `stacked`,
-`stacked_t`) are cached and refreshed in one launch after the optimizer step (`repack_all`).
+`stacked_t`) live in the `WeightCopies` store of the model that owns the parameters (`mainModel.weight_copies`; a shared default
+for stand-alone layers) and are refreshed by the optimizer kernels / in one launch after the optimizer step (`repack_all`).
 """
 import os
 import weakref
@@ -15,31 +16,66 @@ import torch
 from . import ops
 from ._lib import DrnError
 
-_pack_cache = {}
-_weights_epoch = 0
-_cache_gen = 0          # bumped whenever a weight-copy cache gains or loses an entry (drn_amd.optim re-reads them only then)
+class WeightCopies(object):
+    """The re-laid GEMM copies of ONE model's parameters (what `packed`, `stacked`, `stacked_t` and the stacked conv operands
+    hand out), their validity stamps and the two counters the fused optimizer watches.  drn_amd.model.mainModel owns one and
+    tags its parameters with it (`p._drn_store`), so the copies live and die with the model; parameters that belong to no model
+    (stand-alone layers, tests) share `_default_store`.  Entries are only ever dropped when their parameter is gone: a copy of a
+    live parameter may be referenced by raw pointer from a launch descriptor being assembled or from a captured hipGraph."""
+
+    _live = []                                   # weak references to every store (module-level helpers walk them)
+
+    def __init__(self):
+        self.pack, self.pstack, self.stack, self.shape_stack = {}, {}, {}, {}
+        self.epoch = 0                           # bumped by optimizers that update parameters through raw pointers
+        self.gen = 0                             # bumped whenever an entry comes or goes (drn_amd.optim re-reads the tables only then)
+        WeightCopies._live.append(weakref.ref(self))
+
+    def bump_gen(self):
+        self.gen += 1
+
+    def bump_epoch(self):
+        self.epoch += 1
+
+    def adopt(self, module):
+        """Tag every parameter of `module` with this store (call again after parameters were replaced)."""
+        for p in module.parameters():
+            p._drn_store = self
+        return self
+
+    def purge_dead(self, cache, limit, refs_of):
+        """Bound a cache by dropping the entries of parameters that no longer exist -- and ONLY those."""
+        if len(cache) > limit:
+            for k in [k for k, e in cache.items() if any(r() is None for r in refs_of(e))]:
+                del cache[k]
+            self.bump_gen()
 
 
-def _bump_cache_gen():
-    global _cache_gen
-    _cache_gen += 1
+_default_store = WeightCopies()
 
 
+def store_of(params):
+    """The WeightCopies of a parameter (or of the first of a list): its model's, or the shared default."""
+    p = params[0] if isinstance(params, (list, tuple)) else params
+    return getattr(p, "_drn_store", None) or _default_store
 
-def bump_weights_epoch():
-    """Invalidate every cached re-laid weight (called by optimizers that update parameters through raw pointers)."""
-    global _weights_epoch
-    _weights_epoch += 1
+
+def all_stores():
+    live = [r() for r in WeightCopies._live]
+    WeightCopies._live[:] = [weakref.ref(st) for st in live if st is not None]
+    return [st for st in live if st is not None]
 
 
-def _purge_dead(cache, limit, refs_of):
-    """Bound a weight-copy cache by dropping the entries of parameters that no longer exist -- and ONLY those: a copy of a
-    live parameter may be referenced by raw pointer from a launch descriptor being assembled right now (the levels of a
-    grouped launch are packed one after the other) or from a captured hipGraph, so it is never evicted."""
-    if len(cache) > limit:
-        for k in [k for k, e in cache.items() if any(r() is None for r in refs_of(e))]:
-            del cache[k]
-        _bump_cache_gen()
+def cache_generation(stores=None):
+    """Sum of the entry counters of the given stores (all live ones by default): changes whenever a copy comes or goes."""
+    return sum(st.gen for st in (all_stores() if stores is None else stores))
+
+
+def bump_weights_epoch(stores=None):
+    """Invalidate every cached re-laid weight of the given stores (all by default): called by optimizers that update parameters
+    through raw pointers, behind autograd's version counters."""
+    for st in (all_stores() if stores is None else stores):
+        st.bump_epoch()
 
 
 def _w3(w):
@@ -59,21 +95,19 @@ def packed(w, perm, code):
         # temporaries may reuse an address with version 0: never cache them
         out = ops.pack_weight(_w3(w), perm, code)
         return out.view(out.shape[0], -1) if two_d else out
+    S = store_of(w)
     key = (id(w), w.data_ptr(), perm, code)
-    ver = (w._version, _weights_epoch)
-    hit = _pack_cache.get(key)
+    ver = (w._version, S.epoch)
+    hit = S.pack.get(key)
     # the weakref guards against a new Parameter re-using a dead one's id / address / version
     if hit is not None and hit[0] == ver and hit[2]() is w and hit[1].device == w.device:
         out = hit[1]
     else:
         out = ops.pack_weight(_w3(w), perm, code)
-        _purge_dead(_pack_cache, 256, lambda e: (e[2],))
-        _pack_cache[key] = (ver, out, weakref.ref(w))
-        _bump_cache_gen()
+        S.purge_dead(S.pack, 256, lambda e: (e[2],))
+        S.pack[key] = (ver, out, weakref.ref(w))
+        S.bump_gen()
     return out.view(out.shape[0], -1) if two_d else out
-
-
-_pstack_cache = {}
 
 
 def _pstack_items(out, params, perm):
@@ -88,9 +122,10 @@ def _pstack_items(out, params, perm):
 
 
 def _packed_stack(params, perm, code):
+    S = store_of(params)
     key = (tuple((id(p), p.data_ptr()) for p in params), perm, code)
-    ver = (tuple(p._version for p in params), _weights_epoch)
-    hit = _pstack_cache.get(key)
+    ver = (tuple(p._version for p in params), S.epoch)
+    hit = S.pstack.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == params[0].device and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     total = sum(p.shape[0] for p in params)
@@ -99,13 +134,10 @@ def _packed_stack(params, perm, code):
     out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
         torch.empty(shape, dtype=ops.TORCH_DT[code], device=params[0].device)
     ops.pack_weights_into(_pstack_items(out, params, perm), code)
-    _purge_dead(_pstack_cache, 64, lambda e: e[2])
-    _bump_cache_gen()
-    _pstack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
+    S.purge_dead(S.pstack, 64, lambda e: e[2])
+    S.bump_gen()
+    S.pstack[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
-
-
-_stack_cache = {}
 
 
 def _stack_items(out, params):
@@ -123,35 +155,34 @@ def stacked(params):
     """fp32 concatenation along dim 0 of several parameters (e.g. the three qInput{t} weights, W_ih of both LSTM
     directions) so that one GEMM serves them all; built by one drn_pack_weights launch, cached on the parameter versions
     and refreshed in place by repack_all().  Not differentiable: callers compute the per-parameter gradients themselves."""
+    S = store_of(params)
     key = tuple((id(p), p.data_ptr()) for p in params)
-    ver = (tuple(p._version for p in params), _weights_epoch)
-    hit = _stack_cache.get(key)
+    ver = (tuple(p._version for p in params), S.epoch)
+    hit = S.stack.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == params[0].device and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     shape = (sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:])
     out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
         torch.empty(shape, dtype=torch.float32, device=params[0].device)
     ops.pack_weights_into(_stack_items(out, params), ops.F32)
-    _purge_dead(_stack_cache, 64, lambda e: e[2])
-    _bump_cache_gen()
-    _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
+    S.purge_dead(S.stack, 64, lambda e: e[2])
+    S.bump_gen()
+    S.stack[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
-
-
-_shape_stack_cache = {}
 
 
 def _shape_only_stack(params):
     """A buffer with the shape of cat(params, dim 0) whose CONTENTS are never read: the stacked conv weight of the two towers
     only carries its shape and its sources through autograd (the kernels read the re-laid copies `packed` builds from the
     sources), so it is neither filled nor refreshed after optimizer steps."""
+    S = store_of(params)
     key = tuple((id(p), p.data_ptr()) for p in params)
-    hit = _shape_stack_cache.get(key)
+    hit = S.shape_stack.get(key)
     if hit is not None and all(r() is p for r, p in zip(hit[1], params)) and hit[0].device == params[0].device:
         return hit[0]
     out = torch.empty((sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:]), dtype=torch.float32, device=params[0].device)
-    _purge_dead(_shape_stack_cache, 64, lambda e: e[1])
-    _shape_stack_cache[key] = (out, [weakref.ref(p) for p in params])
+    S.purge_dead(S.shape_stack, 64, lambda e: e[1])
+    S.shape_stack[key] = (out, [weakref.ref(p) for p in params])
     return out
 
 
@@ -195,35 +226,38 @@ def _stack_t_items(out, params):
 def stacked_t(params):
     """[W_0^T | W_1^T | ...] for Linear weights W_i (N_i, K): a (K, sum N_i) fp32 matrix, so that the input gradient
     dX = [dY_0 | dY_1 | ...] [W_0; W_1; ...] is one NT product.  Cached / refreshed like `stacked`."""
+    S = store_of(params)
     key = ("t",) + tuple((id(p), p.data_ptr()) for p in params)
-    ver = (tuple(p._version for p in params), _weights_epoch)
-    hit = _stack_cache.get(key)
+    ver = (tuple(p._version for p in params), S.epoch)
+    hit = S.stack.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == params[0].device and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     shape = (params[0].shape[1], sum(p.shape[0] for p in params))
     out = hit[1] if hit is not None and hit[1].shape == shape and hit[1].device == params[0].device else \
         torch.empty(shape, dtype=torch.float32, device=params[0].device)
     ops.pack_weights_into(_stack_t_items(out, params), ops.F32)
-    _purge_dead(_stack_cache, 64, lambda e: e[2])
-    _bump_cache_gen()
-    _stack_cache[key] = (ver, out, [weakref.ref(p) for p in params])
+    S.purge_dead(S.stack, 64, lambda e: e[2])
+    S.bump_gen()
+    S.stack[key] = (ver, out, [weakref.ref(p) for p in params])
     return out
 
 
-def identity_bf16_copies():
+def identity_bf16_copies(stores=None):
     """{parameter data_ptr: (cache key, bf16 copy)} for cached GEMM operands that keep the parameter's element order (Linear
-    weights, 1x1 convs in the forward layout): the fused optimizer rewrites those itself while it has the value in registers."""
+    weights, 1x1 convs in the forward layout): the fused optimizer rewrites those itself while it has the value in registers.
+    stores: the WeightCopies to look in (all live ones by default)."""
     out = {}
-    for key, (ver, buf, ref) in _pack_cache.items():
-        w = ref()
-        if w is None or key[3] != ops.BF16 or key[2] != (0, 2, 1) or w.data_ptr() != key[1]:
-            continue
-        if w.dim() == 2 or w.shape[2] == 1:
-            out[w.data_ptr()] = (key, buf)
+    for S in (all_stores() if stores is None else stores):
+        for key, (ver, buf, ref) in S.pack.items():
+            w = ref()
+            if w is None or key[3] != ops.BF16 or key[2] != (0, 2, 1) or w.data_ptr() != key[1]:
+                continue
+            if w.dim() == 2 or w.shape[2] == 1:
+                out[w.data_ptr()] = (key, buf)
     return out
 
 
-def relaid_copies():
+def relaid_copies(stores=None):
     """Every cached re-laid copy of a live parameter, as the fused optimizer needs it to write the copy itself while it holds
     the updated value (drn_adam_tiled): {parameter data_ptr: [dict(kind 1|2, base tensor, ld, code, k, skip key)]}.
     kind 1 = [r][tap][c] order (element (r, c, tap) at base[(r*k + tap)*ld + c]): forward conv / Linear operands, fp32 stacks;
@@ -235,7 +269,13 @@ def relaid_copies():
         out.setdefault(p.data_ptr(), []).append(dict(param=p, kind=kind, base=base, ld=ld, code=code, key=key,
                                                      k=p.shape[2] if p.dim() == 3 else 1))
 
-    for key, (ver, buf, ref) in _pack_cache.items():
+    for S in (all_stores() if stores is None else stores):
+        _relaid_of_store(S, add)
+    return out
+
+
+def _relaid_of_store(S, add):
+    for key, (ver, buf, ref) in S.pack.items():
         w = ref()
         if w is None or w.data_ptr() != key[1] or buf.device != w.device or w.dim() not in (2, 3):
             continue
@@ -244,7 +284,7 @@ def relaid_copies():
             add(w, 1, buf, Cin, key[3], ("pack", key))
         elif key[2] == (1, 2, 0):
             add(w, 2, buf, Cout, key[3], ("pack", key))
-    for key, (ver, buf, refs) in _pstack_cache.items():
+    for key, (ver, buf, refs) in S.pstack.items():
         ps = [r() for r in refs]
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key[0]:
             continue
@@ -256,7 +296,7 @@ def relaid_copies():
             elif key[1] == (1, 2, 0):
                 add(p, 2, buf[:, :, o:o + n], total, key[2], ("pstack", key))
             o += n
-    for key, (ver, buf, refs) in _stack_cache.items():
+    for key, (ver, buf, refs) in S.stack.items():
         ps = [r() for r in refs]
         transposed = key[0] == "t"
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != (key[1:] if transposed else key):
@@ -271,60 +311,64 @@ def relaid_copies():
             for p in ps:                                     # rows [r, r+n) of the stack = p itself
                 add(p, 1, buf[r:r + p.shape[0]], p.shape[1] if p.dim() == 2 else p.shape[0], ops.F32, ("stack", key))
                 r += p.shape[0]
-    return out
 
 
-def repack_all(skip=(), codes=None, updated=None):
+def repack_all(skip=(), codes=None, updated=None, stores=None):
     """Refresh every cached re-laid weight IN PLACE with one launch per dtype (drn_pack_weights) and mark it current:
     an optimizer that has just updated all parameters calls this instead of leaving ~20 small per-use launches to
     the next forward pass.  The copies keep their addresses, so captured hipGraphs stay valid.  `skip`: cache keys the
     caller has already refreshed itself (identity_bf16_copies).  `codes`: only the copies of these dtypes (ops.F32 holds
     the query side's stacks, ops.BF16 the conv / linear operands of a bf16 model) -- the rest stay stale until their call.
     `updated`: data_ptrs of the parameters the caller has changed; copies of all other parameters (frozen ones: mix_fc and
-    iou_scores in stage 1) are still valid and only marked current."""
+    iou_scores in stage 1) are still valid and only marked current.  `stores`: the WeightCopies to refresh (all live ones by default)."""
+    for S in (all_stores() if stores is None else stores):
+        _repack_store(S, skip, codes, updated)
+
+
+def _repack_store(S, skip, codes, updated):
     want = lambda code: codes is None or code in codes
     same = lambda ps: updated is not None and not any(p.data_ptr() in updated for p in ps)
     by_code = {}
-    for key, (ver, out, ref) in list(_pack_cache.items()):
+    for key, (ver, out, ref) in list(S.pack.items()):
         w = ref()
         if w is None or w.data_ptr() != key[1] or out.device != w.device:
-            del _pack_cache[key]
-            _bump_cache_gen()
+            del S.pack[key]
+            S.bump_gen()
             continue
         if not want(key[3]):
             continue
         # (a copy somebody else refreshed / an untouched parameter's copy is only marked current -- unless the parameter was
         # modified in place since the copy was built (load_state_dict, copy_): then it is repacked like the rest)
         if (key in skip or ("pack", key) in skip or same([w])) and ver[0] == w._version:
-            _pack_cache[key] = ((w._version, _weights_epoch), out, ref)
+            S.pack[key] = ((w._version, S.epoch), out, ref)
             continue
         by_code.setdefault(key[3], []).append((key, w, out))
-    for key, (ver, out, refs) in list(_pstack_cache.items()):
+    for key, (ver, out, refs) in list(S.pstack.items()):
         ps = [r() for r in refs]
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != key[0] or out.device != ps[0].device:
-            del _pstack_cache[key]
-            _bump_cache_gen()
+            del S.pstack[key]
+            S.bump_gen()
             continue
         if not want(key[2]):
             continue
         if (("pstack", key) not in skip and not same(ps)) or ver[0] != tuple(p._version for p in ps):
             by_code.setdefault(key[2], [])
             by_code.setdefault(("stack", key[2]), []).extend(_pstack_items(out, ps, key[1]))
-        _pstack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
+        S.pstack[key] = ((tuple(p._version for p in ps), S.epoch), out, refs)
     stack_items = []
-    for key, (ver, out, refs) in list(_stack_cache.items()):
+    for key, (ver, out, refs) in list(S.stack.items()):
         ps = [r() for r in refs]
         transposed = key[0] == "t"
         if any(p is None for p in ps) or tuple((id(p), p.data_ptr()) for p in ps) != (key[1:] if transposed else key) \
                 or out.device != ps[0].device:
-            del _stack_cache[key]
-            _bump_cache_gen()
+            del S.stack[key]
+            S.bump_gen()
             continue
         if not want(ops.F32):
             continue
         if (("stack", key) not in skip and not same(ps)) or ver[0] != tuple(p._version for p in ps):
             stack_items += _stack_t_items(out, ps) if transposed else _stack_items(out, ps)
-        _stack_cache[key] = ((tuple(p._version for p in ps), _weights_epoch), out, refs)
+        S.stack[key] = ((tuple(p._version for p in ps), S.epoch), out, refs)
     for code, items in by_code.items():
         if isinstance(code, tuple):
             continue
@@ -332,7 +376,7 @@ def repack_all(skip=(), codes=None, updated=None):
         if items or extra:
             ops.pack_weights_into([(_w3(w), key[2], out) for key, w, out in items] + extra, code)
         for key, w, out in items:
-            _pack_cache[key] = ((w._version, _weights_epoch), out, weakref.ref(w))
+            S.pack[key] = ((w._version, S.epoch), out, weakref.ref(w))
     if stack_items and ops.F32 not in by_code:
         ops.pack_weights_into(stack_items, ops.F32)
 

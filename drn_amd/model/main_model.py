@@ -37,6 +37,9 @@ class mainModel(nn.Module):
             setattr(self, "qInput%d" % t, nn.Linear(1024, self.feature_dim if t == 0 else channels_list[t - 1][1]))
         self.set_compute_dtype(compute_dtype)
         self.taps = None      # set to a dict to record intermediate activations (tests / debugging)
+        # the re-laid GEMM copies of this model's weights live in a store the model owns (not in process-wide tables): they
+        # die with the model, and an optimizer only looks at / refreshes the copies of the model it trains
+        self.weight_copies = DF.WeightCopies().adopt(self)
 
     def set_compute_dtype(self, dtype):
         """torch.float32: exact-f32 MFMA (<=1e-4 parity with the reference); torch.bfloat16: bf16 storage + fp32 accumulate."""

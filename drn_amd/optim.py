@@ -53,6 +53,13 @@ class FusedAdam(object):
 
         self._ptr_sig = tuple(p.data_ptr() for b in reducer.buckets for p in b.params)
         self._updated = frozenset(self._ptr_sig)
+        # the weight-copy stores of the parameters this optimizer updates (one per model: drn_amd.functional.WeightCopies)
+        self.stores = []
+        for b in reducer.buckets:
+            for p in b.params:
+                st = DF.store_of(p)
+                if not any(st is x for x in self.stores):
+                    self.stores.append(st)
 
     def _check_ptrs(self):
         """The kernels reach the parameters through raw pointers baked into device tables: refuse to step if a parameter's
@@ -87,13 +94,13 @@ class FusedAdam(object):
                                        P(self.step_counter), ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
                                        ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps), ctypes.c_float(self.max_norm),
                                        ctypes.c_float(self.grad_scale), s), "drn_adam_tiled")
-        DF.bump_weights_epoch()       # parameters changed behind autograd's version counters
+        DF.bump_weights_epoch(self.stores)       # parameters changed behind autograd's version counters
         if repack:
             self.repack()
 
     def repack(self, codes=None):
         """Refresh the other GEMM-layout copies of the weights (one launch per dtype; `codes`: only these dtypes)."""
-        DF.repack_all(skip=self._mirror_keys, codes=codes, updated=self._updated)
+        DF.repack_all(skip=self._mirror_keys, codes=codes, updated=self._updated, stores=self.stores)
 
     def _refresh_mirrors(self):
         """Device tables of the cached GEMM operands the optimizer kernels rewrite themselves while they hold the new value:
@@ -104,11 +111,11 @@ class FusedAdam(object):
             which writes up to one copy of each orientation per parameter.
         Rebuilt only when the set of cached copies changes, and never while a hipGraph is being captured (the table upload is
         a host->device copy): copies that appear later are simply left to repack_all()."""
-        if DF._cache_gen == getattr(self, "_seen_gen", None) or torch.cuda.is_current_stream_capturing():
+        if DF.cache_generation(self.stores) == getattr(self, "_seen_gen", None) or torch.cuda.is_current_stream_capturing():
             return                                   # no cache entry came or went since the tables were built
-        gen = DF._cache_gen
-        copies = DF.identity_bf16_copies()
-        relaid = DF.relaid_copies() if self.tiled else {}
+        gen = DF.cache_generation(self.stores)
+        copies = DF.identity_bf16_copies(self.stores)
+        relaid = DF.relaid_copies(self.stores) if self.tiled else {}
         sig = (tuple(sorted((ptr, buf.data_ptr()) for ptr, (key, buf) in copies.items())),
                tuple(sorted((ptr, c["kind"], c["base"].data_ptr()) for ptr, lst in relaid.items() for c in lst)))
         if sig == self._mirror_sig:

@@ -307,7 +307,7 @@ def load_checkpoint(model, path, map_location="cpu"):
             picked[k] = v
     own.update(picked)
     model.load_state_dict(own)
-    DF.bump_weights_epoch()
+    DF.bump_weights_epoch([DF.store_of(next(model.parameters()))])
     return ckpt.get("epoch", 0), sorted(picked)
 
 
@@ -315,6 +315,6 @@ def init_glove(model, glove_weights):
     """main.py:92-94: copy the (vocab+1, 300) GloVe table into the embedding if the file exists."""
     if glove_weights and os.path.exists(glove_weights):
         model.query_encoder.embedding.weight.data.copy_(torch.load(glove_weights))
-        DF.bump_weights_epoch()
+        DF.bump_weights_epoch([DF.store_of(model.query_encoder.embedding.weight)])
         return True
     return False

@@ -81,3 +81,44 @@ def test_repack_all_refreshes_cached_weight_layouts_in_place(dt):
     assert again.data_ptr() == sptr and torch.equal(again, torch.cat([params[0].detach(), params[6].detach()]))
     again = DF.stacked_t([params[28]])
     assert again.data_ptr() == tptr and torch.equal(again, params[28].detach().t().contiguous())
+
+
+def test_weight_copies_belong_to_their_model():
+    """drn_amd.functional.WeightCopies: every mainModel owns the re-laid GEMM copies of its weights; an optimizer of model A
+    refreshes A's copies and never looks at B's (whose copies go stale only when B's own parameters change)."""
+    from drn_amd import functional as DF
+    from drn_amd import ops
+    from drn_amd.dist import GradReducer
+    from drn_amd.model import mainModel
+    from drn_amd.optim import FusedAdam
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict
+    dev = "cuda:0"
+    cfg = default_cfg("TINY", 64, 1)
+    ma, mb = (mainModel(VOCAB_SIZE, as_namespace(cfg), compute_dtype=torch.bfloat16) for _ in range(2))
+    for m in (ma, mb):
+        m.load_state_dict(seeded_state_dict(m, 0))
+        m.to(dev)
+    assert ma.weight_copies is not mb.weight_copies and DF.store_of(ma.prop_fc.weight) is ma.weight_copies
+    wa, wb = ma.backbone_net.forward_conv1[0].weight, mb.backbone_net.forward_conv1[0].weight
+    ca, cb = DF.packed(wa, (0, 2, 1), ops.BF16), DF.packed(wb, (0, 2, 1), ops.BF16)
+    assert len(ma.weight_copies.pack) == 1 and len(mb.weight_copies.pack) == 1
+    gen_b = mb.weight_copies.gen
+    red = GradReducer(ma.learned_parameters(), world_size=1)
+    opt = FusedAdam(red, lr=1e-2, max_norm=0.0)
+    assert opt.stores == [ma.weight_copies]
+    red.zero()
+    for p in red.params:
+        p.grad = torch.randn_like(p)
+    red.finish()
+    opt.step()
+    torch.cuda.synchronize()
+    assert DF.packed(wa, (0, 2, 1), ops.BF16).data_ptr() == ca.data_ptr()            # refreshed in place
+    assert torch.equal(ca, wa.detach().permute(0, 2, 1).contiguous().to(torch.bfloat16))
+    assert mb.weight_copies.gen == gen_b and mb.weight_copies.epoch == 0               # B's store untouched
+    assert DF.packed(wb, (0, 2, 1), ops.BF16).data_ptr() == cb.data_ptr()
+    assert torch.equal(cb, wb.detach().permute(0, 2, 1).contiguous().to(torch.bfloat16))
+    red.remove()
+    del ma, opt, red
+    import gc
+    gc.collect()
+    assert all(st is not None for st in DF.all_stores())
