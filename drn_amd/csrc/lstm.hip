@@ -217,6 +217,7 @@ struct LstmBwdArgs {
   float* dgates;         // [L][B][2][4H] by time
   float* dc;             // [2][B][H]
   float* dh_pass;        // [2][B][H]  dL/dh that bypasses the cell at padded positions (in/out)
+  bf16_t* dgates16;      // optional: a bf16 copy of dgates, written by the cell backward and read by the bf16 step product (half the bytes)
   const float* dqvec;    // optional [B][4H]: gradient of the [first ; last] sentence vector, added to dout rows 0 and len_b-1 on load
   const long long* lengths;
   int B, L, H, s;
@@ -252,26 +253,37 @@ __device__ __forceinline__ LstmCellIn lstm_cell_bwd_load(const LstmBwdArgs& A, i
   return c;
 }
 __device__ __forceinline__ void lstm_cell_bwd_apply(const LstmBwdArgs& A, const LstmCellIn& c, int dir, int bb, int j, int s, float dh_in) {
+  // No FMA contraction in here: this function is inlined into TWO kernels (the first backward step and the epilogue of the step
+  // kernel), and which of them handles a given time step depends on how far the batch was padded (a padded query adds all-invalid
+  // steps in front).  With contraction left to the compiler the two copies once came out with different fused pairs -- gate
+  // gradients one ulp apart between the padded (hipGraph) and the unpadded (eager) trainer.
+#pragma clang fp contract(off)
   const int B = A.B, L = A.L, H = A.H;
   const int t = dir == 0 ? s : L - 1 - s;
   const long sidx = ((long)dir * B + bb) * H + j;
-  float* dg = A.dgates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+  const long gidx = (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+  float* dg = A.dgates + gidx;
   const float dh = dh_in + (c.valid ? c.dout : 0.f);
   const float dcn = c.dcn;
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
   if (c.valid) {
     const float ig = c.ig, fg = c.fg, gg = c.gg, og = c.og, cn = c.cn, cp = c.cp;
     const float tc = tanhf(cn);
     const float dcv = dcn + dh * og * (1.f - tc * tc);
-    dg[0] = dcv * gg * ig * (1.f - ig);
-    dg[H] = dcv * cp * fg * (1.f - fg);
-    dg[2 * H] = dcv * ig * (1.f - gg * gg);
-    dg[3 * H] = dh * tc * og * (1.f - og);
+    d0 = dcv * gg * ig * (1.f - ig);
+    d1 = dcv * cp * fg * (1.f - fg);
+    d2 = dcv * ig * (1.f - gg * gg);
+    d3 = dh * tc * og * (1.f - og);
     A.dc[sidx] = dcv * fg;
     A.dh_pass[sidx] = 0.f;
   } else {
-    dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
     A.dc[sidx] = dcn;
     A.dh_pass[sidx] = dh;
+  }
+  dg[0] = d0; dg[H] = d1; dg[2 * H] = d2; dg[3 * H] = d3;
+  if (A.dgates16) {
+    bf16_t* dg16 = A.dgates16 + gidx;
+    dg16[0] = (bf16_t)d0; dg16[H] = (bf16_t)d1; dg16[2 * H] = (bf16_t)d2; dg16[3 * H] = (bf16_t)d3;
   }
 }
 __device__ __forceinline__ void lstm_cell_bwd(const LstmBwdArgs& A, int dir, int bb, int j, int s, float dh_in) {
@@ -330,6 +342,23 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmB
   } else {
     const bf16_t* WT_ = (const bf16_t*)A.WhhT[dir];
     const int rc = (l >> 4) * 8;
+    if (A.dgates16) {                   // (uniform) gate gradients from their bf16 copy: 16 bytes per lane and K step instead of 32
+      const bf16_t* arow16 = A.dgates16 + ((long)t * B * 2 + dir) * K + (long)(bb_a < B ? bb_a : 0) * 2 * K;
+      for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 32 * KU) {
+        bf16x8 a[KU], b[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const int r = r0 + u * 32 + rc;
+          a[u] = *(const bf16x8*)(arow16 + r);
+          if (bb_a >= B)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[u][e] = (bf16_t)0.f;
+          b[u] = *(const bf16x8*)(WT_ + (long)(k0 + row) * K + r);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+      }
+    } else
     for (int r0 = w * kq; r0 < (w + 1) * kq; r0 += 32 * KU) {
       f32x4 alo[KU], ahi[KU];
       bf16x8 b[KU];
@@ -360,21 +389,22 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_bwd_kernel(const LstmB
 }
 
 extern "C" int drn_lstm_bwd_first(const float* dout, const float* gates, const float* cseq, float* dgates, float* dc, float* dh_pass,
-                                  const float* dqvec, const int64_t* lengths, int B, int L, int H, void* stream) {
+                                  const float* dqvec, void* dgates16, const int64_t* lengths, int B, int L, int H, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(dout && gates && cseq && dgates && dc && dh_pass && lengths, "drn_lstm_bwd_first: null pointer");
   DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0, "drn_lstm_bwd_first: need B<=64, H%%64==0");
   LstmBwdArgs A;
   memset(&A, 0, sizeof(A));
   A.dout = dout; A.gates = gates; A.cseq = cseq; A.dgates = dgates; A.dc = dc; A.dh_pass = dh_pass; A.dqvec = dqvec;
+  A.dgates16 = (bf16_t*)dgates16;
   A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = L - 1;
   lstm_bwd_first_kernel<<<cdiv(2 * B * H, 256), 256, 0, (hipStream_t)stream>>>(A);
   return drn_launch_status("drn_lstm_bwd_first");
 }
 
 extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const void* WhhT_f, const void* WhhT_r,
-                                 int w_dtype, float* dgates, float* dc, float* dh_pass, const float* dqvec, const int64_t* lengths, int B, int L,
-                                 int H, int s, void* stream_) {
+                                 int w_dtype, float* dgates, float* dc, float* dh_pass, const float* dqvec, void* dgates16, const int64_t* lengths,
+                                 int B, int L, int H, int s, void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(dout && gates && cseq && WhhT_f && WhhT_r && dgates && dc && dh_pass && lengths, "drn_lstm_step_bwd: null pointer");
@@ -382,7 +412,8 @@ extern "C" int drn_lstm_step_bwd(const float* dout, const float* gates, const fl
   LstmBwdArgs A;
   memset(&A, 0, sizeof(A));
   A.dout = dout; A.gates = gates; A.cseq = cseq; A.WhhT[0] = WhhT_f; A.WhhT[1] = WhhT_r; A.dgates = dgates; A.dc = dc;
-  A.dh_pass = dh_pass; A.dqvec = dqvec; A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
+  A.dh_pass = dh_pass; A.dqvec = dqvec; A.dgates16 = (bf16_t*)dgates16;
+  A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
   DRN_CHECK_ARG(w_dtype == DRN_F32 || (w_dtype == DRN_BF16 && H % 128 == 0), "drn_lstm_step_bwd: bf16 weights need H %% 128 == 0");
   dim3 grid(H / 16, 2, cdiv(B, 16));
   if (w_dtype == DRN_BF16) {

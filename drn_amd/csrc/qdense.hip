@@ -283,8 +283,12 @@ struct OwGroupArgs {
 // LDS (row pitch 80 floats: the four row groups of an MFMA operand read land on disjoint bank quarters) and the next
 // slab's loads are already in flight while the current one feeds the MFMAs -- operand loads straight in MFMA layout (4 B per
 // lane, every panel re-read by each wave) held this kernel to ~1.2 TB/s of L2 traffic.
+// LOWP (the bf16 model): the staged fp32 slabs are rounded to bf16 as the MFMA operands are read and multiplied on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- 4 MFMAs per 32-row slab and wave instead of 32 exact-fp32 ones (the fp32
+// kernel is MFMA-bound on the LSTM weights, M = clips x words = 256 rows: ~14 of its 37 us); bias gradients stay exact fp32 sums.
 #define OW_MB 32
 #define OW_PITCH 80
+template <bool LOWP>
 __global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupArgs G) {
   __shared__ __attribute__((aligned(16))) float sm[2][OW_MB][OW_PITCH];   // one block: the epilogue re-uses all of it
   float (*Ys)[OW_PITCH] = sm[0], (*Xs)[OW_PITCH] = sm[1];
@@ -346,12 +350,31 @@ __global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupAr
           rx[h] = fetch(P.X, P.ldx, m0 + OW_MB + sr + 16 * h, k0 + sc, P.K, xvec);
         }
       }
+      if constexpr (LOWP) {
+        // lane group lq takes rows lq, lq + 4, ..., lq + 28 of the slab as its 8 k values (any assignment of k to lanes is fine as
+        // long as A and B agree; this one keeps the four groups on different LDS banks)
+        bf16x8 a8;
 #pragma unroll
-      for (int u = 0; u < OW_MB / 4; ++u) {
-        const float a = Ys[u * 4 + lq][w * 16 + li];
-        bsum += a;
+        for (int e = 0; e < 8; ++e) {
+          const float a = Ys[e * 4 + lq][w * 16 + li];
+          bsum += a;
+          a8[e] = (bf16_t)a;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[u * 4 + lq][j * 16 + li], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          bf16x8 b8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b8[e] = (bf16_t)Xs[e * 4 + lq][j * 16 + li];
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < OW_MB / 4; ++u) {
+          const float a = Ys[u * 4 + lq][w * 16 + li];
+          bsum += a;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[u * 4 + lq][j * 16 + li], acc[j], 0, 0, 0);
+        }
       }
     }
     // D: n = n0 + lq*4 + r, k = k0 + j*16 + li.  Each wave parks its 16 x 64 tile in LDS (the slabs are spent) and writes it
@@ -390,9 +413,10 @@ __global__ __launch_bounds__(QD_THREADS) void outer_wgrad_kernel(const OwGroupAr
   }
 }
 
-extern "C" int drn_outer_wgrad(const DrnOuterDesc* d, int n, void* stream) {
+extern "C" int drn_outer_wgrad(const DrnOuterDesc* d, int n, int dtype, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(d && n >= 1 && n <= DRN_QD_MAX, "drn_outer_wgrad: 1..%d problems", DRN_QD_MAX);
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_outer_wgrad: bad dtype %d", dtype);
   OwGroupArgs G;
   memset(&G, 0, sizeof(G));
   G.n = n;
@@ -407,6 +431,7 @@ extern "C" int drn_outer_wgrad(const DrnOuterDesc* d, int n, void* stream) {
     P.blk0 = blocks;
     blocks += cdiv(s.N, 64) * P.ntk;
   }
-  outer_wgrad_kernel<<<blocks, QD_THREADS, 0, (hipStream_t)stream>>>(G);
+  if (dtype == DRN_BF16) outer_wgrad_kernel<true><<<blocks, QD_THREADS, 0, (hipStream_t)stream>>>(G);
+  else outer_wgrad_kernel<false><<<blocks, QD_THREADS, 0, (hipStream_t)stream>>>(G);
   return drn_launch_status("drn_outer_wgrad");
 }

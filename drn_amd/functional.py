@@ -1309,9 +1309,11 @@ def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L, leaves, dqvec=N
     wtf, wtr = packed(w_hh_f, (1, 2, 0), wcode), packed(w_hh_r, (1, 2, 0), wcode)          # W_hh^T, cached
     dgates = torch.empty((L, B, 2, 4 * H), dtype=torch.float32, device=dev)
     scratch = torch.empty((2, 2, B, H), dtype=torch.float32, device=dev)
-    ops.lstm_bwd_first(dout, gates, cseq, dgates, scratch[0], scratch[1], lens, B, L, H, dqvec=dqvec)
+    # bf16 model: the cell backward also leaves a bf16 copy of the gate gradients for the next step's recurrent product
+    dg16 = torch.empty((L, B, 2, 4 * H), dtype=torch.bfloat16, device=dev) if wcode == ops.BF16 else None
+    ops.lstm_bwd_first(dout, gates, cseq, dgates, scratch[0], scratch[1], lens, B, L, H, dqvec=dqvec, dgates16=dg16)
     for s in range(L - 1, 0, -1):           # W_hh product of step s + cell backward of step s-1 in one launch
-        ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], lens, B, L, H, s, dqvec=dqvec)
+        ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], lens, B, L, H, s, dqvec=dqvec, dgates16=dg16)
     dg = dgates.view(L * B, 8 * H)
     hp = hprev.view(L * B, 2 * H)
     demb_tm = ops.skinny_rows(dg, stacked_t([w_ih_f, w_ih_r]))           # dg [W_f; W_r]: (L*B, E)
@@ -1378,7 +1380,7 @@ class _BiLSTMFn(torch.autograd.Function):
         leaves = []
         demb_tm, grads = _lstm_backward(dout.contiguous().float(), emb_tm, lens, ctx.lstm_params, ctx.saved_tensors[2:], B, L, leaves,
                                         lowp=ctx.lowp)
-        ops.outer_wgrad(leaves)
+        ops.outer_wgrad(leaves, lowp=ctx.lowp)
         return (None, demb_tm.view(L, B, E).transpose(0, 1), None) + grads
 
 
@@ -1481,7 +1483,7 @@ class _QueryEncoderFn(torch.autograd.Function):
         table = ctx.table
         dtable = grad_buffer(table)
         ops.qe_embed_bwd(tokens, demb_tm, dtable, B, L, E, table.shape[0], 0)      # nn.Embedding(padding_idx=0)
-        ops.outer_wgrad(leaves)                                                    # every weight / bias gradient of the node
+        ops.outer_wgrad(leaves, lowp=ctx.lowp)                                     # every weight / bias gradient of the node
         return (None, None, None, dtable) + lstm_grads + (dWq, dbq, dW[0], db[0], dW[1], db[1], dW[2], db[2], dwl, dbl) + gate_grads
 
 

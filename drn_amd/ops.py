@@ -284,9 +284,10 @@ def skinny_rows(X, W, bias=None):
     return Y
 
 
-def outer_wgrad(probs):
+def outer_wgrad(probs, lowp=False):
     """probs: list of dict(dY (M, N), X (M, K) or None, dW (N, K) or None, db=None, db2=None): dW = dY^T X, db = db2 = column
-    sums of dY, all problems in one launch per DRN_QD_MAX (drn_amd/csrc/qdense.hip)."""
+    sums of dY, all problems in one launch per DRN_QD_MAX (drn_amd/csrc/qdense.hip).  lowp (the bf16 model): operands rounded to
+    bf16 on their way into the MFMA, fp32 accumulation."""
     for c0 in range(0, len(probs), _lib.QD_MAX):
         chunk = probs[c0:c0 + _lib.QD_MAX]
         arr = (_lib.OuterDesc * len(chunk))()
@@ -299,7 +300,7 @@ def outer_wgrad(probs):
             if dW is not None:
                 assert X.stride(1) == 1 and X.shape[0] == dY.shape[0] and dW.stride(1) == 1 and dW.shape == (dY.shape[1], X.shape[1])
                 d.ldx, d.ldw, d.K = X.stride(0), dW.stride(0), X.shape[1]
-        check(lib().drn_outer_wgrad(arr, len(chunk), _stream()), "drn_outer_wgrad")
+        check(lib().drn_outer_wgrad(arr, len(chunk), BF16 if lowp else F32, _stream()), "drn_outer_wgrad")
 
 
 def skinny_ok(M, N, K):
@@ -549,15 +550,15 @@ def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens
           "drn_lstm_step_fwd")
 
 
-def lstm_bwd_first(dout, gates, cseq, dgates, dc, dh_pass, lens, B, L, H, dqvec=None):
-    check(lib().drn_lstm_bwd_first(_p(dout), _p(gates), _p(cseq), _p(dgates), _p(dc), _p(dh_pass), _p(dqvec), _p(lens), B, L, H,
+def lstm_bwd_first(dout, gates, cseq, dgates, dc, dh_pass, lens, B, L, H, dqvec=None, dgates16=None):
+    check(lib().drn_lstm_bwd_first(_p(dout), _p(gates), _p(cseq), _p(dgates), _p(dc), _p(dh_pass), _p(dqvec), _p(dgates16), _p(lens), B, L, H,
                                    _stream()), "drn_lstm_bwd_first")
 
 
-def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dc, dh_pass, lens, B, L, H, s, dqvec=None):
+def lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, dc, dh_pass, lens, B, L, H, s, dqvec=None, dgates16=None):
     assert wtf.dtype == wtr.dtype and wtf.is_contiguous() and wtr.is_contiguous()
     check(lib().drn_lstm_step_bwd(_p(dout), _p(gates), _p(cseq), _p(wtf), _p(wtr), BF16 if wtf.dtype == torch.bfloat16 else F32, _p(dgates), _p(dc), _p(dh_pass), _p(dqvec),
-                                  _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")
+                                  _p(dgates16), _p(lens), B, L, H, s, _stream()), "drn_lstm_step_bwd")
 
 
 def postprocess(levels, B, logits, reg, iou, thr, top_n, downsample):

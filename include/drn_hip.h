@@ -355,7 +355,8 @@ int drn_colsum_segs(const float* X, int ld, int M, const DrnColSeg* segs /*host*
  *   leaves them zero).
  * drn_outer_wgrad:  dW[N][K] = sum_m dY[m][N] * X[m][K] (row stride ldw), db[N] = db2[N] = sum_m dY[m][N] (optional):
  *   the weight / bias gradients of the same layers (M = clips, or clips x words for the LSTM weights).  A problem with
- *   dW == NULL only produces the column sums. */
+ *   dW == NULL only produces the column sums.  dtype DRN_F32: exact-fp32 MFMA; DRN_BF16 (the bf16 model): the fp32 operands are
+ *   rounded to bf16 as they enter the MFMA (fp32 accumulation, fp32 results; the column sums stay exact). */
 #define DRN_QD_MAX 16
 #define DRN_QD_COUNTERS 2048
 typedef struct DrnSkinnyDesc {
@@ -376,7 +377,7 @@ typedef struct DrnOuterDesc {
   float* db2; /* or NULL */
   int32_t ldy, ldx, ldw, M, N, K;
 } DrnOuterDesc;
-int drn_outer_wgrad(const DrnOuterDesc* descs /*host*/, int n, void* stream);
+int drn_outer_wgrad(const DrnOuterDesc* descs /*host*/, int n, int dtype, void* stream);
 
 /* ---- language-guided pooling (drn_amd/csrc/lgp.hip; model/LGP.py:29-51) ---------------------------------------
  * x (B, t, C) channels-last, qn (B, C) fp32 = BN(conv1x1(query)) prepared by the caller, out (B, t/2, C),
@@ -404,12 +405,14 @@ int drn_lstm_step_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, 
  * drn_lstm_step_bwd for s = L-1 .. 1 propagates through W_hh of step s (dgates[t(s)] x Whh) and applies the cell backward
  * of step s-1 in its epilogue (the recurrent dL/dh never goes to memory).  dgates is the operand of the weight-gradient
  * GEMMs; dc / dh_pass are [2][B][H] running state.  WhhT_* = Whh^T as [H][4H].  dqvec (optional, [B][4H]): gradient of the
- * sentence vector, added to dout rows 0 and len_b-1 as they are read (dout itself is not modified). */
+ * sentence vector, added to dout rows 0 and len_b-1 as they are read (dout itself is not modified).  dgates16 (optional, with
+ * w_dtype DRN_BF16): a bf16 buffer shaped like dgates; the cell backward writes a rounded copy of every gate gradient there and the
+ * recurrent product reads that copy (half the bytes) -- dgates itself stays fp32 for the weight / input-gradient products. */
 int drn_lstm_bwd_first(const float* dout, const float* gates, const float* cseq, float* dgates, float* dc, float* dh_pass,
-                       const float* dqvec, const int64_t* lengths, int B, int L, int H, void* stream);
+                       const float* dqvec, void* dgates16, const int64_t* lengths, int B, int L, int H, void* stream);
 int drn_lstm_step_bwd(const float* dout, const float* gates, const float* cseq, const void* WhhT_f, const void* WhhT_r, int w_dtype,
-                      float* dgates, float* dc, float* dh_pass, const float* dqvec, const int64_t* lengths, int B, int L, int H, int s,
-                      void* stream);
+                      float* dgates, float* dc, float* dh_pass, const float* dqvec, void* dgates16, const int64_t* lengths, int B, int L,
+                      int H, int s, void* stream);
 
 /* ---- fused clip_grad_norm_ + Adam over flat gradient buckets (drn_amd/csrc/optim.hip; main.py:140,238-243) ---- */
 int64_t drn_opt_nblocks(int64_t n); /* partial sums produced by drn_sumsq_partials for n elements */

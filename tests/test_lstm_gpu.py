@@ -106,3 +106,36 @@ def test_bf16_recurrent_weights_track_the_fp32_kernels(B, L, lens):
         assert rel(g16[k], g32[k]) <= 2e-2, (k, rel(g16[k], g32[k]))
     for b in range(B):                                                # padded positions stay exact zeros
         assert float(o16[b, lens[b]:].abs().max() if lens[b] < L else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("lowp", [False, True])
+def test_padded_time_steps_change_nothing(lowp):
+    """The hipGraph trainer pads queries to a fixed length, the eager one does not: extra all-invalid time steps must leave every
+    output BIT-identical (the cell backward is inlined into two kernels, and which one handles a step depends on the padding --
+    round 3 found them one ulp apart until FMA contraction was switched off in that function)."""
+    from drn_amd import functional as DF
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    B, E, H = 4, 300, 512
+    lens = torch.tensor([3, 2, 2, 1], dtype=torch.int64, device=dev)
+    mod = nn.LSTM(E, H, 1, batch_first=True, bidirectional=True).to(dev)
+    params = DF._lstm_param_list(mod)
+    x3 = torch.randn(3 * B, E, device=dev)
+    g = torch.Generator().manual_seed(1)
+    d3 = torch.randn(B, 3, 2 * H, generator=g).to(dev)
+    dqvec = torch.randn(B, 4 * H, generator=g).to(dev)
+    res = []
+    for L in (3, 4, 8):
+        emb = torch.zeros(L * B, E, device=dev)
+        emb[:3 * B] = x3
+        qvec = torch.empty(B, 4 * H, device=dev)
+        out, saved = DF._lstm_forward(emb, lens, params, B, L, qvec=qvec)
+        dout = torch.zeros(B, L, 2 * H, device=dev)
+        dout[:, :3] = d3
+        leaves = []
+        demb, _ = DF._lstm_backward(dout, emb, lens, params, saved, B, L, leaves, dqvec=dqvec, lowp=lowp)
+        res.append((out[:, :3].clone(), qvec.clone(), demb[:3 * B].clone(), leaves[0]["dY"][:3 * B].clone(), leaves[2]["dY"][:3 * B].clone()))
+        assert float(out[:, 3:].abs().max() if L > 3 else 0.0) == 0.0 and float(demb[3 * B:].abs().max() if L > 3 else 0.0) == 0.0
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a, b)

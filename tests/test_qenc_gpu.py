@@ -168,10 +168,13 @@ def test_skinny_group_ragged_and_masked():
     assert y.shape == (200, 4096)
 
 
-def test_outer_wgrad_group():
+@pytest.mark.parametrize("lowp", [False, True])
+def test_outer_wgrad_group(lowp):
     """drn_outer_wgrad: dW = dY^T X and db = db2 = column sums for a group of problems (M = 32 and M = 256 rows, K = 300,
-    column-sliced dY / X views, a bias-only problem) against fp64."""
+    column-sliced dY / X views, a bias-only problem) against fp64.  lowp (the bf16 model): the operands are rounded to bf16 on their
+    way into the MFMA (two roundings of 2^-9, fp32 accumulation over M <= 256 rows); the column sums stay exact."""
     from drn_amd import ops
+    tol_w = 2e-2 if lowp else 3e-6
     dev = "cuda:0"
     g = torch.Generator().manual_seed(12)
     probs, checks = [], []
@@ -186,14 +189,14 @@ def test_outer_wgrad_group():
         probs.append(dict(dY=dY, X=X, dW=dW, db=db, db2=db2))
         checks.append((dY, X, dW, db, db2))
     probs.append(dict(dY=probs[2]["dY"], X=probs[2]["X"], dW=torch.empty(4096, 1024, device=dev)))      # no bias requested
-    ops.outer_wgrad(probs)
+    ops.outer_wgrad(probs, lowp=lowp)
     for dY, X, dW, db, db2 in checks:
         if X is not None:
-            _close(dW, (dY.double().t() @ X.double()).cpu(), 3e-6, "dW %s" % (tuple(dW.shape),))
+            _close(dW, (dY.double().t() @ X.double()).cpu(), tol_w, "dW %s" % (tuple(dW.shape),))
         want = dY.double().sum(0).cpu()
         _close(db, want, 3e-6, "db")
         assert torch.equal(db, db2)
-    _close(probs[-1]["dW"], (checks[2][0].double().t() @ checks[2][1].double()).cpu(), 3e-6, "dW without bias")
+    _close(probs[-1]["dW"], (checks[2][0].double().t() @ checks[2][1].double()).cpu(), tol_w, "dW without bias")
 
 
 def test_query_side_with_gate_projections_matches_oracle():
