@@ -49,7 +49,7 @@ class PackDesc(ctypes.Structure):
 class SkinnyDesc(ctypes.Structure):
     _fields_ = [("X", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("mask", c_void_p), ("Y", c_void_p),
                 ("ldx", c_int32), ("ldy", c_int32), ("ldm", c_int32), ("M", c_int32), ("N", c_int32), ("K", c_int32),
-                ("relu", c_int32)]
+                ("relu", c_int32), ("x_dtype", c_int32)]
 
 
 class OuterDesc(ctypes.Structure):

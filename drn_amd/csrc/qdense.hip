@@ -17,7 +17,9 @@
 // grouped skinny NT product
 // ---------------------------------------------------------------------------------------------------------------------
 struct SkProb {
-  const float* X;
+  const float* X;      // fp32, or (x_bf16) bf16 rows -- then the weights are rounded to bf16 in registers and the product runs on
+                       // v_mfma_f32_16x16x32_bf16 (the bf16 model's LSTM input gradient reads the gate gradients' bf16 copy: the X
+                       // rows, re-read by every column tile, are most of this kernel's bytes)
   const float* W;
   const float* bias;
   const float* mask;   // optional [M][ldm]: output zeroed where mask <= 0 (ReLU backward of the layer in front)
@@ -27,6 +29,7 @@ struct SkProb {
   int ldx, ldy, ldm, M, N, K;
   int kslice, ksplit, relu;
   int blk0;            // first workgroup of this problem; a problem owns ceil(N/16) * ksplit workgroups
+  int x_bf16;
 };
 struct SkGroupArgs {
   SkProb p[DRN_QD_MAX];
@@ -58,7 +61,7 @@ extern "C" int drn_debug_qd_trace(long long* out, int n) {
 #define QD_STAMP(i) do { } while (0)
 #endif
 
-template <int NBT>
+template <int NBT, bool XB16>
 __global__ __launch_bounds__(QD_THREADS) void skinny_group_kernel(const SkGroupArgs G) {
   __shared__ float red[4][NBT][64][4];
   __shared__ int is_last;
@@ -82,7 +85,41 @@ __global__ __launch_bounds__(QD_THREADS) void skinny_group_kernel(const SkGroupA
   const bool nok = n0 + row < P.N;
   const float* wrow = P.W + (long)(n0 + row) * P.K;
   const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int KU = 4;                                  // 16-wide K steps whose operands are all requested up front
+  constexpr int KU = 4;                                  // 16-wide (bf16 rows: 32-wide) K steps whose operands are all requested up front
+  if constexpr (XB16) {
+    const bf16_t* X16 = (const bf16_t*)P.X;
+    const int kc8 = (l >> 4) * 8;
+    for (int k0 = kbeg; k0 < kend; k0 += 32 * KU) {      // (kslice is a multiple of 128 here: a wave's range is a multiple of 32)
+      bf16x8 a[KU][NBT];
+      f32x4 blo[KU], bhi[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int k = k0 + u * 32 + kc8;
+        const bool kok = k < kend;                       // K % 8 == 0: an 8-element piece is in or out as a whole
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {
+          const int m = bt * 16 + row;
+          a[u][bt] = *(const bf16x8*)(X16 + (long)(m < P.M ? m : 0) * P.ldx + (kok ? k : 0));       // (masked loads read a valid address)
+          if (!(kok && m < P.M))
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[u][bt][e] = (bf16_t)0.f;
+        }
+        const float* wp = wrow + (kok ? k : 0);
+        blo[u] = *(const f32x4*)(nok ? wp : P.W);
+        bhi[u] = *(const f32x4*)(nok ? wp + 4 : P.W);
+        if (!(kok && nok)) { blo[u] = zero4; bhi[u] = zero4; }
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (k0 + u * 32 >= kend) break;                  // wave-uniform
+        bf16x8 bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[e] = (bf16_t)blo[u][e]; bv[4 + e] = (bf16_t)bhi[u][e]; }
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][bt], bv, acc[bt], 0, 0, 0);
+      }
+    }
+  } else
   for (int k0 = kbeg; k0 < kend; k0 += 16 * KU) {
     f32x4 a[KU][NBT], b[KU];
 #pragma unroll
@@ -234,13 +271,18 @@ extern "C" int drn_skinny_group(const DrnSkinnyDesc* d, int n, float* ws, int32_
   for (int i = 0; i < n; ++i) {
     const DrnSkinnyDesc& s = d[i];
     DRN_CHECK_ARG(s.X && s.W && s.Y && s.M > 0 && s.M <= 64 && s.N > 0 && s.K > 0, "drn_skinny_group: problem %d: bad shape (M <= 64)", i);
-    DRN_CHECK_ARG(s.K % 4 == 0 && s.ldx % 4 == 0 && (((uintptr_t)s.X | (uintptr_t)s.W) & 15) == 0,
+    DRN_CHECK_ARG(s.K % 4 == 0 && (s.ldx % 4 == 0 || s.x_dtype == DRN_BF16) && (((uintptr_t)s.X | (uintptr_t)s.W) & 15) == 0,
                   "drn_skinny_group: problem %d: need K %% 4 == 0, ldx %% 4 == 0, 16-byte aligned X / W", i);
     SkProb& P = G.p[i];
-    P.X = s.X; P.W = s.W; P.bias = s.bias; P.mask = s.mask; P.Y = s.Y;
+    P.X = (const float*)s.X; P.W = s.W; P.bias = s.bias; P.mask = s.mask; P.Y = s.Y;
+    P.x_bf16 = s.x_dtype == DRN_BF16;
+    DRN_CHECK_ARG(s.x_dtype == DRN_F32 || s.x_dtype == DRN_BF16, "drn_skinny_group: problem %d: bad x_dtype", i);
+    DRN_CHECK_ARG(s.x_dtype == d[0].x_dtype, "drn_skinny_group: the problems of a launch share one x_dtype");
+    DRN_CHECK_ARG(s.x_dtype == DRN_F32 || (s.K % 8 == 0 && s.ldx % 8 == 0), "drn_skinny_group: problem %d: bf16 rows need K %% 8 == 0, ldx %% 8 == 0", i);
     P.ldx = s.ldx; P.ldy = s.ldy; P.ldm = s.ldm; P.M = s.M; P.N = s.N; P.K = s.K; P.relu = s.relu;
     P.ksplit = qd_ksplit(tiles_long, s.K);
     P.kslice = cdiv(cdiv(s.K, P.ksplit), 64) * 64;       // 4 waves x 16-wide steps
+    if (P.x_bf16) P.kslice = cdiv(P.kslice, 128) * 128;  // ... x 32-wide steps
     P.blk0 = blocks;
     blocks += cdiv(s.N, 16) * P.ksplit;
     if (P.ksplit > 1) {
@@ -254,9 +296,13 @@ extern "C" int drn_skinny_group(const DrnSkinnyDesc* d, int n, float* ws, int32_
     nbt = nbt > cdiv(s.M, 16) ? nbt : cdiv(s.M, 16);
   }
   hipStream_t st = (hipStream_t)stream;
-  if (nbt == 1) skinny_group_kernel<1><<<blocks, QD_THREADS, 0, st>>>(G);
-  else if (nbt == 2) skinny_group_kernel<2><<<blocks, QD_THREADS, 0, st>>>(G);
-  else skinny_group_kernel<4><<<blocks, QD_THREADS, 0, st>>>(G);
+  if (d[0].x_dtype == DRN_BF16) {
+    if (nbt == 1) skinny_group_kernel<1, true><<<blocks, QD_THREADS, 0, st>>>(G);
+    else if (nbt == 2) skinny_group_kernel<2, true><<<blocks, QD_THREADS, 0, st>>>(G);
+    else skinny_group_kernel<4, true><<<blocks, QD_THREADS, 0, st>>>(G);
+  } else if (nbt == 1) skinny_group_kernel<1, false><<<blocks, QD_THREADS, 0, st>>>(G);
+  else if (nbt == 2) skinny_group_kernel<2, false><<<blocks, QD_THREADS, 0, st>>>(G);
+  else skinny_group_kernel<4, false><<<blocks, QD_THREADS, 0, st>>>(G);
   return drn_launch_status("drn_skinny_group");
 }
 

@@ -1316,7 +1316,8 @@ def _lstm_backward(dout, emb_tm, lens, lstm_params, saved, B, L, leaves, dqvec=N
         ops.lstm_step_bwd(dout, gates, cseq, wtf, wtr, dgates, scratch[0], scratch[1], lens, B, L, H, s, dqvec=dqvec, dgates16=dg16)
     dg = dgates.view(L * B, 8 * H)
     hp = hprev.view(L * B, 2 * H)
-    demb_tm = ops.skinny_rows(dg, stacked_t([w_ih_f, w_ih_r]))           # dg [W_f; W_r]: (L*B, E)
+    # dg [W_f; W_r]: (L*B, E); in the bf16 model from the gate gradients' bf16 copy (the rows are most of that product's bytes)
+    demb_tm = ops.skinny_rows(dg16.view(L * B, 8 * H) if dg16 is not None else dg, stacked_t([w_ih_f, w_ih_r]))
     gr = [grad_buffer(p) for p in lstm_params]
     leaves += [dict(dY=dg[:, :4 * H], X=emb_tm, dW=gr[0], db=gr[2], db2=gr[3]), dict(dY=dg[:, :4 * H], X=hp[:, :H], dW=gr[1]),
                dict(dY=dg[:, 4 * H:], X=emb_tm, dW=gr[4], db=gr[6], db2=gr[7]), dict(dY=dg[:, 4 * H:], X=hp[:, H:], dW=gr[5])]

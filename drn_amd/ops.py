@@ -256,7 +256,8 @@ def skinny_group(probs):
             _need_gpu(X, W)
             M, K = X.shape
             N = W.shape[0]
-            assert W.shape[1] == K and W.is_contiguous() and X.stride(1) == 1 and X.dtype == W.dtype == torch.float32
+            assert W.shape[1] == K and W.is_contiguous() and X.stride(1) == 1 and W.dtype == torch.float32
+            assert X.dtype in (torch.float32, torch.bfloat16)       # bf16 rows: the bf16 model's low-precision backward products
             Y = q.get("Y")
             if Y is None:
                 Y = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -264,6 +265,7 @@ def skinny_group(probs):
             d.X, d.W, d.bias, d.mask, d.Y = _p(X), _p(W), _p(q.get("bias")), _p(mask), _p(Y)
             d.ldx, d.ldy, d.ldm = X.stride(0), Y.stride(0), (mask.stride(0) if mask is not None else 0)
             d.M, d.N, d.K, d.relu = M, N, K, int(bool(q.get("relu")))
+            d.x_dtype = BF16 if X.dtype == torch.bfloat16 else F32
             outs.append(Y)
         n_ws = int(lib().drn_skinny_group_ws_elems(arr, len(chunk)))
         ws = workspace(n_ws, dev) if n_ws else None

@@ -360,12 +360,14 @@ int drn_colsum_segs(const float* X, int ld, int M, const DrnColSeg* segs /*host*
 #define DRN_QD_MAX 16
 #define DRN_QD_COUNTERS 2048
 typedef struct DrnSkinnyDesc {
-  const float* X;
+  const void* X;     /* fp32 rows, or bf16 rows when x_dtype == DRN_BF16 (K % 8 == 0, ldx % 8 == 0 elements): the weights are then
+                        rounded to bf16 on load and the product accumulates in fp32 on the bf16 MFMA */
   const float* W;
   const float* bias; /* or NULL */
   const float* mask; /* or NULL; [M][ldm] */
   float* Y;
   int32_t ldx, ldy, ldm, M, N, K, relu;
+  int32_t x_dtype;   /* DRN_F32 (0) or DRN_BF16; the same for every problem of a launch */
 } DrnSkinnyDesc;
 int64_t drn_skinny_group_ws_elems(const DrnSkinnyDesc* descs /*host*/, int n);
 int drn_skinny_group(const DrnSkinnyDesc* descs /*host*/, int n, float* ws, int32_t* counters, void* stream);

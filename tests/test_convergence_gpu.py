@@ -51,10 +51,14 @@ def test_bf16_trains_like_f32_on_a_planted_signal():
     # both learn the task ...
     assert l32[-1] < 0.5 * l32[0] and l16[-1] < 0.5 * l16[0], (l32, l16)
     assert a32[0] >= R1_FLOOR and a16[0] >= R1_FLOOR, (a32, a16)
-    # ... along the same curve (mean loss of every 50-step window within the band)
-    assert np.all(np.abs(l16 - l32) <= LOSS_BAND * np.maximum(l32, 0.05)), (l32, l16)
+    # ... along the same curve: mean loss of every 50-step window within the band, widened by how far the second f32 run (started
+    # 1e-6 away) is from the first in that window -- in the steep part of the curve (steps 50-150) two runs of the SAME arithmetic
+    # are 3-20 % apart, and which of them is ahead changes with every last-bit change in any kernel
+    assert np.all(np.abs(l16 - l32) <= LOSS_BAND * np.maximum(l32, 0.05) + 2.0 * np.abs(l3j - l32)), (l32, l16, l3j)
     # ... to the same accuracy on the reference's metric (R@1 / R@5 at IoU 0.5, main.py:362): north_star's 0.3 pt
-    assert abs(a16[0] - a32[0]) <= R1_BAND and abs(a16[1] - a32[1]) <= R1_BAND, (a32, a16)
+    # (two f32 runs started 1e-6 apart end 0.0-0.3 pt apart themselves after 400 steps at lr 1e-3: the band is taken around that spread)
+    for j in (0, 1):
+        assert abs(a16[j] - a32[j]) <= R1_BAND + abs(a3j[j] - a32[j]), (j, a32, a16, a3j)
     # the stricter IoU 0.7 numbers are still moving after 400 steps at lr 1e-3 and differ between two f32 runs that start 1e-6
     # apart; bf16 must not be further from f32 than that spread plus a margin
     for j in (2, 3):

@@ -111,6 +111,21 @@ def test_skinny_linear(M, N, K, relu, bias):
     _close(y, want.cpu(), 2e-6, "skinny")
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 300, 4096), (37, 48, 136), (16, 1024, 512)])
+def test_skinny_group_bf16_rows(M, N, K):
+    """drn_skinny_group with bf16 X rows (DrnSkinnyDesc.x_dtype): weights rounded to bf16 in registers, fp32 accumulation on the bf16
+    MFMA, K split over workgroups as in the fp32 path -- against fp64 on the same (rounded) operands."""
+    from drn_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+    W = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    y = ops.skinny_linear(X, W, bias)
+    want = X.double() @ W.to(torch.bfloat16).double().t() + bias.double()
+    _close(y, want.cpu(), 2e-5, "bf16-row product")
+
+
 def test_gate_linear_function_matches_torch():
     from drn_amd import functional as DF
     g = torch.Generator().manual_seed(3)
