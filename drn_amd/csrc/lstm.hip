@@ -28,6 +28,8 @@ struct LstmFwdArgs {
   const float* xproj;
   const void* Whh[2];         // [4H][H], fp32 or (w_bf16) the optimizer-maintained bf16 copy in the same element order
   float* hseq;
+  _Float16* hseq16;           // optional fp16 copy of hseq (written by every step): with it the recurrent product reads 32 KB of h per
+                              // workgroup instead of 64 and runs on v_mfma_f32_16x16x32_f16 (W_hh rounded to fp16 in registers)
   float* cseq;
   float* gates;
   float* out;
@@ -46,8 +48,11 @@ struct LstmFwdArgs {
 // 160 KB and 128 fp32 MFMAs per wave) took 7.9 us per step hot and alone (scripts/bench_nodes.py), ~6 of them in the kernel.
 // Every operand of a wave's K range -- and the cell update's own operands -- is requested before the first MFMA.
 //   WT = float : v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode), KU iterations of 16 k at a time
-//   WT = bf16_t: v_mfma_f32_16x16x32_bf16 on the bf16 weight copy; h is rounded to bf16 as it is loaded, accumulation in fp32
-//                (the benchmarked bf16 mode: same precision contract as the rest of the model), KU iterations of 32 k
+//   (a bf16 variant -- bf16 W_hh copy, h rounded to bf16 on load -- was measured and dropped: it moved a head output of configs[3]
+//   past its 6e-2 gate)
+//   WT = _Float16: the bf16 MODEL's forward: h from its fp16 copy (|h| < 1, unit roundoff 2^-11 -- four times finer than bf16), W_hh
+//                fp32 from memory and rounded to fp16 in registers, v_mfma_f32_16x16x32_f16, fp32 accumulation: 64 KB per workgroup
+//                instead of 96, and a step is as long as its operand bytes (section 5 of DESIGN.md)
 template <typename WT, int MT, int KU>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmFwdArgs A) {
   __shared__ float red[4][MT][64][4];   // [wave][batch tile][lane][reg]
@@ -106,34 +111,36 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt][e], b[u][e], acc[mt], 0, 0, 0);
       }
-    } else {
-      const bf16_t* W = (const bf16_t*)A.Whh[dir];
+    } else if constexpr (std::is_same<WT, _Float16>::value) {
+      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+      const float* W = (const float*)A.Whh[dir];
+      const _Float16* h16 = A.hseq16 + ((long)(dir * (L + 1) + s) * B) * H;
       const int kc = (l >> 4) * 8;
       for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 32 * KU) {
-        f32x4 alo[KU][MT], ahi[KU][MT];
-        bf16x8 b[KU];
+        f16x8 a[KU][MT];
+        f32x4 blo[KU], bhi[KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
           const int k = k0 + u * 32 + kc;
-          b[u] = *(const bf16x8*)(W + wrow + k);
+          blo[u] = *(const f32x4*)(W + wrow + k);
+          bhi[u] = *(const f32x4*)(W + wrow + k + 4);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const int bb = mt * 16 + col;
-            const float* hp = hprev + (long)(bb < B ? bb : 0) * H + k;
-            alo[u][mt] = *(const f32x4*)hp;
-            ahi[u][mt] = *(const f32x4*)(hp + 4);
-            if (bb >= B) { alo[u][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ahi[u][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            a[u][mt] = *(const f16x8*)(h16 + (long)(bb < B ? bb : 0) * H + k);
+            if (bb >= B)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[u][mt][e] = (_Float16)0.f;
           }
         }
 #pragma unroll
-        for (int u = 0; u < KU; ++u)
+        for (int u = 0; u < KU; ++u) {
+          f16x8 bv;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            bf16x8 av;
+          for (int e = 0; e < 4; ++e) { bv[e] = (_Float16)blo[u][e]; bv[4 + e] = (_Float16)bhi[u][e]; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { av[e] = (bf16_t)alo[u][mt][e]; av[4 + e] = (bf16_t)ahi[u][mt][e]; }
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc[mt], 0, 0, 0);
-          }
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][mt], bv, acc[mt], 0, 0, 0);
+        }
       }
     }
   }
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_fwd_kernel(const LstmF
     const bool valid = t < e_len;
     A.cseq[st_new] = valid ? cn : cp;
     A.hseq[st_new] = valid ? hn : hp;
+    if (A.hseq16) A.hseq16[st_new] = (_Float16)(valid ? hn : hp);
     float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
     gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
     A.hprev_t[(((long)t * B + bb) * 2 + dir) * H + j] = hp;
@@ -186,21 +194,24 @@ static void lstm_fwd_launch(const LstmFwdArgs& A, hipStream_t stream) {
 
 extern "C" int drn_lstm_step_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, int w_dtype, const float* b_ih_f,
                                  const float* b_hh_f, const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates,
-                                 float* out, float* hprev_t, float* qvec, const int64_t* lengths, int B, int L, int H, int s, void* stream_) {
+                                 float* out, float* hprev_t, float* qvec, void* hseq16, const int64_t* lengths, int B, int L, int H, int s,
+                                 void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(xproj && Whh_f && Whh_r && b_ih_f && b_hh_f && b_ih_r && b_hh_r && hseq && cseq && gates && out && hprev_t && lengths,
                 "drn_lstm_step_fwd: null pointer");
   DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 64 == 0 && s >= 0 && s < L, "drn_lstm_step_fwd: need B<=64, H%%64==0");
-  DRN_CHECK_ARG(w_dtype == DRN_F32 || (w_dtype == DRN_BF16 && H % 128 == 0), "drn_lstm_step_fwd: bf16 weights need H %% 128 == 0");
+  DRN_CHECK_ARG(w_dtype == DRN_F32, "drn_lstm_step_fwd: W_hh is fp32 (low precision enters through hseq16)");
   LstmFwdArgs A;
+  DRN_CHECK_ARG(!hseq16 || (w_dtype == DRN_F32 && H % 128 == 0), "drn_lstm_step_fwd: the fp16 state copy goes with fp32 weights and H %% 128 == 0");
+  A.hseq16 = (_Float16*)hseq16;
   A.xproj = xproj; A.Whh[0] = Whh_f; A.Whh[1] = Whh_r; A.hseq = hseq; A.cseq = cseq; A.gates = gates; A.out = out;
   A.hprev_t = hprev_t; A.qvec = qvec; A.b_ih[0] = b_ih_f; A.b_hh[0] = b_hh_f; A.b_ih[1] = b_ih_r; A.b_hh[1] = b_hh_r;
   A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = s;
   const int mt = cdiv(B, 16);
-  if (w_dtype == DRN_BF16) {
-    if (mt == 1) lstm_fwd_launch<bf16_t, 1>(A, stream); else if (mt == 2) lstm_fwd_launch<bf16_t, 2>(A, stream);
-    else if (mt == 3) lstm_fwd_launch<bf16_t, 3>(A, stream); else lstm_fwd_launch<bf16_t, 4>(A, stream);
+  if (hseq16) {
+    if (mt == 1) lstm_fwd_launch<_Float16, 1>(A, stream); else if (mt == 2) lstm_fwd_launch<_Float16, 2>(A, stream);
+    else if (mt == 3) lstm_fwd_launch<_Float16, 3>(A, stream); else lstm_fwd_launch<_Float16, 4>(A, stream);
   } else {
     if (mt == 1) lstm_fwd_launch<float, 1>(A, stream); else if (mt == 2) lstm_fwd_launch<float, 2>(A, stream);
     else if (mt == 3) lstm_fwd_launch<float, 3>(A, stream); else lstm_fwd_launch<float, 4>(A, stream);

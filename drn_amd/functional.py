@@ -1287,12 +1287,12 @@ def _lstm_forward(emb_tm, lens, lstm_params, B, L, qvec=None, lowp=False):
     hprev = torch.empty((L, B, 2, H), dtype=torch.float32, device=dev)
     out = torch.empty((B, L, 2 * H), dtype=torch.float32, device=dev)
     biases = (b_ih_f.detach(), b_hh_f.detach(), b_ih_r.detach(), b_hh_r.detach())
-    if _lstm_lowp(lowp, H):               # bf16 copies in the parameter's own element order, kept current by the optimizer kernels
-        whf, whr = packed(w_hh_f, (0, 2, 1), ops.BF16), packed(w_hh_r, (0, 2, 1), ops.BF16)
-    else:
-        whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
+    whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
+    # lowp (the bf16 model): the steps keep an fp16 copy of the hidden state and multiply it on the fp16 MFMA (W_hh rounded to fp16 in
+    # registers, fp32 accumulation, fp32 states / outputs): 64 KB of operands per workgroup instead of 96
+    hseq16 = torch.empty((2, L + 1, B, H), dtype=torch.float16, device=dev) if _lstm_lowp(lowp, H) else None
     for s in range(L):
-        ops.lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev, lens, B, L, H, s, qvec=qvec)
+        ops.lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev, lens, B, L, H, s, qvec=qvec, hseq16=hseq16)
     return out, (cseq, gates, hprev)
 
 
@@ -1418,9 +1418,7 @@ class _QueryEncoderFn(torch.autograd.Function):
         emb_tm = torch.empty((L * B, E), dtype=torch.float32, device=dev)
         ops.qe_embed_fwd(tokens, table.detach(), emb_tm, B, L, E)
         qvec = torch.empty((B, 2 * C), dtype=torch.float32, device=dev)
-        # (the forward recurrence stays on the exact-fp32 MFMA in the bf16 model too: it is only 0.5 us per step slower than the
-        # bf16 variant and keeps the gates -- which scale every feature channel -- free of a second rounding; backward uses bf16)
-        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L, qvec=qvec)            # qvec: language_module.py:48-54
+        out, saved = _lstm_forward(emb_tm, lens, lstm_params, B, L, qvec=qvec, lowp=lowp)     # qvec: language_module.py:48-54
         base = ops.skinny_linear(qvec, Wq.detach(), bq.detach(), relu=True)               # language_module.py:55-56
         _tap_relu(Wq, 0, base)
         qcmd = ops.skinny_linear(base, stacked([W0, W1, W2]), stacked([b0, b1, b2]))      # (B, 3*C): all three qInput{t}

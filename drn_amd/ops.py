@@ -542,13 +542,13 @@ def focal_bwd(logits, targets, d_losses, gamma, alpha):
 # ---------------------------------------------------------------------------------------------
 # query-encoder LSTM recurrence
 # ---------------------------------------------------------------------------------------------
-def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens, B, L, H, s, qvec=None):
+def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens, B, L, H, s, qvec=None, hseq16=None):
     """biases = (b_ih_f, b_hh_f, b_ih_r, b_hh_r); lens int64 on the device; layouts in include/drn_hip.h.  qvec (B, 4H) or None:
     the [first ; last] sentence vector, written by the steps that produce its rows.  whf / whr: W_hh (4H, H) fp32, or bf16 copies."""
     _need_gpu(xproj, out)
     assert whf.dtype == whr.dtype and whf.is_contiguous() and whr.is_contiguous()
     check(lib().drn_lstm_step_fwd(_p(xproj), _p(whf), _p(whr), BF16 if whf.dtype == torch.bfloat16 else F32, _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(biases[3]),
-                                  _p(hseq), _p(cseq), _p(gates), _p(out), _p(hprev_t), _p(qvec), _p(lens), B, L, H, s, _stream()),
+                                  _p(hseq), _p(cseq), _p(gates), _p(out), _p(hprev_t), _p(qvec), _p(hseq16), _p(lens), B, L, H, s, _stream()),
           "drn_lstm_step_fwd")
 
 

@@ -399,10 +399,12 @@ int drn_lgp_bwd(const void* x, int ldx, const float* qn, const float* att, const
  * (reverse).  B <= 64, H % 64 == 0.  w_dtype: DRN_F32 (exact-fp32 MFMA, the parity mode) or DRN_BF16 (Whh_* / WhhT_* are bf16
  * copies in the same element order, H % 128 == 0: the hidden state / gate gradients are rounded to bf16 as they are loaded,
  * products accumulate in fp32; states, gates and every output stay fp32).  qvec (optional, [B][4H]): the sentence vector [out[b][0][:] ; out[b][len_b-1][:]]
- * (language_module.py:48-54), each half-row written by the step that produces it -- no gather launch after the recurrence. */
+ * (language_module.py:48-54), each half-row written by the step that produces it -- no gather launch after the recurrence.
+ * hseq16 (optional, fp16 [2][L+1][B][H], with fp32 weights and H % 128 == 0): every step also writes its state there and reads the
+ * previous one from there; the recurrent product then runs on the fp16 MFMA (W_hh rounded in registers, fp32 accumulation). */
 int drn_lstm_step_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, int w_dtype, const float* b_ih_f, const float* b_hh_f,
                       const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out, float* hprev_t,
-                      float* qvec, const int64_t* lengths, int B, int L, int H, int s, void* stream);
+                      float* qvec, void* hseq16, const int64_t* lengths, int B, int L, int H, int s, void* stream);
 /* Backward: drn_lstm_bwd_first does the cell backward of the last step (s = L-1) from dout [B][L][2H] alone; then
  * drn_lstm_step_bwd for s = L-1 .. 1 propagates through W_hh of step s (dgates[t(s)] x Whh) and applies the cell backward
  * of step s-1 in its epilogue (the recurrent dL/dh never goes to memory).  dgates is the operand of the weight-gradient

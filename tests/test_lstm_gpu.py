@@ -74,10 +74,10 @@ def test_sentence_vector_rides_in_the_step_kernels():
 
 
 @pytest.mark.parametrize("B,L,lens", [(32, 8, None), (7, 5, [5, 5, 4, 3, 2, 1, 1]), (40, 3, None)])
-def test_bf16_recurrent_weights_track_the_fp32_kernels(B, L, lens):
-    """The bf16 model's BiLSTM: W_hh / W_hh^T as bf16 copies on v_mfma_f32_16x16x32_bf16 (h and the gate gradients rounded to bf16
-    on load, fp32 accumulation, fp32 states) against the exact-fp32 kernels on the same inputs: bf16 rounding of two operands
-    (2^-9 each) through <= 8 recurrent steps."""
+def test_low_precision_recurrent_products_track_the_fp32_kernels(B, L, lens):
+    """The bf16 model's BiLSTM (lowp): forward on v_mfma_f32_16x16x32_f16 with an fp16 copy of the hidden state (W_hh rounded to fp16
+    in registers), backward on v_mfma_f32_16x16x32_bf16 with bf16 copies of W_hh^T and of the gate gradients; fp32 accumulation and
+    fp32 states everywhere -- against the exact-fp32 kernels on the same inputs."""
     from drn_amd import functional as DF
     torch.manual_seed(3)
     dev = "cuda:0"
@@ -100,7 +100,7 @@ def test_bf16_recurrent_weights_track_the_fp32_kernels(B, L, lens):
     o16, dx16, g16 = res[True]
     assert not torch.equal(o32, o16)                                  # the bf16 path really ran
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
-    assert rel(o16, o32) <= 1e-2, rel(o16, o32)
+    assert rel(o16, o32) <= 2e-3, rel(o16, o32)                     # fp16 forward: unit roundoff 2^-11 on both operands
     assert rel(dx16, dx32) <= 2e-2, rel(dx16, dx32)
     for k in g32:
         assert rel(g16[k], g32[k]) <= 2e-2, (k, rel(g16[k], g32[k]))

@@ -185,7 +185,8 @@ def test_fp32_gradients_match_oracle_to_1e4_given_equal_relu_decisions(B, T, D, 
 # layers in bf16, unit roundoff 2^-9 = 2e-3; ReLU decisions differ freely here, bf16 moves pre-activations by ~1e-2):
 # losses 3e-2 relative; head outputs 6e-2 of their scale; at B=32,T=256 the whole gradient vector 6e-2 relative L2 (measured
 # 3.1e-2 .. 3.6e-2) and every large weight gradient (>= 1e5 elements) 3e-1 (measured: prop_fc.weight 0.14, mix_fc 0.20);
-# at the 2-clip configs[0] shape batch statistics over 2 x 64 positions amplify the noise: 3e-1 / 6e-1 (measured 0.19 / 0.42).
+# at the 2-clip configs[0] shape batch statistics over 2 x 64 positions amplify the noise: 3e-1 / 6e-1 (measured 0.19 / 0.42), head
+# outputs 1e-1 of scale (measured up to 6.7e-2 at the coarsest level).
 @pytest.mark.parametrize("B,T,D,stage,tol_glob,tol_big", [(2, 64, 4096, 3, 3e-1, 6e-1), (32, 256, 4096, 1, 6e-2, 3e-1),
                                                           (32, 256, 4096, 3, 6e-2, 3e-1)])
 def test_bf16_losses_heads_gradients_vs_oracle(B, T, D, stage, tol_glob, tol_big):
@@ -203,7 +204,9 @@ def test_bf16_losses_heads_gradients_vs_oracle(B, T, D, stage, tol_glob, tol_big
     for j in (0, 1, 3):
         for l in range(3):
             x, y = head_h[j][l].detach().float().cpu(), caught["head"][j][l].detach().float()
-            assert float((x - y).abs().max()) <= 6e-2 * max(1.0, float(y.abs().max())), ("head", j, l)
+            # (2 clips: the coarsest level's BatchNorm sees 2 x 16 positions, its IoU-head output moves 5.1e-2 .. 6.7e-2 of scale with
+            # any change of rounding upstream -- gated at 1e-1 like that case's other tolerances)
+            assert float((x - y).abs().max()) <= (1e-1 if B <= 2 else 6e-2) * max(1.0, float(y.abs().max())), ("head", j, l)
     errs, glob = grad_errors(mh, mo)
     big = {k: e for k, e in errs.items() if dict(mo.named_parameters())[k].numel() >= 100000}
     print("bf16 B=%d T=%d stage %d: global %.3e, large-tensor max %.3e (%s)" % (B, T, stage, glob, max(big.values()),
