@@ -130,10 +130,6 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
     }
   };
   if (R.window && lane < nvec) fetch_window(lane);      // in flight while the weights arrive
-  // the output stage's own operands (bias, the level's scale) are requested here as well: fetched after the wave reduction they
-  // were one more serial trip through caches that start every kernel cold
-  const float b_pre = bias[(lane >> 2) % HEAD_MAX_N < N ? (lane >> 2) % HEAD_MAX_N : 0];
-  const float sc_pre = (P.exp_mode && R.window) ? P.g[R.g].scale[0] : 1.f;
   float acc[HEAD_RPW][HEAD_MAX_N];
 #pragma unroll
   for (int i = 0; i < HEAD_RPW; ++i)
@@ -232,10 +228,11 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadMulti MS) {
     const int idx = lane >> 2, i = idx / HEAD_MAX_N, n = idx % HEAD_MAX_N;
     const int r = r0 + i;
     if (r < P.total_rows && n < N) {
-      float v = tot + b_pre;
+      const HeadGroup& G = P.g[head_group_of(P, r)];
+      float v = tot + bias[n];
       if (P.exp_mode) {
         z[(long)r * N + n] = v;
-        v = expf((R.window ? sc_pre : P.g[head_group_of(P, r)].scale[0]) * v);
+        v = expf(G.scale[0] * v);
       }
       out[(long)r * N + n] = v;
     }
