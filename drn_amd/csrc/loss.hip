@@ -15,6 +15,30 @@
 
 #define LOSS_THREADS 1024
 
+// Five block-wide sums at once (blockDim.x <= 1024, a multiple of 64): the same wave trees and the same cross-wave tree as five
+// block_sum() calls -- bit-identical results -- behind 2 barriers instead of 15.  sh: >= 5 * 17 floats.
+__device__ __forceinline__ void block_sum5(float (&v)[5], float* sh) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (l == 0)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sh[k * 17 + w] = v[k];
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float t = l < nw ? sh[k * 17 + l] : 0.f;
+      t = wave_sum(t);
+      if (l == 0) sh[k * 17 + 16] = t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 5; ++k) v[k] = sh[k * 17 + 16];
+}
+
 struct LossParams {
   int nlevels, B, total_rows;
   int row_start[DRN_MAX_GROUPS], L[DRN_MAX_GROUPS];
@@ -36,19 +60,31 @@ __device__ __forceinline__ float load_gt(const LossParams& P, const void* gt, in
 
 struct Loc {
   int level, b, t;
-  float loc;
+  float loc, lo, hi;      // centre of the location; size bounds of its level (loss.py:103-110)
 };
+// The level's fields are picked with selects over STATIC indices: indexing the kernel-argument arrays with the per-lane level made
+// the compiler walk the distinct levels of a wave one by one, a scalar load and a wait each time (most of this kernel's 8 us).
 __device__ __forceinline__ Loc locate(const LossParams& P, int r) {
-  int g = 0;
+  int g = 0, rs = P.row_start[0], L = P.L[0];
+  float st = P.stride[0], lo = P.lo[0], hi = P.hi[0];
 #pragma unroll
-  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
-    if (i < P.nlevels && r >= P.row_start[i]) g = i;
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i) {
+    const bool in = i < P.nlevels && r >= P.row_start[i];
+    g = in ? i : g;
+    rs = in ? P.row_start[i] : rs;
+    L = in ? P.L[i] : L;
+    st = in ? P.stride[i] : st;
+    lo = in ? P.lo[i] : lo;
+    hi = in ? P.hi[i] : hi;
+  }
   Loc o;
   o.level = g;
-  const int m = r - P.row_start[g];
-  o.b = m / P.L[g];
-  o.t = m - o.b * P.L[g];
-  o.loc = (float)o.t * P.stride[g] + P.stride[g] * 0.5f;  // model/fcos.py:204-211
+  const int m = r - rs;
+  o.b = m / L;
+  o.t = m - o.b * L;
+  o.loc = (float)o.t * st + st * 0.5f;  // model/fcos.py:204-211
+  o.lo = lo;
+  o.hi = hi;
   return o;
 }
 
@@ -91,67 +127,21 @@ __device__ __forceinline__ bool assign_label(const LossParams& P, const Loc& q, 
   tl = q.loc - gs * P.target_scale;   // loss.py:98-101
   tr = ge * P.target_scale - q.loc;
   const float mn = fminf(tl, tr), mx = fmaxf(tl, tr);
-  return mn > 0.f && mx >= P.lo[q.level] && mx <= P.hi[q.level];
+  return mn > 0.f && mx >= q.lo && mx <= q.hi;
 }
 
-// Phase 1: one location per thread, per-block partial sums partial[blk][5] = {focal, iou-loss, smooth-l1, n_pos, n_iou}.
-__global__ __launch_bounds__(256) void fcos_loss_fwd_partial_kernel(const LossParams P, const float* __restrict__ logits,
-                                                                    const float* __restrict__ reg, const float* __restrict__ iou,
-                                                                    const void* __restrict__ gt, float* __restrict__ partial,
-                                                                    float* __restrict__ labels) {
-  __shared__ float sh[17];
-  float s_focal = 0.f, s_ioul = 0.f, s_sl1 = 0.f, n_pos = 0.f, n_iou = 0.f;
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < P.total_rows) {
-    const Loc q = locate(P, r);
-    const float gs = load_gt(P, gt, q.b * 2), ge = load_gt(P, gt, q.b * 2 + 1);
-    float tl, tr;
-    const bool pos = assign_label(P, q, gs, ge, tl, tr);
-    if (labels) labels[r] = pos ? 1.f : 0.f;
-    const float x = logits[r];
-    const float p = 1.f / (1.f + expf(-x));
-    // -log(p) = softplus(-x), -log(1-p) = softplus(x)
-    if (pos) s_focal = P.alpha * powf(1.f - p, P.gamma) * softplus(-x);
-    else s_focal = (1.f - P.alpha) * powf(p, P.gamma) * softplus(x);
-    const float pl = reg[r * 2], prr = reg[r * 2 + 1];
-    if (pos) {
-      n_pos = 1.f;
-      const float inter = fminf(prr, tr) + fminf(pl, tl);
-      const float uni = (tl + tr) + (pl + prr) - inter;
-      s_ioul = -logf((inter + 1e-8f) / (uni + 1e-8f));
-    }
-    if (P.iou_stage) {
-      const IouTerm it = iou_term(P, q, pl, prr, gs, ge, iou[r]);
-      if (it.masked) {
-        n_iou = 1.f;
-        const float ad = fabsf(it.d);
-        s_sl1 = ad < 1.f ? 0.5f * it.d * it.d : ad - 0.5f;
-      }
-    }
-  }
-  s_focal = block_sum(s_focal, sh);
-  s_ioul = block_sum(s_ioul, sh);
-  s_sl1 = block_sum(s_sl1, sh);
-  n_pos = block_sum(n_pos, sh);
-  n_iou = block_sum(n_iou, sh);
-  if (threadIdx.x == 0) {
-    float* p = partial + (long)blockIdx.x * 5;
-    p[0] = s_focal; p[1] = s_ioul; p[2] = s_sl1; p[3] = n_pos; p[4] = n_iou;
-  }
-}
-
-// Phase 2 (one workgroup, fixed order): out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ; out[4] = n_iou_pos ;
-// out[5] = their sum (main.py:225)
-__global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ out,
-                                                                  const LossBumps U) {
-  __shared__ float sh[17];
+// The final summation (one workgroup of 256 threads, fixed order): out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ;
+// out[4] = n_iou_pos ; out[5] = their sum (main.py:225); applies the counter bumps.  coherent: the partials were published
+// write-through by other workgroups of the SAME launch -- read them past the caches.
+__device__ __forceinline__ void loss_finalize(const float* __restrict__ partial, int nblk, int B, float* __restrict__ out, const LossBumps& U,
+                                              float* sh, bool coherent) {
   if ((int)threadIdx.x < U.n) *U.ptr[threadIdx.x] += U.inc[threadIdx.x];
   float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int b = threadIdx.x; b < nblk; b += blockDim.x)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] += partial[(long)b * 5 + k];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) v[k] = block_sum(v[k], sh);
+    for (int k = 0; k < 5; ++k)
+      v[k] += coherent ? __hip_atomic_load(partial + (long)b * 5 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partial[(long)b * 5 + k];
+  block_sum5(v, sh);
   if (threadIdx.x == 0) {
     out[0] = v[0] / (v[3] + (float)B);               // loss.py:213
     out[1] = v[3] > 0.f ? v[1] / v[3] : 0.f;          // loss.py:219-231
@@ -160,6 +150,79 @@ __global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* _
     out[4] = v[4];
     out[5] = out[0] + out[1] + out[2];
   }
+}
+
+// Phase 1: one location per thread, per-block partial sums partial[blk][5] = {focal, iou-loss, smooth-l1, n_pos, n_iou}.
+__global__ __launch_bounds__(256) void fcos_loss_fwd_partial_kernel(const LossParams P, const float* __restrict__ logits,
+                                                                    const float* __restrict__ reg, const float* __restrict__ iou,
+                                                                    const void* __restrict__ gt, float* __restrict__ partial,
+                                                                    float* __restrict__ labels, int* __restrict__ ticket,
+                                                                    float* __restrict__ out, const LossBumps U) {
+  __shared__ float sh[5 * 17];
+  __shared__ int s_last;
+  float s_focal = 0.f, s_ioul = 0.f, s_sl1 = 0.f, n_pos = 0.f, n_iou = 0.f;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < P.total_rows) {
+    // every operand is requested HERE, before the transcendental math: left where they are first used, the loads of reg / iou
+    // came after ~1000 instructions of powf / log1pf each behind its own wait -- three serial memory trips in an 8 us kernel
+    const float x = logits[r];
+    const float pl = reg[r * 2], prr = reg[r * 2 + 1];
+    const float iou_x = P.iou_stage ? iou[r] : 0.f;
+    const Loc q = locate(P, r);
+    const float gs = load_gt(P, gt, q.b * 2), ge = load_gt(P, gt, q.b * 2 + 1);
+    float tl, tr;
+    const bool pos = assign_label(P, q, gs, ge, tl, tr);
+    if (labels) labels[r] = pos ? 1.f : 0.f;
+    const float p = 1.f / (1.f + expf(-x));
+    // -log(p) = softplus(-x), -log(1-p) = softplus(x)
+    if (pos) s_focal = P.alpha * powf(1.f - p, P.gamma) * softplus(-x);
+    else s_focal = (1.f - P.alpha) * powf(p, P.gamma) * softplus(x);
+    if (pos) {
+      n_pos = 1.f;
+      const float inter = fminf(prr, tr) + fminf(pl, tl);
+      const float uni = (tl + tr) + (pl + prr) - inter;
+      s_ioul = -logf((inter + 1e-8f) / (uni + 1e-8f));
+    }
+    if (P.iou_stage) {
+      const IouTerm it = iou_term(P, q, pl, prr, gs, ge, iou_x);
+      if (it.masked) {
+        n_iou = 1.f;
+        const float ad = fabsf(it.d);
+        s_sl1 = ad < 1.f ? 0.5f * it.d * it.d : ad - 0.5f;
+      }
+    }
+  }
+  float v5s[5] = {s_focal, s_ioul, s_sl1, n_pos, n_iou};
+  block_sum5(v5s, sh);
+  s_focal = v5s[0]; s_ioul = v5s[1]; s_sl1 = v5s[2]; n_pos = v5s[3]; n_iou = v5s[4];
+  if (threadIdx.x == 0) {
+    float* p = partial + (long)blockIdx.x * 5;
+    if (!ticket) {
+      p[0] = s_focal; p[1] = s_ioul; p[2] = s_sl1; p[3] = n_pos; p[4] = n_iou;
+    } else {
+      // one launch: the partial sums are published write-through, the workgroup that arrives LAST adds them all in the order the
+      // separate final kernel uses (same values whoever is last) and writes the losses
+      const float v5[5] = {s_focal, s_ioul, s_sl1, n_pos, n_iou};
+#pragma unroll
+      for (int k = 0; k < 5; ++k) __hip_atomic_store(p + k, v5[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = prev == (int)gridDim.x - 1;
+      if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed
+    }
+  }
+  if (!ticket) return;
+  __syncthreads();
+  if (!s_last) return;
+  loss_finalize(partial, gridDim.x, P.B, out, U, sh, true);
+}
+
+// Phase 2 (one workgroup, fixed order): out[0..2] = loss_cls, loss_reg, loss_iou ; out[3] = n_pos ; out[4] = n_iou_pos ;
+// out[5] = their sum (main.py:225)
+__global__ __launch_bounds__(256) void fcos_loss_fwd_final_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ out,
+                                                                  const LossBumps U) {
+  __shared__ float sh[5 * 17];
+  loss_finalize(partial, nblk, B, out, U, sh, false);
 }
 
 // g_cls / g_reg / g_iou: upstream gradients (one float each, NULL = 0) of (loss_cls, loss_reg, loss_iou).  Outputs: dlogits[r], dreg[r][2], diou[r].
@@ -174,11 +237,13 @@ __global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, 
   const float k_reg = n_pos > 0.f ? (g_reg ? g_reg[0] : 0.f) / n_pos : 0.f;
   const float k_iou = (P.iou_stage && n_iou > 0.f) ? (g_iou ? g_iou[0] : 0.f) / n_iou : 0.f;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P.total_rows; r += gridDim.x * blockDim.x) {
+    const float x = logits[r];                         // (all loads first: see the forward kernel)
+    const float pl = reg[r * 2], prr = reg[r * 2 + 1];
+    const float iou_x = P.iou_stage ? iou[r] : 0.f;
     const Loc q = locate(P, r);
     const float gs = load_gt(P, gt, q.b * 2), ge = load_gt(P, gt, q.b * 2 + 1);
     float tl, tr;
     const bool pos = assign_label(P, q, gs, ge, tl, tr);
-    const float x = logits[r];
     const float p = 1.f / (1.f + expf(-x));
     float dx;
     if (pos) {
@@ -189,7 +254,6 @@ __global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, 
       dx = (1.f - P.alpha) * powf(p, P.gamma) * (P.gamma * (1.f - p) * softplus(x) + p);
     }
     dlogits[r] = dx * k_cls;
-    const float pl = reg[r * 2], prr = reg[r * 2 + 1];
     float d0 = 0.f, d1 = 0.f;  // gradient w.r.t. reg[r][0..1]
     if (pos && k_reg != 0.f) {
       const float inter = fminf(prr, tr) + fminf(pl, tl);
@@ -201,7 +265,7 @@ __global__ __launch_bounds__(256) void fcos_loss_bwd_kernel(const LossParams P, 
     }
     if (P.iou_stage) {
       float di = 0.f;
-      const IouTerm it = iou_term(P, q, pl, prr, gs, ge, iou[r]);
+      const IouTerm it = iou_term(P, q, pl, prr, gs, ge, iou_x);
       if (it.masked && k_iou != 0.f) {
         const float sl = fabsf(it.d) < 1.f ? it.d : (it.d > 0.f ? 1.f : -1.f);
         di = k_iou * sl * it.p * (1.f - it.p);
@@ -234,7 +298,7 @@ static int fill_loss_params(LossParams& P, const DrnLossLevel* levels, int nleve
 
 extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B, const float* logits, const float* reg, const float* iou,
                                  const void* gt, int gt_f64, float gamma, float alpha, float target_scale, int iou_stage, float* out6,
-                                 float* labels, float* ws, const DrnCounterBump* bumps, int nbumps, void* stream) {
+                                 float* labels, float* ws, int32_t* ticket, const DrnCounterBump* bumps, int nbumps, void* stream) {
   drn_clear_status();
   LossParams P;
   int rc = fill_loss_params(P, levels, nlevels, B, gamma, alpha, target_scale, iou_stage, gt_f64, "drn_fcos_loss_fwd");
@@ -248,8 +312,8 @@ extern "C" int drn_fcos_loss_fwd(const DrnLossLevel* levels, int nlevels, int B,
   memset(&U, 0, sizeof(U));
   U.n = nbumps;
   for (int i = 0; i < nbumps; ++i) { U.ptr[i] = (long long*)bumps[i].counter; U.inc[i] = bumps[i].inc; }
-  fcos_loss_fwd_partial_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, ws, labels);
-  fcos_loss_fwd_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, nblk, B, out6, U);
+  fcos_loss_fwd_partial_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(P, logits, reg, iou, gt, ws, labels, ticket, out6, U);
+  if (!ticket) fcos_loss_fwd_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, nblk, B, out6, U);
   return drn_launch_status("drn_fcos_loss_fwd");
 }
 

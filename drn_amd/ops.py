@@ -508,7 +508,7 @@ def fcos_loss_fwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, i
     arr = (_lib.CounterBump * nb)(*[_lib.CounterBump(counter=_p(t), inc=int(n)) for t, n in bumps]) if nb else None
     check(lib().drn_fcos_loss_fwd(levels, len(levels), B, _p(logits), _p(reg), _p(iou), _p(gt), int(gt.dtype == torch.float64),
                                   ctypes.c_float(gamma), ctypes.c_float(alpha), ctypes.c_float(target_scale), int(iou_stage), _p(out6),
-                                  _p(labels), _p(ws), arr, nb, _stream()), "drn_fcos_loss_fwd")
+                                  _p(labels), _p(ws), _p(_counters(logits.device)[-1:]), arr, nb, _stream()), "drn_fcos_loss_fwd")
 
 
 def fcos_loss_bwd(levels, B, logits, reg, iou, gt, gamma, alpha, target_scale, iou_stage, out6, g3, dlogits, dreg, diou):

@@ -296,6 +296,7 @@ typedef struct DrnCounterBump {
 int drn_fcos_loss_fwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg,
                       const float* iou, const void* gt /*[B][2]*/, int gt_f64, float gamma, float alpha, float target_scale,
                       int iou_stage, float* out6, float* labels /*[R] or NULL*/, float* ws /* >= 5*ceil(R/256) floats */,
+                      int32_t* ticket /* one zeroed int32 (left zero), or NULL: the final summation as a second launch */,
                       const DrnCounterBump* bumps /*host*/, int nbumps, void* stream);
 int drn_fcos_loss_bwd(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg,
                       const float* iou, const void* gt, int gt_f64, float gamma, float alpha, float target_scale, int iou_stage,
