@@ -360,6 +360,61 @@ __global__ __launch_bounds__(256) void pos_embed_bwd_kernel(const T* __restrict_
     __syncthreads();
   }
 }
+// The same sums with 16-byte channel vectors: 32 vectors x 8 row lanes, FOUR rows per thread requested before the first use
+// (the scalar kernel above walks 32 channels at a time behind two barriers each: 8 dependent round trips for C = 256).
+template <typename T>
+__global__ __launch_bounds__(256) void pos_embed_bwd_vec_kernel(const T* __restrict__ dout, int ld, const float* __restrict__ feat,
+                                                                int M, int C, float* __restrict__ partial) {
+  constexpr int N = V16<T>::N;
+  __shared__ float red[8][4][N * 33];
+  const int rows_per = (M + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  const int vl = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int nvec = C / N;
+  for (int v0 = 0; v0 < nvec; v0 += 32) {
+    const int v = v0 + vl;
+    float a[4][N];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < N; ++e) a[k][e] = 0.f;
+    if (v < nvec)
+      for (int m = r0 + ry; m < r1; m += 32) {
+        float g[4][N], f[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int mm = min(m + 8 * i, r1 - 1);
+          V16<T>::load(dout + (long)mm * ld + v * N, g[i]);
+          f[i][0] = feat[mm * 3 + 0]; f[i][1] = feat[mm * 3 + 1]; f[i][2] = feat[mm * 3 + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float w = m + 8 * i < r1 ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < N; ++e) {
+            const float ge = g[i][e] * w;
+            a[0][e] = fmaf(ge, f[i][0], a[0][e]);
+            a[1][e] = fmaf(ge, f[i][1], a[1][e]);
+            a[2][e] = fmaf(ge, f[i][2], a[2][e]);
+            a[3][e] += ge;
+          }
+        }
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < N; ++e) red[ry][k][e * 33 + vl] = a[k][e];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 4 * 32 * N; o += 256) {
+      const int k = o / (32 * N), c = o % (32 * N);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r][k][(c % N) * 33 + c / N];
+      if (v0 * N + c < C) partial[((long)blockIdx.x * 4 + k) * C + v0 * N + c] = sum;
+    }
+    __syncthreads();
+  }
+}
 // block = 32 channels x 8 partial lanes
 __global__ __launch_bounds__(256) void pos_embed_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C,
                                                                   float* __restrict__ dW, float* __restrict__ db, int accumulate) {
@@ -388,10 +443,170 @@ extern "C" int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, in
   drn_clear_status();
   DRN_CHECK_ARG(dout && feat && dW && db && ws && M > 0 && C > 0, "drn_pos_embed_bwd: bad args");
   const int nblk = M < 64 ? 1 : (M < 32 * 256 ? (M + 31) / 32 : 256);   // (128-row blocks: 64 workgroups, 37 us instead of 12)
-  DISPATCH_DT(dtype, "drn_pos_embed_bwd",
-              { pos_embed_bwd_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>((const T*)dout, ld, feat, M, C, ws); });
+  DISPATCH_DT(dtype, "drn_pos_embed_bwd", {
+    if (C % V16<T>::N == 0 && ld % V16<T>::N == 0 && ((uintptr_t)dout & 15) == 0)
+      pos_embed_bwd_vec_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>((const T*)dout, ld, feat, M, C, ws);
+    else
+      pos_embed_bwd_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>((const T*)dout, ld, feat, M, C, ws);
+  });
   pos_embed_bwd_final_kernel<<<dim3(cdiv(C, 32), 4), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, dW, db, accumulate);
   return drn_launch_status("drn_pos_embed_bwd");
+}
+
+// ---------------------------------------------------------------- position-embedding gradient THROUGH the conv that reads it
+// conv0's input is cat(gated features, position embedding) (model/backbone.py:31-32) and the embedding is a Linear(3, P) of
+// the per-row features f (model/main_model.py:34,51-55).  Its weight gradient needs the conv's input gradient on those P
+// channels only as a sum over rows, dWp[c][j] = sum_m dX[m][Cin-P+c] * f[m][j], and dX = sum_tap dY(shifted) x W[:, tap, c] is
+// linear, so the row sum moves inside:
+//   Q[tap][j][o] = sum over output rows (s, to) with t = to*stride - pad + tap inside [0, L):  dY[s,to,o] * f[s*L+t][j]   (j = 3: 1)
+//   dWp[c][j]    = sum_{tap,o} Wd[Cin-P+c][tap][o] * Q[tap][j][o]          dbp[c] = the j = 3 column
+// The conv's input-gradient GEMM then skips those P columns (T = 256: 544 -> 512 tiles of 256x256 = two full rounds on 256
+// CUs instead of two and an eighth), and the gradient is no longer rounded to the activation dtype on the way.
+// Three small launches: partial Q per row block -> Q -> the (P x 4) x (k*Cout) product.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void conv_tail_q_kernel(const T* __restrict__ dy, int ld, const float* __restrict__ feat, int M,
+                                                          int Lo, int L, int stride, int pad, int C, float* __restrict__ partial) {
+  constexpr int N = V16<T>::N;
+  __shared__ float red[8][4][N * 33];
+  const int rows_per = (M + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  const int vl = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int nvec = C / N;
+  for (int v0 = 0; v0 < nvec; v0 += 32) {
+    const int v = v0 + vl;
+    float a[K][4][N];
+#pragma unroll
+    for (int tp = 0; tp < K; ++tp)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < N; ++e) a[tp][j][e] = 0.f;
+    if (v < nvec)
+      for (int m = r0 + ry; m < r1; m += 32) {
+        float g[4][N], f[4][K][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool in = m + 8 * i < r1;
+          const int mm = min(m + 8 * i, r1 - 1);
+          V16<T>::load(dy + (long)mm * ld + v * N, g[i]);
+          const int sq = mm / Lo, to = mm - sq * Lo;
+#pragma unroll
+          for (int tp = 0; tp < K; ++tp) {
+            const int t = to * stride - pad + tp;
+            const bool ok = in && t >= 0 && t < L;
+            const float* fr = feat + ((long)sq * L + (ok ? t : 0)) * 3;
+            f[i][tp][0] = ok ? fr[0] : 0.f;
+            f[i][tp][1] = ok ? fr[1] : 0.f;
+            f[i][tp][2] = ok ? fr[2] : 0.f;
+            f[i][tp][3] = ok ? 1.f : 0.f;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int tp = 0; tp < K; ++tp)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int e = 0; e < N; ++e) a[tp][j][e] = fmaf(g[i][e], f[i][tp][j], a[tp][j][e]);
+      }
+#pragma unroll
+    for (int tp = 0; tp < K; ++tp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < N; ++e) red[ry][j][e * 33 + vl] = a[tp][j][e];
+      __syncthreads();
+      for (int o = threadIdx.x; o < 4 * 32 * N; o += 256) {
+        const int j = o / (32 * N), c = o % (32 * N);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += red[r][j][(c % N) * 33 + c / N];
+        if (v0 * N + c < C) partial[((long)blockIdx.x * (4 * K) + tp * 4 + j) * C + v0 * N + c] = sum;
+      }
+      __syncthreads();
+    }
+  }
+}
+// Q[q][o] = sum over row blocks; grid (C/32, 4K), 32 channels x 8 lanes over the blocks
+__global__ __launch_bounds__(256) void conv_tail_qsum_kernel(const float* __restrict__ partial, int nblk, int nq, int C,
+                                                             float* __restrict__ Q) {
+  __shared__ float red[8][33];
+  const int jl = threadIdx.x & 31, by = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl;
+  const int q = blockIdx.y;
+  float s = 0.f;
+  if (j < C) {
+#pragma unroll 8
+    for (int b = by; b < nblk; b += 8) s += partial[((long)b * nq + q) * C + j];
+  }
+  red[by][jl] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && j < C) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sum += red[r][jl];
+    Q[(long)q * C + j] = sum;
+  }
+}
+// one wave per embedding channel c: 16-byte pieces of its k*Cout weights against the four Q columns
+template <typename T>
+__global__ __launch_bounds__(256) void conv_tail_w_kernel(const T* __restrict__ Wd, long ldw, const float* __restrict__ Q, int K,
+                                                          int C, int P, float* __restrict__ dW, float* __restrict__ db,
+                                                          int accumulate) {
+  constexpr int N = V16<T>::N;
+  const int l = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= P) return;
+  const T* __restrict__ w = Wd + (long)c * ldw;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nvec = K * C / N;
+  for (int v = l; v < nvec; v += 64) {
+    const int kk = v * N, tp = kk / C, o = kk - tp * C;
+    float wv[N];
+    V16<T>::load(w + kk, wv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* q = Q + ((long)(tp * 4 + j)) * C + o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[j] = fmaf(wv[e], q[e], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) acc[j] += __shfl_xor(acc[j], sft, 64);
+  if (l < 4) {
+    const float val = l == 0 ? acc[0] : (l == 1 ? acc[1] : (l == 2 ? acc[2] : acc[3]));
+    float* dst = l < 3 ? dW + c * 3 + l : db + c;
+    *dst = accumulate ? *dst + val : val;
+  }
+}
+extern "C" int64_t drn_conv_tail_bwd_ws_elems(int M, int k, int Cout) {
+  const int nblk = M < 64 ? 1 : (M < 32 * 256 ? (M + 31) / 32 : 256);
+  return ((int64_t)nblk + 1) * 4 * k * Cout;
+}
+extern "C" int drn_conv_tail_bwd(const void* dY, int ld_dy, int B, int Lo, int Cout, const void* Wd, int64_t ldw, int k, int stride,
+                                 int pad, const float* feat, int L, int P, float* dW, float* db, int accumulate, float* ws,
+                                 int dtype, void* stream) {
+  drn_clear_status();
+  const char* who = "drn_conv_tail_bwd";
+  DRN_CHECK_ARG(dY && Wd && feat && dW && db && ws && B > 0 && Lo > 0 && L > 0 && Cout > 0 && P > 0 && stride > 0 && pad >= 0,
+                "%s: bad args", who);
+  DRN_CHECK_ARG(k == 1 || k == 3, "%s: kernel size %d (1 or 3)", who, k);
+  const int M = B * Lo;
+  const int nblk = M < 64 ? 1 : (M < 32 * 256 ? (M + 31) / 32 : 256);
+  float* Q = ws + (long)nblk * 4 * k * Cout;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DT(dtype, "drn_conv_tail_bwd", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(Cout % N == 0 && ld_dy % N == 0 && ldw % N == 0 && ((uintptr_t)dY & 15) == 0 && ((uintptr_t)Wd & 15) == 0,
+                  "%s: Cout / ld / pointers must be 16-byte multiples", who);
+    if (k == 3) conv_tail_q_kernel<T, 3><<<nblk, 256, 0, st>>>((const T*)dY, ld_dy, feat, M, Lo, L, stride, pad, Cout, ws);
+    else conv_tail_q_kernel<T, 1><<<nblk, 256, 0, st>>>((const T*)dY, ld_dy, feat, M, Lo, L, stride, pad, Cout, ws);
+    conv_tail_qsum_kernel<<<dim3(cdiv(Cout, 32), 4 * k), 256, 0, st>>>(ws, nblk, 4 * k, Cout, Q);
+    conv_tail_w_kernel<T><<<cdiv(P, 4), 256, 0, st>>>((const T*)Wd, ldw, Q, k, Cout, P, dW, db, accumulate);
+  });
+  return drn_launch_status(who);
 }
 
 // ---------------------------------------------------------------- FPN top-down backward: dst[s,t] += src[s,2t] + src[s,2t+1]
@@ -444,16 +659,16 @@ extern "C" int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int l
 //   dC[s,t,c] = (add ? add[s,t,c] : 0) + dG[s,t,c] * gate[s,c]        dgate[s,c] = sum_t dG[s,t,c] * act[s,t,c]
 //   dsum[s,c] = sum_t dG[s,t,c] * gate[s,c]   (optional: per-sequence column sums of the gated gradient = bias gradient partials)
 // grid (ceil(nvec/8), nseq); block 256 = 8 channel vectors x 32 row lanes.
-template <typename T>
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG, int ld_dg, const T* __restrict__ act, int ld_act,
+template <typename T, int RY>
+__global__ __launch_bounds__(8 * RY) void gate_bwd_kernel(const T* __restrict__ dG, int ld_dg, const T* __restrict__ act, int ld_act,
                                                        const float* __restrict__ gate, int ldg, const T* __restrict__ add, int ld_add,
                                                        T* __restrict__ dC, int ld_dc, float* __restrict__ dgate, int ld_dgate,
                                                        float* __restrict__ dsum, int L, int C) {
   constexpr int N = V16<T>::N;
-  // 8 channel vectors (one 128-byte line of bf16) x 32 row lanes per workgroup (was 32 x 8, then 16 x 16): every halving of
-  // the sequential row trips halved the launch -- at 64-128 workgroups of 16 dependent trips it was pure latency (19 us
-  // for 4 MB at C = 256)
-  constexpr int VX = 8, RY = 32;
+  // 8 channel vectors (one 128-byte line of bf16) x RY row lanes per workgroup (was 32 x 8, then 16 x 16, then 8 x 32): every
+  // halving of the sequential row trips shortened the launch -- at 64-128 workgroups of 16 dependent trips it was pure latency
+  // (19 us for 4 MB at C = 256).  RY = 32 / 64 / 128 by sequence length: at most 4 rows per thread, all in flight at once.
+  constexpr int VX = 8, NT = VX * RY;
   __shared__ float red[RY][VX * N + 1];
   const int vx = threadIdx.x & (VX - 1), ry = threadIdx.x / VX;
   const int v = blockIdx.x * VX + vx;
@@ -491,7 +706,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
 #pragma unroll
   for (int k = 0; k < N; ++k) red[ry][vx * N + k] = acc[k];
   __syncthreads();
-  for (int i = threadIdx.x; i < VX * N; i += 256) {
+  for (int i = threadIdx.x; i < VX * N; i += NT) {
     const int c = blockIdx.x * VX * N + i;
     if (c < C) {
       float sum = 0.f;
@@ -505,7 +720,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dG,
 #pragma unroll
     for (int k = 0; k < N; ++k) red[ry][vx * N + k] = cs[k] * gt[k];
     __syncthreads();
-    for (int i = threadIdx.x; i < VX * N; i += 256) {
+    for (int i = threadIdx.x; i < VX * N; i += NT) {
       const int c = blockIdx.x * VX * N + i;
       if (c < C) {
         float sum = 0.f;
@@ -526,8 +741,14 @@ extern "C" int drn_gate_bwd(const void* dG, int ld_dg, const void* act, int ld_a
     DRN_CHECK_ARG(C % N == 0 && ld_dg % N == 0 && ld_act % N == 0 && (!dC || ld_dc % N == 0) && (!add || ld_add % N == 0),
                   "drn_gate_bwd: C/ld must be 16-byte multiples");
     dim3 grid(cdiv(C / N, 8), nseq);
-    gate_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (const T*)add,
-                                                                ld_add, (T*)dC, ld_dc, dgate, ld_dgate, dsum, L, C);
+auto go = [&](auto ry) {
+      constexpr int RY_ = decltype(ry)::value;
+      gate_bwd_kernel<T, RY_><<<grid, 8 * RY_, 0, (hipStream_t)stream>>>((const T*)dG, ld_dg, (const T*)act, ld_act, gate, ldg, (const T*)add,
+                                                                           ld_add, (T*)dC, ld_dc, dgate, ld_dgate, dsum, L, C);
+    };
+    if (L > 256) go(std::integral_constant<int, 128>());
+    else if (L > 128) go(std::integral_constant<int, 64>());
+    else go(std::integral_constant<int, 32>());
   });
   return drn_launch_status("drn_gate_bwd");
 }

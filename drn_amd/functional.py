@@ -593,8 +593,9 @@ def _tap_relu(weight, level, out, up=None):
 class ConvMeta(object):
     """Static (non-tensor) description of one conv+BN(+ReLU) block call."""
 
-    def __init__(self, stride, bn, training, dtype, relu=True):
+    def __init__(self, stride, bn, training, dtype, relu=True, tail=None):
         self.stride, self.bn, self.training, self.dtype, self.relu = stride, bn, training, dtype, relu
+        self.tail = tail          # EmbedTail: the last P input channels are a Linear of per-row features (see input_stage)
 
 
 class _ConvBlockFn(torch.autograd.Function):
@@ -740,22 +741,30 @@ class _ConvBlockFn(torch.autograd.Function):
         dxs = [None] * nl
         if any(ctx.needs_input_grad[7 + l] for l in range(nl)):
             wd = packed(ctx.weight_obj, (1, 2, 0), code)               # (Cin, k, Cout)
+            tail = meta.tail if (meta.tail is not None and nl == 1 and k in (1, 3) and meta.tail.usable(Cin, Cout, dt)) else None
+            ncols = Cin - tail.P if tail is not None else Cin
             descs = []
             for l in range(nl):
                 B, L, Lo, M, ld = geo[l]
                 dx = torch.empty((B, L, Cin), dtype=dt, device=dev)
-                descs.append(ops.gemm_desc(draws[l], wd, dx, B * L, Cin, Cout, taps=k, stride=meta.stride, pad=pad, mode=1,
-                                           Lout=L, Lsrc=Lo))
+                # (with a tail the product stops at the feature columns: the embedding columns of dx stay unwritten, and nobody
+                # reads them -- the input stage takes its embedding gradients from the tail)
+                descs.append(ops.gemm_desc(draws[l], wd, dx, B * L, ncols, Cout, taps=k, stride=meta.stride, pad=pad, mode=1,
+                                           Lout=L, Lsrc=Lo, ldc=Cin))
                 dxs[l] = dx
             ops.gemm_nt(descs, code)
+            if tail is not None:
+                B, L, Lo, M, ld = geo[0]
+                tail.backward(draws[0], wd, B, L, Lo, Cout, Cin, k, meta.stride, pad, code)
         # a conv bias in front of a train-mode BN cancels: its gradient is exactly zero -> None (no fill, no copy into the
         # bucket: the reducer's slice of a parameter without gradient reads as zero)
         return (None, dW, None, dgamma, dbeta, dgate, dup) + tuple(dxs)
 
 
-def conv_block(xs, conv, bn, training, dtype, gate=None, up=None, relu=True):
-    """Apply conv->BN->ReLU (modules are parameter holders) to a list of channels-last level inputs."""
-    meta = ConvMeta(conv.stride[0], bn, training, dtype, relu)
+def conv_block(xs, conv, bn, training, dtype, gate=None, up=None, relu=True, tail=None):
+    """Apply conv->BN->ReLU (modules are parameter holders) to a list of channels-last level inputs.  `tail`: the EmbedTail of
+    an input that came out of input_stage (single level only)."""
+    meta = ConvMeta(conv.stride[0], bn, training, dtype, relu, tail=tail)
     res = _ConvBlockFn.apply(meta, conv.weight, conv.bias, bn.weight, bn.bias, gate, up, *xs)
     if gate is not None:
         return list(res[:-1]), res[-1]
@@ -1032,13 +1041,40 @@ def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True):
     return pr
 
 
+class EmbedTail(object):
+    """Link between the input stage and the conv block that consumes its output.  The position embedding occupies the last P
+    channels of that conv's input and is a Linear(3, P) of per-row features, so its two gradients can be taken through the conv
+    from the gradient at the conv's OUTPUT (ops.conv_tail_bwd) and the conv's input-gradient GEMM leaves the P columns out
+    (T = 256: 544 -> 512 tiles of 256x256, two full rounds on 256 CUs instead of two and an eighth).  The conv block's backward
+    fills dW / db; the input stage's backward, which runs after it, hands them to autograd instead of reducing the
+    (unwritten) embedding columns of its incoming gradient."""
+    __slots__ = ("pf", "Wpos", "bpos", "P", "dW", "db", "dtype")
+
+    def __init__(self, pf, Wpos, bpos, dtype):
+        self.pf, self.Wpos, self.bpos, self.P, self.dtype = pf, Wpos, bpos, Wpos.shape[0], dtype
+        self.dW = self.db = None
+
+    def usable(self, Cin, Cout, dt):
+        vn = 8 if dt == torch.bfloat16 else 4
+        return dt == self.dtype and Cin > self.P and Cout % vn == 0 and self.dW is None
+
+    def backward(self, draw, wd, B, L, Lo, Cout, Cin, k, stride, pad, code):
+        dW, db = grad_buffer(self.Wpos), grad_buffer(self.bpos)
+        ops.conv_tail_bwd(draw, Cout, B, Lo, Cout, wd[Cin - self.P:], k * Cout, k, stride, pad, self.pf, L, self.P, dW, db, code)
+        self.dW, self.db = dW, db
+
+    def take(self):
+        dW, db, self.dW, self.db = self.dW, self.db, None, None
+        return dW, db
+
+
 class _InputStageFn(torch.autograd.Function):
     """prop_fc + level-0 query gating + position embedding, written into one (B, T, D+P) buffer that is conv0's
     input (model/main_model.py:51-59,67 + model/backbone.py:28-32: Linear, `q * x`, cat) -- one MFMA GEMM whose
     epilogue adds the bias, keeps the pre-gate value for backward and applies the gate, plus one tiny kernel."""
 
     @staticmethod
-    def forward(ctx, prep, Wfc, bfc, gate0, Wpos, bpos):
+    def forward(ctx, prep, Wfc, bfc, gate0, Wpos, bpos, tail):
         dtype = prep.dtype
         code = code_of(dtype)
         B, T, D = prep.dims
@@ -1053,6 +1089,7 @@ class _InputStageFn(torch.autograd.Function):
         ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
         ctx.dtype, ctx.dims = dtype, (B, T, D, P)
         ctx.param_refs = (Wfc, bfc, Wpos, bpos)
+        ctx.tail = tail
         ctx.save_for_backward(xc, pf, gate0, Z, xcT if xcT is not None else xc.new_empty(0))
         return G0
 
@@ -1067,7 +1104,11 @@ class _InputStageFn(torch.autograd.Function):
         dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
         dsum = torch.empty((B, D), dtype=torch.float32, device=dev)      # per-clip column sums of dZ: prop_fc bias gradient
         Wfc, bfc, Wpos, bpos = ctx.param_refs
-        dW, db, dWp, dbp = grad_buffer(Wfc), grad_buffer(bfc), grad_buffer(Wpos), grad_buffer(bpos)
+        dW, db = grad_buffer(Wfc), grad_buffer(bfc)
+        dWp, dbp = ctx.tail.take() if ctx.tail is not None else (None, None)
+        from_tail = dWp is not None            # the conv block that read G0 has already produced them (EmbedTail)
+        if not from_tail:
+            dWp, dbp = grad_buffer(Wpos), grad_buffer(bpos)
         dZ = dZT = None
         if xcT.numel() and T % 32 == 0:
             # dW[n][c] = sum_m dZ[m][n] * x[m][c] as an NT product of the K-major copies dZ^T (D, B*T) and x^T (D, B*T):
@@ -1091,13 +1132,17 @@ class _InputStageFn(torch.autograd.Function):
             else:
                 ops.gemm_wgrad([ops.wgrad_desc(dZ, xc, B * T, ldy=D, ldx=D)], jW, D, D, taps=1, w_layout=0, dtype=code)
             ops.colsum(dsum, D, B, D, jb, ops.F32)
-            ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, jWp, jbp, code)
+            if not from_tail:
+                ops.pos_embed_bwd(dG0.view(B * T, D + P)[:, D:], D + P, pf, B * T, P, jWp, jbp, code)
         _defer(wgrads, jW, jb, jWp, jbp)
-        return None, dW, db, dgate, dWp, dbp
+        return None, dW, db, dgate, dWp, dbp, None
 
 
-def input_stage(prep, prop_fc, gate0, position_transform):
-    return _InputStageFn.apply(prep, prop_fc.weight, prop_fc.bias, gate0, position_transform.weight, position_transform.bias)
+def input_stage(prep, prop_fc, gate0, position_transform, with_tail=False):
+    """with_tail: also return the EmbedTail to hand to the conv block that reads the result (conv_block(..., tail=))."""
+    tail = EmbedTail(prep.pf, position_transform.weight, position_transform.bias, prep.dtype) if with_tail else None
+    g0 = _InputStageFn.apply(prep, prop_fc.weight, prop_fc.bias, gate0, position_transform.weight, position_transform.bias, tail)
+    return (g0, tail) if with_tail else g0
 
 
 class _HeadOutFn(torch.autograd.Function):

@@ -79,6 +79,7 @@ class TwoPhaseStep(object):
             gd = [g.detach().requires_grad_() for g in gates]
             g0, _ = m.forward_front(tok, qlen, feats, pse, gates=gd)
             g0d = g0.detach().requires_grad_()
+            g0d._drn_tail = getattr(g0, "_drn_tail", None)        # (conv0's backward produces the position-embedding gradients)
             _, losses = m.forward_trunk(g0d, gd, gt)
             DF.backward(self.loss_of(losses))                     # trunk parameters, g0d.grad, gd[1:].grad
             self._carry = (g0, g0d, gates, gd)

@@ -18,17 +18,19 @@ class Backbone(nn.Module):
             self.add_module(name, conv_block(cin, cout, kernel_size=k, stride=stride))
             self.blocks.append(name)
 
-    def forward_from_stage(self, g0, gates):
+    def forward_from_stage(self, g0, gates, tail=None):
         """g0: (B, T, D+P) channels-last = cat(q0 * prop_fc(x), position feats) (drn_amd.functional.input_stage);
         gates[i]: (B, C_i) fp32.  The gate of level i+1 is fused into level i's BN-apply pass.  g0 may arrive in float32
         inside a bfloat16 model (feature dim not a 16-byte multiple in bf16): conv0 then runs on the exact-f32 kernels
-        and its outputs are cast to the model's compute dtype."""
+        and its outputs are cast to the model's compute dtype.  tail: the EmbedTail input_stage returned with g0 (conv0's
+        backward then produces the position-embedding gradients itself and skips those columns of its input gradient)."""
         outs, x = [], g0
         dt = self.compute_dtype
         for idx in range(self.num_layers):
             nxt = gates[idx + 1] if idx + 1 < self.num_layers else None
             conv, bn = conv_bn(getattr(self, self.blocks[idx]), "Backbone." + self.blocks[idx])
-            out, gated = DF.conv_block([x], conv, bn, self.training, x.dtype if idx == 0 else dt, gate=nxt)
+            out, gated = DF.conv_block([x], conv, bn, self.training, x.dtype if idx == 0 else dt, gate=nxt,
+                                       tail=tail if idx == 0 else None)
             outs.append(DF.cast_act(out[0], dt))
             x = DF.cast_act(gated, dt) if gated is not None else None
         return outs

@@ -117,12 +117,13 @@ class mainModel(nn.Module):
             prep = self.prepare_input(props_features, props_start_end)
         if gates is None:
             gates = self.encode_query(query_tokens, query_length)
-        g0 = DF.input_stage(prep, self.prop_fc, gates[0], self.position_transform)
+        g0, tail = DF.input_stage(prep, self.prop_fc, gates[0], self.position_transform, with_tail=True)
+        g0._drn_tail = tail          # rides on the tensor object to forward_trunk (a caller that replaces g0 simply loses it)
         return g0, gates
 
     def forward_trunk(self, g0, gates, gt_start_end):
         """Backbone (gates[1:] only: level 0 is already applied), FPN, heads, losses / post-processor."""
-        backbone_feats = self.backbone_net.forward_from_stage(g0, gates)
+        backbone_feats = self.backbone_net.forward_from_stage(g0, gates, tail=getattr(g0, "_drn_tail", None))
         feats = self.fpn.forward_nlc(backbone_feats)
         head = self.fcos.head
         logits, reg, iou, geo = head.forward_nlc(feats)

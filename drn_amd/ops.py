@@ -333,6 +333,14 @@ def pos_embed_bwd(dout, ld, feat, M, C, dW, db, dtype, accumulate=False):
           "drn_pos_embed_bwd")
 
 
+def conv_tail_bwd(dY, ld_dy, B, Lo, Cout, wd_tail, ldw, k, stride, pad, feat, L, P, dW, db, dtype, accumulate=False):
+    """Position-embedding gradients through the conv that reads the embedding (drn_conv_tail_bwd)."""
+    L_ = lib()
+    ws = workspace(int(L_.drn_conv_tail_bwd_ws_elems(B * Lo, k, Cout)), dW.device)
+    check(L_.drn_conv_tail_bwd(_p(dY), ld_dy, B, Lo, Cout, _p(wd_tail), ctypes.c_int64(ldw), k, stride, pad, _p(feat), L, P, _p(dW),
+                               _p(db), int(accumulate), _p(ws), dtype, _stream()), "drn_conv_tail_bwd")
+
+
 def pairsum_add(dst, ld_dst, src, ld_src, Mdst, C, dtype, accumulate=True):
     check(lib().drn_pairsum_add(_p(dst), ld_dst, _p(src), ld_src, Mdst, C, int(accumulate), dtype, _stream()), "drn_pairsum_add")
 

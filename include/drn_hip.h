@@ -135,6 +135,16 @@ int drn_pos_embed_fwd(const float* feat /*[M][3]*/, const float* W /*[C][3]*/, c
                       int dtype, void* stream);
 int drn_pos_embed_bwd(const void* dout, int ld, const float* feat, int M, int C, float* dW, float* db, int accumulate,
                       float* ws /* >= 1024*C floats */, int dtype, void* stream);
+/* The same two gradients taken THROUGH the convolution that reads the embedding as the last P of its Cin input channels
+ * (model/backbone.py:31-32 cat -> forward_conv0), from the gradient dY (B*Lo rows x Cout) at that conv's output, so that the conv's
+ * input-gradient product can leave those P columns out:  Q[tap][j][o] = sum_rows dY[s,to,o] * f[s*L + to*stride - pad + tap][j]
+ * (f[.][3] = 1, rows outside [0, L) skipped), dW[c][j] = sum_{tap,o} Wd[c][tap*Cout + o] * Q[tap][j][o], db[c] = column j = 3.
+ * Wd: row Cin-P of the (Cin, k, Cout) copy of the conv weight in `dtype` (ldw elements between rows); k = 1 or 3;
+ * ws >= drn_conv_tail_bwd_ws_elems(B*Lo, k, Cout) floats. */
+int64_t drn_conv_tail_bwd_ws_elems(int M, int k, int Cout);
+int drn_conv_tail_bwd(const void* dY, int ld_dy, int B, int Lo, int Cout, const void* Wd, int64_t ldw, int k, int stride, int pad,
+                      const float* feat /*[B*L][3]*/, int L, int P, float* dW /*[P][3]*/, float* db /*[P]*/, int accumulate,
+                      float* ws, int dtype, void* stream);
 /* backward of F.interpolate(nearest, x2) + add (model/FPN.py:63-68): dst[s,t] += src[s,2t] + src[s,2t+1] */
 int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst, int C, int accumulate, int dtype, void* stream);
 /* out-of-place form: dst[s,t] = base[s,t] + src[s,2t] + src[s,2t+1] (base = the level's own incoming gradient) */

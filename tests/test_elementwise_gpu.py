@@ -79,6 +79,40 @@ def test_pos_embed_bwd(dt, M, C, accumulate):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,L,Cout,P,k,stride", [(2, 8, 16, 8, 3, 1), (32, 256, 256, 256, 3, 1), (5, 50, 264, 40, 3, 2), (3, 33, 72, 12, 1, 1),
+                                                 (40, 256, 64, 256, 3, 2)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_conv_tail_bwd(dt, B, L, Cout, P, k, stride, accumulate):
+    """Position-embedding gradients through the conv that reads the embedding == the conv's input gradient on those channels
+    (conv_transpose of dY with the weight slice) reduced against the row features (model/backbone.py:31-32, main_model.py:51-55)."""
+    import torch.nn.functional as F
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda:0"
+    pad = (k - 1) // 2
+    Lo = (L + 2 * pad - k) // stride + 1
+    dY = torch.randn(B, Lo, Cout, generator=g).to(dt)
+    Cin = P + 24
+    wd = (torch.randn(Cin, k, Cout, generator=g) / (k * Cout) ** 0.5).to(dt)          # the (Cin, k, Cout) copy
+    feat = torch.rand(B * L, 3, generator=g)
+    dW0, db0 = torch.randn(P, 3, generator=g), torch.randn(P, generator=g)
+    dW, db = dW0.to(dev), db0.to(dev)
+    dYd, wdd = dY.to(dev), wd.to(dev)
+    ops.conv_tail_bwd(dYd, Cout, B, Lo, Cout, wdd[Cin - P:], k * Cout, k, stride, pad, feat.to(dev), L, P, dW, db, _code(dt),
+                      accumulate=accumulate)
+    w_oik = wd[Cin - P:].double().permute(2, 0, 1)                                        # (Cout, P, k)
+    dx = F.conv_transpose1d(dY.double().permute(0, 2, 1), w_oik, stride=stride, padding=pad,
+                            output_padding=L - ((Lo - 1) * stride - 2 * pad + k))         # (B, P, L)
+    d = dx.permute(0, 2, 1).reshape(B * L, P)
+    want_W = d.t() @ feat.double() + (dW0.double() if accumulate else 0)
+    want_b = d.sum(0) + (db0.double() if accumulate else 0)
+    tol = 1e-4                                             # (bf16 operands are exact inputs here; products and sums are fp32)
+    scale = float(want_W.abs().max())
+    assert float((dW.double().cpu() - want_W).abs().max()) <= tol * max(scale, 1.0)
+    assert float((db.double().cpu() - want_b).abs().max()) <= tol * max(float(want_b.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,C", [(1, 8), (32, 4096), (127, 24), (128, 24), (5000, 520)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_colsum(dt, M, C, accumulate):

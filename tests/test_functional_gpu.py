@@ -12,10 +12,10 @@ DEV = "cuda:0"
 TOL = {torch.float32: 3e-5, torch.bfloat16: 4e-2}
 
 
-def close(got, ref, tol, what):
+def close(got, ref, tol, what, scale=None):
     got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     err = float((got - ref).abs().max())
-    scale = max(float(ref.abs().max()), 1e-3)
+    scale = max(float(ref.abs().max()), 1e-3) if scale is None else scale
     assert err <= tol * scale, "%s: max|err| %.3e > %.1e * %.3g" % (what, err, tol, scale)
 
 
@@ -158,6 +158,65 @@ def test_input_stage_fwd_bwd(dt):
     close(fch.bias.grad, fc.bias.grad, tol * 3, "db prop_fc")
     close(pth.weight.grad, pt.weight.grad, tol * 3, "dW pos")
     close(pth.bias.grad, pt.bias.grad, tol * 3, "db pos")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,stride,T", [(3, 1, 32), (3, 2, 32), (1, 1, 24), (3, 1, 19)])
+def test_input_stage_into_conv_with_tail(dt, k, stride, T):
+    """input_stage -> conv block (model/backbone.py:28-33 at level 0) with the EmbedTail link: the conv's backward takes the
+    position-embedding gradients through the conv and leaves those columns out of its input gradient; every gradient of both
+    stages against fp64 autograd."""
+    from drn_amd import functional as DF
+    B, D, P, Cout = 3, 64, 32, 64
+    torch.manual_seed(0)
+    fc, pt = nn.Linear(D, D).double(), nn.Linear(3, P).double()
+    feats = q(torch.rand(B, T, D, generator=torch.Generator().manual_seed(1), dtype=torch.float64).float().double(), dt)
+    with torch.no_grad():
+        fc.weight.copy_(q(fc.weight, dt))
+    pos = rnd(B, T, 3, seed=2).float().double()
+    gate = rnd(B, D, seed=3).float().double().requires_grad_()
+    w = q(rnd(Cout, D + P, k, seed=11) / np.sqrt((D + P) * k), dt).requires_grad_()
+    gamma = (rnd(Cout, seed=1).abs() + 0.5).requires_grad_()
+    beta = (rnd(Cout, seed=2) * 0.3).requires_grad_()
+    g0r = torch.cat([fc(feats) * gate[:, None, :], pt(pos)], dim=2)
+    if dt == torch.bfloat16:
+        g0r = g0r + (g0r.bfloat16().double() - g0r).detach()
+    y, _, _ = ref_block(g0r.permute(0, 2, 1), w, gamma, beta, stride, dt)
+    w1 = rnd(*y.shape, seed=6)
+    (y * w1).sum().backward()
+    fch, pth = nn.Linear(D, D).to(DEV), nn.Linear(3, P).to(DEV)
+    conv_h = nn.Conv1d(D + P, Cout, k, stride=stride, padding=(k - 1) // 2, bias=False).to(DEV)
+    bn_h = nn.BatchNorm1d(Cout).to(DEV)
+    with torch.no_grad():
+        fch.weight.copy_(fc.weight.float()); fch.bias.copy_(fc.bias.float())
+        pth.weight.copy_(pt.weight.float()); pth.bias.copy_(pt.bias.float())
+        conv_h.weight.copy_(w.float()); bn_h.weight.copy_(gamma.float()); bn_h.bias.copy_(beta.float())
+    qh = gate.detach().float().to(DEV).requires_grad_()
+    prep = DF.input_prep(feats.float().to(DEV), pos.float().to(DEV), fch, dt)
+    g0, tail = DF.input_stage(prep, fch, qh, pth, with_tail=True)
+    outs, _ = DF.conv_block([g0], conv_h, bn_h, True, dt, tail=tail)
+    (outs[0].float() * w1.permute(0, 2, 1).float().to(DEV)).sum().backward()
+    assert tail.dW is None and tail.db is None          # taken by the input stage's backward
+    tol = TOL[dt]
+    close(outs[0].permute(0, 2, 1), y, tol, "conv out")
+    close(pth.weight.grad, pt.weight.grad, tol * 3, "dW pos (through the conv)")
+    # (a 1-tap conv in front of a train-mode BN cancels a constant input shift: the true bias gradient is ~0 there, a sum of
+    # terms of the weight gradient's magnitude -- that magnitude is the scale)
+    wscale = float(pt.weight.grad.abs().max())
+    close(pth.bias.grad, pt.bias.grad, tol * 3, "db pos (through the conv)", scale=wscale)
+    close(qh.grad, gate.grad, tol * 3, "dgate0")
+    close(fch.weight.grad, fc.weight.grad, tol * 3, "dW prop_fc")
+    close(fch.bias.grad, fc.bias.grad, tol * 3, "db prop_fc")
+    close(conv_h.weight.grad, w.grad, tol * 3, "dW conv")
+    # and the same numbers as the path without the link (full input gradient + pos_embed_bwd) to rounding
+    for m in (fch, pth, conv_h, bn_h):
+        m.zero_grad(set_to_none=True)
+    qh2 = gate.detach().float().to(DEV).requires_grad_()
+    g0b = DF.input_stage(prep, fch, qh2, pth)
+    outs2, _ = DF.conv_block([g0b], conv_h, bn_h, True, dt)
+    (outs2[0].float() * w1.permute(0, 2, 1).float().to(DEV)).sum().backward()
+    close(pth.weight.grad, pt.weight.grad, tol * 3, "dW pos (plain path)")
+    close(pth.bias.grad, pt.bias.grad, tol * 3, "db pos (plain path)", scale=wscale)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
