@@ -306,6 +306,63 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
 #pragma unroll
     for (int ch = 0; ch < MI / 2; ++ch) {
       const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        // Fast path (bf16, the chunk's 32 rows x WCOLS columns all inside the matrix and -- if gated -- inside ONE sequence, no
+        // accumulate): the generic path below costs one ds_write_b16, one row -> sequence division and one gate load PER ELEMENT
+        // behind per-element masks (the 256x256 tile's epilogue took 6.9 us, mostly this).  Here the gate row is loaded once
+        // per chunk, and the 4 rows x 4 columns a quad of lanes holds are transposed inside the quad (packed bf16 pairs: 3 DPP
+        // moves + 2 byte permutes + 3 selects) so that every lane owns 4 consecutive columns of one row: one ds_write_b64 where
+        // there were four ds_write_b16.  Same conversions, same values, same 16-byte global stores.
+        const int ncol0 = n0 + wc * WCOLS;
+        const int sq0 = mrow0 / pr.Lout;
+        const bool fast_w = mrow0 + 32 <= M && ncol0 + WCOLS <= N && !pr.accumulate &&
+                            (!pr.gate || (mrow0 + 31) / pr.Lout == sq0);
+        if (__builtin_amdgcn_readfirstlane((int)fast_w)) {
+          float gv[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) gv[ni] = pr.gate ? pr.gate[(long)sq0 * pr.ldg + ncol0 + ni * 16 + (l & 15)] : 1.f;
+          const bool j0 = l & 1, j1 = l & 2;
+          const unsigned sel1 = j0 ? 0x03020706u : 0x05040100u;
+          for (int pass = 0; pass < npass; ++pass) {
+            const bool gated = pr.gate && pass == npass - 1;
+            T* dst = (C2g && pass == 0) ? C2g : Cg;
+            const int ldd = (C2g && pass == 0) ? pr.ldc2 : pr.ldc;
+#pragma unroll
+            for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  v[r] = acc[ch * 2 + mi2][ni][r] + bias_v[ni];
+                  if (gated) v[r] *= gv[ni];
+                }
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t b01 = {(bf16_t)v[0], (bf16_t)v[1]}, b23 = {(bf16_t)v[2], (bf16_t)v[3]};
+                const unsigned p0 = __builtin_bit_cast(unsigned, b01), p1 = __builtin_bit_cast(unsigned, b23);   // (row r, row r+1) of this lane's column
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p0, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p1, 0xB1, 0xf, 0xf, false);
+                // even lane: (own.lo, partner.lo) = row 2*r1, columns (j, j+1); odd lane: (partner.hi, own.hi) = row 2*r1 + 1, columns (j-1, j)
+                const unsigned q0 = __builtin_amdgcn_perm(r0, p0, sel1), q1 = __builtin_amdgcn_perm(r1, p1, sel1);
+                const unsigned snd = j1 ? q0 : q1;
+                const unsigned rcv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                const unsigned o0 = j1 ? rcv : q0, o1 = j1 ? q1 : rcv;         // row (l & 3), columns 0-1 and 2-3 of the quad's four
+                const int rl = mi2 * 16 + (l >> 4) * 4 + (l & 3);
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                *(u32x2_t*)(wbuf + rl * PITCH + (ni * 16 + ((l & 15) >> 2) * 4) * 2) = (u32x2_t){o0, o1};
+              }
+            wave_lds_sync();
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+              const int rl = it * RPI + l / LPR, cv = l % LPR;
+              const uint4 raw = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
+              *(uint4*)(dst + ((long)(mrow0 + rl) * ldd + ncol0 + cv * VEC)) = raw;
+            }
+            wave_lds_sync();
+          }
+          continue;
+        }
+      }
       for (int pass = 0; pass < npass; ++pass) {
         const bool gated = pr.gate && pass == npass - 1;
         T* dst = (C2g && pass == 0) ? C2g : Cg;
