@@ -217,14 +217,14 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
     }
     return;
   }
-  if (pr.stats) {
+  auto bn_stats = [&](float* shs) {
     // BatchNorm statistics of the raw fp32 accumulators per 128-row slab, in the numerically robust (count, sum, M2)
     // form: stats[(slab*2 + 0)*N + n] = sum_rows x, stats[(slab*2 + 1)*N + n] = sum_rows (x - slab mean)^2.
     // bn_finalize_kernel merges the slabs with Chan's parallel-variance formula (no E[x^2]-E[x]^2 cancellation).
     constexpr int WROWS = MI * 16;            // rows owned by one wave row: 64 or 128
     constexpr int WPS = 128 / WROWS;          // wave rows per 128-row slab
     constexpr int SLABS = TM / 128;
-    float* shs = (float*)smem;                // [WM][TN] partial sums, then [SLABS][TN] slab means
+    // shs: [WM][TN] partial sums, then [SLABS][TN] slab means
     float* shm = shs + WM * TN;
     // pass 1: column sums (rows >= M hold exact zeros)
 #pragma unroll
@@ -279,13 +279,18 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
         pr.stats[((long)grow * 2 + 1) * N + n0 + n] = v;
       }
     }
-  }
+  };
 
   T* __restrict__ Cg = (T*)pr.C;
   T* __restrict__ C2g = (T*)pr.C2;
   constexpr int VEC = 16 / (int)sizeof(T);
   const bool vec_ok = (pr.ldc % VEC == 0) && (((uintptr_t)Cg & 15) == 0) &&
                       (!C2g || ((pr.ldc2 % VEC == 0) && (((uintptr_t)C2g & 15) == 0)));
+  const bool stats_first = !vec_ok;
+  if (stats_first && pr.stats) {
+    bn_stats((float*)smem);
+    __syncthreads();
+  }
   if (vec_ok) {
     // Coalesced epilogue: every wave transposes its slab (NI*16 columns) through a private LDS patch, 32 rows at a time, and
     // writes it out as 16-byte row segments (8 store instructions per wave and 64x64 bf16 tile instead of 64 two-byte
@@ -294,7 +299,6 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
     constexpr int PITCH = WCOLS * (int)sizeof(T) + 16;       // bytes per staged row (+16: conflict-free column writes)
     constexpr int LPR = WCOLS * (int)sizeof(T) / 16;         // lanes per staged row in the 16-byte read-back
     constexpr int RPI = 64 / LPR;                            // rows per read-back instruction
-    __syncthreads();                                         // stats (if any) are done with LDS
     char* wbuf = smem + w * (32 * PITCH);
     float bias_v[NI];
 #pragma unroll
@@ -406,6 +410,10 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
         wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
       }
     }
+    // BatchNorm statistics AFTER the stores have been issued: the tile's write burst (the whole chip stores at once: 3-6 us at the
+    // HBM write rate) drains while the three-barrier statistics pass runs, instead of starting behind it.  The statistics use the
+    // LDS beyond the per-wave store patches.
+    if (pr.stats && !stats_first) bn_stats((float*)(smem + NW * (32 * PITCH)));
     return;
   }
 #pragma unroll

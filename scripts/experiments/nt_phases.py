@@ -12,15 +12,17 @@ dt = torch.bfloat16
 big = torch.empty(1 << 28, device=dev)
 # (name, [(clips, L)], N, Cin, taps, stride)
 shapes = [("conv1 fwd  M=4096 N=512 K=768", [(32, 128)], 512, 256, 3, 1), ("laterals-like M=8192 N=512 K=256", [(32, 256)], 512, 256, 1, 1),
-          ("level convs g=3 N=512 K=1536", [(32, 256), (32, 128), (32, 64)], 512, 512, 3, 1), ("prop_fc M=8192 N=4096 K=4096", [(32, 256)], 4096, 4096, 1, 1)]
+          ("level convs g=3 N=512 K=1536", [(32, 256), (32, 128), (32, 64)], 512, 512, 3, 1),
+          ("towers g=3 N=1024 K=1536", [(32, 256), (32, 128), (32, 64)], 1024, 512, 3, 1), ("prop_fc M=8192 N=4096 K=4096", [(32, 256)], 4096, 4096, 1, 1)]
 for name, levels, N, Cin, taps, stride in shapes:
     W = torch.randn(N, taps * Cin, device=dev).to(dt)
     descs, keep = [], []
     for b, L in levels:
         A = torch.randn(b * L, Cin, device=dev).to(dt)
         C = torch.empty(b * L, N, device=dev, dtype=dt)
-        descs.append(ops.gemm_desc(A, W, C, b * L, N, Cin, taps=taps, pad=(taps - 1) // 2, Lout=L, Lsrc=L))
-        keep.append((A, C))
+        st = torch.empty(((b * L + 127) // 128, 2, N), device=dev, dtype=torch.float32) if taps > 1 or Cin < 4096 else None   # conv blocks: BN statistics in the epilogue
+        descs.append(ops.gemm_desc(A, W, C, b * L, N, Cin, taps=taps, pad=(taps - 1) // 2, Lout=L, Lsrc=L, stats=st))
+        keep.append((A, C, st))
     for cold in (False, True):
         for _ in range(3):
             if cold:
