@@ -67,10 +67,13 @@ def nlc(x_ncl):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(300, 200, 264), (128, 128, 64), (1024, 512, 4096), (64, 40, 72)])
-def test_linear_fwd_bias_gate(dt, M, N, K):
+@pytest.mark.parametrize("M,N,K,T", [(300, 200, 264, 4), (128, 128, 64, 4), (1024, 512, 4096, 4), (64, 40, 72, 4), (1024, 512, 256, 64),
+                                     (768, 320, 128, 96), (4096, 4096, 128, 32)])
+def test_linear_fwd_bias_gate(dt, M, N, K, T):
+    """T = rows per gate row (sequence length).  T = 4: every 32-row store chunk spans several sequences (the per-element epilogue);
+    T = 64 / 32: chunks lie inside one sequence (bf16: the quad-transposed fast path, gate row loaded once per chunk); T = 96: both
+    kinds in one launch; the last shape runs the 256x256 tile."""
     from drn_amd import ops
-    T = 4 if M % 4 == 0 else 1
     A, W = rnd((M, K), 1, DT[dt]), rnd((N, K), 2, DT[dt])
     bias = rnd((N,), 3, torch.float32)
     gate = rnd((M // T, N), 4, torch.float32)
@@ -85,6 +88,14 @@ def test_linear_fwd_bias_gate(dt, M, N, K):
     torch.cuda.synchronize()
     close(C2, pre, TOL[dt] * np.sqrt(K / 64), "pre-gate")
     close(C, ref, TOL[dt] * np.sqrt(K / 64), "gated")
+    # the same product into buffers whose row pitch is no 16-byte multiple takes the element-by-element epilogue: same bits
+    Cw = torch.full((M, N + 2), float("nan"), dtype=DT[dt], device=dev())
+    C2w = torch.full((M, N + 2), float("nan"), dtype=DT[dt], device=dev())
+    d2 = ops.gemm_desc(Ad, Wd, Cw, M, N, K, Lout=T, bias=bias_d, gate=gate_d, ldg=N, C2=C2w, ldc=N + 2, ldc2=N + 2)
+    ops.gemm_nt([d2], ops.dtype_code(Ad))
+    torch.cuda.synchronize()
+    assert torch.equal(Cw[:, :N], C) and torch.equal(C2w[:, :N], C2)
+    assert bool(torch.isnan(Cw[:, N:].float()).all())          # nothing written beyond N
 
 
 def conv_case(dt, B, L, Cin, Cout, k, s, seed=0):
