@@ -5,6 +5,7 @@ libdrn_hip.so call on torch's current HIP stream.  Missing library or a non-zero
 return code raises (no fallback).
 """
 import ctypes
+import os
 
 import torch
 
@@ -56,6 +57,11 @@ kernel_timer = None
 # operands the 12-48-step pyramid GEMMs gain nothing from it (the exchange costs 4-8 us: scripts/bench_splitk.py), but inside
 # the step, where their operands are cold, 2-4 splits of >= 12 K-steps each put twice the loads in flight: -25 us per step.
 SPLITK_MIN_KSTEPS = 24
+# Workgroups a split launch aims for.  256 = one 8-wave workgroup per CU on the 4-slot ring (three K-tiles of loads in flight
+# against cold operands) rather than 512 = two per CU on 2-slot rings: conv0's forward (128 tiles x 204 K-steps) 4 -> 2 splits, the
+# step 2.222 -> 2.209 ms at T = 256 in one process (384: 2.237, 192 = conv0 unsplit: 2.27), T = 32 unchanged
+# (scripts/experiments/ab_env.sh DRN_KSPLIT_WGS 512 384 256 192).
+KSPLIT_WGS = int(os.environ.get("DRN_KSPLIT_WGS", "256"))
 
 
 def _timed(tag, flops, launch):
@@ -78,7 +84,7 @@ def _ksplit(descs, dtype):
         return 1
     if tiles > 160 or nkt < (SPLITK_MIN_KSTEPS if dtype == BF16 else 96):
         return 1
-    return max(1, min(8, 512 // tiles, nkt // (12 if dtype == BF16 else 6)))
+    return max(1, min(8, (KSPLIT_WGS if dtype == BF16 else 512) // tiles, nkt // (12 if dtype == BF16 else 6)))
 
 
 def gemm_nt(descs, dtype):
