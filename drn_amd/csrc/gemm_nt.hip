@@ -752,7 +752,8 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     big_tiles += (long)cdiv(s.M, 256) * cdiv(s.N, 256);
     if (s.Cin % (8 * ch) != 0 || (s.mode == 1 && s.stride > 2)) fast = false;
   }
-  int tile = big_tiles >= 200 ? 256 : 128;
+  const int big_min = drn_tuning(DRN_TUNE_EXP0) > 0 ? drn_tuning(DRN_TUNE_EXP0) : 200;     // (exp0: experiment override)
+  int tile = big_tiles >= big_min ? 256 : 128;
   if (const char* e = drn_exp_env("DRN_NT_TILE")) tile = atoi(e) == 256 ? 256 : 128;
   if (drn_exp_env("DRN_NT_GENERIC")) fast = false;
   GemmParams P;
@@ -762,6 +763,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   P.ws = ws;
   P.counters = counters;
   P.xcd_swizzle = drn_exp_env("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
+  if (drn_tuning(DRN_TUNE_EXP0 + 3) > 0) P.xcd_swizzle = drn_tuning(DRN_TUNE_EXP0 + 3) - 1;   // (exp3: experiment override, value - 1)
   if (const char* e = drn_exp_env("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);      // bit 0: XCD-contiguous runs, bit 1: 8-row grouped order
   if (ksplit > 1) tile = 128;
   int total = 0;

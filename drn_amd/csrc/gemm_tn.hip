@@ -748,7 +748,8 @@ static int wgrad_tile(int N, int Cin, int taps) {
 static int wgrad_nsplit(int total_blks, int N, int Cin, int taps) {
   const int tile = wgrad_tile(N, Cin, taps);
   const int tiles = cdiv(N, tile) * taps * cdiv(Cin, tile);
-  int ns = cdiv(tile == 256 ? 256 : 768, tiles);   // ~1 (8-wave) or ~3 (4-wave) workgroups per CU
+  const int tgt = drn_tuning(DRN_TUNE_EXP0 + 2) > 0 ? drn_tuning(DRN_TUNE_EXP0 + 2) : 768;      // (exp2: experiment override)
+  int ns = cdiv(tile == 256 ? 256 : tgt, tiles);   // ~1 (8-wave) or ~3 (4-wave) workgroups per CU
   // every split must own enough row blocks to amortise its fp32 partial tile (write + re-read in the reduce pass)
   const int cap = total_blks / 12;
   if (ns > cap) ns = cap;
@@ -764,7 +765,7 @@ static int total_blocks_upper(int M_total, int ngroups_max) {
 
 // fused 3-tap kernel (conv_wgrad3_tn_kernel): one 8-wave workgroup per CU; row splits fill the chip once.
 static int wgrad3_nsplit(int m_total, int N, int Cin) {
-  int target = 256;
+  int target = drn_tuning(DRN_TUNE_EXP0 + 1) > 0 ? drn_tuning(DRN_TUNE_EXP0 + 1) : 256;      // (exp1: experiment override)
   if (const char* e = drn_exp_env("DRN_TN3_TARGET")) target = atoi(e);
   const int tiles = cdiv(N, 128) * cdiv(Cin, 128);
   int ns = target / tiles;
