@@ -488,7 +488,7 @@ def _defer(job, *grad_bufs):
 
 
 NT_WGRAD = True      # prop_fc weight gradient through the NT kernel on transposed operands (bf16): 250 vs 410 us for the TN kernel
-TOUCH_W = True       # warm the prop_fc weight copy right before its GEMM (round 2 re-measured: 2.562 vs 2.577 ms without)
+TOUCH_W = os.environ.get("DRN_TOUCH_W", "1") != "0"       # warm the prop_fc weight copy right before its GEMM (round 2 re-measured: 2.562 vs 2.577 ms without)
 
 # BatchNorm `num_batches_tracked` increments are collected during a forward pass and applied by ONE multi-tensor add
 # (flush_bn_counters) instead of one tiny launch per BN call.

@@ -56,7 +56,8 @@ kernel_timer = None
 # fill the chip (<= 160 tiles of 128x128 on 256 CUs): conv0 forward (128 tiles x 204 K-steps) 157 -> 69 us 4-way.  With warm
 # operands the 12-48-step pyramid GEMMs gain nothing from it (the exchange costs 4-8 us: scripts/bench_splitk.py), but inside
 # the step, where their operands are cold, 2-4 splits of >= 12 K-steps each put twice the loads in flight: -25 us per step.
-SPLITK_MIN_KSTEPS = 24
+SPLITK_MIN_KSTEPS = int(os.environ.get("DRN_SPLITK_MIN_KSTEPS", "24"))
+SPLITK_STEPS_PER_SPLIT = int(os.environ.get("DRN_SPLITK_STEPS", "12"))     # a bf16 split owns at least that many K-steps
 # Workgroups a split launch aims for.  256 = one 8-wave workgroup per CU on the 4-slot ring (three K-tiles of loads in flight
 # against cold operands) rather than 512 = two per CU on 2-slot rings: conv0's forward (128 tiles x 204 K-steps) 4 -> 2 splits, the
 # step 2.222 -> 2.209 ms at T = 256 in one process (384: 2.237, 192 = conv0 unsplit: 2.27), T = 32 unchanged
@@ -84,7 +85,7 @@ def _ksplit(descs, dtype):
         return 1
     if tiles > 160 or nkt < (SPLITK_MIN_KSTEPS if dtype == BF16 else 96):
         return 1
-    return max(1, min(8, (KSPLIT_WGS if dtype == BF16 else 512) // tiles, nkt // (12 if dtype == BF16 else 6)))
+    return max(1, min(8, (KSPLIT_WGS if dtype == BF16 else 512) // tiles, nkt // (SPLITK_STEPS_PER_SPLIT if dtype == BF16 else 6)))
 
 
 def gemm_nt(descs, dtype):
