@@ -239,7 +239,8 @@ __global__ __launch_bounds__(QD_THREADS) void skinny_group_kernel(const SkGroupA
 static int qd_ksplit(int tiles_long, int K) {
   if (K < 1024) return 1;
   int ks = 1;
-  while (ks < 16 && tiles_long * ks < 256 && K / (2 * ks) >= 256) ks *= 2;
+  const int tgt = drn_tuning(DRN_TUNE_EXP0 + 4) > 0 ? drn_tuning(DRN_TUNE_EXP0 + 4) : 256;      // (exp4: experiment override)
+  while (ks < 16 && tiles_long * ks < tgt && K / (2 * ks) >= 256) ks *= 2;
   return ks;
 }
 static int qd_tiles_long(const DrnSkinnyDesc* d, int n) {
