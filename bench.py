@@ -124,6 +124,21 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
             key = "T%d_%s" % (T, "graph" if graph else "eager")
             out[key] = {"clips_per_s": round(B * len(batches) * n_ep / dt, 1), "ms_per_step": round(dt / (len(batches) * n_ep) * 1e3, 3),
                         "graphs": len([s for s in tr._slots.values() if s.graph is not None]) if graph else 0}
+            if graph:
+                # the same loop fed from PINNED HOST batches (what a DataLoader hands over): the H2D copy of the fp32 features
+                # (B x T x D x 4 bytes per step) rides on the step's stream -- the PCIe-inclusive rate, never the headline value
+                hb = [tuple(t.cpu().pin_memory() if torch.is_tensor(t) else t for t in b) for b in batches]
+                tr.train_epoch(hb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_ep):
+                    tr.train_epoch(hb)
+                torch.cuda.synchronize()
+                dth = time.perf_counter() - t0
+                out["T%d_graph_host_inputs" % T] = {"clips_per_s": round(B * len(hb) * n_ep / dth, 1),
+                                                    "ms_per_step": round(dth / (len(hb) * n_ep) * 1e3, 3),
+                                                    "h2d_MB_per_step": round(B * T * D * 4 / 1e6, 1)}
+                del hb
             if graph and T == Ts[-1]:
                 # evaluation loop (main.py:270-366): eval-mode forward, post-processor, host-side NMS / R@k
                 ev = batches[:4]
@@ -138,7 +153,8 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
             del m, tr
     out["note"] = ("Trainer.train_epoch (what train.py runs) on 8 device-resident synthetic batches, B=%d, query lengths 3..8 padded to "
                    "multiples of 4; graph = hipGraph replay per input geometry (Trainer(graph=True), train.py's default), eager = every "
-                   "kernel launched from Python" % B)
+                   "kernel launched from Python; *_host_inputs = the graph loop fed from pinned host batches (H2D copy of the fp32 "
+                   "features inside the step: the PCIe-inclusive rate)" % B)
     return out
 
 

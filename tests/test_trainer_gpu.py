@@ -122,3 +122,31 @@ def test_graph_trainer_is_bit_identical_to_eager(dtype, stage):
     assert np.array_equal(np.array(l0), np.array(l1)), (l0, l1)
     for k in s0:
         assert torch.equal(s0[k], s1[k]), (k, float((s0[k].float() - s1[k].float()).abs().max()))
+
+
+def test_train_epoch_prefetches_host_batches_without_changing_anything():
+    """Trainer.train_epoch in graph mode moves the NEXT host batch to the device on a copy stream while the current step runs
+    (one batch of look-ahead); the epoch must leave the model exactly where the same batches handed over device-resident leave
+    it, whatever the memory kind (pinned or pageable) and with geometries alternating from step to step."""
+    from drn_amd import functional as DF
+    from drn_amd import trainer as T
+    B, Tp, D, n = 4, 32, 64, 6
+    raw = _varying_batches(n, B, Tp, D)
+    as_loader = lambda bs: [(["v"] * B, b[3], b[2], b[4], b[0], b[1], b[5], b[6]) for b in bs]     # collate_data's 8-tuple
+    kinds = {"device": [[t.to("cuda:0") if torch.is_tensor(t) else t for t in b] for b in raw],
+             "pinned": [[t.pin_memory() if torch.is_tensor(t) else t for t in b] for b in raw],
+             "pageable": raw}
+    states, means = {}, {}
+    for kind, bs in kinds.items():
+        m = hip_model(1)
+        m.set_compute_dtype(torch.bfloat16)
+        tr = T.Trainer(m, 1, lr=1e-4, clip_gradient=0.5, graph=True, lq_bucket=4)
+        means[kind] = [tr.train_epoch(as_loader(bs)) for _ in range(3)]      # warm-up, capture, replay
+        torch.cuda.synchronize()
+        DF.flush_bn_counters()
+        assert any(s.graph is not None for s in tr._slots.values())
+        states[kind] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for kind in ("pinned", "pageable"):
+        assert means[kind] == means["device"], (kind, means[kind], means["device"])
+        for k in states["device"]:
+            assert torch.equal(states[kind][k], states["device"][k]), (kind, k)
