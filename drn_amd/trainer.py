@@ -79,13 +79,23 @@ class _StepSlot(object):
         self.gt.copy_(gt, non_blocking=True)
 
 
+class _Preloaded(object):
+    """A batch whose tensors are already (being) copied into a step slot's input buffers on the copy stream."""
+    __slots__ = ("slot", "event", "batch_size")
+
+    def __init__(self, slot, event, batch_size):
+        self.slot, self.event, self.batch_size = slot, event, batch_size
+
+
 class Trainer(object):
     def __init__(self, model, stage, lr=1e-3, clip_gradient=0.5, world_size=1, fused=True, graph=False, lq_bucket=4,
-                 graph_warmup=2, max_graphs=16):
+                 graph_warmup=2, max_graphs=32, prefetch=None):
         """graph=True (fused stages only): `train_step` replays the step as a hipGraph -- the launch path bench.py measures --
         one capture per input geometry (clips, proposals, feature dim, query length rounded up to a multiple of `lq_bucket`:
-        the query kernels take the true lengths from the device, so padding changes no value); the first `graph_warmup`
-        steps of a geometry, a ragged last batch beyond `max_graphs` geometries and everything in stage 2 run eagerly.  With
+        the query kernels take the true lengths from the device, so padding changes no value) -- two, used in turn, when
+        `train_epoch` is fed from the host: while one replays, the other one's input buffers are filled from the next batch on a
+        copy stream (`prefetch`), so the H2D copy of the features overlaps the previous step.  The first `graph_warmup` steps of each capture, geometries beyond `max_graphs` captures and
+        everything in stage 2 run eagerly.  With
         world_size > 1 forward + backward replay and the gradient exchange + optimizer run eagerly after them."""
         self.model, self.stage, self.clip = model, stage, clip_gradient
         self.params, self.lr, self.default_epochs, self.which = stage_plan(model, stage, lr)
@@ -95,6 +105,9 @@ class Trainer(object):
         self.graph = bool(graph) and self.fused
         self.lq_bucket, self.graph_warmup, self.max_graphs = max(int(lq_bucket), 1), max(int(graph_warmup), 1), max_graphs
         self._slots = {}
+        self._turn = {}                                    # geometry -> uses so far (its two slots alternate)
+        self._copy_stream = None
+        self.prefetch = (os.environ.get("DRN_TRAINER_PREFETCH", "1") != "0") if prefetch is None else bool(prefetch)
         # every step of a graph-mode trainer -- eager ones included -- runs on ONE side stream: autograd's AccumulateGrad nodes
         # remember the stream they were created on, and warm-up, capture and replay must agree on it (drn_amd/graph.py)
         self.stream = torch.cuda.Stream(device=self.device) if self.graph else None
@@ -113,15 +126,23 @@ class Trainer(object):
             self.opt.zero_grad()
 
     # ------------------------------------------------------------------------------------------ hipGraph mode
-    def _slot_for(self, tok, feats, pse, gt):
+    def _slot_for(self, tok, feats, pse, gt, alternate=False):
+        """The slot the NEXT step of this geometry runs from, or None: eager step.  alternate (the look-ahead of train_epoch): the
+        geometry's two slots take turns, so that one can be filled while the other replays."""
         B, T, D = feats.shape
         Lq = -(-int(tok.shape[1]) // self.lq_bucket) * self.lq_bucket
-        key = (int(B), int(T), int(D), Lq)
+        geo = (int(B), int(T), int(D), Lq)
+        turn = self._turn.get(geo, 0)
+        key = geo + ((turn % 2) if alternate else 0,)
         slot = self._slots.get(key)
         if slot is None:
             if len(self._slots) >= self.max_graphs:
                 return None
-            slot = self._slots[key] = _StepSlot(key, self.device, pse.dtype, gt.dtype)
+            slot = self._slots[key] = _StepSlot(geo, self.device, pse.dtype, gt.dtype)
+        if pse.dtype != slot.pse.dtype or gt.dtype != slot.gt.dtype:
+            return None
+        if alternate:
+            self._turn[geo] = turn + 1
         return slot
 
     def _fwd_bwd(self, args):
@@ -136,18 +157,25 @@ class Trainer(object):
         self.opt.step()
 
     def _graph_step(self, args):
-        tok, qlen, feats, pse, gt = args[:5]
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)                       # inputs produced on the caller's stream
         whole = self.world_size == 1                       # one process: the optimizer replays with the rest
+        pre = args if isinstance(args, _Preloaded) else None
+        if pre is not None and pre.event is not None:
+            self.stream.wait_event(pre.event)              # the copy stream has filled the slot's input buffers
         with torch.cuda.stream(self.stream):
-            slot = self._slot_for(tok, feats, pse, gt)
-            if slot is None or pse.dtype != slot.pse.dtype or gt.dtype != slot.gt.dtype:
+            if pre is not None:
+                slot = pre.slot
+            else:
+                tok, qlen, feats, pse, gt = args[:5]
+                slot = self._slot_for(tok, feats, pse, gt)
+            if slot is None:
                 dev_args = tuple(a.to(self.device, non_blocking=True) if torch.is_tensor(a) else a for a in args)
                 out = self._fwd_bwd(dev_args)
                 self._exchange_and_update()
             else:
-                slot.load(tok, qlen, feats, pse, gt)
+                if pre is None:
+                    slot.load(tok, qlen, feats, pse, gt)
                 if slot.graph is None and slot.seen >= self.graph_warmup:
                     if self.world_size > 1:
                         self.reducer.rearm()
@@ -215,25 +243,26 @@ class Trainer(object):
         if epoch is not None and hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)
         total, n = None, 0
-        if self.graph:
-            # One batch of look-ahead: the H2D copies of batch i+1 are queued on a copy stream BEFORE step i is launched, so the
-            # fp32 features (B x T x D x 4 bytes: 134 MB at the benchmarked shape, 2.4 ms of PCIe -- longer than the step) cross
-            # the bus while the previous step computes; the step itself then only moves them device-to-device into the captured
-            # graph's input buffers.  Device-resident batches pass through untouched.
+        if self.graph and self.prefetch:
+            # One batch of look-ahead: batch i+1 is copied into the OTHER slot of its geometry on a copy stream before step i is
+            # launched, so the fp32 features (B x T x D x 4 bytes: 134 MB at the benchmarked shape, 2.4 ms of PCIe -- longer than
+            # the step) cross the bus while the previous step computes and the step's own stream carries only the replay.
             it = iter(loader)
             nxt = self._prefetch(next(it, None))
             while nxt is not None:
-                args, ev = nxt
+                cur_b = nxt
                 nxt = self._prefetch(next(it, None))
-                if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)
-                bs = args[2].size(0)
-                loss = select_loss(self.train_step(args), self.which).detach().reshape(-1)[0] * bs
+                bs = cur_b.batch_size if isinstance(cur_b, _Preloaded) else cur_b[2].size(0)
+                loss = select_loss(self.train_step(cur_b), self.which).detach().reshape(-1)[0] * bs
                 total = loss if total is None else total + loss
                 n += bs
             return float(total) / max(n, 1) if total is not None else 0.0
         for batch in loader:
-            _, args = to_device(batch, self.device)
+            if self.graph:                                 # host tensors go straight into the captured step's input buffers
+                names, pse, feats, gt, tok, qlen, nprops, nframes = batch
+                args = (tok, qlen, feats, pse, gt, nprops, nframes)
+            else:
+                _, args = to_device(batch, self.device)
             bs = args[2].size(0)
             loss = select_loss(self.train_step(args), self.which).detach().reshape(-1)[0] * bs
             total = loss if total is None else total + loss
@@ -241,24 +270,31 @@ class Trainer(object):
         return float(total) / max(n, 1) if total is not None else 0.0
 
     def _prefetch(self, batch):
-        """graph mode: start moving a (host) batch to the device on the copy stream.  -> (model arguments, event or None)."""
+        """graph mode: start copying a batch (host or device tensors) into the input buffers of the slot its step will run from,
+        on the copy stream.  -> _Preloaded, or the plain argument tuple when the step has to run eagerly (no slot left)."""
         if batch is None:
             return None
         names, pse, feats, gt, tok, qlen, nprops, nframes = batch
-        tens = (tok, qlen, feats, pse, gt)
-        if all(t.is_cuda for t in tens):
-            return (tok, qlen, feats, pse, gt, nprops, nframes), None
-        if getattr(self, "_copy_stream", None) is None:
+        if all(t.is_cuda for t in (tok, qlen, feats, pse, gt)):
+            # already on the device: the step copies it into its input buffers itself (a second stream beside the replay only
+            # slows the latency-bound kernels: 1.43 vs 1.40 ms/step at T = 32)
+            return (tok, qlen, feats, pse, gt, nprops, nframes)
+        slot = self._slot_for(tok, feats, pse, gt, alternate=True)
+        if slot is None:
+            return (tok, qlen, feats, pse, gt, nprops, nframes)
+        if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         cs = self._copy_stream
-        cs.wait_stream(torch.cuda.current_stream())        # (a batch produced on the caller's stream)
+        # behind everything queued so far: the previous use of this slot (two steps back) and a batch produced on the caller's stream
+        cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
-            moved = [t.to(self.device, non_blocking=True) for t in tens]
+            slot.load(tok, qlen, feats, pse, gt)
             ev = torch.cuda.Event()
             ev.record(cs)
-        for t in moved:
-            t.record_stream(self.stream)                   # allocated on the copy stream, read by the step's stream
-        return tuple(moved) + (nprops, nframes), ev
+        for t in (tok, qlen, feats, pse, gt):
+            if t.is_cuda:
+                t.record_stream(cs)                        # (a device-resident part of a mixed batch must outlive the copy)
+        return _Preloaded(slot, ev, int(feats.size(0)))
 
     @torch.no_grad()
     def evaluate(self, loader, id2word=None, iou_topk=None):
