@@ -243,7 +243,7 @@ class Trainer(object):
         if epoch is not None and hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)
         total, n = None, 0
-        if self.graph and self.prefetch:
+        if getattr(self, "graph", False) and getattr(self, "prefetch", False):
             # One batch of look-ahead: batch i+1 is copied into the OTHER slot of its geometry on a copy stream before step i is
             # launched, so the fp32 features (B x T x D x 4 bytes: 134 MB at the benchmarked shape, 2.4 ms of PCIe -- longer than
             # the step) cross the bus while the previous step computes and the step's own stream carries only the replay.
