@@ -19,7 +19,7 @@ import os
 import torch
 
 from . import functional as DF
-from .metrics import PostProcessRunner, results_entry
+from .metrics import results_entries, PostProcessRunner, results_entry
 
 
 def stage_plan(model, stage, lr):
@@ -300,17 +300,22 @@ class Trainer(object):
     def evaluate(self, loader, id2word=None, iou_topk=None):
         """main.py:270-366: returns (mean loss, topks, accuracies, raw results dict)."""
         self.model.eval()
-        results, total, n = {}, 0.0, 0
+        results, total, n = {}, None, 0
         for batch in loader:
+            # the words, lengths and ground truth of the records come from the HOST batch (no copy back); the loss is summed on
+            # the device (one sync at the end); detections / scores of all clips cross in one copy each (metrics.results_entries)
+            host_tok, host_qlen, host_gt = batch[4], batch[5], batch[3]
             names, args = to_device(batch, self.device)
             boxes, loss_dict = self.model(*args)
             bs = args[2].size(0)
-            total += float(select_loss(loss_dict, self.which).reshape(-1)[0]) * bs
+            lsum = select_loss(loss_dict, self.which).detach().reshape(-1)[0].float() * bs
+            total = lsum if total is None else total + lsum
             n += bs
-            tokens, qlen, gts = args[0].cpu(), args[1].cpu(), args[4].cpu().numpy()
-            for i in range(bs):
-                words = [id2word[int(t)] if id2word else str(int(t)) for t in tokens[i, :int(qlen[i])]]
-                results.setdefault(names[i], []).append(results_entry(" ".join(words), gts[i], boxes[i]))
+            tokens, qlen, gts = host_tok.cpu(), host_qlen.cpu(), host_gt.cpu().numpy()
+            queries = [" ".join(id2word[int(t)] if id2word else str(int(t)) for t in tokens[i, :int(qlen[i])]) for i in range(bs)]
+            for name, entry in zip(names, results_entries(queries, gts, boxes)):
+                results.setdefault(name, []).append(entry)
+        total = float(total) if total is not None else 0.0
         iou_topk = iou_topk or {"iou": [0.5], "topk": [1, 5]}                            # main.py:362
         topks, accs = PostProcessRunner(results).run_evaluate(iou_topk_dict=iou_topk, temporal_nms=True)
         return total / max(n, 1), topks, accs, results
