@@ -318,7 +318,7 @@ def test_grouped_splitk_equals_plain_grouped_launch(dt, ksplit):
         close(ss, sp.double().cpu(), TOL[dt] * 4, "grouped split-K statistics")
 
 
-@pytest.mark.parametrize("M,N,K,ksplit", [(8192, 256, 6528, 4), (8192, 256, 13056, 3), (64, 512, 3072, 8)])
+@pytest.mark.parametrize("M,N,K,ksplit", [(8192, 256, 6528, 4), (8192, 256, 13056, 3), (8192, 256, 13056, 2), (64, 512, 3072, 8)])
 def test_splitk_exchange_under_load(M, N, K, ksplit):
     """The one-launch split-K exchange with every CU holding two workgroups (512 of them), workspace poisoned before each of
     many launches: every launch must reproduce the first bit for bit and match an fp32 product.  (A first version issued the
