@@ -35,3 +35,17 @@ def test_dead_branches_raise():
     with pytest.raises(NotImplementedError):
         r.run_evaluate({"iou": [0.5], "topk": [1]}, do_merge=True)
     assert r.run_evaluate({"iou": [0.5], "topk": [1]})[1] == [1.0]
+
+
+def test_results_entries_equals_per_clip_records():
+    """The batched record builder (one device->host copy per field) writes what results_entry writes clip by clip."""
+    import torch
+    from drn_amd.metrics import results_entries, results_entry
+    g = torch.Generator().manual_seed(0)
+    boxes = []
+    for n in (3, 1, 5, 2):
+        boxes.append({"detections": torch.rand(n, 2, generator=g), "scores": torch.rand(n, generator=g), "labels": [],
+                      "level": [[0] * (n - 1), [1]], "locations": torch.rand(n, generator=g)})
+    queries = ["q%d" % i for i in range(4)]
+    gts = torch.rand(4, 2, generator=g).numpy()
+    assert results_entries(queries, gts, boxes) == [results_entry(q, t, b) for q, t, b in zip(queries, gts, boxes)]

@@ -121,3 +121,17 @@ def test_target_labels_match_oracle_bit_exact(B, T):
     assert int(out5[3].item()) == int(want.sum().item()) > 0
     per_level = want.split([B * L for L in Ls])
     assert all(int(p.sum()) > 0 for p in per_level)                        # every pyramid level owns some positives
+
+
+def test_results_entries_batched_copy_equals_per_clip_records():
+    """metrics.results_entries concatenates all clips' detections / scores on the device and copies once per field: same records
+    as results_entry clip by clip (main.py:324-348)."""
+    from drn_amd.metrics import results_entries, results_entry
+    g = torch.Generator().manual_seed(0)
+    boxes = []
+    for n in (3, 1, 5, 2):
+        boxes.append({"detections": torch.rand(n, 2, generator=g).cuda(), "scores": torch.rand(n, generator=g).cuda(), "labels": [],
+                      "level": [[0] * (n - 1), [1]], "locations": torch.rand(n, generator=g).cuda()})
+    queries = ["q%d" % i for i in range(4)]
+    gts = torch.rand(4, 2, generator=g).numpy()
+    assert results_entries(queries, gts, boxes) == [results_entry(q, t, b) for q, t, b in zip(queries, gts, boxes)]
