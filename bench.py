@@ -158,6 +158,30 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
     return out
 
 
+def launch_plan(gpus, argv, env, device_count):
+    """What `python bench.py --gpus N` has to do before anything else (replaces the reference's single-process
+    nn.DataParallel entry, main.py:99): None = run in this process (N = 1, or already one rank of a torch.distributed.run
+    launch); a command list = re-exec under torch.distributed.run with one rank per GPU over RCCL.  Raises SystemExit when the
+    box has fewer than N GPUs -- an N = 1 number must never be printed for an N > 1 request.  DRN_FORCE_DEVICE (test mode:
+    several ranks share one device over gloo) waives the device-count check."""
+    if gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" in env:
+        if int(env["WORLD_SIZE"]) != gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (gpus, env["WORLD_SIZE"]))
+        return None
+    if gpus == 1:
+        return None
+    if env.get("DRN_FORCE_DEVICE") is None and device_count < gpus:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to print a smaller run's number" % (gpus, device_count))
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +211,11 @@ def main():
     ap.add_argument("--no-trainer", dest="trainer_line", action="store_false",
                     help="skip the `trainer` object (clips/s through drn_amd.trainer.Trainer.train_epoch at T=256 and T=32, graph and eager)")
     args = ap.parse_args()
+    cmd = launch_plan(args.gpus, sys.argv[1:], os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if cmd is not None:
+        # one process per GPU: the plain command launches its own ranks (a driver that mirrors the N = 1 command gets N ranks)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        os.execvpe(cmd[0], cmd, env)
 
     def note(msg):                       # progress on stderr with --verbose (where a multi-rank run stopped, if it did)
         if args.verbose:
@@ -205,8 +234,8 @@ def main():
     rank, local, world = ddist.init_from_env(backend=os.environ.get("DRN_DIST_BACKEND"))
     if os.environ.get("DRN_FORCE_DEVICE") is not None:
         local = int(os.environ["DRN_FORCE_DEVICE"])
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but %d rank(s) initialised" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
@@ -268,7 +297,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run, mode = step, "eager"
+    run, mode, degraded = step, "eager", False
     if args.graph:
         # all warm-up steps run on the capture stream (see drn_amd/graph.py), then the step is captured once
         from drn_amd.graph import GraphedStep
@@ -303,7 +332,7 @@ def main():
             print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).split(chr(10))[0]), file=sys.stderr)
             torch.cuda.synchronize()
             reducer.overlap = True
-            run, mode = step, "eager (capture failed)"
+            run, mode, degraded = step, "eager (capture failed)", True
     else:
         for _ in range(args.warmup):
             step()
@@ -465,6 +494,10 @@ def main():
                       "global_batch": B * world, "T": T, "D": D, "parallelism": "dp%d" % world, "launch": mode,
                       "loss_cls": float(losses["loss_cls"].detach().reshape(-1)[0])},
            "roofline": roof}
+    out["rccl_ranks"] = torch.distributed.get_world_size() if world > 1 else 1
+    out["backend"] = torch.distributed.get_backend() if world > 1 else "none (single process)"
+    if degraded:
+        out["degraded"] = True          # hipGraph capture failed: `value` is the ~2x slower eager launch mode, see stderr
     if eager_ms is not None:
         out["eager_ms_per_step"] = round(eager_ms, 3)
     if per_rank is not None:

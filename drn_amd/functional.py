@@ -1534,8 +1534,9 @@ class _QueryEncoderFn(torch.autograd.Function):
 def query_encoder(tokens, lengths, enc, gate_linears=None, lowp=False):
     """enc: drn_amd.model.language_module.QueryEncoder (parameter holder).  Returns the three (B, 2H) commands, or -- with
     gate_linears = mainModel's three qInput{t} nn.Linear holders -- the three per-level gate tensors (B, C_t).  lowp (the bf16
-    model): the recurrent products of the BiLSTM's BACKWARD pass use the bf16 copy of W_hh^T on the bf16 MFMA (fp32 accumulation);
-    the forward pass is fp32 in either mode."""
+    model): the BiLSTM's forward recurrence multiplies an fp16 copy of the hidden state by W_hh rounded to fp16 on the fp16 MFMA
+    (fp32 accumulation, fp32 cell state and outputs; `_lstm_forward`), the backward recurrence uses the bf16 copy of W_hh^T and
+    bf16-rounded gate gradients on the bf16 MFMA (`_lstm_backward`); the dense forward products stay exact fp32."""
     if enc.embedding.padding_idx != 0:
         raise DrnError("query encoder kernels assume nn.Embedding(padding_idx=0) (model/language_module.py:13)")
     extra = []

@@ -36,7 +36,7 @@ class GraphedStep(object):
 
     def capture(self):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self.stream):
+        with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
             self.out = self.step_fn()
         self.graph = g
         return self
@@ -114,7 +114,7 @@ class TwoPhaseStep(object):
         for k in range(self.NPHASES):
             g = torch.cuda.CUDAGraph()
             kw = {} if k == 0 else {"pool": self.graphs[0].pool()}
-            with torch.cuda.graph(g, stream=self.stream, **kw):
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local", **kw):
                 self._phase(k)
             self.graphs.append(g)
         return self
@@ -268,7 +268,7 @@ class DualStreamStep(object):
             side = name in self.SIDE
             g = torch.cuda.CUDAGraph()
             kw = {"pool": pools[side]} if side in pools else {}
-            with torch.cuda.graph(g, stream=self.side if side else self.main, **kw):
+            with torch.cuda.graph(g, stream=self.side if side else self.main, capture_error_mode="thread_local", **kw):
                 self._phase(name)
             pools.setdefault(side, g.pool())
             graphs[name] = g

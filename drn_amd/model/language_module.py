@@ -3,7 +3,8 @@
 The BiLSTM recurrence (drn_amd/csrc/lstm.hip) and the glue around it (drn_amd/csrc/qenc.hip: embedding gather /
 scatter, sentence vector, the three attention commands) run with sequence lengths on the device -- no packed
 sequences, no host-side control flow, so the whole training step is hipGraph-capturable; the handful of dense
-products (input projection, qInput*, their gradients) are library GEMMs on stacked weights."""
+products (input projection, qInput*, their gradients) run on the grouped exact-f32 MFMA kernels of drn_amd/csrc/qdense.hip
+(`skinny_group_kernel`, `outer_wgrad_kernel`) over stacked weights -- no rocBLAS / hipBLASLt call anywhere in the step."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -35,8 +36,12 @@ class TextualAttention(nn.Module):
 
 
 class QueryEncoder(nn.Module):
-    # torch.bfloat16 (set by mainModel.set_compute_dtype): the recurrent products of the BiLSTM's backward pass run on the bf16
-    # MFMA with the optimizer-maintained bf16 copy of W_hh^T (fp32 accumulation); the forward pass and everything else stay fp32
+    # torch.bfloat16 (set by mainModel.set_compute_dtype), the numerical contract of the bf16 model's query side:
+    #   forward recurrence: the hidden state is kept as an fp16 copy (|h| < 1, unit roundoff 2^-11) and multiplied on
+    #     v_mfma_f32_16x16x32_f16 with W_hh rounded to fp16 in registers, fp32 accumulation, fp32 cell state / outputs;
+    #   backward recurrence: bf16 MFMA with the optimizer-maintained bf16 copy of W_hh^T and bf16-rounded gate gradients (fp32
+    #     accumulation); the weight-gradient products round their staged operands to bf16;
+    #   every other product of the query side (input projection, qInput*, attention) stays exact fp32 in the forward pass.
     compute_dtype = torch.float32
 
     def __init__(self, vocab_size, hidden_dim=512, embed_dim=300, num_layers=1, bidirection=True):

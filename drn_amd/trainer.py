@@ -64,7 +64,7 @@ class _StepSlot(object):
         self.pse = torch.zeros((B, T, 2), dtype=pse_dtype, device=device)
         self.gt = torch.zeros((B, 2), dtype=gt_dtype, device=device)
         self.args = (self.tok, self.qlen, self.feats, self.pse, self.gt, None, None)
-        self.seen, self.graph, self.out = 0, None, None
+        self.seen, self.graph, self.out, self.gen, self.alt = 0, None, None, None, 0
 
     def load(self, tok, qlen, feats, pse, gt):
         """Copy one batch (host or device tensors) into the static buffers; the token matrix is zero-padded (padding_idx 0)
@@ -105,6 +105,8 @@ class Trainer(object):
         self.graph = bool(graph) and self.fused
         self.lq_bucket, self.graph_warmup, self.max_graphs = max(int(lq_bucket), 1), max(int(graph_warmup), 1), max_graphs
         self._slots = {}
+        self._pools = {}                                   # 0 / 1 (the alternate slots) -> graph memory pool shared by its captures
+        self._eager_geos = set()                           # geometries that fell back to eager launches (logged once each)
         self._turn = {}                                    # geometry -> uses so far (its two slots alternate)
         self._copy_stream = None
         self.prefetch = (os.environ.get("DRN_TRAINER_PREFETCH", "1") != "0") if prefetch is None else bool(prefetch)
@@ -137,8 +139,14 @@ class Trainer(object):
         slot = self._slots.get(key)
         if slot is None:
             if len(self._slots) >= self.max_graphs:
+                if geo not in self._eager_geos:
+                    self._eager_geos.add(geo)
+                    import warnings
+                    warnings.warn("drn_amd.Trainer: %d hipGraph captures exist (max_graphs); steps of geometry B=%d T=%d D=%d Lq=%d "
+                                  "run as eager launches" % ((len(self._slots),) + geo))
                 return None
             slot = self._slots[key] = _StepSlot(geo, self.device, pse.dtype, gt.dtype)
+            slot.alt = key[-1]
         if pse.dtype != slot.pse.dtype or gt.dtype != slot.gt.dtype:
             return None
         if alternate:
@@ -176,15 +184,30 @@ class Trainer(object):
             else:
                 if pre is None:
                     slot.load(tok, qlen, feats, pse, gt)
+                stores = getattr(self.opt, "stores", None)
+                if slot.graph is not None and whole and DF.cache_generation(stores) != slot.gen:
+                    # A re-laid weight copy appeared (or went) after this capture -- an eval-only path, another perm / dtype: the
+                    # captured optimizer nodes do not maintain it and no Python runs in a replay to invalidate it.  Invalidate
+                    # every copy now and re-capture after one eager step (which rebuilds the optimizer's tables).
+                    DF.bump_weights_epoch(stores)
+                    for s_ in self._slots.values():
+                        if s_.graph is not None:
+                            s_.graph, s_.seen = None, self.graph_warmup - 1
                 if slot.graph is None and slot.seen >= self.graph_warmup:
                     if self.world_size > 1:
                         self.reducer.rearm()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self.stream):
+                    # thread_local: a hipHostMalloc from the DataLoader's pin_memory thread during this capture must not fail it
+                    # (global mode turns ANY thread's unsafe call into hipErrorStreamCaptureUnsupported).  Captures share one
+                    # memory pool (they replay one at a time); the alternate slots of the H2D look-ahead share a second one.
+                    alt = slot.alt
+                    kw = {"pool": self._pools[alt]} if alt in self._pools else {}
+                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local", **kw):
                         slot.out = self._fwd_bwd(slot.args)
                         if whole:
                             self._exchange_and_update()
-                    slot.graph = g
+                    self._pools.setdefault(alt, g.pool())
+                    slot.graph, slot.gen = g, DF.cache_generation(stores)
                 if slot.graph is not None:
                     if self.world_size > 1:
                         self.reducer.rearm()               # hooks only ran at capture time
