@@ -9,6 +9,7 @@
 // A conv bias in front of a train-mode BN cancels in the output; it only shifts running_mean, so
 // the GEMM never adds it (its gradient is analytically zero).
 #include "vec.h"
+#include "bn_merge.h"
 #include "../../include/drn_hip.h"
 
 struct BnFinGroup {
@@ -324,66 +325,10 @@ struct BnTrainParams {
   int n, C, relu, nupd, total_blocks;
 };
 
-// (mean, biased variance) of channel cbase + (tid & 63) from the GEMM epilogue's per-128-row-slab (sum, M2) pairs, merged in
-// double with the parallel-variance formula (Chan et al.).  256 threads = 64 channels x 4 slab lanes; the lanes meet in LDS
-// and are added in a fixed order.  Up to 64 slabs (8192 rows) a thread's pairs are loaded once, all in flight together, and
-// kept in registers for the second pass; longer problems re-read them (L2 hits).
+// The statistics merge itself lives in bn_merge.h (shared, bit for bit, with the conv -> BN -> ReLU kernel of gemm_nt_bn.hip).
 __device__ __forceinline__ void bn_merge64(const float* __restrict__ st, const int tiles, const int Mrows, const int C,
                                            const int cbase, double (*shd)[64], double& mean_out, double& var_out) {
-  constexpr int KMAX = 16;
-  const int ci = threadIdx.x & 63, j = threadIdx.x >> 6;
-  const float* __restrict__ p = st + cbase + ci;
-  const bool cached = tiles <= 4 * KMAX;
-  float c0[KMAX], c1[KMAX];
-  double s = 0.0;
-  if (cached) {
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      const int k = min(j + 4 * i, tiles - 1);        // clamped index, masked use: no branch around the loads
-      c0[i] = p[((long)k * 2 + 0) * C];
-      c1[i] = p[((long)k * 2 + 1) * C];
-    }
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i)
-      if (j + 4 * i < tiles) s += (double)c0[i];
-  } else {
-    for (int k = j; k < tiles; k += 4) s += (double)p[((long)k * 2 + 0) * C];
-  }
-  shd[j][ci] = s;
-  __syncthreads();
-  // (double-precision divisions are ~40-instruction sequences: every slab but the last has 128 rows -- an exact power-of-two
-  // reciprocal -- and the two per-channel ones are multiplications by 1/M)
-  const double inv_m = 1.0 / (double)Mrows;
-  const int n_last = Mrows - (tiles - 1) * 128;
-  const double inv_last = n_last == 128 ? 0.0078125 : 1.0 / (double)n_last;
-  const double mean = ((shd[0][ci] + shd[1][ci]) + (shd[2][ci] + shd[3][ci])) * inv_m;
-  double q = 0.0;
-  if (cached) {
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      const int k = j + 4 * i;
-      if (k < tiles) {
-        const bool last = k == tiles - 1;
-        const double d = (double)c0[i] * (last ? inv_last : 0.0078125) - mean;
-        q += (double)c1[i] + (double)(last ? n_last : 128) * d * d;
-      }
-    }
-  } else {
-    for (int k = j; k < tiles; k += 4) {
-      const bool last = k == tiles - 1;
-      const double d = (double)p[((long)k * 2 + 0) * C] * (last ? inv_last : 0.0078125) - mean;
-      q += (double)p[((long)k * 2 + 1) * C] + (double)(last ? n_last : 128) * d * d;
-    }
-  }
-  __syncthreads();
-  shd[j][ci] = q;
-  __syncthreads();
-  q = (shd[0][ci] + shd[1][ci]) + (shd[2][ci] + shd[3][ci]);
-  double var = q * inv_m;
-  if (var < 0.0) var = 0.0;
-  __syncthreads();                       // shd is free again
-  mean_out = mean;
-  var_out = var;
+  bn_merge_cols<64, false>(st, tiles, Mrows, C, cbase, shd, mean_out, var_out);
 }
 
 template <typename T>
@@ -399,16 +344,13 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
       double mean, var;
       bn_merge64(G.stats, G.tiles, G.M, C, cbase, shd, mean, var);
       if (tid < 64) {
-        const float invstd = (float)(1.0 / sqrt(var + (double)G.eps));
-        const float sc = G.gamma[c] * invstd;
+        float sc, sh, invstd;
+        bn_scale_shift(mean, var, G.eps, G.gamma[c], G.beta[c], sc, sh, invstd);
         G.ss[c] = sc;
-        G.ss[C + c] = G.beta[c] - (float)mean * sc;
+        G.ss[C + c] = sh;
         G.save[c] = (float)mean;
         G.save[C + c] = invstd;
-        const float cb = G.conv_bias ? G.conv_bias[c] : 0.f;
-        const float unb = (float)(G.M > 1 ? var * ((double)G.M / (G.M - 1)) : var);
-        if (G.running_mean) G.running_mean[c] = (1.f - G.momentum) * G.running_mean[c] + G.momentum * ((float)mean + cb);
-        if (G.running_var) G.running_var[c] = (1.f - G.momentum) * G.running_var[c] + G.momentum * unb;
+        bn_running_update(mean, var, G.M, G.momentum, G.conv_bias ? G.conv_bias[c] : 0.f, G.running_mean, G.running_var, c);
       }
     }
     return;
@@ -452,10 +394,10 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
     double mean, var;
     bn_merge64(G.stats, G.tiles, G.M, C, cbase, shd, mean, var);
     if (tid < 64) {
-      const float invstd = (float)(1.0 / sqrt(var + (double)G.eps));
-      const float sc = G.gamma[cbase + tid] * invstd;
+      float sc, sh, invstd;
+      bn_scale_shift(mean, var, G.eps, G.gamma[cbase + tid], G.beta[cbase + tid], sc, sh, invstd);
       s_sc[tid] = sc;
-      s_sh[tid] = G.beta[cbase + tid] - (float)mean * sc;
+      s_sh[tid] = sh;
     }
     __syncthreads();
   }

@@ -630,10 +630,11 @@ class _ConvBlockFn(torch.autograd.Function):
             geo.append((B, L, Lo, M, ld))
             raws.append(raw)
             stats.append(st)
-        ops.gemm_nt(descs, code)
         bn = meta.bn
         sss, saves = [], []
         fused = meta.training and Cout % 64 == 0       # statistics merge + running statistics + apply in ONE launch
+        if not fused:
+            ops.gemm_nt(descs, code)
         track = False
         if meta.training:
             if bn.momentum is None:
@@ -674,7 +675,12 @@ class _ConvBlockFn(torch.autograd.Function):
                                   momentum=bn.momentum, eps=bn.eps)
             outs.append(out)
         if fused:
-            ops.bn_train_apply(levels, Cout, code, relu=meta.relu)        # all pyramid levels, statistics included, in one launch
+            # conv -> BN -> ReLU of all pyramid levels in ONE launch (the workgroups normalise their own tiles after a per-column
+            # arrival wait); where that launch does not apply (split-K, external upsample source, grid beyond what the chip holds
+            # at once) the GEMM and the one-launch BatchNorm pass run separately -- same bits either way
+            if not ops.conv_bn_train(descs, levels, code, relu=meta.relu):
+                ops.gemm_nt(descs, code)
+                ops.bn_train_apply(levels, Cout, code, relu=meta.relu)
         else:
             ops.bn_apply_multi(levels, Cout, code, relu=meta.relu)        # all pyramid levels in one launch
         if relu_tap is not None and meta.relu:
@@ -864,7 +870,6 @@ class _MultiConvFn(torch.autograd.Function):
             geo.append((B, L, Lo, M, ld, Cout, Cin, k, pad))
             raws.append(raw)
             stats.append(st)
-        ops.gemm_nt(descs, code)
         sss, saves, fin = [], [], []
         same_c = all(g[5] == geo[0][5] for g in geo)
         for l in range(n):
@@ -887,26 +892,30 @@ class _MultiConvFn(torch.autograd.Function):
             sss.append(ss)
         # C % 64 == 0 (every FPN block): the apply launches merge the statistics themselves; otherwise a finalize launch first
         fused = bool(fin) and all(g[5] % 64 == 0 for g in geo)
-        if fin and not fused:                                  # every level has its own BatchNorm module: one launch
-            for grp in ([fin] if same_c else [[f] for f in fin]):
-                ops.bn_finalize_multi(grp, grp[0]["ss"].shape[1])
-        outs = [None] * n
-        levels = []
-        for l in range(n - 1, -1, -1):                        # coarse to fine (the chain needs out_{l+1})
+        outs = [torch.empty((g[0], g[2], g[5]), dtype=dt, device=dev) for g in geo]
+        lvs = []
+        for l in range(n):
             B, L, Lo, M, ld, Cout = geo[l][:6]
-            out = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
             up = outs[l + 1] if (chain_up and l + 1 < n) else None
-            lv = dict(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, L=Lo, up=up, ld_up=Cout if up is not None else 0)
+            lv = dict(raw=raws[l], ld_raw=Cout, ss=sss[l], out=outs[l], ld_out=Cout, M=M, L=Lo, up=up, ld_up=Cout if up is not None else 0)
             if fused:
                 lv.update(fin[l])
+            lvs.append(lv)
+        # conv -> BN -> ReLU of all blocks in ONE launch; with chain_up a workgroup of level l recomputes the rows of the coarser
+        # levels it adds from their raw outputs and statistics inside that launch (drn_conv_bn_train, up_group)
+        one_launch = fused and same_c and ops.conv_bn_train(descs, lvs, code, up_group=[l + 1 if (chain_up and l + 1 < n) else -1
+                                                                                             for l in range(n)])
+        if not one_launch:
+            ops.gemm_nt(descs, code)
+            if fin and not fused:                              # every level has its own BatchNorm module: one launch
+                for grp in ([fin] if same_c else [[f] for f in fin]):
+                    ops.bn_finalize_multi(grp, grp[0]["ss"].shape[1])
             apply = ops.bn_train_apply if fused else ops.bn_apply_multi
             if chain_up or not same_c:
-                apply([lv], Cout, code)                       # out_l reads out_{l+1}: one launch per level, in order
+                for l in range(n - 1, -1, -1):                # coarse to fine: out_l reads out_{l+1}, one launch per level
+                    apply([lvs[l]], geo[l][5], code)
             else:
-                levels.append(lv)
-            outs[l] = out
-        if levels:
-            (ops.bn_train_apply if fused else ops.bn_apply_multi)(levels, geo[0][5], code)
+                apply(lvs, geo[0][5], code)
         if relu_tap is not None:
             for l in range(n):
                 _tap_relu(weights[l], 0, outs[l], outs[l + 1] if (chain_up and l + 1 < n) else None)

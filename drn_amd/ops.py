@@ -413,6 +413,11 @@ def bn_train_apply(levels, C, dtype, relu=True):
     with the statistics side (stats, tiles, ss, save, gamma, beta[, conv_bias, running_mean, running_var], momentum, eps) and
     the apply side (raw, ld_raw, out, ld_out, M, L[, up, ld_up, gate, gated, ld_gated]) of drn_bn_finalize_multi +
     drn_bn_apply_multi; the groups' running statistics are updated in list order."""
+    arr = _bn_train_descs(levels)
+    check(lib().drn_bn_train_apply(arr, len(levels), C, int(relu), dtype, _stream()), "drn_bn_train_apply")
+
+
+def _bn_train_descs(levels):
     arr = (_lib.BnTrainDesc * len(levels))()
     for d, v in zip(arr, levels):
         gate = v.get("gate")
@@ -423,7 +428,44 @@ def bn_train_apply(levels, C, dtype, relu=True):
         d.ld_raw, d.ld_out, d.ld_up = v["ld_raw"], v["ld_out"], v.get("ld_up", 0)
         d.ldg, d.ld_gated = (gate.stride(0) if gate is not None else 0), v.get("ld_gated", 0)
         d.M, d.L = v["M"], v["L"]
-    check(lib().drn_bn_train_apply(arr, len(levels), C, int(relu), dtype, _stream()), "drn_bn_train_apply")
+    return arr
+
+
+# conv -> BN(train) -> ReLU in ONE launch (drn_conv_bn_train).  Its in-kernel wait needs the whole grid resident on a device
+# this process owns: DRN_FORCE_DEVICE (the test mode that puts several ranks on ONE GPU) and DRN_BN_FUSE=0 switch it off, and
+# the two-launch path (drn_gemm_nt + drn_bn_train_apply, same bits) runs instead.
+BN_FUSE = os.environ.get("DRN_BN_FUSE", "1") != "0" and os.environ.get("DRN_FORCE_DEVICE") is None
+DRN_ERR_UNSUPPORTED = -3
+
+
+def conv_bn_train(descs, levels, dtype, relu=True, up_group=None):
+    """descs: gemm_desc per group (stats set, no bias / gate / C2); levels: the bn_train_apply dicts of the same groups
+    (raw = the GEMM's C).  up_group[i] = j: out_i += nearest_x2(out_j) inside the launch (the FPN top-down chain).
+    -> True when launched; False when this launch cannot be fused (the caller runs gemm_nt + bn_train_apply)."""
+    if not BN_FUSE or _ksplit(descs, dtype) > 1:
+        return False
+    arr = (GemmDesc * len(descs))(*descs)
+    barr = _bn_train_descs(levels)
+    ug = (ctypes.c_int32 * len(descs))(*[int(u) for u in up_group]) if up_group is not None else None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d0 = descs[0]
+    flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
+    tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=0 +bn" % ("bf16" if dtype == BF16 else "f32", len(descs), sum(d.M for d in descs), d0.N,
+                                                           d0.taps * d0.Cin)
+    rc = []
+    _timed(tag, flops, lambda: rc.append(lib().drn_conv_bn_train(arr, barr, len(descs), int(relu), ug, _p(_counters(dev)), dtype,
+                                                                 _stream())))
+    if rc[0] == DRN_ERR_UNSUPPORTED:
+        if kernel_timer is not None:
+            kernel_timer.pop()
+        return False
+    check(rc[0], "drn_conv_bn_train")
+    return True
+
+
+def conv_bn_train_timeouts(reset=True):
+    """Workgroups of fused conv->BN launches that gave up waiting for their tile column (0 in a healthy run).  Synchronises."""
+    return int(lib().drn_conv_bn_train_timeouts(int(reset)))
 
 
 def bn_bwd_multi(levels, C, dtype, relu=True):

@@ -227,6 +227,23 @@ typedef struct DrnBnTrainDesc {
   int32_t tiles, ld_raw, ld_out, ld_up, ldg, ld_gated, M, L;
 } DrnBnTrainDesc;
 int drn_bn_train_apply(const DrnBnTrainDesc* descs /*host*/, int n, int C, int relu, int dtype, void* stream);
+/* Conv1d -> BatchNorm1d (training) -> ReLU in ONE launch (model/basic_blocks.py:9-31; FPN laterals / output convs
+ * model/FPN.py:54-69; head towers model/fcos.py:33-69 with statistics per level call, fcos.py:93-102): drn_gemm_nt +
+ * drn_bn_train_apply without the second launch and without re-reading the raw conv output.  gemm[i] / bn[i] describe group i
+ * (bn[i].raw == gemm[i].C, bn[i].stats == gemm[i].stats; the raw output and the statistics are still written: backward reads
+ * them).  Every workgroup keeps its raw tile in registers, publishes its slab statistics, waits at a per-tile-column arrival
+ * counter until the column is complete, merges the column's statistics exactly as drn_bn_train_apply does (same bits) and
+ * stores the normalised tile.  up_group (host, or NULL): up_group[i] = j > i makes out_i += nearest_x2(out_j) (the FPN top-down
+ * chain), recomputed from group j's raw rows inside the launch; -1 = none.  counters: >= 2 int32 per tile column, zero on
+ * entry, left zero (the DRN_QD_COUNTERS buffer will do).
+ * Returns DRN_ERR_UNSUPPORTED -- nothing launched, call the two-launch path -- when the groups' N differ or are not a
+ * multiple of the tile width, an epilogue option of drn_gemm_nt is requested, or the grid exceeds what the chip holds at once
+ * (the wait needs every workgroup resident; the device must not be shared with another process that also waits).  */
+int drn_conv_bn_train(const DrnGemmDesc* gemm /*host*/, const DrnBnTrainDesc* bn /*host*/, int ngroups, int relu,
+                      const int32_t* up_group /*host or NULL*/, int32_t* counters, int dtype, void* stream);
+/* Watchdog of that wait: workgroups that gave up after 2 s since the last reset (their launch's results are invalid).
+ * Synchronises the device; -1 on error. */
+int drn_conv_bn_train_timeouts(int reset);
 /* dRaw, dgamma, dbeta from dOut; ReLU mask recomputed from raw; draw may alias dout. */
 int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld_raw, const float* scale_shift, const float* save,
                const float* gamma, void* draw, int ld_draw, float* dgamma, float* dbeta, int accumulate, int M, int C, int relu,
