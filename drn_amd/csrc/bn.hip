@@ -328,7 +328,7 @@ struct BnTrainParams {
 // The statistics merge itself lives in bn_merge.h (shared, bit for bit, with the conv -> BN -> ReLU kernel of gemm_nt_bn.hip).
 __device__ __forceinline__ void bn_merge64(const float* __restrict__ st, const int tiles, const int Mrows, const int C,
                                            const int cbase, double (*shd)[64], double& mean_out, double& var_out) {
-  bn_merge_cols<64, false>(st, tiles, Mrows, C, cbase, shd, mean_out, var_out);
+  bn_merge_cols<64, BN_ST_PLAIN>(st, tiles, Mrows, C, cbase, shd, mean_out, var_out);
 }
 
 template <typename T>

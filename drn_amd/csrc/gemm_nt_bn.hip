@@ -17,15 +17,29 @@ static int nt_resident_capacity(KernelT kernel, int threads, int lds_bytes) {
     cus[dev] = n;
   }
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, threads, (size_t)lds_bytes) != hipSuccess) return 0;
+  // A variant that spills to scratch cannot count on the occupancy the register / LDS arithmetic promises: the waves that may
+  // hold scratch at once are limited per shader engine (measured: ~415 of 448 eight-wave workgroups resident, the rest starting
+  // only after the first had given up waiting).  One workgroup per CU is what such a variant is trusted with.
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)kernel) != hipSuccess) return 0;
+  if (fa.localSizeBytes > 0 && per_cu > 1) per_cu = 1;
   return per_cu * cus[dev];
 }
 
+extern "C" int64_t drn_conv_bn_train_ws_bytes(const DrnGemmDesc* d, int ngroups) {
+  int64_t n = 0;
+  for (int g = 0; g < ngroups; ++g) n += (int64_t)cdiv(d[g].M, 128) * 2 * d[g].N * 8;
+  return n;
+}
+
 extern "C" int drn_conv_bn_train(const DrnGemmDesc* d, const DrnBnTrainDesc* bn, int ngroups, int relu, const int32_t* up_group,
-                                 int32_t* counters, int dtype, void* stream_) {
+                                 void* tagged_ws, int64_t ws_bytes, int32_t* generation, int dtype, void* stream_) {
   drn_clear_status();
   const char* who = "drn_conv_bn_train";
   hipStream_t stream = (hipStream_t)stream_;
-  DRN_CHECK_ARG(d && bn && counters && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "%s: bad arguments", who);
+  DRN_CHECK_ARG(d && bn && tagged_ws && generation && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "%s: bad arguments", who);
+  DRN_CHECK_ARG(((uintptr_t)tagged_ws & 7) == 0 && ws_bytes >= drn_conv_bn_train_ws_bytes(d, ngroups),
+                "%s: statistics workspace too small or misaligned (drn_conv_bn_train_ws_bytes)", who);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "%s: bad dtype %d", who, dtype);
   const int ch = dtype == DRN_BF16 ? 8 : 4;
   long big_tiles = 0;
@@ -35,12 +49,12 @@ extern "C" int drn_conv_bn_train(const DrnGemmDesc* d, const DrnBnTrainDesc* bn,
   for (int g = 0; g < ngroups; ++g) {
     const DrnGemmDesc& s = d[g];
     const DrnBnTrainDesc& b = bn[g];
-    DRN_CHECK_ARG(s.A && s.B && s.C && s.stats, "%s: null operand in group %d", who, g);
+    DRN_CHECK_ARG(s.A && s.B && s.C, "%s: null operand in group %d", who, g);
     DRN_CHECK_ARG(s.M > 0 && s.N > 0 && s.Cin > 0 && s.taps >= 1 && s.stride >= 1, "%s: bad dims in group %d", who, g);
     DRN_CHECK_ARG(s.Cin % ch == 0 && s.lda % ch == 0 && s.ldb % ch == 0, "%s: Cin/lda/ldb must be multiples of %d elements", who, ch);
     DRN_CHECK_ARG(((uintptr_t)s.A & 15) == 0 && ((uintptr_t)s.B & 15) == 0, "%s: A/B must be 16-byte aligned", who);
     DRN_CHECK_ARG(s.Lout > 0 && s.Lsrc > 0 && s.M % s.Lout == 0, "%s: M=%d not a multiple of Lout=%d", who, s.M, s.Lout);
-    DRN_CHECK_ARG(b.raw == s.C && b.stats == s.stats && b.M == s.M && b.L == s.Lout && b.tiles == cdiv(s.M, 128) && b.ld_raw == s.ldc,
+    DRN_CHECK_ARG(b.raw == s.C && b.M == s.M && b.L == s.Lout && b.tiles == cdiv(s.M, 128) && b.ld_raw == s.ldc,
                   "%s: group %d: the BatchNorm descriptor does not describe the GEMM's output", who, g);
     DRN_CHECK_ARG(b.out && b.scale_shift && b.save && b.gamma && b.beta, "%s: group %d: null BatchNorm operand", who, g);
     DRN_CHECK_ARG((b.gate != nullptr) == (b.gated != nullptr), "%s: gate and gated must come together", who);
@@ -65,19 +79,21 @@ extern "C" int drn_conv_bn_train(const DrnGemmDesc* d, const DrnBnTrainDesc* bn,
   P.xcd_swizzle = drn_exp_env("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
   if (drn_tuning(DRN_TUNE_EXP0 + 3) > 0) P.xcd_swizzle = drn_tuning(DRN_TUNE_EXP0 + 3) - 1;
   if (const char* e = drn_exp_env("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);
-  int total = 0, row_tiles = 0;
+  int total = 0;
   bool chain = false;
+  unsigned long long* tws = (unsigned long long*)tagged_ws;
   for (int g = 0; g < ngroups; ++g) {
     const DrnGemmDesc& s = d[g];
     const DrnBnTrainDesc& b = bn[g];
     GemmProb& p = P.p[g];
-    p.A = s.A; p.B = s.B; p.C = s.C; p.stats = s.stats; p.gate = b.gate;
+    p.A = s.A; p.B = s.B; p.C = s.C; p.gate = b.gate;
+    p.stats = (float*)tws;                       // this group's TAGGED statistics pairs [slab][2][N] x 8 bytes
+    tws += (long)cdiv(s.M, 128) * 2 * s.N;
     p.M = s.M; p.N = s.N; p.K = s.taps * s.Cin; p.Cin = s.Cin; p.taps = s.taps; p.stride = s.stride; p.pad = s.pad;
     p.mode = 0; p.Lout = s.Lout; p.Lsrc = s.Lsrc; p.lda = s.lda; p.ldb = s.ldb; p.ldc = s.ldc; p.ldg = b.ldg;
     p.tiles_n = cdiv(s.N, tile);
     p.tile_start = total;
     total += cdiv(s.M, tile) * p.tiles_n;
-    row_tiles += cdiv(s.M, tile);
     BnFuse& F = P.bn[g];
     F.out = b.out; F.gated = b.gated; F.ss = b.scale_shift; F.save = b.save; F.gamma = b.gamma; F.beta = b.beta; F.cbias = b.conv_bias;
     F.rm = b.running_mean; F.rv = b.running_var; F.momentum = b.momentum; F.eps = b.eps;
@@ -111,12 +127,10 @@ extern "C" int drn_conv_bn_train(const DrnGemmDesc* d, const DrnBnTrainDesc* bn,
     for (int h = P.bn[g].up_group; h >= 0; h = P.bn[h].up_group) ++depth;
     BN_UNSUPPORTED(depth > 3, "%s: upsample chain deeper than three levels", who);
   }
-  P.bn_counters = (int*)counters;
-  P.bn_expected = row_tiles;
+  P.counters = (int*)generation;               // the launch generation word (read by every workgroup, advanced by workgroup 0)
   P.bn_relu = relu;
   P.bn_chain = chain ? 1 : 0;
   P.nblocks = total;
-  BN_UNSUPPORTED(P.p[0].tiles_n * 2 > DRN_QD_COUNTERS, "%s: more tile columns than counters", who);
   const bool deep8 = tile == 128 && drn_tuning(DRN_TUNE_NT_DEEP) > 0 && total <= drn_tuning(DRN_TUNE_NT_DEEP) && !drn_exp_env("DRN_NT_STAGES");
 
   static bool attr_set = false;

@@ -71,9 +71,9 @@ struct BnFuse {
   int rs_mask;           // ... of itself and then of these later groups (bit h), which share the BatchNorm module, in order
 };
 struct GemmParamsBn : GemmParams {
+  // GemmProb::stats of every group points into the TAGGED statistics workspace (64-bit {value, tag} pairs, bn_merge.h);
+  // GemmParams::counters carries the address of the launch generation word (fetched with the descriptor header)
   BnFuse bn[DRN_MAX_GROUPS];
-  int* bn_counters;      // [tiles_n][2] arrive / depart, zero on entry, re-armed by the last departer
-  int bn_expected;       // row tiles of ALL groups: arrivals per tile column
   int bn_relu;
   int bn_chain;          // 1: some group has up_group >= 0 (raw outputs are exchanged between workgroups)
 };
@@ -195,14 +195,15 @@ __device__ __forceinline__ void nt_locate(const NtHeader& H, const GemmProb& pr,
 
 // BatchNorm statistics of a tile's raw fp32 accumulators (see the comment inside).  COHERENT: write-through stores, for readers
 // in OTHER workgroups of the same launch (nt_epilogue_bn).
-template <bool COHERENT>
-__device__ __forceinline__ void nt_st_stat(float* p, float v) {
-  if constexpr (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
+template <int MODE>
+__device__ __forceinline__ void nt_st_stat(float* stats, long idx, float v, unsigned tag) {
+  if constexpr (MODE == BN_ST_TAGGED)      // one 8-byte write-through store: value and tag become visible together
+    __hip_atomic_store((unsigned long long*)stats + idx, bn_tag_pack(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else stats[idx] = v;
 }
-template <int WM, int WN, int MI, int NI, bool COHERENT>
+template <int WM, int WN, int MI, int NI, int MODE>
 __device__ __forceinline__ void nt_bn_stats(f32x4 (&acc)[MI][NI], float* shs, float* __restrict__ stats, const int M, const int N,
-                                            const int m0, const int n0, const int tm) {
+                                            const int m0, const int n0, const int tm, const unsigned tag = 0u) {
   constexpr int NW = WM * WN, TM = WM * MI * 16, TN = WN * NI * 16;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int wr = w / WN, wc = w % WN;
@@ -235,7 +236,7 @@ __device__ __forceinline__ void nt_bn_stats(f32x4 (&acc)[MI][NI], float* shs, fl
       for (int k = 0; k < WPS; ++k) v += shs[(slab * WPS + k) * TN + n];
       const int rows = min(128, M - grow * 128);
       shm[i] = rows > 0 ? v / (float)rows : 0.f;
-      if (n0 + n < N && rows > 0) nt_st_stat<COHERENT>(stats + ((long)grow * 2 + 0) * N + n0 + n, v);
+      if (n0 + n < N && rows > 0) nt_st_stat<MODE>(stats, ((long)grow * 2 + 0) * N + n0 + n, v, tag);
     }
     __syncthreads();
     // pass 2: centred sums of squares (only rows < M)
@@ -264,7 +265,7 @@ __device__ __forceinline__ void nt_bn_stats(f32x4 (&acc)[MI][NI], float* shs, fl
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < WPS; ++k) v += shs[(slab * WPS + k) * TN + n];
-        nt_st_stat<COHERENT>(stats + ((long)grow * 2 + 1) * N + n0 + n, v);
+        nt_st_stat<MODE>(stats, ((long)grow * 2 + 1) * N + n0 + n, v, tag);
       }
     }
 }
@@ -323,7 +324,7 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
     }
     return;
   }
-  auto bn_stats = [&](float* shs) { nt_bn_stats<WM, WN, MI, NI, false>(acc, shs, pr.stats, M, N, m0, n0, tm); };
+  auto bn_stats = [&](float* shs) { nt_bn_stats<WM, WN, MI, NI, BN_ST_PLAIN>(acc, shs, pr.stats, M, N, m0, n0, tm); };
 
   T* __restrict__ Cg = (T*)pr.C;
   T* __restrict__ C2g = (T*)pr.C2;
@@ -487,19 +488,21 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
 // conv -> BatchNorm1d (training) -> ReLU in ONE launch (model/basic_blocks.py:9-31; per-level-call statistics,
 // model/fcos.py:93-102).  Before: the GEMM wrote the raw tile, bn_train_apply_kernel re-read it, normalised and wrote it again
 // -- 7 extra launches and ~160 MB of re-reads per forward of FPN + heads.  Here a workgroup
-//   1. stages its tile through the per-wave LDS patches, stores the RAW rows (backward needs them) and KEEPS the 16-byte row
-//      segments it stored in registers (exactly the bits the stand-alone pass would re-read);
-//   2. publishes its per-128-row-slab (sum, M2) statistics with write-through stores and counts itself in at its tile COLUMN;
-//   3. waits until every row tile of that column (all groups of the launch) has arrived -- the launch is co-resident by
-//      construction (the launcher checks grid <= occupancy x CUs), so this is a wait for the slowest neighbour, not a dependency
-//      on unscheduled work; bounded: after 2 s the watchdog flag is raised and the workgroup carries on;
-//   4. merges the column's slab statistics with the SAME routine, in the same order, as bn_train_apply_kernel (bn_merge.h):
-//      every workgroup of a column computes bit-identical scale / shift;
-//   5. normalises (+ReLU) its registers and stores the output once; `gated` = out * gate[seq] (the next layer's query gating)
+//   1. publishes its per-128-row-slab (sum, M2) statistics as TAGGED 64-bit pairs {value, launch generation} with one
+//      write-through store each (bn_merge.h), stages its tile through the per-wave LDS patches, stores the RAW rows (backward
+//      needs them) and KEEPS the 16-byte row segments it stored in registers (exactly the bits the stand-alone pass would read);
+//   2. merges the statistics of its tile column with the SAME routine, in the same order, as bn_train_apply_kernel -- polling the
+//      pairs themselves until they carry this launch's tag: no arrival counter (the first version's per-column counter cost
+//      15-20 us per launch: ~112 device-scope read-modify-writes on one address queue up at the memory side), no flag to clear,
+//      one store -> load hand-off.  The launch is co-resident by construction (the launcher checks grid <= occupancy x CUs), so
+//      this is a wait for the slowest neighbour, not a dependency on unscheduled work; bounded: after 2 s a reader raises the
+//      watchdog counter and carries on.  Every workgroup of a column computes bit-identical scale / shift;
+//   3. normalises (+ReLU) its registers and stores the output once; `gated` = out * gate[seq] (the next layer's query gating)
 //      and the FPN top-down chain out_l += nearest_x2(out_{l+1}) (recomputed from the coarser levels' raw rows and statistics,
 //      rounding where the stand-alone passes round) ride along;
-//   6. first-row workgroups write scale/shift + (mean, invstd) and update the running statistics, groups that share a
-//      BatchNorm module in group order.
+//   4. first-row workgroups write scale/shift + (mean, invstd) and update the running statistics, groups that share a
+//      BatchNorm module in group order; workgroup 0 finally advances the generation word -- after it has seen a tagged pair of
+//      EVERY tile of the launch, i.e. after every workgroup has read the old value.
 static __device__ int g_bn_fuse_timeouts;   // (one copy per translation unit; gemm_nt_bn.hip owns the live one)
 
 __device__ __forceinline__ uint4 nt_ld16_coherent(const void* p) {
@@ -551,9 +554,10 @@ template <> struct NtSeg<float> {
   static __device__ __forceinline__ float round(float v) { return v; }
 };
 
+// gen: the launch generation this workgroup read at its start (GemmParams::counters points at the word).
 template <typename T, int WM, int WN, int MI, int NI, bool CHAIN>
-__device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const GemmProb& pr, const int g, f32x4 (&acc)[MI][NI],
-                                               char* smem, const int m0, const int n0, const int tm, const int tn) {
+__device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, int* gen_word, const unsigned gen, const GemmProb& pr, const int g,
+                                               f32x4 (&acc)[MI][NI], char* smem, const int m0, const int n0, const int tm, const int tn) {
   constexpr int NW = WM * WN, TM = WM * MI * 16, TN = WN * NI * 16;
   constexpr int VEC = NtSeg<T>::VEC;
   constexpr int WCOLS = NI * 16;                           // columns owned by one wave
@@ -563,99 +567,100 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
   constexpr int NIT = 32 / RPI, NCH = MI / 2;              // row segments per lane: NCH x NIT
   constexpr int MAXLEV = CHAIN ? 3 : 1;                   // levels a workgroup normalises: its own + the coarser ones of the chain
   static_assert(NW == 8 && TN % 128 == 0, "the statistics merge runs 128 channels x 4 slab lanes on 512 threads");
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: patch addresses, tile offsets stay in SGPRs
   const int wr = w / WN, wc = w % WN;
   const int M = pr.M, N = pr.N, L = pr.Lout;
   T* __restrict__ rawg = (T*)pr.C;
   const BnFuse& F = K.bn[g];
-  constexpr bool chain = CHAIN;
+  const BnTagged tg{gen + 1u, &g_bn_fuse_timeouts};
+  // The kept row segments: registers -- or, for the bf16 128x128 tile (two workgroups per CU, 128 registers per lane, where 16
+  // more live registers across the statistics merge meant scratch and with it no guaranteed occupancy), the LDS patches
+  // themselves, sized for the whole 64-row wave tile and read a second time after the merge.
+  constexpr bool SEG_LDS = sizeof(T) == 2 && MI * NI == 8;
+  constexpr int PROWS = SEG_LDS ? 64 : 32;                 // rows per wave patch
   // LDS: per-wave store patches | statistics scratch | merge lanes | scale / shift per chain level
-  char* wbuf = smem + w * (32 * PITCH);
-  float* st_scratch = (float*)(smem + NW * (32 * PITCH));
-  double (*shd)[128] = (double (*)[128])(smem + NW * (32 * PITCH) + (WM + TM / 128) * TN * 4);
+  char* wbuf = smem + w * (PROWS * PITCH);
+  float* st_scratch = (float*)(smem + NW * (PROWS * PITCH));
+  double (*shd)[128] = (double (*)[128])(smem + NW * (PROWS * PITCH) + (WM + TM / 128) * TN * 4);
   float* s_sc = (float*)((char*)shd + 4 * 128 * 8);       // [MAXLEV][TN]
   float* s_sh = s_sc + MAXLEV * TN;
 
-  // ---- 1a. slab statistics first (write-through; the accumulators die in 1b, and the stores get the longest head start)
-  nt_bn_stats<WM, WN, MI, NI, true>(acc, st_scratch, pr.stats, M, N, m0, n0, tm);
-  // ---- 1b. raw tile -> LDS patches -> 16-byte row segments: stored, and kept
   const int cv = l % LPR;
   const int ncol = n0 + wc * WCOLS + cv * VEC;             // this lane's first column (N % TN == 0: always inside)
-  uint4 seg[NCH][NIT];
+  uint4 seg[SEG_LDS ? 1 : NCH][SEG_LDS ? 1 : NIT];
+  // raw tile -> LDS patches -> 16-byte row segments: stored, and kept
+  auto stage_and_store = [&]() {
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
-    if constexpr (std::is_same<T, bf16_t>::value) {
-      // quad transposition of nt_epilogue's fast path: a lane ends up with 4 consecutive columns of one row (one ds_write_b64)
-      const bool j0 = l & 1, j1 = l & 2;
-      const unsigned sel1 = j0 ? 0x03020706u : 0x05040100u;
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
+      char* wbuf = smem + w * (PROWS * PITCH) + (SEG_LDS ? ch * 32 * PITCH : 0);
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        // quad transposition of nt_epilogue's fast path: a lane ends up with 4 consecutive columns of one row (one ds_write_b64)
+        const bool j0 = l & 1, j1 = l & 2;
+        const unsigned sel1 = j0 ? 0x03020706u : 0x05040100u;
 #pragma unroll
-      for (int mi2 = 0; mi2 < 2; ++mi2)
+        for (int mi2 = 0; mi2 < 2; ++mi2)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const f32x4 v = acc[ch * 2 + mi2][ni];
-          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-          const bf16x2_t b01 = {(bf16_t)v[0], (bf16_t)v[1]}, b23 = {(bf16_t)v[2], (bf16_t)v[3]};
-          const unsigned p0 = __builtin_bit_cast(unsigned, b01), p1 = __builtin_bit_cast(unsigned, b23);
-          const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p0, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
-          const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p1, 0xB1, 0xf, 0xf, false);
-          const unsigned q0 = __builtin_amdgcn_perm(r0, p0, sel1), q1 = __builtin_amdgcn_perm(r1, p1, sel1);
-          const unsigned snd = j1 ? q0 : q1;
-          const unsigned rcv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-          const unsigned o0 = j1 ? rcv : q0, o1 = j1 ? q1 : rcv;
-          const int rl = mi2 * 16 + (l >> 4) * 4 + (l & 3);
-          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-          *(u32x2_t*)(wbuf + rl * PITCH + (ni * 16 + ((l & 15) >> 2) * 4) * 2) = (u32x2_t){o0, o1};
+          for (int ni = 0; ni < NI; ++ni) {
+            const f32x4 v = acc[ch * 2 + mi2][ni];
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t b01 = {(bf16_t)v[0], (bf16_t)v[1]}, b23 = {(bf16_t)v[2], (bf16_t)v[3]};
+            const unsigned p0 = __builtin_bit_cast(unsigned, b01), p1 = __builtin_bit_cast(unsigned, b23);
+            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p0, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p1, 0xB1, 0xf, 0xf, false);
+            const unsigned q0 = __builtin_amdgcn_perm(r0, p0, sel1), q1 = __builtin_amdgcn_perm(r1, p1, sel1);
+            const unsigned snd = j1 ? q0 : q1;
+            const unsigned rcv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+            const unsigned o0 = j1 ? rcv : q0, o1 = j1 ? q1 : rcv;
+            const int rl = mi2 * 16 + (l >> 4) * 4 + (l & 3);
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            *(u32x2_t*)(wbuf + rl * PITCH + (ni * 16 + ((l & 15) >> 2) * 4) * 2) = (u32x2_t){o0, o1};
+          }
+      } else {
+#pragma unroll
+        for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCH) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int rl = it * RPI + l / LPR;
+        const uint4 sv = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
+        if constexpr (!SEG_LDS) seg[ch][it] = sv;
+        const int m = mrow0 + rl;
+        if (m < M) {
+          T* dst = rawg + ((long)m * pr.ldc + ncol);
+          if constexpr (CHAIN) nt_st16_coherent(dst, sv);       // other workgroups of this launch read it (the top-down chain)
+          else *(uint4*)dst = sv;
         }
-    } else {
-#pragma unroll
-      for (int mi2 = 0; mi2 < 2; ++mi2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCH) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int rl = it * RPI + l / LPR;
-      seg[ch][it] = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
-      const int m = mrow0 + rl;
-      if (m < M) {
-        T* dst = rawg + ((long)m * pr.ldc + ncol);
-        if (chain) nt_st16_coherent(dst, seg[ch][it]);       // other workgroups of this launch read it (the top-down chain)
-        else *(uint4*)dst = seg[ch][it];
       }
+      wave_lds_sync();
     }
-    wave_lds_sync();
+  };
+  // ---- 1. publish.  Plain launches: the statistics first (the accumulators die while the tile is staged, and the tagged pairs
+  // get the longest head start).  Chain launches: a reader that sees this tile's pairs also reads its RAW rows, so those go
+  // out first and have reached the coherence point (vmcnt(0) + barrier) before the first pair is stored.
+  if constexpr (CHAIN) {
+    stage_and_store();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    nt_bn_stats<WM, WN, MI, NI, BN_ST_TAGGED>(acc, st_scratch, pr.stats, M, N, m0, n0, tm, tg.want);
+  } else if constexpr (sizeof(T) == 4 && MI * NI == 8) {
+    // (exact-f32 128x128 tile: in this order the 128-register variant stays out of scratch -- a kernel with scratch cannot
+    // count on full occupancy, which the column wait needs)
+    stage_and_store();
+    nt_bn_stats<WM, WN, MI, NI, BN_ST_TAGGED>(acc, st_scratch, pr.stats, M, N, m0, n0, tm, tg.want);
+  } else {
+    nt_bn_stats<WM, WN, MI, NI, BN_ST_TAGGED>(acc, st_scratch, pr.stats, M, N, m0, n0, tm, tg.want);
+    stage_and_store();
   }
 
-  // ---- 2. arrive at the tile column
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every thread's stores have reached the coherence point
-  __syncthreads();
-  int* cnt = K.bn_counters + 2 * tn;
-  if (tid == 0) {
-    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- 3. wait for the column (bounded: 2 s of the 100 MHz wall clock)
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < K.bn_expected) {
-      __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > 200000000LL) {
-        __hip_atomic_fetch_add(&g_bn_fuse_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    // the last workgroup to LEAVE the wait re-arms both counters (everybody is past its poll by then)
-    const int prev = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == K.bn_expected - 1) {
-      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-
-  // ---- 4. merge: own group, then the coarser levels of the chain
+  // ---- 2. merge: own group, then the coarser levels of the chain (each merge polls its pairs until they carry this tag)
   const int ci = tid & 127;
   int lev_group[MAXLEV];
   int nlev = 0;
@@ -670,6 +675,15 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
       }
     }
   }
+  if (w == 0) {                                   // one wave waits (quietly) for the column's slabs of every level it needs
+#pragma unroll
+    for (int lev = 0; lev < MAXLEV; ++lev)
+      if (lev < nlev) bn_wait_slabs(K.p[lev_group[lev]].stats, K.bn[lev_group[lev]].slabs, N, n0, tg);
+    if (tm == 0 && F.rs_owner && F.rs_mask)
+      for (int h = g + 1; h < K.ngroups; ++h)
+        if ((F.rs_mask >> h) & 1) bn_wait_slabs(K.p[h].stats, K.bn[h].slabs, N, n0, tg);
+  }
+  __syncthreads();
 #pragma unroll
   for (int lev = 0; lev < MAXLEV; ++lev) {
     if (lev >= nlev) break;
@@ -680,14 +694,14 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
     for (int half = 0; half < TN / 128; ++half) {
       const int cbase = n0 + half * 128;
       double mean, var;
-      bn_merge_cols<128, true>(ph.stats, Fh.slabs, ph.M, N, cbase, shd, mean, var);
+      bn_merge_cols<128, BN_ST_TAGGED, (sizeof(T) == 4 ? 4 : 8)>(ph.stats, Fh.slabs, ph.M, N, cbase, shd, mean, var, tg);
       if (tid < 128) {
         const int c = cbase + ci;
         float sc, sh, invstd;
         bn_scale_shift(mean, var, Fh.eps, Fh.gamma[c], Fh.beta[c], sc, sh, invstd);
         s_sc[lev * TN + half * 128 + ci] = sc;
         s_sh[lev * TN + half * 128 + ci] = sh;
-        if (lev == 0 && tm == 0) {                        // ---- 6. once per channel and group
+        if (lev == 0 && tm == 0) {                        // ---- 4. once per channel and group
           Fh.ss[c] = sc;
           Fh.ss[N + c] = sh;
           Fh.save[c] = (float)mean;
@@ -699,22 +713,17 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
   }
   __syncthreads();
 
-  // ---- 5. normalise the kept row segments
-  float sc[MAXLEV][VEC], sh[MAXLEV][VEC];
-#pragma unroll
-  for (int lev = 0; lev < MAXLEV; ++lev)
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      sc[lev][k] = lev < nlev ? s_sc[lev * TN + wc * WCOLS + cv * VEC + k] : 0.f;
-      sh[lev][k] = lev < nlev ? s_sh[lev * TN + wc * WCOLS + cv * VEC + k] : 0.f;
-    }
+  // ---- 3. normalise the kept row segments (scale / shift of the lane's columns are read from LDS where they are used: the
+  // registers they would occupy across the whole loop are what pushed the 128-register variants into scratch)
+  const float* my_sc = s_sc + wc * WCOLS + cv * VEC;
+  const float* my_sh = s_sh + wc * WCOLS + cv * VEC;
   const bool relu = K.bn_relu != 0;
   T* __restrict__ outg = (T*)F.out;
   T* __restrict__ gatedg = (T*)F.gated;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
-    uint4 upseg[NIT][MAXLEV - 1];
+    uint4 upseg[NIT][MAXLEV > 1 ? MAXLEV - 1 : 1];
     int sq[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -734,10 +743,13 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
     for (int it = 0; it < NIT; ++it) {
       const int m = mrow0 + it * RPI + l / LPR;
       float x[VEC];
-      NtSeg<T>::cvt(seg[ch][it], x);
+      uint4 sv;
+      if constexpr (SEG_LDS) sv = *(const uint4*)(wbuf + (ch * 32 + it * RPI + l / LPR) * PITCH + cv * 16);
+      else sv = seg[ch][it];
+      NtSeg<T>::cvt(sv, x);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        const float y = fmaf(x[k], sc[0][k], sh[0][k]);
+        const float y = fmaf(x[k], my_sc[k], my_sh[k]);
         x[k] = relu ? fmaxf(y, 0.f) : y;
       }
       if (nlev > 1) {
@@ -751,7 +763,7 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
             NtSeg<T>::cvt(upseg[it][lev - 1], xv);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-              const float y = fmaf(xv[k], sc[lev][k], sh[lev][k]);
+              const float y = fmaf(xv[k], my_sc[lev * TN + k], my_sh[lev * TN + k]);
               const float v = (relu ? fmaxf(y, 0.f) : y) + (lev + 1 < nlev ? u[k] : 0.f);
               u[k] = NtSeg<T>::round(v);                   // (the stand-alone pass stores out_{lev} in T and re-reads it)
             }
@@ -771,7 +783,7 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
     }
   }
 
-  // ---- 6b. running statistics of the later groups that share this group's BatchNorm module, in group order
+  // ---- 4b. running statistics of the later groups that share this group's BatchNorm module, in group order
   if (tm == 0 && F.rs_owner && F.rs_mask) {
     for (int h = g + 1; h < K.ngroups; ++h) {
       if (!((F.rs_mask >> h) & 1)) continue;
@@ -781,10 +793,29 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, const Gemm
       for (int half = 0; half < TN / 128; ++half) {
         const int cbase = n0 + half * 128;
         double mean, var;
-        bn_merge_cols<128, true>(ph.stats, Fh.slabs, ph.M, N, cbase, shd, mean, var);
+        bn_merge_cols<128, BN_ST_TAGGED, (sizeof(T) == 4 ? 4 : 8)>(ph.stats, Fh.slabs, ph.M, N, cbase, shd, mean, var, tg);
         if (tid < 128) bn_running_update(mean, var, ph.M, Fh.momentum, Fh.cbias ? Fh.cbias[cbase + ci] : 0.f, Fh.rm, Fh.rv, cbase + ci);
       }
     }
+  }
+
+  // ---- 4c. workgroup 0 advances the generation once EVERY tile of the launch has published under the old one (a tile's pairs
+  // are written after its workgroup read the word): one pair per (group, slab, 128-channel block) is looked at
+  if (blockIdx.x == 0) {
+    const int cblocks = N >> 7;
+    for (int h = 0; h < K.ngroups; ++h) {
+      const unsigned long long* base = (const unsigned long long*)K.p[h].stats;
+      const int cnt = K.bn[h].slabs * cblocks;
+      const long long t0 = wall_clock64();
+      for (int i = tid; i < cnt; i += 64 * NW) {
+        const int slab = i / cblocks, cb = i - slab * cblocks;
+        const unsigned long long* q = base + ((long)slab * 2 + 1) * N + cb * 128;
+        while ((unsigned)(bn_ld_pair(q) >> 32) != tg.want)
+          if (bn_wait_expired(t0, tg.timeouts)) break;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(gen_word, (int)(gen + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -840,6 +871,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BNF && MI * NI == 8 && STAGES == 2) 
   GemmProb pr;
   int g, tm, tn;
   nt_fetch(P_arg, P, pr, g, blockIdx.x);
+  // conv -> BN -> ReLU launches: the launch generation (tag of this launch's statistics pairs), requested now, needed in the epilogue
+  unsigned bn_gen_v = 0;
+  if constexpr (BNF) bn_gen_v = (unsigned)__hip_atomic_load(P.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   nt_locate<TM>(P, pr, tm, tn);
   const int m0 = tm * TM, n0 = tn * TN;
   const int M = pr.M, N = pr.N, K = pr.K, Cin = pr.Cin, taps = pr.taps;
@@ -956,6 +990,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BNF && MI * NI == 8 && STAGES == 2) 
   NT_PHASE(1);
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st) stage(st);
+  // (wave-uniform: into an SGPR now -- the first tiles' loads are in flight behind it -- instead of a VGPR carried through the loop)
+  const unsigned bn_gen = BNF ? (unsigned)__builtin_amdgcn_readfirstlane((int)bn_gen_v) : 0u;
   int cur = 0;
   for (int kt = kt_lo; kt < nkt; ++kt) {
     // each thread issues 8 loads per tile; tiles kt+1 .. kt+STAGES-2 may still be in flight
@@ -1007,7 +1043,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BNF && MI * NI == 8 && STAGES == 2) 
   NT_PHASE(3);
 
   if constexpr (BNF) {                   // conv -> BN -> ReLU in this launch (never split)
-    nt_epilogue_bn<T, WM, WN, MI, NI, CHAIN>(P_arg, pr, g, acc, smem, m0, n0, tm, tn);
+    nt_epilogue_bn<T, WM, WN, MI, NI, CHAIN>(P_arg, P.counters, bn_gen, pr, g, acc, smem, m0, n0, tm, tn);
     NT_PHASE(4);
     return;
   } else if constexpr (MI * NI == 8) {   // (the 128x128 tiles: split launches always use them)

@@ -624,17 +624,22 @@ class _ConvBlockFn(torch.autograd.Function):
             Lo = (L + 2 * pad - k) // meta.stride + 1
             M = B * Lo
             raw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
-            st = torch.empty(((M + 127) // 128, 2, Cout), dtype=torch.float32, device=dev) if meta.training else None
-            descs.append(ops.gemm_desc(x, wp, raw, M, Cout, Cin, taps=k, stride=meta.stride, pad=pad, Lout=Lo, Lsrc=L,
-                                       lda=ld, stats=st))
+            descs.append(ops.gemm_desc(x, wp, raw, M, Cout, Cin, taps=k, stride=meta.stride, pad=pad, Lout=Lo, Lsrc=L, lda=ld))
             geo.append((B, L, Lo, M, ld))
             raws.append(raw)
-            stats.append(st)
         bn = meta.bn
         sss, saves = [], []
         fused = meta.training and Cout % 64 == 0       # statistics merge + running statistics + apply in ONE launch
-        if not fused:
+
+        def gemm_with_stats():
+            """The conv as its own launch; in training it leaves the per-slab statistics for the BatchNorm pass that follows."""
+            for l in range(nl):
+                st = torch.empty(((geo[l][3] + 127) // 128, 2, Cout), dtype=torch.float32, device=dev) if meta.training else None
+                stats.append(st)
+                descs[l].stats = ops._p(st)
             ops.gemm_nt(descs, code)
+        if not fused:
+            gemm_with_stats()
         track = False
         if meta.training:
             if bn.momentum is None:
@@ -643,7 +648,8 @@ class _ConvBlockFn(torch.autograd.Function):
             for l in range(nl):
                 ss = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                 sv = torch.empty((2, Cout), dtype=torch.float32, device=dev)
-                groups.append((stats[l], stats[l].shape[0], geo[l][3], ss, sv))
+                if not fused:
+                    groups.append((stats[l], stats[l].shape[0], geo[l][3], ss, sv))
                 sss.append(ss)
                 saves.append(sv)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -670,7 +676,7 @@ class _ConvBlockFn(torch.autograd.Function):
             levels.append(dict(raw=raws[l], ld_raw=Cout, ss=sss[l], out=out, ld_out=Cout, M=M, L=Lo, up=upl,
                                ld_up=upl.stride(1) if upl is not None else 0, gate=gate, gated=gated, ld_gated=Cout))
             if fused:
-                levels[-1].update(stats=stats[l], tiles=stats[l].shape[0], save=saves[l], gamma=gamma, beta=beta, conv_bias=cbias,
+                levels[-1].update(tiles=(M + 127) // 128, save=saves[l], gamma=gamma, beta=beta, conv_bias=cbias,
                                   running_mean=bn.running_mean if track else None, running_var=bn.running_var if track else None,
                                   momentum=bn.momentum, eps=bn.eps)
             outs.append(out)
@@ -679,7 +685,9 @@ class _ConvBlockFn(torch.autograd.Function):
             # arrival wait); where that launch does not apply (split-K, external upsample source, grid beyond what the chip holds
             # at once) the GEMM and the one-launch BatchNorm pass run separately -- same bits either way
             if not ops.conv_bn_train(descs, levels, code, relu=meta.relu):
-                ops.gemm_nt(descs, code)
+                gemm_with_stats()
+                for l in range(nl):
+                    levels[l]["stats"] = stats[l]
                 ops.bn_train_apply(levels, Cout, code, relu=meta.relu)
         else:
             ops.bn_apply_multi(levels, Cout, code, relu=meta.relu)        # all pyramid levels in one launch
@@ -864,12 +872,10 @@ class _MultiConvFn(torch.autograd.Function):
             Lo = (L + 2 * pad - k) // strides[l] + 1
             M = B * Lo
             raw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
-            st = torch.empty(((M + 127) // 128, 2, Cout), dtype=torch.float32, device=dev) if training else None
             descs.append(ops.gemm_desc(x, packed(w, (0, 2, 1), code), raw, M, Cout, Cin, taps=k, stride=strides[l], pad=pad,
-                                       Lout=Lo, Lsrc=L, lda=ld, stats=st))
+                                       Lout=Lo, Lsrc=L, lda=ld))
             geo.append((B, L, Lo, M, ld, Cout, Cin, k, pad))
             raws.append(raw)
-            stats.append(st)
         sss, saves, fin = [], [], []
         same_c = all(g[5] == geo[0][5] for g in geo)
         for l in range(n):
@@ -880,7 +886,7 @@ class _MultiConvFn(torch.autograd.Function):
                     raise DrnError("cumulative-average BatchNorm (momentum=None) is not supported")
                 sv = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                 track = bn.track_running_stats and bn.running_mean is not None
-                fin.append(dict(stats=stats[l], tiles=stats[l].shape[0], M=geo[l][3], ss=ss, save=sv, gamma=gammas[l], beta=betas[l],
+                fin.append(dict(tiles=(geo[l][3] + 127) // 128, M=geo[l][3], ss=ss, save=sv, gamma=gammas[l], beta=betas[l],
                                 running_mean=bn.running_mean if track else None, running_var=bn.running_var if track else None,
                                 momentum=bn.momentum, eps=bn.eps))
                 if track and bn.num_batches_tracked is not None:
@@ -906,6 +912,14 @@ class _MultiConvFn(torch.autograd.Function):
         one_launch = fused and same_c and ops.conv_bn_train(descs, lvs, code, up_group=[l + 1 if (chain_up and l + 1 < n) else -1
                                                                                              for l in range(n)])
         if not one_launch:
+            for l in range(n):                                 # the convs as their own launch leave per-slab statistics behind
+                st = torch.empty(((geo[l][3] + 127) // 128, 2, geo[l][5]), dtype=torch.float32, device=dev) if training else None
+                stats.append(st)
+                descs[l].stats = ops._p(st)
+                if training:
+                    fin[l]["stats"] = st
+                    if fused:
+                        lvs[l]["stats"] = st
             ops.gemm_nt(descs, code)
             if fin and not fused:                              # every level has its own BatchNorm module: one launch
                 for grp in ([fin] if same_c else [[f] for f in fin]):

@@ -421,7 +421,7 @@ def _bn_train_descs(levels):
     arr = (_lib.BnTrainDesc * len(levels))()
     for d, v in zip(arr, levels):
         gate = v.get("gate")
-        d.stats, d.scale_shift, d.save, d.gamma, d.beta = _p(v["stats"]), _p(v["ss"]), _p(v["save"]), _p(v["gamma"]), _p(v["beta"])
+        d.stats, d.scale_shift, d.save, d.gamma, d.beta = _p(v.get("stats")), _p(v["ss"]), _p(v["save"]), _p(v["gamma"]), _p(v["beta"])
         d.conv_bias, d.running_mean, d.running_var = _p(v.get("conv_bias")), _p(v.get("running_mean")), _p(v.get("running_var"))
         d.raw, d.out, d.up, d.gate, d.gated = _p(v["raw"]), _p(v["out"]), _p(v.get("up")), _p(gate), _p(v.get("gated"))
         d.momentum, d.eps, d.tiles = v["momentum"], v["eps"], v["tiles"]
@@ -438,9 +438,28 @@ BN_FUSE = os.environ.get("DRN_BN_FUSE", "1") != "0" and os.environ.get("DRN_FORC
 DRN_ERR_UNSUPPORTED = -3
 
 
+_bn_tagged = {}
+
+
+def _bn_tagged_ws(device, nbytes):
+    """(workspace, generation word) of the one-launch conv->BN kernel per device and stream: 64-bit {value, generation} pairs,
+    zero at first and afterwards written by that kernel only (a pair is valid when it carries the current launch's generation,
+    so the buffer is never cleared); grows in powers of two from 16 MB (a new, zeroed buffer; the generation keeps counting)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ent = _bn_tagged.get(key)
+    if ent is None or ent[0].numel() * 8 < nbytes:
+        n = 1 << 21
+        while n * 8 < nbytes:
+            n *= 2
+        gen = ent[1] if ent is not None else torch.zeros(1, dtype=torch.int32, device=device)
+        retired = ent[2] + [ent[0]] if ent is not None else []      # (a captured hipGraph may still point into the old buffer)
+        ent = _bn_tagged[key] = (torch.zeros(n, dtype=torch.int64, device=device), gen, retired)
+    return ent[0], ent[1]
+
+
 def conv_bn_train(descs, levels, dtype, relu=True, up_group=None):
-    """descs: gemm_desc per group (stats set, no bias / gate / C2); levels: the bn_train_apply dicts of the same groups
-    (raw = the GEMM's C).  up_group[i] = j: out_i += nearest_x2(out_j) inside the launch (the FPN top-down chain).
+    """descs: gemm_desc per group (no bias / gate / C2; `stats` unused); levels: the bn_train_apply dicts of the same groups
+    (raw = the GEMM's C; `stats` unused).  up_group[i] = j: out_i += nearest_x2(out_j) inside the launch (the FPN top-down chain).
     -> True when launched; False when this launch cannot be fused (the caller runs gemm_nt + bn_train_apply)."""
     if not BN_FUSE or _ksplit(descs, dtype) > 1:
         return False
@@ -448,13 +467,15 @@ def conv_bn_train(descs, levels, dtype, relu=True, up_group=None):
     barr = _bn_train_descs(levels)
     ug = (ctypes.c_int32 * len(descs))(*[int(u) for u in up_group]) if up_group is not None else None
     dev = torch.device("cuda", torch.cuda.current_device())
+    nbytes = int(lib().drn_conv_bn_train_ws_bytes(arr, len(descs)))
+    ws, gen = _bn_tagged_ws(dev, nbytes)
     d0 = descs[0]
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
     tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=0 +bn" % ("bf16" if dtype == BF16 else "f32", len(descs), sum(d.M for d in descs), d0.N,
                                                            d0.taps * d0.Cin)
     rc = []
-    _timed(tag, flops, lambda: rc.append(lib().drn_conv_bn_train(arr, barr, len(descs), int(relu), ug, _p(_counters(dev)), dtype,
-                                                                 _stream())))
+    _timed(tag, flops, lambda: rc.append(lib().drn_conv_bn_train(arr, barr, len(descs), int(relu), ug, _p(ws), ctypes.c_int64(ws.numel() * 8),
+                                                                 _p(gen), dtype, _stream())))
     if rc[0] == DRN_ERR_UNSUPPORTED:
         if kernel_timer is not None:
             kernel_timer.pop()

@@ -230,17 +230,20 @@ int drn_bn_train_apply(const DrnBnTrainDesc* descs /*host*/, int n, int C, int r
 /* Conv1d -> BatchNorm1d (training) -> ReLU in ONE launch (model/basic_blocks.py:9-31; FPN laterals / output convs
  * model/FPN.py:54-69; head towers model/fcos.py:33-69 with statistics per level call, fcos.py:93-102): drn_gemm_nt +
  * drn_bn_train_apply without the second launch and without re-reading the raw conv output.  gemm[i] / bn[i] describe group i
- * (bn[i].raw == gemm[i].C, bn[i].stats == gemm[i].stats; the raw output and the statistics are still written: backward reads
- * them).  Every workgroup keeps its raw tile in registers, publishes its slab statistics, waits at a per-tile-column arrival
- * counter until the column is complete, merges the column's statistics exactly as drn_bn_train_apply does (same bits) and
- * stores the normalised tile.  up_group (host, or NULL): up_group[i] = j > i makes out_i += nearest_x2(out_j) (the FPN top-down
- * chain), recomputed from group j's raw rows inside the launch; -1 = none.  counters: >= 2 int32 per tile column, zero on
- * entry, left zero (the DRN_QD_COUNTERS buffer will do).
+ * (bn[i].raw == gemm[i].C; the raw output is still written: backward reads it; gemm[i].stats / bn[i].stats are ignored).
+ * Every workgroup keeps its raw tile in registers, publishes its per-slab statistics as 64-bit {value, generation} pairs in
+ * tagged_ws, merges the pairs of its tile column -- polling them until they carry this launch's generation -- exactly as
+ * drn_bn_train_apply merges (same bits), and stores the normalised tile.  up_group (host, or NULL): up_group[i] = j > i makes
+ * out_i += nearest_x2(out_j) (the FPN top-down chain), recomputed from group j's raw rows inside the launch; -1 = none.
+ * tagged_ws: >= drn_conv_bn_train_ws_bytes() bytes, 8-byte aligned, ZERO when first used and afterwards written by this entry
+ * point only; generation: one int32, zero at first, advanced by the kernel (one pair of buffers per stream).
  * Returns DRN_ERR_UNSUPPORTED -- nothing launched, call the two-launch path -- when the groups' N differ or are not a
  * multiple of the tile width, an epilogue option of drn_gemm_nt is requested, or the grid exceeds what the chip holds at once
  * (the wait needs every workgroup resident; the device must not be shared with another process that also waits).  */
+int64_t drn_conv_bn_train_ws_bytes(const DrnGemmDesc* gemm /*host*/, int ngroups);
 int drn_conv_bn_train(const DrnGemmDesc* gemm /*host*/, const DrnBnTrainDesc* bn /*host*/, int ngroups, int relu,
-                      const int32_t* up_group /*host or NULL*/, int32_t* counters, int dtype, void* stream);
+                      const int32_t* up_group /*host or NULL*/, void* tagged_ws, int64_t ws_bytes, int32_t* generation, int dtype,
+                      void* stream);
 /* Watchdog of that wait: workgroups that gave up after 2 s since the last reset (their launch's results are invalid).
  * Synchronises the device; -1 on error. */
 int drn_conv_bn_train_timeouts(int reset);

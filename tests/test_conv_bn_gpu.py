@@ -31,12 +31,14 @@ def _launches(fn):
     return out, tags
 
 
-def _both(fn):
-    """fn() through the one-launch path and through the two-launch path; asserts the first really fused."""
+def _both(fn, may_decline=False):
+    """fn() through the one-launch path and through the two-launch path; asserts the first really fused (may_decline: the
+    launcher is allowed to decline -- the exact-f32 128x128 variant spills a few registers and is only trusted with one
+    workgroup per CU, so a 448-workgroup f32 launch runs as two launches)."""
     from drn_amd import ops
     assert ops.BN_FUSE, "fused conv->BN is switched off in this environment (DRN_BN_FUSE / DRN_FORCE_DEVICE)"
     fused, tags = _launches(fn)
-    assert any(t.endswith("+bn") for t in tags), "the one-launch kernel did not run: %s" % tags
+    assert may_decline or any(t.endswith("+bn") for t in tags), "the one-launch kernel did not run: %s" % tags
     ops.BN_FUSE = False
     try:
         plain, tags2 = _launches(fn)
@@ -135,7 +137,7 @@ def test_independent_blocks_and_the_top_down_chain(dt, chain, B, Ls, Cins, N, k)
         stats = [t.clone() for _, bn in blocks for t in (bn.running_mean, bn.running_var)]
         return outs, stats, _saved_of(outs[0])
 
-    (o1, st1, sv1), (o2, st2, sv2) = _both(run)
+    (o1, st1, sv1), (o2, st2, sv2) = _both(run, may_decline=(dt == torch.float32 and B == 32))
     for l, (a, b) in enumerate(zip(o1, o2)):
         _same(a, b, "out level %d" % l)
     for i, (a, b) in enumerate(zip(st1, st2)):
@@ -144,13 +146,17 @@ def test_independent_blocks_and_the_top_down_chain(dt, chain, B, Ls, Cins, N, k)
         _same(a, b, "saved tensor %d" % i)
 
 
-def test_one_launch_is_deterministic_and_rearms_its_counters():
-    """Ten launches in a row on the same inputs: the same bits every time (the arrival counters are left zero)."""
+def test_one_launch_is_deterministic_and_advances_its_generation():
+    """Ten launches in a row on the same inputs: the same bits every time, and the generation word that tags the statistics
+    pairs moved on by exactly one per launch (a stale pair of an earlier launch can never pass for a fresh one)."""
     from drn_amd import functional as DF, ops
     dt = torch.bfloat16
     xs = [rnd(32, L, 512, seed=9 + i).to(DEV, dt) for i, L in enumerate((256, 128, 64))]
     conv, bn = _mk_block(512, 512, 3, 1, seed=40)
     first = None
+    DF.conv_block(xs, conv, bn, True, dt)
+    ws, gen = ops._bn_tagged_ws(torch.device(DEV), 0)
+    g0 = int(gen)
     for _ in range(10):
         outs, _ = DF.conv_block(xs, conv, bn, True, dt)
         if first is None:
@@ -160,7 +166,7 @@ def test_one_launch_is_deterministic_and_rearms_its_counters():
                 assert torch.equal(a, b)
     torch.cuda.synchronize()
     assert ops.conv_bn_train_timeouts() == 0
-    assert int(ops._counters(torch.device(DEV)).abs().sum()) == 0
+    assert int(gen) == g0 + 10
 
 
 def test_unsupported_launches_fall_back_to_two_launches():
@@ -175,3 +181,32 @@ def test_unsupported_launches_fall_back_to_two_launches():
     ref = torch.relu(torch.nn.functional.batch_norm(torch.nn.functional.conv1d(x.permute(0, 2, 1), conv.weight, padding=1), None, None,
                                                     bn.weight, bn.bias, True))
     assert float((outs[0].permute(0, 2, 1) - ref).abs().max()) < 1e-4
+
+
+def test_waiting_launches_under_load_never_time_out():
+    """300 one-launch conv->BN blocks back to back at the benchmarked pyramid shapes (448 workgroups, two per CU; 224 of the
+    256x256 tile) with and without the top-down chain: every launch fuses and none of their waits runs into the watchdog.
+    (A version whose 512 threads all polled the statistics they merge flooded the fabric with L2-bypassing loads and starved the
+    workgroups still computing: launches of more than one workgroup per CU timed out now and then.)"""
+    from drn_amd import functional as DF, ops
+    dt = torch.bfloat16
+    B = 32
+    xs = [rnd(B, L, Ci, seed=5 + i).to(DEV, dt) for i, (L, Ci) in enumerate(zip((256, 128, 64), (256, 512, 1024)))]
+    lat = [_mk_block(Ci, 512, 1, 1, seed=60 + i) for i, Ci in enumerate((256, 512, 1024))]
+    lvl = [_mk_block(512, 512, 3, 1, seed=70 + i) for i in range(3)]
+    tower = _mk_block(512, 1024, 3, 1, seed=80)
+    ops.conv_bn_train_timeouts()
+    with torch.no_grad():
+        def step():
+            inner = DF.multi_conv_block(xs, lat, True, dt, chain_up=True)
+            outs = DF.multi_conv_block(inner, lvl, True, dt)
+            return DF.conv_block(outs, tower[0], tower[1], True, dt)[0]
+        _, tags = _launches(step)
+        assert [t.endswith("+bn") for t in tags] == [True, True, True], tags
+        first = [o.clone() for o in step()]
+        for _ in range(100):
+            last = step()
+        torch.cuda.synchronize()
+    assert ops.conv_bn_train_timeouts() == 0
+    for a, b in zip(first, last):
+        assert torch.equal(a, b)
