@@ -319,6 +319,8 @@ struct BnTrainLv {
   float* running_var;
   float momentum, eps;
   int ld_raw, ld_out, ld_up, ld_gated, ldg, M, L, tiles, blk0, rows_wg;
+  int chain_next;   // >= 0: `up` is the output of THAT level of this launch (the FPN top-down chain, model/FPN.py:63-68): the
+                    // rows to add are recomputed from its raw rows and statistics here instead of waiting for its output
 };
 struct BnTrainParams {
   BnTrainLv lv[DRN_MAX_GROUPS];
@@ -373,16 +375,26 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
   const float* __restrict__ gate = G.gate;
   const int row0 = rblk * G.rows_wg, row1 = min(M, row0 + G.rows_wg);
   constexpr int U = 4;
-  typename V16<T>::raw_t xr[U], ur[U];
+  typename V16<T>::raw_t xr[U], ur[U], ur2[U];
   int sq[U];
+  // top-down chain inside one launch: out_l = relu(bn_l(raw_l)) + nearest_x2(out_{l+1}), out_{l+1} = T(relu(bn(raw_{l+1})) +
+  // nearest_x2(out_{l+2})), out_{l+2} = T(relu(bn(raw_{l+2}))) -- every intermediate rounded to T exactly where the one-launch-
+  // per-level order stores and re-reads it, so the bits are the same and the three levels need no order between them
+  const int h1 = G.chain_next, h2 = h1 >= 0 ? P.lv[h1].chain_next : -1;
+  const T* __restrict__ raw1 = h1 >= 0 ? (const T*)P.lv[h1].raw : nullptr;
+  const T* __restrict__ raw2 = h2 >= 0 ? (const T*)P.lv[h2].raw : nullptr;
+  const long ld1 = h1 >= 0 ? P.lv[h1].ld_raw : 0, ld2 = h2 >= 0 ? P.lv[h2].ld_raw : 0;
   auto load_batch = [&](int mb) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int m = min(mb + u * RP, M - 1);           // clamped index, masked store
       xr[u] = V16<T>::ldraw(raw + (long)m * ld_raw + c0);
       sq[u] = m / L;
-      if (up) {
-        const int t = m - sq[u] * L;
+      const int t = m - sq[u] * L;
+      if (raw1) {
+        ur[u] = V16<T>::ldraw(raw1 + ((long)sq[u] * (L >> 1) + (t >> 1)) * ld1 + c0);
+        if (raw2) ur2[u] = V16<T>::ldraw(raw2 + ((long)sq[u] * (L >> 2) + (t >> 2)) * ld2 + c0);
+      } else if (up) {
         ur[u] = V16<T>::ldraw(up + ((long)sq[u] * (L >> 1) + (t >> 1)) * ld_up + c0);
       }
     }
@@ -390,6 +402,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
   // the rows of the first trip are requested BEFORE the statistics merge: every workgroup of a launch reaches its merge at the
   // same time, and without this the memory system idles through it
   load_batch(row0 + ry);
+  __shared__ float s_sc1[2][64], s_sh1[2][64];
   {
     double mean, var;
     bn_merge64(G.stats, G.tiles, G.M, C, cbase, shd, mean, var);
@@ -399,11 +412,27 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
       s_sc[tid] = sc;
       s_sh[tid] = sh;
     }
+    for (int lev = 0; lev < 2; ++lev) {
+      const int h = lev == 0 ? h1 : h2;
+      if (h < 0) break;
+      const BnTrainLv& H = P.lv[h];
+      bn_merge64(H.stats, H.tiles, H.M, C, cbase, shd, mean, var);
+      if (tid < 64) {
+        float sc, sh, invstd;
+        bn_scale_shift(mean, var, H.eps, H.gamma[cbase + tid], H.beta[cbase + tid], sc, sh, invstd);
+        s_sc1[lev][tid] = sc;
+        s_sh1[lev][tid] = sh;
+      }
+    }
     __syncthreads();
   }
-  float sc[N], sh[N];
+  float sc[N], sh[N], sc1[N], sh1[N], sc2[N], sh2[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) { sc[k] = s_sc[v * N + k]; sh[k] = s_sh[v * N + k]; }
+  for (int k = 0; k < N; ++k) {
+    sc[k] = s_sc[v * N + k]; sh[k] = s_sh[v * N + k];
+    sc1[k] = raw1 ? s_sc1[0][v * N + k] : 0.f; sh1[k] = raw1 ? s_sh1[0][v * N + k] : 0.f;
+    sc2[k] = raw2 ? s_sc1[1][v * N + k] : 0.f; sh2[k] = raw2 ? s_sh1[1][v * N + k] : 0.f;
+  }
   for (int mb = row0 + ry; mb < row1; mb += U * RP) {
     if (mb != row0 + ry) load_batch(mb);
 #pragma unroll
@@ -416,7 +445,26 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const BnTrainParams
         const float y = fmaf(x[k], sc[k], sh[k]);
         x[k] = relu ? fmaxf(y, 0.f) : y;
       }
-      if (up) {
+      if (raw1) {
+        float u1[N];
+        V16<T>::cvt(ur[u], u1);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const float y = fmaf(u1[k], sc1[k], sh1[k]);
+          u1[k] = relu ? fmaxf(y, 0.f) : y;
+        }
+        if (raw2) {
+          float u2[N];
+          V16<T>::cvt(ur2[u], u2);
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const float y = fmaf(u2[k], sc2[k], sh2[k]);
+            u1[k] += DT<T>::round(relu ? fmaxf(y, 0.f) : y);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] += DT<T>::round(u1[k]);
+      } else if (up) {
         float uu[N];
         V16<T>::cvt(ur[u], uu);
 #pragma unroll
@@ -466,6 +514,20 @@ extern "C" int drn_bn_train_apply(const DrnBnTrainDesc* d, int n, int C, int rel
     G.ld_raw = s.ld_raw; G.ld_out = s.ld_out; G.ld_up = s.ld_up; G.ld_gated = s.ld_gated; G.ldg = s.ldg; G.M = s.M; G.L = s.L;
     G.tiles = s.tiles; G.blk0 = blocks; G.rows_wg = rows_wg;
     blocks += cdiv(s.M, rows_wg) * (C / 64);
+    // `up` = the output of another level of THIS launch (half the length, same clips): recomputed in place, no order needed
+    G.chain_next = -1;
+    for (int j = 0; j < n && s.up; ++j)
+      if (j != i && d[j].out == s.up && d[j].L * 2 == s.L && d[j].M * 2 == s.M) {
+        G.chain_next = j;
+        G.up = nullptr;
+      }
+  }
+  for (int i = 0; i < n; ++i) {
+    int depth = 1;
+    for (int h = P.lv[i].chain_next; h >= 0 && depth <= n; h = P.lv[h].chain_next) ++depth;
+    DRN_CHECK_ARG(depth <= 3, "%s: an upsample chain of more than three levels inside one launch (launch the levels in order)", who);
+    DRN_CHECK_ARG(P.lv[i].chain_next < 0 || P.lv[i].L % 4 == 0 || P.lv[P.lv[i].chain_next].chain_next < 0,
+                  "%s: a three-level chain needs sequence lengths that are multiples of 4", who);
   }
   P.total_blocks = blocks;
   if (dtype == DRN_BF16) bn_train_apply_kernel<bf16_t><<<blocks, 256, 0, (hipStream_t)stream>>>(P);

@@ -22,6 +22,9 @@ __device__ __forceinline__ unsigned long long bn_tag_pack(float v, unsigned tag)
 __device__ __forceinline__ unsigned long long bn_ld_pair(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // global_load_dwordx2 ... sc1
 }
+// (Reading the pairs through this XCD's L2 once bn_wait_slabs() has seen the writers -- ~14 workgroups per XCD merge the same
+// column -- was tried: merge phase 4.7 -> 12 us.  The coherent polling loads leave their lines in L2 as they were when
+// polled, later plain loads hit those and fail the tag check, and the coherent retry comes on top.)
 __device__ __forceinline__ bool bn_wait_expired(const long long t0, int* timeouts) {
   __builtin_amdgcn_s_sleep(32);
   if (wall_clock64() - t0 <= 200000000LL) return false;                            // 2 s of the 100 MHz wall clock
@@ -45,7 +48,7 @@ __device__ __forceinline__ void bn_wait_slabs(const void* st_, const int slabs, 
     for (;;) {
       if (!ready) ready = (unsigned)(bn_ld_pair(p + ((long)s * 2 + 1) * C) >> 32) == tg.want;
       if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
-      __builtin_amdgcn_s_sleep(32);
+      __builtin_amdgcn_s_sleep(12);
       if (wall_clock64() - t0 > 200000000LL) {                                          // 2 s of the 100 MHz wall clock
         if (!ready) __hip_atomic_fetch_add(tg.timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;

@@ -72,10 +72,12 @@ template <typename T> struct DT;
 template <> struct DT<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }          // value as a T would hold it
 };
 template <> struct DT<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+  static __device__ __forceinline__ float round(float v) { return (float)(bf16_t)v; }
 };
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -2,6 +2,7 @@
 // (gemm_nt_kernel.h: conv_gemm_nt_kernel<..., BNF = true> / nt_epilogue_bn).  Replaces drn_gemm_nt + drn_bn_train_apply for
 // the conv blocks of model/basic_blocks.py:9-31, the FPN laterals / output convs (model/FPN.py:54-69) and the head towers
 // (model/fcos.py:33-69, statistics per level call: fcos.py:93-102).
+#define DRN_NT_PHASES_NAME drn_debug_nt_phases_bn
 #include "gemm_nt_kernel.h"
 
 // Workgroups of a kernel variant the chip holds at once (the column wait needs the whole grid resident).

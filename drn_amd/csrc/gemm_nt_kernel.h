@@ -484,6 +484,27 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
   }
 }
 
+// Optional per-wave timeline (build with -DDRN_NT_TRACE, scripts/experiments/nt_trace.py): workgroup 0 stamps s_memtime at
+// seven points of every K-step into P.ws (pass a buffer through drn_gemm_nt_splitk with ksplit = 1).
+// -DDRN_NT_PHASES (scripts/experiments/nt_phases.py): wall_clock64() (100 MHz) per workgroup at entry / staging state ready /
+// first K-tile landed / K loop done / exit, read back with drn_debug_nt_phases() -- the fixed part of a small launch.
+#ifdef DRN_NT_PHASES
+static __device__ long long g_nt_phases[4096 * 8];
+#define NT_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) g_nt_phases[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#ifndef DRN_NT_PHASES_NAME
+#define DRN_NT_PHASES_NAME drn_debug_nt_phases
+#endif
+extern "C" int DRN_NT_PHASES_NAME(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_phases), (size_t)n * 8); }
+#else
+#define NT_PHASE(i) do { } while (0)
+#endif
+#ifdef DRN_NT_TRACE
+#define NT_STAMP(slot) do { if (P.ws && P.ksplit == 1 && blockIdx.x == 0 && l == 0 && kt - kt_lo < 64) \
+    ((long long*)P.ws)[((w * 64) + (kt - kt_lo)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NT_STAMP(slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // conv -> BatchNorm1d (training) -> ReLU in ONE launch (model/basic_blocks.py:9-31; per-level-call statistics,
 // model/fcos.py:93-102).  Before: the GEMM wrote the raw tile, bn_train_apply_kernel re-read it, normalised and wrote it again
@@ -660,6 +681,7 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, int* gen_w
     stage_and_store();
   }
 
+  NT_PHASE(4);
   // ---- 2. merge: own group, then the coarser levels of the chain (each merge polls its pairs until they carry this tag)
   const int ci = tid & 127;
   int lev_group[MAXLEV];
@@ -684,6 +706,7 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, int* gen_w
         if ((F.rs_mask >> h) & 1) bn_wait_slabs(K.p[h].stats, K.bn[h].slabs, N, n0, tg);
   }
   __syncthreads();
+  NT_PHASE(5);
 #pragma unroll
   for (int lev = 0; lev < MAXLEV; ++lev) {
     if (lev >= nlev) break;
@@ -713,6 +736,7 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, int* gen_w
   }
   __syncthreads();
 
+  NT_PHASE(6);
   // ---- 3. normalise the kept row segments (scale / shift of the lane's columns are read from LDS where they are used: the
   // registers they would occupy across the whole loop are what pushed the 128-register variants into scratch)
   const float* my_sc = s_sc + wc * WCOLS + cv * VEC;
@@ -783,6 +807,7 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, int* gen_w
     }
   }
 
+  NT_PHASE(7);
   // ---- 4b. running statistics of the later groups that share this group's BatchNorm module, in group order
   if (tm == 0 && F.rs_owner && F.rs_mask) {
     for (int h = g + 1; h < K.ngroups; ++h) {
@@ -818,24 +843,6 @@ __device__ __forceinline__ void nt_epilogue_bn(const GemmParamsBn& K, int* gen_w
     if (tid == 0) __hip_atomic_store(gen_word, (int)(gen + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-
-// Optional per-wave timeline (build with -DDRN_NT_TRACE, scripts/experiments/nt_trace.py): workgroup 0 stamps s_memtime at
-// seven points of every K-step into P.ws (pass a buffer through drn_gemm_nt_splitk with ksplit = 1).
-// -DDRN_NT_PHASES (scripts/experiments/nt_phases.py): wall_clock64() (100 MHz) per workgroup at entry / staging state ready /
-// first K-tile landed / K loop done / exit, read back with drn_debug_nt_phases() -- the fixed part of a small launch.
-#ifdef DRN_NT_PHASES
-__device__ long long g_nt_phases[4096 * 8];
-#define NT_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) g_nt_phases[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-extern "C" int drn_debug_nt_phases(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_phases), (size_t)n * 8); }
-#else
-#define NT_PHASE(i) do { } while (0)
-#endif
-#ifdef DRN_NT_TRACE
-#define NT_STAMP(slot) do { if (P.ws && P.ksplit == 1 && blockIdx.x == 0 && l == 0 && kt - kt_lo < 64) \
-    ((long long*)P.ws)[((w * 64) + (kt - kt_lo)) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define NT_STAMP(slot) do { } while (0)
-#endif
 
 // STAGES-deep LDS ring (STAGES x 32 KB).  Iteration kt: wait until tile kt's global_load_lds have landed with a COUNTED
 // vmcnt (the STAGES-2 younger tiles stay in flight across the barrier), one raw s_barrier, issue tile kt+STAGES-1 into the
@@ -1044,7 +1051,6 @@ __global__ __launch_bounds__(64 * WM * WN, (BNF && MI * NI == 8 && STAGES == 2) 
 
   if constexpr (BNF) {                   // conv -> BN -> ReLU in this launch (never split)
     nt_epilogue_bn<T, WM, WN, MI, NI, CHAIN>(P_arg, P.counters, bn_gen, pr, g, acc, smem, m0, n0, tm, tn);
-    NT_PHASE(4);
     return;
   } else if constexpr (MI * NI == 8) {   // (the 128x128 tiles: split launches always use them)
     if (P.ksplit > 1) {

@@ -925,7 +925,12 @@ class _MultiConvFn(torch.autograd.Function):
                 for grp in ([fin] if same_c else [[f] for f in fin]):
                     ops.bn_finalize_multi(grp, grp[0]["ss"].shape[1])
             apply = ops.bn_train_apply if fused else ops.bn_apply_multi
-            if chain_up or not same_c:
+            if chain_up and fused and same_c and n <= 3 and all(g[2] % 4 == 0 for g in geo[:max(n - 2, 0)]):
+                # the whole top-down chain in ONE launch: a level whose `up` is another level's output of the same launch
+                # recomputes the rows it adds from that level's raw rows and statistics (drn_bn_train_apply) -- same bits as
+                # the coarse-to-fine order, two launches fewer
+                apply(lvs, geo[0][5], code)
+            elif chain_up or not same_c:
                 for l in range(n - 1, -1, -1):                # coarse to fine: out_l reads out_{l+1}, one launch per level
                     apply([lvs[l]], geo[l][5], code)
             else:

@@ -431,10 +431,13 @@ def _bn_train_descs(levels):
     return arr
 
 
-# conv -> BN(train) -> ReLU in ONE launch (drn_conv_bn_train).  Its in-kernel wait needs the whole grid resident on a device
-# this process owns: DRN_FORCE_DEVICE (the test mode that puts several ranks on ONE GPU) and DRN_BN_FUSE=0 switch it off, and
-# the two-launch path (drn_gemm_nt + drn_bn_train_apply, same bits) runs instead.
-BN_FUSE = os.environ.get("DRN_BN_FUSE", "1") != "0" and os.environ.get("DRN_FORCE_DEVICE") is None
+# conv -> BN(train) -> ReLU in ONE launch (drn_conv_bn_train): built, bit-identical to the two-launch path and stress-tested
+# (tests/test_conv_bn_gpu.py) -- and OFF by default, because it measures slower inside the step (DESIGN.md section 8, round 4:
+# FPN + heads forward 274 vs 257 us).  After a workgroup's K loop the hand-off is publish -> wait -> merge, three memory-side round
+# trips plus 45 MB of L2-bypassing statistics reads per launch (11-13 us), against ~3 us of epilogue + a 6-15 us BatchNorm launch
+# that reads the same statistics out of L2.  DRN_BN_FUSE=1 turns it on (never together with DRN_FORCE_DEVICE, the test mode that
+# puts several ranks on ONE GPU: its in-kernel wait needs the whole grid resident on a device this process owns).
+BN_FUSE = os.environ.get("DRN_BN_FUSE", "0") == "1" and os.environ.get("DRN_FORCE_DEVICE") is None
 DRN_ERR_UNSUPPORTED = -3
 
 

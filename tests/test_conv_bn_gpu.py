@@ -36,14 +36,15 @@ def _both(fn, may_decline=False):
     launcher is allowed to decline -- the exact-f32 128x128 variant spills a few registers and is only trusted with one
     workgroup per CU, so a 448-workgroup f32 launch runs as two launches)."""
     from drn_amd import ops
-    assert ops.BN_FUSE, "fused conv->BN is switched off in this environment (DRN_BN_FUSE / DRN_FORCE_DEVICE)"
-    fused, tags = _launches(fn)
-    assert may_decline or any(t.endswith("+bn") for t in tags), "the one-launch kernel did not run: %s" % tags
-    ops.BN_FUSE = False
+    saved = ops.BN_FUSE
     try:
+        ops.BN_FUSE = True                 # (off by default: slower inside the step, see drn_amd/ops.py)
+        fused, tags = _launches(fn)
+        assert may_decline or any(t.endswith("+bn") for t in tags), "the one-launch kernel did not run: %s" % tags
+        ops.BN_FUSE = False
         plain, tags2 = _launches(fn)
     finally:
-        ops.BN_FUSE = True
+        ops.BN_FUSE = saved
     assert not any(t.endswith("+bn") for t in tags2)
     assert ops.conv_bn_train_timeouts() == 0
     return fused, plain
@@ -146,7 +147,7 @@ def test_independent_blocks_and_the_top_down_chain(dt, chain, B, Ls, Cins, N, k)
         _same(a, b, "saved tensor %d" % i)
 
 
-def test_one_launch_is_deterministic_and_advances_its_generation():
+def test_one_launch_is_deterministic_and_advances_its_generation(monkeypatch):
     """Ten launches in a row on the same inputs: the same bits every time, and the generation word that tags the statistics
     pairs moved on by exactly one per launch (a stale pair of an earlier launch can never pass for a fresh one)."""
     from drn_amd import functional as DF, ops
@@ -154,6 +155,7 @@ def test_one_launch_is_deterministic_and_advances_its_generation():
     xs = [rnd(32, L, 512, seed=9 + i).to(DEV, dt) for i, L in enumerate((256, 128, 64))]
     conv, bn = _mk_block(512, 512, 3, 1, seed=40)
     first = None
+    monkeypatch.setattr(ops, "BN_FUSE", True)
     DF.conv_block(xs, conv, bn, True, dt)
     ws, gen = ops._bn_tagged_ws(torch.device(DEV), 0)
     g0 = int(gen)
@@ -169,10 +171,11 @@ def test_one_launch_is_deterministic_and_advances_its_generation():
     assert int(gen) == g0 + 10
 
 
-def test_unsupported_launches_fall_back_to_two_launches():
+def test_unsupported_launches_fall_back_to_two_launches(monkeypatch):
     """Different N per group / N not a multiple of 128: drn_conv_bn_train declines (nothing launched) and the caller runs the
     GEMM and the BatchNorm pass separately."""
-    from drn_amd import functional as DF
+    from drn_amd import functional as DF, ops
+    monkeypatch.setattr(ops, "BN_FUSE", True)
     dt = torch.float32
     x = rnd(2, 32, 64, seed=1).to(DEV, dt)
     conv, bn = _mk_block(64, 64, 3, 1, seed=50)
@@ -183,7 +186,7 @@ def test_unsupported_launches_fall_back_to_two_launches():
     assert float((outs[0].permute(0, 2, 1) - ref).abs().max()) < 1e-4
 
 
-def test_waiting_launches_under_load_never_time_out():
+def test_waiting_launches_under_load_never_time_out(monkeypatch):
     """300 one-launch conv->BN blocks back to back at the benchmarked pyramid shapes (448 workgroups, two per CU; 224 of the
     256x256 tile) with and without the top-down chain: every launch fuses and none of their waits runs into the watchdog.
     (A version whose 512 threads all polled the statistics they merge flooded the fabric with L2-bypassing loads and starved the
@@ -195,6 +198,7 @@ def test_waiting_launches_under_load_never_time_out():
     lat = [_mk_block(Ci, 512, 1, 1, seed=60 + i) for i, Ci in enumerate((256, 512, 1024))]
     lvl = [_mk_block(512, 512, 3, 1, seed=70 + i) for i in range(3)]
     tower = _mk_block(512, 1024, 3, 1, seed=80)
+    monkeypatch.setattr(ops, "BN_FUSE", True)
     ops.conv_bn_train_timeouts()
     with torch.no_grad():
         def step():
@@ -210,3 +214,60 @@ def test_waiting_launches_under_load_never_time_out():
     assert ops.conv_bn_train_timeouts() == 0
     for a, b in zip(first, last):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Ls,C", [(2, (64, 32, 16), 128), (3, (40, 20), 64), (32, (256, 128, 64), 512)])
+def test_top_down_chain_in_one_batchnorm_launch(dt, B, Ls, C):
+    """drn_bn_train_apply with the whole FPN top-down chain in ONE launch (a level whose `up` is another level's output of the
+    same launch recomputes the rows it adds from that level's raw rows and statistics; model/FPN.py:63-68) against one launch per
+    level, coarse to fine: the same bits."""
+    from drn_amd import ops
+    code = ops.BF16 if dt == torch.bfloat16 else ops.F32
+    n = len(Ls)
+    raws = [(rnd(B, L, C, seed=90 + i) * (1.0 + i)).to(DEV, dt) for i, L in enumerate(Ls)]
+    gam = [(rnd(C, seed=95 + i).abs() + 0.5).to(DEV) for i in range(n)]
+    bet = [(rnd(C, seed=98 + i) * 0.3).to(DEV) for i in range(n)]
+
+    def stats_of(raw):
+        """per-128-row-slab (sum, M2) as the GEMM epilogue leaves them (from the stored values: any consistent numbers do)"""
+        x = raw.float().reshape(-1, C)
+        out = []
+        for r0 in range(0, x.shape[0], 128):
+            blk = x[r0:r0 + 128]
+            out.append(torch.stack([blk.sum(0), ((blk - blk.mean(0)) ** 2).sum(0)]))
+        return torch.stack(out).contiguous()
+    sts = [stats_of(r) for r in raws]
+
+    def run(one_launch):
+        outs = [torch.empty_like(r) for r in raws]
+        lvs = []
+        for l in range(n):
+            M = B * Ls[l]
+            up = outs[l + 1] if l + 1 < n else None
+            lvs.append(dict(raw=raws[l], ld_raw=C, out=outs[l], ld_out=C, M=M, L=Ls[l], up=up, ld_up=C if up is not None else 0,
+                            stats=sts[l], tiles=sts[l].shape[0], ss=torch.empty(2, C, device=DEV), save=torch.empty(2, C, device=DEV),
+                            gamma=gam[l], beta=bet[l], momentum=0.1, eps=1e-5,
+                            running_mean=torch.zeros(C, device=DEV), running_var=torch.ones(C, device=DEV)))
+        if one_launch:
+            ops.bn_train_apply(lvs, C, code)
+        else:
+            for l in range(n - 1, -1, -1):
+                ops.bn_train_apply([lvs[l]], C, code)
+        torch.cuda.synchronize()
+        return outs, [lv[k] for lv in lvs for k in ("ss", "save", "running_mean", "running_var")]
+    (o1, s1), (o2, s2) = run(True), run(False)
+    for l in range(n):
+        _same(o1[l], o2[l], "out level %d" % l)
+    for i, (a, b) in enumerate(zip(s1, s2)):
+        _same(a, b, "statistic tensor %d" % i)
+    # and against the definition, fp64
+    ref_up = None
+    for l in range(n - 1, -1, -1):
+        x = raws[l].double().reshape(-1, C)
+        y = torch.relu((x - x.mean(0)) / torch.sqrt(x.var(0, unbiased=False) + 1e-5) * gam[l].double() + bet[l].double()).reshape(B, Ls[l], C)
+        if ref_up is not None:
+            y = y + ref_up.repeat_interleave(2, dim=1)
+        ref_up = y
+        tol = 3e-2 if dt == torch.bfloat16 else 1e-4
+        assert float((o1[l].double() - y).abs().max()) <= tol * max(1.0, float(y.abs().max())), l
