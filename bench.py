@@ -125,20 +125,27 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
             out[key] = {"clips_per_s": round(B * len(batches) * n_ep / dt, 1), "ms_per_step": round(dt / (len(batches) * n_ep) * 1e3, 3),
                         "graphs": len([s for s in tr._slots.values() if s.graph is not None]) if graph else 0}
             if graph:
-                # the same loop fed from PINNED HOST batches (what a DataLoader hands over): the H2D copy of the fp32 features
-                # (B x T x D x 4 bytes per step) rides on the step's stream -- the PCIe-inclusive rate, never the headline value
-                hb = [tuple(t.cpu().pin_memory() if torch.is_tensor(t) else t for t in b) for b in batches]
-                tr.train_epoch(hb)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n_ep):
+                # the same loop fed from PINNED HOST batches (what a DataLoader hands over): the H2D copy of the features rides on
+                # a copy stream one batch ahead -- the PCIe-inclusive rate, never the headline value.  train.py's hand-over for a
+                # bf16 model is bf16 features (drn_amd.data.collate_data(feature_dtype=...): rounded in the DataLoader workers by
+                # the rule the step's cast applies, B x T x D x 2 bytes per step); `_fp32` = the reference's fp32 hand-over
+                for key, fdt in (("T%d_graph_host_inputs" % T, cdt), ("T%d_graph_host_inputs_fp32" % T, torch.float32)):
+                    if key.endswith("_fp32") and cdt == torch.float32:
+                        continue
+                    hb = [tuple((t.to(fdt) if i == 2 else t).cpu().pin_memory() if torch.is_tensor(t) else t for i, t in enumerate(b))
+                          for b in batches]
                     tr.train_epoch(hb)
-                torch.cuda.synchronize()
-                dth = time.perf_counter() - t0
-                out["T%d_graph_host_inputs" % T] = {"clips_per_s": round(B * len(hb) * n_ep / dth, 1),
-                                                    "ms_per_step": round(dth / (len(hb) * n_ep) * 1e3, 3),
-                                                    "h2d_MB_per_step": round(B * T * D * 4 / 1e6, 1)}
-                del hb
+                    tr.train_epoch(hb)
+                    tr.train_epoch(hb)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(n_ep):
+                        tr.train_epoch(hb)
+                    torch.cuda.synchronize()
+                    dth = time.perf_counter() - t0
+                    out[key] = {"clips_per_s": round(B * len(hb) * n_ep / dth, 1), "ms_per_step": round(dth / (len(hb) * n_ep) * 1e3, 3),
+                                "h2d_MB_per_step": round(B * T * D * (2 if fdt == torch.bfloat16 else 4) / 1e6, 1)}
+                    del hb
             if graph and T == Ts[-1]:
                 # evaluation loop (main.py:270-366): eval-mode forward, post-processor, host-side NMS / R@k
                 ev = batches[:4]
@@ -153,8 +160,9 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
             del m, tr
     out["note"] = ("Trainer.train_epoch (what train.py runs) on 8 device-resident synthetic batches, B=%d, query lengths 3..8 padded to "
                    "multiples of 4; graph = hipGraph replay per input geometry (Trainer(graph=True), train.py's default), eager = every "
-                   "kernel launched from Python; *_host_inputs = the graph loop fed from pinned host batches (H2D copy of the fp32 "
-                   "features inside the step: the PCIe-inclusive rate)" % B)
+                   "kernel launched from Python; *_host_inputs = the graph loop fed from pinned host batches, features in the compute "
+                   "dtype as train.py's DataLoader hands them over (H2D copy one batch ahead on a copy stream: the PCIe-inclusive "
+                   "rate); *_host_inputs_fp32 = the same with fp32 features (the reference's hand-over)" % B)
     return out
 
 

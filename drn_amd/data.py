@@ -100,14 +100,18 @@ class CharadesSTA(Dataset):
         return vid, props_s_e, props_fts, gt, tokens, len(smp["tokens"]), len(proposals), num_frames
 
 
-def collate_data(batch):
-    """dataset.py:180-224: sort by query length (descending, stable), zero-pad proposals and tokens."""
+def collate_data(batch, feature_dtype=None):
+    """dataset.py:180-224: sort by query length (descending, stable), zero-pad proposals and tokens.
+    feature_dtype (torch.bfloat16 for a bf16 model; train.py passes it): the padded feature tensor is built in the model's
+    compute dtype here, in the DataLoader workers -- the same round-to-nearest-even the step's first kernel would apply to the
+    fp32 values, so every result stays bit-identical while the host -> device copy of the features (134 MB per step at
+    T = 256, D = 4096: longer than the step itself) halves."""
     data = sorted(batch, key=lambda x: x[5], reverse=True)
     bs = len(batch)
     ft_dim = batch[0][2].size(-1)
     max_props = max(x[6] for x in batch)
     max_len = max(x[5] for x in batch)
-    props_features = torch.zeros(bs, max_props, ft_dim)
+    props_features = torch.zeros(bs, max_props, ft_dim, dtype=feature_dtype or torch.float32)
     props_s_e = torch.zeros(bs, max_props, 2, dtype=torch.double)
     query_tokens = torch.zeros(bs, max_len)
     names, gts, qlens, nprops, nframes = [], [], [], [], []

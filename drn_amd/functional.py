@@ -1044,11 +1044,15 @@ def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True):
     xc = feats.contiguous()
     # bf16 training: the prop_fc weight gradient runs as an NT product of K-major operands (see backward); the
     # transposed copy of the features is written by the same pass that casts them
-    nt_wgrad = (code == ops.BF16 and NT_WGRAD and (B * T) % 8 == 0 and D % 8 == 0 and xc.dtype == torch.float32 and want_wgrad)
+    nt_wgrad = code == ops.BF16 and NT_WGRAD and (B * T) % 8 == 0 and D % 8 == 0 and want_wgrad
     pr.xcT = None
-    if nt_wgrad:
+    if nt_wgrad and xc.dtype == torch.float32:
         xc2, pr.xcT = ops.cast_transpose(xc.view(B * T, D), code)
         xc = xc2.view(B, T, D)
+    elif nt_wgrad and xc.dtype == dtype:
+        # features handed over in the compute dtype (drn_amd.data.collate_data(feature_dtype=...): rounded on the host by the
+        # same rule): only the K-major copy is left to produce
+        pr.xcT = ops.transpose2d(xc.view(B * T, D), code)
     elif xc.dtype != dtype:
         xc = ops.cast(xc.float(), code)
     pr.xc = xc

@@ -55,12 +55,12 @@ class _StepSlot(object):
     """Static device inputs + the captured hipGraph of one training-step geometry (clips, proposals, feature dim, padded query
     length)."""
 
-    def __init__(self, key, device, pse_dtype, gt_dtype):
+    def __init__(self, key, device, pse_dtype, gt_dtype, feat_dtype=torch.float32):
         B, T, D, Lq = key
         self.key = key
         self.tok = torch.zeros((B, Lq), dtype=torch.int64, device=device)
         self.qlen = torch.zeros((B,), dtype=torch.int64, device=device)
-        self.feats = torch.zeros((B, T, D), dtype=torch.float32, device=device)
+        self.feats = torch.zeros((B, T, D), dtype=feat_dtype, device=device)
         self.pse = torch.zeros((B, T, 2), dtype=pse_dtype, device=device)
         self.gt = torch.zeros((B, 2), dtype=gt_dtype, device=device)
         self.args = (self.tok, self.qlen, self.feats, self.pse, self.gt, None, None)
@@ -134,6 +134,8 @@ class Trainer(object):
         B, T, D = feats.shape
         Lq = -(-int(tok.shape[1]) // self.lq_bucket) * self.lq_bucket
         geo = (int(B), int(T), int(D), Lq)
+        if feats.dtype != torch.float32:
+            geo = geo + (feats.dtype,)        # features handed over in the compute dtype: their own captures (no cast in the step)
         turn = self._turn.get(geo, 0)
         key = geo + ((turn % 2) if alternate else 0,)
         slot = self._slots.get(key)
@@ -143,9 +145,9 @@ class Trainer(object):
                     self._eager_geos.add(geo)
                     import warnings
                     warnings.warn("drn_amd.Trainer: %d hipGraph captures exist (max_graphs); steps of geometry B=%d T=%d D=%d Lq=%d "
-                                  "run as eager launches" % ((len(self._slots),) + geo))
+                                  "run as eager launches" % ((len(self._slots),) + geo[:4]))
                 return None
-            slot = self._slots[key] = _StepSlot(geo, self.device, pse.dtype, gt.dtype)
+            slot = self._slots[key] = _StepSlot(geo[:4], self.device, pse.dtype, gt.dtype, feats.dtype)
             slot.alt = key[-1]
         if pse.dtype != slot.pse.dtype or gt.dtype != slot.gt.dtype:
             return None

@@ -46,3 +46,21 @@ def test_dataloader_round_trip():
     assert sum(len(b[0]) for b in batches) == len(ds)
     for b in batches:
         assert b[2].shape[:2] == b[1].shape[:2] and b[2].shape[2] == 12 and b[4].shape[1] == int(b[5].max())
+
+
+def test_collate_in_the_compute_dtype_rounds_like_the_device_cast():
+    """collate_data(feature_dtype=torch.bfloat16) -- what train.py hands a bf16 model -- equals the fp32 collate rounded to
+    nearest-even, element for element (the rule drn_cast_transpose applies on the device), and changes nothing else."""
+    import torch
+    from drn_amd.data import collate_data
+    g = torch.Generator().manual_seed(0)
+    batch = []
+    for i, (nprops, qlen) in enumerate([(5, 3), (7, 6), (4, 6)]):
+        batch.append(("v%d" % i, torch.rand(nprops, 2, generator=g, dtype=torch.float64), torch.randn(nprops, 24, generator=g) * 3,
+                      (0.1 * i, 0.5 + 0.1 * i), torch.randint(1, 50, (qlen,), generator=g), qlen, nprops, 100 + i))
+    a = collate_data(batch)
+    b = collate_data(batch, feature_dtype=torch.bfloat16)
+    assert b[2].dtype == torch.bfloat16 and torch.equal(b[2], a[2].bfloat16())
+    for i in (1, 3, 4, 5, 6, 7):
+        assert torch.equal(a[i], b[i])
+    assert a[0] == b[0]

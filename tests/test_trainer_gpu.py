@@ -133,9 +133,14 @@ def test_train_epoch_prefetches_host_batches_without_changing_anything():
     B, Tp, D, n = 4, 32, 64, 6
     raw = _varying_batches(n, B, Tp, D)
     as_loader = lambda bs: [(["v"] * B, b[3], b[2], b[4], b[0], b[1], b[5], b[6]) for b in bs]     # collate_data's 8-tuple
+    # "bf16 host": the features handed over in the compute dtype, as drn_amd.data.collate_data(feature_dtype=torch.bfloat16)
+    # builds them in the DataLoader workers (train.py's default for a bf16 model): rounded on the host by the rule the step's
+    # cast kernel applies on the device, so half the bytes cross PCIe and nothing changes
     kinds = {"device": [[t.to("cuda:0") if torch.is_tensor(t) else t for t in b] for b in raw],
              "pinned": [[t.pin_memory() if torch.is_tensor(t) else t for t in b] for b in raw],
-             "pageable": raw}
+             "pageable": raw,
+             "bf16 host": [[(t.bfloat16() if i == 2 else t).pin_memory() if torch.is_tensor(t) else t for i, t in enumerate(b)] for b in raw],
+             "bf16 device": [[(t.bfloat16() if i == 2 else t).to("cuda:0") if torch.is_tensor(t) else t for i, t in enumerate(b)] for b in raw]}
     states, means = {}, {}
     for kind, bs in kinds.items():
         m = hip_model(1)
@@ -146,7 +151,45 @@ def test_train_epoch_prefetches_host_batches_without_changing_anything():
         DF.flush_bn_counters()
         assert any(s.graph is not None for s in tr._slots.values())
         states[kind] = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    for kind in ("pinned", "pageable"):
+    for kind in ("pinned", "pageable", "bf16 host", "bf16 device"):
         assert means[kind] == means["device"], (kind, means[kind], means["device"])
         for k in states["device"]:
             assert torch.equal(states[kind][k], states["device"][k]), (kind, k)
+
+
+def test_graph_trainer_over_a_real_dataloader_with_pinning_workers(tmp_path):
+    """train.py's loop as a user runs it: Trainer(graph=True).train_epoch over DataLoader(num_workers > 0, pin_memory=True) with
+    the bf16 hand-over of the features.  The DataLoader's pin_memory THREAD calls hipHostMalloc while the first steps are being
+    captured -- in the default (global) capture error mode that fails the capture; the captures run thread_local."""
+    import functools
+    from torch.utils.data import DataLoader
+    from drn_amd import functional as DF
+    from drn_amd import trainer as T
+    from drn_amd.data import CharadesSTA, collate_data
+    from drn_amd.utils.synthetic import default_cfg
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.join(here, "golden", "charades_mini")
+    cfg = default_cfg("TINY", 12, 1)
+    cfg["feature_type"] = "C3D"
+    cfg["C3D"] = {"feature_root": "./features", "feature_dim": 12, "ft_window_size": 16, "ft_overlap": 0.5}
+    cfg["props_file_path"] = "./data/dataset/Charades/mini_props.txt"
+    ds = CharadesSTA(cfg, "train", root, lambda s: s.split())
+    runs = {}
+    for mode in ("loader", "plain"):
+        m = hip_model(1, cfg=cfg)
+        m.set_compute_dtype(torch.bfloat16)
+        tr = T.Trainer(m, 1, lr=1e-4, graph=True)
+        collate = functools.partial(collate_data, feature_dtype=torch.bfloat16)
+        if mode == "loader":
+            loader = DataLoader(ds, batch_size=4, shuffle=False, collate_fn=collate, num_workers=2, pin_memory=True, drop_last=True)
+        else:
+            loader = list(DataLoader(ds, batch_size=4, shuffle=False, collate_fn=collate, drop_last=True))
+        means = [tr.train_epoch(loader, e) for e in range(4)]          # warm-up, capture (while the pin thread works), replay
+        torch.cuda.synchronize()
+        DF.flush_bn_counters()
+        assert any(s.graph is not None for s in tr._slots.values()), "no step was ever captured"
+        assert all(np.isfinite(means))
+        runs[mode] = (means, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    assert runs["loader"][0] == runs["plain"][0]
+    for k, v in runs["plain"][1].items():
+        assert torch.equal(v, runs["loader"][1][k]), k

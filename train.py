@@ -9,6 +9,7 @@
 config's `Charades` section, data/glove_weights).  One process per GPU; each rank reads its own shard of the training
 set (DistributedSampler) and the gradients are averaged over RCCL (drn_amd.dist)."""
 import argparse
+import functools
 import json
 import os
 
@@ -55,9 +56,11 @@ def main():
     test_set = CharadesSTA(cfg, "test", args.root)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set, world, rank, shuffle=True) if world > 1 else None
     bs = args.batch_size or cfg.get("batch_size", 32)
-    train_loader = DataLoader(train_set, batch_size=bs, shuffle=sampler is None, sampler=sampler, collate_fn=collate_data,
+    # the workers hand the features over in the compute dtype (bf16: half the bytes over PCIe, same bits after the step's cast)
+    collate = functools.partial(collate_data, feature_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
+    train_loader = DataLoader(train_set, batch_size=bs, shuffle=sampler is None, sampler=sampler, collate_fn=collate,
                               num_workers=args.workers, pin_memory=True, drop_last=world > 1)
-    test_loader = DataLoader(test_set, batch_size=cfg.get("test_batch_size", 16), shuffle=False, collate_fn=collate_data,
+    test_loader = DataLoader(test_set, batch_size=cfg.get("test_batch_size", 16), shuffle=False, collate_fn=collate,
                              num_workers=args.workers, pin_memory=True)
 
     model = mainModel(len(word2id), argparse.Namespace(**cfg),
