@@ -147,14 +147,19 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
                                 "h2d_MB_per_step": round(B * T * D * (2 if fdt == torch.bfloat16 else 4) / 1e6, 1)}
                     del hb
             if graph and T == Ts[-1]:
-                # evaluation loop (main.py:270-366): eval-mode forward, post-processor, host-side NMS / R@k
-                ev = batches[:4]
-                tr.evaluate(ev)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                tr.evaluate(ev)
-                out["evaluate_T%d" % T] = {"clips_per_s": round(B * len(ev) / (time.perf_counter() - t0), 1),
-                                           "note": "Trainer.evaluate: eval forward + drn_postprocess + host-side result records, temporal NMS, R@1/R@5"}
+                # evaluation loop (main.py:270-366) as Trainer.fit runs it: eval-mode forward, post-processor, Recall@k with
+                # temporal NMS on the device (drn_eval_recall), one host copy at the end; `records` = the path that also builds the
+                # reference's raw-results records and runs the host evaluator on them (Trainer.evaluate's default)
+                ev = batches[:4] * 4
+                for key, kw in (("evaluate_T%d" % T, {"with_results": False}), ("evaluate_T%d_records" % T, {})):
+                    tr.evaluate(ev, **kw)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    tr.evaluate(ev, **kw)
+                    out[key] = {"clips_per_s": round(B * len(ev) / (time.perf_counter() - t0), 1)}
+                out["evaluate_T%d" % T]["note"] = ("Trainer.evaluate(with_results=False), what fit() runs: eval forward + drn_postprocess + "
+                                                   "drn_eval_recall (temporal NMS, R@1/R@5 on the device); *_records: + the host-side "
+                                                   "raw-results records and the host evaluator")
             if tr.reducer is not None:
                 tr.reducer.remove()
             del m, tr

@@ -115,3 +115,76 @@ extern "C" int drn_postprocess(const DrnLossLevel* levels, int nlevels, int B, c
   postprocess_kernel<<<B, PP_THREADS, 0, (hipStream_t)stream>>>(P, logits, reg, iou, det, scores, locs, counts);
   return drn_launch_status("drn_postprocess");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Recall@k at temporal-IoU thresholds with temporal NMS, on the device (utils/evaluate_utils.py:131-215 as driven by
+// main.py:324-364): one wavefront per (clip, IoU threshold).  The host evaluator sorts a clip's predictions by score (stable),
+// runs a greedy NMS at threshold iou - 0.05 from the highest score down -- score ties go to the LATER prediction -- and counts
+// the clip when one of the first k survivors overlaps the ground truth by >= iou (un-clamped IoU).  Only the first
+// K = max(k) survivors matter, so no sort is needed: K times, the best candidate still alive is found with a wave reduction
+// over (score, index), tested against the ground truth, and everything it suppresses is struck out.  All arithmetic in
+// double on the float32 detections, exactly the numbers the host path sees after .tolist().
+// out[b][q] = position of the first survivor that hits (0-based), or K when none of the first K does.
+#define ER_MAX_CAND 4096
+__global__ __launch_bounds__(64) void eval_recall_kernel(const float* __restrict__ det, const float* __restrict__ scores,
+                                                         const int* __restrict__ counts, int nlevels, int rows_per_clip,
+                                                         const void* __restrict__ gt, int gt_f64, const double* __restrict__ ious,
+                                                         int K, int* __restrict__ out, int n_iou) {
+  __shared__ unsigned char alive[ER_MAX_CAND];
+  const int b = blockIdx.x, q = blockIdx.y, lane = threadIdx.x;
+  int n = 0;
+  for (int l = 0; l < nlevels; ++l) n += counts[b * nlevels + l];
+  const float* __restrict__ d = det + (long)b * rows_per_clip * 2;
+  const float* __restrict__ s = scores + (long)b * rows_per_clip;
+  const double iou_thr = ious[q], overlap = ious[q] - 0.05;
+  const double g0 = gt_f64 ? ((const double*)gt)[b * 2] : (double)((const float*)gt)[b * 2];
+  const double g1 = gt_f64 ? ((const double*)gt)[b * 2 + 1] : (double)((const float*)gt)[b * 2 + 1];
+  const bool empty = n == 0;                 // model/inference.py:192-197: one detection (0, 1) with score 1
+  if (empty) n = 1;
+  for (int j = lane; j < n; j += 64) alive[j] = 1;
+  __syncthreads();
+  int first_hit = K;
+  for (int p = 0; p < K; ++p) {
+    float bs = -1.f;
+    int bj = -1;
+    for (int j = lane; j < n; j += 64)
+      if (alive[j]) {
+        const float sj = empty ? 1.f : s[j];
+        if (bj < 0 || sj > bs || (sj == bs && j > bj)) { bs = sj; bj = j; }
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(bs, o, 64);
+      const int oj = __shfl_xor(bj, o, 64);
+      if (oj >= 0 && (bj < 0 || os > bs || (os == bs && oj > bj))) { bs = os; bj = oj; }
+    }
+    if (bj < 0) break;                        // nothing left
+    const double x1 = empty ? 0.0 : (double)d[bj * 2], x2 = empty ? 1.0 : (double)d[bj * 2 + 1];
+    if (first_hit == K) {
+      const double iou = (fmin(g1, x2) - fmax(g0, x1)) / (fmax(g1, x2) - fmin(g0, x1));      // evaluate_utils.py:228-232
+      if (iou >= iou_thr) first_hit = p;
+    }
+    const double len = x2 - x1;
+    for (int j = lane; j < n; j += 64)
+      if (alive[j]) {
+        const double y1 = (double)d[j * 2], y2 = (double)d[j * 2 + 1];
+        const double inter = fmax(0.0, fmin(x2, y2) - fmax(x1, y1));
+        const double o = inter / (len + (y2 - y1) - inter);
+        if (!(o <= overlap) || j == bj) alive[j] = 0;     // (0/0 = NaN is not <= overlap: struck out, as in the reference)
+      }
+    __syncthreads();
+  }
+  if (lane == 0) out[b * n_iou + q] = first_hit;
+}
+
+extern "C" int drn_eval_recall(const float* det, const float* scores, const int32_t* counts, int B, int nlevels, int rows_per_clip,
+                               const void* gt, int gt_is_f64, const double* ious, int n_iou, int max_topk, int32_t* first_hit,
+                               void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(det && scores && counts && gt && ious && first_hit && B > 0 && nlevels >= 1 && n_iou >= 1 && max_topk >= 1,
+                "drn_eval_recall: bad args");
+  DRN_CHECK_ARG(rows_per_clip > 0 && rows_per_clip <= ER_MAX_CAND, "drn_eval_recall: %d candidate slots per clip (max %d)", rows_per_clip, ER_MAX_CAND);
+  eval_recall_kernel<<<dim3(B, n_iou), 64, 0, (hipStream_t)stream>>>(det, scores, counts, nlevels, rows_per_clip, gt, gt_is_f64, ious,
+                                                                     max_topk, first_hit, n_iou);
+  return drn_launch_status("drn_eval_recall");
+}

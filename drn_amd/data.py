@@ -100,6 +100,20 @@ class CharadesSTA(Dataset):
         return vid, props_s_e, props_fts, gt, tokens, len(smp["tokens"]), len(proposals), num_frames
 
 
+class ShardSampler(torch.utils.data.Sampler):
+    """Evaluation shard of one rank: indices rank, rank + world, ... in dataset order -- every sample exactly once over the
+    ranks (torch's DistributedSampler pads the last round with repeats, which would count some queries twice in Recall@k)."""
+
+    def __init__(self, dataset, world_size, rank):
+        self.n, self.world, self.rank = len(dataset), int(world_size), int(rank)
+
+    def __iter__(self):
+        return iter(range(self.rank, self.n, self.world))
+
+    def __len__(self):
+        return (self.n - self.rank + self.world - 1) // self.world
+
+
 def collate_data(batch, feature_dtype=None):
     """dataset.py:180-224: sort by query length (descending, stable), zero-pad proposals and tokens.
     feature_dtype (torch.bfloat16 for a bf16 model; train.py passes it): the padded feature tensor is built in the model's

@@ -49,7 +49,8 @@ class PostProcessRunner(object):
                 break
             rest = np.asarray(order)
             inter = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]))
-            o = inter / (length[i] + length[rest] - inter)
+            with np.errstate(invalid="ignore", divide="ignore"):      # two empty segments: 0/0 = NaN, "not <= overlap" -> dropped, as in the reference
+                o = inter / (length[i] + length[rest] - inter)
             order = [int(j) for j, keep in zip(rest, o <= overlap) if keep]
         return pick
 
@@ -102,6 +103,14 @@ class PostProcessRunner(object):
             for topk in iou_topk_dict["topk"]:
                 accs.append(self.compute_IoU_recall_top_n_ours(topk, iou_thresh, temporal_nms)[2])
         return iou_topk_dict["topk"], accs
+
+
+def recall_from_first_hits(first_hits, ious, topks):
+    """accs in run_evaluate's order (for iou: for topk) from the per-query first-hit positions of ops.eval_recall:
+    first_hits (n_queries, len(ious)) integer array."""
+    fh = np.asarray(first_hits).reshape(-1, len(ious))
+    total = max(fh.shape[0], 1)
+    return [float((fh[:, q] < k).sum()) / total for q in range(len(ious)) for k in topks]
 
 
 def results_entries(queries, gts, boxes):

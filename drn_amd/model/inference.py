@@ -8,6 +8,20 @@ import torch
 from .. import ops
 
 
+class DeviceDetections(object):
+    """What drn_postprocess leaves on the device for a whole batch, un-sliced: det (B, R, 2), scores (B, R), locs (B, R),
+    counts (B, levels) -- clip b's detections are det[b, :counts[b].sum()], level after level.  Returned instead of the
+    per-clip dicts when FCOSPostProcessor.device_only is set (drn_amd.trainer.Trainer.evaluate(with_results=False)): the
+    per-batch host copy of the counts -- the eval path's one synchronisation -- and ~100 tensor slices per batch go away, and
+    drn_amd.metrics.device_first_hits computes Recall@k from these buffers where they are."""
+
+    def __init__(self, det, scores, locs, counts):
+        self.det, self.scores, self.locs, self.counts = det, scores, locs, counts
+
+    def __len__(self):
+        return int(self.det.shape[0])
+
+
 class FCOSPostProcessor(torch.nn.Module):
     def __init__(self, pre_nms_thresh, pre_nms_top_n, nms_thresh, fpn_post_nms_top_n, min_size, num_classes,
                  is_first_stage, is_second_stage):
@@ -22,6 +36,7 @@ class FCOSPostProcessor(torch.nn.Module):
         self.is_first_stage = is_first_stage
         self.is_second_stage = is_second_stage
         self.strides = None          # set by FCOSModule (fpn_stride); otherwise recovered from the locations
+        self.device_only = False     # HIP path: hand back DeviceDetections (no host copy, no per-clip dicts)
 
     def forward_for_single_feature_map(self, locations, box_cls, box_regression, level, iou_scores):
         N = box_cls.shape[0]
@@ -57,6 +72,8 @@ class FCOSPostProcessor(torch.nn.Module):
         iou = None if self.is_first_stage else iou_scores.flat
         det, scores, locs, counts = ops.postprocess(levels, B, box_cls.flat, box_regression.flat, iou, self.pre_nms_thresh,
                                                     self.pre_nms_top_n, float(self.downsample_scale))
+        if self.device_only:
+            return DeviceDetections(det, scores, locs, counts)
         counts = counts.tolist()                                           # the only host sync of the eval path
         results = []
         for b in range(B):

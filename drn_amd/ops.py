@@ -658,6 +658,19 @@ def postprocess(levels, B, logits, reg, iou, thr, top_n, downsample):
     return det, scores, locs, counts
 
 
+def eval_recall(det, scores, counts, gt, ious, max_topk):
+    """first_hit (B, len(ious)) int32 on the device: 0-based position, among the temporal-NMS survivors of clip b at IoU threshold
+    ious[q], of the first one that overlaps gt[b] by >= ious[q]; max_topk when none of the first max_topk does
+    (drn_eval_recall; utils/evaluate_utils.py:131-215).  ious: a device tensor of doubles."""
+    _need_gpu(det, scores, counts, gt, ious)
+    B, R = scores.shape
+    assert gt.dtype in (torch.float32, torch.float64) and gt.is_contiguous() and ious.dtype == torch.float64
+    out = torch.empty((B, ious.numel()), dtype=torch.int32, device=det.device)
+    check(lib().drn_eval_recall(_p(det), _p(scores), _p(counts), B, counts.shape[1], R, _p(gt), int(gt.dtype == torch.float64), _p(ious),
+                                ious.numel(), int(max_topk), _p(out), _stream()), "drn_eval_recall")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # query-encoder glue (drn_amd/csrc/qenc.hip)
 # ---------------------------------------------------------------------------------------------

@@ -19,7 +19,9 @@ import os
 import torch
 
 from . import functional as DF
-from .metrics import results_entries, PostProcessRunner, results_entry
+import numpy as np
+
+from .metrics import results_entries, PostProcessRunner, results_entry, recall_from_first_hits
 
 
 def stage_plan(model, stage, lr):
@@ -322,32 +324,72 @@ class Trainer(object):
         return _Preloaded(slot, ev, int(feats.size(0)))
 
     @torch.no_grad()
-    def evaluate(self, loader, id2word=None, iou_topk=None):
-        """main.py:270-366: returns (mean loss, topks, accuracies, raw results dict)."""
+    def evaluate(self, loader, id2word=None, iou_topk=None, with_results=True, group=None):
+        """main.py:270-366: returns (mean loss, topks, accuracies, raw results dict).
+        with_results=False (what fit() uses): the raw-results records are not built -- Recall@k with temporal NMS is computed
+        on the device from the post-processor's buffers (drn_eval_recall), one small copy at the end of the pass and no host
+        synchronisation per batch; the fourth return value is then None.
+        One process per GPU: every rank evaluates ITS shard of the test set (train.py builds the loader over
+        drn_amd.data.ShardSampler) and the ranks' counts (or records) are merged with all_gather_object, so all ranks return
+        the same numbers (`group`: the process group, default world; a single process skips the exchange)."""
         self.model.eval()
-        results, total, n = {}, None, 0
-        for batch in loader:
-            # the words, lengths and ground truth of the records come from the HOST batch (no copy back); the loss is summed on
-            # the device (one sync at the end); detections / scores of all clips cross in one copy each (metrics.results_entries)
-            host_tok, host_qlen, host_gt = batch[4], batch[5], batch[3]
-            names, args = to_device(batch, self.device)
-            boxes, loss_dict = self.model(*args)
-            bs = args[2].size(0)
-            lsum = select_loss(loss_dict, self.which).detach().reshape(-1)[0].float() * bs
-            total = lsum if total is None else total + lsum
-            n += bs
-            tokens, qlen, gts = host_tok.cpu(), host_qlen.cpu(), host_gt.cpu().numpy()
-            queries = [" ".join(id2word[int(t)] if id2word else str(int(t)) for t in tokens[i, :int(qlen[i])]) for i in range(bs)]
-            for name, entry in zip(names, results_entries(queries, gts, boxes)):
-                results.setdefault(name, []).append(entry)
-        total = float(total) if total is not None else 0.0
         iou_topk = iou_topk or {"iou": [0.5], "topk": [1, 5]}                            # main.py:362
+        results, total, n, hits = {}, None, 0, []
+        selector = getattr(getattr(self.model, "fcos", None), "box_selector_test", None)
+        fast = (not with_results) and selector is not None and self.device.type == "cuda"
+        ious_dev = torch.tensor([float(x) for x in iou_topk["iou"]], dtype=torch.float64, device=self.device) if fast else None
+        if fast:
+            selector.device_only = True
+        try:
+            for batch in loader:
+                # the words, lengths and ground truth of the records come from the HOST batch (no copy back); the loss is summed on
+                # the device (one sync at the end); detections / scores of all clips cross in one copy each (metrics.results_entries)
+                host_tok, host_qlen, host_gt = batch[4], batch[5], batch[3]
+                names, args = to_device(batch, self.device)
+                boxes, loss_dict = self.model(*args)
+                bs = args[2].size(0)
+                lsum = select_loss(loss_dict, self.which).detach().reshape(-1)[0].float() * bs
+                total = lsum if total is None else total + lsum
+                n += bs
+                if fast and not isinstance(boxes, list):
+                    from . import ops
+                    hits.append(ops.eval_recall(boxes.det, boxes.scores, boxes.counts, args[4].contiguous(), ious_dev,
+                                                max(iou_topk["topk"])))
+                    continue
+                tokens, qlen, gts = host_tok.cpu(), host_qlen.cpu(), host_gt.cpu().numpy()
+                queries = [" ".join(id2word[int(t)] if id2word else str(int(t)) for t in tokens[i, :int(qlen[i])]) for i in range(bs)]
+                for name, entry in zip(names, results_entries(queries, gts, boxes)):
+                    results.setdefault(name, []).append(entry)
+        finally:
+            if fast:
+                selector.device_only = False
+        total = float(total) if total is not None else 0.0
+        import torch.distributed as td
+        multi = td.is_available() and td.is_initialized() and td.get_world_size(group) > 1
+        if hits or (fast and not results):
+            fh = torch.cat(hits).cpu().numpy() if hits else np.zeros((0, len(iou_topk["iou"])), dtype=np.int32)
+            if multi:
+                parts = [None] * td.get_world_size(group)
+                td.all_gather_object(parts, (fh, total, n), group=group)
+                fh = np.concatenate([p[0] for p in parts])
+                total, n = sum(p[1] for p in parts), sum(p[2] for p in parts)
+            return total / max(n, 1), iou_topk["topk"], recall_from_first_hits(fh, iou_topk["iou"], iou_topk["topk"]), None
+        if multi:
+            parts = [None] * td.get_world_size(group)
+            td.all_gather_object(parts, (results, total, n), group=group)
+            results = {}
+            for part, _, _ in parts:                                   # rank order: deterministic, and the metric does not depend on it
+                for vid, items in part.items():
+                    results.setdefault(vid, []).extend(items)
+            total, n = sum(p[1] for p in parts), sum(p[2] for p in parts)
         topks, accs = PostProcessRunner(results).run_evaluate(iou_topk_dict=iou_topk, temporal_nms=True)
         return total / max(n, 1), topks, accs, results
 
     def fit(self, train_loader, test_loader, n_epoch=None, eval_freq=1, snapshot_pref=None, dataset="Charades", id2word=None,
-            start_epoch=0):
-        """main.py:142-190: train, validate every eval_freq epochs, keep the best-R@1 and best-R@5 checkpoints."""
+            start_epoch=0, rank=0):
+        """main.py:142-190: train, validate every eval_freq epochs, keep the best-R@1 and best-R@5 checkpoints.
+        One process per GPU: EVERY rank calls fit() -- training steps and the sharded evaluation are collective -- and rank 0
+        alone writes checkpoints (`rank`)."""
         n_epoch = self.default_epochs if self.default_epochs is not None else n_epoch
         best1 = best5 = 0.0
         history = []
@@ -355,12 +397,12 @@ class Trainer(object):
             train_loss = self.train_epoch(train_loader, epoch)
             rec = {"epoch": epoch, "train_loss": train_loss}
             if (epoch + 1) % eval_freq == 0 or epoch == n_epoch - 1:
-                val_loss, topks, accs, _ = self.evaluate(test_loader, id2word)
+                val_loss, topks, accs, _ = self.evaluate(test_loader, id2word, with_results=False)
                 top1, top5 = accs[0] * 100, accs[1] * 100
                 rec.update(val_loss=val_loss, top1=top1, top5=top5)
                 state = {"epoch": epoch + 1, "state_dict": checkpoint_state_dict(self.model), "loss": val_loss, "top1": top1,
                          "top5": top5}
-                if snapshot_pref is not None:
+                if snapshot_pref is not None and rank == 0:
                     if top1 > best1:
                         save_checkpoint(state, snapshot_pref, dataset, epoch, top1, top5)
                     if top5 > best5:

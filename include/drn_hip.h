@@ -350,6 +350,14 @@ int drn_focal_bwd(const float* logits, const int32_t* targets, const float* d_lo
  * det [B][sum L][2], scores / locs [B][sum L], counts [B][nlevels] = kept candidates per level, written level after level. */
 int drn_postprocess(const DrnLossLevel* levels /*host*/, int nlevels, int B, const float* logits, const float* reg, const float* iou,
                     float thr, int top_n, float downsample, float* det, float* scores, float* locs, int32_t* counts, void* stream);
+/* Recall@k with temporal NMS on the device, straight from drn_postprocess's outputs (utils/evaluate_utils.py:131-215: stable
+ * sort by score, greedy NMS at IoU threshold iou - 0.05 visiting score ties from the later prediction, hit = one of the first
+ * k survivors overlaps gt by >= iou, un-clamped IoU; double arithmetic on the float32 detections, as the host path).
+ * first_hit[b][q] = 0-based position among the NMS survivors of the first one that hits at ious[q], or max_topk when none of the
+ * first max_topk does: recall@k counts first_hit < k.  gt: (B, 2) fp64 or fp32; ious: device array of n_iou doubles. */
+int drn_eval_recall(const float* det, const float* scores, const int32_t* counts, int B, int nlevels, int rows_per_clip,
+                    const void* gt, int gt_is_f64, const double* ious /*device*/, int n_iou, int max_topk, int32_t* first_hit,
+                    void* stream);
 
 /* ---- query-encoder glue (drn_amd/csrc/qenc.hip; model/language_module.py:17-63), all fp32 ----------------------
  * Word embedding lookup written time-major (L, B, E) and its dense gradient (row padding_idx stays zero). */

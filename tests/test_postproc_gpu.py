@@ -135,3 +135,85 @@ def test_results_entries_batched_copy_equals_per_clip_records():
     queries = ["q%d" % i for i in range(4)]
     gts = torch.rand(4, 2, generator=g).numpy()
     assert results_entries(queries, gts, boxes) == [results_entry(q, t, b) for q, t, b in zip(queries, gts, boxes)]
+
+
+def _host_first_hits(det, scores, counts, gts, ious, K):
+    """The reference evaluator (drn_amd.metrics.PostProcessRunner, pinned to utils/evaluate_utils.py by tests/test_metrics_cpu.py)
+    applied clip by clip: position of the first NMS survivor among the first K that hits, else K."""
+    import numpy as np
+    from drn_amd.metrics import PostProcessRunner as R
+    out = np.full((det.shape[0], len(ious)), K, dtype=np.int64)
+    for b in range(det.shape[0]):
+        n = int(counts[b].sum())
+        preds = [[0.0, 1.0, 1.0]] if n == 0 else np.concatenate([det[b, :n], scores[b, :n, None]], axis=1).tolist()
+        preds = sorted(preds, key=lambda x: x[-1], reverse=True)
+        for q, iou in enumerate(ious):
+            picks = R.nms_temporal([p[0] for p in preds], [p[1] for p in preds], [p[-1] for p in preds], iou - 0.05)
+            for pos, i in enumerate(picks[:K]):
+                if R.calculate_IoU((gts[b][0], gts[b][1]), (preds[i][0], preds[i][1])) >= iou:
+                    out[b, q] = pos
+                    break
+    return out
+
+
+@pytest.mark.parametrize("gt_dtype", [torch.float64, torch.float32])
+def test_device_recall_matches_the_host_evaluator(gt_dtype):
+    """drn_eval_recall (temporal NMS + first hit among the survivors, on the device) against the host evaluator on random
+    detections: score ties (visited from the later prediction), zero-length segments (0/0 in the NMS overlap), duplicates,
+    clips without any detection (the (0, 1) default), ground truths that nothing reaches."""
+    import numpy as np
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, R, nl, K = 64, 96, 3, 5
+    ious = [0.3, 0.5, 0.7]
+    a = torch.rand(B, R, generator=g)
+    w = torch.rand(B, R, generator=g) * 0.5
+    det = torch.stack([a.clamp(0, 1), (a + w).clamp(0, 1)], dim=2).float()
+    scores = (torch.randint(0, 12, (B, R), generator=g).float() / 12.0 + 0.05).sqrt()        # many exact ties
+    det[:, 5] = det[:, 4]                                    # duplicates
+    det[:, 7, 1] = det[:, 7, 0]                              # empty segments
+    det[:, 8] = det[:, 7]                                    # two equal empty segments: 0/0
+    counts = torch.randint(0, 33, (B, nl), generator=g).int()
+    counts[0] = 0                                            # no detection at all
+    counts[1] = torch.tensor([1, 0, 0])
+    gts = torch.sort(torch.rand(B, 2, generator=g, dtype=torch.float64), dim=1)[0]
+    gts[2] = torch.tensor([0.0, 1.0])
+    gts = gts.to(gt_dtype)
+    dev = "cuda:0"
+    fh = ops.eval_recall(det.to(dev), scores.to(dev), counts.to(dev), gts.to(dev), torch.tensor(ious, dtype=torch.float64, device=dev), K)
+    want = _host_first_hits(det.numpy(), scores.numpy(), counts.numpy(), gts.double().numpy(), ious, K)
+    got = fh.cpu().numpy()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:10]
+    assert (want < K).any() and (want == K).any() and (want > 0).any()
+
+
+def test_fast_evaluate_equals_the_record_building_path():
+    """Trainer.evaluate(with_results=False) -- device post-processor buffers -> drn_eval_recall, no per-batch host sync -- returns
+    the loss and Recall@k of the default path that builds the reference's raw-results records and runs the host evaluator
+    (main.py:270-366), on a model whose classifier passes ~every location so that top-n truncation and NMS have work to do."""
+    from drn_amd import trainer as T
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    for stage in (1, 3):
+        cfg = default_cfg("TINY", 64, stage)
+        m = mainModel(VOCAB_SIZE, as_namespace(cfg))
+        m.load_state_dict(seeded_state_dict(m, 0))
+        with torch.no_grad():
+            m.fcos.head.cls_logits.bias.fill_(0.5)
+            m.fcos.head.cls_logits.weight.mul_(30.0)
+        m = m.to("cuda:0")
+        tr = T.Trainer(m, stage, lr=1e-3)
+        batches = []
+        for i in range(5):
+            tok, qlen, feats, pse, gt, nprops, nframes = synthetic_batch(8, 64, 64, seed=40 + i)
+            gt = pse[:, 5 + i, :].clone()                     # a proposal as ground truth: some queries are answerable
+            batches.append((["v%d" % (i % 3)] * 8, pse, feats, gt, tok, qlen, nprops, nframes))
+        iou_topk = {"iou": [0.3, 0.5, 0.7], "topk": [1, 5]}
+        l0, k0, a0, res = tr.evaluate(batches, iou_topk=iou_topk)
+        l1, k1, a1, none = tr.evaluate(batches, iou_topk=iou_topk, with_results=False)
+        assert none is None and res and k0 == k1
+        assert a0 == a1, (a0, a1)
+        assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+        assert sum(len(v) for v in res.values()) == 40
+        n_preds = [len(e["node_predictions"]) for v in res.values() for e in v]
+        assert max(n_preds) > 32, "the classifier should pass enough locations for top-n / NMS to matter"

@@ -19,7 +19,7 @@ from torch.utils.data import DataLoader
 
 from drn_amd import dist as ddist
 from drn_amd import trainer as T
-from drn_amd.data import CharadesSTA, collate_data
+from drn_amd.data import CharadesSTA, ShardSampler, collate_data
 from drn_amd.model import mainModel
 
 
@@ -60,7 +60,10 @@ def main():
     collate = functools.partial(collate_data, feature_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     train_loader = DataLoader(train_set, batch_size=bs, shuffle=sampler is None, sampler=sampler, collate_fn=collate,
                               num_workers=args.workers, pin_memory=True, drop_last=world > 1)
+    # evaluation is sharded too: every rank scores its share of the test queries (Recall@k with temporal NMS on the device)
+    # and the ranks merge their counts (drn_amd.trainer.Trainer.evaluate) -- replaces main.py:275-366 on one process
     test_loader = DataLoader(test_set, batch_size=cfg.get("test_batch_size", 16), shuffle=False, collate_fn=collate,
+                             sampler=ShardSampler(test_set, world, rank) if world > 1 else None,
                              num_workers=args.workers, pin_memory=True)
 
     model = mainModel(len(word2id), argparse.Namespace(**cfg),
@@ -75,18 +78,15 @@ def main():
     tr = T.Trainer(model, args.stage, lr=args.lr or cfg.get("lr", 1e-3), clip_gradient=cfg.get("clip_gradient", 0.5), world_size=world,
                    graph=args.graph)
     if args.evaluate:
+        _, topks, accs, _ = tr.evaluate(test_loader, id2word, with_results=False)      # collective: all ranks, merged numbers
         if rank == 0:
-            _, topks, accs, _ = tr.evaluate(test_loader, id2word)
             for k, a in zip(topks, accs):
                 print("R@{}: {:.1f}".format(k, a * 100))
         return
     n_epoch = args.n_epoch or cfg.get("n_epoch", 50)
     first = 0 if args.stage > 1 else start_epoch                     # the same epoch range on every rank
-    if rank == 0:
-        hist = tr.fit(train_loader, test_loader, n_epoch=n_epoch, eval_freq=cfg.get("eval_freq", 1),
-                      snapshot_pref=args.snapshot_pref, dataset=args.dataset, id2word=id2word, start_epoch=first)
-    else:
-        hist = tr.fit_train_only(train_loader, n_epoch, start_epoch=first)
+    hist = tr.fit(train_loader, test_loader, n_epoch=n_epoch, eval_freq=cfg.get("eval_freq", 1),
+                  snapshot_pref=args.snapshot_pref, dataset=args.dataset, id2word=id2word, start_epoch=first, rank=rank)
     if rank == 0:
         print(json.dumps(hist[-1] if hist else {}))
 
