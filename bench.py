@@ -56,6 +56,50 @@ def time_graph(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
+def other_config_lines(dev, reps=10):
+    """Every other BASELINE.json config at the size ONE GPU runs it, each as its own hipGraph of the whole step (forward + backward
+    + clip + Adam), `reps` replays timed with HIP events: configs[2] and [4] at their 8-way data-parallel per-GPU batch (256 / 8,
+    128 / 8), configs[3] whole; configs[4] in bf16 and in f32 (its tolerance sweep).  path_frac as in `roofline.path`."""
+    from drn_amd import dist as ddist
+    from drn_amd import functional as DF
+    from drn_amd.model import mainModel
+    from drn_amd.optim import FusedAdam
+    lines = {}
+    todo = [("configs[2] per-GPU: T=256 D=4096 B=32 stage 3 (batch 256 over 8 GPUs)", 32, 256, 4096, 3, "bf16"),
+            ("configs[3]: T=512 D=1024 B=64 stage 1 (I3D-shaped bandwidth probe)", 64, 512, 1024, 1, "bf16"),
+            ("configs[4] per-GPU: T=1024 D=500 B=16 stage 1 (batch 128 over 8 GPUs)", 16, 1024, 500, 1, "bf16"),
+            ("configs[4] per-GPU, f32: T=1024 D=500 B=16 stage 1", 16, 1024, 500, 1, "f32")]
+    for name, B, T, D, stage, dt in todo:
+        try:
+            cdt = torch.bfloat16 if dt == "bf16" else torch.float32
+            cfg = default_cfg("C3D" if D == 4096 else "SYN", D, stage)
+            m = build(mainModel, cfg, dev, compute_dtype=cdt)
+            params = stage_params(m, stage)
+            m.train()
+            red = ddist.GradReducer(params, world_size=1, overlap=True, adjacent=m.grad_stack_groups(), bucket_bytes=1 << 30)
+            opt = FusedAdam(red, lr=1e-3, max_norm=0.5)
+            batch = [b.to(dev) for b in synthetic_batch(B, T, D, seed=7)]
+
+            def step():
+                red.zero()
+                _, ls = m(*batch)
+                DF.backward(DF.loss_total(ls))
+                red.finish()
+                opt.step()
+                return ls
+            t = time_graph(step, reps=reps)
+            fl = path_flops(T, D, stage)
+            lines[name] = {"B": B, "T": T, "D": D, "stage": stage, "dtype": dt, "ms_per_step": round(t, 3),
+                           "clips_per_s": round(B / (t * 1e-3), 1),
+                           "path_frac": round(fl["step"] * B / (t * 1e-3) / 1e12 / PEAK_TFLOPS[dt], 4)}
+            red.remove()
+            del m, opt, red, batch
+            torch.cuda.empty_cache()
+        except Exception as e:
+            lines[name] = {"error": "%s: %s" % (type(e).__name__, str(e).split(chr(10))[0])}
+    return lines
+
+
 def build(model_cls, cfg, device, **kw):
     m = model_cls(VOCAB_SIZE, as_namespace(cfg), **kw)
     m.load_state_dict(seeded_state_dict(m, 0))
@@ -221,6 +265,8 @@ def main():
                     help="write the MFMA launches of one step in launch order [(tag, flops)] as JSON (scripts/gemm_table.py joins them "
                          "with a rocprofv3 kernel trace of the replayed graph)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="drn_tune(KEY, VALUE) before anything runs (experiments)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip `other_configs` (BASELINE configs[2..4] at their single-GPU size, ~10 graph-replayed steps each)")
     ap.add_argument("--no-trainer", dest="trainer_line", action="store_false",
                     help="skip the `trainer` object (clips/s through drn_amd.trainer.Trainer.train_epoch at T=256 and T=32, graph and eager)")
     args = ap.parse_args()
@@ -517,6 +563,11 @@ def main():
         out["per_rank"] = per_rank
     if f32_line is not None:
         out["f32"] = f32_line
+    if rank == 0 and world == 1 and args.other_configs and args.graph and not args.torch_adam:
+        try:
+            out["other_configs"] = other_config_lines(dev)
+        except Exception as e:
+            print("other_configs timing failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
     if rank == 0 and world == 1 and args.trainer_line and args.graph and not args.torch_adam:
         try:
             del run
