@@ -1032,7 +1032,7 @@ class InputPrep(object):
     """Everything the input stage needs that does not depend on the query: the feature tensor in the compute dtype (and, for
     the bf16 weight-gradient product, its transpose), the proposal position features, the GEMM copy of the prop_fc weight
     (warmed into the caches).  Non-differentiable."""
-    __slots__ = ("xc", "xcT", "pf", "wfc", "dtype", "dims")
+    __slots__ = ("xc", "xcT", "pf", "wfc", "dtype", "dims", "fc")
 
 
 def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True):

@@ -1,4 +1,6 @@
 """Query-gated temporal conv backbone (reference: model/backbone.py:4-36)."""
+import types
+
 import torch
 import torch.nn as nn
 
@@ -29,6 +31,13 @@ class Backbone(nn.Module):
         for idx in range(self.num_layers):
             nxt = gates[idx + 1] if idx + 1 < self.num_layers else None
             conv, bn = conv_bn(getattr(self, self.blocks[idx]), "Backbone." + self.blocks[idx])
+            if idx == 0 and x.shape[2] > conv.weight.shape[1]:
+                # g0 carries zero-padded feature channels (mainModel, bf16 with a feature dim that is not a 16-byte multiple):
+                # conv0's weight gets zero input channels at the same places -- [features | zeros | position embedding]
+                W, extra = conv.weight, x.shape[2] - conv.weight.shape[1]
+                P = tail.P if tail is not None else 256
+                Wp = torch.cat([W[:, :W.shape[1] - P], W.new_zeros((W.shape[0], extra, W.shape[2])), W[:, W.shape[1] - P:]], dim=1)
+                conv = types.SimpleNamespace(weight=Wp, bias=conv.bias, stride=conv.stride)
             out, gated = DF.conv_block([x], conv, bn, self.training, x.dtype if idx == 0 else dt, gate=nxt,
                                        tail=tail if idx == 0 else None)
             outs.append(DF.cast_act(out[0], dt))

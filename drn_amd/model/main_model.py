@@ -1,6 +1,9 @@
 """DRN top-level model (reference: model/main_model.py:13-81): same constructor/forward signature, attribute
 names and state_dict keys, so main.py-style trainers and reference checkpoints work unchanged."""
+import types
+
 import torch
+import torch.nn.functional as F
 import torch.nn as nn
 
 from .. import functional as DF
@@ -103,11 +106,26 @@ class mainModel(nn.Module):
         if not props_features.is_cuda:
             raise DrnError("drn_amd.mainModel runs on an MI355X only (inputs on %s); no CPU fallback" % props_features.device)
         dt = self.compute_dtype
-        # bf16 rows must be 16-byte multiples for the MFMA kernels' LDS staging; a feature dim that is not (D = 500, the
-        # ActivityNet C3D-PCA convention) keeps the two layers that see D -- prop_fc and conv0 -- on the exact-f32 kernels
-        front_dt = torch.float32 if (dt == torch.bfloat16 and props_features.shape[2] % 8) else dt
         want_wgrad = self.prop_fc.weight.requires_grad and torch.is_grad_enabled()
-        return DF.input_prep(props_features, props_start_end, self.prop_fc, front_dt, want_wgrad)
+        pad = self._front_pad(props_features.shape[2])
+        if pad:
+            # bf16 rows must be 16-byte multiples for the MFMA kernels' LDS staging.  A feature dim that is not (D = 500, the
+            # ActivityNet C3D-PCA convention, BASELINE configs[4]) runs the front -- prop_fc, gating, conv0 -- on a ZERO-PADDED
+            # width Dp = 512: features, prop_fc's weight / bias, the level-0 gate and conv0's input channels get zero columns, so
+            # every padded activation is exactly 0 and the real ones are what they were; torch's pad / cat nodes hand the real
+            # slices of the gradients back to the parameters.  (Round 3 kept these two layers on the exact-f32 kernels inside the
+            # bf16 model instead: 1/16 of the MFMA rate for the two largest GEMMs of the step.)
+            props_features = F.pad(props_features, (0, pad))
+            fc = types.SimpleNamespace(weight=F.pad(self.prop_fc.weight, (0, pad, 0, pad)), bias=F.pad(self.prop_fc.bias, (0, pad)))
+        else:
+            fc = self.prop_fc
+        prep = DF.input_prep(props_features, props_start_end, fc, dt, want_wgrad)
+        prep.fc = fc
+        return prep
+
+    def _front_pad(self, D):
+        """Zero columns appended to the feature dim inside a bf16 model (0 when its rows already are 16-byte multiples)."""
+        return (-D) % 64 if (self.compute_dtype == torch.bfloat16 and D % 8) else 0
 
     def forward_front(self, query_tokens, query_length, props_features, props_start_end, gates=None, prep=None):
         """-> (g0 (B, T, D+P) channels-last, gates): query encoder, gate projections, prop_fc + gating + position embedding.
@@ -117,7 +135,9 @@ class mainModel(nn.Module):
             prep = self.prepare_input(props_features, props_start_end)
         if gates is None:
             gates = self.encode_query(query_tokens, query_length)
-        g0, tail = DF.input_stage(prep, self.prop_fc, gates[0], self.position_transform, with_tail=True)
+        pad = self._front_pad(self.feature_dim)
+        gate0 = F.pad(gates[0], (0, pad)) if pad else gates[0]
+        g0, tail = DF.input_stage(prep, prep.fc, gate0, self.position_transform, with_tail=True)
         g0._drn_tail = tail          # rides on the tensor object to forward_trunk (a caller that replaces g0 simply loses it)
         return g0, gates
 

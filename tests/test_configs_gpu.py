@@ -71,7 +71,7 @@ def test_fp32_parity_at_config_shapes(name, B, T, D, stage):
 def test_bf16_tolerance_sweep(name, B, T, D, stage):
     """bf16 storage / fp32 accumulation vs the exact-f32 path (configs[4]'s sweep): losses within 3e-2 relative,
     head outputs within 6e-2 of their scale (13 stacked conv+BN layers in bf16).  D = 500 is not a 16-byte multiple in
-    bf16: prop_fc and conv0 stay on the exact-f32 kernels there, the rest of the model runs in bf16."""
+    bf16: the front runs on a zero-padded width of 512 there (mainModel.prepare_input), on the bf16 MFMA like everything else."""
     from drn_amd.model import mainModel
     cfg = default_cfg("C3D" if D == 4096 else "SYN", D, stage)
     batch = synthetic_batch(B, T, D, seed=3)
@@ -87,8 +87,34 @@ def test_bf16_tolerance_sweep(name, B, T, D, stage):
             assert float((x - y).abs().max()) <= 6e-2 * max(1.0, float(y.abs().max())), (j, l)
 
 
+def test_bf16_unaligned_feature_dim_stays_on_the_bf16_mfma():
+    """D=500 in a bf16 model (BASELINE configs[4]): no exact-f32 GEMM launch in forward + backward -- prop_fc and conv0 run on a
+    zero-padded feature width (round 3 dropped them to the f32 kernels, 1/16 of the MFMA rate) -- the padded columns of the
+    front's output are exactly zero, and gradients have the parameters' own shapes."""
+    from drn_amd import ops
+    from drn_amd.model import mainModel
+    cfg = default_cfg("SYN", 500, 1)
+    batch = [x.to(DEV) for x in synthetic_batch(4, 64, 500, seed=1)]
+    m = build(mainModel, cfg, DEV, compute_dtype=torch.bfloat16)
+    m.train()
+    ops.kernel_timer = []
+    try:
+        g0, gates = m.forward_front(*batch[:4])
+        assert g0.dtype == torch.bfloat16 and g0.shape[2] == 512 + 256
+        assert float(g0[:, :, 500:512].abs().max()) == 0.0
+        _, losses = m.forward_trunk(g0, gates, batch[4])
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        tags = [t[0] for t in ops.kernel_timer]
+    finally:
+        ops.kernel_timer = None
+    assert tags and not [t for t in tags if "[f32]" in t], [t for t in tags if "[f32]" in t]
+    assert m.prop_fc.weight.grad.shape == (500, 500) and m.backbone_net.forward_conv0[0].weight.grad.shape == (256, 756, 3)
+    assert torch.isfinite(m.prop_fc.weight.grad).all() and float(m.prop_fc.weight.grad.abs().max()) > 0
+
+
 def test_bf16_unaligned_feature_dim_trains():
-    """D=500 in a bf16 model: forward + backward run (f32 front, bf16 trunk) and every trainable parameter gets a finite
+    """D=500 in a bf16 model: forward + backward run (zero-padded bf16 front) and every trainable parameter gets a finite
     gradient close to the all-f32 model's."""
     from drn_amd.model import mainModel
     cfg = default_cfg("SYN", 500, 1)
@@ -107,11 +133,61 @@ def test_bf16_unaligned_feature_dim_trains():
         assert torch.isfinite(g16).all(), k
         num += float((g16 - g32).double().pow(2).sum())
         den += float(g32.double().pow(2).sum())
-    # two clips, 13 bf16 layers: individual small gradients are noisy; the whole gradient vector must agree
-    assert (num / den) ** 0.5 <= 0.15, (num / den) ** 0.5
-    for k in ("prop_fc.weight", "backbone_net.forward_conv0.0.weight"):          # the layers that ran in f32
+    # two clips, 13 bf16 layers (since round 4 the front too): individual small gradients are noisy and a single ReLU flip weighs
+    # 1/sqrt(rows); the whole gradient vector must agree.  (What pins the padded front exactly is the next test.)
+    assert (num / den) ** 0.5 <= 0.3, (num / den) ** 0.5
+    for k in ("prop_fc.weight", "backbone_net.forward_conv0.0.weight"):          # the layers that see the padded width
         g32, g16 = grads[torch.float32][k], grads[torch.bfloat16][k]
-        assert float((g16 - g32).norm()) <= 0.2 * float(g32.norm()), k
+        assert float((g16 - g32).norm()) <= 0.4 * float(g32.norm()), k
+
+
+def test_bf16_padded_front_equals_the_explicitly_padded_model():
+    """The D=500 bf16 model (front on a zero-padded width of 512) against a D=512 model whose extra feature channels are zero by
+    construction -- zero feature columns, zero rows / columns in prop_fc, zero gate rows, zero conv0 input channels: the same
+    kernels on the same shapes, so losses, head outputs and the real slices of every gradient are bit-identical."""
+    from drn_amd.model import mainModel
+    B, T = 4, 64
+    m5 = build(mainModel, default_cfg("SYN", 500, 3), DEV, compute_dtype=torch.bfloat16)
+    m6 = build(mainModel, default_cfg("SYN", 512, 3), DEV, compute_dtype=torch.bfloat16)
+    sd5, sd6 = m5.state_dict(), m6.state_dict()
+    with torch.no_grad():
+        for k, v in sd5.items():
+            w = sd6[k]
+            if v.shape == w.shape:
+                w.copy_(v)
+                continue
+            w.zero_()
+            if k == "backbone_net.forward_conv0.0.weight":            # (256, D + 256, 3): [features | position embedding]
+                w[:, :500].copy_(v[:, :500])
+                w[:, 512:].copy_(v[:, 500:])
+            else:                                                      # prop_fc.weight / .bias, qInput0.weight / .bias
+                w[tuple(slice(0, n) for n in v.shape)].copy_(v)
+    batch = [x.to(DEV) for x in synthetic_batch(B, T, 500, seed=2)]
+    batch6 = list(batch)
+    batch6[2] = torch.nn.functional.pad(batch[2], (0, 12))
+    outs = []
+    for m, b in ((m5, batch), (m6, batch6)):
+        m.train()
+        m.taps = {}
+        _, losses = m(*b)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        outs.append((losses, m.taps["head"], {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    (l5, h5, g5), (l6, h6, g6) = outs
+    for k in l5:
+        assert torch.equal(l5[k], l6[k]), k
+    for j in (0, 1, 3):
+        for a, b in zip(h5[j], h6[j]):
+            assert torch.equal(a, b)
+    assert set(g5) == set(g6)
+    for k, g in g5.items():
+        w = g6[k]
+        if g.shape == w.shape:
+            assert torch.equal(g, w), (k, float((g - w).abs().max()))
+        elif k == "backbone_net.forward_conv0.0.weight":
+            assert torch.equal(g[:, :500], w[:, :500]) and torch.equal(g[:, 500:], w[:, 512:]), k
+        else:
+            assert torch.equal(g, w[tuple(slice(0, n) for n in g.shape)]), k
 
 
 def test_clip_permutation_invariance_full_size():
