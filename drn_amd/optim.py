@@ -25,13 +25,14 @@ class FusedAdam(object):
         for b in reducer.buckets:
             n = b.flat.numel()
             offs, ptrs = [], []
-            for p, off in zip(b.params, b.offsets):
+            ends = list(b.offsets[1:]) + [n]
+            for p, off, nxt in zip(b.params, b.offsets, ends):
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdam needs contiguous fp32 parameters")
                 offs.append(off)
                 ptrs.append(p.data_ptr())
                 pad_start = off + p.numel()
-                if pad_start % 4:                             # alignment padding: a segment with a null pointer
+                if pad_start != nxt:                          # alignment padding (16 B / cache line): a segment with a null pointer
                     offs.append(pad_start)
                     ptrs.append(0)
             offs.append(n)
