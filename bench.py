@@ -260,6 +260,9 @@ def main():
                     help="N=1: replay the step as seven linear hipGraphs on two streams (drn_amd.graph.DualStreamStep: query side beside "
                          "input prep / deferred weight gradients) instead of ONE linear hipGraph; measured 0.5 %% SLOWER on ROCm 7.2 "
                          "(DESIGN.md section 5), kept as an experiment")
+    ap.add_argument("--no-forked", dest="forked", action="store_false",
+                    help="N=1: never use the two-branch hipGraph (by default it replaces the linear one when a short A/B at warm-up "
+                         "time says it is faster)")
     ap.add_argument("--torch-adam", action="store_true", help="torch clip_grad_norm_ + optim.Adam instead of the fused HIP step")
     ap.add_argument("--dump-gemms", default=None, metavar="PATH",
                     help="write the MFMA launches of one step in launch order [(tag, flops)] as JSON (scripts/gemm_table.py joins them "
@@ -356,7 +359,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run, mode, degraded = step, "eager", False
+    run, mode, degraded, launch_ab = step, "eager", False, None
     if args.graph:
         # all warm-up steps run on the capture stream (see drn_amd/graph.py), then the step is captured once
         from drn_amd.graph import GraphedStep
@@ -368,9 +371,44 @@ def main():
                 run = DualStreamStep(model, batch[:5], loss_of, reducer, opt).warm(max(args.warmup, 2)).capture()
                 mode = "hipGraph replay of the full step: 7 linear graphs on 2 streams (query side beside input prep / deferred weight gradients)"
             elif world == 1:
-                # the whole step (query encoder, HIP path forward+backward, fused clip+Adam) replays as ONE hipGraph
+                # the whole step (query encoder, HIP path forward+backward, fused clip+Adam) replays as ONE hipGraph: the linear
+                # one, or -- when it measures faster in a short A/B of the two captures here, during warm-up -- the same launches
+                # with two branches (drn_amd.graph.ForkedStep: query side beside input preparation / weight gradients; same bits)
                 run = GraphedStep(step, warmup=max(args.warmup, 2)).capture()
                 mode = "hipGraph replay of the full step"
+                if args.forked and not args.torch_adam:
+                    try:
+                        # (its own model / reducer / optimizer: autograd's AccumulateGrad nodes remember the stream they were created
+                        # on, so two captures of one model on different streams race -- drn_amd/graph.py)
+                        from drn_amd.graph import ForkedStep
+                        from drn_amd.optim import FusedAdam as _FA
+                        model_f = build(mainModel, cfg, dev, compute_dtype=cdt)
+                        params_f = stage_params(model_f, stage)
+                        model_f.train()
+                        reducer_f = ddist.GradReducer(params_f, world_size=1, overlap=True, adjacent=model_f.grad_stack_groups(),
+                                                      bucket_bytes=1 << 30)
+                        forked = ForkedStep(model_f, batch[:5], loss_of, reducer_f, _FA(reducer_f, lr=1e-3, max_norm=0.5)).warm(
+                            max(args.warmup, 2)).capture()
+
+                        def probe(fn, n=12):
+                            fn(); fn()
+                            torch.cuda.synchronize()
+                            tp = time.perf_counter()
+                            for _ in range(n):
+                                fn()
+                            torch.cuda.synchronize()
+                            return (time.perf_counter() - tp) / n * 1e3
+                        ab = [(probe(run), probe(forked)) for _ in range(2)]
+                        t_lin, t_fork = min(a for a, _ in ab), min(b for _, b in ab)
+                        launch_ab = {"linear_ms": round(t_lin, 3), "forked_ms": round(t_fork, 3)}
+                        if t_fork < 0.995 * t_lin:
+                            run = forked
+                            mode = "hipGraph replay of the full step, two branches (query side beside input prep / weight gradients)"
+                        else:
+                            reducer_f.remove()
+                            del forked, model_f, reducer_f
+                    except Exception as e:
+                        print("forked graph not used (%s: %s)" % (type(e).__name__, str(e).split(chr(10))[0]), file=sys.stderr)
             else:
                 # forward+backward replay as three hipGraphs per rank; RCCL all-reduces + fused optimizer stay outside them
                 from drn_amd.graph import TwoPhaseStep
@@ -550,7 +588,7 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "Charades-STA-shaped C3D features, T=%d, D=%d, batch %d/GPU, stage-%d losses; "
                                   "step = fwd+bwd+grad all-reduce+clip(0.5)+Adam" % (T, D, B, stage),
-                      "global_batch": B * world, "T": T, "D": D, "parallelism": "dp%d" % world, "launch": mode,
+                      "global_batch": B * world, "T": T, "D": D, "parallelism": "dp%d" % world, "launch": mode, "launch_ab": launch_ab,
                       "loss_cls": float(losses["loss_cls"].detach().reshape(-1)[0])},
            "roofline": roof}
     out["rccl_ranks"] = torch.distributed.get_world_size() if world > 1 else 1

@@ -660,6 +660,51 @@ extern "C" int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int l
   return drn_launch_status("drn_pairsum_add_to");
 }
 
+// ---------------------------------------------------------------- query gate, forward, as its own pass
+// out[s,t,c] = z[s,t,c] * gate[s,c]  (model/backbone.py:28-30 for level 0: `q * x` on prop_fc's output).  The GEMM epilogue
+// applies the gate itself when the gate exists before the GEMM starts; this pass is for the schedule that runs the query encoder
+// BESIDE the prop_fc GEMM (drn_amd.graph.ForkedStep): the GEMM writes z, the gate arrives later.  16-byte vectors, 4 rows per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ z, int ld_z, const float* __restrict__ gate, int ldg,
+                                                       T* __restrict__ out, int ld_out, int M, int L, int C) {
+  constexpr int N = V16<T>::N, U = 4;
+  const int nvec = C / N;
+  const long total = (long)((M + U - 1) / U) * nvec;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const int m0 = (int)(i / nvec) * U;
+    const int c0 = v * N;
+    typename V16<T>::raw_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = V16<T>::ldraw(z + (long)min(m0 + u, M - 1) * ld_z + c0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + u;
+      if (m >= M) break;
+      const float* gp = gate + (long)(m / L) * ldg + c0;
+      float x[N];
+      V16<T>::cvt(r[u], x);
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[k] *= gp[k];
+      V16<T>::store(out + (long)m * ld_out + c0, x);
+    }
+  }
+}
+extern "C" int drn_gate_fwd(const void* z, int ld_z, const float* gate, int ldg, void* out, int ld_out, int nseq, int L, int C,
+                            int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(z && gate && out && nseq > 0 && L > 0 && C > 0, "drn_gate_fwd: bad args");
+  DISPATCH_DT(dtype, "drn_gate_fwd", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(C % N == 0 && ld_z % N == 0 && ld_out % N == 0 && ldg % 4 == 0 && ((((uintptr_t)z) | ((uintptr_t)out) | ((uintptr_t)gate)) & 15) == 0,
+                  "drn_gate_fwd: C / ld must be 16-byte multiples");
+    const int M = nseq * L;
+    gate_fwd_kernel<T><<<ew_blocks((long)cdiv(M, 4) * (C / N), 256, 8192), 256, 0, (hipStream_t)stream>>>((const T*)z, ld_z, gate, ldg, (T*)out,
+                                                                                                        ld_out, M, L, C);
+  });
+  return drn_launch_status("drn_gate_fwd");
+}
+
 // ---------------------------------------------------------------- query-gate backward
 // forward was G[s,t,c] = act[s,t,c] * gate[s,c].  Here:
 //   dC[s,t,c] = (add ? add[s,t,c] : 0) + dG[s,t,c] * gate[s,c]        dgate[s,c] = sum_t dG[s,t,c] * act[s,t,c]

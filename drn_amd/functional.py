@@ -1032,11 +1032,14 @@ class InputPrep(object):
     """Everything the input stage needs that does not depend on the query: the feature tensor in the compute dtype (and, for
     the bf16 weight-gradient product, its transpose), the proposal position features, the GEMM copy of the prop_fc weight
     (warmed into the caches).  Non-differentiable."""
-    __slots__ = ("xc", "xcT", "pf", "wfc", "dtype", "dims", "fc")
+    __slots__ = ("xc", "xcT", "pf", "wfc", "dtype", "dims", "fc", "Z")
 
 
-def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True):
-    """props_start_end: (B, T, 2) proposal boundaries, or the (B, T, 3) position features themselves."""
+def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True, split_gate=False):
+    """props_start_end: (B, T, 2) proposal boundaries, or the (B, T, 3) position features themselves.
+    split_gate: also run the prop_fc GEMM here, WITHOUT the query gate (-> pr.Z, the pre-gate value backward keeps anyway); the
+    input stage then applies the gate in a pass of its own (ops.gate_fwd).  For schedules that run the query encoder beside this
+    GEMM (drn_amd.graph.ForkedStep).  In bf16 the gated value is then bf16(bf16(z) * gate) instead of bf16(z * gate)."""
     code = code_of(dtype)
     B, T, D = feats.shape
     pr = InputPrep()
@@ -1070,6 +1073,10 @@ def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True):
         duration = (props_start_end[:, :, 1] - props_start_end[:, :, 0]).unsqueeze(-1)
         pf = torch.cat((props_start_end, duration), dim=-1).float()
     pr.pf = pf.reshape(B * T, 3).contiguous()
+    pr.Z = None
+    if split_gate:
+        pr.Z = torch.empty((B, T, D), dtype=dtype, device=xc.device)
+        ops.gemm_nt([ops.gemm_desc(pr.xc, pr.wfc, pr.Z, B * T, D, D, Lout=T, ldc=D, bias=prop_fc.bias.detach())], code)
     return pr
 
 
@@ -1114,9 +1121,13 @@ class _InputStageFn(torch.autograd.Function):
         xc, xcT, pf, wfc = prep.xc, prep.xcT, prep.pf, prep.wfc
         dev = xc.device
         G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
-        Z = torch.empty((B, T, D), dtype=dtype, device=dev)
-        ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),
-                                   C2=Z, ldc2=D)], code)
+        if getattr(prep, "Z", None) is not None:
+            Z = prep.Z                                    # the GEMM already ran, un-gated (input_prep(split_gate=True))
+            ops.gate_fwd(Z, D, gate0, G0, D + P, B, T, D, code)
+        else:
+            Z = torch.empty((B, T, D), dtype=dtype, device=dev)
+            ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),
+                                       C2=Z, ldc2=D)], code)
         pos_slice = G0.view(B * T, D + P)[:, D:]
         ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
         ctx.dtype, ctx.dims = dtype, (B, T, D, P)

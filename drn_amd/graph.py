@@ -286,3 +286,64 @@ class DualStreamStep(object):
             self._fresh, self._last_main = True, M.cuda_stream
         self._schedule(lambda name: self.graphs[name].replay(), M, self.side)
         return self.out
+
+
+class ForkedStep(DualStreamStep):
+    """The DualStreamStep schedule as ONE hipGraph with two branches: the query encoder beside the input preparation, the query
+    side's backward beside the weight gradients -- the prop_fc one first, so that the ~35 small latency-bound launches of that
+    side run next to an MFMA-bound kernel instead of after it.  Round 2 gave up on branches ("host 0.05 -> 1.9 ms per replay");
+    measured in round 4 on ROCm 7.2 the host side of a replay is 0.4 ms, all of it hidden behind the ~2 ms the device needs, and
+    the step 2.18-2.21 -> 2.11-2.13 ms (scripts/experiments/one_graph_two_branches.py).  WHAT runs beside what decides
+    everything: the small weight gradients first (TN kernels + their reduce passes beside the BiLSTM backward) = 4.37 ms, and
+    `split_gate=True` -- the prop_fc GEMM un-gated so that the query encoder can run beside IT -- = 4.27 ms: two BiLSTM steps
+    next to the 512-workgroup GEMM take 100-130 us each instead of 7 (rocprofv3 timeline), the query side finishes after the
+    GEMM it was meant to hide behind.  Results equal the single-stream step bit for bit (tests/test_graph_gpu.py)."""
+
+    def __init__(self, model, batch, loss_of, reducer, opt, split_gate=False):
+        model.split_gate = bool(split_gate)
+        super(ForkedStep, self).__init__(model, batch, loss_of, reducer, opt, wgrads_first=False)
+        self.graph = None
+
+    def _capture_once(self):
+        g = torch.cuda.CUDAGraph()
+        self._fresh = True
+        with torch.cuda.graph(g, stream=self.main, capture_error_mode="thread_local"):
+            self._schedule(self._phase, self.main, self.side)
+            self.main.wait_stream(self.side)
+        self._c.clear()
+        return g
+
+    def capture(self, tries=4, probe=6):
+        """Capture with up to `tries` different side streams and keep the fastest graph.  Which pair of streams the branches were
+        captured on decides whether they overlap at all: the same schedule measured 2.11 ms/step on one pair and 4.2-4.4 ms on the
+        next one torch handed out (the two then share a hardware queue, and every cross-branch dependency stalls it) -- so each
+        candidate is replayed `probe` times (real training steps) and timed.  The main stream never changes: autograd's
+        AccumulateGrad nodes are bound to it."""
+        import time
+        best = None
+        for i in range(max(int(tries), 1)):
+            if i:
+                self.side = torch.cuda.Stream(priority=-1)
+                self.warm(1)                     # (allocator pools / workspaces of the new stream)
+            g = self._capture_once()
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(probe):
+                g.replay()
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / probe
+            if best is None or t < best[0]:
+                best = (t, g, self.side)
+            else:
+                del g
+        self.probe_ms = best[0] * 1e3
+        self.graph, self.side = best[1], best[2]
+        return self
+
+    def __call__(self):
+        if self.graph is None:
+            self.warm(1)
+            return self.out
+        self.graph.replay()
+        return self.out

@@ -356,6 +356,11 @@ def pairsum_add_to(dst, ld_dst, base, ld_base, src, ld_src, Mdst, C, dtype):
     check(lib().drn_pairsum_add_to(_p(dst), ld_dst, _p(base), ld_base, _p(src), ld_src, Mdst, C, dtype, _stream()), "drn_pairsum_add_to")
 
 
+def gate_fwd(z, ld_z, gate, out, ld_out, nseq, L, C, dtype):
+    """out[s, t, :C] = z[s, t, :C] * gate[s]  (the level-0 query gate as its own pass, see drn_amd.graph.ForkedStep)."""
+    check(lib().drn_gate_fwd(_p(z), ld_z, _p(gate), gate.stride(0), _p(out), ld_out, nseq, L, C, dtype, _stream()), "drn_gate_fwd")
+
+
 def gate_bwd(dG, ld_dg, act, ld_act, gate, dC, ld_dc, add, ld_add, dgate, nseq, L, C, dtype, dsum=None):
     """dC = (add or 0) + dG * gate; dgate = sum_t dG * act; dsum (nseq, C) fp32 = sum_t dG * gate."""
     check(lib().drn_gate_bwd(_p(dG), ld_dg, _p(act), ld_act, _p(gate), gate.stride(0), _p(add), ld_add, _p(dC), ld_dc, _p(dgate),

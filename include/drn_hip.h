@@ -150,6 +150,10 @@ int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst
 /* out-of-place form: dst[s,t] = base[s,t] + src[s,2t] + src[s,2t+1] (base = the level's own incoming gradient) */
 int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int ld_base, const void* src, int ld_src, int Mdst, int C,
                        int dtype, void* stream);
+/* out[s,t,c] = z[s,t,c] * gate[s,c]: the level-0 query gate (model/backbone.py:28-30 on prop_fc's output) as its own pass, for
+ * the schedule that runs the query encoder beside the prop_fc GEMM (otherwise drn_gemm_nt's epilogue applies the gate). */
+int drn_gate_fwd(const void* z, int ld_z, const float* gate, int ldg, void* out, int ld_out, int nseq, int L, int C, int dtype,
+                 void* stream);
 /* backward of the query gating x = q[:, :, None] * x (model/backbone.py:28-30):
  * dC = (add ? add : 0) + dG * gate[seq] (skipped when dC is NULL); dgate[seq][c] = sum_t dG*act;
  * dsum (optional, [nseq][C]) = sum_t dG * gate[seq]: per-clip column sums of dC's gated term (bias-gradient partials) */

@@ -7,9 +7,9 @@ TAG=${1:-r02_a}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --no-trainer --no-other-configs --steps 30"
+CMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --no-trainer --no-other-configs --no-forked --steps 30"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/bench_under_trace.json 2> /dev/null
-PMCCMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --no-trainer --no-other-configs --steps 4 --warmup 2"
+PMCCMD="python $GRAFT_REPO_ROOT/bench.py --cpu-steps 0 --no-kernel-timing --no-f32 --no-trainer --no-other-configs --no-forked --steps 4 --warmup 2"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- $PMCCMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- $PMCCMD > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT

@@ -271,3 +271,81 @@ def test_adjacent_stack_groups_write_gradients_in_place():
     assert grads[0].keys() == grads[1].keys()
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_forked_graph_step_is_bit_identical(dtype):
+    """drn_amd.graph.ForkedStep -- the whole step as ONE hipGraph with two branches (query side beside input preparation / weight
+    gradients; bench.py's launch mode at N = 1 when it measures faster) -- against the plain single-stream eager step: losses
+    and every parameter / buffer after n steps, bit for bit, through warm-up and 30 replays."""
+    from drn_amd.dist import GradReducer
+    from drn_amd.graph import ForkedStep
+    from drn_amd.model import mainModel
+    from drn_amd.optim import FusedAdam
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    import drn_amd.functional as DF
+    dev = "cuda:0"
+
+    def build():
+        m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", 64, 3)), compute_dtype=dtype)
+        m.load_state_dict(seeded_state_dict(m, 0))
+        m = m.to(dev).train()
+        red = GradReducer([p for p in m.parameters() if p.requires_grad], world_size=1, bucket_bytes=1 << 30,
+                          adjacent=m.grad_stack_groups())
+        return m, red, FusedAdam(red, lr=1e-4, max_norm=0.5)
+
+    batch = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=1)]
+    n = 33
+    m1, r1, o1 = build()
+    ref = []
+    for _ in range(n):
+        r1.zero()
+        _, ls = m1(*batch)
+        DF.backward(DF.loss_total(ls))
+        r1.finish()
+        o1.step()
+        ref.append([float(ls[k].reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
+    r1.remove()
+    m2, r2, o2 = build()
+    fs = ForkedStep(m2, batch, DF.loss_total, r2, o2)
+    got = []
+    for _ in range(3):
+        ls = fs()
+        got.append([float(ls[k].reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
+    fs.capture()
+    for _ in range(n - 3):
+        ls = fs()
+        got.append([float(ls[k].reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
+    torch.cuda.synchronize()
+    assert ref[0] != ref[-1], "training made no progress"
+    assert got == ref, [(i, a, b) for i, (a, b) in enumerate(zip(got, ref)) if a != b][:3]
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    r2.remove()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_split_gate_input_stage(dtype):
+    """mainModel.split_gate: the prop_fc GEMM un-gated + drn_gate_fwd as its own pass (model/backbone.py:28-30 for level 0).  In
+    f32 the result is the fused epilogue's bit for bit (one multiplication either way); in bf16 the gated value is rounded from the
+    rounded pre-gate value -- within one bf16 ulp of the fused one -- and the gradients follow."""
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    dev = "cuda:0"
+    batch = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=2)]
+    outs = []
+    for split in (False, True):
+        m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", 64, 1)), compute_dtype=dtype)
+        m.load_state_dict(seeded_state_dict(m, 0))
+        m = m.to(dev).train()
+        m.split_gate = split
+        g0, gates = m.forward_front(*batch[:4])
+        g0.float().square().sum().backward()
+        outs.append((g0.detach().float(), m.prop_fc.weight.grad.clone(), m.qInput0.weight.grad.clone()))
+    (a, wa, qa), (b, wb, qb) = outs
+    if dtype == torch.float32:
+        assert torch.equal(a, b) and torch.equal(wa, wb) and torch.equal(qa, qb)
+    else:
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
+        assert float((wa - wb).norm()) <= 2e-2 * float(wa.norm()) and float((qa - qb).norm()) <= 2e-2 * float(qa.norm())
