@@ -67,20 +67,13 @@ g = GraphedStep(step, warmup=3).capture()
 print("linear graph            : %.3f ms/step (host side of one replay %.3f ms)" % (wall(g), host_only(g)))
 del g, m, red, opt
 
-# (b) one graph, two branches
-for wg_first in (True, False):
-    m, red, opt, batch = setup()
-    ds = DualStreamStep(m, batch[:5], loss_of, red, opt, wgrads_first=wg_first).warm(3)
-    graph = torch.cuda.CUDAGraph()
-    ds._fresh = True
-    with torch.cuda.graph(graph, stream=ds.main, capture_error_mode="thread_local"):
-        ds._schedule(ds._phase, ds.main, ds.side)
-        ds.main.wait_stream(ds.side)
-    run = graph.replay
-    print("one graph, two branches (wgrads_first=%s): %.3f ms/step (host side of one replay %.3f ms)" % (wg_first, wall(run), host_only(run)))
-    del graph, ds, m, red, opt
-
+# (b) one graph, two branches: schedule variants, each on the best of four candidate side streams (ForkedStep.capture)
 from drn_amd.graph import ForkedStep
-m, red, opt, batch = setup()
-fs = ForkedStep(m, batch[:5], loss_of, red, opt).warm(3).capture()
-print("ForkedStep (split gate: query encoder beside the prop_fc GEMM): %.3f ms/step (host side %.3f ms)" % (wall(fs), host_only(fs)))
+for name, kw, wf in (("prop_fc weight gradient first (shipped)", {}, False), ("small weight gradients first", {}, True),
+                     ("split gate: query encoder beside the prop_fc GEMM", {"split_gate": True}, False)):
+    m, red, opt, batch = setup()
+    fs = ForkedStep(m, batch[:5], loss_of, red, opt, **kw)
+    fs.wgrads_first = wf
+    fs.warm(3).capture()
+    print("forked, %-52s: %.3f ms/step (host side of one replay %.3f ms) candidates %s" % (name, wall(fs), host_only(fs), fs.probe_log))
+    del fs, m, red, opt

@@ -295,7 +295,7 @@ def test_forked_graph_step_is_bit_identical(dtype):
         return m, red, FusedAdam(red, lr=1e-4, max_norm=0.5)
 
     batch = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=1)]
-    n = 33
+    n = 64
     m1, r1, o1 = build()
     ref = []
     for _ in range(n):
@@ -312,13 +312,17 @@ def test_forked_graph_step_is_bit_identical(dtype):
     for _ in range(3):
         ls = fs()
         got.append([float(ls[k].reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
-    fs.capture()
-    for _ in range(n - 3):
+    fs.capture()                                             # times candidate side streams: spends `tuning_steps` real steps
+    skipped = fs.tuning_steps
+    assert 0 < skipped < n - 8
+    got += [None] * skipped
+    for _ in range(n - 3 - skipped):
         ls = fs()
         got.append([float(ls[k].reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
     torch.cuda.synchronize()
     assert ref[0] != ref[-1], "training made no progress"
-    assert got == ref, [(i, a, b) for i, (a, b) in enumerate(zip(got, ref)) if a != b][:3]
+    bad = [(i, a, b) for i, (a, b) in enumerate(zip(got, ref)) if a is not None and a != b]
+    assert not bad, bad[:3]
     sd1, sd2 = m1.state_dict(), m2.state_dict()
     for k in sd1:
         assert torch.equal(sd1[k], sd2[k]), k
