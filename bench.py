@@ -609,6 +609,10 @@ def main():
     if rank == 0 and world == 1 and args.trainer_line and args.graph and not args.torch_adam:
         try:
             del run
+            forked = model_f = reducer_f = params_f = None        # (the two-branch capture, its model and its streams)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             out["trainer"] = trainer_lines(cfg, dev, cdt, stage, B, D, (32, T) if T != 32 else (T,), min(args.steps * 2, 48))
         except Exception as e:
             print("trainer timing failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)

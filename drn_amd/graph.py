@@ -10,9 +10,30 @@ Every warm-up step and the capture itself run on ONE dedicated side stream: auto
 alive by the reducer's hooks) remember the stream they were created on, and a node created on the default stream
 would run -- uncaptured and unordered -- outside the graph.  So do not run `step_fn` eagerly on another stream first.
 """
+import contextlib
+import gc
+
 import torch
 
 from . import functional as DF
+
+
+@contextlib.contextmanager
+def capture_graph(g, stream, **kw):
+    """torch.cuda.graph(g, stream, capture_error_mode="thread_local") with Python's cyclic garbage collector switched OFF for the
+    duration: a collection that happens to run in the middle of a capture may finalise an unreachable CUDAGraph / stream / event
+    of some earlier, already dropped step object (anything that sat in a reference cycle) -- destroying those while a capture is
+    open aborts the process (seen as a rare "Fatal Python error: Aborted ... Garbage-collecting" in the trainer tests).
+    thread_local: a hipHostMalloc from another thread (a DataLoader's pin_memory thread) must not fail the capture."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local", **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GraphedStep(object):
@@ -36,7 +57,7 @@ class GraphedStep(object):
 
     def capture(self):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+        with capture_graph(g, self.stream):
             self.out = self.step_fn()
         self.graph = g
         return self
@@ -114,7 +135,7 @@ class TwoPhaseStep(object):
         for k in range(self.NPHASES):
             g = torch.cuda.CUDAGraph()
             kw = {} if k == 0 else {"pool": self.graphs[0].pool()}
-            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local", **kw):
+            with capture_graph(g, self.stream, **kw):
                 self._phase(k)
             self.graphs.append(g)
         return self
@@ -151,7 +172,7 @@ class DualStreamStep(object):
     PHASES = ("q_fwd", "prep", "trunk", "q_bwd", "wgrads", "opt", "repack")
     SIDE = ("q_fwd", "q_bwd")
 
-    def __init__(self, model, batch, loss_of, reducer, opt, wgrads_first=True, side_priority=-1, main_first=False):
+    def __init__(self, model, batch, loss_of, reducer, opt, wgrads_first=True, side_priority=0, main_first=False):
         self.model, self.batch, self.loss_of, self.reducer, self.opt = model, batch, loss_of, reducer, opt
         self.main_first = main_first
         # the side stream's launches are few workgroups each and latency-bound: at high priority they get CU slots ahead of the
@@ -268,7 +289,7 @@ class DualStreamStep(object):
             side = name in self.SIDE
             g = torch.cuda.CUDAGraph()
             kw = {"pool": pools[side]} if side in pools else {}
-            with torch.cuda.graph(g, stream=self.side if side else self.main, capture_error_mode="thread_local", **kw):
+            with capture_graph(g, self.side if side else self.main, **kw):
                 self._phase(name)
             pools.setdefault(side, g.pool())
             graphs[name] = g
@@ -292,46 +313,57 @@ class ForkedStep(DualStreamStep):
     """The DualStreamStep schedule as ONE hipGraph with two branches: the query encoder beside the input preparation, the query
     side's backward beside the weight gradients.  Round 2 gave up on branches ("host 0.05 -> 1.9 ms per replay"); measured in
     round 4 on ROCm 7.2 the host side of a replay is 0.3-0.4 ms, all of it hidden behind the ~2 ms the device needs, and the
-    step 2.18-2.21 -> 2.11-2.15 ms (scripts/experiments/one_graph_two_branches.py) -- PROVIDED the second branch sits on the
-    right stream, see capture().  Schedule variants measured on a working stream, all within 1 %: small weight gradients first or
-    the prop_fc one first; `split_gate=True` (the prop_fc GEMM un-gated so that the query encoder can run beside IT, the gate as
-    a pass of its own: two BiLSTM steps next to the 512-workgroup GEMM take 100-130 us instead of 7, nothing gained).
-    Results equal the single-stream step bit for bit (tests/test_graph_gpu.py)."""
+    step 2.18-2.21 -> 2.11-2.15 ms (scripts/experiments/one_graph_two_branches.py).  The second branch must sit on a stream of
+    the SAME priority as the first: captured on a `priority=-1` stream (what DualStreamStep asked for) three candidates in four
+    ran the step in 4.1-4.4 ms, and the high-priority hardware queues left behind slowed every later two-stream user of the
+    process (the trainer's H2D look-ahead 12.9 -> 9.0 k clips/s); from the default pool all candidates measure the same.
+    Schedule variants, all on working streams: small weight gradients first or the prop_fc one first, within 1 %;
+    `split_gate=True` (the prop_fc GEMM un-gated so that the query encoder can run beside IT, the gate as a pass of its own) within
+    1 % too -- two BiLSTM steps next to the 512-workgroup GEMM take 100-130 us instead of 7 (rocprofv3 timeline); a THIRD branch
+    (every weight gradient launched the moment backward has its operands, beside the data-gradient chain) 2.26 ms, slower than the
+    linear graph: the MFMA kernels of two branches only take each other's CUs.  Results equal the single-stream step bit for bit
+    (tests/test_graph_gpu.py)."""
 
-    def __init__(self, model, batch, loss_of, reducer, opt, split_gate=False):
+    def __init__(self, model, batch, loss_of, reducer, opt, split_gate=False, main=None, side=None):
+        """main / side: the streams to capture on (default: new ones).  `main` must be the stream every earlier step of this
+        model ran on (autograd's AccumulateGrad nodes are bound to it)."""
         model.split_gate = bool(split_gate)
-        super(ForkedStep, self).__init__(model, batch, loss_of, reducer, opt, wgrads_first=False)
+        self._streams = (main, side)
+        # (side stream from the DEFAULT-priority pool: high-priority streams bring a second set of hardware queues into being, and
+        # with them around everything else in the process that uses two streams ran slower afterwards -- the trainer's H2D
+        # look-ahead 12.9 -> 9.0 k clips/s, evaluation 22 -> 15 k, measured in bench.py after a capture on priority -1 streams)
+        super(ForkedStep, self).__init__(model, batch, loss_of, reducer, opt, wgrads_first=False, side_priority=0)
+        if self._streams[0] is not None:
+            self.main = self._streams[0]
+        if self._streams[1] is not None:
+            self.side = self._streams[1]
         self.graph = None
 
-    def _capture_once(self):
+    def _capture_once(self, pool=None):
         g = torch.cuda.CUDAGraph()
         self._fresh = True
-        with torch.cuda.graph(g, stream=self.main, capture_error_mode="thread_local"):
+        with capture_graph(g, self.main, **({"pool": pool} if pool is not None else {})):
             self._schedule(self._phase, self.main, self.side)
             self.main.wait_stream(self.side)
         self._c.clear()
         return g
 
-    def capture(self, tries=6, probe=6):
-        """Capture with up to `tries` different side streams and keep the fastest graph.  Which stream the second branch was
-        captured on decides whether the branches overlap or stall each other: the same schedule measured 2.11-2.15 ms/step on one
-        stream and 4.1-4.4 ms on the next three or four torch handed out (about one in four works -- presumably how streams fall
-        onto the hardware queues: within one queue independent nodes simply go without a barrier bit, across queues every
-        dependency is a signal round trip), so each candidate is replayed `probe` times (real training steps) and timed; capture
-        stops at the first candidate that beats 0.75 x the slowest seen.  A THIRD branch (every weight gradient on its own stream
-        the moment backward has its operands, beside the data-gradient chain) never found a working stream in 15 candidates
-        (3.8-4.2 ms each) and was removed.  The main stream never changes: autograd's AccumulateGrad nodes are bound to it."""
+    def capture(self, tries=2, probe=6, pool=None):
+        """Capture (with `tries` > 1: on that many different side streams, each candidate replayed `probe` times -- real training
+        steps, counted in `tuning_steps` -- and the fastest graph kept: a safety net from the time one stream in four worked;
+        probe=0 takes the first candidate without running anything).  The main stream never changes: autograd's AccumulateGrad
+        nodes are bound to it."""
         import time
         log = self.__dict__.setdefault("probe_log", [])
         self.tuning_steps = 0                    # training steps executed in here (timing replays, warm-up of candidate streams)
         best, worst = None, 0.0
         for i in range(max(int(tries), 1)):
             if i:
-                self.side = torch.cuda.Stream(priority=-1)
+                self.side = torch.cuda.Stream()
                 self.warm(1)                     # (allocator pools / workspaces of the new stream)
             if i:
                 self.tuning_steps += 1
-            g = self._capture_once()
+            g = self._capture_once(pool)
             if probe <= 0:                       # no timing (tests): the first candidate is taken, no training step is spent
                 best = (0.0, g, self.side, self.out)
                 break

@@ -14,6 +14,7 @@ clip+Adam kernels (drn_amd.optim.FusedAdam) in stages 1 and 3.  Stage 2 keeps to
 reference clips over ALL parameters while zeroing only the optimizer's (main.py:238-243), so the gradients of the frozen
 trunk accumulate step after step and keep shrinking the clip coefficient -- reproduced exactly by leaving those
 `p.grad` to autograd; it trains 0.9 M parameters, so the optimizer is not the cost there."""
+import functools
 import os
 
 import torch
@@ -67,6 +68,7 @@ class _StepSlot(object):
         self.gt = torch.zeros((B, 2), dtype=gt_dtype, device=device)
         self.args = (self.tok, self.qlen, self.feats, self.pse, self.gt, None, None)
         self.seen, self.graph, self.out, self.gen, self.alt = 0, None, None, None, 0
+        self.forked, self.forked_warm = None, False      # drn_amd.graph.ForkedStep of this geometry (one process), and whether it ran eagerly once
 
     def load(self, tok, qlen, feats, pse, gt):
         """Copy one batch (host or device tensors) into the static buffers; the token matrix is zero-padded (padding_idx 0)
@@ -91,7 +93,7 @@ class _Preloaded(object):
 
 class Trainer(object):
     def __init__(self, model, stage, lr=1e-3, clip_gradient=0.5, world_size=1, fused=True, graph=False, lq_bucket=4,
-                 graph_warmup=2, max_graphs=32, prefetch=None):
+                 graph_warmup=2, max_graphs=32, prefetch=None, forked=None):
         """graph=True (fused stages only): `train_step` replays the step as a hipGraph -- the launch path bench.py measures --
         one capture per input geometry (clips, proposals, feature dim, query length rounded up to a multiple of `lq_bucket`:
         the query kernels take the true lengths from the device, so padding changes no value) -- two, used in turn, when
@@ -115,6 +117,12 @@ class Trainer(object):
         # every step of a graph-mode trainer -- eager ones included -- runs on ONE side stream: autograd's AccumulateGrad nodes
         # remember the stream they were created on, and warm-up, capture and replay must agree on it (drn_amd/graph.py)
         self.stream = torch.cuda.Stream(device=self.device) if self.graph else None
+        # forked=True (one process): the captured step is ONE hipGraph with two branches (drn_amd.graph.ForkedStep: query side
+        # beside input preparation / weight gradients; the same launches and bits as the linear capture).  Worth 3.5 % in bench.py's
+        # back-to-back replays, NOTHING inside this loop (2.360 vs 2.369 ms/step at T = 256, scripts/experiments/trainer_forked_probe.py:
+        # the per-step input copies and stream hand-offs around the replay sit where the overlap was) -- so it is opt-in
+        self.forked = bool(forked) and self.graph and world_size == 1 and hasattr(model, "forward_trunk")
+        self._side = torch.cuda.Stream(device=self.device) if self.forked else None
         if self.fused:
             from .dist import GradReducer
             from .optim import FusedAdam
@@ -200,16 +208,38 @@ class Trainer(object):
                 if slot.graph is None and slot.seen >= self.graph_warmup:
                     if self.world_size > 1:
                         self.reducer.rearm()
-                    g = torch.cuda.CUDAGraph()
                     # thread_local: a hipHostMalloc from the DataLoader's pin_memory thread during this capture must not fail it
                     # (global mode turns ANY thread's unsafe call into hipErrorStreamCaptureUnsupported).  Captures share one
                     # memory pool (they replay one at a time); the alternate slots of the H2D look-ahead share a second one.
                     alt = slot.alt
                     kw = {"pool": self._pools[alt]} if alt in self._pools else {}
-                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local", **kw):
-                        slot.out = self._fwd_bwd(slot.args)
-                        if whole:
-                            self._exchange_and_update()
+                    if self.forked and whole:
+                        from .graph import ForkedStep
+                        fs = slot.forked
+                        if fs is None:
+                            # (the loss selector must not close over `self`: trainer -> slot -> step -> closure -> trainer would be a
+                            # reference cycle, and with it the trainer's graphs and streams would die whenever the GC gets to them)
+                            fs = slot.forked = ForkedStep(self.model, slot.args[:5], functools.partial(select_loss, which=self.which),
+                                                          self.reducer, self.opt, main=self.stream, side=self._side)
+                        if not slot.forked_warm:
+                            # this step runs the two-branch schedule EAGERLY once (workspaces / counters of the side stream come
+                            # into being outside a capture); the next one captures it
+                            slot.forked_warm = True
+                            fs._fresh = True
+                            fs._schedule(fs._phase, fs.main, fs.side)
+                            fs.main.wait_stream(fs.side)
+                            slot.seen += 1
+                            cur.wait_stream(self.stream)
+                            return fs.out
+                        g = fs._capture_once(kw.get("pool"))
+                        slot.out = fs.out
+                    else:
+                        g = torch.cuda.CUDAGraph()
+                        from .graph import capture_graph          # (thread_local capture, cyclic GC off while it is open)
+                        with capture_graph(g, self.stream, **kw):
+                            slot.out = self._fwd_bwd(slot.args)
+                            if whole:
+                                self._exchange_and_update()
                     self._pools.setdefault(alt, g.pool())
                     slot.graph, slot.gen = g, DF.cache_generation(stores)
                 if slot.graph is not None:

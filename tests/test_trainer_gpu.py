@@ -91,8 +91,9 @@ def _varying_batches(n, B, T, D, seed=3):
     return out
 
 
+@pytest.mark.parametrize("forked", [False, True])
 @pytest.mark.parametrize("dtype,stage", [(torch.bfloat16, 1), (torch.float32, 3)])
-def test_graph_trainer_is_bit_identical_to_eager(dtype, stage):
+def test_graph_trainer_is_bit_identical_to_eager(dtype, stage, forked):
     """Trainer(graph=True) -- train.py's default -- replays each step as a hipGraph from static input buffers, tokens padded to
     the geometry's query length; fed batches of varying query length and a ragged last batch it must leave EVERY parameter and
     buffer bit-identical to the eager trainer, and report the same losses (main.py:198-252 is the loop both implement)."""
@@ -105,8 +106,9 @@ def test_graph_trainer_is_bit_identical_to_eager(dtype, stage):
     for graph in (False, True):
         m = hip_model(stage)
         m.set_compute_dtype(dtype)
-        tr = T.Trainer(m, stage, lr=1e-4 if stage == 1 else 1.0, clip_gradient=0.5, graph=graph, lq_bucket=4)   # (stage 3 divides lr by 1e4)
-        assert tr.graph == graph
+        tr = T.Trainer(m, stage, lr=1e-4 if stage == 1 else 1.0, clip_gradient=0.5, graph=graph, lq_bucket=4,
+                       forked=forked)                            # (stage 3 divides lr by 1e4; forked: one graph, two branches)
+        assert tr.graph == graph and tr.forked == (forked and graph)
         losses = []
         for i in order:
             b = batches[i]
