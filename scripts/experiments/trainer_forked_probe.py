@@ -6,7 +6,7 @@ from drn_amd.model import mainModel
 from drn_amd.utils.synthetic import default_cfg, synthetic_batch
 dev = torch.device("cuda:0")
 cfg = default_cfg("C3D", 4096, 1)
-T = 256
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 batches = [B.collate_like([t.to(dev) if torch.is_tensor(t) else t for t in synthetic_batch(32, T, 4096, seed=100 + i)], ["v%d" % i] * 32) for i in range(8)]
 for forked in (False, True, False, True):
     m = B.build(mainModel, cfg, dev, compute_dtype=torch.bfloat16)
