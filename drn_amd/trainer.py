@@ -14,6 +14,7 @@ clip+Adam kernels (drn_amd.optim.FusedAdam) in stages 1 and 3.  Stage 2 keeps to
 reference clips over ALL parameters while zeroing only the optimizer's (main.py:238-243), so the gradients of the frozen
 trunk accumulate step after step and keep shrinking the clip coefficient -- reproduced exactly by leaving those
 `p.grad` to autograd; it trains 0.9 M parameters, so the optimizer is not the cost there."""
+import contextlib
 import functools
 import os
 
@@ -310,9 +311,12 @@ class Trainer(object):
                 cur_b = nxt
                 nxt = self._prefetch(next(it, None))
                 bs = cur_b.batch_size if isinstance(cur_b, _Preloaded) else cur_b[2].size(0)
-                loss = select_loss(self.train_step(cur_b), self.which).detach().reshape(-1)[0] * bs
-                total = loss if total is None else total + loss
+                ld = self.train_step(cur_b)
+                with torch.cuda.stream(self.stream):       # (on the step's own stream: the caller's stream stays empty, so the
+                    loss = select_loss(ld, self.which).detach().reshape(-1)[0] * bs    # hand-offs around the next replay wait for nothing)
+                    total = loss if total is None else total + loss
                 n += bs
+            torch.cuda.current_stream().wait_stream(self.stream)
             return float(total) / max(n, 1) if total is not None else 0.0
         for batch in loader:
             if self.graph:                                 # host tensors go straight into the captured step's input buffers
@@ -321,9 +325,13 @@ class Trainer(object):
             else:
                 _, args = to_device(batch, self.device)
             bs = args[2].size(0)
-            loss = select_loss(self.train_step(args), self.which).detach().reshape(-1)[0] * bs
-            total = loss if total is None else total + loss
+            ld = self.train_step(args)
+            with torch.cuda.stream(self.stream) if self.graph else contextlib.nullcontext():
+                loss = select_loss(ld, self.which).detach().reshape(-1)[0] * bs
+                total = loss if total is None else total + loss
             n += bs
+        if self.graph:
+            torch.cuda.current_stream().wait_stream(self.stream)
         return float(total) / max(n, 1) if total is not None else 0.0
 
     def _prefetch(self, batch):
