@@ -353,3 +353,52 @@ def test_split_gate_input_stage(dtype):
     else:
         assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
         assert float((wa - wb).norm()) <= 2e-2 * float(wa.norm()) and float((qa - qb).norm()) <= 2e-2 * float(qa.norm())
+
+
+def test_forked_graph_at_the_benchmarked_shape_equals_the_linear_graph():
+    """bench.py's two launch modes at N = 1 on the benchmarked workload (B = 32, T = 256, D = 4096, stage 1, bf16): the step
+    replayed as one linear hipGraph and as one hipGraph with two branches (ForkedStep) leave the same losses and the same
+    parameters, bit for bit, after the same number of steps."""
+    import bench as B
+    from drn_amd import dist as ddist, functional as DF
+    from drn_amd.graph import ForkedStep, GraphedStep
+    from drn_amd.model import mainModel
+    from drn_amd.optim import FusedAdam
+    from drn_amd.utils.synthetic import default_cfg, synthetic_batch
+    dev = torch.device("cuda:0")
+    cfg = default_cfg("C3D", 4096, 1)
+    batch = [b.to(dev) for b in synthetic_batch(32, 256, 4096, seed=1)]
+
+    def setup():
+        m = B.build(mainModel, cfg, dev, compute_dtype=torch.bfloat16)
+        params = B.stage_params(m, 1)
+        m.train()
+        red = ddist.GradReducer(params, world_size=1, overlap=True, adjacent=m.grad_stack_groups(), bucket_bytes=1 << 30)
+        return m, red, FusedAdam(red, lr=1e-3, max_norm=0.5)
+
+    m1, r1, o1 = setup()
+
+    def step():
+        r1.zero()
+        _, ls = m1(*batch)
+        DF.backward(DF.loss_total(ls))
+        r1.finish()
+        o1.step()
+        return ls
+    lin = GraphedStep(step, warmup=2).capture()
+    m2, r2, o2 = setup()
+    fk = ForkedStep(m2, batch[:5], DF.loss_total, r2, o2).warm(2).capture()
+    n_lin, n_fk = 2, 2 + fk.tuning_steps
+    total = n_fk + 5
+    for _ in range(total - n_lin):
+        l1 = lin()
+    for _ in range(total - n_fk):
+        l2 = fk()
+    torch.cuda.synchronize()
+    for k in ("loss_cls", "loss_reg"):
+        assert torch.equal(l1[k], l2[k]), (k, float(l1[k].reshape(-1)[0]), float(l2[k].reshape(-1)[0]))
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    r1.remove()
+    r2.remove()
