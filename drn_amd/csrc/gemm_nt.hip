@@ -1,6 +1,9 @@
 // Launchers of the grouped implicit-GEMM (NT) kernel (gemm_nt_kernel.h): drn_gemm_nt, drn_gemm_nt_splitk(_grouped).
 #include "gemm_nt_kernel.h"
 
+bool drn_nt_w4_eligible(const DrnGemmDesc* d, int ngroups, int dtype);            // gemm_nt_w4.hip
+int drn_nt_w4_launch(const GemmParams& P, int total, hipStream_t stream);
+
 static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr,
                      int* counters = nullptr) {
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_nt: ngroups=%d out of range", ngroups);
@@ -82,6 +85,10 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     P.nblocks = total; \
     if (fast) conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); \
     else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
+  if (tile == 256 && ksplit == 1 && drn_tuning(DRN_TUNE_NT_W4) > 0 && drn_nt_w4_eligible(d, ngroups, dtype)) {
+    P.nblocks = total;
+    return drn_nt_w4_launch(P, total, stream);
+  }
   if (tile == 256) {
     if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 65536, 2, 4, 8, 4); else NT_LAUNCH(float, 2, 512, 2 * 65536, 2, 4, 8, 4);
   } else if (deep8) {     // few workgroups, cold operands: three tiles of loads in flight instead of one

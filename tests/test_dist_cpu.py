@@ -248,6 +248,7 @@ def test_fit_train_only_runs_the_same_epochs_and_sets_sampler_epoch():
 
     tr = T.Trainer.__new__(T.Trainer)
     tr.default_epochs = None
+    tr.graph = False
     seen = []
     tr.train_step = lambda args: seen.append(1)
     loader = Loader()

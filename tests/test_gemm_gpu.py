@@ -16,7 +16,7 @@ TOL = {"f32": 2e-5, "bf16": 1e-2}
 def tune(monkeypatch, key, value):
     """drn_tune(key, value) for the duration of one test (defaults restored afterwards)."""
     from drn_amd import _lib
-    defaults = {"tn3_minrows": 4096, "tn_fused": 1}
+    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "exp0": 0}
     _lib.check(_lib.lib().drn_tune(key.encode(), int(value)), "drn_tune")
     _RESTORE.append((key, defaults[key]))
 
@@ -490,3 +490,75 @@ def test_conv_wgrad_fused_taps_levels(monkeypatch, multi):
     for a, b in zip(res["1"], res["0"]):
         assert torch.isfinite(a).all()
         assert torch.allclose(a, b, rtol=1e-5, atol=2e-6 * float(b.abs().max()) * np.sqrt(B * 256 / 64))
+
+
+# ---- the 4-wave hand-scheduled kernel of the large plain bf16 products (gemm_nt_w4.hip) -----------------------------------------
+W4_CASES = [
+    # B, Lout, N, K, bias, gate, C2, out_f32
+    (1, 256, 256, 128, False, False, False, False),      # K/64 = 2: prologue + tail only
+    (1, 256, 256, 192, True, False, False, False),       # one trip of the main loop
+    (2, 256, 512, 512, True, True, True, False),         # the prop_fc epilogue: bias, gate, pre-gate copy
+    (4, 256, 768, 1152, True, True, False, False),
+    (1, 512, 256, 640, False, False, False, True),       # fp32 destination (the weight gradient as an NT product)
+    (1, 768, 512, 2048, True, False, False, True),
+]
+
+
+@pytest.mark.parametrize("case", W4_CASES)
+def test_w4_kernel_is_bit_identical_to_the_general_kernel_and_close_to_torch(monkeypatch, case):
+    """gemm_nt_w4_kernel (4 waves, 128 x 128 per wave, asm main loop) runs the same MFMAs in the same K order through the same
+    epilogue code as conv_gemm_nt_kernel<bf16, 2, true, 2, 4, 8, 4>: equal bits, and both within bf16 tolerance of torch."""
+    from drn_amd import ops
+    B, Lo, N, K, bias, gate, c2, f32out = case
+    M = B * Lo
+    A = rnd((M, K), 11, torch.bfloat16).to(dev())
+    W = (rnd((N, K), 12, torch.float32) * 0.05).to(torch.bfloat16).to(dev())
+    bias_t = rnd((N,), 13, torch.float32).to(dev()) if bias else None
+    gate_t = torch.rand(B, N, generator=torch.Generator().manual_seed(14)).to(dev()) if gate else None
+    tune(monkeypatch, "exp0", 1)             # 256 x 256 tiles from one big tile on
+    outs = []
+    for w4 in (0, 1):
+        tune(monkeypatch, "nt_w4", w4)
+        C = torch.full((M, N), 7.0, device=dev(), dtype=torch.float32 if f32out else torch.bfloat16)
+        C2 = torch.full((M, N), 5.0, device=dev(), dtype=torch.bfloat16) if c2 else None
+        d = ops.gemm_desc(A, W, C, M, N, K, Lout=Lo, Lsrc=Lo, bias=bias_t, gate=gate_t, ldg=N, C2=C2, out_f32=f32out)
+        ops.gemm_nt([d], ops.BF16)
+        torch.cuda.synchronize()
+        outs.append((C, C2))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if c2:
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = A.double().cpu() @ W.double().cpu().t()
+    if bias:
+        ref = ref + bias_t.double().cpu()
+    if c2:
+        close(outs[1][1], ref, TOL["bf16"], "pre-gate copy")
+    if gate:
+        ref = ref * gate_t.double().cpu().repeat_interleave(Lo, 0)
+    close(outs[1][0], ref, TOL["bf16"] if not f32out else 2e-3, "w4 output")
+
+
+def test_w4_kernel_declines_what_it_cannot_run(monkeypatch):
+    """Shapes off the 256 / 64 grid, conv taps, strided operands with odd leading dimensions: the general kernel runs, results right."""
+    from drn_amd import ops
+    tune(monkeypatch, "exp0", 1)
+    for (M, N, K) in [(256, 256, 96), (384, 256, 128), (256, 320, 128)]:
+        A = rnd((M, K), 21, torch.bfloat16).to(dev())
+        W = (rnd((N, K), 22, torch.float32) * 0.05).to(torch.bfloat16).to(dev())
+        C = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+        ops.gemm_nt([ops.gemm_desc(A, W, C, M, N, K)], ops.BF16)
+        torch.cuda.synchronize()
+        close(C, A.double().cpu() @ W.double().cpu().t(), TOL["bf16"], "declined %s" % ((M, N, K),))
+    # padded leading dimensions ARE eligible (row stride != K)
+    M, N, K = 512, 256, 256
+    Ap = rnd((M, K + 64), 23, torch.bfloat16).to(dev())
+    Wp = (rnd((N, K + 128), 24, torch.float32) * 0.05).to(torch.bfloat16).to(dev())
+    outs = []
+    for w4 in (0, 1):
+        tune(monkeypatch, "nt_w4", w4)
+        C = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+        ops.gemm_nt([ops.gemm_desc(Ap, Wp, C, M, N, K, lda=K + 64, ldb=K + 128)], ops.BF16)
+        torch.cuda.synchronize()
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    close(outs[1], Ap[:, :K].double().cpu() @ Wp[:, :K].double().cpu().t(), TOL["bf16"], "padded rows")
