@@ -270,6 +270,10 @@ __device__ __forceinline__ void nt_bn_stats(f32x4 (&acc)[MI][NI], float* shs, fl
     }
 }
 
+// The two store paths of nt_epilogue below, one 32-row chunk at a time, for kernels that do not hold their accumulators in a C++
+// array (gemm_nt_w4.hip reads them out of fixed AGPRs chunk by chunk).  SAME statements as the loop bodies of nt_epilogue -- kept
+// apart because calling these from nt_epilogue cost the general bf16 kernels registers (128x128 tile 118 -> 141 VGPRs = one
+// workgroup per CU instead of two); tests/test_gemm_gpu.py holds the two kernels to equal bits.
 // One 32-row chunk (two rows of a wave's grid of 16x16 MFMA tiles) of the fp32-destination epilogue: a2[mi2][ni] = the wave's
 // accumulators of grid rows 2*ch + mi2.  wbuf: this wave's private LDS patch; mrow0 / ncol0: first row / column of the chunk.
 template <int NI>
@@ -435,12 +439,41 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
     float* __restrict__ Cf = (float*)pr.C;
     constexpr int WCOLS = NI * 16;           // columns owned by one wave
     constexpr int PITCHF = WCOLS * 4 + 16;
+    constexpr int LPRF = WCOLS / 4;          // lanes per staged row in the 16-byte read-back
+    constexpr int RPIF = 64 / LPRF;          // rows per read-back instruction
     char* wbuf = smem + w * (32 * PITCHF);
     const bool vec4 = (pr.ldc % 4 == 0) && (((uintptr_t)Cf & 15) == 0);
 #pragma unroll
     for (int ch = 0; ch < MI / 2; ++ch) {
       const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
-      nt_epi_chunk_f32<NI>(pr, *(const f32x4(*)[2][NI])&acc[ch * 2], wbuf, mrow0, n0 + wc * (NI * 16), vec4);
+#pragma unroll
+      for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            *((float*)(wbuf + (mi2 * 16 + (l >> 4) * 4 + r) * PITCHF) + ni * 16 + (l & 15)) = acc[ch * 2 + mi2][ni][r];
+      wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
+#pragma unroll
+      for (int it = 0; it < 32 / RPIF; ++it) {  // LPRF lanes per row, RPIF rows per instruction
+        const int rl = it * RPIF + l / LPRF, cv = l % LPRF;
+        const int m = mrow0 + rl, n = n0 + wc * (NI * 16) + cv * 4;
+        if (m < M && n < N) {
+          f32x4 v = *(const f32x4*)(wbuf + rl * PITCHF + cv * 16);
+          float* g = Cf + ((long)m * pr.ldc + n);
+          if (pr.bias)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += n + k < N ? pr.bias[n + k] : 0.f;
+          if (vec4 && n + 4 <= N && !pr.accumulate) {
+            *(f32x4*)g = v;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (n + k < N) g[k] = pr.accumulate ? g[k] + v[k] : v[k];
+          }
+        }
+      }
+      wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
     }
     return;
   }
@@ -462,6 +495,8 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
     // ones -- the narrow stores were ~8 us of issue-bound tail per launch).
     constexpr int WCOLS = NI * 16;                           // columns owned by one wave
     constexpr int PITCH = WCOLS * (int)sizeof(T) + 16;       // bytes per staged row (+16: conflict-free column writes)
+    constexpr int LPR = WCOLS * (int)sizeof(T) / 16;         // lanes per staged row in the 16-byte read-back
+    constexpr int RPI = 64 / LPR;                            // rows per read-back instruction
     char* wbuf = smem + w * (32 * PITCH);
     float bias_v[NI];
 #pragma unroll
@@ -469,10 +504,109 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
       const int n = n0 + wc * (NI * 16) + ni * 16 + (l & 15);
       bias_v[ni] = (pr.bias && n < N) ? pr.bias[n] : 0.f;
     }
+    const int npass = C2g ? 2 : 1;
 #pragma unroll
     for (int ch = 0; ch < MI / 2; ++ch) {
       const int mrow0 = m0 + wr * (MI * 16) + ch * 32;
-      nt_epi_chunk_vec<T, NI>(pr, *(const f32x4(*)[2][NI])&acc[ch * 2], wbuf, mrow0, n0 + wc * (NI * 16), bias_v);
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        // Fast path (bf16, the chunk's 32 rows x WCOLS columns all inside the matrix and -- if gated -- inside ONE sequence, no
+        // accumulate): the generic path below costs one ds_write_b16, one row -> sequence division and one gate load PER ELEMENT
+        // behind per-element masks (the 256x256 tile's epilogue took 6.9 us, mostly this).  Here the gate row is loaded once
+        // per chunk, and the 4 rows x 4 columns a quad of lanes holds are transposed inside the quad (packed bf16 pairs: 3 DPP
+        // moves + 2 byte permutes + 3 selects) so that every lane owns 4 consecutive columns of one row: one ds_write_b64 where
+        // there were four ds_write_b16.  Same conversions, same values, same 16-byte global stores.
+        const int ncol0 = n0 + wc * WCOLS;
+        const int sq0 = mrow0 / pr.Lout;
+        const bool fast_w = mrow0 + 32 <= M && ncol0 + WCOLS <= N && !pr.accumulate &&
+                            (!pr.gate || (mrow0 + 31) / pr.Lout == sq0);
+        if (__builtin_amdgcn_readfirstlane((int)fast_w)) {
+          float gv[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) gv[ni] = pr.gate ? pr.gate[(long)sq0 * pr.ldg + ncol0 + ni * 16 + (l & 15)] : 1.f;
+          const bool j0 = l & 1, j1 = l & 2;
+          const unsigned sel1 = j0 ? 0x03020706u : 0x05040100u;
+          for (int pass = 0; pass < npass; ++pass) {
+            const bool gated = pr.gate && pass == npass - 1;
+            T* dst = (C2g && pass == 0) ? C2g : Cg;
+            const int ldd = (C2g && pass == 0) ? pr.ldc2 : pr.ldc;
+#pragma unroll
+            for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  v[r] = acc[ch * 2 + mi2][ni][r] + bias_v[ni];
+                  if (gated) v[r] *= gv[ni];
+                }
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t b01 = {(bf16_t)v[0], (bf16_t)v[1]}, b23 = {(bf16_t)v[2], (bf16_t)v[3]};
+                const unsigned p0 = __builtin_bit_cast(unsigned, b01), p1 = __builtin_bit_cast(unsigned, b23);   // (row r, row r+1) of this lane's column
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p0, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p1, 0xB1, 0xf, 0xf, false);
+                // even lane: (own.lo, partner.lo) = row 2*r1, columns (j, j+1); odd lane: (partner.hi, own.hi) = row 2*r1 + 1, columns (j-1, j)
+                const unsigned q0 = __builtin_amdgcn_perm(r0, p0, sel1), q1 = __builtin_amdgcn_perm(r1, p1, sel1);
+                const unsigned snd = j1 ? q0 : q1;
+                const unsigned rcv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                const unsigned o0 = j1 ? rcv : q0, o1 = j1 ? q1 : rcv;         // row (l & 3), columns 0-1 and 2-3 of the quad's four
+                const int rl = mi2 * 16 + (l >> 4) * 4 + (l & 3);
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                *(u32x2_t*)(wbuf + rl * PITCH + (ni * 16 + ((l & 15) >> 2) * 4) * 2) = (u32x2_t){o0, o1};
+              }
+            wave_lds_sync();
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+              const int rl = it * RPI + l / LPR, cv = l % LPR;
+              const uint4 raw = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
+              *(uint4*)(dst + ((long)(mrow0 + rl) * ldd + ncol0 + cv * VEC)) = raw;
+            }
+            wave_lds_sync();
+          }
+          continue;
+        }
+      }
+      for (int pass = 0; pass < npass; ++pass) {
+        const bool gated = pr.gate && pass == npass - 1;
+        T* dst = (C2g && pass == 0) ? C2g : Cg;
+        const int ldd = (C2g && pass == 0) ? pr.ldc2 : pr.ldc;
+#pragma unroll
+        for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = mi2 * 16 + (l >> 4) * 4 + r;
+            const int m = mrow0 + rl;
+            const float* grow = (gated && m < M) ? pr.gate + (long)(m / pr.Lout) * pr.ldg : nullptr;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              float v = acc[ch * 2 + mi2][ni][r] + bias_v[ni];
+              if (grow) {
+                const int n = n0 + wc * (NI * 16) + ni * 16 + (l & 15);
+                v *= n < N ? grow[n] : 0.f;
+              }
+              DT<T>::st((T*)(wbuf + rl * PITCH) + ni * 16 + (l & 15), v);
+            }
+          }
+        wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int rl = it * RPI + l / LPR, cv = l % LPR;
+          const int m = mrow0 + rl, n = n0 + wc * (NI * 16) + cv * VEC;
+          if (m < M && n < N) {
+            const uint4 raw = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
+            T* g = dst + ((long)m * ldd + n);
+            const bool acc_c = pr.accumulate && dst == Cg;
+            if (n + VEC <= N && !acc_c) {
+              *(uint4*)g = raw;
+            } else {
+              const T* e = (const T*)&raw;
+#pragma unroll
+              for (int k = 0; k < VEC; ++k)
+                if (n + k < N) DT<T>::st(g + k, acc_c ? DT<T>::ld(e + k) + DT<T>::ld(g + k) : DT<T>::ld(e + k));
+            }
+          }
+        }
+        wave_lds_sync();   // the patch is private to this wave: LDS executes a wave's accesses in order
+      }
     }
     // BatchNorm statistics AFTER the stores have been issued: the tile's write burst (the whole chip stores at once: 3-6 us at the
     // HBM write rate) drains while the three-barrier statistics pass runs, instead of starting behind it.  The statistics use the
