@@ -7,7 +7,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB-ish units of 1024 B per the rocprofv3 derived
 128-B requests tallied at 64 B for wide coalesced reads, MI355X_MICROARCH.md "HBM").  Infinity-Cache hits are counted: the
 figure is fabric traffic behind the L2, an upper bound of HBM traffic.
 usage: python scripts/pmc_hbm_table.py trace.db fetch.db write.db [pmc_traffic.json] > profiles/rNN_hbm_kernels.txt
-With a 4th argument the per-launch bytes of the two prop_fc GEMMs (the 256x256-tile kernel's 512- and 256-workgroup launches) are
+With a 4th argument the per-launch bytes of the two prop_fc GEMMs (gemm_nt_w4_kernel's 512- and 256-workgroup launches) are
 written there in the format bench.py reads for roofline.traffic."""
 import collections
 import sqlite3
@@ -76,7 +76,7 @@ def by_grid(dbpath, counter, name_part):
 
 def write_traffic_json(path, fetch, write):
     import json
-    big = "2, 4, 8, 4, false"               # the 256x256-tile NT kernel (plain, not the conv->BN variant)
+    big = "gemm_nt_w4_kernel"               # the two prop_fc products run the 4-wave kernel (round 4; before: "2, 4, 8, 4, false", the 256x256-tile NT kernel)
     F, W = by_grid(fetch, "FETCH_SIZE", big), by_grid(write, "WRITE_SIZE", big)
     out = {"_comment": "Fabric traffic per launch of the two prop_fc GEMMs INSIDE the replayed step, from this round's rocprofv3 --pmc passes "
                        "(FETCH_SIZE and WRITE_SIZE in separate passes, only --kernel-trace beside them; FETCH_SIZE doubled per the gfx950 "
