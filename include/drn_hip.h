@@ -27,8 +27,10 @@ extern "C" {
 
 int drn_abi_version(void);
 /* Process-wide tuning values that tests use to reach kernels their shapes would not select: "tn3_minrows" (fewest rows for
- * the fused-tap weight-gradient kernel, default 4096), "tn_fused" (0 switches that kernel off).  The library never reads the
- * environment (the experiment build `make EXPERIMENTS=1` does). */
+ * the fused-tap weight-gradient kernel, default 4096), "tn_fused" (0 switches that kernel off), "nt_w4" (0: drn_gemm_nt runs the
+ * general 8-wave kernel also for the large plain bf16 products that gemm_nt_w4_kernel takes by default; results are bit-identical
+ * either way), "nt_deep", "exp0".."exp4" (launch heuristics, 0 = shipped).  The library never reads the environment (the
+ * experiment build `make EXPERIMENTS=1` does). */
 int drn_tune(const char* key, int value);
 const char* drn_last_error(void); /* thread-local, valid until the next failing call on this thread */
 
