@@ -501,6 +501,7 @@ W4_CASES = [
     (4, 256, 768, 1152, True, True, False, False),
     (1, 512, 256, 640, False, False, False, True),       # fp32 destination (the weight gradient as an NT product)
     (1, 768, 512, 2048, True, False, False, True),
+    (16, 80, 256, 256, True, True, True, False),         # 32-row store chunks straddle sequences: the per-element gate path
 ]
 
 
@@ -584,3 +585,23 @@ def test_w4_kernel_stress_many_launches_stay_bit_identical(monkeypatch):
         torch.cuda.synchronize()
         bad += int(not torch.equal(outs[0], outs[1]))
     assert bad == 0, "%d of 60 launches differ" % bad
+
+
+@pytest.mark.parametrize("f32out", [False, True])
+def test_w4_kernel_accumulates_like_the_general_kernel(monkeypatch, f32out):
+    """accumulate = 1 (C += A W^T) takes the epilogue's read-modify-write path in both kernels: equal bits."""
+    from drn_amd import ops
+    M, N, K = 512, 256, 384
+    A = rnd((M, K), 31, torch.bfloat16).to(dev())
+    W = (rnd((N, K), 32, torch.float32) * 0.05).to(torch.bfloat16).to(dev())
+    C0 = rnd((M, N), 33, torch.float32).to(dev()).to(torch.float32 if f32out else torch.bfloat16)
+    tune(monkeypatch, "exp0", 1)
+    outs = []
+    for w4 in (0, 1):
+        tune(monkeypatch, "nt_w4", w4)
+        C = C0.clone()
+        ops.gemm_nt([ops.gemm_desc(A, W, C, M, N, K, accumulate=True, out_f32=f32out)], ops.BF16)
+        torch.cuda.synchronize()
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    close(outs[1], C0.double().cpu() + A.double().cpu() @ W.double().cpu().t(), 2e-2, "accumulate")
