@@ -23,7 +23,7 @@ def timeit(fn, reps=15):
     return ts[len(ts) // 2]
 modes = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 6]
 for (M, N, K, f32out) in [(4096, 4096, 8192, True), (8192, 4096, 4096, False)]:
-    for pad in (0,):
+    for pad in (0, 32, 64, 128, 256):
         A = torch.randn(M + 8, K + pad, device=dev).to(bf)
         W = (torch.randn(N + 8, K + pad, device=dev) * 0.05).to(bf)
         C = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else bf)

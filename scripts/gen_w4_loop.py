@@ -22,7 +22,7 @@ of A_j, B_j are free.  A piece is in flight for one to three half-steps before a
 Register plan (fixed inside the statement; everything the compiler allocates stays below v124 / outside s[80:91]):
   v[128:159] A fragments set 0   v[160:191] B set 0   v[192:223] A set 1   v[224:255] B set 1   v124 / v125 fragment base of A / B
   s[80:81] / s[82:83] A / B row-panel base + k offset (+128 bytes per K-step), s84 trip count, s85 LDS address of this wave's
-  first piece in slot 0, s86 byte offset of the slot being staged, s87 / s88 of the slots being read (A / B), s89-s90 scratch.
+  first piece in slot 0, s86 byte offset of the slot being staged, s87 / s88 of the slots being read (A / B), s89 = s85 + s86, s90 / s91 scratch.
 """
 import argparse, os
 
@@ -41,6 +41,8 @@ class Cfg:
     no_ds = False
     no_barrier = False
     no_mfma = False
+    hoist = True        # scalar bookkeeping and M0 writes inside the MFMA stream (False: after it / in front of each piece)
+    adv = 128           # bytes the operand pointers advance per K-step (0: every K-step re-reads the first one -- L2-hit ablation)
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -85,55 +87,82 @@ def dma_item(op):
     return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "global_load_lds_dwordx4 %%[vo%s%d], %s" % (op, i, src)] for i in range(8)]
 
 
-def advance_stage(op):
+def advance_stage_groups(op):
+    """source pointer of the operand + 128 bytes, staging slot + 1 (mod the ring); groups of instructions that stay adjacent
+    (producer and consumer of SCC)"""
     ptr = (80, 81) if op == "a" else (82, 83)
-    return ["s_add_u32 s%d, s%d, 128" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1]),
-            "s_add_u32 s86, s86, %d" % SLOT, "s_cmp_lt_u32 s86, %d" % RING, "s_cselect_b32 s86, s86, 0", "s_add_u32 s89, s85, s86"]
+    return [["s_add_u32 s%d, s%d, %d" % (ptr[0], ptr[0], cfg.adv), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])],
+            ["s_add_u32 s86, s86, %d" % SLOT], ["s_cmp_lt_u32 s86, %d" % RING, "s_cselect_b32 s86, s86, 0"], ["s_add_u32 s89, s85, s86"]]
 
 
-def advance_read():
+def advance_stage(op):
+    return [i for g in advance_stage_groups(op) for i in g]
+
+
+def advance_read_groups():
     """the slots being read move on by one K-step = two slots (mod the ring)"""
-    L = []
-    for r in ("s87", "s88"):
-        L += ["s_add_u32 %s, %s, %d" % (r, r, 2 * SLOT), "s_sub_u32 s90, %s, %d" % (r, RING), "s_cmp_lt_u32 %s, %d" % (r, RING),
-              "s_cselect_b32 %s, %s, s90" % (r, r)]
-    return L
+    G = []
+    for r, t in (("s87", "s90"), ("s88", "s91")):
+        G += [["s_add_u32 %s, %s, %d" % (r, r, 2 * SLOT), "s_sub_u32 %s, %s, %d" % (t, r, RING)],
+              ["s_cmp_lt_u32 %s, %d" % (r, RING), "s_cselect_b32 %s, %s, %s" % (r, r, t)]]
+    return G
 
 
-def half_step(ks, reads=True, dma=None, wait=None, barrier=False, pre=()):
-    """MFMAs of k-slice ks on set ks; `reads`: the fragments of the NEXT k-slice (1 - ks) into the other set; dma: "a" / "b" / None"""
+def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False):
+    """MFMAs of k-slice ks on set ks; `reads`: the fragments of the NEXT k-slice (1 - ks) into the other set; dma: "a" / "b" / None;
+    adv_read: move the read slots on by one K-step once this half-step's fragment bases have been formed.
+    Everything that is not an MFMA goes INTO the MFMA stream (one or two instructions per gap: a 16-cycle MFMA leaves ~3 issue
+    slots): the scalar bookkeeping, and M0 is written one MFMA ahead of its LDS-DMA piece (the MFMA is the wait state)."""
     L = []
     if wait:
         L.append("s_waitcnt %s" % wait)
     if barrier and not cfg.no_barrier:
         L.append("s_barrier")
-    L += list(pre)
     do_reads = reads and not cfg.no_ds
     if do_reads:
         L += frag_bases(1 - ks)
+    fill = {n: [] for n in range(64)}
     rs = ds_reads(1 - ks) if do_reads else []
+    for k, r in enumerate(rs):
+        fill[min(63, cfg.ds_first + k * cfg.ds_every)].append(r)
     ps = dma_item(dma) if dma and not cfg.no_dma else []
-    n = 0
-    for mi in range(8):
-        for ni in range(8):
-            if not cfg.no_mfma:
-                L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(mi, ni), frag(A_SET[ks], mi), frag(B_SET[ks], ni), acc(mi, ni)))
-            if rs and n >= cfg.ds_first and (n - cfg.ds_first) % cfg.ds_every == 0:
-                L.append(rs.pop(0))
-            if ps and n >= cfg.dma_first and (n - cfg.dma_first) % cfg.dma_every == 0:
-                L.extend(ps.pop(0))
-            n += 1
-    L += rs
-    for p in ps:
-        L.extend(p)
-    if dma:
-        L += advance_stage(dma)
+    last_dma = 0
+    for k, (m0w, nop, ld) in enumerate(ps):
+        n = min(63, cfg.dma_first + k * cfg.dma_every)
+        if cfg.hoist and n >= 1 and not cfg.no_mfma:
+            fill[n - 1].append(m0w)
+            fill[n].append(ld)
+        else:
+            fill[n] += [m0w, nop, ld]
+        last_dma = n
+    tail = []
+    rd_groups = advance_read_groups() if adv_read else []
+    st_groups = advance_stage_groups(dma) if dma else []
+    if cfg.hoist:
+        # the read slots may move as soon as the bases are formed; the staging pointers only after the last piece has been issued
+        for k, g in enumerate(rd_groups):
+            fill[4 + 2 * k] += g
+        pos = last_dma + 1
+        for g in st_groups:
+            if pos <= 63:
+                fill[pos] += g
+                pos += 1
+            else:
+                tail += g
+    else:
+        tail = [i for g in rd_groups + st_groups for i in g]
+    for n in range(64):
+        if not cfg.no_mfma:
+            mi, ni = n // 8, n % 8
+            L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(mi, ni), frag(A_SET[ks], mi), frag(B_SET[ks], ni), acc(mi, ni)))
+        L += fill[n]
+    L += tail
     return L
 
 
 def k_step(dma=True, last_wait="vmcnt(8) lgkmcnt(0)", next_reads=True):
-    L = half_step(0, reads=True, dma="a" if dma else None, wait="lgkmcnt(0)")
-    L += half_step(1, reads=next_reads, dma="b" if dma else None, wait=last_wait, barrier=next_reads, pre=advance_read() if next_reads else ())
+    L = half_step(0, reads=True, dma="a" if dma else None, wait="lgkmcnt(0)", adv_read=next_reads)
+    L += half_step(1, reads=next_reads, dma="b" if dma else None, wait=last_wait, barrier=next_reads)
     return L
 
 
@@ -164,16 +193,44 @@ def build():
     return lines
 
 
-clob = ["memory", "scc"] + ["s%d" % i for i in range(80, 91)] + ["v%d" % i for i in range(124, 256)] + ["a%d" % i for i in range(256)]
+def check_scc(lines):
+    """every consumer of SCC must see the producer it was written for (the generator moves scalar instructions around)"""
+    last = None
+    for ln in lines:
+        op = ln.split()[0]
+        args_ = [a.strip(",") for a in ln.split()[1:]]
+        if op == "s_cselect_b32":
+            assert last and last[0] == "s_cmp_lt_u32" and last[1][0] == args_[1], (last, ln)
+        elif op == "s_addc_u32":
+            assert last and last[0] == "s_add_u32" and int(last[1][0][1:]) + 1 == int(args_[0][1:]), (last, ln)
+        elif op.startswith("s_cbranch_scc"):
+            assert last and last[0].startswith("s_cmp"), (last, ln)
+        if op in ("s_add_u32", "s_sub_u32", "s_addc_u32") or op.startswith("s_cmp"):
+            last = (op, args_)
+    # M0: each LDS-DMA piece is preceded by exactly one M0 write with at least one instruction between them
+    m0_age = None
+    for ln in lines:
+        if ln.startswith("s_add_u32 m0"):
+            assert m0_age is None, "M0 written twice before its piece"
+            m0_age = 0
+        elif ln.startswith("global_load_lds"):
+            assert m0_age is not None and m0_age >= 1, "piece without a settled M0: %s" % ln
+            m0_age = None
+        elif m0_age is not None:
+            m0_age += 1
+
+
+clob = ["memory", "scc"] + ["s%d" % i for i in range(80, 92)] + ["v%d" % i for i in range(124, 256)] + ["a%d" % i for i in range(256)]
 VARIANTS = [Cfg()]
 if args.experiments:
     VARIANTS += [Cfg(no_dma=True), Cfg(no_ds=True), Cfg(no_barrier=True), Cfg(no_dma=True, no_ds=True), Cfg(no_mfma=True),
-                 Cfg(ds_every=2, ds_first=0), Cfg(dma_every=4, dma_first=32), Cfg(dma_every=4, dma_first=1), Cfg(ds_every=1, ds_first=0)]
+                 Cfg(hoist=False), Cfg(no_mfma=True, adv=0), Cfg(dma_every=7, dma_first=6), Cfg(adv=0)]
 with open(args.out, "w") as f:
     f.write("// GENERATED by scripts/gen_w4_loop.py%s -- do not edit.\n" % (" --experiments" if args.experiments else ""))
     for vi, c in enumerate(VARIANTS):
         cfg = c
         lines = build()
+        check_scc(lines)
         f.write("// variant %d: %s (%d instructions)\n" % (vi, c.desc, len(lines)))
         f.write("#define W4_LOOP_ASM_%d \\\n" % vi)
         for ln in lines:
