@@ -41,6 +41,7 @@ class Cfg:
     no_ds = False
     no_barrier = False
     no_mfma = False
+    mfma32 = False      # timing-only ablation: half as many v_mfma_f32_32x32x16_bf16 (same pipe time, twice the issue slack per gap)
     hoist = True        # scalar bookkeeping and M0 writes inside the MFMA stream (False: after it / in front of each piece)
     adv = 128           # bytes the operand pointers advance per K-step (0: every K-step re-reads the first one -- L2-hit ablation)
 
@@ -154,7 +155,12 @@ def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False
     for n in range(64):
         if not cfg.no_mfma:
             mi, ni = n // 8, n % 8
-            L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(mi, ni), frag(A_SET[ks], mi), frag(B_SET[ks], ni), acc(mi, ni)))
+            if cfg.mfma32:
+                if n % 2 == 0:
+                    q = (n // 2) % 16
+                    L.append("v_mfma_f32_32x32x16_bf16 a[%d:%d], %s, %s, a[%d:%d]" % (16 * q, 16 * q + 15, frag(A_SET[ks], mi), frag(B_SET[ks], ni), 16 * q, 16 * q + 15))
+            else:
+                L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(mi, ni), frag(A_SET[ks], mi), frag(B_SET[ks], ni), acc(mi, ni)))
         L += fill[n]
     L += tail
     return L
@@ -224,7 +230,7 @@ clob = ["memory", "scc"] + ["s%d" % i for i in range(80, 92)] + ["v%d" % i for i
 VARIANTS = [Cfg()]
 if args.experiments:
     VARIANTS += [Cfg(no_dma=True), Cfg(no_ds=True), Cfg(no_barrier=True), Cfg(no_dma=True, no_ds=True), Cfg(no_mfma=True),
-                 Cfg(hoist=False), Cfg(no_mfma=True, adv=0), Cfg(dma_every=7, dma_first=6), Cfg(adv=0)]
+                 Cfg(mfma32=True, dma_first=4), Cfg(mfma32=True, no_dma=True), Cfg(mfma32=True, no_dma=True, no_ds=True), Cfg(mfma32=True, adv=0, dma_first=4)]
 with open(args.out, "w") as f:
     f.write("// GENERATED by scripts/gen_w4_loop.py%s -- do not edit.\n" % (" --experiments" if args.experiments else ""))
     for vi, c in enumerate(VARIANTS):
