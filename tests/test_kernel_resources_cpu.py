@@ -1,0 +1,58 @@
+"""Register budgets of the built GEMM kernels, read from the code objects inside libdrn_hip.so (no GPU needed).
+
+Why a test: occupancy is part of these kernels' design and nothing else notices when it is lost.  Round 4 routed the general NT
+kernel's epilogue through two helper functions; its bf16 128x128 variant went from 118 to 141 VGPRs -- one 8-wave workgroup per CU
+instead of two, the six 448-workgroup launches of a step 13-38 us slower each -- with every parity test green."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "drn_amd", "libdrn_hip.so")
+
+
+def kernel_table(tmp_path):
+    objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not found")
+    if not os.path.exists(LIB):
+        pytest.skip("libdrn_hip.so not built")
+    so = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(LIB, so)
+    subprocess.run([objdump, "--offloading", so], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    table = {}
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", os.path.join(str(tmp_path), f)], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name:
+                continue
+            get = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, blk).group(1))
+            table[name.group(1)] = {"agpr": int(blk.split()[0]), "vgpr": get("vgpr_count"), "spill": get("vgpr_spill_count"),
+                                    "scratch": get("private_segment_fixed_size")}
+    assert table, "no gfx950 kernels found in the library"
+    return table
+
+
+def test_gemm_kernels_keep_their_register_budgets(tmp_path):
+    table = kernel_table(tmp_path)
+    # conv_gemm_nt_kernel<T, STAGES, FAST, WM, WN, MI, NI, BNF = false, CHAIN = false> -- Itanium mangling of the template arguments
+    small = [k for k in table if re.search(r"conv_gemm_nt_kernelI(f|DF16b)Li[24]ELb[01]ELi2ELi4ELi4ELi2ELb0ELb0E", k)]
+    big = [k for k in table if re.search(r"conv_gemm_nt_kernelI(f|DF16b)Li2ELb[01]ELi2ELi4ELi8ELi4ELb0ELb0E", k)]
+    assert len(small) == 8 and len(big) == 4, (len(small), len(big))
+    for k in small:      # 128x128 tile, 8 waves: two workgroups per CU need <= 128 registers per lane
+        r = table[k]
+        assert r["vgpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0 and r["agpr"] == 0, (k, r)
+    for k in big:        # 256x256 tile, 8 waves = 2 per SIMD: <= 256, and nothing in scratch
+        r = table[k]
+        assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (k, r)
+    w4 = [k for k in table if "gemm_nt_w4_kernel" in k]
+    assert w4, "gemm_nt_w4_kernel missing"
+    for k in w4:         # one wave per SIMD: the statement owns a[0:255] and v[124:255]; the compiler must not spill around it
+        r = table[k]
+        assert r["agpr"] == 256 and r["vgpr"] == 512 and r["spill"] == 0 and r["scratch"] == 0, (k, r)
