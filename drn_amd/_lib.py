@@ -123,7 +123,7 @@ def lib():
                            "Run __graft_entry__.build() or `make -C drn_amd/csrc`." % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.drn_last_error.restype = ctypes.c_char_p
-        for fn in ("drn_wgrad_ws_elems", "drn_skinny_group_ws_elems", "drn_opt_nblocks", "drn_gemm_nt_splitk_ws_elems", "drn_heads_ws_elems",
+        for fn in ("drn_wgrad_ws_elems", "drn_skinny_group_ws_elems", "drn_opt_nblocks", "drn_gemm_nt_splitk_ws_elems", "drn_gemm_nt_splitk256_ws_elems", "drn_heads_ws_elems",
                    "drn_conv_tail_bwd_ws_elems", "drn_conv_bn_train_ws_bytes"):
             if hasattr(_lib, fn):
                 getattr(_lib, fn).restype = c_int64

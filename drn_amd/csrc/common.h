@@ -62,6 +62,7 @@ int drn_tuning(int key);
 #define DRN_TUNE_EXP0 3         // exp0..exp4: experiment overrides, 0 = shipped behaviour (scripts/experiments/ab_tune.sh A/Bs them inside
                                 // one process): exp0 = 256x256-tile threshold of the NT launches (200 big tiles), exp1 = workgroup
                                 // target of the fused-tap weight gradient (256), exp2 = of the per-tap one (768), exp3 = NT tile order + 1, exp4 = of the K-split skinny launches (256)
+#define DRN_TUNE_NT_W4C 9        // 1: eligible k = 3 / stride 1 bf16 convolutions on 256x256 tiles run gemm_nt_w4c_kernel (gemm_nt_w4.hip)
 #define DRN_TUNE_NT_W4 8         // 1: eligible large bf16 products run the 4-wave hand-scheduled kernel (gemm_nt_w4.hip); 0: the general kernel
 #define DRN_TUNE_NT_DEEP 2       // > 0: 128x128 NT launches of at most that many workgroups run the 4-slot ring (one workgroup per CU)
 

@@ -3,9 +3,11 @@
 
 bool drn_nt_w4_eligible(const DrnGemmDesc* d, int ngroups, int dtype);            // gemm_nt_w4.hip
 int drn_nt_w4_launch(const GemmParams& P, int total, hipStream_t stream);
+bool drn_nt_w4c_eligible(const DrnGemmDesc* d, int ngroups, int dtype);
+int drn_nt_w4c_launch(const GemmParams& P, int total, hipStream_t stream, int ksplit);
 
 static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr,
-                     int* counters = nullptr) {
+                     int* counters = nullptr, bool planes256 = false) {
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_nt: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_nt: bad dtype %d", dtype);
   const int ch = dtype == DRN_BF16 ? 8 : 4;
@@ -38,7 +40,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   P.xcd_swizzle = drn_exp_env("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
   if (drn_tuning(DRN_TUNE_EXP0 + 3) > 0) P.xcd_swizzle = drn_tuning(DRN_TUNE_EXP0 + 3) - 1;   // (exp3: experiment override, value - 1)
   if (const char* e = drn_exp_env("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);      // bit 0: XCD-contiguous runs, bit 1: 8-row grouped order
-  if (ksplit > 1) tile = 128;
+  if (ksplit > 1) tile = planes256 ? 256 : 128;
   int total = 0;
   for (int g = 0; g < ngroups; ++g) {
     const DrnGemmDesc& s = d[g];
@@ -88,6 +90,14 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   if (tile == 256 && ksplit == 1 && drn_tuning(DRN_TUNE_NT_W4) > 0 && drn_nt_w4_eligible(d, ngroups, dtype)) {
     P.nblocks = total;
     return drn_nt_w4_launch(P, total, stream);
+  }
+  if (tile == 256 && (planes256 || (ksplit == 1 && drn_tuning(DRN_TUNE_NT_W4C) > 0)) && drn_nt_w4c_eligible(d, ngroups, dtype)) {
+    P.nblocks = total;
+    return drn_nt_w4c_launch(P, total, stream, ksplit);
+  }
+  if (planes256) {
+    drn_set_error("drn_gemm_nt_splitk256: the problem is not one gemm_nt_w4c_kernel runs (bf16, k = 3 / stride 1 / pad 1, M and N multiples of 256, Cin of 64)");
+    return DRN_ERR_UNSUPPORTED;
   }
   if (tile == 256) {
     if (dtype == DRN_BF16) NT_LAUNCH(bf16_t, 2, 512, 2 * 65536, 2, 4, 8, 4); else NT_LAUNCH(float, 2, 512, 2 * 65536, 2, 4, 8, 4);
@@ -140,4 +150,89 @@ extern "C" int drn_gemm_nt_splitk(const DrnGemmDesc* desc, int ksplit, float* ws
   DRN_CHECK_ARG(ksplit == 1 || (cdiv(desc->M, 128) * cdiv(desc->N, 128) <= DRN_QD_COUNTERS && (((uintptr_t)ws) & 15) == 0),
                 "drn_gemm_nt_splitk: more than %d output tiles or unaligned workspace", DRN_QD_COUNTERS);
   return launch_nt(desc, 1, dtype, (hipStream_t)stream, ksplit, ws, (int*)counters);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-K on 256x256 tiles in TWO launches, for ONE long-K k = 3 convolution with few output tiles (conv0's forward: 8192 x 256 x
+// 13056 = 32 tiles): with 128x128 tiles (the in-launch split above) every A panel is staged once per 128 output columns -- 856 MB
+// from the L2s into LDS for conv0, which is what its 81 us were; full-width 256-column tiles halve that, and gemm_nt_w4c_kernel's
+// five-slot ring keeps the loads coming (the same split on the 8-wave 256x256 kernel measured 94 us: one K-step in flight against
+// operands that come straight from HBM).  Launch 1: grid (tiles, ksplit), split y writes its fp32 partial product as plane y of
+// ws[ksplit][M][N].  Launch 2 (below): adds the planes in split order
+// (deterministic), + bias, writes the output in `dtype` and the per-128-row-slab BatchNorm statistics of the fp32 sums -- what the
+// one-launch epilogue would have written.  No gate / pre-gate copy / accumulate here (conv -> BN callers have none).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk256_reduce_kernel(const float* __restrict__ ws, int ksplit, T* __restrict__ C, int ldc,
+                                                               const float* __restrict__ bias, float* __restrict__ stats, int M, int N) {
+  // one workgroup = one 128-row slab x 64 columns; thread = column tid % 64, rows (tid / 64) * 32 .. + 32
+  __shared__ float sh[4][64];
+  const int c = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int n = blockIdx.y * 64 + c, slab = blockIdx.x;
+  const int r0 = slab * 128 + j * 32;
+  const long plane = (long)M * N;
+  const bool ncol = n < N;
+  float v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = 0.f;
+  for (int s = 0; s < ksplit; ++s) {
+    const float* p = ws + s * plane + (long)r0 * N + n;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] += (ncol && r0 + i < M) ? p[(long)i * N] : 0.f;
+  }
+  const float b = (bias && ncol) ? bias[n] : 0.f;
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    sm += v[i];                                                   // statistics of the RAW sums (rows >= M hold exact zeros)
+    if (ncol && r0 + i < M) DT<T>::st(C + (long)(r0 + i) * ldc + n, v[i] + b);
+  }
+  if (!stats) return;
+  sh[j][c] = sm;
+  __syncthreads();
+  const float tot = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  const int rows = min(128, M - slab * 128);
+  const float mean = tot / (float)rows;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float dlt = v[i] - mean;
+    q += r0 + i < M ? dlt * dlt : 0.f;
+  }
+  __syncthreads();
+  sh[j][c] = q;
+  __syncthreads();
+  if (j == 0 && ncol) {
+    stats[((long)slab * 2 + 0) * N + n] = tot;
+    stats[((long)slab * 2 + 1) * N + n] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  }
+}
+
+extern "C" int64_t drn_gemm_nt_splitk256_ws_elems(int M, int N, int ksplit) { return (int64_t)ksplit * M * N; }
+
+extern "C" int drn_gemm_nt_splitk256(const DrnGemmDesc* desc, int ksplit, float* ws, int dtype, void* stream_) {
+  drn_clear_status();
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(desc && ksplit >= 2 && ksplit <= 64 && ws && (((uintptr_t)ws) & 15) == 0, "drn_gemm_nt_splitk256: bad ksplit / workspace");
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_nt_splitk256: bad dtype %d", dtype);
+  DRN_CHECK_ARG(!desc->gate && !desc->C2 && !desc->accumulate && !desc->out_f32 && desc->C,
+                "drn_gemm_nt_splitk256: gate / pre-gate copy / accumulate / fp32 destination are not supported here");
+  DRN_CHECK_ARG(desc->N % 4 == 0, "drn_gemm_nt_splitk256: N must be a multiple of 4 (16-byte rows of the fp32 planes)");
+  {
+    const int ksteps = desc->taps * desc->Cin / 64, per = cdiv(ksteps, ksplit);
+    DRN_CHECK_ARG(ksteps - (cdiv(ksteps, per) - 1) * per >= 2 && cdiv(ksteps, per) == ksplit,
+                  "drn_gemm_nt_splitk256: %d K-steps do not split %d ways with at least 2 per split", ksteps, ksplit);
+  }
+  DrnGemmDesc part = *desc;
+  part.C = ws;                       // (gemm_nt_w4c_kernel addresses plane `split` of P.ws itself)
+  part.ldc = desc->N;
+  part.bias = nullptr;
+  part.stats = nullptr;
+  const int rc = launch_nt(&part, 1, dtype, stream, ksplit, ws, nullptr, true);
+  if (rc != DRN_OK) return rc;
+  const dim3 grid(cdiv(desc->M, 128), cdiv(desc->N, 64));
+  if (dtype == DRN_BF16)
+    splitk256_reduce_kernel<bf16_t><<<grid, 256, 0, stream>>>(ws, ksplit, (bf16_t*)desc->C, desc->ldc, desc->bias, desc->stats, desc->M, desc->N);
+  else
+    splitk256_reduce_kernel<float><<<grid, 256, 0, stream>>>(ws, ksplit, (float*)desc->C, desc->ldc, desc->bias, desc->stats, desc->M, desc->N);
+  return drn_launch_status("drn_gemm_nt_splitk256(reduce)");
 }

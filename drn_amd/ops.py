@@ -88,9 +88,39 @@ def _ksplit(descs, dtype):
     return max(1, min(8, (KSPLIT_WGS if dtype == BF16 else 512) // tiles, nkt // (SPLITK_STEPS_PER_SPLIT if dtype == BF16 else 6)))
 
 
+# One long-K bf16 k = 3 convolution with 16-64 tiles of 256x256 (conv0's forward: 32 tiles x 204 K-steps): full-width tiles on the
+# 4-wave kernel, the K loop split so that ~256 workgroups exist, fp32 partial planes + a second launch that adds them
+# (drn_gemm_nt_splitk256) -- half the L2 -> LDS bytes of the 128x128 in-launch split below.  DRN_SPLITK256=0 switches it off.
+SPLITK256 = os.environ.get("DRN_SPLITK256", "0") == "1"
+
+
+def _ksplit256(descs, dtype):
+    if not SPLITK256 or dtype != BF16 or len(descs) != 1:
+        return 1
+    d = descs[0]
+    if d.gate or d.C2 or d.accumulate or d.out_f32:
+        return 1
+    if d.taps != 3 or d.stride != 1 or d.pad != 1 or d.mode not in (0, 1) or d.Lout != d.Lsrc or d.M % 256 or d.N % 256 or d.Cin % 64 or d.M % d.Lout:
+        return 1
+    if d.ldc % 8 or (d.C or 0) % 16:
+        return 1
+    tiles = (d.M // 256) * (d.N // 256)
+    nkt = (d.taps * d.Cin) // 64
+    if tiles > 64 or tiles < 16 or nkt < 96:
+        return 1
+    return max(1, min(8, 256 // tiles, nkt // 12))
+
+
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
+    ks = _ksplit256(descs, dtype)
+    if ks > 1:
+        d0 = descs[0]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ws = workspace(ks * d0.M * d0.N, dev)
+        tag = "gemm_nt[bf16] g=1 M=%d N=%d K=%d mode=%d splitK256=%d" % (d0.M, d0.N, d0.taps * d0.Cin, d0.mode, ks)
+        return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk256(arr, ks, _p(ws), dtype, _stream()), "drn_gemm_nt_splitk256"))
     ks = _ksplit(descs, dtype)
     if ks > 1:
         d0 = descs[0]

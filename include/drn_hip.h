@@ -29,7 +29,8 @@ int drn_abi_version(void);
 /* Process-wide tuning values that tests use to reach kernels their shapes would not select: "tn3_minrows" (fewest rows for
  * the fused-tap weight-gradient kernel, default 4096), "tn_fused" (0 switches that kernel off), "nt_w4" (0: drn_gemm_nt runs the
  * general 8-wave kernel also for the large plain bf16 products that gemm_nt_w4_kernel takes by default; results are bit-identical
- * either way), "nt_deep", "exp0".."exp4" (launch heuristics, 0 = shipped).  The library never reads the environment (the
+ * either way), "nt_w4c" (the same for the k = 3 / stride 1 convolutions on 256x256 tiles and gemm_nt_w4c_kernel), "nt_deep",
+ * "exp0".."exp4" (launch heuristics, 0 = shipped).  The library never reads the environment (the
  * experiment build `make EXPERIMENTS=1` does). */
 int drn_tune(const char* key, int value);
 const char* drn_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -78,6 +79,13 @@ int drn_gemm_nt_splitk(const DrnGemmDesc* desc /*host*/, int ksplit, float* ws, 
  * 128x128 output tiles) * 16384 floats, one counter per tile of the launch. */
 int drn_gemm_nt_splitk_grouped(const DrnGemmDesc* descs /*host*/, int ngroups, int ksplit, float* ws, int32_t* counters, int dtype,
                                void* stream);
+
+/* ... and for ONE long-K k = 3 / stride 1 convolution with few output tiles (conv0's forward) on full-width 256x256 tiles in two
+ * launches: every split writes its fp32 partial product as plane `split` of ws (drn_gemm_nt_splitk256_ws_elems floats), a second
+ * kernel adds the planes in split order (+ bias), writes C and the per-128-row-slab BatchNorm statistics.  bf16 only, M and N
+ * multiples of 256, Cin of 64, at least 2 K-steps of 64 per split; no gate / C2 / accumulate / out_f32 (DRN_ERR_UNSUPPORTED). */
+int64_t drn_gemm_nt_splitk256_ws_elems(int M, int N, int ksplit);
+int drn_gemm_nt_splitk256(const DrnGemmDesc* desc /*host*/, int ksplit, float* ws, int dtype, void* stream);
 
 /* Weight gradient:  dW[n][tap][c] (fp32) = sum_m dY[m][n] * X[src(m,tap)][c]   (mode-0 addressing of X).
  * dW is written as [N][taps][Cin] when w_layout==0 or [N][Cin][taps] (the nn.Conv1d parameter layout) when 1.

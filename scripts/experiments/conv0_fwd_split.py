@@ -1,9 +1,7 @@
 """conv0's forward (8192 x 256 x 13056, k = 3, BatchNorm statistics) through ops.gemm_nt: 128x128 tiles with the in-launch 2-way
-split (DRN_SPLITK256=0) against 256x256 tiles, 8 fp32 partial planes and the adding launch (default), cold operands.
-usage (after `git apply scripts/experiments/gemm_nt_splitk256.patch` and a rebuild): python scripts/experiments/conv0_fwd_split.py
-Measured (round 4): 84-88 us (in-launch 2-way split, 128x128 tiles, 4-slot ring) against 94 us (73 us for the 256 workgroups x 25.5
-K-steps + 17 us for the adding launch): with ONE tile column every A byte is read by exactly one workgroup, straight from HBM, and the
-256x256 kernel keeps one K-step of loads in flight -- 2.9 us per K-step.  Not adopted."""
+split (ops.SPLITK256 = False) against gemm_nt_w4c_kernel on 256x256 tiles with 8 fp32 partial planes + the adding launch
+(drn_gemm_nt_splitk256, default), cold operands.  usage: python scripts/experiments/conv0_fwd_split.py
+(The same split on the 8-wave 256x256 kernel -- scripts/experiments/gemm_nt_splitk256.patch -- measured 94 us against 84-88.)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

@@ -19,10 +19,20 @@ One barrier per K-step, at the top of half-step 2j+1: before it every wave waits
 A_{j+2}'s are younger) and for its own fragment reads of K-step j -- so after it A/B_{j+1} are visible to everybody and the slots
 of A_j, B_j are free.  A piece is in flight for one to three half-steps before anybody needs it.
 
-Register plan (fixed inside the statement; everything the compiler allocates stays below v124 / outside s[80:91]):
+Conv mode (W4C_LOOP_ASM, gemm_nt_w4c_kernel): k = 3 / stride 1 / pad 1 convolutions, forward and data gradient.  The A operand of
+K-step j is channel block c0(j) of the source rows shifted by the tap of j; A is staged through a buffer descriptor
+(`buffer_load_dwordx4 v, s[92:95], s96 offen lds`): v[116:123] = the lanes' row offsets for the CURRENT tap of the staging stream,
+0x80000000 -- out of range, the hardware writes zeros into those LDS cells -- where the shifted row leaves the lane's sequence;
+s96 = channel byte offset inside the tap.  After every staged A item one K-step less is left in the tap (s97); at zero the stream
+moves to the next tap: s96 = 0, new row shift (%[sh0..2]), new zero lanes (bit i of %[ma] / %[mc] for piece i at the first / last
+tap).  Nothing else differs from the plain loop: MFMAs, fragment reads, B staging, waits and barriers do not know about taps.
+
+Register plan (fixed inside the statement; everything the compiler allocates stays below v113 / outside s[79:99]):
   v[128:159] A fragments set 0   v[160:191] B set 0   v[192:223] A set 1   v[224:255] B set 1   v124 / v125 fragment base of A / B
   s[80:81] / s[82:83] A / B row-panel base + k offset (+128 bytes per K-step), s84 trip count, s85 LDS address of this wave's
-  first piece in slot 0, s86 byte offset of the slot being staged, s87 / s88 of the slots being read (A / B), s89 = s85 + s86, s90 / s91 scratch.
+  first piece in slot 0, s86 byte offset of the slot being staged, s87 / s88 of the slots being read (A / B), s89 = s85 + s86,
+  s90 / s91 scratch; conv mode: s[92:95] A descriptor, s96-s99 tap state, s79 scratch, v114 scratch, v115 = 0x80000000,
+  v[116:123] lane offsets of the current tap.
 """
 import argparse, os
 
@@ -41,6 +51,7 @@ class Cfg:
     no_ds = False
     no_barrier = False
     no_mfma = False
+    conv = False        # k = 3 / stride 1 convolutions: A staged through a buffer descriptor, per-tap row shift, zero rows at the sequence edges
     mfma32 = False      # timing-only ablation: half as many v_mfma_f32_32x32x16_bf16 (same pipe time, twice the issue slack per gap)
     hoist = True        # scalar bookkeeping and M0 writes inside the MFMA stream (False: after it / in front of each piece)
     adv = 128           # bytes the operand pointers advance per K-step (0: every K-step re-reads the first one -- L2-hit ablation)
@@ -84,16 +95,54 @@ def frag_bases(ks):
 
 def dma_item(op):
     """this wave's 8 LDS-DMA pieces of one operand's K-step into the slot at offset s86 (s89 = s85 + s86)"""
+    if op == "a" and cfg.conv:
+        # conv mode: A through a buffer descriptor (s[92:95]): lane offset v[116 + i] = row offset of the CURRENT tap, 0x80000000
+        # (out of range -> the piece gets zeros) where the tap leaves the lane's sequence; s96 = channel byte offset inside the tap
+        return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "buffer_load_dwordx4 v%d, s[92:95], s96 offen lds" % (116 + i)] for i in range(8)]
     src = "s[80:81]" if op == "a" else "s[82:83]"
     return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "global_load_lds_dwordx4 %%[vo%s%d], %s" % (op, i, src)] for i in range(8)]
+
+
+def apply_tap(tag):
+    """conv mode: lane offsets of the staging stream's tap s99 (0 / 1 / 2) into v[116:123]: row shift %[sh0..2] on top of the lane's
+    own offset, then 0x80000000 (v115) for the lanes whose source row leaves the sequence -- tap 0: bit i of %[ma], tap 2: of %[mc]"""
+    L = ["s_cmp_eq_u32 s99, 0", "s_cselect_b32 s79, %[sh0], %[sh1]", "s_cmp_eq_u32 s99, 2", "s_cselect_b32 s79, %[sh2], s79"]
+    L += ["v_add_u32 v%d, s79, %%[voa%d]" % (116 + i, i) for i in range(8)]
+    L += ["s_cmp_eq_u32 s99, 1", "s_cbranch_scc1 L_w4_tapdone_%s%%=" % tag, "s_cmp_eq_u32 s99, 0", "s_cbranch_scc0 L_w4_tap2_%s%%=" % tag]
+    for name, msk in (("tap0", "%[ma]"), ("tap2", "%[mc]")):
+        if name == "tap2":
+            L.append("L_w4_tap2_%s%%=:" % tag)
+        for i in range(8):
+            L += ["v_and_b32 v114, %d, %s" % (1 << i, msk), "v_cmp_ne_u32 vcc, 0, v114", "v_cndmask_b32 v%d, v%d, v115, vcc" % (116 + i, 116 + i)]
+        if name == "tap0":
+            L.append("s_branch L_w4_tapdone_%s%%=" % tag)
+    L.append("L_w4_tapdone_%s%%=:" % tag)
+    return L
+
+
+_tap_seq = [0]
+
+
+def advance_tap():
+    """conv mode, after an A item: one K-step less in the staging stream's tap; at zero the stream moves to the next tap
+    (s97 = K-steps left in the tap, s98 = K-steps per tap, s96 = channel byte offset)"""
+    _tap_seq[0] += 1
+    tag = "t%d" % _tap_seq[0]
+    L = ["s_sub_u32 s97, s97, 1", "s_cmp_lg_u32 s97, 0", "s_cbranch_scc1 L_w4_same_%s%%=" % tag,
+         "s_mov_b32 s97, s98", "s_mov_b32 s96, 0", "s_add_u32 s99, s99, 1"]
+    L += apply_tap(tag)
+    L.append("L_w4_same_%s%%=:" % tag)
+    return L
 
 
 def advance_stage_groups(op):
     """source pointer of the operand + 128 bytes, staging slot + 1 (mod the ring); groups of instructions that stay adjacent
     (producer and consumer of SCC)"""
     ptr = (80, 81) if op == "a" else (82, 83)
-    return [["s_add_u32 s%d, s%d, %d" % (ptr[0], ptr[0], cfg.adv), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])],
-            ["s_add_u32 s86, s86, %d" % SLOT], ["s_cmp_lt_u32 s86, %d" % RING, "s_cselect_b32 s86, s86, 0"], ["s_add_u32 s89, s85, s86"]]
+    first = ["s_add_u32 s%d, s%d, %d" % (ptr[0], ptr[0], cfg.adv), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+    if op == "a" and cfg.conv:
+        first = ["s_add_u32 s96, s96, 128"]
+    return [first, ["s_add_u32 s86, s86, %d" % SLOT], ["s_cmp_lt_u32 s86, %d" % RING, "s_cselect_b32 s86, s86, 0"], ["s_add_u32 s89, s85, s86"]]
 
 
 def advance_stage(op):
@@ -152,6 +201,8 @@ def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False
                 tail += g
     else:
         tail = [i for g in rd_groups + st_groups for i in g]
+    if dma == "a" and cfg.conv:
+        tail += advance_tap()
     for n in range(64):
         if not cfg.no_mfma:
             mi, ni = n // 8, n % 8
@@ -173,14 +224,25 @@ def k_step(dma=True, last_wait="vmcnt(8) lgkmcnt(0)", next_reads=True):
 
 
 def build():
-    lines = ["s_mov_b64 s[80:81], %[sa]", "s_mov_b64 s[82:83], %[sb]", "s_mov_b32 s84, %[cnt]", "s_mov_b32 s85, %[lw]",
+    _tap_seq[0] = 0
+    lines = ["s_mov_b64 s[82:83], %[sb]", "s_mov_b32 s84, %[cnt]", "s_mov_b32 s85, %[lw]",
              "s_mov_b32 s86, 0", "s_mov_b32 s87, 0", "s_mov_b32 s88, %d" % SLOT, "s_mov_b32 s89, s85"]
+    if cfg.conv:
+        lines += ["s_mov_b32 s92, %[d0]", "s_mov_b32 s93, %[d1]", "s_mov_b32 s94, %[d2]", "s_mov_b32 s95, %[d3]",
+                  "s_mov_b32 s96, %[c0]", "s_mov_b32 s97, %[left]", "s_mov_b32 s98, %[per]", "s_mov_b32 s99, %[tap]",
+                  "v_mov_b32 v115, 0x80000000"]
+        lines += apply_tap("init")
+        lines += ["s_nop 4"]          # v[116:123] / s96 written just above: settle before the first piece reads them
+    else:
+        lines += ["s_mov_b64 s[80:81], %[sa]"]
     # prologue: A_0, B_0, A_1, B_1 into slots 0..3
     for q in range(4):
         op = "ab"[q & 1]
         for p in dma_item(op):
             lines.extend(p)
         lines += advance_stage(op)
+        if op == "a" and cfg.conv:
+            lines += advance_tap()
     # accumulators = 0, while the first K-steps are on their way
     for i in range(256):
         lines.append("v_accvgpr_write_b32 a%d, 0" % i)
@@ -205,8 +267,11 @@ def check_scc(lines):
     for ln in lines:
         op = ln.split()[0]
         args_ = [a.strip(",") for a in ln.split()[1:]]
+        if op.endswith(":") or op == "s_branch":
+            last = None
+            continue
         if op == "s_cselect_b32":
-            assert last and last[0] == "s_cmp_lt_u32" and last[1][0] == args_[1], (last, ln)
+            assert last and (last[0] == "s_cmp_eq_u32" or (last[0] == "s_cmp_lt_u32" and last[1][0] == args_[1])), (last, ln)
         elif op == "s_addc_u32":
             assert last and last[0] == "s_add_u32" and int(last[1][0][1:]) + 1 == int(args_[0][1:]), (last, ln)
         elif op.startswith("s_cbranch_scc"):
@@ -219,14 +284,14 @@ def check_scc(lines):
         if ln.startswith("s_add_u32 m0"):
             assert m0_age is None, "M0 written twice before its piece"
             m0_age = 0
-        elif ln.startswith("global_load_lds"):
+        elif ln.startswith("global_load_lds") or ln.startswith("buffer_load_dwordx4"):
             assert m0_age is not None and m0_age >= 1, "piece without a settled M0: %s" % ln
             m0_age = None
         elif m0_age is not None:
             m0_age += 1
 
 
-clob = ["memory", "scc"] + ["s%d" % i for i in range(80, 92)] + ["v%d" % i for i in range(124, 256)] + ["a%d" % i for i in range(256)]
+clob = ["memory", "scc", "vcc"] + ["s%d" % i for i in range(79, 100)] + ["v%d" % i for i in range(113, 256)] + ["a%d" % i for i in range(256)]
 VARIANTS = [Cfg()]
 if args.experiments:
     VARIANTS += [Cfg(no_dma=True), Cfg(no_ds=True), Cfg(no_barrier=True), Cfg(no_dma=True, no_ds=True), Cfg(no_mfma=True),
@@ -242,6 +307,14 @@ with open(args.out, "w") as f:
         for ln in lines:
             f.write('  "%s\\n\\t" \\\n' % ln)
         f.write('  ""\n')
+    cfg = Cfg(conv=True)
+    lines = build()
+    check_scc(lines)
+    f.write("// conv mode (k = 3, stride 1): %d instructions\n" % len(lines))
+    f.write("#define W4C_LOOP_ASM \\\n")
+    for ln in lines:
+        f.write('  "%s\\n\\t" \\\n' % ln)
+    f.write('  ""\n')
     f.write("#define W4_VARIANTS %d\n" % len(VARIANTS))
     f.write("#define W4_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
 print("wrote %s: %d variant(s)" % (args.out, len(VARIANTS)))

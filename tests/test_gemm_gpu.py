@@ -16,7 +16,7 @@ TOL = {"f32": 2e-5, "bf16": 1e-2}
 def tune(monkeypatch, key, value):
     """drn_tune(key, value) for the duration of one test (defaults restored afterwards)."""
     from drn_amd import _lib
-    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "exp0": 0}
+    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0}
     _lib.check(_lib.lib().drn_tune(key.encode(), int(value)), "drn_tune")
     _RESTORE.append((key, defaults[key]))
 
@@ -605,3 +605,114 @@ def test_w4_kernel_accumulates_like_the_general_kernel(monkeypatch, f32out):
         outs.append(C)
     assert torch.equal(outs[0], outs[1])
     close(outs[1], C0.double().cpu() + A.double().cpu() @ W.double().cpu().t(), 2e-2, "accumulate")
+
+
+# ---- the 4-wave kernel for k = 3 / stride 1 convolutions (gemm_nt_w4c_kernel) ------------------------------------------------------
+W4C_CASES = [
+    # B, L, N, Cin, mode, bias, stats, gate, lda padding
+    (1, 256, 256, 64, 0, False, False, False, 0),        # one K-step per tap: a tap switch after every staged item
+    (2, 128, 256, 128, 0, True, True, False, 0),         # two sequences per tile: zero rows inside the tile
+    (4, 64, 512, 192, 0, False, True, False, 0),
+    (2, 256, 256, 256, 1, False, False, False, 0),       # data gradient: the taps run the other way
+    (8, 32, 256, 128, 1, True, False, True, 0),
+    (2, 128, 256, 128, 0, True, False, True, 64),        # row stride != channels
+]
+
+
+@pytest.mark.parametrize("case", W4C_CASES)
+def test_w4c_conv_kernel_is_bit_identical_to_the_general_kernel(monkeypatch, case):
+    """Same MFMAs, same K order, same epilogue statements and the same statistics order as conv_gemm_nt_kernel<bf16, 2, true, 2, 4, 8, 4>;
+    the zero rows at the sequence edges come from out-of-range lanes of the staging loads instead of the zero page."""
+    from drn_amd import ops
+    B, L, N, Cin, mode, bias, stats, gate, pad = case
+    M = B * L
+    A = rnd((M, Cin + pad), 41, torch.bfloat16).to(dev())
+    W = (rnd((N, 3 * Cin), 42, torch.float32) * 0.05).to(torch.bfloat16).to(dev())
+    bias_t = rnd((N,), 43, torch.float32).to(dev()) if bias else None
+    gate_t = torch.rand(B, N, generator=torch.Generator().manual_seed(44)).to(dev()) if gate else None
+    tune(monkeypatch, "exp0", 1)
+    outs = []
+    for flag in (0, 1):
+        tune(monkeypatch, "nt_w4c", flag)
+        C = torch.full((M, N), 7.0, device=dev(), dtype=torch.bfloat16)
+        st = torch.full((M // 128, 2, N), float("nan"), device=dev()) if stats else None
+        d = ops.gemm_desc(A, W, C, M, N, Cin, taps=3, pad=1, mode=mode, Lout=L, Lsrc=L, lda=Cin + pad, bias=bias_t, gate=gate_t, ldg=N, stats=st)
+        ops.gemm_nt([d], ops.BF16)
+        torch.cuda.synchronize()
+        outs.append((C, st))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if stats:
+        assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[1][0].float()).all()
+
+
+def test_w4c_conv_forward_matches_torch(monkeypatch):
+    from drn_amd import ops
+    B, L, Cin, Cout = 2, 128, 128, 256
+    x, w = conv_case("bf16", B, L, Cin, Cout, 3, 1)
+    ref = F.conv1d(x.double(), w.double(), padding=1).permute(0, 2, 1).reshape(B * L, Cout)
+    xd, wp = nlc(x).to(dev()), w.permute(0, 2, 1).contiguous().to(dev())
+    tune(monkeypatch, "exp0", 1)
+    C = torch.empty(B * L, Cout, device=dev(), dtype=torch.bfloat16)
+    ops.gemm_nt([ops.gemm_desc(xd, wp, C, B * L, Cout, Cin, taps=3, pad=1, Lout=L, Lsrc=L)], ops.BF16)
+    torch.cuda.synchronize()
+    close(C, ref, TOL["bf16"] * 2, "w4c conv forward")
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128, 256, 3, 0), (1, 512, 320, 256, 5, 0), (4, 64, 192, 512, 3, 0), (2, 256, 128, 256, 2, 1)])
+def test_conv_splitk256_two_launches(monkeypatch, shape):
+    """drn_gemm_nt_splitk256 (conv0's forward): gemm_nt_w4c_kernel on 256x256 tiles, every split writes an fp32 partial plane, the
+    second launch adds the planes in split order (+ bias) and writes the output and the per-slab BatchNorm statistics."""
+    import ctypes
+    from drn_amd import ops, _lib
+    B, L, Cin, Cout, ksplit, mode = shape
+    M = B * L
+    L_ = _lib.lib()
+    ws = torch.empty(int(L_.drn_gemm_nt_splitk256_ws_elems(M, Cout, ksplit)), dtype=torch.float32, device=dev())
+    bias = rnd((Cout,), 3, torch.float32)
+    bias_d = bias.to(dev())
+    if mode == 0:
+        x, w = conv_case("bf16", B, L, Cin, Cout, 3, 1)
+        ref = F.conv1d(x.double(), w.double(), padding=1).permute(0, 2, 1).reshape(M, Cout)
+        xd, wp = nlc(x).to(dev()), w.permute(0, 2, 1).contiguous().to(dev())
+    else:      # any weights will do for mode 1: the reference is the one-launch kernel on the same descriptor
+        xd = rnd((M, Cin), 51, torch.bfloat16).to(dev())
+        wp = (rnd((Cout, 3 * Cin), 52, torch.float32) * 0.05).to(torch.bfloat16).to(dev())
+        tune(monkeypatch, "exp0", 1)
+        Cr = torch.empty(M, Cout, device=dev(), dtype=torch.float32)
+        tune(monkeypatch, "nt_w4c", 0)
+        Cb = torch.empty(M, Cout, device=dev(), dtype=torch.bfloat16)
+        ops.gemm_nt([ops.gemm_desc(xd, wp, Cb, M, Cout, Cin, taps=3, pad=1, mode=1, Lout=L, Lsrc=L)], ops.BF16)
+        torch.cuda.synchronize()
+        ref = Cb.double().cpu()
+    outs = []
+    for rep in range(2):                  # deterministic: the planes are added in split order
+        C = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device=dev())
+        stats = torch.full((M // 128, 2, Cout), float("nan"), dtype=torch.float32, device=dev())
+        d = ops.gemm_desc(xd, wp, C, M, Cout, Cin, taps=3, pad=1, mode=mode, Lout=L, Lsrc=L, stats=stats, bias=bias_d)
+        _lib.check(L_.drn_gemm_nt_splitk256((_lib.GemmDesc * 1)(d), ksplit, ctypes.c_void_p(ws.data_ptr()), ops.BF16,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "splitk256")
+        torch.cuda.synchronize()
+        outs.append((C, stats))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    close(outs[0][0], ref + bias.double(), TOL["bf16"] * 2, "output")
+    tot, m2 = merged_stats(outs[0][1], M)
+    close(tot, ref.sum(0), TOL["bf16"] * 4, "col sum (raw conv)")
+    close(m2, ((ref - ref.mean(0)) ** 2).sum(0), TOL["bf16"] * 4, "col M2")
+
+
+def test_splitk256_refuses_what_it_cannot_do():
+    import ctypes
+    from drn_amd import ops, _lib
+    M, N, K = 256, 256, 256
+    A = rnd((M, K), 1, torch.bfloat16).to(dev())
+    W = rnd((N, K), 2, torch.bfloat16).to(dev())
+    C = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ws = torch.empty(4 * M * N, dtype=torch.float32, device=dev())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gate = torch.rand(1, N, device=dev())
+    d = ops.gemm_desc(A, W, C, M, N, K, gate=gate, ldg=N)
+    assert _lib.lib().drn_gemm_nt_splitk256((_lib.GemmDesc * 1)(d), 4, ctypes.c_void_p(ws.data_ptr()), ops.BF16, stream) != 0
+    assert b"not supported" in _lib.lib().drn_last_error()
+    d = ops.gemm_desc(A, W, C, M, N, K)             # a plain product (taps = 1): not a problem of the conv kernel
+    assert _lib.lib().drn_gemm_nt_splitk256((_lib.GemmDesc * 1)(d), 2, ctypes.c_void_p(ws.data_ptr()), ops.BF16, stream) != 0
