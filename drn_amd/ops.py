@@ -108,7 +108,13 @@ def _ksplit256(descs, dtype):
     nkt = (d.taps * d.Cin) // 64
     if tiles > 64 or tiles < 16 or nkt < 96:
         return 1
-    return max(1, min(8, 256 // tiles, nkt // 12))
+    # a multiple of the 3 taps: the splits of a tile that sit a whole tap apart walk the same channel blocks of the same source
+    # rows at the same time (all splits of a tile run on one XCD: grid x = tile), so the input is mostly read from HBM once
+    per_tap = (256 // tiles) // 3
+    per = nkt // 3
+    while per_tap > 1 and per % per_tap:
+        per_tap -= 1
+    return 3 * per_tap if per_tap >= 1 and per // per_tap >= 8 else 1
 
 
 def gemm_nt(descs, dtype):
