@@ -1061,8 +1061,12 @@ def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True, split_ga
     pr.xc = xc
     Wfc = prop_fc.weight
     pr.wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
-    if TOUCH_W and code == ops.BF16:
+    Nfc, Mfc = Wfc.shape[0], B * T
+    on_w4 = Mfc % 256 == 0 and Nfc % 256 == 0 and D % 64 == 0 and D >= 128 and (Mfc // 256) * (Nfc // 256) >= 200
+    if TOUCH_W and code == ops.BF16 and not on_w4:
         ops.touch(pr.wfc)                                  # 2.9 ms old and evicted: ~8 us here saves the GEMM ~29 us
+        # (not when the product runs on gemm_nt_w4_kernel, whose ring keeps 1.5 K-steps of loads in flight: 2.042 ms per step
+        # without the touch against 2.051 with it, three rounds in one process)
         # (doing the same for the other forward weight copies -- 20 MB in a handful of launches -- measured 10 us SLOWER)
     # main_model.py:51-55: [start, end, end-start] in fp64, then float(); only level 0 is consumed (backbone.py:31)
     if props_start_end.shape[-1] == 3:                     # already [start, end, end-start]
