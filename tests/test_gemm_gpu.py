@@ -716,3 +716,28 @@ def test_splitk256_refuses_what_it_cannot_do():
     assert b"not supported" in _lib.lib().drn_last_error()
     d = ops.gemm_desc(A, W, C, M, N, K)             # a plain product (taps = 1): not a problem of the conv kernel
     assert _lib.lib().drn_gemm_nt_splitk256((_lib.GemmDesc * 1)(d), 2, ctypes.c_void_p(ws.data_ptr()), ops.BF16, stream) != 0
+
+
+def test_w4c_conv_kernel_stress_many_launches_stay_bit_identical(monkeypatch):
+    """40 back-to-back launches on fresh data, forward and data gradient alternating, four sequences per tile (zero rows inside the
+    tiles, a tap switch every second K-step), statistics on: each compared with the general kernel on the same inputs."""
+    from drn_amd import ops
+    tune(monkeypatch, "exp0", 1)
+    B, L, N, Cin = 8, 64, 256, 128
+    M = B * L
+    g = torch.Generator(device="cuda").manual_seed(9)
+    bad = 0
+    for it in range(40):
+        mode = it & 1
+        A = torch.randn(M, Cin, generator=g, device=dev()).to(torch.bfloat16)
+        W = (torch.randn(N, 3 * Cin, generator=g, device=dev()) * 0.05).to(torch.bfloat16)
+        outs = []
+        for flag in (1, 0):
+            tune(monkeypatch, "nt_w4c", flag)
+            C = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+            st = torch.empty(M // 128, 2, N, device=dev()) if mode == 0 else None
+            ops.gemm_nt([ops.gemm_desc(A, W, C, M, N, Cin, taps=3, pad=1, mode=mode, Lout=L, Lsrc=L, stats=st)], ops.BF16)
+            outs.append((C, st))
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(outs[0][0], outs[1][0]) or (mode == 0 and not torch.equal(outs[0][1], outs[1][1])))
+    assert bad == 0, "%d of 40 launches differ" % bad
