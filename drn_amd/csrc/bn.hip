@@ -517,7 +517,11 @@ extern "C" int drn_bn_train_apply(const DrnBnTrainDesc* d, int n, int C, int rel
     // `up` = the output of another level of THIS launch (half the length, same clips): recomputed in place, no order needed
     G.chain_next = -1;
     for (int j = 0; j < n && s.up; ++j)
-      if (j != i && d[j].out == s.up && d[j].L * 2 == s.L && d[j].M * 2 == s.M) {
+      if (j != i && d[j].out == s.up) {
+        // a buffer this launch writes, read with nothing ordering the write before the read, unless it can be recomputed in place
+        DRN_CHECK_ARG(d[j].L * 2 == s.L && d[j].M * 2 == s.M,
+                      "%s: level %d adds the output of level %d of the same launch, whose geometry (M=%d L=%d) is not half of its own "
+                      "(M=%d L=%d): launch the levels in order", who, i, j, d[j].M, d[j].L, s.M, s.L);
         G.chain_next = j;
         G.up = nullptr;
       }

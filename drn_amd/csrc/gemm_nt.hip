@@ -6,8 +6,17 @@ int drn_nt_w4_launch(const GemmParams& P, int total, hipStream_t stream);
 bool drn_nt_w4c_eligible(const DrnGemmDesc* d, int ngroups, int dtype);
 int drn_nt_w4c_launch(const GemmParams& P, int total, hipStream_t stream, int ksplit);
 
+// Which kernel a launch runs on, given the tile size launch_nt chose (drn_gemm_nt_plan reports it to callers that schedule
+// around a launch -- functional.input_prep's weight pre-touch -- instead of re-deriving the rule on their side).
+static int nt_kind(const DrnGemmDesc* d, int ngroups, int dtype, int tile, int ksplit, bool planes256) {
+  if (tile == 256 && ksplit == 1 && drn_tuning(DRN_TUNE_NT_W4) > 0 && drn_nt_w4_eligible(d, ngroups, dtype)) return DRN_NT_KIND_W4;
+  if (tile == 256 && (planes256 || (ksplit == 1 && drn_tuning(DRN_TUNE_NT_W4C) > 0)) && drn_nt_w4c_eligible(d, ngroups, dtype))
+    return DRN_NT_KIND_W4C;
+  return tile == 256 ? DRN_NT_KIND_TILE256 : DRN_NT_KIND_TILE128;
+}
+
 static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr,
-                     int* counters = nullptr, bool planes256 = false) {
+                     int* counters = nullptr, bool planes256 = false, bool plan_only = false) {
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_nt: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_nt: bad dtype %d", dtype);
   const int ch = dtype == DRN_BF16 ? 8 : 4;
@@ -87,11 +96,13 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     P.nblocks = total; \
     if (fast) conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); \
     else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
-  if (tile == 256 && ksplit == 1 && drn_tuning(DRN_TUNE_NT_W4) > 0 && drn_nt_w4_eligible(d, ngroups, dtype)) {
+  const int kind = nt_kind(d, ngroups, dtype, tile, ksplit, planes256);
+  if (plan_only) return kind;
+  if (kind == DRN_NT_KIND_W4) {
     P.nblocks = total;
     return drn_nt_w4_launch(P, total, stream);
   }
-  if (tile == 256 && (planes256 || (ksplit == 1 && drn_tuning(DRN_TUNE_NT_W4C) > 0)) && drn_nt_w4c_eligible(d, ngroups, dtype)) {
+  if (kind == DRN_NT_KIND_W4C) {
     P.nblocks = total;
     return drn_nt_w4c_launch(P, total, stream, ksplit);
   }
@@ -118,6 +129,11 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   }
 #undef NT_LAUNCH
   return drn_launch_status("drn_gemm_nt");
+}
+
+extern "C" int drn_gemm_nt_plan(const DrnGemmDesc* descs, int ngroups, int dtype) {
+  drn_clear_status();
+  return launch_nt(descs, ngroups, dtype, nullptr, 1, nullptr, nullptr, false, true);
 }
 
 extern "C" int drn_gemm_nt(const DrnGemmDesc* descs, int ngroups, int dtype, void* stream) {

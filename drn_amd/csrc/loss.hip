@@ -396,3 +396,74 @@ extern "C" int drn_focal_bwd(const float* logits, const int32_t* targets, const 
   focal_bwd_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(logits, targets, d_losses, total, num_classes, gamma, alpha, d_logits);
   return drn_launch_status("drn_focal_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stand-alone IOULoss (model/layers/iou_loss.py:5-24; the module the reference exports from model.layers next to the focal loss):
+// per row i of pred / target (N, 2) = (left, right) distances,
+//   inter = min(pr, tr) + min(pl, tl), union = (tl + tr) + (pl + pr) - inter, l_i = -log((inter + 1e-8) / (union + 1e-8));
+//   weight given and sum(weight) > 0: sum(l_i w_i) / sum(w), else mean(l_i).
+// One workgroup, fixed summation order (deterministic); the decision "weighted or not" stays on the device: out2 = {loss, the
+// divisor used WITH its sign as the mode flag (> 0: sum of weights, < 0: -(N) = plain mean)}; backward reads it there.
+// Gradients flow to pred and target (ties in min split evenly: torch's elementwise rule); the weight is treated as a constant.
+__global__ __launch_bounds__(LOSS_THREADS) void iou_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                                    const float* __restrict__ weight, long N, float* __restrict__ out2) {
+  __shared__ float sh[5 * 17];
+  float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};       // sum l, sum l*w, sum w
+  for (long i = threadIdx.x; i < N; i += LOSS_THREADS) {
+    const float pl = pred[2 * i], pr = pred[2 * i + 1], tl = target[2 * i], tr = target[2 * i + 1];
+    const float inter = fminf(pr, tr) + fminf(pl, tl);
+    const float uni = (tl + tr) + (pl + pr) - inter;
+    const float l = -logf((inter + 1e-8f) / (uni + 1e-8f));
+    const float w = weight ? weight[i] : 0.f;
+    v[0] += l;
+    v[1] += l * w;
+    v[2] += w;
+  }
+  block_sum5(v, sh);
+  if (threadIdx.x == 0) {
+    const bool weighted = weight != nullptr && v[2] > 0.f;
+    out2[0] = weighted ? v[1] / v[2] : v[0] / (float)N;
+    out2[1] = weighted ? v[2] : -(float)N;
+  }
+}
+
+__global__ __launch_bounds__(256) void iou_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           const float* __restrict__ weight, long N, const float* __restrict__ out2,
+                                                           const float* __restrict__ gout, float* __restrict__ dpred,
+                                                           float* __restrict__ dtarget) {
+  const float div = out2[1], g = gout ? gout[0] : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const float pl = pred[2 * i], pr = pred[2 * i + 1], tl = target[2 * i], tr = target[2 * i + 1];
+    const float inter = fminf(pr, tr) + fminf(pl, tl);
+    const float uni = (tl + tr) + (pl + pr) - inter;
+    const float coef = g * (div > 0.f ? weight[i] / div : 1.f / -div);
+    // l = -log(inter + eps) + log(union + eps)
+    const float di = coef * (-1.f / (inter + 1e-8f) - 1.f / (uni + 1e-8f)), du = coef / (uni + 1e-8f);
+    const float ml_p = pl < tl ? 1.f : (pl == tl ? 0.5f : 0.f), mr_p = pr < tr ? 1.f : (pr == tr ? 0.5f : 0.f);
+    if (dpred) {
+      dpred[2 * i] = di * ml_p + du;
+      dpred[2 * i + 1] = di * mr_p + du;
+    }
+    if (dtarget) {
+      dtarget[2 * i] = di * (1.f - ml_p) + du;
+      dtarget[2 * i + 1] = di * (1.f - mr_p) + du;
+    }
+  }
+}
+
+extern "C" int drn_iou_loss_fwd(const float* pred, const float* target, const float* weight, int64_t N, float* out2, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(N > 0, "drn_iou_loss_fwd: no rows (the reference asserts losses.numel() != 0, iou_loss.py:23)");
+  DRN_CHECK_ARG(pred && target && out2, "drn_iou_loss_fwd: null pointer");
+  iou_loss_fwd_kernel<<<1, LOSS_THREADS, 0, (hipStream_t)stream>>>(pred, target, weight, (long)N, out2);
+  return drn_launch_status("drn_iou_loss_fwd");
+}
+
+extern "C" int drn_iou_loss_bwd(const float* pred, const float* target, const float* weight, int64_t N, const float* out2,
+                                const float* gout, float* dpred, float* dtarget, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(N > 0 && pred && target && out2 && (dpred || dtarget), "drn_iou_loss_bwd: bad args");
+  const int nblk = (int)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024);
+  iou_loss_bwd_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(pred, target, weight, (long)N, out2, gout, dpred, dtarget);
+  return drn_launch_status("drn_iou_loss_bwd");
+}

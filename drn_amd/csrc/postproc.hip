@@ -125,7 +125,8 @@ extern "C" int drn_postprocess(const DrnLossLevel* levels, int nlevels, int B, c
 // over (score, index), tested against the ground truth, and everything it suppresses is struck out.  All arithmetic in
 // double on the float32 detections, exactly the numbers the host path sees after .tolist().
 // out[b][q] = position of the first survivor that hits (0-based), or K when none of the first K does.
-#define ER_MAX_CAND 4096
+// every level table drn_postprocess accepts fits: DRN_MAX_GROUPS levels of at most PP_MAX_L locations
+#define ER_MAX_CAND (DRN_MAX_GROUPS * PP_MAX_L)
 __global__ __launch_bounds__(64) void eval_recall_kernel(const float* __restrict__ det, const float* __restrict__ scores,
                                                          const int* __restrict__ counts, int nlevels, int rows_per_clip,
                                                          const void* __restrict__ gt, int gt_f64, const double* __restrict__ ious,

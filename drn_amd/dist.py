@@ -39,6 +39,50 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def _initialized(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def broadcast_tensors(tensors, src=0, group=None):
+    """In-place broadcast of `tensors` from rank `src`: one flat message per dtype (few, large messages: xGMI links are
+    point-to-point), copied back into the tensors' own storage."""
+    if not _initialized(group):
+        return 0
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    n = 0
+    with torch.no_grad():
+        for dt, ts in by_dtype.items():
+            flat = torch._utils._flatten_dense_tensors([t.detach().contiguous() for t in ts])
+            dist.broadcast(flat, src=src, group=group)
+            for t, r in zip(ts, torch._utils._unflatten_dense_tensors(flat, ts)):
+                t.detach().copy_(r)
+            n += flat.numel()
+    return n
+
+
+def sync_model_state(model, src=0, group=None, buffers_only=False):
+    """Make every rank hold rank `src`'s replica: parameters AND buffers (BatchNorm running statistics / step counters).  The
+    reference's nn.DataParallel (main.py:99) broadcasts the one model's parameters and buffers to its replicas every forward;
+    one process per GPU has to do it explicitly -- once at start-up (ranks may have initialised / resumed differently) and, for
+    the buffers, before every sharded evaluation (per-rank BatchNorm running statistics drift apart during training: each rank
+    normalises its own shard, exactly like DataParallel's replicas, whose statistics are thrown away except replica 0's).
+    The re-laid GEMM copies of the parameters are invalidated when parameters were overwritten."""
+    if not _initialized(group):
+        return 0
+    DF.flush_bn_counters()
+    ts = [] if buffers_only else [p for p in model.parameters()]
+    ts += [b for b in model.buffers()]
+    n = broadcast_tensors(ts, src=src, group=group)
+    if not buffers_only:
+        stores = set()
+        for p in model.parameters():
+            stores.add(DF.store_of(p))
+        DF.bump_weights_epoch(list(stores))
+    return n
+
+
 class _Bucket(object):
     __slots__ = ("flat", "params", "offsets", "views", "pending", "handle", "launched")
 
@@ -80,9 +124,13 @@ class GradReducer(object):
             grp = [p for p in grp if id(p) in wanted]
             # back to back only when no 4-element alignment padding falls between them; one-element parameters are kept
             # together too (equal 4-element spacing: functional.grad_buffer hands out a strided view)
-            if len(grp) > 1 and (all(p.numel() % 4 == 0 for p in grp[:-1]) or all(p.numel() == 1 for p in grp)):
+            if len(grp) > 1 and (all(self._packs_tight(p, q) for p, q in zip(grp, grp[1:])) or all(p.numel() == 1 for p in grp)):
                 for p in grp:
                     adj_of[id(p)] = grp
+            elif len(grp) > 1:
+                import warnings
+                warnings.warn("GradReducer: adjacent group of sizes %s cannot lie back to back (alignment padding between its "
+                              "members); its stacked gradient takes the copy path" % [p.numel() for p in grp])
         for part in plan:
             first = len(self.buckets)
             cur, cur_bytes = [], 0
@@ -103,6 +151,15 @@ class GradReducer(object):
                 self._make_bucket(cur)
             self.group_buckets.append(self.buckets[first:])
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    @staticmethod
+    def _packs_tight(p, q):
+        """No alignment padding falls between `p` and `q` placed right behind it (see _offsets): a successor of >= 1024 elements
+        starts on a 32-element boundary, so `p` must start on one too (>= 1024 elements itself) and be a multiple of 32 long; a
+        smaller successor only needs `p` to be a multiple of 4 long."""
+        if q.numel() >= 1024:
+            return p.numel() >= 1024 and p.numel() % 32 == 0
+        return p.numel() % 4 == 0
 
     @staticmethod
     def _offsets(params):

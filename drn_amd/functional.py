@@ -925,7 +925,8 @@ class _MultiConvFn(torch.autograd.Function):
                 for grp in ([fin] if same_c else [[f] for f in fin]):
                     ops.bn_finalize_multi(grp, grp[0]["ss"].shape[1])
             apply = ops.bn_train_apply if fused else ops.bn_apply_multi
-            if chain_up and fused and same_c and n <= 3 and all(g[2] % 4 == 0 for g in geo[:max(n - 2, 0)]):
+            halves = all(geo[l][2] == 2 * geo[l + 1][2] and geo[l][0] == geo[l + 1][0] for l in range(n - 1))
+            if chain_up and fused and same_c and n <= 3 and halves and all(g[2] % 4 == 0 for g in geo[:max(n - 2, 0)]):
                 # the whole top-down chain in ONE launch: a level whose `up` is another level's output of the same launch
                 # recomputes the rows it adds from that level's raw rows and statistics (drn_bn_train_apply) -- same bits as
                 # the coarse-to-fine order, two launches fewer
@@ -1061,9 +1062,7 @@ def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True, split_ga
     pr.xc = xc
     Wfc = prop_fc.weight
     pr.wfc = Wfc.detach() if code == ops.F32 else packed(Wfc, (0, 2, 1), code)
-    Nfc, Mfc = Wfc.shape[0], B * T
-    on_w4 = Mfc % 256 == 0 and Nfc % 256 == 0 and D % 64 == 0 and D >= 128 and (Mfc // 256) * (Nfc // 256) >= 200
-    if TOUCH_W and code == ops.BF16 and not on_w4:
+    if TOUCH_W and code == ops.BF16 and _fc_kernel_kind(B, T, D, Wfc.shape[0], xc, pr.wfc, code, split_gate) != ops.NT_KIND_W4:
         ops.touch(pr.wfc)                                  # 2.9 ms old and evicted: ~8 us here saves the GEMM ~29 us
         # (not when the product runs on gemm_nt_w4_kernel, whose ring keeps 1.5 K-steps of loads in flight: 2.042 ms per step
         # without the touch against 2.051 with it, three rounds in one process)
@@ -1082,6 +1081,16 @@ def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True, split_ga
         pr.Z = torch.empty((B, T, D), dtype=dtype, device=xc.device)
         ops.gemm_nt([ops.gemm_desc(pr.xc, pr.wfc, pr.Z, B * T, D, D, Lout=T, ldc=D, bias=prop_fc.bias.detach())], code)
     return pr
+
+
+def _fc_kernel_kind(B, T, D, N, xc, wfc, code, split_gate):
+    """Which kernel the prop_fc product of the input stage will run on, asked of the library (drn_gemm_nt_plan) with a descriptor
+    of the launch's shape and alignment class -- the rule (tile threshold, drn_tune switches, stride / alignment conditions)
+    lives in gemm_nt.hip only.  No launch, one ctypes call."""
+    P = 0 if split_gate else 256
+    # (the output / pre-gate copy are allocated later: any 16-byte aligned address with the real row strides stands in)
+    d = ops.gemm_desc(xc, wfc, xc, B * T, N, D, Lout=T, ldc=D + P, C2=None if split_gate else xc, ldc2=D)
+    return ops.gemm_nt_plan([d], code)
 
 
 class EmbedTail(object):
@@ -1601,7 +1610,7 @@ class _LGPFn(torch.autograd.Function):
     both run as the small exact-fp32 GEMM + BN kernels; the pooling itself is drn_lgp_fwd/bwd on the (B, t, C) tensor."""
 
     @staticmethod
-    def forward(ctx, dtype, bn, training, x, query, weight, gamma, beta):
+    def forward(ctx, dtype, bn, training, x, query, weight, gamma, beta, cbias=None):
         code = code_of(dtype)
         B, t, C, ldx = geom(x)
         Cq = weight.shape[1]
@@ -1619,18 +1628,20 @@ class _LGPFn(torch.autograd.Function):
                 n = B * t
                 with torch.no_grad():        # (C,)-sized buffer updates: n = B*t samples for the unbiased variance
                     var = 1.0 / (save[1] * save[1]) - bn.eps
-                    bn.running_mean.mul_(1 - bn.momentum).add_(save[0], alpha=bn.momentum)
+                    # (use_bn=False: the biased conv's bias cancels in the normalised value and only shifts the batch mean)
+                    bn.running_mean.mul_(1 - bn.momentum).add_(save[0] if cbias is None else save[0] + cbias.detach(), alpha=bn.momentum)
                     bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
                     bump_bn_counter(bn.num_batches_tracked, 1)
                 flush_bn_counters()
         else:
-            ops.bn_eval_scale_shift(C, gamma, beta, None, bn.running_mean, bn.running_var, bn.eps, ss)
+            ops.bn_eval_scale_shift(C, gamma, beta, cbias.detach() if cbias is not None else None, bn.running_mean, bn.running_var, bn.eps, ss)
         qn = torch.empty((B, C), dtype=torch.float32, device=dev)
         ops.bn_apply(raw, C, ss, qn, C, B, C, 1, ops.F32, relu=False)
         out = torch.empty((B, t // 2, C), dtype=dtype, device=dev)
         att = torch.empty((B, t // 2, 2), dtype=torch.float32, device=dev)
         ops.lgp_fwd(x, ldx, qn, out, att, B, t, C, code)
         ctx.dtype, ctx.dims, ctx.training = dtype, (B, t, C, Cq, ldx), training
+        ctx.has_cbias = cbias is not None
         ctx.save_for_backward(x, q, weight, gamma, raw, ss, save, qn, att)
         return out
 
@@ -1656,8 +1667,10 @@ class _LGPFn(torch.autograd.Function):
         wt = ops.pack_weight(weight.detach().reshape(C, Cq, 1), (1, 2, 0), ops.F32).view(Cq, C)
         dq = torch.empty((B, Cq), dtype=torch.float32, device=dev)
         ops.gemm_nt([ops.gemm_desc(draw, wt, dq, B, Cq, C, Lout=1, Lsrc=1)], ops.F32)
-        return None, None, None, dx, dq, dW, dgamma, dbeta
+        # a conv bias in front of a train-mode BatchNorm cancels: its gradient is exactly zero (the reference's is 1e-8 noise)
+        dcb = torch.zeros(C, dtype=torch.float32, device=dev) if ctx.has_cbias else None
+        return None, None, None, dx, dq, dW, dgamma, dbeta, dcb
 
 
 def lgp(x, query, conv, bn, training, dtype):
-    return _LGPFn.apply(dtype, bn, training, x, query, conv.weight, bn.weight, bn.bias)
+    return _LGPFn.apply(dtype, bn, training, x, query, conv.weight, bn.weight, bn.bias, conv.bias)

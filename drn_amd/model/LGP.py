@@ -10,9 +10,8 @@ class LGP(nn.Module):
 
     def __init__(self, input_dim=1024, query_dim=1024, use_bn=True):
         super(LGP, self).__init__()
-        if not use_bn:
-            raise NotImplementedError("LGP without BN is not used by DRN")
-        conv = nn.Conv1d(query_dim, input_dim, kernel_size=1, stride=1, padding=0, dilation=1, bias=False)
+        # model/LGP.py:11-25: use_bn only decides whether the 1x1 conv carries a bias; the BatchNorm is appended either way
+        conv = nn.Conv1d(query_dim, input_dim, kernel_size=1, stride=1, padding=0, dilation=1, bias=not use_bn)
         nn.init.kaiming_uniform_(conv.weight, a=1)
         self.query_fc = nn.Sequential(conv, nn.BatchNorm1d(input_dim))
 

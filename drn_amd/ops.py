@@ -117,6 +117,18 @@ def _ksplit256(descs, dtype):
     return 3 * per_tap if per_tap >= 1 and per // per_tap >= 8 else 1
 
 
+NT_KIND_TILE128, NT_KIND_TILE256, NT_KIND_W4, NT_KIND_W4C = 0, 1, 2, 3
+
+
+def gemm_nt_plan(descs, dtype):
+    """The kernel drn_gemm_nt would pick for these problems (NT_KIND_*), asked of the library itself (drn_gemm_nt_plan)."""
+    arr = (GemmDesc * len(descs))(*descs)
+    kind = lib().drn_gemm_nt_plan(arr, len(descs), dtype)
+    if kind < 0:
+        check(kind, "drn_gemm_nt_plan")
+    return kind
+
+
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
@@ -659,6 +671,24 @@ def focal_bwd(logits, targets, d_losses, gamma, alpha):
     check(lib().drn_focal_bwd(_p(logits), _p(targets), _p(d_losses), ctypes.c_int64(logits.shape[0]), logits.shape[1],
                               ctypes.c_float(gamma), ctypes.c_float(alpha), _p(out), _stream()), "drn_focal_bwd")
     return out
+
+
+def iou_loss_fwd(pred, target, weight=None):
+    """out2 = (loss, signed divisor) of the stand-alone IOULoss (drn_iou_loss_fwd; model/layers/iou_loss.py:6-24)."""
+    _need_gpu(pred, target, weight)
+    assert pred.dtype == torch.float32 and pred.is_contiguous() and pred.dim() == 2 and pred.shape[1] == 2 and target.shape == pred.shape
+    assert weight is None or (weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() == pred.shape[0])
+    out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+    check(lib().drn_iou_loss_fwd(_p(pred), _p(target), _p(weight), ctypes.c_int64(pred.shape[0]), _p(out2), _stream()), "drn_iou_loss_fwd")
+    return out2
+
+
+def iou_loss_bwd(pred, target, weight, out2, gout, want_pred=True, want_target=False):
+    dpred = torch.empty_like(pred) if want_pred else None
+    dtarget = torch.empty_like(target) if want_target else None
+    check(lib().drn_iou_loss_bwd(_p(pred), _p(target), _p(weight), ctypes.c_int64(pred.shape[0]), _p(out2), _p(gout), _p(dpred),
+                                 _p(dtarget), _stream()), "drn_iou_loss_bwd")
+    return dpred, dtarget
 
 
 # ---------------------------------------------------------------------------------------------

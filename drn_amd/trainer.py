@@ -105,6 +105,12 @@ class Trainer(object):
         self.model, self.stage, self.clip = model, stage, clip_gradient
         self.params, self.lr, self.default_epochs, self.which = stage_plan(model, stage, lr)
         self.device = next(model.parameters()).device
+        if world_size > 1:
+            # one process per GPU: every rank must start from rank 0's replica (parameters and BatchNorm buffers) -- what
+            # nn.DataParallel's per-forward broadcast guarantees in the reference (main.py:99).  Ranks that built / resumed their
+            # model differently would otherwise train `world` different models on averaged gradients.
+            from .dist import sync_model_state
+            sync_model_state(model, src=0)
         self.fused = fused and stage != 2 and self.device.type == "cuda"
         self.world_size = world_size
         self.graph = bool(graph) and self.fused
@@ -371,10 +377,21 @@ class Trainer(object):
         drn_amd.data.ShardSampler) and the ranks' counts (or records) are merged with all_gather_object, so all ranks return
         the same numbers (`group`: the process group, default world; a single process skips the exchange)."""
         self.model.eval()
+        import torch.distributed as td
+        multi = td.is_available() and td.is_initialized() and td.get_world_size(group) > 1
+        if multi:
+            # every rank scores its shard with ITS replica: the parameters are equal by construction (same start, same averaged
+            # gradients), the BatchNorm running statistics are not (per-rank batches) -- take rank 0's, the replica whose
+            # state_dict fit() saves under the merged metric (nn.DataParallel keeps replica 0's buffers, main.py:99)
+            from .dist import sync_model_state
+            sync_model_state(self.model, src=0, group=group, buffers_only=True)
         iou_topk = iou_topk or {"iou": [0.5], "topk": [1, 5]}                            # main.py:362
         results, total, n, hits = {}, None, 0, []
         selector = getattr(getattr(self.model, "fcos", None), "box_selector_test", None)
         fast = (not with_results) and selector is not None and self.device.type == "cuda"
+        # (decided ONCE, from static facts, so every rank takes the same branch of the merge below; drn_eval_recall serves every
+        # level table drn_postprocess accepts, so the fast path has no per-batch fallback to disagree about)
+        fast0 = fast
         ious_dev = torch.tensor([float(x) for x in iou_topk["iou"]], dtype=torch.float64, device=self.device) if fast else None
         if fast:
             selector.device_only = True
@@ -394,6 +411,8 @@ class Trainer(object):
                     hits.append(ops.eval_recall(boxes.det, boxes.scores, boxes.counts, args[4].contiguous(), ious_dev,
                                                 max(iou_topk["topk"])))
                     continue
+                if fast:
+                    raise RuntimeError("Trainer.evaluate: the post-processor returned host records in device-only mode")
                 tokens, qlen, gts = host_tok.cpu(), host_qlen.cpu(), host_gt.cpu().numpy()
                 queries = [" ".join(id2word[int(t)] if id2word else str(int(t)) for t in tokens[i, :int(qlen[i])]) for i in range(bs)]
                 for name, entry in zip(names, results_entries(queries, gts, boxes)):
@@ -402,19 +421,20 @@ class Trainer(object):
             if fast:
                 selector.device_only = False
         total = float(total) if total is not None else 0.0
-        import torch.distributed as td
-        multi = td.is_available() and td.is_initialized() and td.get_world_size(group) > 1
-        if hits or (fast and not results):
+        if fast0:                                          # (the branch every rank decided on before its first batch)
             fh = torch.cat(hits).cpu().numpy() if hits else np.zeros((0, len(iou_topk["iou"])), dtype=np.int32)
             if multi:
                 parts = [None] * td.get_world_size(group)
-                td.all_gather_object(parts, (fh, total, n), group=group)
-                fh = np.concatenate([p[0] for p in parts])
-                total, n = sum(p[1] for p in parts), sum(p[2] for p in parts)
+                td.all_gather_object(parts, ("hits", fh, total, n), group=group)
+                assert all(p[0] == "hits" for p in parts), "ranks disagree on the evaluation path"
+                fh = np.concatenate([p[1] for p in parts])
+                total, n = sum(p[2] for p in parts), sum(p[3] for p in parts)
             return total / max(n, 1), iou_topk["topk"], recall_from_first_hits(fh, iou_topk["iou"], iou_topk["topk"]), None
         if multi:
             parts = [None] * td.get_world_size(group)
-            td.all_gather_object(parts, (results, total, n), group=group)
+            td.all_gather_object(parts, ("records", results, total, n), group=group)
+            assert all(p[0] == "records" for p in parts), "ranks disagree on the evaluation path"
+            parts = [p[1:] for p in parts]
             results = {}
             for part, _, _ in parts:                                   # rank order: deterministic, and the metric does not depend on it
                 for vid, items in part.items():

@@ -69,6 +69,14 @@ typedef struct DrnGemmDesc {
  * Replaces nn.Linear (model/main_model.py:59), nn.Conv1d (model/basic_blocks.py:9,
  * model/fcos.py:33,37,59,65) forward and their input gradients. */
 int drn_gemm_nt(const DrnGemmDesc* descs /*host*/, int ngroups, int dtype, void* stream);
+/* Which kernel drn_gemm_nt would run these problems on (no launch; arguments validated the same way): >= 0 one of the kinds
+ * below, < 0 an error code.  For callers that schedule around a launch (functional.input_prep pre-touches the prop_fc weight
+ * only when the general kernel runs) instead of re-deriving the library's rule. */
+#define DRN_NT_KIND_TILE128 0  /* conv_gemm_nt_kernel, 128x128 tiles */
+#define DRN_NT_KIND_TILE256 1  /* conv_gemm_nt_kernel, 256x256 tiles */
+#define DRN_NT_KIND_W4 2       /* gemm_nt_w4_kernel: large plain bf16 products, 4 waves, 5-slot ring */
+#define DRN_NT_KIND_W4C 3      /* gemm_nt_w4c_kernel: the same loop for k = 3 / stride 1 convolutions */
+int drn_gemm_nt_plan(const DrnGemmDesc* descs /*host*/, int ngroups, int dtype);
 /* Same for ONE problem with the K loop split `ksplit` ways (few output tiles: conv0, the coarse pyramid levels), in ONE
  * launch: every split publishes its fp32 partial tile in ws (drn_gemm_nt_splitk_ws_elems floats, 16-byte aligned), the
  * split that arrives last at a tile adds them in split order (deterministic) and runs the epilogue.  counters: >= one int32
@@ -356,6 +364,15 @@ int drn_focal_fwd(const float* logits, const int32_t* targets, int64_t N, int nu
                   void* stream);
 int drn_focal_bwd(const float* logits, const int32_t* targets, const float* d_losses, int64_t N, int num_classes, float gamma,
                   float alpha, float* d_logits, void* stream);
+
+/* Stand-alone IOULoss (model/layers/iou_loss.py:5-24, exported by model/layers/__init__.py): pred / target fp32 [N][2] =
+ * (left, right) distances, weight fp32 [N] or NULL.  out2[0] = sum(l_i w_i) / sum(w) when weight != NULL and sum(w) > 0, else
+ * mean(l_i), l_i = -log((min(pr,tr) + min(pl,tl) + 1e-8) / (union + 1e-8)); out2[1] = the divisor, negative for the plain mean
+ * (backward reads the mode there: no host sync).  N == 0 is an error (the reference asserts).  Backward: gout = upstream
+ * gradient (1 float, NULL = 1); dpred / dtarget [N][2], either may be NULL; ties in min() split evenly. */
+int drn_iou_loss_fwd(const float* pred, const float* target, const float* weight, int64_t N, float* out2, void* stream);
+int drn_iou_loss_bwd(const float* pred, const float* target, const float* weight, int64_t N, const float* out2, const float* gout,
+                     float* dpred, float* dtarget, void* stream);
 
 /* ---- eval post-processor (drn_amd/csrc/postproc.hip; model/inference.py:51-120,166-199) ------------------------
  * Per clip and level: candidates sigmoid(logit) > thr, score = sigmoid(logit)[*sigmoid(iou)] (iou NULL in the first stage),

@@ -209,6 +209,17 @@ def iou_loss_mean(pred, target):
     return (-torch.log((inter + 1e-8) / (union + 1e-8))).mean()
 
 
+def iou_loss(pred, target, weight=None):
+    """model/layers/iou_loss.py:6-24, the `weight` branch included (the module model/layers/__init__.py exports)."""
+    inter = torch.min(pred[:, 1], target[:, 1]) + torch.min(pred[:, 0], target[:, 0])
+    union = (target[:, 0] + target[:, 1]) + (pred[:, 0] + pred[:, 1]) - inter
+    losses = -torch.log((inter + 1e-8) / (union + 1e-8))
+    if weight is not None and weight.sum() > 0:
+        return (losses * weight).sum() / weight.sum()
+    assert losses.numel() != 0
+    return losses.mean()
+
+
 def segment_tiou(a, b):
     """model/loss.py:241-256."""
     inter = torch.clamp(torch.min(a[..., 1], b[..., 1]) - torch.max(a[..., 0], b[..., 0]), min=0)
@@ -364,9 +375,9 @@ def build_fcos(cfg, in_channels):
 class LGP(nn.Module):
     """model/LGP.py:3-51 (dead in the reference; standalone op)."""
 
-    def __init__(self, input_dim=1024, query_dim=1024):
+    def __init__(self, input_dim=1024, query_dim=1024, use_bn=True):
         super().__init__()
-        conv = nn.Conv1d(query_dim, input_dim, 1, bias=False)
+        conv = nn.Conv1d(query_dim, input_dim, 1, bias=not use_bn)       # LGP.py:18 (the BatchNorm is appended either way, :25)
         nn.init.kaiming_uniform_(conv.weight, a=1)
         self.query_fc = nn.Sequential(conv, nn.BatchNorm1d(input_dim))
 

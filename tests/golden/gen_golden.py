@@ -177,6 +177,52 @@ def run_lgp():
     print("lgp", float(y.abs().sum()))
 
 
+def run_layers():
+    """model/layers/iou_loss.py:5-24 (IOULoss, all three branches of its return) and model/LGP.py with use_bn=False (biased 1x1
+    conv, BatchNorm still appended) -> layers.npz."""
+    from model.layers.iou_loss import IOULoss
+    from model.LGP import LGP
+    g = np.random.default_rng(21)
+    out = {}
+    N = 37
+    pred = torch.from_numpy(g.uniform(0.2, 9.0, (N, 2)).astype(np.float32))
+    target = torch.from_numpy(g.uniform(0.2, 9.0, (N, 2)).astype(np.float32))
+    weights = {"none": None, "pos": torch.from_numpy(g.uniform(0.0, 1.0, (N,)).astype(np.float32)),
+               "zero": torch.zeros(N)}
+    out["iou/pred"], out["iou/target"], out["iou/weight_pos"] = pred.numpy(), target.numpy(), weights["pos"].numpy()
+    for tag, w in weights.items():
+        p, t = pred.clone().requires_grad_(), target.clone().requires_grad_()
+        loss = IOULoss()(p, t, w)
+        (loss * 1.7).backward()
+        out["iou/%s/loss" % tag] = loss.detach().numpy().reshape(1)
+        out["iou/%s/dpred" % tag], out["iou/%s/dtarget" % tag] = p.grad.numpy(), t.grad.numpy()
+    B, C, t = 4, 64, 16
+    for mode in ("train", "eval"):
+        net = LGP(input_dim=C, query_dim=C, use_bn=False)
+        net.load_state_dict(seeded_state_dict(net, seed=4))
+        with torch.no_grad():                                  # a bias and running statistics that matter
+            net.query_fc[0].bias.copy_(torch.from_numpy(g.standard_normal(C).astype(np.float32)))
+            net.query_fc[1].running_mean.copy_(torch.from_numpy(g.standard_normal(C).astype(np.float32) * 0.3))
+            net.query_fc[1].running_var.copy_(torch.from_numpy(g.uniform(0.5, 2.0, C).astype(np.float32)))
+        out["lgp_nobn/%s/bias" % mode] = net.query_fc[0].bias.detach().numpy().copy()
+        out["lgp_nobn/%s/rm0" % mode] = net.query_fc[1].running_mean.numpy().copy()
+        out["lgp_nobn/%s/rv0" % mode] = net.query_fc[1].running_var.numpy().copy()
+        net.train(mode == "train")
+        x = torch.from_numpy(g.standard_normal((B, C, t)).astype(np.float32)).requires_grad_()
+        q = torch.from_numpy(g.standard_normal((B, C)).astype(np.float32)).requires_grad_()
+        y = net(x, q)
+        w = torch.from_numpy(g.standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * w).sum().backward()
+        pre = "lgp_nobn/%s/" % mode
+        out[pre + "x"], out[pre + "q"], out[pre + "w"], out[pre + "y"] = x.detach().numpy(), q.detach().numpy(), w.numpy(), y.detach().numpy()
+        out[pre + "dx"], out[pre + "dq"] = x.grad.numpy(), q.grad.numpy()
+        out[pre + "dw"], out[pre + "dbias"] = net.query_fc[0].weight.grad.numpy(), net.query_fc[0].bias.grad.numpy()
+        out[pre + "dgamma"], out[pre + "dbeta"] = net.query_fc[1].weight.grad.numpy(), net.query_fc[1].bias.grad.numpy()
+        out[pre + "rm"], out[pre + "rv"] = net.query_fc[1].running_mean.numpy().copy(), net.query_fc[1].running_var.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "layers.npz"), **out)
+    print("layers", {k: float(out[k][0]) for k in out if k.endswith("/loss")})
+
+
 def run_metrics():
     """utils/evaluate_utils.py:13-16,91-215,328-354 (PostProcessRunner.run_evaluate, the R@k / IoU metric of main.py:362-364)
     on a synthetic raw-results dict in main.py:324-348's format.  cwd must be the reference root while the
@@ -368,6 +414,9 @@ def run_keys():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     install_shims()
+    if sys.argv[1:] == ["layers"]:
+        run_layers()
+        sys.exit(0)
     if sys.argv[1:] == ["metrics"]:
         run_metrics()
         sys.exit(0)
@@ -388,6 +437,7 @@ if __name__ == "__main__":
     run_case("c3d_s1", 2, 64, 4096, 1)
     run_case("c3d_s3", 2, 64, 4096, 3, match=True)
     run_lgp()
+    run_layers()
     run_metrics()
     run_dataset()
     for st in (1, 2, 3):

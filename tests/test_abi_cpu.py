@@ -56,3 +56,21 @@ def test_state_dict_keys_match_reference():
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
     m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("C3D", 4096, 1)))
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref
+
+
+def test_generated_w4_loop_is_what_the_generator_emits(tmp_path):
+    """drn_amd/csrc/gemm_nt_w4_loop.inc (the hand-scheduled main loop of gemm_nt_w4_kernel / gemm_nt_w4c_kernel, 2 k lines of one
+    asm statement) is a GENERATED file: the committed copy must be exactly what scripts/gen_w4_loop.py writes today."""
+    import subprocess
+    import sys
+    out = tmp_path / "loop.inc"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "gen_w4_loop.py"), "--out", str(out)])
+    want = open(os.path.join(ROOT, "drn_amd", "csrc", "gemm_nt_w4_loop.inc")).read()
+    assert out.read_text() == want, "gemm_nt_w4_loop.inc is stale: run python scripts/gen_w4_loop.py"
+
+
+def test_iou_loss_module_is_exported_and_has_no_cpu_fallback():
+    from drn_amd import _lib
+    from drn_amd.model.layers import IOULoss, SigmoidFocalLoss      # noqa: F401  (what model/layers/__init__.py exports on this path)
+    with pytest.raises(_lib.DrnError):
+        IOULoss()(torch.ones(3, 2), torch.ones(3, 2))

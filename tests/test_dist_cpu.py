@@ -262,7 +262,7 @@ def test_fit_train_only_runs_the_same_epochs_and_sets_sampler_epoch():
 # ---------------------------------------------------------------------------------------------------------------------
 # Sharded evaluation (main.py:275-366 on one process): every rank scores its ShardSampler share of the test
 # queries, the ranks merge with all_gather_object, all ranks return the single-process numbers.
-def _mini_eval_setup():
+def _mini_eval_setup(perturb=False):
     from torch.utils.data import DataLoader
     from drn_amd import trainer as T
     from drn_amd.data import CharadesSTA, ShardSampler, collate_data
@@ -279,7 +279,24 @@ def _mini_eval_setup():
     m.load_state_dict(seeded_state_dict(m, 0))
     with torch.no_grad():                                     # pass enough locations for NMS / top-k to matter
         m.fcos.head.cls_logits.bias.fill_(0.5)
-    tr = T.Trainer(m, 3, lr=1e-3, fused=False)
+    world_now = dist.get_world_size() if dist.is_initialized() else 1
+    if perturb:
+        # this rank built / resumed its model differently: other weights AND other BatchNorm running statistics.  The Trainer
+        # must bring every rank to rank 0's replica (drn_amd.dist.sync_model_state; nn.DataParallel's broadcast, main.py:99)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(99)))
+            for b in m.buffers():
+                if b.dtype.is_floating_point:
+                    b.mul_(1.5).add_(0.1)
+    tr = T.Trainer(m, 3, lr=1e-3, fused=False, world_size=world_now)
+    if perturb:
+        # ... and its BatchNorm running statistics drifted apart again during training (per-rank batches): evaluate() scores
+        # every shard with rank 0's buffers, the replica whose state_dict fit() saves under the merged metric
+        with torch.no_grad():
+            for b in m.buffers():
+                if b.dtype.is_floating_point:
+                    b.mul_(0.7).sub_(0.05)
     loader = lambda world, rank: DataLoader(ds, batch_size=3, shuffle=False, collate_fn=collate_data,
                                             sampler=ShardSampler(ds, world, rank) if world > 1 else None)
     return tr, loader, len(ds)
@@ -290,8 +307,13 @@ def _worker_sharded_eval(rank, world, port, q):
     from drn_amd.dist import init_from_env
     init_from_env(backend="gloo")
     torch.set_num_threads(2)
-    tr, loader, n = _mini_eval_setup()
+    tr, loader, n = _mini_eval_setup(perturb=rank == 1)
     loss, topks, accs, results = tr.evaluate(loader(world, rank), iou_topk={"iou": [0.3, 0.5], "topk": [1, 5]})
+    # after the pass every rank holds rank 0's buffers and parameters
+    mine = torch.cat([t.detach().double().reshape(-1) for t in list(tr.model.parameters()) + list(tr.model.buffers())])
+    other = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    assert all(torch.equal(o, mine) for o in other), "replicas differ after a sharded evaluation"
     q.put((rank, loss, topks, accs, sum(len(v) for v in results.values())))
     dist.destroy_process_group()
 
@@ -315,6 +337,64 @@ def test_sharded_evaluation_world2_equals_single_process():
         # (the validation loss is normalised per BATCH -- n_pos + B, model/loss.py -- so it depends on how the queries fall into
         # batches and is not expected to be shard-invariant; both ranks must agree on the merged value)
         assert np.isfinite(loss) and loss == got[0][1]
+
+
+def _worker_sync_state(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from drn_amd.dist import init_from_env, sync_model_state
+    init_from_env(backend="gloo")
+    torch.manual_seed(rank)                                   # every rank its own weights, statistics and step counter
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.BatchNorm1d(8), torch.nn.Linear(8, 3))
+    net.train()
+    for _ in range(rank + 1):
+        net(torch.randn(5, 6))
+    before = [p.detach().clone() for p in net.parameters()]
+    sync_model_state(net, src=0, buffers_only=True)           # buffers follow rank 0, parameters stay
+    assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+    assert int(net[1].num_batches_tracked) == 1
+    bufs = torch.cat([b.detach().double().reshape(-1) for b in net.buffers()])
+    got = [torch.empty_like(bufs) for _ in range(world)]
+    dist.all_gather(got, bufs)
+    assert all(torch.equal(g, got[0]) for g in got)
+    sync_model_state(net, src=0)                              # the whole replica
+    flat = torch.cat([t.detach().double().reshape(-1) for t in list(net.parameters()) + list(net.buffers())])
+    got = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(got, flat)
+    assert all(torch.equal(g, got[0]) for g in got)
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.BatchNorm1d(8), torch.nn.Linear(8, 3))
+    assert all(torch.equal(a, b) for a, b in zip(ref.parameters(), net.parameters())), "not rank 0's parameters"
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_sync_model_state_world2_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sync_state, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
+def test_adjacent_group_with_alignment_padding_takes_the_copy_path():
+    """A stacked group whose members cannot lie back to back under _offsets' 32-element alignment is dropped from the adjacency
+    plan (with a warning) instead of silently ending up apart."""
+    import warnings
+    from drn_amd.dist import GradReducer
+    a, b = torch.nn.Parameter(torch.randn(1030)), torch.nn.Parameter(torch.randn(2048))      # 1030 % 32 != 0: padding before b
+    c, d = torch.nn.Parameter(torch.randn(64, 32)), torch.nn.Parameter(torch.randn(64, 32))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        red = GradReducer([a, b, c, d], world_size=1, adjacent=[[a, b], [c, d]])
+    assert any("adjacent group" in str(x.message) for x in w)
+    (bc, ic), (bd, idd) = red._of[c], red._of[d]
+    assert bc is bd and idd == ic + 1 and bc.offsets[ic] + c.numel() == bc.offsets[idd]
+    red.remove()
 
 
 def test_shard_sampler_covers_every_sample_once():

@@ -72,3 +72,43 @@ def test_known_answers():
     # tIoU of identical segments ~ 1
     a = torch.tensor([[[0.2, 0.6]]])
     assert abs(O.segment_tiou(a, a).item() - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["none", "pos", "zero"])
+def test_iou_loss_oracle_matches_reference_golden(tag):
+    """model/layers/iou_loss.py:5-24, all three branches of its return (no weight / weighted / weight.sum() == 0)."""
+    g = load_golden("layers")
+    p = torch.from_numpy(g["iou/pred"]).requires_grad_()
+    t = torch.from_numpy(g["iou/target"]).requires_grad_()
+    w = {"none": None, "pos": torch.from_numpy(g["iou/weight_pos"]), "zero": torch.zeros(p.shape[0])}[tag]
+    loss = O.iou_loss(p, t, w)
+    (loss * 1.7).backward()
+    np.testing.assert_allclose(loss.detach().numpy().reshape(1), g["iou/%s/loss" % tag], rtol=1e-6)
+    np.testing.assert_allclose(p.grad.numpy(), g["iou/%s/dpred" % tag], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(t.grad.numpy(), g["iou/%s/dtarget" % tag], rtol=1e-5, atol=1e-8)
+    if tag == "none":
+        assert abs(float(O.iou_loss_mean(p, t)) - float(loss)) < 1e-7
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_lgp_without_bn_flag_oracle_matches_reference_golden(mode):
+    """model/LGP.py:5-27 with use_bn=False: a biased 1x1 conv, the BatchNorm still appended."""
+    g = load_golden("layers")
+    pre = "lgp_nobn/%s/" % mode
+    net = O.LGP(input_dim=64, query_dim=64, use_bn=False)
+    net.load_state_dict(seeded_state_dict(net, seed=4))
+    with torch.no_grad():
+        net.query_fc[0].bias.copy_(torch.from_numpy(g[pre + "bias"]))
+        net.query_fc[1].running_mean.copy_(torch.from_numpy(g[pre + "rm0"]))
+        net.query_fc[1].running_var.copy_(torch.from_numpy(g[pre + "rv0"]))
+    net.train(mode == "train")
+    x = torch.from_numpy(g[pre + "x"]).requires_grad_()
+    q = torch.from_numpy(g[pre + "q"]).requires_grad_()
+    y = net(x, q)
+    (y * torch.from_numpy(g[pre + "w"])).sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), g[pre + "y"], atol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g[pre + "dx"], atol=1e-5)
+    np.testing.assert_allclose(q.grad.numpy(), g[pre + "dq"], atol=1e-4)
+    np.testing.assert_allclose(net.query_fc[0].weight.grad.numpy(), g[pre + "dw"], atol=1e-4)
+    np.testing.assert_allclose(net.query_fc[1].running_mean.numpy(), g[pre + "rm"], atol=1e-6)
+    np.testing.assert_allclose(net.query_fc[1].running_var.numpy(), g[pre + "rv"], atol=1e-6)
