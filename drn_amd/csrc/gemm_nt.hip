@@ -77,7 +77,12 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   // launches that leave CUs idle anyway (<= 256 workgroups: most of the pyramid GEMMs at T = 256, everything at Charades-STA's
   // T = 32) run one workgroup per CU with a 4-slot ring -- three K-tiles of loads in flight against the cold operands instead of
   // one: step 1.51 -> 1.435 ms at T = 32, 2.448 -> 2.434 at T = 256 (512 as the bound: 2.465)
-  const bool deep8 = waves8 && stages == 2 && drn_tuning(DRN_TUNE_NT_DEEP) > 0 && (long)total * ksplit <= drn_tuning(DRN_TUNE_NT_DEEP);
+  int max_ksteps = 0;
+  for (int g = 0; g < ngroups; ++g) max_ksteps = max(max_ksteps, cdiv(cdiv(d[g].taps * d[g].Cin, 8 * ch), ksplit));
+  const bool deep8 = waves8 && stages == 2 &&
+                     ((drn_tuning(DRN_TUNE_NT_DEEP) > 0 && (long)total * ksplit <= drn_tuning(DRN_TUNE_NT_DEEP)) ||
+                      (drn_tuning(DRN_TUNE_NT_DEEP2) > 0 && (long)total * ksplit <= drn_tuning(DRN_TUNE_NT_DEEP2) &&
+                       max_ksteps <= drn_tuning(DRN_TUNE_NT_DEEP_KS)));
   static bool attr_set = false;
   if (!attr_set) {
 #define NT_ATTR(TT, SS, ...) \
