@@ -5,6 +5,8 @@ bool drn_nt_w4_eligible(const DrnGemmDesc* d, int ngroups, int dtype);          
 int drn_nt_w4_launch(const GemmParams& P, int total, hipStream_t stream);
 bool drn_nt_w4c_eligible(const DrnGemmDesc* d, int ngroups, int dtype);
 int drn_nt_w4c_launch(const GemmParams& P, int total, hipStream_t stream, int ksplit);
+bool drn_nt_w4h_eligible(const DrnGemmDesc* d, int ngroups, int dtype, bool* conv_out);  // gemm_nt_w4h.hip
+int drn_nt_w4h_launch(const GemmParams& P, int total, bool conv, hipStream_t stream);
 
 // Which kernel a launch runs on, given the tile size launch_nt chose (drn_gemm_nt_plan reports it to callers that schedule
 // around a launch -- functional.input_prep's weight pre-touch -- instead of re-deriving the rule on their side).
@@ -50,6 +52,14 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   if (drn_tuning(DRN_TUNE_EXP0 + 3) > 0) P.xcd_swizzle = drn_tuning(DRN_TUNE_EXP0 + 3) - 1;   // (exp3: experiment override, value - 1)
   if (const char* e = drn_exp_env("DRN_NT_ORDER")) P.xcd_swizzle = atoi(e);      // bit 0: XCD-contiguous runs, bit 1: 8-row grouped order
   if (ksplit > 1) tile = planes256 ? 256 : 128;
+  // launches on 128x128 tiles whose problems make enough 256x128 tiles: the 4-wave loop on half-width tiles (gemm_nt_w4h.hip)
+  bool w4h = false, w4h_conv = false;
+  if (tile == 128 && ksplit == 1 && !planes256 && drn_tuning(DRN_TUNE_NT_W4H) > 0 && drn_nt_w4h_eligible(d, ngroups, dtype, &w4h_conv)) {
+    long th = 0;
+    for (int g = 0; g < ngroups; ++g) th += (long)(d[g].M / 256) * (d[g].N / 128);
+    w4h = th >= drn_tuning(DRN_TUNE_NT_W4H);
+  }
+  const int tile_m = w4h ? 256 : tile, tile_n = w4h ? 128 : tile;
   int total = 0;
   for (int g = 0; g < ngroups; ++g) {
     const DrnGemmDesc& s = d[g];
@@ -59,9 +69,9 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     p.mode = s.mode; p.Lout = s.Lout; p.Lsrc = s.Lsrc; p.lda = s.lda; p.ldb = s.ldb; p.ldc = s.ldc; p.ldg = s.ldg; p.ldc2 = s.ldc2;
     p.accumulate = s.accumulate;
     p.out_f32 = s.out_f32;
-    p.tiles_n = cdiv(s.N, tile);
+    p.tiles_n = cdiv(s.N, tile_n);
     p.tile_start = total;
-    total += cdiv(s.M, tile) * p.tiles_n;
+    total += cdiv(s.M, tile_m) * p.tiles_n;
   }
   // Pipeline depth for the 128x128 tile: 2 stages leave room for two workgroups per CU (best when the grid
   // oversubscribes the chip); 4 stages (one workgroup per CU) otherwise.  DRN_NT_STAGES overrides for experiments.
@@ -101,8 +111,12 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     P.nblocks = total; \
     if (fast) conv_gemm_nt_kernel<TT, SS, true, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); \
     else conv_gemm_nt_kernel<TT, SS, false, __VA_ARGS__><<<dim3(total, ksplit), THREADS, LDS, stream>>>(P); } while (0)
-  const int kind = nt_kind(d, ngroups, dtype, tile, ksplit, planes256);
+  const int kind = w4h ? DRN_NT_KIND_W4H : nt_kind(d, ngroups, dtype, tile, ksplit, planes256);
   if (plan_only) return kind;
+  if (kind == DRN_NT_KIND_W4H) {
+    P.nblocks = total;
+    return drn_nt_w4h_launch(P, total, w4h_conv, stream);
+  }
   if (kind == DRN_NT_KIND_W4) {
     P.nblocks = total;
     return drn_nt_w4_launch(P, total, stream);

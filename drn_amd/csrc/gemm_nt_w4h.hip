@@ -1,0 +1,239 @@
+// The hand-scheduled 4-wave loop of gemm_nt_w4.hip on 256 x 128 output tiles, for the bf16 launches whose N (512 for every FPN /
+// head convolution of DRN: model/FPN.py:54-69, model/fcos.py:58-62) gives too few 256 x 256 tiles to fill 256 CUs -- the three
+// pyramid levels of a grouped launch make 112 -- and which on 128 x 128 tiles of eight 64 x 32 waves are bound by the LDS, not by
+// the matrix pipe: 96 KB of fragment reads + 32 KB of LDS-DMA writes per 128 x 128 x 64 MACs = 1024 LDS cycles per K-step and
+// workgroup against 512 of MFMA (measured: 35 / 55 us for the 24- / 48-K-step launches = two workgroups per CU x K-steps x 1024
+// cycles + ~8 us).  Here a workgroup is 4 waves = ONE per SIMD, a wave owns 128 x 64 outputs (8 x 4 MFMA tiles, 128 accumulator
+// AGPRs): 24 KB of fragment reads per 128 x 64 x 64 MACs, 1152 LDS cycles per K-step and CU against 1024 of MFMA, and 224 tiles for
+// the same launch.  Ring: three K-steps as [A 32 KB | B 16 KB] pairs (144 KB); schedule, staging and waits as in the 256 x 256 loop
+// (scripts/gen_w4_loop.py, `Geo`).
+//
+// Two kernels: plain products (1x1 convolutions / Linear, forward or data gradient: taps = 1, stride 1) and k = 3 / stride 1 / pad 1
+// convolutions (forward: mode 0, data gradient: mode 1) -- the A side of the latter is gemm_nt_w4c_kernel's (buffer descriptor, tap
+// shifts, zero rows at the sequence edges).  Same MFMA instruction, same K order per output element, same epilogue statements
+// (nt_epi_chunk_vec) and the BatchNorm statistics in the order nt_bn_stats<2, 4, 4, 2> adds them (a 128-row slab = two 64-row wave
+// rows there, the two halves of a wave's 128 rows here): results are bit-identical to the 128 x 128 kernel these launches ran on.
+#include "gemm_nt_kernel.h"
+#include "gemm_nt_w4_loop.inc"
+
+template <int R>
+__device__ __forceinline__ float w4h_acc_read() {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(R));
+  return v;
+}
+// a2[mi2][ni] = accumulator tile (2*CH + mi2, ni) of the wave's 8 x 4 grid = a[((2*CH + mi2)*4 + ni)*4 .. +3]
+template <int CH, int I = 0>
+__device__ __forceinline__ void w4h_acc_chunk(f32x4 (&a2)[2][4]) {
+  if constexpr (I < 8) {
+    constexpr int R = (CH * 8 + I) * 4;
+    a2[I / 4][I % 4] = (f32x4){w4h_acc_read<R>(), w4h_acc_read<R + 1>(), w4h_acc_read<R + 2>(), w4h_acc_read<R + 3>()};
+    w4h_acc_chunk<CH, I + 1>(a2);
+  }
+}
+// column sums of grid rows [MI0, MI0 + 4) (64 rows: one wave row of the 128 x 128 kernel), mi ascending, r ascending
+template <int MI0, int I = 0>
+__device__ __forceinline__ void w4h_colsum(float (&sm)[4]) {
+  if constexpr (I < 16) {
+    constexpr int R = ((MI0 + I / 4) * 4 + I % 4) * 4;
+    sm[I % 4] += w4h_acc_read<R>();
+    sm[I % 4] += w4h_acc_read<R + 1>();
+    sm[I % 4] += w4h_acc_read<R + 2>();
+    sm[I % 4] += w4h_acc_read<R + 3>();
+    w4h_colsum<MI0, I + 1>(sm);
+  }
+}
+template <int MI0, int I = 0>
+__device__ __forceinline__ void w4h_colsq(float (&q)[4], const float (&mean)[4], const int mrow0, const int M) {
+  if constexpr (I < 16) {
+    constexpr int R = ((MI0 + I / 4) * 4 + I % 4) * 4;
+    const int m = mrow0 + (I / 4) * 16 + ((threadIdx.x & 63) >> 4) * 4;
+    const float d0 = w4h_acc_read<R>() - mean[I % 4], d1 = w4h_acc_read<R + 1>() - mean[I % 4];
+    const float d2 = w4h_acc_read<R + 2>() - mean[I % 4], d3 = w4h_acc_read<R + 3>() - mean[I % 4];
+    q[I % 4] += m + 0 < M ? d0 * d0 : 0.f;
+    q[I % 4] += m + 1 < M ? d1 * d1 : 0.f;
+    q[I % 4] += m + 2 < M ? d2 * d2 : 0.f;
+    q[I % 4] += m + 3 < M ? d3 * d3 : 0.f;
+    w4h_colsq<MI0, I + 1>(q, mean, mrow0, M);
+  }
+}
+
+// Per-128-row-slab BatchNorm statistics of the wave's 128 rows x 64 columns, the arithmetic and ORDER of nt_bn_stats<2, 4, 4, 2>
+// (128 x 128 tile of 64 x 32 waves): there a slab's column sum is (sum over wave row 0: mi, r ascending, then lanes +16, +32) +
+// (the same over wave row 1), added as 0 + a + b; the mean is that / rows; the centred squares likewise.
+__device__ __forceinline__ void w4h_bn_stats(float* shs, float* __restrict__ stats, const int M, const int N, const int m0, const int n0,
+                                             const int tm, const int wr, const int wc) {
+  const int tid = threadIdx.x, l = tid & 63;
+  constexpr int TN = 128, SLABS = 2;
+  float* shm = shs + 2 * TN;                       // [SLABS][TN] slab means
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  w4h_colsum<0>(sa);
+  w4h_colsum<4>(sb);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    float a = sa[ni], b = sb[ni];
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 16, 64);
+    b += __shfl_xor(b, 32, 64);
+    float v = 0.f;
+    v += a;
+    v += b;
+    if (l < 16) shs[wr * TN + wc * 64 + ni * 16 + l] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < SLABS * TN; i += 256) {
+    const int n = i % TN, slab = i / TN;
+    const int grow = tm * SLABS + slab;
+    const float v = shs[slab * TN + n];
+    const int rows = min(128, M - grow * 128);
+    shm[i] = rows > 0 ? v / (float)rows : 0.f;
+    if (n0 + n < N && rows > 0) stats[((long)grow * 2 + 0) * N + n0 + n] = v;
+  }
+  __syncthreads();
+  float mean[4], qa[4] = {0.f, 0.f, 0.f, 0.f}, qb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) mean[ni] = shm[wr * TN + wc * 64 + ni * 16 + (l & 15)];
+  const int mw = m0 + wr * 128;
+  w4h_colsq<0>(qa, mean, mw, M);
+  w4h_colsq<4>(qb, mean, mw + 64, M);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    float a = qa[ni], b = qb[ni];
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 16, 64);
+    b += __shfl_xor(b, 32, 64);
+    float v = 0.f;
+    v += a;
+    v += b;
+    if (l < 16) shs[wr * TN + wc * 64 + ni * 16 + l] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < SLABS * TN; i += 256) {
+    const int n = i % TN, slab = i / TN;
+    const int grow = tm * SLABS + slab;
+    if (n0 + n < N && grow * 128 < M) stats[((long)grow * 2 + 1) * N + n0 + n] = shs[slab * TN + n];
+  }
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_arg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  NtHeader P;
+  GemmProb pr;
+  int g, tm, tn;
+  nt_fetch(P_arg, P, pr, g, blockIdx.x);
+  nt_locate<256>(P, pr, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 128;
+  const int wr = w >> 1, wc = w & 1;
+
+  // ---- staging.  A: piece p = 8*w + i = rows 8*p .. 8*p + 7 of the tile's 256; B: piece p = 4*w + i of its 128 rows; lane l carries
+  // the 16-byte chunk that belongs at position l & 7 of row 8*p + (l >> 3), i.e. chunk (l & 7) ^ ((row >> 1) & 7)
+  unsigned voa[8], vob[4], mask_first = 0u, mask_last = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned row = (unsigned)((w * 8 + i) * 8 + (l >> 3));
+    const unsigned chunk = (unsigned)((l & 7) ^ ((((i & 1) << 2) + (l >> 4)) & 7)) * 16u;
+    voa[i] = row * (unsigned)pr.lda * 2u + chunk;
+    if constexpr (CONV) {
+      const int t = (m0 + (int)row) % pr.Lout;
+      mask_first |= (t == 0 ? 1u : 0u) << i;
+      mask_last |= (t == pr.Lout - 1 ? 1u : 0u) << i;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned row = (unsigned)((w * 4 + i) * 8 + (l >> 3));
+    const unsigned chunk = (unsigned)((l & 7) ^ ((((i & 1) << 2) + (l >> 4)) & 7)) * 16u;
+    vob[i] = row * (unsigned)pr.ldb * 2u + chunk;
+  }
+  // ---- fragments of k-slice ks: lane l reads chunk 4*ks + (l >> 4) of row l & 15 of a 16-row block
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned lrow = lds0 + (unsigned)(l & 15) * 128u, swz = (unsigned)(l >> 1) & 7u;
+  const unsigned pc0 = (((unsigned)(l >> 4)) ^ swz) * 16u, pc1 = ((4u + (unsigned)(l >> 4)) ^ swz) * 16u;
+  const unsigned la0 = lrow + (unsigned)wr * 16384u + pc0, la1 = lrow + (unsigned)wr * 16384u + pc1;
+  const unsigned lb0 = lrow + (unsigned)wc * 8192u + pc0, lb1 = lrow + (unsigned)wc * 8192u + pc1;
+  const unsigned lw = lds0 + (unsigned)w * 8192u, lwb = lds0 + (unsigned)w * 4096u;
+  const char* sb = (const char*)pr.B + (long)n0 * pr.ldb * 2;
+  const int trips = pr.K / 64 - 2;
+
+  if constexpr (CONV) {
+    const unsigned long long abase = (unsigned long long)(uintptr_t)pr.A + (unsigned long long)((long)(m0 - 1) * pr.lda * 2);
+    const unsigned d0 = (unsigned)abase, d1 = (unsigned)(abase >> 32) & 0xffffu, d2 = 0x7fffffffu, d3 = 0x00020000u;
+    const unsigned lda2 = (unsigned)pr.lda * 2u;
+    // forward (mode 0): tap k reads row m + k - 1 -> shifts 0, 1, 2 rows, zeros for the first row at tap 0 and the last at tap 2;
+    // data gradient (mode 1): tap k reads row m + 1 - k -> 2, 1, 0 and the masks change places
+    const bool fwd = pr.mode == 0;
+    const unsigned sh0 = fwd ? 0u : 2u * lda2, sh1 = lda2, sh2 = fwd ? 2u * lda2 : 0u;
+    const unsigned ma = fwd ? mask_first : mask_last, mc = fwd ? mask_last : mask_first;
+    const int per = pr.Cin / 64;                      // K-steps per tap
+    asm volatile(W4HC_LOOP_ASM
+                 :
+                 : [sb] "s"(sb), [cnt] "s"(trips), [lw] "s"(lw), [lwb] "s"(lwb), [d0] "s"(d0), [d1] "s"(d1), [d2] "s"(d2), [d3] "s"(d3),
+                   [c0] "s"(0), [left] "s"(per), [per] "s"(per), [tap] "s"(0), [sh0] "s"(sh0), [sh1] "s"(sh1), [sh2] "s"(sh2),
+                   [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [voa5] "v"(voa[5]),
+                   [voa6] "v"(voa[6]), [voa7] "v"(voa[7]), [ma] "v"(ma), [mc] "v"(mc),
+                   [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vob2] "v"(vob[2]), [vob3] "v"(vob[3]),
+                   [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1)
+                 : W4H_LOOP_CLOBBERS);
+  } else {
+    const char* sa = (const char*)pr.A + (long)m0 * pr.lda * 2;
+    asm volatile(W4H_LOOP_ASM
+                 :
+                 : [sa] "s"(sa), [sb] "s"(sb), [cnt] "s"(trips), [lw] "s"(lw), [lwb] "s"(lwb),
+                   [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [voa5] "v"(voa[5]),
+                   [voa6] "v"(voa[6]), [voa7] "v"(voa[7]),
+                   [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vob2] "v"(vob[2]), [vob3] "v"(vob[3]),
+                   [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1)
+                 : W4H_LOOP_CLOBBERS);
+  }
+  __syncthreads();        // everybody is past its last fragment read: the LDS becomes the epilogue's staging patches
+
+  const int ncol0 = n0 + wc * 64;
+  char* wbuf = smem + w * (32 * (64 * 2 + 16));
+  float bias_v[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) bias_v[ni] = pr.bias ? pr.bias[ncol0 + ni * 16 + (l & 15)] : 0.f;
+  f32x4 a2[2][4];
+#define W4H_CH(CH) w4h_acc_chunk<CH>(a2); nt_epi_chunk_vec<bf16_t, 4>(pr, a2, wbuf, m0 + wr * 128 + CH * 32, ncol0, bias_v)
+  W4H_CH(0); W4H_CH(1); W4H_CH(2); W4H_CH(3);
+#undef W4H_CH
+  // statistics after the stores have been issued (as nt_epilogue does), in the LDS beyond the store patches
+  if (pr.stats) w4h_bn_stats((float*)(smem + 4 * (32 * (64 * 2 + 16))), pr.stats, pr.M, pr.N, m0, n0, tm, wr, wc);
+}
+
+// Can every problem of this launch run on gemm_nt_w4h_kernel<conv>?  All problems of a launch must be of one kind.
+bool drn_nt_w4h_eligible(const DrnGemmDesc* d, int ngroups, int dtype, bool* conv_out) {
+  if (dtype != DRN_BF16) return false;
+  bool conv = false;
+  for (int g = 0; g < ngroups; ++g) {
+    const DrnGemmDesc& s = d[g];
+    const bool plain = s.taps == 1 && s.stride == 1 && s.pad == 0 && s.Lout == s.Lsrc;          // (mode 0 / 1 coincide: one tap, no shift)
+    const bool k3 = s.taps == 3 && s.stride == 1 && s.pad == 1 && s.Lout == s.Lsrc && (s.mode == 0 || s.mode == 1) && s.M % s.Lout == 0;
+    if (!plain && !k3) return false;
+    if (g == 0) conv = k3;
+    else if (conv != k3) return false;
+    if (s.M % 256 || s.N % 128 || s.Cin % 64 || s.taps * s.Cin < 128 || s.out_f32 || s.accumulate) return false;
+    if ((long)s.lda >= (1L << 22) || (long)s.ldb >= (1L << 22)) return false;            // 32-bit staging offsets
+    if (s.ldc % 8 || ((uintptr_t)s.C & 15) || (s.C2 && (s.ldc2 % 8 || ((uintptr_t)s.C2 & 15)))) return false;
+    if (s.stats && (s.gate || s.C2)) return false;       // (statistics of gated outputs: no caller; nt_epilogue orders them differently)
+  }
+  *conv_out = conv;
+  return true;
+}
+
+int drn_nt_w4h_launch(const GemmParams& P, int total, bool conv, hipStream_t stream) {
+  static bool attr_set = false;
+  constexpr int LDS = 3 * (32768 + 16384);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  if (conv) gemm_nt_w4h_kernel<true><<<dim3(total, 1), 256, LDS, stream>>>(P);
+  else gemm_nt_w4h_kernel<false><<<dim3(total, 1), 256, LDS, stream>>>(P);
+  return drn_launch_status("drn_gemm_nt");
+}

@@ -117,7 +117,7 @@ def _ksplit256(descs, dtype):
     return 3 * per_tap if per_tap >= 1 and per // per_tap >= 8 else 1
 
 
-NT_KIND_TILE128, NT_KIND_TILE256, NT_KIND_W4, NT_KIND_W4C = 0, 1, 2, 3
+NT_KIND_TILE128, NT_KIND_TILE256, NT_KIND_W4, NT_KIND_W4C, NT_KIND_W4H = 0, 1, 2, 3, 4
 
 
 def gemm_nt_plan(descs, dtype):

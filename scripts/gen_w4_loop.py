@@ -55,6 +55,7 @@ class Cfg:
     mfma32 = False      # timing-only ablation: half as many v_mfma_f32_32x32x16_bf16 (same pipe time, twice the issue slack per gap)
     hoist = True        # scalar bookkeeping and M0 writes inside the MFMA stream (False: after it / in front of each piece)
     adv = 128           # bytes the operand pointers advance per K-step (0: every K-step re-reads the first one -- L2-hit ablation)
+    half = False        # 256 x 128 output tile (gemm_nt_w4h_kernel): 128 x 64 per wave, B items of 128 rows -- see the notes at `Geo`
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -72,12 +73,41 @@ A_SET = [128, 192]
 B_SET = [160, 224]
 
 
+class Geo:
+    """Tile geometry of the variant being generated.  Full (shipped W4 / W4C): 256 x 256 per workgroup, 128 x 128 per wave (8 x 8 MFMA
+    tiles, a[0:255]), A and B items of 256 rows = 32 KB each, five 32 KB slots.
+    Half (W4H / W4HC, cfg.half): 256 x 128 per workgroup for the launches whose N = 512 gives too few 256 x 256 tiles to fill the
+    chip (the pyramid-level convolutions: 112 of them on 256 CUs) and which are LDS-bound on 128 x 128 tiles of eight 64 x 32
+    waves (96 KB of fragment reads per 128 x 128 x 64 MACs: 1024 LDS cycles per K-step and workgroup against 512 of MFMA).  Here a
+    wave owns 128 x 64 (8 x 4 MFMA tiles, a[0:127]): 24 KB of fragment reads per 128 x 64 x 64 MACs -- 1152 LDS cycles per K-step
+    and CU against 1024 of MFMA.  A items stay 256 rows = 32 KB (8 pieces per wave), B items are 128 rows = 16 KB (4 pieces per
+    wave); the ring holds THREE K-steps as [A | B] pairs of 48 KB (144 KB): K-step j lives in pair j % 3, its A at +0, its B at
+    +32 KB.  Same schedule: A_{j+2} is staged during half-step 2j into the pair K-step j-1 left at the barrier of half-step 2j-1,
+    B_{j+2} during half-step 2j+1.  The stream offset s86 advances by 32 KB after an A item and by 16 KB after a B item and wraps
+    at 144 KB; the wave's first piece sits at s85 + s86 for A items (s85 = LDS base + 8 KB x wave) and at s100 + s86 for B items
+    (s100 = LDS base + 4 KB x wave)."""
+
+    def __init__(self, half):
+        self.half = half
+        self.NI = 4 if half else 8
+        self.PB = 4 if half else 8                      # B pieces per wave and K-step
+        self.A_BYTES = SLOT
+        self.B_BYTES = SLOT // 2 if half else SLOT
+        self.RING = 3 * (SLOT + SLOT // 2) if half else RING
+        self.NM = 8 * self.NI                           # MFMAs per half-step
+        self.NACC = 32 * self.NI                        # accumulator registers
+
+
+def geo():
+    return Geo(cfg.half)
+
+
 def frag(base, i):
     return "v[%d:%d]" % (base + 4 * i, base + 4 * i + 3)
 
 
 def acc(mi, ni):
-    b = (mi * 8 + ni) * 4
+    b = (mi * geo().NI + ni) * 4
     return "a[%d:%d]" % (b, b + 3)
 
 
@@ -85,7 +115,7 @@ def ds_reads(dst_set):
     """the 16 fragment reads of one k-slice into register set dst_set (bases in v124 / v125): A first (the previous half-step's
     last MFMAs still name B registers of this set)."""
     out = ["ds_read_b128 %s, v124 offset:%d" % (frag(A_SET[dst_set], i), i * 2048) for i in range(8)]
-    out += ["ds_read_b128 %s, v125 offset:%d" % (frag(B_SET[dst_set], i), i * 2048) for i in range(8)]
+    out += ["ds_read_b128 %s, v125 offset:%d" % (frag(B_SET[dst_set], i), i * 2048) for i in range(geo().NI)]
     return out
 
 
@@ -100,7 +130,8 @@ def dma_item(op):
         # (out of range -> the piece gets zeros) where the tap leaves the lane's sequence; s96 = channel byte offset inside the tap
         return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "buffer_load_dwordx4 v%d, s[92:95], s96 offen lds" % (116 + i)] for i in range(8)]
     src = "s[80:81]" if op == "a" else "s[82:83]"
-    return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "global_load_lds_dwordx4 %%[vo%s%d], %s" % (op, i, src)] for i in range(8)]
+    return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "global_load_lds_dwordx4 %%[vo%s%d], %s" % (op, i, src)]
+            for i in range(8 if op == "a" else geo().PB)]
 
 
 def apply_tap(tag):
@@ -142,6 +173,10 @@ def advance_stage_groups(op):
     first = ["s_add_u32 s%d, s%d, %d" % (ptr[0], ptr[0], cfg.adv), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
     if op == "a" and cfg.conv:
         first = ["s_add_u32 s96, s96, 128"]
+    G = geo()
+    if G.half:      # the item after an A item is a B item (wave base s100) and vice versa (s85)
+        return [first, ["s_add_u32 s86, s86, %d" % (G.A_BYTES if op == "a" else G.B_BYTES)],
+                ["s_cmp_lt_u32 s86, %d" % G.RING, "s_cselect_b32 s86, s86, 0"], ["s_add_u32 s89, %s, s86" % ("s100" if op == "a" else "s85")]]
     return [first, ["s_add_u32 s86, s86, %d" % SLOT], ["s_cmp_lt_u32 s86, %d" % RING, "s_cselect_b32 s86, s86, 0"], ["s_add_u32 s89, s85, s86"]]
 
 
@@ -152,9 +187,11 @@ def advance_stage(op):
 def advance_read_groups():
     """the slots being read move on by one K-step = two slots (mod the ring)"""
     G = []
+    g = geo()
+    step, ring = (g.A_BYTES + g.B_BYTES, g.RING) if g.half else (2 * SLOT, RING)
     for r, t in (("s87", "s90"), ("s88", "s91")):
-        G += [["s_add_u32 %s, %s, %d" % (r, r, 2 * SLOT), "s_sub_u32 %s, %s, %d" % (t, r, RING)],
-              ["s_cmp_lt_u32 %s, %d" % (r, RING), "s_cselect_b32 %s, %s, %s" % (r, r, t)]]
+        G += [["s_add_u32 %s, %s, %d" % (r, r, step), "s_sub_u32 %s, %s, %d" % (t, r, ring)],
+              ["s_cmp_lt_u32 %s, %d" % (r, ring), "s_cselect_b32 %s, %s, %s" % (r, r, t)]]
     return G
 
 
@@ -171,14 +208,15 @@ def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False
     do_reads = reads and not cfg.no_ds
     if do_reads:
         L += frag_bases(1 - ks)
-    fill = {n: [] for n in range(64)}
+    NM, NI = geo().NM, geo().NI
+    fill = {n: [] for n in range(NM)}
     rs = ds_reads(1 - ks) if do_reads else []
     for k, r in enumerate(rs):
-        fill[min(63, cfg.ds_first + k * cfg.ds_every)].append(r)
+        fill[min(NM - 1, cfg.ds_first + k * cfg.ds_every)].append(r)
     ps = dma_item(dma) if dma and not cfg.no_dma else []
     last_dma = 0
     for k, (m0w, nop, ld) in enumerate(ps):
-        n = min(63, cfg.dma_first + k * cfg.dma_every)
+        n = min(NM - 1, cfg.dma_first + k * cfg.dma_every)
         if cfg.hoist and n >= 1 and not cfg.no_mfma:
             fill[n - 1].append(m0w)
             fill[n].append(ld)
@@ -194,7 +232,7 @@ def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False
             fill[4 + 2 * k] += g
         pos = last_dma + 1
         for g in st_groups:
-            if pos <= 63:
+            if pos <= NM - 1:
                 fill[pos] += g
                 pos += 1
             else:
@@ -203,9 +241,9 @@ def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False
         tail = [i for g in rd_groups + st_groups for i in g]
     if dma == "a" and cfg.conv:
         tail += advance_tap()
-    for n in range(64):
+    for n in range(NM):
         if not cfg.no_mfma:
-            mi, ni = n // 8, n % 8
+            mi, ni = n // NI, n % NI
             if cfg.mfma32:
                 if n % 2 == 0:
                     q = (n // 2) % 16
@@ -225,8 +263,11 @@ def k_step(dma=True, last_wait="vmcnt(8) lgkmcnt(0)", next_reads=True):
 
 def build():
     _tap_seq[0] = 0
+    G = geo()
     lines = ["s_mov_b64 s[82:83], %[sb]", "s_mov_b32 s84, %[cnt]", "s_mov_b32 s85, %[lw]",
              "s_mov_b32 s86, 0", "s_mov_b32 s87, 0", "s_mov_b32 s88, %d" % SLOT, "s_mov_b32 s89, s85"]
+    if G.half:
+        lines += ["s_mov_b32 s100, %[lwb]"]
     if cfg.conv:
         lines += ["s_mov_b32 s92, %[d0]", "s_mov_b32 s93, %[d1]", "s_mov_b32 s94, %[d2]", "s_mov_b32 s95, %[d3]",
                   "s_mov_b32 s96, %[c0]", "s_mov_b32 s97, %[left]", "s_mov_b32 s98, %[per]", "s_mov_b32 s99, %[tap]",
@@ -244,9 +285,9 @@ def build():
         if op == "a" and cfg.conv:
             lines += advance_tap()
     # accumulators = 0, while the first K-steps are on their way
-    for i in range(256):
+    for i in range(G.NACC):
         lines.append("v_accvgpr_write_b32 a%d, 0" % i)
-    lines += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    lines += ["s_waitcnt vmcnt(%d)" % (8 + G.PB), "s_barrier"]
     if not cfg.no_ds:
         lines += frag_bases(0) + ds_reads(0)
     # main loop: K/64 - 2 trips of one K-step
@@ -315,6 +356,17 @@ with open(args.out, "w") as f:
     for ln in lines:
         f.write('  "%s\\n\\t" \\\n' % ln)
     f.write('  ""\n')
+    # 256 x 128 tiles (gemm_nt_w4h_kernel): 32 MFMAs per half-step -> one fragment read after every 2nd, one piece after every 3rd
+    for name, c in (("W4H_LOOP_ASM", Cfg(half=True, ds_every=2, dma_every=3)), ("W4HC_LOOP_ASM", Cfg(half=True, conv=True, ds_every=2, dma_every=3))):
+        cfg = c
+        lines = build()
+        check_scc(lines)
+        f.write("// %s: %d instructions\n" % (c.desc, len(lines)))
+        f.write("#define %s \\\n" % name)
+        for ln in lines:
+            f.write('  "%s\\n\\t" \\\n' % ln)
+        f.write('  ""\n')
     f.write("#define W4_VARIANTS %d\n" % len(VARIANTS))
     f.write("#define W4_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
+    f.write("#define W4H_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob + ["s100"]))
 print("wrote %s: %d variant(s)" % (args.out, len(VARIANTS)))

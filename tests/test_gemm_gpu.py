@@ -16,7 +16,7 @@ TOL = {"f32": 2e-5, "bf16": 1e-2}
 def tune(monkeypatch, key, value):
     """drn_tune(key, value) for the duration of one test (defaults restored afterwards)."""
     from drn_amd import _lib
-    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0}
+    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0, "nt_w4h": 128}
     _lib.check(_lib.lib().drn_tune(key.encode(), int(value)), "drn_tune")
     _RESTORE.append((key, defaults[key]))
 
@@ -741,3 +741,129 @@ def test_w4c_conv_kernel_stress_many_launches_stay_bit_identical(monkeypatch):
         torch.cuda.synchronize()
         bad += int(not torch.equal(outs[0][0], outs[1][0]) or (mode == 0 and not torch.equal(outs[0][1], outs[1][1])))
     assert bad == 0, "%d of 40 launches differ" % bad
+
+
+# ---- the 4-wave loop on 256 x 128 tiles (gemm_nt_w4h_kernel): launches that would run 128 x 128 tiles ------------------------------
+W4H_CASES = [
+    # levels [(B, L)], N, Cin (one int or one per level), taps, mode, bias, stats, gate, lda padding
+    ([(1, 256)], 128, 128, 1, 0, False, False, False, 0),            # two K-steps: the loop runs zero trips, only its tail
+    ([(2, 128)], 256, 192, 1, 0, True, True, False, 0),              # plain product, statistics, three K-steps
+    ([(4, 64), (2, 128)], 256, [256, 128], 1, 1, False, False, False, 0),   # grouped 1x1 data gradients, K differs per problem
+    ([(1, 256)], 128, 64, 3, 0, False, True, False, 0),              # k = 3: one K-step per tap, a tap switch after every staged item
+    ([(2, 128), (4, 64)], 256, 128, 3, 0, True, True, False, 0),     # two pyramid levels, sequences end inside the tiles
+    ([(2, 256), (2, 128), (8, 32)], 512, 128, 3, 1, False, False, False, 0),    # data gradient: the taps run the other way
+    ([(8, 32)], 128, 128, 3, 1, True, False, True, 0),
+    ([(2, 128)], 256, 128, 3, 0, True, False, True, 64),             # row stride != channels
+]
+
+
+def _w4h_launch(ops, case, flag, monkeypatch, seed=0):
+    levels, N, Cin, taps, mode, bias, stats, gate, pad = case
+    tune(monkeypatch, "nt_w4h", flag)
+    descs, keep, outs = [], [], []
+    for li, (B, L) in enumerate(levels):
+        cin = Cin[li] if isinstance(Cin, list) else Cin
+        M = B * L
+        A = rnd((M, cin + pad), 61 + li + seed, torch.bfloat16).to(dev())
+        W = (rnd((N, taps * cin), 71 + li + seed, torch.float32) * 0.05).to(torch.bfloat16).to(dev())
+        bias_t = rnd((N,), 81 + li, torch.float32).to(dev()) if bias else None
+        gate_t = torch.rand(B, N, generator=torch.Generator().manual_seed(44 + li)).to(dev()) if gate else None
+        C = torch.full((M, N), 7.0, device=dev(), dtype=torch.bfloat16)
+        st = torch.full((M // 128, 2, N), float("nan"), device=dev()) if stats else None
+        descs.append(ops.gemm_desc(A, W, C, M, N, cin, taps=taps, pad=1 if taps == 3 else 0, mode=mode, Lout=L, Lsrc=L, lda=cin + pad,
+                                   bias=bias_t, gate=gate_t, ldg=N, stats=st))
+        keep.append((A, W, bias_t, gate_t))
+        outs.append((C, st))
+    kind = ops.gemm_nt_plan(descs, ops.BF16)
+    ops.gemm_nt(descs, ops.BF16)
+    torch.cuda.synchronize()
+    return kind, outs, keep
+
+
+@pytest.mark.parametrize("case", W4H_CASES)
+def test_w4h_kernel_is_bit_identical_to_the_128_tile_kernel(monkeypatch, case):
+    """Same MFMAs, same K order per output element, same epilogue statements, BatchNorm statistics in nt_bn_stats<2, 4, 4, 2>'s
+    order: what the 4-wave 256 x 128 kernel writes equals what conv_gemm_nt_kernel<bf16, 2, true, 2, 4, 4, 2> writes, bit for bit."""
+    from drn_amd import ops
+    kind_h, outs_h, _ = _w4h_launch(ops, case, 1, monkeypatch)          # from ONE 256 x 128 tile on
+    kind_g, outs_g, keep = _w4h_launch(ops, case, 0, monkeypatch)
+    assert kind_h == ops.NT_KIND_W4H and kind_g == ops.NT_KIND_TILE128
+    for (Ch, sh), (Cg, sg) in zip(outs_h, outs_g):
+        assert torch.equal(Ch, Cg)
+        assert torch.isfinite(Ch.float()).all()
+        if sh is not None:
+            assert torch.equal(sh, sg)
+    # ... and close to the product itself (first level, plain cases without a gate)
+    levels, N, Cin, taps, mode, bias, stats, gate, pad = case
+    if taps == 1 and not gate:
+        A, W, bias_t, _ = keep[0]
+        cin = Cin[0] if isinstance(Cin, list) else Cin
+        ref = A[:, :cin].double().cpu() @ W.double().cpu().t() + (bias_t.double().cpu() if bias else 0.0)
+        close(outs_h[0][0], ref, TOL["bf16"] * 2, "w4h plain product")
+
+
+def test_w4h_conv_forward_matches_torch(monkeypatch):
+    from drn_amd import ops
+    B, L, Cin, Cout = 2, 128, 128, 256
+    x, w = conv_case("bf16", B, L, Cin, Cout, 3, 1)
+    ref = F.conv1d(x.double(), w.double(), padding=1).permute(0, 2, 1).reshape(B * L, Cout)
+    xd, wp = nlc(x).to(dev()), w.permute(0, 2, 1).contiguous().to(dev())
+    tune(monkeypatch, "nt_w4h", 1)
+    C = torch.empty(B * L, Cout, device=dev(), dtype=torch.bfloat16)
+    d = ops.gemm_desc(xd, wp, C, B * L, Cout, Cin, taps=3, pad=1, Lout=L, Lsrc=L)
+    assert ops.gemm_nt_plan([d], ops.BF16) == ops.NT_KIND_W4H
+    ops.gemm_nt([d], ops.BF16)
+    torch.cuda.synchronize()
+    close(C, ref, TOL["bf16"] * 2, "w4h conv forward")
+
+
+def test_w4h_kernel_takes_the_pyramid_launches_and_declines_the_rest(monkeypatch):
+    """With the shipped threshold (>= 128 tiles of 256 x 128) the grouped FPN / head launches of the benchmarked shape go to the
+    4-wave kernel; strided convolutions, fp32 destinations, short pyramids (Charades-STA's T = 32) and fp32 models do not."""
+    from drn_amd import ops
+    A = torch.zeros(8192, 1536, device=dev(), dtype=torch.bfloat16)
+    W = torch.zeros(1024, 3 * 1024, device=dev(), dtype=torch.bfloat16)
+    C = torch.zeros(8192, 1024, device=dev(), dtype=torch.bfloat16)
+
+    def levels(B, T, N, Cin, **kw):
+        return [ops.gemm_desc(A, W, C, B * (T >> l), N, Cin, Lout=T >> l, Lsrc=T >> l, lda=Cin, **kw) for l in range(3)]
+    assert ops.gemm_nt_plan(levels(32, 256, 512, 512, taps=3, pad=1), ops.BF16) == ops.NT_KIND_W4H          # FPN output convs
+    assert ops.gemm_nt_plan(levels(32, 256, 512, 512, taps=3, pad=1, mode=1), ops.BF16) == ops.NT_KIND_W4H  # ... their data gradient
+    assert ops.gemm_nt_plan(levels(32, 256, 512, 1024), ops.BF16) == ops.NT_KIND_W4H                          # mix_fc (1x1)
+    assert ops.gemm_nt_plan(levels(32, 256, 1024, 512, taps=3, pad=1), ops.BF16) == ops.NT_KIND_W4C          # the towers keep 256 x 256 tiles
+    assert ops.gemm_nt_plan(levels(32, 32, 512, 512, taps=3, pad=1), ops.BF16) == ops.NT_KIND_TILE128        # T = 32: 28 tiles
+    assert ops.gemm_nt_plan(levels(32, 256, 512, 512, taps=3, pad=1), ops.F32) == ops.NT_KIND_TILE128
+    d = ops.gemm_desc(A, W, C, 4096, 512, 256, taps=3, stride=2, pad=1, Lout=128, Lsrc=256, lda=256)             # conv1: stride 2
+    assert ops.gemm_nt_plan([d], ops.BF16) == ops.NT_KIND_TILE128
+    Cf = torch.zeros(8192, 512, device=dev(), dtype=torch.float32)
+    d = ops.gemm_desc(A, W, Cf, 8192, 512, 1024, out_f32=True)
+    assert ops.gemm_nt_plan([d] * 3, ops.BF16) == ops.NT_KIND_TILE128
+
+
+def test_w4h_kernel_stress_many_launches_stay_bit_identical(monkeypatch):
+    """40 back-to-back grouped launches on fresh data, forward (statistics on) and data gradient alternating, three levels with
+    sequences that end inside the tiles: each compared with the 128 x 128 kernel on the same inputs."""
+    from drn_amd import ops
+    N, Cin = 256, 128
+    levels = [(4, 128), (4, 64), (8, 32)]
+    g = torch.Generator(device="cuda").manual_seed(19)
+    bad = 0
+    for it in range(40):
+        mode = it & 1
+        data = [(torch.randn(B * L, Cin, generator=g, device=dev()).to(torch.bfloat16),
+                 (torch.randn(N, 3 * Cin, generator=g, device=dev()) * 0.05).to(torch.bfloat16)) for B, L in levels]
+        outs = []
+        for flag in (1, 0):
+            tune(monkeypatch, "nt_w4h", flag)
+            descs, res = [], []
+            for (B, L), (A, W) in zip(levels, data):
+                C = torch.empty(B * L, N, device=dev(), dtype=torch.bfloat16)
+                st = torch.empty(B * L // 128, 2, N, device=dev()) if mode == 0 else None
+                descs.append(ops.gemm_desc(A, W, C, B * L, N, Cin, taps=3, pad=1, mode=mode, Lout=L, Lsrc=L, stats=st))
+                res.append((C, st))
+            ops.gemm_nt(descs, ops.BF16)
+            outs.append(res)
+        torch.cuda.synchronize()
+        for (Ch, sh), (Cg, sg) in zip(*outs):
+            bad += int(not torch.equal(Ch, Cg) or (mode == 0 and not torch.equal(sh, sg)))
+    assert bad == 0, "%d level outputs of 40 launches differ" % bad
