@@ -324,22 +324,148 @@ class ForkedStep(DualStreamStep):
     linear graph: the MFMA kernels of two branches only take each other's CUs.  Results equal the single-stream step bit for bit
     (tests/test_graph_gpu.py)."""
 
-    def __init__(self, model, batch, loss_of, reducer, opt, split_gate=False, main=None, side=None):
+    def __init__(self, model, batch, loss_of, reducer, opt, split_gate=False, main=None, side=None, rotate=None):
         """main / side: the streams to capture on (default: new ones).  `main` must be the stream every earlier step of this
-        model ran on (autograd's AccumulateGrad nodes are bound to it)."""
+        model ran on (autograd's AccumulateGrad nodes are bound to it).
+        rotate (default: whenever the reducer keeps the query side's gradients in buckets of their own, i.e. was built with
+        groups=[model.query_parameters(), the rest]): OPTIMIZER-FIRST order.  A call applies the optimizer to the gradients the
+        PREVIOUS call left in the reducer's buckets and then runs forward + backward of its own batch:
+
+            main   norm -> Adam(query side) -> Adam(rest) + weight copies -> input prep -> (join) trunk fwd/bwd -> weight gradients
+            side                            \-> query encoder forward ---------------------/              \-> query side backward
+
+        so the query encoder's forward -- ~16 dependent, latency-bound launches, 130 us alone -- runs beside the ~200 us of
+        bandwidth-bound optimizer kernels, whose short-lived workgroups leave it room, instead of in front of the prop_fc GEMM,
+        which had to wait ~100 us for the gate (profiles/r05_*_forked_timeline.txt).  The sequence of operations over a run is the
+        one of the plain loop -- f0 b0 | o0 f1 b1 | o1 f2 b2 | ... | o_n -- bit for bit: the first call only computes gradients
+        (`prime`), `flush()` applies the pending update; read parameters (evaluation, checkpoints) only after a flush."""
         model.split_gate = bool(split_gate)
         self._streams = (main, side)
+        qp = set(id(p) for p in model.query_parameters())
+        gb = getattr(reducer, "group_buckets", [])
+        can = len(gb) >= 2 and len(gb[0]) >= 1 and all(id(p) in qp for b in gb[0] for p in b.params) and \
+            not any(id(p) in qp for g in gb[1:] for b in g for p in b.params)
+        if rotate and not can:
+            raise ValueError("ForkedStep(rotate=True) needs GradReducer(groups=[model.query_parameters(), the other parameters])")
+        self.rotate = can if rotate is None else bool(rotate)
+        self._primed = False
+        import os
+        if os.environ.get("DRN_FORK_ROTATE") is not None:              # experiment switches (scripts/experiments/ab_r05_c.sh)
+            self.rotate = can and os.environ["DRN_FORK_ROTATE"] == "1"
+        self._env_wf = os.environ.get("DRN_FORK_WGRADS_FIRST")
+        self._env_mf = os.environ.get("DRN_FORK_MAIN_FIRST")
         # (side stream from the DEFAULT-priority pool: high-priority streams bring a second set of hardware queues into being, and
         # with them around everything else in the process that uses two streams ran slower afterwards -- the trainer's H2D
         # look-ahead 12.9 -> 9.0 k clips/s, evaluation 22 -> 15 k, measured in bench.py after a capture on priority -1 streams)
         super(ForkedStep, self).__init__(model, batch, loss_of, reducer, opt, wgrads_first=False, side_priority=0)
+        if self._env_wf is not None:
+            self.wgrads_first = self._env_wf == "1"
+        if self._env_mf is not None:
+            self.main_first = self._env_mf == "1"
         if self._streams[0] is not None:
             self.main = self._streams[0]
         if self._streams[1] is not None:
             self.side = self._streams[1]
         self.graph = None
 
+    # ---- optimizer-first order
+    def _phase(self, name):
+        red = self.reducer
+        if name == "norm":
+            self.opt.norm()
+        elif name == "opt_q":
+            self.opt.update(red.group_buckets[0])
+            self.opt.repack(codes=(0,), buckets=red.group_buckets[0])          # ops.F32: the query side's stacks
+        elif name == "opt_rest":
+            rest = [b for g in red.group_buckets[1:] for b in g]
+            self.opt.update(rest)
+            self.opt.repack(buckets=rest)
+        elif name == "collect":
+            red.finish()                                     # (one process: gradients produced outside their sinks are moved in)
+        else:
+            super(ForkedStep, self)._phase(name)
+
+    def _schedule(self, run, M, Q):
+        if not self.rotate:
+            return super(ForkedStep, self)._schedule(run, M, Q)
+        ev = self._ev
+        ev.setdefault("optq", torch.cuda.Event())
+        if self._fresh:                       # first step on these streams: the side stream starts behind everything queued so far
+            ev["start"].record(M)
+            Q.wait_event(ev["start"])
+            self._fresh = False
+        if self.main_first:                   # issue order: the main branch's launches ahead of the side branch's wherever both are ready
+            with torch.cuda.stream(M):
+                if self._primed:
+                    run("norm")
+                    run("opt_q")
+                    ev["optq"].record(M)
+                    run("opt_rest")
+                run("prep")
+            with torch.cuda.stream(Q):
+                if self._primed:
+                    Q.wait_event(ev["optq"])
+                run("q_fwd")
+                ev["q_fwd"].record(Q)
+            with torch.cuda.stream(M):
+                M.wait_event(ev["q_fwd"])
+                run("trunk")
+                ev["trunk"].record(M)
+                run("wgrads")
+            with torch.cuda.stream(Q):
+                Q.wait_event(ev["trunk"])
+                run("q_bwd")
+                ev["q_bwd"].record(Q)
+            with torch.cuda.stream(M):
+                M.wait_event(ev["q_bwd"])
+                run("collect")
+            self._primed = True
+            return
+        with torch.cuda.stream(M):
+            if self._primed:                  # the update the previous call's gradients are waiting for
+                run("norm")
+                run("opt_q")
+                ev["optq"].record(M)
+        with torch.cuda.stream(Q):
+            if self._primed:
+                Q.wait_event(ev["optq"])
+            run("q_fwd")
+            ev["q_fwd"].record(Q)
+        with torch.cuda.stream(M):
+            if self._primed:
+                run("opt_rest")
+            run("prep")
+            M.wait_event(ev["q_fwd"])
+            run("trunk")
+            ev["trunk"].record(M)
+        with torch.cuda.stream(Q):
+            Q.wait_event(ev["trunk"])
+            run("q_bwd")
+            ev["q_bwd"].record(Q)
+        with torch.cuda.stream(M):
+            run("wgrads")
+            M.wait_event(ev["q_bwd"])
+            run("collect")
+        self._primed = True
+
+    def flush(self):
+        """Apply the update the last call's gradients are waiting for (optimizer-first order; a no-op otherwise and when nothing
+        is pending).  Eager launches on the main stream; the next call primes again."""
+        if not (self.rotate and self._primed):
+            return
+        cur = torch.cuda.current_stream()
+        self.main.wait_stream(cur)
+        self.main.wait_stream(self.side)
+        with torch.cuda.stream(self.main):
+            for name in ("norm", "opt_q", "opt_rest"):
+                self._phase(name)
+        cur.wait_stream(self.main)
+        self._primed = False
+        self._fresh = True
+
     def _capture_once(self, pool=None):
+        if self.rotate and not self._primed:
+            self.warm(1)                                     # the captured step starts with an update: there must be gradients
         g = torch.cuda.CUDAGraph()
         self._fresh = True
         with capture_graph(g, self.main, **({"pool": pool} if pool is not None else {})):
@@ -388,7 +514,7 @@ class ForkedStep(DualStreamStep):
         return self
 
     def __call__(self):
-        if self.graph is None:
+        if self.graph is None or (self.rotate and not self._primed):       # (after a flush(): the replay starts with an update)
             self.warm(1)
             return self.out
         self.graph.replay()

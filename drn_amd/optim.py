@@ -71,6 +71,14 @@ class FusedAdam(object):
     def step(self, repack=True):
         """repack=False leaves the refresh of the re-laid weight copies to the caller (`repack(codes)`), who may split it
         over two points of its schedule (drn_amd.graph.DualStreamStep)."""
+        self.norm()
+        self.update()
+        if repack:
+            self.repack()
+
+    def norm(self):
+        """First half of a step: the squared global gradient norm over ALL buckets (+ the device-side step counter).  `update()`
+        calls may follow in any split: every one of them clips with this norm and uses this step number."""
         self._check_ptrs()
         L = lib()
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -82,13 +90,22 @@ class FusedAdam(object):
         check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), ctypes.c_float(self.grad_scale), s),
               "drn_sumsq_finalize")
         self._refresh_mirrors()
-        for b, st in zip(self.reducer.buckets, self.state):
+
+    def update(self, buckets=None):
+        """Second half: clip + Adam on the given buckets of the reducer (all by default), the re-laid copies the kernels maintain
+        included.  A caller may update one part of the model early -- the query side, whose next forward pass can then start
+        while the rest is still being updated (drn_amd.graph.ForkedStep, optimizer-first order)."""
+        L = lib()
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        todo = [(b, st) for b, st in zip(self.reducer.buckets, self.state) if buckets is None or any(b is x for x in buckets)]
+        for b, st in todo:
             check(L.drn_adam_bucket(P(b.flat), P(st["m"]), P(st["v"]), ctypes.c_int64(b.flat.numel()), P(st["seg"]), P(st["ptr"]),
                                     st["nseg"], P(st["blk_seg"]), P(st.get("mirror")), P(self.total_sumsq), P(self.step_counter),
                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                                     ctypes.c_float(self.eps), ctypes.c_float(self.max_norm), ctypes.c_float(self.grad_scale), s),
                       "drn_adam_bucket")
-        for b, st in zip(self.reducer.buckets, self.state):
+        for b, st in todo:
             if st.get("tiled") is not None:
                 raw, bi, bt, nb = st["tiled"]
                 check(L.drn_adam_tiled(P(b.flat), P(st["m"]), P(st["v"]), P(raw), P(bi), P(bt), nb, P(self.total_sumsq),
@@ -96,12 +113,12 @@ class FusedAdam(object):
                                        ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps), ctypes.c_float(self.max_norm),
                                        ctypes.c_float(self.grad_scale), s), "drn_adam_tiled")
         DF.bump_weights_epoch(self.stores)       # parameters changed behind autograd's version counters
-        if repack:
-            self.repack()
 
-    def repack(self, codes=None):
-        """Refresh the other GEMM-layout copies of the weights (one launch per dtype; `codes`: only these dtypes)."""
-        DF.repack_all(skip=self._mirror_keys, codes=codes, updated=self._updated, stores=self.stores)
+    def repack(self, codes=None, buckets=None):
+        """Refresh the other GEMM-layout copies of the weights (one launch per dtype; `codes`: only these dtypes; `buckets`: only
+        the copies of the parameters in these buckets changed -- the rest are marked current)."""
+        updated = self._updated if buckets is None else frozenset(p.data_ptr() for b in buckets for p in b.params)
+        DF.repack_all(skip=self._mirror_keys, codes=codes, updated=updated, stores=self.stores)
 
     def _refresh_mirrors(self):
         """Device tables of the cached GEMM operands the optimizer kernels rewrite themselves while they hold the new value:

@@ -13,7 +13,7 @@ rows = list(db.execute("select name, start, end, grid_x, workgroup_x, grid_y, gr
 marks = [i for i, r in enumerate(rows) if r[0].startswith("adam_bucket_kernel")]
 bursts = [i for k, i in enumerate(marks) if k + 1 == len(marks) or marks[k + 1] != i + 1]
 step = rows[bursts[-2] + 1:bursts[-1] + 1]
-is_gemm = lambda n: "conv_gemm_nt_kernel" in n or "conv_wgrad" in n or "gemm_nt_w4_kernel" in n or "gemm_nt_w4c_kernel" in n
+is_gemm = lambda n: "conv_gemm_nt_kernel" in n or "conv_wgrad" in n or "gemm_nt_w4_kernel" in n or "gemm_nt_w4c_kernel" in n or "gemm_nt_w4h_kernel" in n
 # a weight gradient with a separate reduce pass is ONE tagged launch followed by its wgrad_reduce kernel(s): fold them in
 launches = []
 for n, s, e, gx, wx, gy, gz in step:
