@@ -316,8 +316,12 @@ def main():
     # Eager mode overlaps 32 MB bucket all-reduces with backward from post-accumulate-grad hooks.
     deferred = args.graph and world > 1
     if deferred:
+        # four parts, one bucket each, in the order backward finishes them: trunk (41 MB), input stage (prop_fc: 67 MB), gate
+        # projections (20 MB), query encoder (25 MB) -- each travels while the next part's backward replays; only the last is
+        # exposed by construction (round 5: the query side's 45 MB used to be one exposed bucket)
         reducer = ddist.GradReducer(params, world_size=world, overlap=False, bucket_bytes=1 << 30,
-                                    groups=[model.trunk_parameters(), model.input_parameters(), model.query_parameters()],
+                                    groups=[model.trunk_parameters(), model.input_parameters(), model.gate_parameters(),
+                                            model.encoder_parameters()],
                                     adjacent=model.grad_stack_groups())
     else:
         # one process: nothing to overlap, so ONE bucket (one norm pass + one Adam launch instead of one pair per 32 MB)
@@ -333,12 +337,13 @@ def main():
     loss_of = lambda losses: losses["loss_iou"] if stage == 2 else DF.loss_total(losses)             # main.py:222-225
 
     ar_events = None                 # N>1: HIP events around the exchange wait of every timed step (exposed all-reduce time)
+    ar_bucket_events = []            # ... and around each bucket's own wait (bucket index, start, end)
 
     def opt_step():
         if ar_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            reducer.finish()
+            reducer.finish(timings=ar_bucket_events)
             e1.record()
             ar_events.append((e0, e1))
         else:
@@ -430,7 +435,8 @@ def main():
                 for _ in range(max(args.warmup, 2)):
                     run()
                 core.capture()
-                mode = "hipGraph replay of forward+backward in three phases; trunk / prop_fc all-reduces overlap the next phase; optimizer eager"
+                mode = ("hipGraph replay of forward+backward in %d phases; each part's all-reduce (trunk / prop_fc / gate projections) "
+                        "overlaps the next phase; optimizer eager" % core.NPHASES)
             run()
         except Exception as e:                                          # keep the eager path measurable
             print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, str(e).split(chr(10))[0]), file=sys.stderr)
@@ -451,6 +457,11 @@ def main():
     dt = time.perf_counter() - t0
     note("timed loop done")
     exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
+    exposed_by_bucket = {}
+    for i, a, b in ar_bucket_events:
+        exposed_by_bucket[i] = exposed_by_bucket.get(i, 0.0) + a.elapsed_time(b)
+    n_timed = max(len(ar_events), 1) if ar_events else 1
+    exposed_by_bucket = [round(exposed_by_bucket.get(i, 0.0) / n_timed, 4) for i in range(len(reducer.buckets))]
     ar_events = None
     # the same step launched kernel by kernel from Python (what the hipGraph replay saves): wall clock over a few steps
     eager_ms = None
@@ -480,13 +491,19 @@ def main():
                 json.dump([[t[0], t[1]] for t in timers[-per:]], f)
     per_rank = None
     if world > 1:
-        mine = torch.tensor([dt, exposed_ms], device=dev, dtype=torch.float64)
+        mine = torch.tensor([dt, exposed_ms] + exposed_by_bucket, device=dev, dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)
         per_rank = {"clips_per_s": [round(B * args.steps / float(t[0]), 1) for t in allr],
                     "allreduce_exposed_ms_per_step": [round(float(t[1]), 4) for t in allr],
-                    "note": "exposed = GPU time the step's stream waits in GradReducer.finish() (query-side bucket + whatever of the "
-                            "trunk / prop_fc exchanges the next phase did not hide), HIP events"}
+                    "exposed_ms_by_bucket": {"buckets": ["%s (%.0f MB)" % (nm, b.flat.numel() * 4 / 1e6) for nm, b in
+                                                         zip(("trunk", "input stage", "gate projections", "query encoder")
+                                                             if deferred else ["bucket %d" % i for i in range(len(reducer.buckets))],
+                                                             reducer.buckets)],
+                                             "max_over_ranks": [round(max(float(t[2 + i]) for t in allr), 4) for i in range(len(reducer.buckets))]},
+                    "note": "exposed = GPU time the step's stream waits in GradReducer.finish(): per bucket, HIP events around that "
+                            "bucket's wait (the exchanges are launched after the phase that produces them and overlap the next phase's "
+                            "replay; the last bucket has nothing to hide behind)"}
         dt = max(float(t[0]) for t in allr)
         note("per-rank gather done")
     ms = dt / args.steps * 1e3
@@ -541,6 +558,42 @@ def main():
         except Exception as e:
             print("f32 timing failed: %s" % e, file=sys.stderr)
 
+    # the same step fed with features ALREADY in the compute dtype (what train.py's DataLoader hands a bf16 model): no cast pass,
+    # only the K-major copy for the prop_fc weight gradient is produced -- the headline's fp32 hand-over (the reference's dtype) costs
+    # the cast_transpose pass on top.  Linear graph on both sides (`launch_ab.linear_ms` is the fp32-input twin).
+    bf16_feat = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and args.graph and not args.torch_adam and not args.no_kernel_timing:
+        try:
+            from drn_amd.optim import FusedAdam
+            mb = build(mainModel, cfg, dev, compute_dtype=cdt)
+            pb = stage_params(mb, stage)
+            mb.train()
+            rb = ddist.GradReducer(pb, world_size=1, overlap=True, adjacent=mb.grad_stack_groups(), bucket_bytes=1 << 30)
+            ob = FusedAdam(rb, lr=1e-3, max_norm=0.5)
+            batch_b = list(batch)
+            batch_b[2] = batch[2].to(cdt)
+
+            def step_b(feed):
+                def fn():
+                    rb.zero()
+                    _, ls = mb(*feed)
+                    DF.backward(loss_of(ls))
+                    rb.finish()
+                    ob.step()
+                    return ls
+                return fn
+            tb = time_graph(step_b(batch_b), reps=min(args.steps, 20))
+            tf = time_graph(step_b(batch), reps=min(args.steps, 20))
+            bf16_feat = {"ms_per_step": round(tb, 3), "clips_per_s": round(B / (tb * 1e-3), 1), "fp32_features_ms_per_step": round(tf, 3),
+                         "handover_cost_us": round((tf - tb) * 1e3, 1),
+                         "note": "one linear hipGraph each, same model: features handed over in bf16 (B x T x D x 2 bytes, rounded by the "
+                                 "rule the step's cast applies) vs in fp32 (the headline's and the reference's hand-over); the difference "
+                                 "is the cast half of cast_transpose_kernel, a hand-over cost, not kernel time of the path"}
+            rb.remove()
+            del mb, ob, rb, batch_b
+        except Exception as e:
+            print("bf16-features timing failed: %s" % e, file=sys.stderr)
+
     roof = None
     if timers:
         agg = {}
@@ -567,8 +620,19 @@ def main():
                 traffic_note = "bytes/launch from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes); %s" % ent["served_by"]
         except (OSError, ValueError, KeyError):
             pass
+        # the same launch INSIDE the replayed graph (what the timed steps run): from the committed rocprofv3 kernel trace of this
+        # command (profiles/gemm_in_graph.json, written by scripts/prof_round.sh -> scripts/gemm_table.py), when there is one
+        in_graph = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "gemm_in_graph.json")) as f:
+                ent = json.load(f).get(tag)
+            if ent:
+                in_graph = {"us": ent["us"], "achieved": ent["TFLOP/s"], "frac": ent["frac"],
+                            "source": "profiles/gemm_in_graph.json (rocprofv3 --kernel-trace of the replayed step, scripts/gemm_table.py)"}
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic, "traffic_note": traffic_note,
+                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "in_graph": in_graph, "traffic": traffic, "traffic_note": traffic_note,
                 "avg_launch_ms_eager": round(avg_ms, 4),
                 "launches_per_step": n // timed_steps, "mfma_kernels_ms_per_step_eager": round(gemm_ms, 3),
                 "note": "dominant kernel by total time; flops = 2*M*N*K of that launch; `*_eager` figures (and `achieved`, `frac`) are "
@@ -608,6 +672,8 @@ def main():
         out["per_rank"] = per_rank
     if f32_line is not None:
         out["f32"] = f32_line
+    if bf16_feat is not None:
+        out["bf16_features"] = bf16_feat
     if rank == 0 and world == 1 and args.other_configs and args.graph and not args.torch_adam:
         try:
             out["other_configs"] = other_config_lines(dev)

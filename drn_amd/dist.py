@@ -261,13 +261,23 @@ class GradReducer(object):
             if not b.launched:
                 self._launch(b)
 
-    def wait(self):
-        """Wait for all collectives and turn sums into means (unless the optimizer does that: `defer_average`)."""
+    def wait(self, timings=None):
+        """Wait for all collectives and turn sums into means (unless the optimizer does that: `defer_average`).
+        timings: a list that receives, per bucket in bucket order, (bucket index, start event, end event) recorded on the
+        current stream around that bucket's wait -- the time the step's stream is held up by each exchange (bench.py's
+        per-bucket `exposed_ms`); CUDA tensors only."""
         if self.world > 1:
-            for b in self.buckets:
+            for i, b in enumerate(self.buckets):
                 if b.handle is not None:
+                    ev = None
+                    if timings is not None and b.flat.is_cuda:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record()
                     b.handle.wait()
                     b.handle = None
+                    if ev is not None:
+                        ev[1].record()
+                        timings.append((i, ev[0], ev[1]))
                     if not self.defer_average:
                         b.flat.div_(self.world)
 
@@ -276,12 +286,12 @@ class GradReducer(object):
         for b in self.buckets:
             b.launched, b.handle = False, None
 
-    def finish(self):
+    def finish(self, timings=None):
         """Call after backward: collect(), reduce the buckets that are not in flight yet (those whose parameters got no
-        gradient this step contribute zeros), wait for all collectives and turn sums into means."""
+        gradient this step contribute zeros), wait for all collectives and turn sums into means.  timings: see wait()."""
         self.collect()
         self.reduce()
-        self.wait()
+        self.wait(timings)
 
     def remove(self):
         for h in self._hooks:

@@ -1604,6 +1604,50 @@ def query_encoder(tokens, lengths, enc, gate_linears=None, lowp=False):
                                  enc.cmd_inter2logits.weight, enc.cmd_inter2logits.bias, *extra)
 
 
+class _GateProjFn(torch.autograd.Function):
+    """mainModel's three per-level gate projections gate_t = qInput{t}(cmd_t) (model/main_model.py:47-50) as a node of their own:
+    the same two launches `_QueryEncoderFn` spends on them when they ride inside it (one grouped skinny product each way, their
+    weight / bias gradients in one outer-product launch), but with the commands as a cut point in the autograd graph -- the
+    multi-GPU step (drn_amd.graph.TwoPhaseStep, four phases) sends the projections' 20 MB of gradients on their way while the
+    query encoder's backward is still replaying."""
+
+    @staticmethod
+    def forward(ctx, c0, c1, c2, W0, b0, W1, b1, W2, b2):
+        cmds = [c.contiguous().float() for c in (c0, c1, c2)]
+        ctx.save_for_backward(*cmds, W0, b0, W1, b1, W2, b2)
+        return tuple(ops.skinny_group([dict(X=cmds[t], W=W.detach(), bias=b.detach()) for t, (W, b) in enumerate(((W0, b0), (W1, b1), (W2, b2)))]))
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        sv = ctx.saved_tensors
+        cmds, Ws, bs = sv[:3], sv[3::2], sv[4::2]
+        douts = [None if d is None else d.contiguous().float() for d in (d0, d1, d2)]
+        live = [t for t in range(3) if douts[t] is not None]
+        dc = ops.skinny_group([dict(X=douts[t], W=packed(Ws[t], (1, 2, 0), ops.F32)) for t in live]) if live else []
+        dcmds = [None] * 3
+        for t, d in zip(live, dc):
+            dcmds[t] = d
+        leaves, grads = [], []
+        for t in range(3):
+            if douts[t] is None:
+                grads += [torch.zeros_like(Ws[t]), torch.zeros_like(bs[t])]
+            else:
+                dW, db = grad_buffer(Ws[t]), grad_buffer(bs[t])
+                leaves.append(dict(dY=douts[t], X=cmds[t], dW=dW, db=db))
+                grads += [dW, db]
+        if leaves:
+            ops.outer_wgrad(leaves)
+        return tuple(dcmds) + tuple(grads)
+
+
+def gate_projections(cmds, linears):
+    """cmds: the query encoder's three (B, 2H) commands; linears: mainModel's three qInput{t} nn.Linear holders."""
+    args = []
+    for lin in linears:
+        args += [lin.weight, lin.bias]
+    return list(_GateProjFn.apply(cmds[0], cmds[1], cmds[2], *args))
+
+
 class _LGPFn(torch.autograd.Function):
     """Language-guided pooling (model/LGP.py:29-51).  The 1x1 conv on the tiled query is one (B, Cq)x(Cq, C) product and
     its train-mode BN sees B*t samples that repeat t times, i.e. batch statistics over B (unbiased factor from B*t):

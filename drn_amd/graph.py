@@ -85,7 +85,13 @@ class TwoPhaseStep(object):
     NPHASES = 3
 
     def __init__(self, model, batch, loss_of, reducer, between=None):
+        """A reducer built with FOUR groups -- [trunk, input stage, model.gate_parameters(), model.encoder_parameters()] -- splits
+        the last phase in two (round 5): phase 3 = backward of the gate projections (20 MB of gradients), phase 4 = backward of
+        the query encoder (25 MB); the projections' bucket then travels while the query encoder's backward (~0.15 ms of BiLSTM
+        steps) replays, and only the encoder's own bucket is left exposed.  Same kernels on the same values as the three-phase
+        split (the projections run as their own autograd node, DF.gate_projections)."""
         self.model, self.batch, self.loss_of, self.reducer, self.between = model, batch, loss_of, reducer, between
+        self.NPHASES = 4 if len(getattr(reducer, "group_buckets", [])) == 4 else 3
         self.stream = torch.cuda.Stream()
         self.graphs = None
         self.out = None
@@ -96,21 +102,32 @@ class TwoPhaseStep(object):
         if k == 0:
             tok, qlen, feats, pse, gt = self.batch[:5]
             red.zero()
-            gates = m.encode_query(tok, qlen)
+            cmds = cd = None
+            if self.NPHASES == 4:
+                cmds = m.encode_commands(tok, qlen)
+                cd = [c.detach().requires_grad_() for c in cmds]
+                gates = m.project_gates(cd)
+            else:
+                gates = m.encode_query(tok, qlen)
             gd = [g.detach().requires_grad_() for g in gates]
             g0, _ = m.forward_front(tok, qlen, feats, pse, gates=gd)
             g0d = g0.detach().requires_grad_()
             g0d._drn_tail = getattr(g0, "_drn_tail", None)        # (conv0's backward produces the position-embedding gradients)
             _, losses = m.forward_trunk(g0d, gd, gt)
             DF.backward(self.loss_of(losses))                     # trunk parameters, g0d.grad, gd[1:].grad
-            self._carry = (g0, g0d, gates, gd)
+            self._carry = (g0, g0d, gates, gd, cmds, cd)
             self.out = losses
         elif k == 1:
-            g0, g0d, gates, gd = self._carry
+            g0, g0d, gates, gd, cmds, cd = self._carry
             torch.autograd.backward([g0], [g0d.grad])             # prop_fc, position_transform, gd[0].grad
+        elif k == 2:
+            g0, g0d, gates, gd, cmds, cd = self._carry
+            torch.autograd.backward(list(gates), [g.grad for g in gd])     # gate projections (, query encoder: three phases)
+            if self.NPHASES == 3:
+                self._carry = None
         else:
-            g0, g0d, gates, gd = self._carry
-            torch.autograd.backward(list(gates), [g.grad for g in gd])     # gate projections, query encoder
+            g0, g0d, gates, gd, cmds, cd = self._carry
+            torch.autograd.backward(list(cmds), [c.grad for c in cd])      # query encoder
             self._carry = None
         red.collect(red.group_buckets[k])
 

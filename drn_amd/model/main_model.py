@@ -54,6 +54,22 @@ class mainModel(nn.Module):
         self.compute_dtype = dtype
         return self
 
+    def encode_commands(self, query_tokens, query_length):
+        """The query encoder alone: its three (B, 2H) commands (model/language_module.py:38-63), one autograd node."""
+        return list(DF.query_encoder(query_tokens, query_length, self.query_encoder, None, lowp=self.compute_dtype == torch.bfloat16))
+
+    def project_gates(self, cmds):
+        """The per-level gate projections on given commands (model/main_model.py:47-50), one autograd node (DF.gate_projections):
+        encode_query == project_gates(encode_commands(...)), value for value, with the commands as a cut point for schedules that
+        exchange the projections' gradients early (drn_amd.graph.TwoPhaseStep)."""
+        return DF.gate_projections(cmds, [getattr(self, "qInput%d" % i) for i in range(3)])
+
+    def gate_parameters(self):
+        return [p for t in range(len(self.backbone_net.blocks)) for p in getattr(self, "qInput%d" % t).parameters()]
+
+    def encoder_parameters(self):
+        return list(self.query_encoder.parameters())
+
     def encode_query(self, query_tokens, query_length):
         """Query encoder + per-level gate projections (model/main_model.py:47-50): three (B, C_l) fp32 gate tensors."""
         n = len(self.backbone_net.blocks)

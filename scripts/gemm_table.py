@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-GEMM table of ONE replayed step: joins the MFMA launches of a step in launch order (bench.py --dump-gemms: tag with the
 shape, FLOPs) with the durations of the same launches inside the replayed hipGraph (rocprofv3 --kernel-trace rocpd DB).
-usage: python scripts/gemm_table.py <results.db> <gemms.json> [peak TFLOP/s = 2500]"""
+usage: python scripts/gemm_table.py <results.db> <gemms.json> [peak TFLOP/s = 2500] [out.json: {tag: {us, TFLOP/s, frac}}, read by
+bench.py for `roofline.in_graph`]"""
 import json
 import sqlite3
 import sys
@@ -31,5 +32,10 @@ for i, ((tag, fl), (n, us, wgs, red)) in enumerate(zip(gemms, launches)):
     tot_us += us + red
     tot_fl += fl
     print("%-3d %-58s %7d %8.1f %8.1f %7.0f %5.1f%%" % (i, tag[:58], wgs, us, red, tf, 100.0 * tf / peak))
+if len(sys.argv) > 4:
+    out = {}
+    for (tag, fl), (n, us, wgs, red) in zip(gemms, launches):
+        out[tag] = {"us": round(us, 1), "reduce_us": round(red, 1), "TFLOP/s": round(fl / (us * 1e-6) / 1e12, 1), "frac": round(fl / (us * 1e-6) / 1e12 / peak, 4)}
+    json.dump(out, open(sys.argv[4], "w"), indent=0)
 print("# total %.1f us (reduce passes included), %.1f GFLOP, %.0f TFLOP/s = %.1f %% of peak"
       % (tot_us, tot_fl / 1e9, tot_fl / (tot_us * 1e-6) / 1e12, 100.0 * tot_fl / (tot_us * 1e-6) / 1e12 / peak))

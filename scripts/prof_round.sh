@@ -16,7 +16,7 @@ cd $GRAFT_REPO_ROOT
 python bench.py --dump-gemms $OUT/gemms.json > $OUT/bench_default.json 2> $OUT/bench_default.err
 python scripts/rocprof_summary.py $OUT/trace/t_results.db 35 > $OUT/kernel_stats.txt
 python scripts/rocprof_step.py $OUT/trace/t_results.db > $OUT/step_kernel_sequence.txt
-python scripts/gemm_table.py $OUT/trace/t_results.db $OUT/gemms.json > $OUT/gemm_table.txt 2> $OUT/gemm_table.err
+python scripts/gemm_table.py $OUT/trace/t_results.db $OUT/gemms.json 2500 $OUT/gemm_in_graph.json > $OUT/gemm_table.txt 2> $OUT/gemm_table.err
 python scripts/pmc_hbm_table.py $OUT/trace/t_results.db $OUT/fetch/f_results.db $OUT/write/w_results.db $OUT/pmc_traffic.json > $OUT/hbm_kernels.txt 2> $OUT/hbm_kernels.err
 rm -rf $OUT/trace $OUT/fetch $OUT/write
 tail -3 $OUT/step_kernel_sequence.txt; head -30 $OUT/hbm_kernels.txt; cat $OUT/hbm_kernels.err | tail -5; cat $OUT/bench_default.json | head -c 400

@@ -134,6 +134,65 @@ def test_grad_reducer_groups_two_phase_world2_gloo():
     assert got == [(0, "ok"), (1, "ok")]
 
 
+def _worker_four_groups(rank, world, port, q):
+    """bench.py's N > 1 layout in miniature: four bucket groups reduced one after the other while the next part's backward runs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from drn_amd.dist import GradReducer, init_from_env
+    init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    parts = [torch.nn.Linear(16, 24), torch.nn.Linear(24, 20), torch.nn.Linear(20, 12), torch.nn.Linear(12, 4)]     # encoder .. trunk
+    params = [p for m in parts for p in m.parameters()]
+    red = GradReducer(params, world_size=world, overlap=False, bucket_bytes=1 << 30, groups=[list(m.parameters()) for m in parts[::-1]])
+    assert [len(g) for g in red.group_buckets] == [1, 1, 1, 1]
+    for it in range(2):
+        x = torch.randn(5, 16, generator=torch.Generator().manual_seed(100 * it + rank))
+        red.zero()
+        red.rearm()
+        acts, cuts = [], []
+        h = x
+        for m in parts:
+            h = m(h)
+            acts.append(h)
+            h = h.detach().requires_grad_()
+            cuts.append(h)
+        acts[-1].pow(2).sum().backward()                      # the last part (group 0)
+        for k in range(4):
+            red.collect(red.group_buckets[k])
+            if k < 3:
+                red.reduce(red.group_buckets[k])              # in flight while the next part's backward runs
+                assert red.group_buckets[k][0].launched and not red.group_buckets[k + 1][0].launched
+                torch.autograd.backward([acts[2 - k]], [cuts[2 - k].grad])
+        tm = []
+        red.finish(timings=tm)
+        assert tm == []                                       # (CPU tensors: nothing to time with device events)
+        got = [p.grad.clone() for p in params]
+        acc = None
+        for r in range(world):
+            x = torch.randn(5, 16, generator=torch.Generator().manual_seed(100 * it + r))
+            for p in params:
+                p.grad = None
+            torch.nn.Sequential(*parts)(x).pow(2).sum().backward()
+            gs = [p.grad.clone() for p in params]
+            acc = gs if acc is None else [a + b for a, b in zip(acc, gs)]
+        for a, b in zip(acc, got):
+            assert torch.allclose(a / world, b, atol=1e-6), (it, float((a / world - b).abs().max()))
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_four_groups_world2_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_four_groups, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
 def test_adjacent_groups_are_contiguous_in_the_bucket():
     """GradReducer(adjacent=[[a, b], ...]): the members of a group occupy consecutive slices of one flat bucket in the given
     order (no alignment padding between them), whatever their position in the parameter list; everything is still

@@ -69,8 +69,9 @@ def _worker(rank, world, port, q, case):
         def make(graph):
             m = build()
             params = [p for p in m.parameters() if p.requires_grad]
+            # bench.py's N > 1 layout: four parts, the gate projections' bucket exchanged during the query encoder's backward
             red = GradReducer(params, world_size=world, overlap=False, bucket_bytes=1 << 30,
-                              groups=[m.trunk_parameters(), m.input_parameters(), m.query_parameters()],
+                              groups=[m.trunk_parameters(), m.input_parameters(), m.gate_parameters(), m.encoder_parameters()],
                               adjacent=m.grad_stack_groups())
             opt = FusedAdam(red, lr=1e-3, max_norm=0.5)
             core = TwoPhaseStep(m, batches[rank][:5], loss_of, red, between=lambda k: red.reduce(red.group_buckets[k]))
@@ -78,7 +79,10 @@ def _worker(rank, world, port, q, case):
             def fwd_bwd_exchange():
                 red.rearm()
                 losses = core()
-                red.finish()
+                assert core.NPHASES == 4
+                tm = []
+                red.finish(timings=tm)
+                assert [i for i, _, _ in tm] == list(range(len(red.buckets)))      # every bucket's wait is timed, in bucket order
                 return losses
             return m, red, opt, core, fwd_bwd_exchange
 

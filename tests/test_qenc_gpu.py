@@ -256,3 +256,31 @@ def test_query_side_with_gate_projections_matches_oracle():
     for k, p in mod.named_parameters():
         if not k.startswith("textualAttention"):
             _close(p.grad, refp[k].grad, 2e-4, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gate_projections_as_their_own_node_equal_the_fused_query_side(dtype):
+    """mainModel.project_gates(encode_commands(...)) -- the cut the four-phase multi-GPU step makes so that the projections' gradients
+    travel during the query encoder's backward -- against encode_query(...) (one node): gates and every parameter gradient of the
+    query side, bit for bit."""
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import VOCAB_SIZE, as_namespace, default_cfg, seeded_state_dict, synthetic_batch
+    dev = "cuda:0"
+    tok, qlen = [b.to(dev) for b in synthetic_batch(8, 32, 64, seed=3)[:2]]
+    res = []
+    for split in (False, True):
+        m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY", 64, 1)), compute_dtype=dtype)
+        m.load_state_dict(seeded_state_dict(m, 0))
+        m = m.to(dev).train()
+        gates = m.project_gates(m.encode_commands(tok, qlen)) if split else m.encode_query(tok, qlen)
+        g = torch.Generator(device=dev).manual_seed(5)
+        loss = sum((gt * torch.randn(gt.shape, generator=g, device=dev)).sum() for gt in gates)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append(([gt.detach().clone() for gt in gates],
+                    {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 20
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
