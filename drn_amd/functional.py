@@ -1612,8 +1612,9 @@ class _GateProjFn(torch.autograd.Function):
     query encoder's backward is still replaying."""
 
     @staticmethod
-    def forward(ctx, c0, c1, c2, W0, b0, W1, b1, W2, b2):
+    def forward(ctx, lowp, c0, c1, c2, W0, b0, W1, b1, W2, b2):
         cmds = [c.contiguous().float() for c in (c0, c1, c2)]
+        ctx.lowp = bool(lowp)                          # (the bf16 model: weight-gradient operands rounded to bf16, as inside the fused node)
         ctx.save_for_backward(*cmds, W0, b0, W1, b1, W2, b2)
         return tuple(ops.skinny_group([dict(X=cmds[t], W=W.detach(), bias=b.detach()) for t, (W, b) in enumerate(((W0, b0), (W1, b1), (W2, b2)))]))
 
@@ -1636,16 +1637,17 @@ class _GateProjFn(torch.autograd.Function):
                 leaves.append(dict(dY=douts[t], X=cmds[t], dW=dW, db=db))
                 grads += [dW, db]
         if leaves:
-            ops.outer_wgrad(leaves)
-        return tuple(dcmds) + tuple(grads)
+            ops.outer_wgrad(leaves, lowp=ctx.lowp)
+        return (None,) + tuple(dcmds) + tuple(grads)
 
 
-def gate_projections(cmds, linears):
-    """cmds: the query encoder's three (B, 2H) commands; linears: mainModel's three qInput{t} nn.Linear holders."""
+def gate_projections(cmds, linears, lowp=False):
+    """cmds: the query encoder's three (B, 2H) commands; linears: mainModel's three qInput{t} nn.Linear holders; lowp: as
+    query_encoder's (the bf16 model)."""
     args = []
     for lin in linears:
         args += [lin.weight, lin.bias]
-    return list(_GateProjFn.apply(cmds[0], cmds[1], cmds[2], *args))
+    return list(_GateProjFn.apply(bool(lowp), cmds[0], cmds[1], cmds[2], *args))
 
 
 class _LGPFn(torch.autograd.Function):

@@ -62,7 +62,7 @@ class mainModel(nn.Module):
         """The per-level gate projections on given commands (model/main_model.py:47-50), one autograd node (DF.gate_projections):
         encode_query == project_gates(encode_commands(...)), value for value, with the commands as a cut point for schedules that
         exchange the projections' gradients early (drn_amd.graph.TwoPhaseStep)."""
-        return DF.gate_projections(cmds, [getattr(self, "qInput%d" % i) for i in range(3)])
+        return DF.gate_projections(cmds, [getattr(self, "qInput%d" % i) for i in range(3)], lowp=self.compute_dtype == torch.bfloat16)
 
     def gate_parameters(self):
         return [p for t in range(len(self.backbone_net.blocks)) for p in getattr(self, "qInput%d" % t).parameters()]
