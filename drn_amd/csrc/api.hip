@@ -16,7 +16,7 @@ extern "C" int drn_abi_version(void) {
   drn_clear_status(); return DRN_ABI_VERSION; }
 extern "C" const char* drn_last_error(void) { return g_err; }
 
-static int g_tune[13] = {4096, 1, 256, 0, 0, 0, 0, 0, 1, 1, 0, 16, 128};   // DRN_TUNE_TN3_MINROWS, DRN_TUNE_TN_FUSED, DRN_TUNE_NT_DEEP, DRN_TUNE_EXP0..4, DRN_TUNE_NT_W4, DRN_TUNE_NT_W4C
+static int g_tune[13] = {4096, 1, 256, 0, 0, 0, 0, 0, 1, 1, 0, 16, 160};   // DRN_TUNE_TN3_MINROWS, DRN_TUNE_TN_FUSED, DRN_TUNE_NT_DEEP, DRN_TUNE_EXP0..4, DRN_TUNE_NT_W4, DRN_TUNE_NT_W4C
 int drn_tuning(int key) { return g_tune[key]; }
 extern "C" int drn_tune(const char* key, int value) {
   drn_clear_status();

@@ -6,7 +6,7 @@ int drn_nt_w4_launch(const GemmParams& P, int total, hipStream_t stream);
 bool drn_nt_w4c_eligible(const DrnGemmDesc* d, int ngroups, int dtype);
 int drn_nt_w4c_launch(const GemmParams& P, int total, hipStream_t stream, int ksplit);
 bool drn_nt_w4h_eligible(const DrnGemmDesc* d, int ngroups, int dtype, bool* conv_out);  // gemm_nt_w4h.hip
-int drn_nt_w4h_launch(const GemmParams& P, int total, bool conv, hipStream_t stream);
+int drn_nt_w4h_launch(const GemmParams& P, int total, bool conv, hipStream_t stream, int ksplit);
 
 // Which kernel a launch runs on, given the tile size launch_nt chose (drn_gemm_nt_plan reports it to callers that schedule
 // around a launch -- functional.input_prep's weight pre-touch -- instead of re-deriving the rule on their side).
@@ -54,10 +54,19 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   if (ksplit > 1) tile = planes256 ? 256 : 128;
   // launches on 128x128 tiles whose problems make enough 256x128 tiles: the 4-wave loop on half-width tiles (gemm_nt_w4h.hip)
   bool w4h = false, w4h_conv = false;
-  if (tile == 128 && ksplit == 1 && !planes256 && drn_tuning(DRN_TUNE_NT_W4H) > 0 && drn_nt_w4h_eligible(d, ngroups, dtype, &w4h_conv)) {
+  if (tile == 128 && !planes256 && drn_tuning(DRN_TUNE_NT_W4H) > 0 && drn_nt_w4h_eligible(d, ngroups, dtype, &w4h_conv)) {
     long th = 0;
-    for (int g = 0; g < ngroups; ++g) th += (long)(d[g].M / 256) * (d[g].N / 128);
-    w4h = th >= drn_tuning(DRN_TUNE_NT_W4H);
+    int min_ksteps = 1 << 30;
+    for (int g = 0; g < ngroups; ++g) {
+      th += (long)(d[g].M / 256) * (d[g].N / 128);
+      const int ksteps = d[g].taps * d[g].Cin / 64, per = cdiv(ksteps, ksplit);
+      min_ksteps = min(min_ksteps, ksteps - (cdiv(ksteps, per) - 1) * per);          // the last split's share
+      if (cdiv(ksteps, per) != ksplit) min_ksteps = 0;                               // (a split would be empty)
+    }
+    // one launch: enough tiles; split (drn_gemm_nt_splitk*: the caller sized ksplit for this kernel -- every split keeps at least two
+    // K-steps and the tiles have arrival counters)
+    w4h = ksplit == 1 ? th >= drn_tuning(DRN_TUNE_NT_W4H)
+                      : (ngroups == 1 && th * ksplit >= drn_tuning(DRN_TUNE_NT_W4H) && min_ksteps >= 2 && th <= DRN_QD_COUNTERS && ws && counters);
   }
   const int tile_m = w4h ? 256 : tile, tile_n = w4h ? 128 : tile;
   int total = 0;
@@ -115,7 +124,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   if (plan_only) return kind;
   if (kind == DRN_NT_KIND_W4H) {
     P.nblocks = total;
-    return drn_nt_w4h_launch(P, total, w4h_conv, stream);
+    return drn_nt_w4h_launch(P, total, w4h_conv, stream, ksplit);
   }
   if (kind == DRN_NT_KIND_W4) {
     P.nblocks = total;
@@ -153,6 +162,14 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
 extern "C" int drn_gemm_nt_plan(const DrnGemmDesc* descs, int ngroups, int dtype) {
   drn_clear_status();
   return launch_nt(descs, ngroups, dtype, nullptr, 1, nullptr, nullptr, false, true);
+}
+
+extern "C" int drn_gemm_nt_splitk_plan(const DrnGemmDesc* descs, int ngroups, int ksplit, int dtype) {
+  drn_clear_status();
+  DRN_CHECK_ARG(ksplit >= 1 && ksplit <= 64, "drn_gemm_nt_splitk_plan: bad ksplit");
+  static float dummy_ws;           // (plan only: non-null workspace / counters so that the split kernels' preconditions read as met)
+  static int dummy_cnt;
+  return launch_nt(descs, ngroups, dtype, nullptr, ksplit, ksplit > 1 ? &dummy_ws : nullptr, ksplit > 1 ? &dummy_cnt : nullptr, false, true);
 }
 
 extern "C" int drn_gemm_nt(const DrnGemmDesc* descs, int ngroups, int dtype, void* stream) {

@@ -129,9 +129,41 @@ def gemm_nt_plan(descs, dtype):
     return kind
 
 
+# One long-K bf16 problem with few output tiles (conv0's forward: 8192 x 256 x 13056 = 64 tiles of 256 x 128, 204 K-steps) on the
+# 4-wave kernel's half-width tiles with the K loop split INSIDE the launch so that ~256 workgroups exist (gemm_nt_w4h_kernel:
+# partial accumulators exchanged through the workspace, the last-arriving split of a tile sums them in split order).
+KSPLIT_W4H = os.environ.get("DRN_KSPLIT_W4H", "1") == "1"
+
+
+def _ksplit_w4h(descs, dtype):
+    if not KSPLIT_W4H or dtype != BF16 or len(descs) != 1:
+        return 1
+    d = descs[0]
+    if d.M % 256 or d.N % 128 or d.Cin % 64:
+        return 1
+    tiles, nkt = (d.M // 256) * (d.N // 128), (d.taps * d.Cin) // 64
+    if tiles > 128 or nkt < 96:
+        return 1
+    ks = min(8, KSPLIT_WGS // tiles, nkt // 24)
+    while ks > 1 and -(-nkt // -(-nkt // ks)) != ks:           # every split non-empty
+        ks -= 1
+    if ks < 2:
+        return 1
+    arr = (GemmDesc * 1)(d)
+    return ks if lib().drn_gemm_nt_splitk_plan(arr, 1, ks, dtype) == NT_KIND_W4H else 1
+
+
 def gemm_nt(descs, dtype):
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
+    ks = _ksplit_w4h(descs, dtype)
+    if ks > 1:
+        d0 = descs[0]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ws = torch.empty(ks * d0.M * d0.N, dtype=torch.float32, device=dev)
+        tag = "gemm_nt[bf16] g=1 M=%d N=%d K=%d mode=%d splitK=%d(w4h)" % (d0.M, d0.N, d0.taps * d0.Cin, d0.mode, ks)
+        return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk_grouped(arr, 1, ks, _p(ws), _p(_counters(dev)), dtype, _stream()),
+                                                "drn_gemm_nt_splitk_grouped"))
     ks = _ksplit256(descs, dtype)
     if ks > 1:
         d0 = descs[0]

@@ -78,6 +78,8 @@ int drn_gemm_nt(const DrnGemmDesc* descs /*host*/, int ngroups, int dtype, void*
 #define DRN_NT_KIND_W4C 3      /* gemm_nt_w4c_kernel: the same loop for k = 3 / stride 1 convolutions */
 #define DRN_NT_KIND_W4H 4      /* gemm_nt_w4h_kernel: the same loop on 256x128 tiles (N too narrow to fill the chip with 256x256) */
 int drn_gemm_nt_plan(const DrnGemmDesc* descs /*host*/, int ngroups, int dtype);
+/* ... and which kernel drn_gemm_nt_splitk / _grouped would run them on with the K loop split ksplit ways. */
+int drn_gemm_nt_splitk_plan(const DrnGemmDesc* descs /*host*/, int ngroups, int ksplit, int dtype);
 /* Same for ONE problem with the K loop split `ksplit` ways (few output tiles: conv0, the coarse pyramid levels), in ONE
  * launch: every split publishes its fp32 partial tile in ws (drn_gemm_nt_splitk_ws_elems floats, 16-byte aligned), the
  * split that arrives last at a tile adds them in split order (deterministic) and runs the epilogue.  counters: >= one int32

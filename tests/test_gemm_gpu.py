@@ -16,7 +16,7 @@ TOL = {"f32": 2e-5, "bf16": 1e-2}
 def tune(monkeypatch, key, value):
     """drn_tune(key, value) for the duration of one test (defaults restored afterwards)."""
     from drn_amd import _lib
-    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0, "nt_w4h": 128}
+    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0, "nt_w4h": 160}
     _lib.check(_lib.lib().drn_tune(key.encode(), int(value)), "drn_tune")
     _RESTORE.append((key, defaults[key]))
 
@@ -818,7 +818,7 @@ def test_w4h_conv_forward_matches_torch(monkeypatch):
 
 
 def test_w4h_kernel_takes_the_pyramid_launches_and_declines_the_rest(monkeypatch):
-    """With the shipped threshold (>= 128 tiles of 256 x 128) the grouped FPN / head launches of the benchmarked shape go to the
+    """With the shipped threshold (>= 160 tiles of 256 x 128) the grouped FPN / head launches of the benchmarked shape go to the
     4-wave kernel; strided convolutions, fp32 destinations, short pyramids (Charades-STA's T = 32) and fp32 models do not."""
     from drn_amd import ops
     A = torch.zeros(8192, 1536, device=dev(), dtype=torch.bfloat16)
@@ -867,3 +867,41 @@ def test_w4h_kernel_stress_many_launches_stay_bit_identical(monkeypatch):
         for (Ch, sh), (Cg, sg) in zip(*outs):
             bad += int(not torch.equal(Ch, Cg) or (mode == 0 and not torch.equal(sh, sg)))
     assert bad == 0, "%d level outputs of 40 launches differ" % bad
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 2048, 128, 3, 0, True), (1, 256, 6144, 128, 1, 0, False), (2, 128, 2048, 256, 3, 1, False),
+                                   (4, 128, 2112, 128, 3, 0, True)])
+def test_w4h_kernel_splitk_in_launch(monkeypatch, shape):
+    """conv0's forward shape class: few 256 x 128 tiles, a long K loop split inside the launch (ops._ksplit_w4h ->
+    drn_gemm_nt_splitk_grouped -> gemm_nt_w4h_kernel): partial accumulators exchanged through the workspace, the last-arriving split sums
+    them in split order.  Deterministic (two runs equal bits), equal to the unsplit kernel within fp32 re-association, statistics included,
+    counters left re-armed."""
+    from drn_amd import ops
+    B, L, Cin, N, taps, mode, stats = shape
+    M = B * L
+    A = rnd((M, Cin), 91, torch.bfloat16).to(dev())
+    W = (rnd((N, taps * Cin), 92, torch.float32) * 0.02).to(torch.bfloat16).to(dev())
+    bias = rnd((N,), 93, torch.float32).to(dev())
+    tune(monkeypatch, "nt_w4h", 1)
+
+    def run(split):
+        monkeypatch.setattr(ops, "KSPLIT_W4H", split)
+        C = torch.full((M, N), 7.0, device=dev(), dtype=torch.bfloat16)
+        st = torch.full((M // 128, 2, N), float("nan"), device=dev()) if stats else None
+        d = ops.gemm_desc(A, W, C, M, N, Cin, taps=taps, pad=1 if taps == 3 else 0, mode=mode, Lout=L, Lsrc=L, bias=bias, stats=st)
+        ks = ops._ksplit_w4h([d], ops.BF16)
+        ops.gemm_nt([d], ops.BF16)
+        torch.cuda.synchronize()
+        return ks, C, st
+    ks1, C1, s1 = run(True)
+    ks2, C2, s2 = run(True)
+    ks0, C0, s0 = run(False)
+    assert ks1 >= 2 and ks0 == 1
+    assert torch.equal(C1, C2) and (not stats or torch.equal(s1, s2))
+    close(C1, C0.double().cpu(), 1e-2, "split vs unsplit output")
+    if stats:
+        t1, q1 = merged_stats(s1, M)
+        t0, q0 = merged_stats(s0, M)
+        close(t1, t0, 1e-4, "column sums")
+        close(q1, q0, 1e-4, "column M2")
+    assert int(ops._counters(dev()).abs().sum()) == 0
