@@ -4,6 +4,8 @@ import copy
 import pytest
 import torch
 
+from helpers import isolated
+
 pytestmark = pytest.mark.gpu
 
 
@@ -282,6 +284,7 @@ def test_adjacent_stack_groups_write_gradients_in_place():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@isolated
 def test_forked_graph_step_is_bit_identical(dtype):
     """drn_amd.graph.ForkedStep -- the whole step as ONE hipGraph with two branches (query side beside input preparation / weight
     gradients; bench.py's launch mode at N = 1 when it measures faster) -- against the plain single-stream eager step: losses
@@ -413,6 +416,7 @@ def test_forked_graph_at_the_benchmarked_shape_equals_the_linear_graph():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@isolated
 def test_forked_graph_optimizer_first_order_is_bit_identical(dtype):
     """ForkedStep with the query side's gradients in buckets of their own runs OPTIMIZER-FIRST (a call = pending update, then
     forward + backward; the query encoder's forward beside the Adam kernels): over a run -- prime, eager steps, capture, replays,
