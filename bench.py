@@ -159,10 +159,13 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
             tr.train_epoch(batches)                          # warm-up: every geometry passes warm-up steps
             tr.train_epoch(batches)                          # ... and capture
             torch.cuda.synchronize()
+            # ONE epoch of `steps` steps (the eight batches in turn): train_epoch returns the epoch's mean loss, i.e. ends with a host
+            # sync, and a real epoch is hundreds of steps (Charades-STA: 388 at batch 32) -- eight-step epochs, as timed before round 5,
+            # charged every step an eighth of that pipeline bubble
             n_ep = max(1, steps // len(batches))
+            epoch = batches * n_ep
             t0 = time.perf_counter()
-            for _ in range(n_ep):
-                tr.train_epoch(batches)                      # (returns the epoch's mean loss: one host sync per epoch)
+            tr.train_epoch(epoch)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             key = "T%d_%s" % (T, "graph" if graph else "eager")
@@ -183,8 +186,7 @@ def trainer_lines(cfg, dev, cdt, stage, B, D, Ts, steps, graph_modes=(True, Fals
                     tr.train_epoch(hb)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    for _ in range(n_ep):
-                        tr.train_epoch(hb)
+                    tr.train_epoch(hb * n_ep)
                     torch.cuda.synchronize()
                     dth = time.perf_counter() - t0
                     out[key] = {"clips_per_s": round(B * len(hb) * n_ep / dth, 1), "ms_per_step": round(dth / (len(hb) * n_ep) * 1e3, 3),

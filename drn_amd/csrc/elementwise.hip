@@ -977,3 +977,69 @@ extern "C" int drn_colsum(const void* X, int ld, int M, int C, float* out, int a
   if (nblk > 1) reduce_partials_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(ws, nblk, C, out, accumulate);
   return drn_launch_status("drn_colsum");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Up to DRN_COPY_MAX byte ranges copied (or zero-filled: src NULL) in ONE launch: the trainer's per-step refill of a captured
+// step's static input buffers (tokens, lengths, features, proposal boundaries, ground truth -- five framework copies of 5-8 us each
+// between two replays before).  A workgroup moves one 64 KB chunk with 16-byte accesses (ranges whose pointers or sizes are not
+// 16-byte multiples take the byte path for their ragged head / tail).
+struct CopyMultiParams {
+  const char* src[DRN_COPY_MAX];
+  char* dst[DRN_COPY_MAX];
+  long bytes[DRN_COPY_MAX];
+  int row_bytes[DRN_COPY_MAX];     // > 0: a 2-D range -- dst rows of dst_pitch bytes, the first row_bytes of each from src rows of
+  int src_pitch[DRN_COPY_MAX];     // src_pitch bytes, the rest of the row zero (a token matrix padded out to the slot's query length)
+  int dst_pitch[DRN_COPY_MAX];
+  int blk0[DRN_COPY_MAX + 1];      // first workgroup of every range
+  int n;
+};
+#define COPY_CHUNK 65536
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyMultiParams P) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < DRN_COPY_MAX; ++k)
+    if (k < P.n && (int)blockIdx.x >= P.blk0[k]) i = k;
+  const long off = (long)((int)blockIdx.x - P.blk0[i]) * COPY_CHUNK;
+  const long n = min((long)COPY_CHUNK, P.bytes[i] - off);
+  if (P.row_bytes[i] > 0) {           // padded rows (small: byte path)
+    const int rb = P.row_bytes[i], sp = P.src_pitch[i], dp = P.dst_pitch[i];
+    for (long k = off + threadIdx.x; k < off + n; k += 256) {
+      const long row = k / dp;
+      const int col = (int)(k - row * dp);
+      P.dst[i][k] = col < rb ? P.src[i][row * sp + col] : (char)0;
+    }
+    return;
+  }
+  const char* __restrict__ s = P.src[i] ? P.src[i] + off : nullptr;
+  char* __restrict__ d = P.dst[i] + off;
+  const bool vec = ((((uintptr_t)d) | ((uintptr_t)(s ? s : d))) & 15) == 0;
+  const long nv = vec ? n / 16 : 0;
+  for (long k = threadIdx.x; k < nv; k += 256) ((uint4*)d)[k] = s ? ((const uint4*)s)[k] : make_uint4(0u, 0u, 0u, 0u);
+  for (long k = nv * 16 + threadIdx.x; k < n; k += 256) d[k] = s ? s[k] : (char)0;
+}
+
+extern "C" int drn_copy_multi(const void* const* srcs, void* const* dsts, const int64_t* bytes, const int32_t* rows2d, int n, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(srcs && dsts && bytes && n >= 1 && n <= DRN_COPY_MAX, "drn_copy_multi: 1..%d ranges", DRN_COPY_MAX);
+  CopyMultiParams P;
+  memset(&P, 0, sizeof(P));
+  int blocks = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    DRN_CHECK_ARG(bytes[i] >= 0 && (bytes[i] == 0 || dsts[i]), "drn_copy_multi: bad range %d", i);
+    if (bytes[i] == 0) continue;
+    P.src[m] = (const char*)srcs[i]; P.dst[m] = (char*)dsts[i]; P.bytes[m] = bytes[i]; P.blk0[m] = blocks;
+    if (rows2d && rows2d[3 * i] > 0) {
+      P.row_bytes[m] = rows2d[3 * i]; P.src_pitch[m] = rows2d[3 * i + 1]; P.dst_pitch[m] = rows2d[3 * i + 2];
+      DRN_CHECK_ARG(srcs[i] && P.row_bytes[m] <= P.src_pitch[m] && P.row_bytes[m] <= P.dst_pitch[m] && bytes[i] % P.dst_pitch[m] == 0,
+                    "drn_copy_multi: bad 2-D range %d", i);
+    }
+    blocks += (int)((bytes[i] + COPY_CHUNK - 1) / COPY_CHUNK);
+    ++m;
+  }
+  if (m == 0) return DRN_OK;
+  P.blk0[m] = blocks;
+  P.n = m;
+  copy_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(P);
+  return drn_launch_status("drn_copy_multi");
+}

@@ -404,6 +404,28 @@ def touch(t):
     check(lib().drn_touch(_p(t), ctypes.c_int64(t.numel() * t.element_size()), _stream()), "drn_touch")
 
 
+def copy_multi(pairs):
+    """pairs: [(dst, src or None)] device tensors -- one launch (drn_copy_multi).  Contiguous pairs of equal byte size are flat
+    copies (src None: zero-fill); a 2-D `src` with fewer columns than the contiguous 2-D `dst` (same rows, same dtype) is copied into
+    the leading columns and the rest of every row is zeroed."""
+    n = len(pairs)
+    assert 1 <= n <= 8
+    rows2d = (ctypes.c_int32 * (3 * n))()
+    for i, (d, s_) in enumerate(pairs):
+        _need_gpu(d, s_)
+        assert d.is_contiguous()
+        if s_ is None or (s_.is_contiguous() and s_.numel() == d.numel() and s_.dtype == d.dtype):
+            continue
+        assert s_.dim() == 2 and d.dim() == 2 and s_.dtype == d.dtype and s_.shape[0] == d.shape[0] and s_.shape[1] <= d.shape[1] \
+            and s_.stride(1) == 1, "copy_multi: a padded pair needs (rows, <= cols) -> (rows, cols) of one dtype"
+        es = d.element_size()
+        rows2d[3 * i], rows2d[3 * i + 1], rows2d[3 * i + 2] = s_.shape[1] * es, s_.stride(0) * es, d.shape[1] * es
+    srcs = (ctypes.c_void_p * n)(*[s_.data_ptr() if s_ is not None else None for _, s_ in pairs])
+    dsts = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    nbytes = (ctypes.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    check(lib().drn_copy_multi(srcs, dsts, nbytes, rows2d, n, _stream()), "drn_copy_multi")
+
+
 def pos_feat(start_end):
     """(B, T, 2) fp64 / fp32 proposal boundaries -> (B, T, 3) fp32 [start, end, end - start] (main_model.py:51-55)."""
     _need_gpu(start_end)

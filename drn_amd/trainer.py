@@ -75,6 +75,14 @@ class _StepSlot(object):
         """Copy one batch (host or device tensors) into the static buffers; the token matrix is zero-padded (padding_idx 0)
         out to the slot's query length -- the kernels read the true lengths from `qlen` on the device."""
         L = tok.shape[1]
+        srcs, dsts = (tok, qlen, feats, pse, gt), (self.tok, self.qlen, self.feats, self.pse, self.gt)
+        if all(t.is_cuda and t.device == d.device and t.dtype == d.dtype for t, d in zip(srcs, dsts)) and \
+                all(t.is_contiguous() for t in srcs[1:]) and tok.stride(-1) == 1:
+            # a device-resident batch: all five buffers (token padding included) in ONE launch instead of five or six framework
+            # copies of 5-8 us each between two replays (drn_copy_multi)
+            from . import ops
+            ops.copy_multi(list(zip(dsts, srcs)))
+            return
         self.tok[:, :L].copy_(tok, non_blocking=True)
         if L < self.tok.shape[1]:
             self.tok[:, L:].zero_()
@@ -130,6 +138,10 @@ class Trainer(object):
         # the per-step input copies and stream hand-offs around the replay sit where the overlap was) -- so it is opt-in
         self.forked = bool(forked) and self.graph and world_size == 1 and hasattr(model, "forward_trunk")
         self._side = torch.cuda.Stream(device=self.device) if self.forked else None
+        # graph mode: the epoch's loss sum (train_epoch's return value) is accumulated ON THE DEVICE by one add that is part of
+        # every step -- captured with it -- instead of two framework launches on the step's stream after every replay
+        # (the eager modes add the same way after each step, so every mode returns the same bits)
+        self._loss_acc = torch.zeros((), dtype=torch.float32, device=self.device)
         if self.fused:
             from .dist import GradReducer
             from .optim import FusedAdam
@@ -175,9 +187,14 @@ class Trainer(object):
     def _fwd_bwd(self, args):
         self.reducer.zero()
         _, loss_dict = self.model(*args)
-        DF.backward(select_loss(loss_dict, self.which))
+        loss = select_loss(loss_dict, self.which)
+        DF.backward(loss)
         self.reducer.collect()
+        self._accumulate(loss, args[2].size(0))
         return loss_dict
+
+    def _accumulate(self, loss, batch_size):
+        self._loss_acc.add_(loss.detach().reshape(-1)[0].float(), alpha=float(batch_size))
 
     def _exchange_and_update(self):
         self.reducer.finish()
@@ -235,11 +252,13 @@ class Trainer(object):
                             fs._fresh = True
                             fs._schedule(fs._phase, fs.main, fs.side)
                             fs.main.wait_stream(fs.side)
+                            self._accumulate(select_loss(fs.out, self.which), slot.feats.size(0))
                             slot.seen += 1
                             cur.wait_stream(self.stream)
                             return fs.out
                         g = fs._capture_once(kw.get("pool"))
                         slot.out = fs.out
+                        slot.acc_outside = True              # (the two-branch capture does not contain the epoch-loss add)
                     else:
                         g = torch.cuda.CUDAGraph()
                         from .graph import capture_graph          # (thread_local capture, cyclic GC off while it is open)
@@ -253,6 +272,8 @@ class Trainer(object):
                     if self.world_size > 1:
                         self.reducer.rearm()               # hooks only ran at capture time
                     slot.graph.replay()
+                    if getattr(slot, "acc_outside", False):
+                        self._accumulate(select_loss(slot.out, self.which), slot.feats.size(0))
                     if not whole:
                         self._exchange_and_update()
                     out = slot.out
@@ -306,24 +327,27 @@ class Trainer(object):
         sampler = getattr(loader, "sampler", None)
         if epoch is not None and hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)
-        total, n = None, 0
+        n = 0
+        if getattr(self, "_loss_acc", None) is None:       # (a trainer built without __init__: tests)
+            self._loss_acc = torch.zeros((), dtype=torch.float32, device=getattr(self, "device", "cpu"))
         if getattr(self, "graph", False) and getattr(self, "prefetch", False):
             # One batch of look-ahead: batch i+1 is copied into the OTHER slot of its geometry on a copy stream before step i is
             # launched, so the fp32 features (B x T x D x 4 bytes: 134 MB at the benchmarked shape, 2.4 ms of PCIe -- longer than
             # the step) cross the bus while the previous step computes and the step's own stream carries only the replay.
             it = iter(loader)
             nxt = self._prefetch(next(it, None))
+            with torch.cuda.stream(self.stream):
+                self._loss_acc.zero_()                     # (every step adds its loss x batch size itself: _accumulate)
             while nxt is not None:
                 cur_b = nxt
                 nxt = self._prefetch(next(it, None))
                 bs = cur_b.batch_size if isinstance(cur_b, _Preloaded) else cur_b[2].size(0)
-                ld = self.train_step(cur_b)
-                with torch.cuda.stream(self.stream):       # (on the step's own stream: the caller's stream stays empty, so the
-                    loss = select_loss(ld, self.which).detach().reshape(-1)[0] * bs    # hand-offs around the next replay wait for nothing)
-                    total = loss if total is None else total + loss
+                self.train_step(cur_b)
                 n += bs
             torch.cuda.current_stream().wait_stream(self.stream)
-            return float(total) / max(n, 1) if total is not None else 0.0
+            return float(self._loss_acc) / max(n, 1) if n else 0.0
+        with torch.cuda.stream(self.stream) if self.graph else contextlib.nullcontext():
+            self._loss_acc.zero_()
         for batch in loader:
             if self.graph:                                 # host tensors go straight into the captured step's input buffers
                 names, pse, feats, gt, tok, qlen, nprops, nframes = batch
@@ -332,13 +356,12 @@ class Trainer(object):
                 _, args = to_device(batch, self.device)
             bs = args[2].size(0)
             ld = self.train_step(args)
-            with torch.cuda.stream(self.stream) if self.graph else contextlib.nullcontext():
-                loss = select_loss(ld, self.which).detach().reshape(-1)[0] * bs
-                total = loss if total is None else total + loss
+            if not self.graph:
+                self._accumulate(select_loss(ld, self.which), bs)
             n += bs
         if self.graph:
             torch.cuda.current_stream().wait_stream(self.stream)
-        return float(total) / max(n, 1) if total is not None else 0.0
+        return float(self._loss_acc) / max(n, 1) if n else 0.0
 
     def _prefetch(self, batch):
         """graph mode: start copying a batch (host or device tensors) into the input buffers of the slot its step will run from,

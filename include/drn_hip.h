@@ -147,6 +147,15 @@ int drn_pack_weights(const DrnPackDesc* items /*host*/, int n, int dtype, void* 
 /* Read `bytes` (16-byte aligned buffer) through the caches and discard: warms an operand that was written long ago (the
  * bf16 weight copy of prop_fc) right before the GEMM that streams it. */
 int drn_touch(const void* p, int64_t bytes, void* stream);
+/* n <= DRN_COPY_MAX device byte ranges copied dst[i] <- src[i] (src[i] NULL: zero-filled) in ONE launch: the refill of a captured
+ * step's static input buffers between two hipGraph replays (drn_amd.trainer; replaces the reference loop's per-tensor .cuda()
+ * copies, main.py:214-217, on device-resident batches).  Ranges must not overlap. */
+#define DRN_COPY_MAX 8
+/* rows2d (host, 3 ints per range, or NULL): {row_bytes, src_pitch, dst_pitch} > 0 makes range i two-dimensional -- bytes[i] =
+ * rows * dst_pitch bytes of dst are written, the first row_bytes of every row from src rows src_pitch apart, the rest zero (a
+ * token matrix padded out to the captured step's query length). */
+int drn_copy_multi(const void* const* srcs /*host array of device ptrs*/, void* const* dsts, const int64_t* bytes /*host*/,
+                   const int32_t* rows2d /*host or NULL*/, int n, void* stream);
 /* feat[m][3] = (float)[start, end, end - start] from props_start_end (M x 2, fp64 or fp32): the position features of
  * model/main_model.py:51-55 in one launch (the reference: subtraction, torch.cat, .float()). */
 int drn_pos_feat(const void* start_end, int is_f64, float* feat, int M, void* stream);

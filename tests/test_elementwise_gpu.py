@@ -182,3 +182,29 @@ def test_gate_bwd_transposed_output(dt, shape):
     ops.gate_bwd_t(dGw, ld, act, C, gate, dCT, dgate2, B, L, C, _code(dt), dsum=dsum2)
     assert torch.equal(dCT, dC.view(B * L, C).t().contiguous())
     assert torch.allclose(dgate2, dgate, rtol=1e-5, atol=1e-5) and torch.allclose(dsum2, dsum, rtol=1e-5, atol=1e-5)
+
+
+def test_copy_multi_refills_step_inputs_in_one_launch():
+    """drn_copy_multi: flat ranges of mixed dtypes / sizes (16-byte aligned and not), a zero-fill, and a token matrix padded out to a
+    wider row -- against plain tensor copies."""
+    from drn_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(1, 1000, (32, 6), generator=g).to(dev)                     # (B, L) -> (B, 8): two zero columns
+    qlen = torch.randint(1, 7, (32,), generator=g).to(dev)
+    feats = torch.randn(32, 32, 4096, generator=g).to(dev)
+    pse = torch.rand(32, 32, 2, generator=g, dtype=torch.float64).to(dev)
+    gt = torch.rand(32, 2, generator=g, dtype=torch.float64).to(dev)
+    odd = torch.randn(1001, generator=g).to(dev)[1:]                                # 4000 bytes at a 4-byte offset: the byte path
+    dst = [torch.full((32, 8), 7, dtype=torch.int64, device=dev), torch.full_like(qlen, 7), torch.full_like(feats, 7.0),
+           torch.full_like(pse, 7.0), torch.full_like(gt, 7.0), torch.full((1000,), 7.0, device=dev), torch.full((513,), 7.0, device=dev)]
+    ops.copy_multi([(dst[0], tok), (dst[1], qlen), (dst[2], feats), (dst[3], pse), (dst[4], gt), (dst[5], odd), (dst[6], None)])
+    torch.cuda.synchronize()
+    assert torch.equal(dst[0][:, :6], tok) and int(dst[0][:, 6:].abs().sum()) == 0
+    for d, s_ in zip(dst[1:6], (qlen, feats, pse, gt, odd)):
+        assert torch.equal(d, s_)
+    assert float(dst[6].abs().sum()) == 0.0
+    full = torch.randint(1, 1000, (32, 8), generator=g).to(dev)                    # no padding: a flat range
+    ops.copy_multi([(dst[0], full)])
+    torch.cuda.synchronize()
+    assert torch.equal(dst[0], full)
