@@ -92,15 +92,31 @@ extern "C" int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out,
 // (Four consecutive rows per thread, so that the four values of one k go to the tile as ONE 8-byte write instead of four 2-byte ones
 // -- 8 LDS write instructions per thread instead of 32 -- measured the same inside the step: the pass is not LDS-bound.)
 template <typename T, int TM, int TK, int NT>
+__device__ __forceinline__ void cast_transpose_tile(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ outT, int M, int K,
+                                                    const int m0, const int k0);
+// tiles_k > 0: a THROTTLED launch -- gridDim.x workgroups walk the tiles_k x tiles_m tiles in a grid-stride loop, so only gridDim.x
+// workgroups are ever resident (drn_cast_transpose_throttled: the pass when it runs beside the query encoder's latency-bound launches).
+template <typename T, int TM, int TK, int NT>
 __global__ __launch_bounds__(NT) void cast_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ outT,
-                                                            int M, int K) {
+                                                            int M, int K, int tiles_k = 0, int tiles_m = 0) {
+  if (tiles_k > 0) {
+    for (int t = blockIdx.x; t < tiles_k * tiles_m; t += gridDim.x) {
+      cast_transpose_tile<T, TM, TK, NT>(in, out, outT, M, K, (t / tiles_k) * TM, (t % tiles_k) * TK);
+      __syncthreads();
+    }
+    return;
+  }
+  cast_transpose_tile<T, TM, TK, NT>(in, out, outT, M, K, blockIdx.y * TM, blockIdx.x * TK);
+}
+template <typename T, int TM, int TK, int NT>
+__device__ __forceinline__ void cast_transpose_tile(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ outT,
+                                                    int M, int K, const int m0, const int k0) {
   constexpr int VN = V16<T>::N;              // elements per 16-byte piece of the outputs
   constexpr int PITCH = TM + 16 / (int)sizeof(T);          // [k][m] tile, rows stay 16-byte aligned
   constexpr int CPR = TM / VN;                               // 16-byte pieces per tile row (a power of two)
   constexpr int UPR = TK / 8;                                // 8-float units per source row of the tile
   constexpr int NU = TM * UPR / NT;                          // units per thread
   __shared__ __attribute__((aligned(16))) T tile[TK][PITCH];
-  const int m0 = blockIdx.y * TM, k0 = blockIdx.x * TK;
   f32x4 v[NU][2];
   int mm[NU], kk[NU];
 #pragma unroll
@@ -137,6 +153,21 @@ __global__ __launch_bounds__(NT) void cast_transpose_kernel(const float* __restr
     if (k < K && m < M) *(uint4*)(outT + (long)k * M + m) = *(const uint4*)&tile[r][((cv ^ (r >> 3)) & (CPR - 1)) * VN];
   }
 }
+extern "C" int drn_cast_transpose_throttled(const float* in, void* out, void* outT, int M, int K, int dtype, int max_workgroups, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(in && out && outT && M > 0 && K > 0 && max_workgroups > 0, "drn_cast_transpose_throttled: bad args");
+  DISPATCH_DT(dtype, "drn_cast_transpose_throttled", {
+    constexpr int VN = V16<T>::N;
+    DRN_CHECK_ARG(M % VN == 0 && K % 8 == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)outT) & 15) == 0,
+                  "drn_cast_transpose_throttled: M must be a 16-byte multiple in the output type, K a multiple of 8");
+    const int tk = cdiv(K, 128), tm = cdiv(M, 64);
+    const long tiles = (long)tk * tm;
+    cast_transpose_kernel<T, 64, 128, 256><<<(int)(tiles < max_workgroups ? tiles : max_workgroups), 256, 0, (hipStream_t)stream>>>(
+        in, (T*)out, (T*)outT, M, K, tk, tm);
+  });
+  return drn_launch_status("drn_cast_transpose_throttled");
+}
+
 extern "C" int drn_cast_transpose(const float* in, void* out, void* outT, int M, int K, int dtype, void* stream) {
   drn_clear_status();
   DRN_CHECK_ARG(in && out && outT && M > 0 && K > 0, "drn_cast_transpose: bad args");

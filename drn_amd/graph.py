@@ -211,7 +211,12 @@ class DualStreamStep(object):
         if name == "q_fwd":
             c["gates"] = m.encode_query(tok, qlen)
         elif name == "prep":
-            c["prep"] = m.prepare_input(feats, pse)
+            from . import ops
+            ops.CAST_THROTTLE, was = getattr(self, "prep_throttle", 0), ops.CAST_THROTTLE
+            try:
+                c["prep"] = m.prepare_input(feats, pse)
+            finally:
+                ops.CAST_THROTTLE = was
         elif name == "trunk":
             red.zero()
             gd = c["gd"] = [g.detach().requires_grad_() for g in c["gates"]]
@@ -375,6 +380,11 @@ class ForkedStep(DualStreamStep):
         # with them around everything else in the process that uses two streams ran slower afterwards -- the trainer's H2D
         # look-ahead 12.9 -> 9.0 k clips/s, evaluation 22 -> 15 k, measured in bench.py after a capture on priority -1 streams)
         super(ForkedStep, self).__init__(model, batch, loss_of, reducer, opt, wgrads_first=False, side_priority=0)
+        # the input cast runs beside the query encoder's forward, which is the critical path there (prop_fc waits for the gate): at
+        # full rate it stretches the latency-bound query launches 2-3 x (first dense product 18 -> 47 us, an LSTM step 7.5 -> 20);
+        # held to 128 resident workgroups it takes 121 instead of 64 us -- still hidden -- and the query forward 164 instead of
+        # 174 us: 2.028 / 2.019 -> 2.012 / 2.013 ms per step (64: 2.055, 96: 2.012-2.024, 192: 2.010-2.027, 256: 2.016-2.020)
+        self.prep_throttle = int(os.environ.get("DRN_FORK_PREP_THROTTLE", "128"))
         if self._env_wf is not None:
             self.wgrads_first = self._env_wf == "1"
         if self._env_mf is not None:

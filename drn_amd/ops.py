@@ -270,8 +270,16 @@ def cast_transpose(x, dtype):
     M, K = x.shape
     out = torch.empty((M, K), dtype=TORCH_DT[dtype], device=x.device)
     outT = torch.empty((K, M), dtype=TORCH_DT[dtype], device=x.device)
-    check(lib().drn_cast_transpose(_p(x), _p(out), _p(outT), M, K, dtype, _stream()), "drn_cast_transpose")
+    if CAST_THROTTLE > 0:
+        check(lib().drn_cast_transpose_throttled(_p(x), _p(out), _p(outT), M, K, dtype, CAST_THROTTLE, _stream()), "drn_cast_transpose_throttled")
+    else:
+        check(lib().drn_cast_transpose(_p(x), _p(out), _p(outT), M, K, dtype, _stream()), "drn_cast_transpose")
     return out, outT
+
+
+# > 0: cast_transpose runs with at most that many workgroups resident (set by schedules that run the input preparation beside
+# the query encoder: drn_amd.graph.ForkedStep)
+CAST_THROTTLE = 0
 
 
 def transpose2d(x, dtype):

@@ -132,6 +132,10 @@ int drn_cast(const float* in, void* out, int64_t n, int dtype, void* stream);
  * operands let the largest weight gradient run as an NT product (see drn_amd/functional.py, _InputStageFn). */
 /* out[m][k] = outT[k][m] = (dtype) in[m][k] for a contiguous fp32 M x K matrix: cast and K-major copy in one pass. */
 int drn_cast_transpose(const float* in, void* out, void* outT, int M, int K, int dtype, void* stream);
+/* The same pass with at most max_workgroups workgroups resident (a grid-stride loop over the tiles): for schedules that run it
+ * BESIDE latency-bound launches of another branch (drn_amd.graph.ForkedStep: the query encoder's forward), which a full-rate
+ * streaming pass next to them stretches 2-3 x. */
+int drn_cast_transpose_throttled(const float* in, void* out, void* outT, int M, int K, int dtype, int max_workgroups, void* stream);
 int drn_transpose2d(const void* in, int ld_in, void* out, int ld_out, int M, int K, int dtype, void* stream);
 int drn_pack_weight(const float* in, void* out, int A, int B, int C, int64_t sa, int64_t sb, int64_t sc, int dtype, void* stream);
 /* The same for n weights in one launch (all GEMM operands of the model after an optimizer step; the reference's cuDNN

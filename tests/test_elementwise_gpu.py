@@ -208,3 +208,21 @@ def test_copy_multi_refills_step_inputs_in_one_launch():
     ops.copy_multi([(dst[0], full)])
     torch.cuda.synchronize()
     assert torch.equal(dst[0], full)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_cast_transpose_throttled_equals_the_full_rate_pass(dt):
+    """drn_cast_transpose_throttled (at most N workgroups resident, grid-stride loop over the tiles: the input cast when it runs beside
+    the query encoder in the two-branch step) writes the same bits as drn_cast_transpose."""
+    from drn_amd import ops
+    code = ops.BF16 if dt == torch.bfloat16 else ops.F32
+    x = torch.randn(1024, 520, device="cuda:0")
+    a, aT = ops.cast_transpose(x, code)
+    ops.CAST_THROTTLE = 7
+    try:
+        b, bT = ops.cast_transpose(x, code)
+    finally:
+        ops.CAST_THROTTLE = 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(aT, bT)
+    assert torch.equal(aT, x.to(dt).t().contiguous())
