@@ -739,6 +739,109 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+// ---- deferred reduce passes.  Inside a training step six weight-gradient launches each ended with their own reduce launch
+// (wgrad_reduce*: 7-13 us apiece, most of it the launch floor and the ramp of a 2000-workgroup streaming pass over 10-50 MB).
+// With drn_wgrad_defer(1) the GEMM launches only record what their reduce would have been; drn_wgrad_reduce_pending() then runs
+// ALL of them as ONE launch -- same per-element summation order over the splits, so the same bits.  The caller keeps the workspaces
+// alive until then and must flush before anything reads the gradients (drn_amd.dist.GradReducer.collect does).
+struct WgradPendItem {
+  const float* ws;
+  float* out;
+  int nsplit, N, Cin, taps, w_layout, accumulate;
+};
+#define WGRAD_PEND_MAX 24
+struct WgradPendParams {
+  WgradPendItem it[WGRAD_PEND_MAX];
+  int blk_start[WGRAD_PEND_MAX + 1];
+  int n;
+};
+static thread_local int g_pend_on = 0;
+static thread_local WgradPendParams g_pend;
+
+static bool wgrad_pend_push(const float* ws, float* out, int nsplit, int N, int Cin, int taps, int w_layout, int accumulate) {
+  if (!g_pend_on || g_pend.n >= WGRAD_PEND_MAX) return false;
+  g_pend.it[g_pend.n++] = WgradPendItem{ws, out, nsplit, N, Cin, taps, w_layout, accumulate};
+  return true;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendParams P) {
+  int i = 0;
+  for (int k = 1; k < P.n; ++k)
+    if ((int)blockIdx.x >= P.blk_start[k]) i = k;
+  const WgradPendItem& I = P.it[i];
+  const int nb = P.blk_start[i + 1] - P.blk_start[i], b = blockIdx.x - P.blk_start[i];
+  const float* __restrict__ ws = I.ws;
+  float* __restrict__ out = I.out;
+  const int N = I.N, Cin = I.Cin, taps = I.taps, nsplit = I.nsplit, accumulate = I.accumulate, w_layout = I.w_layout;
+  const long KW = (long)taps * Cin;
+  const long total = (long)N * KW;
+  if (w_layout == 1 && taps == 3) {               // the arithmetic of wgrad_reduce_kernel, statement for statement
+    const long pairs = (long)N * Cin;
+    for (long idx = (long)b * 256 + threadIdx.x; idx < pairs; idx += (long)nb * 256) {
+      const long n = idx / Cin;
+      const int c = (int)(idx - n * Cin);
+      const float* p = ws + n * KW + c;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+      for (int z = 0; z < nsplit; ++z) {
+        s0 += p[(long)z * total];
+        s1 += p[(long)z * total + Cin];
+        s2 += p[(long)z * total + 2 * Cin];
+      }
+      float* o = out + n * KW + (long)c * 3;
+      if (accumulate) {
+        s0 += o[0];
+        s1 += o[1];
+        s2 += o[2];
+      }
+      o[0] = s0;
+      o[1] = s1;
+      o[2] = s2;
+    }
+    return;
+  }
+  for (long idx = (long)b * 256 + threadIdx.x; idx < total; idx += (long)nb * 256) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
+    long o = idx;
+    if (w_layout == 1) {
+      const long n = idx / KW;
+      const int rem = (int)(idx - n * KW);
+      const int tap = rem / Cin, c = rem - tap * Cin;
+      o = n * KW + (long)c * taps + tap;
+    }
+    if (accumulate) s += out[o];
+    out[o] = s;
+  }
+}
+
+extern "C" int drn_wgrad_defer(int on) {
+  drn_clear_status();
+  const int was = g_pend_on;
+  g_pend_on = on != 0;
+  return was;
+}
+
+extern "C" int drn_wgrad_pending(void) { return g_pend.n; }
+
+extern "C" int drn_wgrad_reduce_pending(void* stream) {
+  drn_clear_status();
+  if (g_pend.n == 0) return DRN_OK;
+  int blocks = 0;
+  for (int i = 0; i < g_pend.n; ++i) {
+    const WgradPendItem& I = g_pend.it[i];
+    const long work = (I.w_layout == 1 && I.taps == 3) ? (long)I.N * I.Cin : (long)I.N * I.taps * I.Cin;
+    int nb = (int)((work + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    g_pend.blk_start[i] = blocks;
+    blocks += nb;
+  }
+  g_pend.blk_start[g_pend.n] = blocks;
+  wgrad_reduce_all_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_pend);
+  g_pend.n = 0;
+  return drn_launch_status("drn_wgrad_reduce_pending");
+}
+
 // 256x256 tiles only when they alone fill half the chip (the 4096x4096 prop_fc gradient: 256 tiles)
 static int wgrad_tile(int N, int Cin, int taps) {
   if (const char* e = drn_exp_env("DRN_TN_TILE")) return atoi(e) == 256 ? 256 : 128;
@@ -868,7 +971,7 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
     WGRAD3_LAUNCH(dim3(cdiv(N, 128), cdiv(Cin, 128), ns), P);
     int rc = drn_launch_status("drn_gemm_wgrad(fused taps)");
     if (rc) return rc;
-    if (!P.direct) {
+    if (!P.direct && !wgrad_pend_push(ws, dW, ns, N, Cin, taps, w_layout, accumulate)) {
       const long total = (long)N * taps * Cin;
       int nb = (int)((total + 255) / 256);
       if (nb > 2048) nb = 2048;
@@ -917,7 +1020,7 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
   }
   int rc = drn_launch_status("drn_gemm_wgrad");
   if (rc) return rc;
-  if (!P.direct) {
+  if (!P.direct && !wgrad_pend_push(ws, dW, ns, N, Cin, taps, w_layout, accumulate)) {
     const long total = (long)N * taps * Cin;
     int nb = (int)((total + 255) / 256);
     if (nb > 2048) nb = 2048;
@@ -1014,6 +1117,11 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
   else conv_wgrad_tn_kernel<float, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
   int rc = drn_launch_status("drn_gemm_wgrad_multi");
   if (rc || !any_split) return rc;
+  if (g_pend_on && g_pend.n + n <= WGRAD_PEND_MAX) {
+    for (int g = 0; g < n; ++g)
+      if (RM.nsplit[g] > 1) wgrad_pend_push(RM.ws[g], RM.out[g], RM.nsplit[g], N, RM.cin[g], taps, w_layout, accumulate);
+    return rc;
+  }
   int nb = (int)(((long)N * taps * Cin + 255) / 256);
   if (nb > 1024) nb = 1024;
   wgrad_reduce_multi_kernel<<<dim3(nb, n), 256, 0, stream>>>(RM, N, taps, w_layout, accumulate);

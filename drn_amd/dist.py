@@ -39,6 +39,9 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+WGRAD_DEFER = os.environ.get("DRN_WGRAD_DEFER", "1") != "0"      # (experiment switch: 0 = every weight gradient reduces in its own launch)
+
+
 def _initialized(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
@@ -208,9 +211,23 @@ class GradReducer(object):
         if self.overlap and b.pending == 0 and not b.launched:
             self._launch(b)
 
+    def _wgrad_defer(self, on):
+        """Between zero() and collect() the conv weight-gradient launches leave their reduce passes to ONE launch that collect()
+        issues (drn_amd.ops.wgrad_defer / wgrad_reduce_pending): nothing reads a gradient before collect() -- except the eager
+        multi-GPU mode, whose hooks hand buckets to RCCL as backward fills them; that mode keeps the per-launch reduces."""
+        if not self.params or not self.params[0].is_cuda or (self.world > 1 and self.overlap) or not WGRAD_DEFER:
+            return
+        from . import ops
+        if on:
+            ops.wgrad_defer(True)
+        else:
+            ops.wgrad_reduce_pending()
+            ops.wgrad_defer(False)
+
     def zero(self):
         """Call before each backward: re-arm the buckets.  steal mode drops p.grad (the flat slices get overwritten by
         backward); otherwise the flat buffers are zeroed and p.grad stay views that autograd accumulates into."""
+        self._wgrad_defer(True)
         for b in self.buckets:
             b.pending, b.handle, b.launched = len(b.params), None, False
             if self.steal:
@@ -236,6 +253,7 @@ class GradReducer(object):
         read as zero, gradients produced outside the sinks (stock autograd ops, hand-set) are copied in with one
         multi-tensor launch per bucket.  Device work only, so it can sit inside a captured hipGraph: call it at the end
         of the captured forward+backward and `reduce()` after the replay."""
+        self._wgrad_defer(False)
         for b in (self.buckets if buckets is None else buckets):
             if not self.steal:
                 continue
@@ -294,6 +312,7 @@ class GradReducer(object):
         self.wait(timings)
 
     def remove(self):
+        self._wgrad_defer(False)
         for h in self._hooks:
             h.remove()
         DF.unregister_grad_sinks(self.params)          # this reducer's parameters only: other models keep their sinks

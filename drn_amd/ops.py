@@ -197,6 +197,21 @@ def wgrad_desc(dY, X, M, Lout=None, Lsrc=None, ldy=None, ldx=None):
                      ldy=dY.shape[-1] if ldy is None else ldy, ldx=X.shape[-1] if ldx is None else ldx)
 
 
+_pending_ws = []          # workspaces of weight-gradient launches whose reduce pass is deferred (wgrad_defer): alive until the flush
+
+
+def wgrad_defer(on):
+    """Deferred reduce passes on / off (drn_wgrad_defer); returns the previous setting."""
+    return bool(lib().drn_wgrad_defer(int(bool(on))))
+
+
+def wgrad_reduce_pending():
+    """Run every deferred weight-gradient reduce in ONE launch on the current stream (drn_wgrad_reduce_pending)."""
+    if lib().drn_wgrad_pending() > 0:
+        check(lib().drn_wgrad_reduce_pending(_stream()), "drn_wgrad_reduce_pending")
+    del _pending_ws[:]
+
+
 def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulate=False, dtype=F32):
     """dW (fp32) = sum over all groups / rows of dY^T * im2col(X); see include/drn_hip.h."""
     _need_gpu(dW)
@@ -209,6 +224,9 @@ def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulat
     _timed(tag, 2.0 * m_total * N * taps * Cin,
            lambda: check(lib().drn_gemm_wgrad(arr, len(descs), _p(dW), N, Cin, taps, stride, pad, w_layout, int(accumulate),
                                               _p(ws), dtype, _stream()), "drn_gemm_wgrad"))
+    _pending_ws.append((ws, dW))                    # (cheap; emptied by every flush -- and by the next one when nothing was deferred)
+    if len(_pending_ws) > 64 and lib().drn_wgrad_pending() == 0:
+        del _pending_ws[:]
 
 
 def gemm_wgrad_multi(descs, dWs, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulate=False, dtype=F32):
@@ -231,6 +249,9 @@ def gemm_wgrad_multi(descs, dWs, N, Cin, taps=1, stride=1, pad=0, w_layout=0, ac
     _timed(tag, flops,
            lambda: check(lib().drn_gemm_wgrad_multi(arr, len(descs), ptrs, N, Cin, cins, taps, stride, pad, w_layout, int(accumulate),
                                                     _p(ws), dtype, _stream()), "drn_gemm_wgrad_multi"))
+    _pending_ws.append((ws, list(dWs)))
+    if len(_pending_ws) > 64 and lib().drn_wgrad_pending() == 0:
+        del _pending_ws[:]
 
 
 # ---------------------------------------------------------------------------------------------

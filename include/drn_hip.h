@@ -122,6 +122,13 @@ int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, i
 int drn_gemm_wgrad_multi(const DrnWgradDesc* problems /*host*/, int n, float* const* dWs /*host*/, int N, int Cin,
                          const int32_t* Cins /*host*/, int taps, int stride, int pad, int w_layout, int accumulate, float* ws,
                          int dtype, void* stream);
+/* Deferred reduce passes (per host thread).  drn_wgrad_defer(1): the drn_gemm_wgrad* launches that split their rows no longer end
+ * with their own reduce launch -- they record it; drn_wgrad_reduce_pending() runs every recorded reduce in ONE launch (same
+ * summation order over the splits: same bits) and empties the list.  The caller keeps the workspaces alive until then and flushes
+ * before anything reads the gradients.  drn_wgrad_defer returns the previous setting; drn_wgrad_pending the number recorded. */
+int drn_wgrad_defer(int on);
+int drn_wgrad_pending(void);
+int drn_wgrad_reduce_pending(void* stream);
 
 /* ---- HBM-bound helpers (drn_amd/csrc/elementwise.hip) -------------------------------------------------- */
 /* fp32 -> dtype cast of n contiguous elements (feature tensor / weights; the reference is fp32-only). */

@@ -17,9 +17,12 @@ step = rows[bursts[-2] + 1:bursts[-1] + 1]
 is_gemm = lambda n: "conv_gemm_nt_kernel" in n or "conv_wgrad" in n or "gemm_nt_w4_kernel" in n or "gemm_nt_w4c_kernel" in n or "gemm_nt_w4h_kernel" in n
 # a weight gradient with a separate reduce pass is ONE tagged launch followed by its wgrad_reduce kernel(s): fold them in
 launches = []
+reduce_all = 0.0
 for n, s, e, gx, wx, gy, gz in step:
     if is_gemm(n):
         launches.append([n, (e - s) / 1e3, (gx // max(wx, 1)) * max(gy, 1) * max(gz, 1), 0.0])
+    elif n.startswith("wgrad_reduce_all"):           # the step's deferred reduce passes in one launch: its own line below
+        reduce_all = (e - s) / 1e3
     elif n.startswith("wgrad_reduce") and launches:
         launches[-1][3] += (e - s) / 1e3
 if len(launches) != len(gemms):
@@ -37,5 +40,8 @@ if len(sys.argv) > 4:
     for (tag, fl), (n, us, wgs, red) in zip(gemms, launches):
         out[tag] = {"us": round(us, 1), "reduce_us": round(red, 1), "TFLOP/s": round(fl / (us * 1e-6) / 1e12, 1), "frac": round(fl / (us * 1e-6) / 1e12 / peak, 4)}
     json.dump(out, open(sys.argv[4], "w"), indent=0)
+if reduce_all:
+    print("#   + wgrad_reduce_all_kernel (every weight gradient's reduce pass, one launch) %.1f us" % reduce_all)
+    tot_us += reduce_all
 print("# total %.1f us (reduce passes included), %.1f GFLOP, %.0f TFLOP/s = %.1f %% of peak"
       % (tot_us, tot_fl / 1e9, tot_fl / (tot_us * 1e-6) / 1e12, 100.0 * tot_fl / (tot_us * 1e-6) / 1e12 / peak))

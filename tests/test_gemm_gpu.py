@@ -905,3 +905,43 @@ def test_w4h_kernel_splitk_in_launch(monkeypatch, shape):
         close(t1, t0, 1e-4, "column sums")
         close(q1, q0, 1e-4, "column M2")
     assert int(ops._counters(dev()).abs().sum()) == 0
+
+
+def test_deferred_wgrad_reduce_passes_in_one_launch_equal_the_immediate_ones():
+    """drn_wgrad_defer / drn_wgrad_reduce_pending: three weight gradients (fused-tap k = 3, per-tap stride 2, a grouped multi launch)
+    whose reduce passes run as ONE launch at the end give the bits of the launches that reduce themselves."""
+    from drn_amd import ops, _lib
+    g = torch.Generator().manual_seed(3)
+
+    def case(B, L, Cin, Cout, k, stride):
+        x = torch.randn(B, L, Cin, generator=g).to(torch.bfloat16).to(dev())
+        Lo = (L + 2 * ((k - 1) // 2) - k) // stride + 1
+        dy = torch.randn(B, Lo, Cout, generator=g).to(torch.bfloat16).to(dev())
+        return x, dy, (B, L, Lo, Cin, Cout, k, stride)
+    cases = [case(32, 256, 256, 256, 3, 1), case(16, 128, 128, 256, 3, 2), case(32, 128, 512, 128, 1, 1)]
+    levels = [case(32, 256, 128, 128, 3, 1), case(32, 128, 128, 128, 3, 1), case(32, 64, 128, 128, 3, 1)]
+
+    def run():
+        outs = []
+        for x, dy, (B, L, Lo, Cin, Cout, k, stride) in cases:
+            dW = torch.full((Cout, Cin, k), float("nan"), device=dev())
+            ops.gemm_wgrad([ops.wgrad_desc(dy, x, B * Lo, Lout=Lo, Lsrc=L, ldy=Cout, ldx=Cin)], dW, Cout, Cin, taps=k, stride=stride,
+                           pad=(k - 1) // 2, w_layout=1, dtype=ops.BF16)
+            outs.append(dW)
+        dWs = [torch.full((128, 128, 3), float("nan"), device=dev()) for _ in levels]
+        ops.gemm_wgrad_multi([ops.wgrad_desc(dy, x, m[0] * m[2], Lout=m[2], Lsrc=m[1], ldy=128, ldx=128) for x, dy, m in levels], dWs, 128, 128,
+                             taps=3, stride=1, pad=1, w_layout=1, dtype=ops.BF16)
+        return outs + dWs
+    ref = run()
+    torch.cuda.synchronize()
+    assert ops.wgrad_defer(True) is False
+    try:
+        got = run()
+        n_pending = _lib.lib().drn_wgrad_pending()
+        ops.wgrad_reduce_pending()
+    finally:
+        ops.wgrad_defer(False)
+    torch.cuda.synchronize()
+    assert n_pending >= 3 and _lib.lib().drn_wgrad_pending() == 0
+    for a, b in zip(ref, got):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
