@@ -32,7 +32,7 @@ class GemmDesc(ctypes.Structure):
                 ("Cin", c_int32), ("taps", c_int32), ("stride", c_int32), ("pad", c_int32), ("mode", c_int32),
                 ("Lout", c_int32), ("Lsrc", c_int32),
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldg", c_int32),
-                ("accumulate", c_int32), ("ldc2", c_int32), ("out_f32", c_int32)]
+                ("accumulate", c_int32), ("ldc2", c_int32), ("out_f32", c_int32), ("sumsq", c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -124,7 +124,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.drn_last_error.restype = ctypes.c_char_p
         for fn in ("drn_wgrad_ws_elems", "drn_skinny_group_ws_elems", "drn_opt_nblocks", "drn_gemm_nt_splitk_ws_elems", "drn_gemm_nt_splitk256_ws_elems", "drn_heads_ws_elems",
-                   "drn_conv_tail_bwd_ws_elems", "drn_conv_bn_train_ws_bytes"):
+                   "drn_conv_tail_bwd_ws_elems", "drn_conv_bn_train_ws_bytes", "drn_wgrad_pending_bytes"):
             if hasattr(_lib, fn):
                 getattr(_lib, fn).restype = c_int64
     return _lib

@@ -78,6 +78,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     p.mode = s.mode; p.Lout = s.Lout; p.Lsrc = s.Lsrc; p.lda = s.lda; p.ldb = s.ldb; p.ldc = s.ldc; p.ldg = s.ldg; p.ldc2 = s.ldc2;
     p.accumulate = s.accumulate;
     p.out_f32 = s.out_f32;
+    p.sumsq = s.sumsq;
     p.tiles_n = cdiv(s.N, tile_n);
     p.tile_start = total;
     total += cdiv(s.M, tile_m) * p.tiles_n;
@@ -126,6 +127,10 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     P.nblocks = total;
     return drn_nt_w4h_launch(P, total, w4h_conv, stream, ksplit);
   }
+  for (int g = 0; g < ngroups; ++g)
+    DRN_CHECK_ARG(!d[g].sumsq || (kind == DRN_NT_KIND_W4 && d[g].out_f32 && !d[g].bias && !d[g].accumulate && ngroups == 1),
+                  "drn_gemm_nt: DrnGemmDesc::sumsq needs a single fp32-output launch on gemm_nt_w4_kernel without bias / accumulate "
+                  "(ask drn_gemm_nt_plan first)");
   if (kind == DRN_NT_KIND_W4) {
     P.nblocks = total;
     return drn_nt_w4_launch(P, total, stream);

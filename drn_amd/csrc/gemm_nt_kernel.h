@@ -39,6 +39,7 @@ struct GemmProb {
   int accumulate;
   int out_f32;      // C is fp32 [M][ldc] whatever T is (weight gradients computed as an NT product of transposed operands)
   int tiles_n, tile_start;
+  float* sumsq;     // gemm_nt_w4_kernel, out_f32: [workgroups] sum of the squares of each workgroup's outputs (DrnGemmDesc::sumsq)
 };
 struct GemmParams {
   int ngroups;

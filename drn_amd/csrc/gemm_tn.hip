@@ -754,9 +754,12 @@ struct WgradPendParams {
   WgradPendItem it[WGRAD_PEND_MAX];
   int blk_start[WGRAD_PEND_MAX + 1];
   int n;
+  float* sumsq;     // or NULL: [gridDim.x] sum of the squares of what each workgroup wrote
 };
-static thread_local int g_pend_on = 0;
-static thread_local WgradPendParams g_pend;
+// process-wide, NOT thread-local: autograd runs a step's backward -- and with it these launches -- on its own device thread while the
+// thread that called backward() (and that switches the mode and flushes) waits; the two never launch at the same time.
+static int g_pend_on = 0;
+static WgradPendParams g_pend;
 
 static bool wgrad_pend_push(const float* ws, float* out, int nsplit, int N, int Cin, int taps, int w_layout, int accumulate) {
   if (!g_pend_on || g_pend.n >= WGRAD_PEND_MAX) return false;
@@ -765,6 +768,8 @@ static bool wgrad_pend_push(const float* ws, float* out, int nsplit, int N, int 
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendParams P) {
+  __shared__ float sh_sq[17];
+  float sq = 0.f;
   int i = 0;
   for (int k = 1; k < P.n; ++k)
     if ((int)blockIdx.x >= P.blk_start[k]) i = k;
@@ -775,6 +780,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendPa
   const int N = I.N, Cin = I.Cin, taps = I.taps, nsplit = I.nsplit, accumulate = I.accumulate, w_layout = I.w_layout;
   const long KW = (long)taps * Cin;
   const long total = (long)N * KW;
+  // (16-byte accesses -- four channels per thread -- were measured and bought nothing: 61.5 vs 60.5 us at the training shapes)
   if (w_layout == 1 && taps == 3) {               // the arithmetic of wgrad_reduce_kernel, statement for statement
     const long pairs = (long)N * Cin;
     for (long idx = (long)b * 256 + threadIdx.x; idx < pairs; idx += (long)nb * 256) {
@@ -797,21 +803,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendPa
       o[0] = s0;
       o[1] = s1;
       o[2] = s2;
+      sq = fmaf(s0, s0, sq); sq = fmaf(s1, s1, sq); sq = fmaf(s2, s2, sq);
     }
-    return;
+  } else {
+    for (long idx = (long)b * 256 + threadIdx.x; idx < total; idx += (long)nb * 256) {
+      float s = 0.f;
+      for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
+      long o = idx;
+      if (w_layout == 1) {
+        const long n = idx / KW;
+        const int rem = (int)(idx - n * KW);
+        const int tap = rem / Cin, c = rem - tap * Cin;
+        o = n * KW + (long)c * taps + tap;
+      }
+      if (accumulate) s += out[o];
+      out[o] = s;
+      sq = fmaf(s, s, sq);
+    }
   }
-  for (long idx = (long)b * 256 + threadIdx.x; idx < total; idx += (long)nb * 256) {
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
-    long o = idx;
-    if (w_layout == 1) {
-      const long n = idx / KW;
-      const int rem = (int)(idx - n * KW);
-      const int tap = rem / Cin, c = rem - tap * Cin;
-      o = n * KW + (long)c * taps + tap;
-    }
-    if (accumulate) s += out[o];
-    out[o] = s;
+  if (P.sumsq) {                       // (wave-uniform: a kernel argument)
+    sq = block_sum(sq, sh_sq);
+    if (threadIdx.x == 0) P.sumsq[blockIdx.x] = sq;
   }
 }
 
@@ -824,9 +836,7 @@ extern "C" int drn_wgrad_defer(int on) {
 
 extern "C" int drn_wgrad_pending(void) { return g_pend.n; }
 
-extern "C" int drn_wgrad_reduce_pending(void* stream) {
-  drn_clear_status();
-  if (g_pend.n == 0) return DRN_OK;
+static int wgrad_pend_plan() {
   int blocks = 0;
   for (int i = 0; i < g_pend.n; ++i) {
     const WgradPendItem& I = g_pend.it[i];
@@ -837,10 +847,41 @@ extern "C" int drn_wgrad_reduce_pending(void* stream) {
     blocks += nb;
   }
   g_pend.blk_start[g_pend.n] = blocks;
+  return blocks;
+}
+
+extern "C" int drn_wgrad_pending_blocks(void) { return wgrad_pend_plan(); }
+
+// bytes the pending launch will move (partials read + gradients written [+ read when accumulating]): its roofline denominator
+extern "C" int64_t drn_wgrad_pending_bytes(void) {
+  int64_t b = 0;
+  for (int i = 0; i < g_pend.n; ++i) {
+    const WgradPendItem& I = g_pend.it[i];
+    b += (int64_t)I.N * I.taps * I.Cin * 4 * (I.nsplit + 1 + (I.accumulate ? 1 : 0));
+  }
+  return b;
+}
+
+extern "C" int drn_wgrad_pending_outputs(void** outs, int64_t* numels) {
+  for (int i = 0; i < g_pend.n; ++i) {
+    outs[i] = g_pend.it[i].out;
+    numels[i] = (int64_t)g_pend.it[i].N * g_pend.it[i].taps * g_pend.it[i].Cin;
+  }
+  return g_pend.n;
+}
+
+extern "C" int drn_wgrad_reduce_pending_sumsq(float* sumsq, void* stream) {
+  drn_clear_status();
+  if (g_pend.n == 0) return DRN_OK;
+  const int blocks = wgrad_pend_plan();
+  g_pend.sumsq = sumsq;
   wgrad_reduce_all_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_pend);
   g_pend.n = 0;
+  g_pend.sumsq = nullptr;
   return drn_launch_status("drn_wgrad_reduce_pending");
 }
+
+extern "C" int drn_wgrad_reduce_pending(void* stream) { return drn_wgrad_reduce_pending_sumsq(nullptr, stream); }
 
 // 256x256 tiles only when they alone fill half the chip (the 4096x4096 prop_fc gradient: 256 tiles)
 static int wgrad_tile(int N, int Cin, int taps) {

@@ -34,7 +34,148 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_kernel(const float
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+extern "C" int64_t drn_opt_nblocks(int64_t n);
+// The same pass with up to DRN_SUMSQ_MAX_SKIP element ranges LEFT OUT: gradients whose squared sums were produced by the kernels that
+// wrote them (the prop_fc weight gradient's GEMM epilogue, the one-launch reduce of the conv weight gradients) and reach
+// drn_sumsq_finalize2 as external partials -- 108 of the 153 MB of a step's gradients are not read a second time.  A block inside a
+// range writes 0 and leaves; blocks clear of every range run the statements of sumsq_partials_kernel; the (few) boundary blocks test
+// every element.
+struct SumsqSkip {
+  long lo[DRN_SUMSQ_MAX_SKIP], hi[DRN_SUMSQ_MAX_SKIP];
+  int n;
+};
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_partials_skip_kernel(const float* __restrict__ g, long n, float* __restrict__ partials,
+                                                                           int* __restrict__ step_counter, const SumsqSkip K,
+                                                                           const unsigned char* __restrict__ cls) {
+  __shared__ float sh[17];
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
+  const long base = (long)blockIdx.x * OPT_ELEMS_PER_BLOCK, end = min(n, base + OPT_ELEMS_PER_BLOCK);
+  bool inside = false, touches = false;
+  if (cls) {                             // host-classified blocks (drn_sumsq_block_classes): 0 clear of every range, 1 inside one, 2 boundary
+    const int c = cls[blockIdx.x];       // (walking the ranges in every block put ~1.5 us of dependent scalar loads in front of each:
+    inside = c == 1;                     //  37 us for a third of the bytes the plain pass reads in 28)
+    touches = c != 0;
+  } else {
+#pragma unroll
+    for (int r = 0; r < DRN_SUMSQ_MAX_SKIP; ++r) {      // (static indices: the ranges are read from the kernel arguments once)
+      inside |= r < K.n && K.lo[r] <= base && end <= K.hi[r];
+      touches |= r < K.n && K.lo[r] < end && base < K.hi[r];
+    }
+  }
+  if (inside) {
+    if (threadIdx.x == 0) partials[blockIdx.x] = 0.f;
+    return;
+  }
+  float s = 0.f;
+  if (!touches) {
+    for (int i = threadIdx.x * 4; i < OPT_ELEMS_PER_BLOCK; i += OPT_THREADS * 4) {
+      const long k = base + i;
+      if (k + 4 <= n) {
+        const f32x4 v = *(const f32x4*)(g + k);
+        s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+      } else {
+        for (int e = 0; e < 4 && k + e < n; ++e) s = fmaf(g[k + e], g[k + e], s);
+      }
+    }
+  } else {
+    // a boundary block: the (one or two) ranges that reach into it, clipped to block-local offsets -- walking K.lo[r] with a
+    // run-time r costs a dependent scalar load per test, which made these 16 blocks a 30 us tail
+    int l0 = 0, h0 = 0, l1 = 0, h1 = 0, extra = 0;
+#pragma unroll
+    for (int r = 0; r < DRN_SUMSQ_MAX_SKIP; ++r) {
+      if (r < K.n && K.lo[r] < end && base < K.hi[r]) {
+        const int l = (int)(max(K.lo[r], base) - base), h = (int)(min(K.hi[r], end) - base);
+        if (h0 == 0) { l0 = l; h0 = h; }
+        else if (h1 == 0) { l1 = l; h1 = h; }
+        else extra = 1;
+      }
+    }
+    const int len = (int)(end - base);
+    for (int k = threadIdx.x; k < len; k += OPT_THREADS) {
+      bool skip = (l0 <= k && k < h0) || (l1 <= k && k < h1);
+      if (extra) {                       // three or more ranges meet in one block (ranges shorter than a block)
+        for (int r = 0; r < K.n; ++r) skip |= K.lo[r] <= base + k && base + k < K.hi[r];
+      }
+      if (!skip) s = fmaf(g[base + k], g[base + k], s);
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
 extern "C" int64_t drn_opt_nblocks(int64_t n) { return (n + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK; }
+
+extern "C" int drn_sumsq_block_classes(int64_t n, const int64_t* skip_lo, const int64_t* skip_hi, int nskip, unsigned char* cls_host) {
+  drn_clear_status();
+  DRN_CHECK_ARG(n > 0 && cls_host && nskip >= 0 && (nskip == 0 || (skip_lo && skip_hi)), "drn_sumsq_block_classes: bad args");
+  const long nb = drn_opt_nblocks(n);
+  for (long b = 0; b < nb; ++b) {
+    const long base = b * OPT_ELEMS_PER_BLOCK, end = base + OPT_ELEMS_PER_BLOCK < n ? base + OPT_ELEMS_PER_BLOCK : n;
+    bool inside = false, touches = false;
+    for (int r = 0; r < nskip; ++r) {
+      inside |= skip_lo[r] <= base && end <= skip_hi[r];
+      touches |= skip_lo[r] < end && base < skip_hi[r];
+    }
+    cls_host[b] = inside ? 1 : (touches ? 2 : 0);
+  }
+  return DRN_OK;
+}
+
+extern "C" int drn_sumsq_partials_skip(const float* g, int64_t n, float* partials, int* step_counter, const int64_t* skip_lo,
+                                       const int64_t* skip_hi, int nskip, const unsigned char* cls_dev, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(g && partials && n > 0 && nskip >= 0 && nskip <= DRN_SUMSQ_MAX_SKIP && (nskip == 0 || (skip_lo && skip_hi)),
+                "drn_sumsq_partials_skip: bad args (at most %d ranges)", DRN_SUMSQ_MAX_SKIP);
+  SumsqSkip K;
+  memset(&K, 0, sizeof(K));
+  K.n = nskip;
+  for (int r = 0; r < nskip; ++r) {
+    DRN_CHECK_ARG(skip_lo[r] >= 0 && skip_lo[r] <= skip_hi[r] && skip_hi[r] <= n, "drn_sumsq_partials_skip: bad range %d", r);
+    K.lo[r] = skip_lo[r]; K.hi[r] = skip_hi[r];
+  }
+  sumsq_partials_skip_kernel<<<(int)drn_opt_nblocks(n), OPT_THREADS, 0, (hipStream_t)stream>>>(g, n, partials, step_counter, K, cls_dev);
+  return drn_launch_status("drn_sumsq_partials_skip");
+}
+
+struct SumsqExt {
+  const float* p[DRN_SUMSQ_MAX_EXT];
+  int n[DRN_SUMSQ_MAX_EXT];
+  int next;
+};
+__global__ __launch_bounds__(1024) void sumsq_finalize2_kernel(const float* __restrict__ partials, int n, const SumsqExt E,
+                                                               float* __restrict__ out, float grad_scale) {
+  __shared__ float sh[17];
+  float s = 0.f;
+#pragma unroll 8
+  for (int i = threadIdx.x; i < n; i += 1024) s += partials[i];
+#pragma unroll
+  for (int e = 0; e < DRN_SUMSQ_MAX_EXT; ++e) {
+    if (e < E.next) {
+      const float* __restrict__ q = E.p[e];
+      const int ne = E.n[e];
+#pragma unroll 8
+      for (int i = threadIdx.x; i < ne; i += 1024) s += q[i];
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s * grad_scale * grad_scale;
+}
+
+extern "C" int drn_sumsq_finalize2(const float* partials, int npartials, const float* const* ext, const int32_t* ext_n, int next,
+                                   float* total_sumsq, float grad_scale, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(partials && total_sumsq && npartials > 0 && next >= 0 && next <= DRN_SUMSQ_MAX_EXT && (next == 0 || (ext && ext_n)),
+                "drn_sumsq_finalize2: bad args (at most %d external partial arrays)", DRN_SUMSQ_MAX_EXT);
+  SumsqExt E;
+  memset(&E, 0, sizeof(E));
+  E.next = next;
+  for (int e = 0; e < next; ++e) {
+    DRN_CHECK_ARG(ext[e] && ext_n[e] > 0, "drn_sumsq_finalize2: bad external array %d", e);
+    E.p[e] = ext[e]; E.n[e] = ext_n[e];
+  }
+  sumsq_finalize2_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partials, npartials, E, total_sumsq, grad_scale);
+  return drn_launch_status("drn_sumsq_finalize2");
+}
 
 extern "C" int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_counter, void* stream) {
   drn_clear_status();

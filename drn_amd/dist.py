@@ -218,11 +218,20 @@ class GradReducer(object):
         if not self.params or not self.params[0].is_cuda or (self.world > 1 and self.overlap) or not WGRAD_DEFER:
             return
         from . import ops
+        want = bool(getattr(self, "ext_sumsq", False)) and self.world == 1
         if on:
             ops.wgrad_defer(True)
+            DF.want_sumsq(want)
+            self.sumsq_notes = []
         else:
-            ops.wgrad_reduce_pending()
+            res = ops.wgrad_reduce_pending(sumsq=want)
             ops.wgrad_defer(False)
+            if want:
+                if res is not None:
+                    DF.note_sumsq(*res)
+                # (kept until the next zero(): the fused optimizer's norm pass leaves these ranges out and adds the partials)
+                self.sumsq_notes = getattr(self, "sumsq_notes", []) + DF.take_sumsq_notes()
+                DF.want_sumsq(False)
 
     def zero(self):
         """Call before each backward: re-arm the buckets.  steal mode drops p.grad (the flat slices get overwritten by

@@ -487,6 +487,29 @@ def _defer(job, *grad_bufs):
         job()
 
 
+# Squared-sum partials left behind by the kernels that write gradients (for the fused optimizer's norm pass, one process only):
+# a reducer that wants them says so before backward (want_sumsq), producers note what they covered, the reducer collects the notes.
+_sumsq_want = False
+_sumsq_notes = []
+
+
+def want_sumsq(on):
+    global _sumsq_want
+    _sumsq_want = bool(on)
+    del _sumsq_notes[:]
+
+
+def note_sumsq(ranges, partials):
+    """ranges: [(data_ptr, elements)] of gradient memory whose squares are summed in `partials` (a device tensor, all of it)."""
+    _sumsq_notes.append((list(ranges), partials))
+
+
+def take_sumsq_notes():
+    notes = list(_sumsq_notes)
+    del _sumsq_notes[:]
+    return notes
+
+
 NT_WGRAD = True      # prop_fc weight gradient through the NT kernel on transposed operands (bf16): 250 vs 410 us for the TN kernel
 TOUCH_W = os.environ.get("DRN_TOUCH_W", "1") != "0"       # warm the prop_fc weight copy right before its GEMM (round 2 re-measured: 2.562 vs 2.577 ms without)
 
@@ -1181,7 +1204,13 @@ class _InputStageFn(torch.autograd.Function):
 
         def wgrads():
             if dZT is not None:
-                ops.gemm_nt([ops.gemm_desc(dZT, xcT, jW, D, D, B * T, out_f32=True)], code)
+                d = ops.gemm_desc(dZT, xcT, jW, D, D, B * T, out_f32=True)
+                if _sumsq_want and ops.gemm_nt_plan([d], code) == ops.NT_KIND_W4:
+                    # the GEMM's epilogue leaves sum(dW^2) per output tile: the optimizer's norm pass does not read these 67 MB again
+                    part = ops.persistent_buffer(("prop_fc_wgrad", jW.data_ptr()), (D // 256) * (D // 256), jW.device)
+                    d.sumsq = ops._p(part)
+                    note_sumsq([(jW.data_ptr(), jW.numel())], part)
+                ops.gemm_nt([d], code)
             elif xcT.numel():
                 dZt = ops.transpose2d(dZ.view(B * T, D), code)      # (a descriptor holds raw pointers: keep the operand alive)
                 ops.gemm_nt([ops.gemm_desc(dZt, xcT, jW, D, D, B * T, out_f32=True)], code)

@@ -38,7 +38,7 @@ def _need_gpu(*ts):
 
 
 def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Lsrc=None, lda=None, ldb=None,
-              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, ldc2=None, accumulate=False, out_f32=False):
+              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, ldc2=None, accumulate=False, out_f32=False, sumsq=None):
     _need_gpu(A, B, C, bias, gate, stats, C2)
     Lout = M if Lout is None else Lout
     Lsrc = Lout if Lsrc is None else Lsrc
@@ -46,7 +46,7 @@ def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Ls
                     M=M, N=N, Cin=Cin, taps=taps, stride=stride, pad=pad, mode=mode, Lout=Lout, Lsrc=Lsrc,
                     lda=Cin if lda is None else lda, ldb=taps * Cin if ldb is None else ldb,
                     ldc=N if ldc is None else ldc, ldg=ldg, accumulate=int(accumulate),
-                    ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2, out_f32=int(out_f32))
+                    ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2, out_f32=int(out_f32), sumsq=_p(sumsq))
 
 
 # Optional per-launch timing of the MFMA kernels (bench.py): a list collecting (tag, flops, start_event, end_event),
@@ -205,11 +205,49 @@ def wgrad_defer(on):
     return bool(lib().drn_wgrad_defer(int(bool(on))))
 
 
-def wgrad_reduce_pending():
-    """Run every deferred weight-gradient reduce in ONE launch on the current stream (drn_wgrad_reduce_pending)."""
-    if lib().drn_wgrad_pending() > 0:
-        check(lib().drn_wgrad_reduce_pending(_stream()), "drn_wgrad_reduce_pending")
+_persistent = {}
+
+
+def persistent_buffer(key, n, device, dtype=torch.float32):
+    """A buffer that keeps its address for the life of the process (per key and size): small per-step outputs that a LATER launch of
+    the same or of the next step reads -- the squared-sum partials the gradient-writing kernels leave for the optimizer's norm pass --
+    must not move between an eager step and a captured one."""
+    k = (key, int(n), str(device), dtype)
+    buf = _persistent.get(k)
+    if buf is None:
+        if len(_persistent) > 256:
+            _persistent.clear()
+        buf = _persistent[k] = torch.zeros(int(n), dtype=dtype, device=device)
+    return buf
+
+
+last_reduce_bytes = 0
+
+
+def wgrad_reduce_pending(sumsq=False):
+    """Run every deferred weight-gradient reduce in ONE launch on the current stream (drn_wgrad_reduce_pending).  sumsq=True: the
+    launch also leaves the squared sums of what it wrote; returns (ranges [(data_ptr, elements)] of the reduced gradients, partials
+    tensor) -- or None when nothing was pending."""
+    global last_reduce_bytes
+    L = lib()
+    n = L.drn_wgrad_pending()
+    res = None
+    if n > 0:
+        last_reduce_bytes = int(L.drn_wgrad_pending_bytes())      # (for the profile tables: the launch's HBM-roofline denominator)
+    if n > 0 and sumsq:
+        outs = (ctypes.c_void_p * n)()
+        numels = (ctypes.c_int64 * n)()
+        L.drn_wgrad_pending_outputs(outs, numels)
+        ranges = [(int(outs[i]), int(numels[i])) for i in range(n)]
+        blocks = int(L.drn_wgrad_pending_blocks())
+        dev = torch.device("cuda", torch.cuda.current_device())
+        part = persistent_buffer(("wgrad_reduce_all", ranges[0][0]), blocks, dev)
+        check(L.drn_wgrad_reduce_pending_sumsq(_p(part), _stream()), "drn_wgrad_reduce_pending_sumsq")
+        res = (ranges, part)
+    elif n > 0:
+        check(L.drn_wgrad_reduce_pending(_stream()), "drn_wgrad_reduce_pending")
     del _pending_ws[:]
+    return res
 
 
 def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulate=False, dtype=F32):

@@ -5,8 +5,16 @@ import ctypes
 
 import torch
 
+import os
+
 from . import functional as DF
 from ._lib import check, lib
+
+# 1 = the norm pass leaves out the gradients whose producers already summed their squares (prop_fc's GEMM epilogue, the one-launch
+# reduce of the conv weight gradients): the pass drops 28 -> 16 us, and the step does not move (2.051 vs 2.050-2.067 ms, in one box) --
+# the plain pass was also pulling those 108 MB into the 256 MB infinity cache for the Adam kernels behind it (adam_tiled +9 us
+# without it), and the producers pay 1-5 us for the sums.  Kept as a measured option, off.
+EXT_SUMSQ = os.environ.get("DRN_EXT_SUMSQ", "0") != "0"
 
 
 class FusedAdam(object):
@@ -17,6 +25,9 @@ class FusedAdam(object):
         # division by the world size rides here instead of one elementwise launch per bucket and step
         reducer.defer_average = True
         self.grad_scale = 1.0 / float(reducer.world)
+        # one process: the kernels that write the large gradients leave their squared sums behind and the norm pass skips those
+        # ranges (drn_sumsq_partials_skip / drn_sumsq_finalize2); with several ranks the norm is of the all-reduced gradients
+        reducer.ext_sumsq = reducer.world == 1 and EXT_SUMSQ
         L = lib()
         L.drn_opt_nblocks.restype = ctypes.c_int64
         dev = reducer.buckets[0].flat.device
@@ -83,12 +94,49 @@ class FusedAdam(object):
         L = lib()
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        notes = list(getattr(self.reducer, "sumsq_notes", None) or []) if getattr(self.reducer, "ext_sumsq", False) else []
+        spans = [(b.flat.data_ptr(), b.flat.data_ptr() + 4 * b.flat.numel()) for b in self.reducer.buckets]
+        # a note is used whole or not at all: every range it covers must be bucket memory (a gradient that was produced elsewhere
+        # and copied in is read by the pass like everything else) -- and at most DRN_SUMSQ_MAX_EXT arrays
+        notes = [nt for nt in notes if all(any(lo <= ptr and ptr + 4 * ne <= hi for lo, hi in spans) for ptr, ne in nt[0])][:8]
+        used = []
         for i, (b, st) in enumerate(zip(self.reducer.buckets, self.state)):
             part = self.partials[st["part_off"]:]
-            check(L.drn_sumsq_partials(P(b.flat), ctypes.c_int64(b.flat.numel()), P(part),
-                                       P(self.step_counter) if i == 0 else None, s), "drn_sumsq_partials")
-        check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), ctypes.c_float(self.grad_scale), s),
-              "drn_sumsq_finalize")
+            base, n = b.flat.data_ptr(), b.flat.numel()
+            rng = sorted((ptr - base) // 4 for nt in notes for ptr, ne in nt[0] if base <= ptr < base + 4 * n)
+            ends = {(ptr - base) // 4: (ptr - base) // 4 + ne for nt in notes for ptr, ne in nt[0] if base <= ptr < base + 4 * n}
+            merged = []
+            for lo in rng:                                  # adjacent ranges (stacked parameters) become one
+                if merged and merged[-1][1] >= lo:
+                    merged[-1][1] = max(merged[-1][1], ends[lo])
+                else:
+                    merged.append([lo, ends[lo]])
+            if len(merged) > 16:                            # DRN_SUMSQ_MAX_SKIP: not with DRN's parameter count; take the plain pass
+                notes, merged = [], []
+            if merged:
+                lo_a = (ctypes.c_int64 * len(merged))(*[m[0] for m in merged])
+                hi_a = (ctypes.c_int64 * len(merged))(*[min(m[1], n) for m in merged])
+                key = (i, tuple((m[0], m[1]) for m in merged))
+                cls = self.__dict__.setdefault("_skip_cls", {}).get(key)
+                if cls is None and not torch.cuda.is_current_stream_capturing():     # (an upload: never inside a capture)
+                    host = (ctypes.c_ubyte * st["nb"])()
+                    check(L.drn_sumsq_block_classes(ctypes.c_int64(n), lo_a, hi_a, len(merged), host), "drn_sumsq_block_classes")
+                    cls = self._skip_cls[key] = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(b.flat.device)
+                check(L.drn_sumsq_partials_skip(P(b.flat), ctypes.c_int64(n), P(part), P(self.step_counter) if i == 0 else None, lo_a, hi_a,
+                                                len(merged), P(cls), s), "drn_sumsq_partials_skip")
+                used.append(True)
+            else:
+                check(L.drn_sumsq_partials(P(b.flat), ctypes.c_int64(n), P(part), P(self.step_counter) if i == 0 else None, s),
+                      "drn_sumsq_partials")
+        if used and notes:
+            # (every range of a note must have been left out: they all lie in this reducer's buckets by construction)
+            ext = (ctypes.c_void_p * len(notes))(*[nt[1].data_ptr() for nt in notes])
+            ext_n = (ctypes.c_int32 * len(notes))(*[nt[1].numel() for nt in notes])
+            check(L.drn_sumsq_finalize2(P(self.partials), self.partials.numel(), ext, ext_n, len(notes), P(self.total_sumsq),
+                                        ctypes.c_float(self.grad_scale), s), "drn_sumsq_finalize2")
+        else:
+            check(L.drn_sumsq_finalize(P(self.partials), self.partials.numel(), P(self.total_sumsq), ctypes.c_float(self.grad_scale), s),
+                  "drn_sumsq_finalize")
         self._refresh_mirrors()
 
     def update(self, buckets=None):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 5
+#define DRN_ABI_VERSION 6
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
@@ -63,6 +63,9 @@ typedef struct DrnGemmDesc {
   int32_t accumulate; /* 1: C += result */
   int32_t ldc2;       /* row stride of C2 */
   int32_t out_f32;    /* 1: C is fp32 [M][ldc] regardless of dtype (no C2 / gate / stats): weight gradients as an NT product */
+  float* sumsq;       /* or NULL.  out_f32 launches on gemm_nt_w4_kernel only (drn_gemm_nt_plan says DRN_NT_KIND_W4; no bias / accumulate):
+                       * sumsq[t] = sum of the squares of output tile t's values (256x256 tiles in launch order, (M/256)*(N/256) floats):
+                       * the gradient's contribution to the global norm without reading it again (drn_sumsq_finalize2) */
 } DrnGemmDesc;
 
 /* Grouped NT implicit GEMM on MFMA (conv1d fwd / dgrad, linear fwd / dgrad).
@@ -122,13 +125,20 @@ int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, i
 int drn_gemm_wgrad_multi(const DrnWgradDesc* problems /*host*/, int n, float* const* dWs /*host*/, int N, int Cin,
                          const int32_t* Cins /*host*/, int taps, int stride, int pad, int w_layout, int accumulate, float* ws,
                          int dtype, void* stream);
-/* Deferred reduce passes (per host thread).  drn_wgrad_defer(1): the drn_gemm_wgrad* launches that split their rows no longer end
+/* Deferred reduce passes (process-wide: one training step at a time).  drn_wgrad_defer(1): the drn_gemm_wgrad* launches that split their rows no longer end
  * with their own reduce launch -- they record it; drn_wgrad_reduce_pending() runs every recorded reduce in ONE launch (same
  * summation order over the splits: same bits) and empties the list.  The caller keeps the workspaces alive until then and flushes
  * before anything reads the gradients.  drn_wgrad_defer returns the previous setting; drn_wgrad_pending the number recorded. */
 int drn_wgrad_defer(int on);
 int drn_wgrad_pending(void);
 int drn_wgrad_reduce_pending(void* stream);
+/* ... with the squared sums of the reduced gradients: drn_wgrad_pending_blocks() = workgroups the flush will launch; sumsq (device,
+ * that many floats, or NULL) receives one partial per workgroup.  drn_wgrad_pending_outputs lists the recorded outputs (device
+ * pointer and element count each; arrays of >= drn_wgrad_pending() entries). */
+int drn_wgrad_pending_blocks(void);
+int64_t drn_wgrad_pending_bytes(void);      /* partials read + gradients written by that flush: its HBM roofline denominator */
+int drn_wgrad_pending_outputs(void** outs /*host*/, int64_t* numels /*host*/);
+int drn_wgrad_reduce_pending_sumsq(float* sumsq, void* stream);
 
 /* ---- HBM-bound helpers (drn_amd/csrc/elementwise.hip) -------------------------------------------------- */
 /* fp32 -> dtype cast of n contiguous elements (feature tensor / weights; the reference is fp32-only). */
@@ -518,6 +528,20 @@ int drn_sumsq_partials(const float* g, int64_t n, float* partials, int* step_cou
 /* total_sumsq[0] = grad_scale^2 * sum of ALL buckets' partials, one workgroup, fixed order: the squared global norm of the
  * gradients the Adam kernels see, grad_scale * g (grad_scale = 1/world when the buckets hold the all-reduced SUM; 1 otherwise). */
 int drn_sumsq_finalize(const float* partials, int npartials, float* total_sumsq, float grad_scale, void* stream);
+/* The norm pass WITHOUT the gradients whose squared sums the producing kernels left behind (one process only: after an all-reduce
+ * the producers' sums are stale).  drn_sumsq_partials_skip: elements in the nskip <= DRN_SUMSQ_MAX_SKIP ranges [skip_lo[i],
+ * skip_hi[i]) (host arrays, element offsets into g) are not read.  drn_sumsq_finalize2 adds next <= DRN_SUMSQ_MAX_EXT external
+ * partial arrays (host arrays of device pointers / lengths: DrnGemmDesc::sumsq of the prop_fc weight gradient,
+ * drn_wgrad_reduce_pending's sumsq) to the pass's own partials, everything in a fixed order. */
+#define DRN_SUMSQ_MAX_SKIP 16
+#define DRN_SUMSQ_MAX_EXT 8
+int drn_sumsq_partials_skip(const float* g, int64_t n, float* partials, int* step_counter, const int64_t* skip_lo /*host*/,
+                            const int64_t* skip_hi /*host*/, int nskip, const unsigned char* block_classes /*device or NULL*/, void* stream);
+/* Host helper: block_classes[b] for the drn_opt_nblocks(n) blocks of that pass (0 = clear of every range, 1 = inside one, 2 = on a
+ * boundary); uploaded once per range set, it spares every block the walk over the ranges. */
+int drn_sumsq_block_classes(int64_t n, const int64_t* skip_lo /*host*/, const int64_t* skip_hi /*host*/, int nskip, unsigned char* classes /*host*/);
+int drn_sumsq_finalize2(const float* partials, int npartials, const float* const* ext /*host*/, const int32_t* ext_n /*host*/, int next,
+                        float* total_sumsq, float grad_scale, void* stream);
 /* One bucket: g/m/v flat [n]; tensor i covers [seg_start[i], seg_start[i+1]) and lives at p_ptr[i] (both tables on the
  * device).  blk_seg (device, drn_opt_nblocks(n) ints, or NULL): index of the tensor holding element 4096*b, so a block
  * does not search the table.  mirror_dev (device table of nseg pointers, or NULL; entries may be NULL): a bf16 copy of tensor

@@ -1,0 +1,13 @@
+#!/bin/bash
+# in-box A/B: producer-provided squared sums (DRN_EXT_SUMSQ) on top of the one-launch deferred reduce
+B="python bench.py --cpu-steps 0 --no-f32 --no-trainer --no-other-configs --no-kernel-timing --steps 60"
+get() { python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$1', d['ms_per_step'], d['config']['launch_ab'])"; }
+for rep in 1 2 3; do
+  DRN_EXT_SUMSQ=0 DRN_WGRAD_DEFER=0 $B 2>/dev/null | get "T256 defer=0 ext=0"
+  DRN_EXT_SUMSQ=0 DRN_WGRAD_DEFER=1 $B 2>/dev/null | get "T256 defer=1 ext=0"
+  DRN_EXT_SUMSQ=1 DRN_WGRAD_DEFER=1 $B 2>/dev/null | get "T256 defer=1 ext=1"
+done
+for rep in 1 2; do
+  DRN_EXT_SUMSQ=0 DRN_WGRAD_DEFER=1 $B --T 32 2>/dev/null | get "T32 defer=1 ext=0"
+  DRN_EXT_SUMSQ=1 DRN_WGRAD_DEFER=1 $B --T 32 2>/dev/null | get "T32 defer=1 ext=1"
+done

@@ -122,3 +122,86 @@ def test_weight_copies_belong_to_their_model():
     import gc
     gc.collect()
     assert all(st is not None for st in DF.all_stores())
+
+
+def test_sumsq_skip_ranges_and_external_partials():
+    """drn_sumsq_partials_skip + drn_sumsq_finalize2: ranges left out of the pass (whole blocks, ragged edges, a range inside one
+    block) and their squared sums handed in as external partial arrays give the norm of the whole buffer."""
+    import ctypes
+    from drn_amd import _lib
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    n = 4096 * 37 + 1234
+    g = torch.randn(n, device=dev)
+    ranges = [(100, 900), (4096 * 3, 4096 * 9), (4096 * 10 + 7, 4096 * 20 + 501), (n - 600, n)]
+    nb = int(L.drn_opt_nblocks(ctypes.c_int64(n)))
+    part = torch.full((nb,), float("nan"), device=dev)
+    lo = (ctypes.c_int64 * len(ranges))(*[r[0] for r in ranges])
+    hi = (ctypes.c_int64 * len(ranges))(*[r[1] for r in ranges])
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(L.drn_sumsq_partials_skip(P(g), ctypes.c_int64(n), P(part), None, lo, hi, len(ranges), None, st), "skip")
+    host = (ctypes.c_ubyte * nb)()
+    _lib.check(L.drn_sumsq_block_classes(ctypes.c_int64(n), lo, hi, len(ranges), host), "classes")
+    cls = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
+    assert sorted(set(cls.tolist())) == [0, 1, 2]
+    part2 = torch.full((nb,), float("nan"), device=dev)
+    _lib.check(L.drn_sumsq_partials_skip(P(g), ctypes.c_int64(n), P(part2), None, lo, hi, len(ranges), P(cls), st), "skip+classes")
+    torch.cuda.synchronize()
+    assert torch.equal(part, part2)
+    ext1 = torch.stack([(g[a:b].double() ** 2).sum() for a, b in ranges[:2]]).float()
+    ext2 = torch.stack([(g[a:b].double() ** 2).sum() for a, b in ranges[2:]]).float()
+    tot = torch.zeros(1, device=dev)
+    ext = (ctypes.c_void_p * 2)(ext1.data_ptr(), ext2.data_ptr())
+    ext_n = (ctypes.c_int32 * 2)(2, 2)
+    _lib.check(L.drn_sumsq_finalize2(P(part), nb, ext, ext_n, 2, P(tot), ctypes.c_float(0.5), st), "fin2")
+    torch.cuda.synchronize()
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    for a, b in ranges:
+        keep[a:b] = False
+    want_pass = float((g[keep].double() ** 2).sum())
+    assert abs(float(part.double().sum()) - want_pass) <= 1e-5 * want_pass
+    want = 0.25 * float((g.double() ** 2).sum())
+    assert abs(float(tot) - want) <= 1e-5 * want
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_norm_pass_with_producer_partials_equals_the_plain_pass(dtype, monkeypatch):
+    """One step of the benchmarked model: with the squared sums of the prop_fc weight gradient (GEMM epilogue) and of the conv weight
+    gradients (one-launch reduce) handed to the optimizer, the squared global norm equals the plain pass's within fp32 re-association,
+    ranges were really left out, and the updated parameters agree."""
+    import bench as B
+    from drn_amd import dist as ddist, functional as DF, optim
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import default_cfg, synthetic_batch
+    dev = torch.device("cuda:0")
+    cfg = default_cfg("C3D", 4096, 1)
+    batch = [b.to(dev) for b in synthetic_batch(32, 256, 4096, seed=1)]
+    res = {}
+    for ext in (False, True):
+        monkeypatch.setattr(optim, "EXT_SUMSQ", ext)
+        m = B.build(mainModel, cfg, dev, compute_dtype=dtype)
+        params = B.stage_params(m, 1)
+        m.train()
+        red = ddist.GradReducer(params, world_size=1, overlap=True, adjacent=m.grad_stack_groups(), bucket_bytes=1 << 30)
+        opt = optim.FusedAdam(red, lr=1e-3, max_norm=0.5)
+        assert red.ext_sumsq == ext
+        for _ in range(1):                       # (ONE step: the two variants' norms differ in the last bits, and training amplifies that)
+            red.zero()
+            _, ls = m(*batch)
+            DF.backward(DF.loss_total(ls))
+            red.finish()
+            notes = list(red.sumsq_notes) if ext else []
+            opt.step()
+        torch.cuda.synchronize()
+        res[ext] = (float(opt.total_sumsq), {k: v.detach().clone() for k, v in m.state_dict().items()}, notes)
+        red.remove()
+    notes = res[True][2]
+    covered = sum(ne for nt in notes for _, ne in nt[0])
+    assert len(notes) == 2 and covered > 25e6, (len(notes), covered)          # prop_fc.weight 16.8 M + the conv weights ~10 M elements
+    a, b = res[False][0], res[True][0]
+    assert abs(a - b) <= 1e-5 * a, (a, b)
+    for k, v in res[False][1].items():
+        w = res[True][1][k]
+        if v.dtype.is_floating_point:
+            assert float((v - w).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
