@@ -988,6 +988,370 @@ static int bn_bwd_launch64(const DrnBnBwdDesc* d, int n, int C, int relu, float*
   return drn_launch_status(who);
 }
 
+// ---- backward in ONE launch (C % 64 == 0 and the whole grid resident at once).  The same (row block x 64-channel tile)
+// workgroups, but a workgroup keeps its rows of dout and raw IN REGISTERS (up to NP x 32 rows x 64 channels of bf16 = 16 bytes x
+// 2 x NP per thread) between the two halves: it sums them, publishes its (sum g, sum g*xhat) pairs as TAGGED 64-bit words
+// {value, launch generation} (bn_merge.h: one write-through store each, readers poll the data itself), waits for the other row
+// blocks of ITS level and channel tile, derives the three coefficients like bn_bwd_apply64_kernel does and writes draw -- every
+// element of dout and raw is read once, and the second launch with its ~5 us floor is gone.  The first workgroup of every
+// channel tile also writes dgamma / dbeta, level after level; workgroup 0 finally advances the generation word, once it has seen
+// a pair of every workgroup (each read the word before it published).
+struct BnBwd1Lv {
+  const void* dout;
+  const void* raw;
+  void* draw;
+  const float* ss;
+  const float* save;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  unsigned long long* pairs;   // [rb][2][C] tagged
+  unsigned long long* totals;  // [2][C] tagged: (dgamma, dbeta) contribution of this level
+  int ld_dout, ld_raw, ld_draw, M, accumulate, rb, blk0;
+};
+struct BnBwd1Params {
+  BnBwd1Lv lv[DRN_MAX_GROUPS];
+  int n, C, relu;
+  int* gen_word;
+};
+static __device__ int g_bn_bwd_timeouts;
+
+// Sums of the rb <= 64 tagged (sum g, sum g*xhat) pairs of channel cbase + (tid & 63): bn_bwd_sum64's lanes and order.  First a
+// quiet wait -- wave 0 alone polls, lane i the (sum g*xhat) pair of row block i, channel cbase; the other waves park at the barrier
+// -- then every thread reads its pairs and checks each against the launch's tag.  (Requesting the pairs BEFORE the wait, so that a
+// workgroup arriving late pays one round trip instead of two, was measured: every launch +20 us -- a pair read too early is re-read
+// behind a ~1 us sleep, one after the other.)
+__device__ __forceinline__ void bn_bwd_wait_sum64(const unsigned long long* __restrict__ pp, const int rb, const int C, const int cbase,
+                                                  double (*shd)[4][64], double& sg_out, double& sx_out, const BnTagged tg) {
+  constexpr int KH = 8;                                // two rounds of 8 pairs per lane (the rows this thread holds stay in registers)
+  const int ci = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const unsigned long long* __restrict__ p = pp + cbase + ci;
+  const long long t0 = wall_clock64();
+  if (threadIdx.x < 64) {
+    const unsigned long long* q = pp + ((long)min((int)threadIdx.x, rb - 1) * 2 + 1) * C + cbase;
+    bool ready = (int)threadIdx.x >= rb;
+    for (;;) {
+      if (!ready) ready = (unsigned)(bn_ld_pair(q) >> 32) == tg.want;
+      if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 200000000LL) {                                          // 2 s of the 100 MHz wall clock
+        if (!ready) __hip_atomic_fetch_add(tg.timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  double sg = 0.0, sx = 0.0;
+  for (int h = 0; h < 2; ++h) {
+    if (h * 4 * KH >= rb) break;                       // (workgroup-uniform)
+    unsigned long long v0[KH], v1[KH];
+#pragma unroll
+    for (int i = 0; i < KH; ++i) {
+      const int k = min(j + 4 * (h * KH + i), rb - 1);
+      v0[i] = bn_ld_pair(p + ((long)k * 2 + 0) * C);
+      v1[i] = bn_ld_pair(p + ((long)k * 2 + 1) * C);
+    }
+#pragma unroll
+    for (int i = 0; i < KH; ++i) {
+      const int k = min(j + 4 * (h * KH + i), rb - 1);
+      while ((unsigned)(v0[i] >> 32) != tg.want) {     // (the pairs of one row block land within the same microsecond)
+        if (bn_wait_expired(t0, tg.timeouts)) break;
+        v0[i] = bn_ld_pair(p + ((long)k * 2 + 0) * C);
+      }
+      while ((unsigned)(v1[i] >> 32) != tg.want) {
+        if (bn_wait_expired(t0, tg.timeouts)) break;
+        v1[i] = bn_ld_pair(p + ((long)k * 2 + 1) * C);
+      }
+      if (j + 4 * (h * KH + i) < rb) {
+        sg += (double)__uint_as_float((unsigned)v0[i]);
+        sx += (double)__uint_as_float((unsigned)v1[i]);
+      }
+    }
+  }
+  shd[0][j][ci] = sg;
+  shd[1][j][ci] = sx;
+  __syncthreads();
+  sg_out = (shd[0][0][ci] + shd[0][1][ci]) + (shd[0][2][ci] + shd[0][3][ci]);
+  sx_out = (shd[1][0][ci] + shd[1][1][ci]) + (shd[1][2][ci] + shd[1][3][ci]);
+  __syncthreads();
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(256, 2) void bn_bwd_one_kernel(const BnBwd1Params P) {
+  constexpr int N = V16<T>::N, NV = 64 / N, RP = 256 / NV, ROWS = NP * RP;
+  __shared__ float red[2][RP][65];
+  __shared__ double shd[2][4][64];
+  __shared__ float s_k[3][64];
+  const int tid = threadIdx.x, C = P.C, relu = P.relu;
+  const unsigned gen = (unsigned)__hip_atomic_load(P.gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const BnTagged tg{gen + 1u, &g_bn_bwd_timeouts};
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < DRN_MAX_GROUPS; ++i)
+    if (i < P.n && (int)blockIdx.x >= P.lv[i].blk0) li = i;
+  const BnBwd1Lv& G = P.lv[li];
+  const int M = G.M, ctiles = C >> 6;
+  const int b = blockIdx.x - G.blk0;
+  const int rblk = b / ctiles, ct = b - rblk * ctiles, cbase = ct * 64;
+  const int v = tid % NV, ry = tid / NV, c0 = cbase + v * N;
+  const T* __restrict__ dout = (const T*)G.dout;
+  const T* __restrict__ raw = (const T*)G.raw;
+  T* __restrict__ draw = (T*)G.draw;
+  const long ldd = G.ld_dout, ldr = G.ld_raw, ldw = G.ld_draw;
+  const int row0 = rblk * ROWS + ry;
+  typename V16<T>::raw_t gr[NP], xr[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {                       // everything this workgroup will ever read, in flight at once
+    const int m = min(row0 + p * RP, M - 1);           // clamped index, masked use
+    gr[p] = V16<T>::ldraw(dout + (long)m * ldd + c0);
+    xr[p] = V16<T>::ldraw(raw + (long)m * ldr + c0);
+  }
+  float sc[N], sh[N];
+  {
+    float mean[N], istd[N], sg[N], sx[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      mean[k] = G.save[c0 + k];
+      istd[k] = G.save[C + c0 + k];
+      sc[k] = G.ss[c0 + k];
+      sh[k] = G.ss[C + c0 + k];
+      sg[k] = 0.f;
+      sx[k] = 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const bool in = row0 + p * RP < M;
+      float g[N], x[N];
+      V16<T>::cvt(gr[p], g);
+      V16<T>::cvt(xr[p], x);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float gg = (!in || (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f))) ? 0.f : g[k];
+        sg[k] += gg;
+        sx[k] = fmaf(gg, (x[k] - mean[k]) * istd[k], sx[k]);
+      }
+      __builtin_amdgcn_sched_barrier(0);               // (one pass at a time: the conversions of all NP passes hoisted to the top spill)
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      red[0][ry][v * N + k] = sg[k];
+      red[1][ry][v * N + k] = sx[k];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)                         // the rows stay as LOADED (16 bytes per vector), not as the floats of the pass above
+    asm volatile("" : "+v"(gr[p]), "+v"(xr[p]));
+  __syncthreads();
+  if (tid < 64) {                                      // ONE wave publishes both sums, the polled one (sum g*xhat) last
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) a0 += red[0][r][tid];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) a1 += red[1][r][tid];
+    __hip_atomic_store(G.pairs + ((long)rblk * 2 + 0) * C + cbase + tid, bn_tag_pack(a0, tg.want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(G.pairs + ((long)rblk * 2 + 1) * C + cbase + tid, bn_tag_pack(a1, tg.want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  float my_dg = 0.f, my_db = 0.f;
+  {
+    double sg, sx;
+    bn_bwd_wait_sum64(G.pairs, G.rb, C, cbase, shd, sg, sx, tg);
+    if (tid < 64) {                                    // the statements of bn_bwd_apply64_kernel
+      const int c = cbase + tid;
+      const float mean = G.save[c], istd = G.save[C + c];
+      const float s = G.gamma[c] * istd;
+      const float dg = (float)sx, db = (float)sg;
+      my_dg = dg;
+      my_db = db;
+      if (rblk == 0 && li > 0) {                       // this level's totals, for the workgroup that writes dgamma / dbeta (below)
+        __hip_atomic_store(G.totals + c, bn_tag_pack(dg, tg.want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(G.totals + C + c, bn_tag_pack(db, tg.want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const float invM = 1.f / (float)M;
+      s_k[0][tid] = s;
+      s_k[1][tid] = -s * dg * istd * invM;
+      s_k[2][tid] = -s * db * invM + s * dg * istd * mean * invM;
+    }
+    __syncthreads();
+  }
+  {
+    float ka[N], kb[N], kc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      ka[k] = s_k[0][v * N + k];
+      kb[k] = s_k[1][v * N + k];
+      kc[k] = s_k[2][v * N + k];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int m = row0 + p * RP;
+      float g[N], x[N];
+      V16<T>::cvt(gr[p], g);
+      V16<T>::cvt(xr[p], x);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float gg = (relu && !(fmaf(x[k], sc[k], sh[k]) > 0.f)) ? 0.f : g[k];
+        x[k] = fmaf(ka[k], gg, fmaf(kb[k], x[k], kc[k]));
+      }
+      if (m < M) V16<T>::store(draw + (long)m * ldw + c0, x);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- dgamma / dbeta of this channel tile, level after level (levels that share a module accumulate in that order): written by the
+  // first row block of the first level, which has its own totals and receives the other levels' from THEIR first row blocks
+  if (li == 0 && rblk == 0 && tid < 64) {
+    const int c = cbase + tid;
+    const long long t0 = wall_clock64();
+    for (int g = 0; g < P.n; ++g) {
+      const BnBwd1Lv& H = P.lv[g];
+      float dg = my_dg, db = my_db;
+      if (g > 0) {
+        unsigned long long a = bn_ld_pair(H.totals + c), b2 = bn_ld_pair(H.totals + C + c);
+        while ((unsigned)(a >> 32) != tg.want || (unsigned)(b2 >> 32) != tg.want) {
+          __builtin_amdgcn_s_sleep(4);
+          if (wall_clock64() - t0 > 200000000LL) {
+            __hip_atomic_fetch_add(tg.timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          a = bn_ld_pair(H.totals + c);
+          b2 = bn_ld_pair(H.totals + C + c);
+        }
+        dg = __uint_as_float((unsigned)a);
+        db = __uint_as_float((unsigned)b2);
+      }
+      if (H.dgamma) H.dgamma[c] = H.accumulate ? H.dgamma[c] + dg : dg;
+      if (H.dbeta) H.dbeta[c] = H.accumulate ? H.dbeta[c] + db : db;
+    }
+  }
+  // ---- the generation moves on once EVERY workgroup of the launch has published under the old one
+  if (blockIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    for (int g = 0; g < P.n; ++g) {
+      const BnBwd1Lv& H = P.lv[g];
+      const int cnt = H.rb * ctiles;
+      for (int i = tid; i < cnt; i += 256) {
+        const int r = i / ctiles, t = i - r * ctiles;
+        const unsigned long long* q = H.pairs + ((long)r * 2 + 1) * C + t * 64;
+        while ((unsigned)(bn_ld_pair(q) >> 32) != tg.want)
+          if (bn_wait_expired(t0, tg.timeouts)) break;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(P.gen_word, (int)(gen + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename KernelT>
+static int bn_resident_capacity(KernelT kernel) {
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, 256, 0) != hipSuccess) return 0;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)kernel) != hipSuccess) return 0;
+  if (fa.localSizeBytes > 0) return 0;                 // (a variant that spills is not trusted with the wait: gemm_nt_bn.hip)
+  return per_cu * cus;
+}
+
+// rows per workgroup index (NP = 2 << index) the launch would use, or -1: the smallest row block whose grid is at most `max_wg`
+// workgroups (drn_tune bn1_maxwg, 512: two per CU, what the chip holds of them) with at most 64 row blocks per level -- and the
+// next bigger one when that still leaves a workgroup for every CU (512 workgroups of 64 rows: 10.8 / 11.5 / 11.6 us for the three
+// backbone stages; 256 of 128 rows: 10.6 / 10.2 / 11.0.  Below one per CU it loses: 224 of 512 rows 20.3 us, 448 of 256 rows 18.0)
+static long bn_bwd_one_grid(const DrnBnBwdDesc* d, int n, int ctiles, int rows, int* rbmax) {
+  long total = 0;
+  *rbmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rb = cdiv(d[i].M, rows);
+    total += (long)rb * ctiles;
+    if (rb > *rbmax) *rbmax = rb;
+  }
+  return total;
+}
+static int bn_bwd_one_plan(const DrnBnBwdDesc* d, int n, int C, int dtype, int* total_out) {
+  if (C % 64 != 0 || n < 1 || n > DRN_MAX_GROUPS) return -1;
+  const int max_wg = drn_tuning(DRN_TUNE_BN1_MAXWG);
+  const int RP = dtype == DRN_BF16 ? 32 : 16, ctiles = C / 64;
+  for (int idx = 0; idx < 4; ++idx) {
+    int rbmax = 0;
+    long total = bn_bwd_one_grid(d, n, ctiles, (2 << idx) * RP, &rbmax);
+    if (rbmax <= 64 && total <= max_wg) {
+      if (idx < 3) {
+        int rb2 = 0;
+        const long t2 = bn_bwd_one_grid(d, n, ctiles, (4 << idx) * RP, &rb2);
+        if (t2 >= 256) { ++idx; total = t2; }
+      }
+      if (total_out) *total_out = (int)total;
+      return idx;
+    }
+  }
+  return -1;
+}
+
+extern "C" int64_t drn_bn_bwd_one_ws_bytes(const DrnBnBwdDesc* descs, int n, int C, int dtype) {
+  if (!descs || bn_bwd_one_plan(descs, n, C, dtype, nullptr) < 0) return 0;
+  return 64 + (int64_t)n * 65 * 2 * C * 8;
+}
+
+extern "C" int drn_bn_bwd_one(const DrnBnBwdDesc* d, int n, int C, int relu, void* tagged_ws, int64_t ws_bytes, int dtype, void* stream_) {
+  drn_clear_status();
+  const char* who = "drn_bn_bwd_one";
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(d && n >= 1 && n <= DRN_MAX_GROUPS && C > 0 && tagged_ws && ((uintptr_t)tagged_ws & 63) == 0, "%s: bad args", who);
+  DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "%s: bad dtype %d", who, dtype);
+  int total = 0;
+  const int idx = bn_bwd_one_plan(d, n, C, dtype, &total);
+  if (idx < 0) {
+    drn_set_error("%s: the launch does not fit the chip at once (or C %% 64 != 0): use drn_bn_bwd_multi", who);
+    return DRN_ERR_UNSUPPORTED;
+  }
+  DRN_CHECK_ARG(ws_bytes >= drn_bn_bwd_one_ws_bytes(d, n, C, dtype), "%s: workspace too small (drn_bn_bwd_one_ws_bytes)", who);
+  const int vn = dtype == DRN_BF16 ? 8 : 4, RP = 256 / (64 / vn), rows = (2 << idx) * RP, ctiles = C / 64;
+  BnBwd1Params P;
+  memset(&P, 0, sizeof(P));
+  P.n = n; P.C = C; P.relu = relu;
+  P.gen_word = (int*)tagged_ws;
+  unsigned long long* pairs = (unsigned long long*)((char*)tagged_ws + 64);
+  int blk = 0;
+  for (int i = 0; i < n; ++i) {
+    const DrnBnBwdDesc& s = d[i];
+    DRN_CHECK_ARG(s.dout && s.raw && s.scale_shift && s.save && s.gamma && s.draw && s.M > 0, "%s: bad level %d", who, i);
+    DRN_CHECK_ARG(s.ld_dout % vn == 0 && s.ld_raw % vn == 0 && s.ld_draw % vn == 0, "%s: ld must be 16-byte multiples", who);
+    BnBwd1Lv& G = P.lv[i];
+    G.dout = s.dout; G.raw = s.raw; G.draw = s.draw; G.ss = s.scale_shift; G.save = s.save; G.gamma = s.gamma;
+    G.dgamma = s.dgamma; G.dbeta = s.dbeta; G.ld_dout = s.ld_dout; G.ld_raw = s.ld_raw; G.ld_draw = s.ld_draw; G.M = s.M;
+    G.accumulate = s.accumulate;
+    G.rb = cdiv(s.M, rows);
+    G.pairs = pairs + (long)i * 65 * 2 * C;
+    G.totals = G.pairs + (long)64 * 2 * C;
+    G.blk0 = blk;
+    blk += G.rb * ctiles;
+  }
+  static int capacity[2][4];
+  int& cap = capacity[dtype == DRN_BF16][idx];
+#define BN1_CASE(TT, NPV) do { \
+    if (!cap) cap = bn_resident_capacity(bn_bwd_one_kernel<TT, NPV>); \
+    if (total > cap) { drn_set_error("%s: %d workgroups exceed the %d the chip holds at once", who, total, cap); return DRN_ERR_UNSUPPORTED; } \
+    bn_bwd_one_kernel<TT, NPV><<<total, 256, 0, stream>>>(P); } while (0)
+  if (dtype == DRN_BF16) {
+    switch (idx) { case 0: BN1_CASE(bf16_t, 2); break; case 1: BN1_CASE(bf16_t, 4); break; case 2: BN1_CASE(bf16_t, 8); break; default: BN1_CASE(bf16_t, 16); }
+  } else {
+    switch (idx) { case 0: BN1_CASE(float, 2); break; case 1: BN1_CASE(float, 4); break; case 2: BN1_CASE(float, 8); break; default: BN1_CASE(float, 16); }
+  }
+#undef BN1_CASE
+  return drn_launch_status(who);
+}
+
+// Watchdog of drn_bn_bwd_one's wait: workgroups that gave up after 2 s (0 in a healthy run; results of such a launch are invalid).
+// Synchronises the device.
+extern "C" int drn_bn_bwd_one_timeouts(int reset) {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bn_bwd_timeouts), sizeof(int)) != hipSuccess) return -1;
+  if (reset && v) {
+    const int z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bn_bwd_timeouts), &z, sizeof(int));
+  }
+  return v;
+}
+
 // draw may alias dout (in place).  ws >= n * (2*256 + 3) * C floats.
 static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* ws, int dtype, void* stream_, const char* who) {
   hipStream_t stream = (hipStream_t)stream_;

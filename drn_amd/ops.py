@@ -669,6 +669,10 @@ def conv_bn_train_timeouts(reset=True):
     return int(lib().drn_conv_bn_train_timeouts(int(reset)))
 
 
+BN_BWD_ONE = os.environ.get("DRN_BN_BWD_ONE", "1") != "0"      # (experiment switch: 0 = reduce + apply launches, drn_bn_bwd_multi)
+_bn1_maxwg = os.environ.get("DRN_BN1_MAXWG")                  # (experiment switch: workgroup budget of the one-launch kernel)
+
+
 def bn_bwd_multi(levels, C, dtype, relu=True):
     """levels: list of dicts(dout, ld_dout, raw, ld_raw, ss, save, gamma, draw, ld_draw, dgamma, dbeta, accumulate, M)."""
     arr = (_lib.BnBwdDesc * len(levels))()
@@ -676,8 +680,27 @@ def bn_bwd_multi(levels, C, dtype, relu=True):
         d.dout, d.raw, d.scale_shift, d.save, d.gamma = _p(v["dout"]), _p(v["raw"]), _p(v["ss"]), _p(v["save"]), _p(v["gamma"])
         d.draw, d.dgamma, d.dbeta = _p(v["draw"]), _p(v["dgamma"]), _p(v["dbeta"])
         d.ld_dout, d.ld_raw, d.ld_draw, d.accumulate, d.M = v["ld_dout"], v["ld_raw"], v["ld_draw"], int(v["accumulate"]), v["M"]
+    global _bn1_maxwg
+    if _bn1_maxwg:
+        lib().drn_tune(b"bn1_maxwg", int(_bn1_maxwg))
+        _bn1_maxwg = None
+    if BN_BWD_ONE:
+        # one launch when the grid fits the chip at once (drn_bn_bwd_one): the tagged-pair workspace is zero at birth and keeps the
+        # launch generation afterwards -- one buffer per size, launches on it are stream-ordered
+        nbytes = int(lib().drn_bn_bwd_one_ws_bytes(arr, len(levels), C, dtype))
+        if nbytes > 0:
+            tws = persistent_buffer("bn_bwd_one", nbytes // 8, levels[0]["draw"].device, torch.int64)
+            rc = lib().drn_bn_bwd_one(arr, len(levels), C, int(relu), _p(tws), ctypes.c_int64(nbytes), dtype, _stream())
+            if rc != DRN_ERR_UNSUPPORTED:
+                check(rc, "drn_bn_bwd_one")
+                return
     ws = workspace(len(levels) * 515 * C, levels[0]["draw"].device)
     check(lib().drn_bn_bwd_multi(arr, len(levels), C, int(relu), _p(ws), dtype, _stream()), "drn_bn_bwd_multi")
+
+
+def bn_bwd_one_timeouts(reset=True):
+    """Workgroups of one-launch BatchNorm backward passes that gave up waiting for their channel tile (0 in a healthy run).  Synchronises."""
+    return int(lib().drn_bn_bwd_one_timeouts(int(reset)))
 
 
 def bn_eval_scale_shift(C, gamma, beta, conv_bias, running_mean, running_var, eps, ss):

@@ -320,6 +320,16 @@ typedef struct DrnBnBwdDesc {
   int32_t ld_dout, ld_raw, ld_draw, accumulate, M;
 } DrnBnBwdDesc;
 int drn_bn_bwd_multi(const DrnBnBwdDesc* descs /*host*/, int n, int C, int relu, float* ws, int dtype, void* stream);
+/* The same in ONE launch: every workgroup keeps its rows of dout and raw in registers between the sums and the apply half and
+ * meets the other row blocks of its channel tile through tagged pairs in `tagged_ws` (64-byte aligned, >=
+ * drn_bn_bwd_one_ws_bytes() bytes, ZERO before its first use and then left to the library: it carries the launch generation;
+ * one launch at a time per workspace).  Needs C % 64 == 0 and a grid the chip holds at once: DRN_ERR_UNSUPPORTED (nothing
+ * launched) / 0 bytes otherwise -- the caller then takes drn_bn_bwd_multi.  Per-row-block partial sums are formed over
+ * different row blocks than drn_bn_bwd_multi's, so the two agree to rounding, not bit for bit.
+ * drn_bn_bwd_one_timeouts: workgroups that gave up waiting (2 s watchdog; 0 in a healthy run); synchronises the device. */
+int64_t drn_bn_bwd_one_ws_bytes(const DrnBnBwdDesc* descs /*host*/, int n, int C, int dtype);
+int drn_bn_bwd_one(const DrnBnBwdDesc* descs /*host*/, int n, int C, int relu, void* tagged_ws, int64_t ws_bytes, int dtype, void* stream);
+int drn_bn_bwd_one_timeouts(int reset);
 
 /* ---- 1-2 channel output heads (drn_amd/csrc/heads.hip; model/fcos.py:43-49,68,96-102) ------------------- */
 typedef struct DrnHeadGroup {

@@ -56,3 +56,14 @@ def test_gemm_kernels_keep_their_register_budgets(tmp_path):
     for k in w4:         # one wave per SIMD: the statement owns a[0:255] and v[124:255]; the compiler must not spill around it
         r = table[k]
         assert r["agpr"] == 256 and r["vgpr"] == 512 and r["spill"] == 0 and r["scratch"] == 0, (k, r)
+
+
+def test_one_launch_batchnorm_backward_holds_its_rows_in_registers(tmp_path):
+    """bn_bwd_one_kernel<T, NP> keeps 2 x NP 16-byte vectors per thread between its two halves and waits for its siblings in between:
+    a variant that spills is refused at launch (bn_resident_capacity), and past 256 registers only one workgroup per CU would fit."""
+    table = kernel_table(tmp_path)
+    ks = [k for k in table if "bn_bwd_one_kernel" in k]
+    assert len(ks) == 8, ks
+    for k in ks:
+        r = table[k]
+        assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (k, r)
