@@ -118,74 +118,10 @@ __device__ __forceinline__ void w4h_bn_stats(float* shs, float* __restrict__ sta
 }
 
 // ---- split-K inside the launch (conv0's forward: 64 tiles x 204 K-steps): workgroup row y owns K-steps [k_lo, k_hi), publishes its
-// 128 accumulator registers per lane as 32 write-through 16-byte pieces (lane-contiguous: 4 KB per wave instruction), takes a
-// ticket, and the split that arrives LAST at a tile re-reads all partials -- its own included, in split order, so the sum does not
-// depend on who was last -- into the AGPRs and runs the normal epilogue.  Same protocol as conv_gemm_nt_kernel's split (gemm_nt_kernel.h).
-template <int R>
-__device__ __forceinline__ void w4h_acc_write(const float v) {
-  asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(v), "i"(R));
-}
-template <int G>
-__device__ __forceinline__ f32x4 w4h_acc_group() {       // registers 4G .. 4G + 3
-  return (f32x4){w4h_acc_read<4 * G>(), w4h_acc_read<4 * G + 1>(), w4h_acc_read<4 * G + 2>(), w4h_acc_read<4 * G + 3>()};
-}
-// eight groups (32 registers) of this lane -> the split's slab; ONE asm statement for the stores and their drain (the compiler
-// does not know these are stores: as separate statements it may recycle a data register inside the hazard window of a > 64-bit store)
-template <int G0>
-__device__ __forceinline__ void w4h_publish8(f32x4* slab) {
-  constexpr int NT = 256;
-  const f32x4 v0 = w4h_acc_group<G0>(), v1 = w4h_acc_group<G0 + 1>(), v2 = w4h_acc_group<G0 + 2>(), v3 = w4h_acc_group<G0 + 3>();
-  const f32x4 v4 = w4h_acc_group<G0 + 4>(), v5 = w4h_acc_group<G0 + 5>(), v6 = w4h_acc_group<G0 + 6>(), v7 = w4h_acc_group<G0 + 7>();
-  f32x4* p = slab + G0 * NT;
-  asm volatile(
-      "global_store_dwordx4 %0, %8, off sc1\n\t"
-      "global_store_dwordx4 %1, %9, off sc1\n\t"
-      "global_store_dwordx4 %2, %10, off sc1\n\t"
-      "global_store_dwordx4 %3, %11, off sc1\n\t"
-      "global_store_dwordx4 %4, %12, off sc1\n\t"
-      "global_store_dwordx4 %5, %13, off sc1\n\t"
-      "global_store_dwordx4 %6, %14, off sc1\n\t"
-      "global_store_dwordx4 %7, %15, off sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      :
-      : "v"(p), "v"(p + NT), "v"(p + 2 * NT), "v"(p + 3 * NT), "v"(p + 4 * NT), "v"(p + 5 * NT), "v"(p + 6 * NT), "v"(p + 7 * NT),
-        "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7)
-      : "memory");
-}
-// the same eight groups summed over all splits, in split order, back into the AGPRs
-template <int G0>
-__device__ __forceinline__ void w4h_gather8(const f32x4* tile_base, const int ks) {
-  constexpr int NT = 256, SLAB = 32 * NT;
-  f32x4 s[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const f32x4* src = tile_base + G0 * NT;
-  for (int q = 0; q < ks; ++q, src += SLAB) {
-    // ONE asm statement for the eight loads AND their wait (an asm output counts as ready when its statement ends)
-    f32x4 p0, p1, p2, p3, p4, p5, p6, p7;
-    asm volatile(
-        "global_load_dwordx4 %0, %8, off sc1\n\t"
-        "global_load_dwordx4 %1, %9, off sc1\n\t"
-        "global_load_dwordx4 %2, %10, off sc1\n\t"
-        "global_load_dwordx4 %3, %11, off sc1\n\t"
-        "global_load_dwordx4 %4, %12, off sc1\n\t"
-        "global_load_dwordx4 %5, %13, off sc1\n\t"
-        "global_load_dwordx4 %6, %14, off sc1\n\t"
-        "global_load_dwordx4 %7, %15, off sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
-        : "v"(src), "v"(src + NT), "v"(src + 2 * NT), "v"(src + 3 * NT), "v"(src + 4 * NT), "v"(src + 5 * NT), "v"(src + 6 * NT),
-          "v"(src + 7 * NT)
-        : "memory");
-    const f32x4 part[8] = {p0, p1, p2, p3, p4, p5, p6, p7};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] += part[i];
-  }
-#define W4H_WB(I) w4h_acc_write<4 * (G0 + I)>(s[I][0]); w4h_acc_write<4 * (G0 + I) + 1>(s[I][1]); w4h_acc_write<4 * (G0 + I) + 2>(s[I][2]); w4h_acc_write<4 * (G0 + I) + 3>(s[I][3])
-  W4H_WB(0); W4H_WB(1); W4H_WB(2); W4H_WB(3); W4H_WB(4); W4H_WB(5); W4H_WB(6); W4H_WB(7);
-#undef W4H_WB
-}
-
+// 128 accumulator registers per lane as 32 write-through 16-byte pieces straight out of the AGPRs (lane-contiguous: 4 KB per wave
+// instruction), takes a ticket, and the split that arrives LAST at a tile re-reads all partials -- its own included, in split order,
+// so the sum does not depend on who was last -- into the AGPRs and runs the normal epilogue.  Same protocol as
+// conv_gemm_nt_kernel's split (gemm_nt_kernel.h); the two statements are W4H_PUBLISH_ASM / W4H_GATHER_ASM (gen_w4_loop.py).
 template <bool CONV>
 __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,9 +204,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
 
   if (P.ksplit > 1) {
     const int tile_id = blockIdx.x, ks = P.ksplit;
-    f32x4* tile_base = (f32x4*)P.ws + (long)tile_id * ks * (32 * 256) + tid;
-    f32x4* slab = tile_base + (long)blockIdx.y * (32 * 256);
-    w4h_publish8<0>(slab); w4h_publish8<8>(slab); w4h_publish8<16>(slab); w4h_publish8<24>(slab);
+    const char* tile_base = (const char*)P.ws + (long)tile_id * ks * (32 * 256 * 16);      // (wave-uniform: scalar registers)
+    const char* slab = tile_base + (long)blockIdx.y * (32 * 256 * 16);
+    const unsigned lane_off = (unsigned)tid * 16u;
+    asm volatile(W4H_PUBLISH_ASM : : [base] "s"(slab), [off] "v"(lane_off) : W4H_XCHG_CLOBBERS);
     __syncthreads();
     int& s_last = *(int*)smem;
     if (tid == 0) {
@@ -280,8 +217,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
     }
     __syncthreads();
     if (!s_last) return;
-    w4h_gather8<0>(tile_base, ks); w4h_gather8<8>(tile_base, ks); w4h_gather8<16>(tile_base, ks); w4h_gather8<24>(tile_base, ks);
-    asm volatile("s_nop 4" ::: "memory");      // (accumulator writes settle before the epilogue's v_accvgpr_read)
+    asm volatile(W4H_GATHER_ASM : : [base] "s"(tile_base), [ks] "s"(ks), [off] "v"(lane_off) : W4H_XCHG_CLOBBERS);
     __syncthreads();
   }
 

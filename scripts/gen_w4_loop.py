@@ -366,6 +366,55 @@ with open(args.out, "w") as f:
         for ln in lines:
             f.write('  "%s\\n\\t" \\\n' % ln)
         f.write('  ""\n')
+    # ---- split-K exchange of gemm_nt_w4h_kernel (accumulators a[0:127], 32 groups of 4; a lane's group g of split q lives at
+    # base + ((q*32 + g)*256 + tid)*16 bytes: 4 KB per wave instruction, consecutive groups 4096 bytes apart, consecutive splits too).
+    # PUBLISH: the 32 groups straight out of the AGPRs (write-through), ONE wait.  GATHER (the last arriver): a[0:127] = 0, then
+    # split after split is added in split order; a split comes in as two halves of 16 loads into v[128:191] / v[192:255], the next
+    # half in flight while the current one is added (the first version waited for 8 loads at a time: 16 dependent ~2.5 us round
+    # trips = the 40 us that made the in-launch split lose).
+    def bump(lo):
+        return ["s_add_u32 s%d, s%d, 0x1000" % (lo, lo), "s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1)]
+    pub = ["s_mov_b64 s[80:81], %[base]"]
+    for g in range(32):
+        pub.append("global_store_dwordx4 %%[off], a[%d:%d], s[80:81] sc1" % (4 * g, 4 * g + 3))
+        pub += bump(80)
+    pub.append("s_waitcnt vmcnt(0)")
+    def loads(v0):
+        out = []
+        for g in range(16):
+            out.append("global_load_dwordx4 v[%d:%d], %%[off], s[82:83] sc1" % (v0 + 4 * g, v0 + 4 * g + 3))
+            out += bump(82)
+        return out
+    def add(v0, a0):
+        out = []
+        for b in range(0, 64, 8):                         # 8 at a time through v[113:120]: read, add, write back
+            out += ["v_accvgpr_read_b32 v%d, a%d" % (113 + i, a0 + b + i) for i in range(8)]
+            out += ["v_add_f32 v%d, v%d, v%d" % (113 + i, 113 + i, v0 + b + i) for i in range(8)]
+            out += ["v_accvgpr_write_b32 a%d, v%d" % (a0 + b + i, 113 + i) for i in range(8)]
+        return out
+    gat = ["s_mov_b64 s[82:83], %[base]", "s_mov_b32 s84, %[ks]", "v_mov_b32 v113, 0"]
+    gat += ["v_accvgpr_write_b32 a%d, v113" % r for r in range(128)]
+    gat += loads(128)
+    gat.append("1:")
+    gat += loads(192)
+    gat.append("s_waitcnt vmcnt(16)")
+    gat += add(128, 0)
+    gat += ["s_sub_u32 s84, s84, 1", "s_cmp_eq_u32 s84, 0", "s_cbranch_scc1 2f"]
+    gat += loads(128)
+    gat.append("s_waitcnt vmcnt(16)")
+    gat += add(192, 64)
+    gat.append("s_branch 1b")
+    gat.append("2:")
+    gat.append("s_waitcnt vmcnt(0)")
+    gat += add(192, 64)
+    gat.append("s_nop 4")
+    for name, lines in (("W4H_PUBLISH_ASM", pub), ("W4H_GATHER_ASM", gat)):
+        f.write("// %s: %d instructions\n" % (name, len(lines)))
+        f.write("#define %s \\\n" % name)
+        for ln in lines:
+            f.write('  "%s\\n\\t" \\\n' % ln)
+        f.write('  ""\n')
+    f.write("#define W4H_XCHG_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in ["memory", "scc", "s80", "s81", "s82", "s83", "s84"] + ["v%d" % i for i in range(113, 121)] + ["v%d" % i for i in range(128, 256)]))
     f.write("#define W4_VARIANTS %d\n" % len(VARIANTS))
     f.write("#define W4_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
     f.write("#define W4H_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob + ["s100"]))
