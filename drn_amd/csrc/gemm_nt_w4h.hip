@@ -122,6 +122,7 @@ __device__ __forceinline__ void w4h_bn_stats(float* shs, float* __restrict__ sta
 // instruction), takes a ticket, and the split that arrives LAST at a tile re-reads all partials -- its own included, in split order,
 // so the sum does not depend on who was last -- into the AGPRs and runs the normal epilogue.  Same protocol as
 // conv_gemm_nt_kernel's split (gemm_nt_kernel.h); the two statements are W4H_PUBLISH_ASM / W4H_GATHER_ASM (gen_w4_loop.py).
+#define W4H_TAPIL 0x10000      // flag in GemmParams::ksplit (this kernel only)
 template <bool CONV>
 __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -162,9 +163,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
   const unsigned la0 = lrow + (unsigned)wr * 16384u + pc0, la1 = lrow + (unsigned)wr * 16384u + pc1;
   const unsigned lb0 = lrow + (unsigned)wc * 8192u + pc0, lb1 = lrow + (unsigned)wc * 8192u + pc1;
   const unsigned lw = lds0 + (unsigned)w * 8192u, lwb = lds0 + (unsigned)w * 4096u;
-  // split K (P.ksplit > 1): workgroup row y owns K-steps [k_lo, k_hi)
+  // split K (ksplit > 1): workgroup row y owns K-steps [k_lo, k_hi).  W4H_TAPIL (conv launches with a wide input): the K loop walks
+  // (channel block, tap) instead of (tap, channel block) -- W4HT_LOOP_ASM -- and a split starts at a whole channel block
+  const bool tapil = CONV && (P.ksplit & W4H_TAPIL) != 0;
+  P.ksplit &= W4H_TAPIL - 1;
   const int ksteps_all = pr.K / 64;
-  const int kt_per = (ksteps_all + P.ksplit - 1) / P.ksplit;
+  int kt_per = (ksteps_all + P.ksplit - 1) / P.ksplit;
+  if (tapil) kt_per = (kt_per + 2) / 3 * 3;
   const int k_lo = (int)blockIdx.y * kt_per, k_hi = min(ksteps_all, k_lo + kt_per);
   const char* sb = (const char*)pr.B + (long)n0 * pr.ldb * 2 + (long)k_lo * 128;
   const int trips = (k_hi - k_lo) - 2;
@@ -179,6 +184,19 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
     const unsigned sh0 = fwd ? 0u : 2u * lda2, sh1 = lda2, sh2 = fwd ? 2u * lda2 : 0u;
     const unsigned ma = fwd ? mask_first : mask_last, mc = fwd ? mask_last : mask_first;
     const int per = pr.Cin / 64;                      // K-steps per tap
+    if (tapil) {
+      const int c0 = (k_lo / 3) * 128, dstep = pr.Cin * 2, dwrap = 128 - 2 * dstep;
+      const char* sbt = (const char*)pr.B + (long)n0 * pr.ldb * 2 + c0;
+      asm volatile(W4HT_LOOP_ASM
+                   :
+                   : [sb] "s"(sbt), [cnt] "s"(trips), [lw] "s"(lw), [lwb] "s"(lwb), [d0] "s"(d0), [d1] "s"(d1), [d2] "s"(d2), [d3] "s"(d3),
+                     [c0] "s"(c0), [dstep] "s"(dstep), [dwrap] "s"(dwrap), [sh0] "s"(sh0), [sh1] "s"(sh1), [sh2] "s"(sh2),
+                     [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [voa4] "v"(voa[4]), [voa5] "v"(voa[5]),
+                     [voa6] "v"(voa[6]), [voa7] "v"(voa[7]), [ma] "v"(ma), [mc] "v"(mc),
+                     [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vob2] "v"(vob[2]), [vob3] "v"(vob[3]),
+                     [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1)
+                   : W4HT_LOOP_CLOBBERS);
+    } else {
     const int tap = k_lo / per, c0 = (k_lo - tap * per) * 128, left = per - (k_lo - tap * per);
     asm volatile(W4HC_LOOP_ASM
                  :
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
                    [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vob2] "v"(vob[2]), [vob3] "v"(vob[3]),
                    [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1)
                  : W4H_LOOP_CLOBBERS);
+    }
   } else {
     const char* sa = (const char*)pr.A + (long)m0 * pr.lda * 2 + (long)k_lo * 128;
     asm volatile(W4H_LOOP_ASM
@@ -261,6 +280,17 @@ int drn_nt_w4h_launch(const GemmParams& P, int total, bool conv, hipStream_t str
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
+  }
+  if (conv && ksplit > 1 && drn_tuning(DRN_TUNE_W4H_TAPIL) > 0 && P.p[0].Cin >= drn_tuning(DRN_TUNE_W4H_TAPIL)) {
+    // split conv launches over a wide input (conv0's forward: 4352 channels): taps interleaved, splits of whole channel blocks --
+    // if every split still gets its share
+    const int ksteps = P.p[0].K / 64, per = (cdiv(ksteps, ksplit) + 2) / 3 * 3;
+    if ((ksplit - 1) * per < ksteps) {
+      GemmParams Q = P;
+      Q.ksplit = ksplit | W4H_TAPIL;
+      gemm_nt_w4h_kernel<true><<<dim3(total, ksplit), 256, LDS, stream>>>(Q);
+      return drn_launch_status("drn_gemm_nt");
+    }
   }
   if (conv) gemm_nt_w4h_kernel<true><<<dim3(total, ksplit), 256, LDS, stream>>>(P);
   else gemm_nt_w4h_kernel<false><<<dim3(total, ksplit), 256, LDS, stream>>>(P);

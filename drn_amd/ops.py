@@ -132,10 +132,13 @@ def gemm_nt_plan(descs, dtype):
 # One long-K bf16 problem with few output tiles (conv0's forward: 8192 x 256 x 13056 = 64 tiles of 256 x 128, 204 K-steps) on the
 # 4-wave kernel's half-width tiles with the K loop split INSIDE the launch so that ~256 workgroups exist (gemm_nt_w4h_kernel:
 # partial accumulators exchanged through the workspace, the last-arriving split of a tile sums them in split order).
-# OFF by default: three boxes, three answers -- 2.059 -> 2.037 ms per step on the first, 2.017 -> 2.025 and 1.996 -> 2.004 on the next two
-# (kernel trace: 84.1 us on 128x128 tiles split 2 ways, 91.3 us here); conv0's forward is bound by how its A operand streams out of HBM
-# (DESIGN.md section 8), not by the tile.  DRN_KSPLIT_W4H=1 switches it on.
-KSPLIT_W4H = os.environ.get("DRN_KSPLIT_W4H", "0") == "1"
+# With the K loop in tap-major order this lost to 128x128 tiles split 2 ways (91 against 84 us: every 128-byte piece of conv0's
+# 71 MB input sits in a DRAM page of its own and was fetched three times, once per tap, 68 K-steps apart; with the rows of A aliased
+# -- scripts/experiments/conv0_alias_bench.py -- the same launch took 56 us).  Split k = 3 launches over >= 2048 input channels now
+# walk K as (channel block, tap) (W4HT_LOOP_ASM, drn_tune "w4h_tapil"): the three taps of a channel block read the same lines one
+# K-step after the other.  conv0's forward 85.8 -> 70.0 us alone and 81.9 -> 75.4 us inside the step (one box each, both paths
+# traced); the step itself moves inside its noise (2.007 -> 2.002 ms).  DRN_KSPLIT_W4H=0 switches it off.
+KSPLIT_W4H = os.environ.get("DRN_KSPLIT_W4H", "1") == "1"
 
 
 def _ksplit_w4h(descs, dtype):

@@ -55,6 +55,7 @@ class Cfg:
     mfma32 = False      # timing-only ablation: half as many v_mfma_f32_32x32x16_bf16 (same pipe time, twice the issue slack per gap)
     hoist = True        # scalar bookkeeping and M0 writes inside the MFMA stream (False: after it / in front of each piece)
     adv = 128           # bytes the operand pointers advance per K-step (0: every K-step re-reads the first one -- L2-hit ablation)
+    tapil = False       # conv mode with the taps INTERLEAVED: K-step j = (channel block j / 3, tap j % 3) -- see advance_tap_il
     half = False        # 256 x 128 output tile (gemm_nt_w4h_kernel): 128 x 64 per wave, B items of 128 rows -- see the notes at `Geo`
 
     def __init__(self, **kw):
@@ -128,7 +129,8 @@ def dma_item(op):
     if op == "a" and cfg.conv:
         # conv mode: A through a buffer descriptor (s[92:95]): lane offset v[116 + i] = row offset of the CURRENT tap, 0x80000000
         # (out of range -> the piece gets zeros) where the tap leaves the lane's sequence; s96 = channel byte offset inside the tap
-        return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "buffer_load_dwordx4 v%d, s[92:95], s96 offen lds" % (116 + i)] for i in range(8)]
+        soff = "s98" if cfg.tapil else "s96"       # (interleaved taps: s98 = channel offset + the tap's row shift)
+        return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "buffer_load_dwordx4 v%d, s[92:95], %s offen lds" % (116 + i, soff)] for i in range(8)]
     src = "s[80:81]" if op == "a" else "s[82:83]"
     return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "global_load_lds_dwordx4 %%[vo%s%d], %s" % (op, i, src)]
             for i in range(8 if op == "a" else geo().PB)]
@@ -166,6 +168,35 @@ def advance_tap():
     return L
 
 
+def tap_il_select():
+    """interleaved taps: soffset s98 = s96 + row shift of tap s99; lane offsets v[116:123] = the tap's set -- tap 1: the lanes' own
+    offsets (%[voa..]), tap 0 / 2: v[97:104] / v[105:112], the same with 0x80000000 where the shifted row leaves the lane's sequence"""
+    L = ["s_cmp_eq_u32 s99, 0", "s_cselect_b32 s79, %[sh0], %[sh1]", "s_cmp_eq_u32 s99, 2", "s_cselect_b32 s79, %[sh2], s79",
+         "s_add_u32 s98, s96, s79", "s_cmp_eq_u32 s99, 0", "s_cselect_b64 vcc, -1, 0"]
+    L += ["v_cndmask_b32 v%d, %%[voa%d], v%d, vcc" % (116 + i, i, 97 + i) for i in range(8)]
+    L += ["s_cmp_eq_u32 s99, 2", "s_cselect_b64 vcc, -1, 0"]
+    L += ["v_cndmask_b32 v%d, v%d, v%d, vcc" % (116 + i, 116 + i, 105 + i) for i in range(8)]
+    return L
+
+
+def advance_tap_il():
+    """conv mode with interleaved taps, after an A item: the staging stream moves to the next tap of the SAME channel block, and to
+    the next channel block (+128 bytes) after tap 2.  The three taps of a channel block read rows m-1 .. m+256 of the same 128-byte
+    column one K-step after the other: the second and third find the lines in L2.  (Tap-major order reads each of conv0's 71 MB
+    three times 68 K-steps apart, every 128-byte piece in a DRAM page of its own.)"""
+    L = ["s_add_u32 s99, s99, 1", "s_cmp_eq_u32 s99, 3", "s_cselect_b32 s99, 0, s99",
+         "s_cmp_eq_u32 s99, 0", "s_cselect_b32 s79, 128, 0", "s_add_u32 s96, s96, s79"]
+    return L + tap_il_select()
+
+
+def advance_b_il():
+    """... and the B stream (its own tap counter s97): + one tap (%[dstep] = Cin * 2 bytes) twice, then back two taps and on by one
+    channel block (%[dwrap] = 128 - 2 * Cin * 2, negative: the high word gets -1)"""
+    return ["s_add_u32 s97, s97, 1", "s_cmp_eq_u32 s97, 3", "s_cselect_b32 s97, 0, s97",
+            "s_cmp_eq_u32 s97, 0", "s_cselect_b32 s79, %[dwrap], %[dstep]", "s_cselect_b32 s101, -1, 0",
+            "s_add_u32 s82, s82, s79", "s_addc_u32 s83, s83, s101"]
+
+
 def advance_stage_groups(op):
     """source pointer of the operand + 128 bytes, staging slot + 1 (mod the ring); groups of instructions that stay adjacent
     (producer and consumer of SCC)"""
@@ -173,6 +204,8 @@ def advance_stage_groups(op):
     first = ["s_add_u32 s%d, s%d, %d" % (ptr[0], ptr[0], cfg.adv), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
     if op == "a" and cfg.conv:
         first = ["s_add_u32 s96, s96, 128"]
+    if cfg.tapil:
+        first = ["s_nop 0"] if op == "a" else advance_b_il()      # (A: the channel offset moves in advance_tap_il)
     G = geo()
     if G.half:      # the item after an A item is a B item (wave base s100) and vice versa (s85)
         return [first, ["s_add_u32 s86, s86, %d" % (G.A_BYTES if op == "a" else G.B_BYTES)],
@@ -240,7 +273,7 @@ def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False
     else:
         tail = [i for g in rd_groups + st_groups for i in g]
     if dma == "a" and cfg.conv:
-        tail += advance_tap()
+        tail += advance_tap_il() if cfg.tapil else advance_tap()
     for n in range(NM):
         if not cfg.no_mfma:
             mi, ni = n // NI, n % NI
@@ -269,10 +302,17 @@ def build():
     if G.half:
         lines += ["s_mov_b32 s100, %[lwb]"]
     if cfg.conv:
-        lines += ["s_mov_b32 s92, %[d0]", "s_mov_b32 s93, %[d1]", "s_mov_b32 s94, %[d2]", "s_mov_b32 s95, %[d3]",
-                  "s_mov_b32 s96, %[c0]", "s_mov_b32 s97, %[left]", "s_mov_b32 s98, %[per]", "s_mov_b32 s99, %[tap]",
-                  "v_mov_b32 v115, 0x80000000"]
-        lines += apply_tap("init")
+        lines += ["s_mov_b32 s92, %[d0]", "s_mov_b32 s93, %[d1]", "s_mov_b32 s94, %[d2]", "s_mov_b32 s95, %[d3]", "s_mov_b32 s96, %[c0]"]
+        if cfg.tapil:
+            lines += ["s_mov_b32 s97, 0", "s_mov_b32 s99, 0", "v_mov_b32 v115, 0x80000000"]
+            for base, msk in ((97, "%[ma]"), (105, "%[mc]")):      # the lane offsets of tap 0 / tap 2: zero rows at the sequence edges
+                for i in range(8):
+                    lines += ["v_and_b32 v114, %d, %s" % (1 << i, msk), "v_cmp_ne_u32 vcc, 0, v114",
+                              "v_cndmask_b32 v%d, %%[voa%d], v115, vcc" % (base + i, i)]
+            lines += ["s_nop 1"] + tap_il_select()
+        else:
+            lines += ["s_mov_b32 s97, %[left]", "s_mov_b32 s98, %[per]", "s_mov_b32 s99, %[tap]", "v_mov_b32 v115, 0x80000000"]
+            lines += apply_tap("init")
         lines += ["s_nop 4"]          # v[116:123] / s96 written just above: settle before the first piece reads them
     else:
         lines += ["s_mov_b64 s[80:81], %[sa]"]
@@ -283,7 +323,7 @@ def build():
             lines.extend(p)
         lines += advance_stage(op)
         if op == "a" and cfg.conv:
-            lines += advance_tap()
+            lines += advance_tap_il() if cfg.tapil else advance_tap()
     # accumulators = 0, while the first K-steps are on their way
     for i in range(G.NACC):
         lines.append("v_accvgpr_write_b32 a%d, 0" % i)
@@ -357,7 +397,8 @@ with open(args.out, "w") as f:
         f.write('  "%s\\n\\t" \\\n' % ln)
     f.write('  ""\n')
     # 256 x 128 tiles (gemm_nt_w4h_kernel): 32 MFMAs per half-step -> one fragment read after every 2nd, one piece after every 3rd
-    for name, c in (("W4H_LOOP_ASM", Cfg(half=True, ds_every=2, dma_every=3)), ("W4HC_LOOP_ASM", Cfg(half=True, conv=True, ds_every=2, dma_every=3))):
+    for name, c in (("W4H_LOOP_ASM", Cfg(half=True, ds_every=2, dma_every=3)), ("W4HC_LOOP_ASM", Cfg(half=True, conv=True, ds_every=2, dma_every=3)),
+                    ("W4HT_LOOP_ASM", Cfg(half=True, conv=True, tapil=True, ds_every=2, dma_every=3))):
         cfg = c
         lines = build()
         check_scc(lines)
@@ -418,4 +459,5 @@ with open(args.out, "w") as f:
     f.write("#define W4_VARIANTS %d\n" % len(VARIANTS))
     f.write("#define W4_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
     f.write("#define W4H_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob + ["s100"]))
+    f.write("#define W4HT_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob + ["s100", "s101"] + ["v%d" % i for i in range(97, 113)]))
 print("wrote %s: %d variant(s)" % (args.out, len(VARIANTS)))

@@ -16,7 +16,7 @@ TOL = {"f32": 2e-5, "bf16": 1e-2}
 def tune(monkeypatch, key, value):
     """drn_tune(key, value) for the duration of one test (defaults restored afterwards)."""
     from drn_amd import _lib
-    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0, "nt_w4h": 160}
+    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0, "nt_w4h": 160, "w4h_tapil": 2048}
     _lib.check(_lib.lib().drn_tune(key.encode(), int(value)), "drn_tune")
     _RESTORE.append((key, defaults[key]))
 
@@ -893,18 +893,24 @@ def test_w4h_kernel_splitk_in_launch(monkeypatch, shape):
         ops.gemm_nt([d], ops.BF16)
         torch.cuda.synchronize()
         return ks, C, st
-    ks1, C1, s1 = run(True)
-    ks2, C2, s2 = run(True)
     ks0, C0, s0 = run(False)
-    assert ks1 >= 2 and ks0 == 1
-    assert torch.equal(C1, C2) and (not stats or torch.equal(s1, s2))
-    close(C1, C0.double().cpu(), 1e-2, "split vs unsplit output")
-    if stats:
-        t1, q1 = merged_stats(s1, M)
-        t0, q0 = merged_stats(s0, M)
-        close(t1, t0, 1e-4, "column sums")
-        close(q1, q0, 1e-4, "column M2")
-    assert int(ops._counters(dev()).abs().sum()) == 0
+    outs = []
+    for tapil in (2048, 0):          # split k = 3 launches over >= 2048 channels walk K as (channel block, tap); 0: tap-major as unsplit
+        tune(monkeypatch, "w4h_tapil", tapil)
+        ks1, C1, s1 = run(True)
+        ks2, C2, s2 = run(True)
+        assert ks1 >= 2 and ks0 == 1
+        assert torch.equal(C1, C2) and (not stats or torch.equal(s1, s2))
+        close(C1, C0.double().cpu(), 1e-2, "split vs unsplit output")
+        if stats:
+            t1, q1 = merged_stats(s1, M)
+            t0, q0 = merged_stats(s0, M)
+            close(t1, t0, 1e-4, "column sums")
+            close(q1, q0, 1e-4, "column M2")
+        assert int(ops._counters(dev()).abs().sum()) == 0
+        outs.append(C1)
+    if taps == 3:                    # another summation order: the two walks agree to rounding, and (almost surely) not bit for bit
+        close(outs[0], outs[1].double().cpu(), 1e-2, "interleaved vs tap-major")
 
 
 def test_deferred_wgrad_reduce_passes_in_one_launch_equal_the_immediate_ones():
