@@ -32,7 +32,9 @@ class GemmDesc(ctypes.Structure):
                 ("Cin", c_int32), ("taps", c_int32), ("stride", c_int32), ("pad", c_int32), ("mode", c_int32),
                 ("Lout", c_int32), ("Lsrc", c_int32),
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldg", c_int32),
-                ("accumulate", c_int32), ("ldc2", c_int32), ("out_f32", c_int32), ("sumsq", c_void_p)]
+                ("accumulate", c_int32), ("ldc2", c_int32), ("out_f32", c_int32), ("sumsq", c_void_p),
+                ("gb_act", c_void_p), ("gb_dct", c_void_p), ("gb_dgate", c_void_p), ("gb_dsum", c_void_p),
+                ("gb_ld_act", c_int32), ("gb_ldt", c_int32)]
 
 
 class WgradDesc(ctypes.Structure):

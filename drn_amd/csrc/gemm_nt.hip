@@ -79,6 +79,7 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     p.accumulate = s.accumulate;
     p.out_f32 = s.out_f32;
     p.sumsq = s.sumsq;
+    p.gb_act = s.gb_act; p.gb_dct = s.gb_dct; p.gb_dgate = s.gb_dgate; p.gb_dsum = s.gb_dsum; p.gb_ld_act = s.gb_ld_act; p.gb_ldt = s.gb_ldt;
     p.tiles_n = cdiv(s.N, tile_n);
     p.tile_start = total;
     total += cdiv(s.M, tile_m) * p.tiles_n;
@@ -131,6 +132,15 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
     DRN_CHECK_ARG(!d[g].sumsq || (kind == DRN_NT_KIND_W4 && d[g].out_f32 && !d[g].bias && !d[g].accumulate && ngroups == 1),
                   "drn_gemm_nt: DrnGemmDesc::sumsq needs a single fp32-output launch on gemm_nt_w4_kernel without bias / accumulate "
                   "(ask drn_gemm_nt_plan first)");
+  for (int g = 0; g < ngroups; ++g) {
+    const DrnGemmDesc& s = d[g];
+    if (!s.gb_act) continue;
+    DRN_CHECK_ARG(kind == DRN_NT_KIND_W4C && ngroups == 1 && ksplit == 1 && s.mode == 1 && s.gate && s.gb_dct && s.gb_dgate && s.gb_dsum &&
+                      !s.bias && !s.C2 && !s.stats && !s.accumulate && (s.Lout == 32 || s.Lout == 64 || s.Lout == 128 || s.Lout == 256) &&
+                      s.gb_ld_act % 8 == 0 && s.gb_ldt % 8 == 0 && !((uintptr_t)s.gb_act & 15) && !((uintptr_t)s.gb_dct & 15) && s.ldg >= s.N,
+                  "drn_gemm_nt: DrnGemmDesc::gb_* needs a single bf16 data-gradient launch on gemm_nt_w4c_kernel (ask drn_gemm_nt_plan "
+                  "first) with gate and all three outputs set, clips of 32 / 64 / 128 / 256 rows, no bias / C2 / stats / accumulate");
+  }
   if (kind == DRN_NT_KIND_W4) {
     P.nblocks = total;
     return drn_nt_w4_launch(P, total, stream);

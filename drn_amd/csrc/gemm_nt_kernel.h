@@ -40,6 +40,13 @@ struct GemmProb {
   int out_f32;      // C is fp32 [M][ldc] whatever T is (weight gradients computed as an NT product of transposed operands)
   int tiles_n, tile_start;
   float* sumsq;     // gemm_nt_w4_kernel, out_f32: [workgroups] sum of the squares of each workgroup's outputs (DrnGemmDesc::sumsq)
+  // gemm_nt_w4c_kernel, data gradient followed by the input stage's gate backward (DrnGemmDesc::gb_*): the product is not stored as
+  // C but as dct[c][m] = bf16(product) * gate[m / Lout][c], with dgate[seq][c] = sum_t product * act, dsum[seq][c] = sum_t of dct's values
+  const void* gb_act;
+  void* gb_dct;
+  float* gb_dgate;
+  float* gb_dsum;
+  int gb_ld_act, gb_ldt;
 };
 struct GemmParams {
   int ngroups;

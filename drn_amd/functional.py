@@ -789,6 +789,18 @@ class _ConvBlockFn(torch.autograd.Function):
                 descs.append(ops.gemm_desc(draws[l], wd, dx, B * L, ncols, Cout, taps=k, stride=meta.stride, pad=pad, mode=1,
                                            Lout=L, Lsrc=Lo, ldc=Cin))
                 dxs[l] = dx
+            gctx = tail.gate_ctx if tail is not None else None
+            if (gctx is not None and k == 3 and meta.stride == 1 and gctx[2:] == (geo[0][0], geo[0][1], ncols)
+                    and ops.gemm_nt_plan(descs, code) == ops.NT_KIND_W4C):
+                # the input stage's gate backward in this launch's epilogue: dx is not written, its consumer gets these instead
+                Z, gate0, B, T, D = gctx
+                dZT = torch.empty((D, B * T), dtype=dt, device=dev)
+                dgate0 = torch.empty((B, D), dtype=torch.float32, device=dev)
+                dsum0 = torch.empty((B, D), dtype=torch.float32, device=dev)
+                descs = [ops.gemm_desc(draws[0], wd, dxs[0], B * T, ncols, Cout, taps=k, stride=1, pad=pad, mode=1, Lout=T, Lsrc=T, ldc=Cin,
+                                       gate=gate0, ldg=gate0.stride(0),
+                                       gate_bwd=dict(act=Z, ld_act=D, dct=dZT, ldt=B * T, dgate=dgate0, dsum=dsum0))]
+                tail.gate_out = (dZT, dgate0, dsum0)
             ops.gemm_nt(descs, code)
             if tail is not None:
                 B, L, Lo, M, ld = geo[0]
@@ -1116,6 +1128,9 @@ def _fc_kernel_kind(B, T, D, N, xc, wfc, code, split_gate):
     return ops.gemm_nt_plan([d], code)
 
 
+GATE_BWD_FUSE = os.environ.get("DRN_GATE_BWD_FUSE", "1") != "0"      # (experiment switch: 0 = drn_gate_bwd_t as a launch of its own)
+
+
 class EmbedTail(object):
     """Link between the input stage and the conv block that consumes its output.  The position embedding occupies the last P
     channels of that conv's input and is a Linear(3, P) of per-row features, so its two gradients can be taken through the conv
@@ -1123,11 +1138,15 @@ class EmbedTail(object):
     (T = 256: 544 -> 512 tiles of 256x256, two full rounds on 256 CUs instead of two and an eighth).  The conv block's backward
     fills dW / db; the input stage's backward, which runs after it, hands them to autograd instead of reducing the
     (unwritten) embedding columns of its incoming gradient."""
-    __slots__ = ("pf", "Wpos", "bpos", "P", "dW", "db", "dtype")
+    __slots__ = ("pf", "Wpos", "bpos", "P", "dW", "db", "dtype", "gate_ctx", "gate_out")
 
     def __init__(self, pf, Wpos, bpos, dtype):
         self.pf, self.Wpos, self.bpos, self.P, self.dtype = pf, Wpos, bpos, Wpos.shape[0], dtype
         self.dW = self.db = None
+        # the input stage's gate backward inside the conv block's data-gradient launch (DrnGemmDesc::gb_*): the input stage leaves
+        # (Z, gate0, B, T, D) here in its forward; the conv block's backward, if its launch runs on gemm_nt_w4c_kernel, leaves
+        # (dZT, dgate, dsum) -- and the input stage's backward does not read its incoming gradient at all
+        self.gate_ctx = self.gate_out = None
 
     def usable(self, Cin, Cout, dt):
         vn = 8 if dt == torch.bfloat16 else 4
@@ -1141,6 +1160,10 @@ class EmbedTail(object):
     def take(self):
         dW, db, self.dW, self.db = self.dW, self.db, None, None
         return dW, db
+
+    def take_gate(self):
+        out, self.gate_out = self.gate_out, None
+        return out
 
 
 class _InputStageFn(torch.autograd.Function):
@@ -1169,6 +1192,10 @@ class _InputStageFn(torch.autograd.Function):
         ctx.dtype, ctx.dims = dtype, (B, T, D, P)
         ctx.param_refs = (Wfc, bfc, Wpos, bpos)
         ctx.tail = tail
+        if tail is not None:
+            fuse = GATE_BWD_FUSE and dtype == torch.bfloat16 and xcT is not None and xcT.numel() and T in (32, 64, 128, 256) and D % 256 == 0
+            tail.gate_ctx = (Z, gate0, B, T, D) if fuse else None
+            tail.gate_out = None
         ctx.save_for_backward(xc, pf, gate0, Z, xcT if xcT is not None else xc.new_empty(0))
         return G0
 
@@ -1179,9 +1206,11 @@ class _InputStageFn(torch.autograd.Function):
         B, T, D, P = ctx.dims
         xc, pf, gate0, Z, xcT = ctx.saved_tensors
         dev = xc.device
-        dG0 = _grad_nlc(dG0, None, dtype)
-        dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
-        dsum = torch.empty((B, D), dtype=torch.float32, device=dev)      # per-clip column sums of dZ: prop_fc bias gradient
+        fused = ctx.tail.take_gate() if ctx.tail is not None else None
+        if fused is None:
+            dG0 = _grad_nlc(dG0, None, dtype)
+            dgate = torch.empty((B, D), dtype=torch.float32, device=dev)
+            dsum = torch.empty((B, D), dtype=torch.float32, device=dev)      # per-clip column sums of dZ: prop_fc bias gradient
         Wfc, bfc, Wpos, bpos = ctx.param_refs
         dW, db = grad_buffer(Wfc), grad_buffer(bfc)
         dWp, dbp = ctx.tail.take() if ctx.tail is not None else (None, None)
@@ -1189,7 +1218,9 @@ class _InputStageFn(torch.autograd.Function):
         if not from_tail:
             dWp, dbp = grad_buffer(Wpos), grad_buffer(bpos)
         dZ = dZT = None
-        if xcT.numel() and T % 32 == 0:
+        if fused is not None:
+            dZT, dgate, dsum = fused         # conv0's data-gradient launch did the gate backward in its epilogue (dG0 was never written)
+        elif xcT.numel() and T % 32 == 0:
             # dW[n][c] = sum_m dZ[m][n] * x[m][c] as an NT product of the K-major copies dZ^T (D, B*T) and x^T (D, B*T):
             # the NT kernel streams both operands with 16-byte LDS reads (1.1 PFLOP/s on this shape), while the TN
             # kernel's transposing ds_read_b64_tr_b16 fragments hold it to ~0.7.  dZ is only ever needed transposed.

@@ -38,15 +38,22 @@ def _need_gpu(*ts):
 
 
 def gemm_desc(A, B, C, M, N, Cin, taps=1, stride=1, pad=0, mode=0, Lout=None, Lsrc=None, lda=None, ldb=None,
-              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, ldc2=None, accumulate=False, out_f32=False, sumsq=None):
+              ldc=None, bias=None, gate=None, ldg=0, stats=None, C2=None, ldc2=None, accumulate=False, out_f32=False, sumsq=None,
+              gate_bwd=None):
+    """gate_bwd: dict(act, ld_act, dct, ldt, dgate, dsum) -- the data gradient feeds the input stage's gate backward, which then
+    happens in the launch's epilogue (DrnGemmDesc::gb_*; gemm_nt_w4c_kernel only: ask gemm_nt_plan)."""
     _need_gpu(A, B, C, bias, gate, stats, C2)
     Lout = M if Lout is None else Lout
     Lsrc = Lout if Lsrc is None else Lsrc
+    gb = gate_bwd or {}
+    _need_gpu(gb.get("act"), gb.get("dct"), gb.get("dgate"), gb.get("dsum"))
     return GemmDesc(A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), gate=_p(gate), stats=_p(stats),
                     M=M, N=N, Cin=Cin, taps=taps, stride=stride, pad=pad, mode=mode, Lout=Lout, Lsrc=Lsrc,
                     lda=Cin if lda is None else lda, ldb=taps * Cin if ldb is None else ldb,
                     ldc=N if ldc is None else ldc, ldg=ldg, accumulate=int(accumulate),
-                    ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2, out_f32=int(out_f32), sumsq=_p(sumsq))
+                    ldc2=(N if ldc is None else ldc) if ldc2 is None else ldc2, out_f32=int(out_f32), sumsq=_p(sumsq),
+                    gb_act=_p(gb.get("act")), gb_dct=_p(gb.get("dct")), gb_dgate=_p(gb.get("dgate")), gb_dsum=_p(gb.get("dsum")),
+                    gb_ld_act=int(gb.get("ld_act", 0)), gb_ldt=int(gb.get("ldt", 0)))
 
 
 # Optional per-launch timing of the MFMA kernels (bench.py): a list collecting (tag, flops, start_event, end_event),

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 6
+#define DRN_ABI_VERSION 7
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
@@ -66,6 +66,18 @@ typedef struct DrnGemmDesc {
   float* sumsq;       /* or NULL.  out_f32 launches on gemm_nt_w4_kernel only (drn_gemm_nt_plan says DRN_NT_KIND_W4; no bias / accumulate):
                        * sumsq[t] = sum of the squares of output tile t's values (256x256 tiles in launch order, (M/256)*(N/256) floats):
                        * the gradient's contribution to the global norm without reading it again (drn_sumsq_finalize2) */
+  /* gb_act != NULL: a data gradient (mode 1, k = 3 / stride 1) whose consumer is the input stage's gate backward (drn_gate_bwd_t;
+   * model/backbone.py:28-30 on prop_fc's output): C is NOT written; with g = the product rounded to dtype, s = m / Lout,
+   *   gb_dct[c][m] = dtype(g[m][c] * gate[s][c])   (row stride gb_ldt: the K-major operand of prop_fc's weight gradient),
+   *   gb_dgate[s][c] = sum_t g * gb_act[m][c]       ([M / Lout][N] fp32; gb_act: the pre-gate activation, row stride gb_ld_act),
+   *   gb_dsum[s][c]  = sum_t g * gate[s][c]         ([M / Lout][N] fp32: per-clip column sums, the bias gradient's partials).
+   * bf16 launches on gemm_nt_w4c_kernel only (drn_gemm_nt_plan says DRN_NT_KIND_W4C), Lout in {32, 64, 128, 256}, gate set,
+   * no bias / C2 / stats / accumulate; one problem per launch. */
+  const void* gb_act;
+  void* gb_dct;
+  float* gb_dgate;
+  float* gb_dsum;
+  int32_t gb_ld_act, gb_ldt;
 } DrnGemmDesc;
 
 /* Grouped NT implicit GEMM on MFMA (conv1d fwd / dgrad, linear fwd / dgrad).

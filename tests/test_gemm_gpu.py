@@ -951,3 +951,44 @@ def test_deferred_wgrad_reduce_passes_in_one_launch_equal_the_immediate_ones():
     assert n_pending >= 3 and _lib.lib().drn_wgrad_pending() == 0
     for a, b in zip(ref, got):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,L,Cout,D", [(2, 256, 256, 512), (4, 128, 128, 256), (8, 64, 64, 256), (16, 32, 64, 512), (32, 256, 256, 4096)])
+def test_w4c_data_gradient_with_the_gate_backward_in_its_epilogue(monkeypatch, B, L, Cout, D):
+    """DrnGemmDesc::gb_*: conv0's data gradient (k = 3, gemm_nt_w4c_kernel) followed by the input stage's gate backward, in one launch,
+    against the two launches it replaces (drn_gemm_nt + drn_gate_bwd_t): the transposed gated gradient bit for bit (the epilogue rounds
+    the product to bf16 before gating, exactly what the second launch read back), the per-clip sums to fp32 re-association.  Clips of
+    256 / 128 / 64 / 32 rows (one clip over two waves ... eight clips per tile) and the benchmarked shape."""
+    from drn_amd import ops
+    M = B * L
+    P = 64
+    Cin = D + P
+    dY = rnd((M, Cout), 41, torch.bfloat16).to(dev())
+    Wd = (rnd((D, 3 * Cout), 42, torch.float32) * 0.05).to(torch.bfloat16).to(dev())          # (Cin - P, k, Cout) as the GEMM's B operand
+    Z = rnd((M, D), 43, torch.bfloat16).to(dev())
+    gate = (rnd((B, D), 44, torch.float32) * 0.5 + 1.0).to(dev())
+    tune(monkeypatch, "exp0", 1)                       # 256 x 256 tiles whatever the tile count (the toy shapes)
+    dx = torch.zeros((M, Cin), device=dev(), dtype=torch.bfloat16)
+    d0 = ops.gemm_desc(dY, Wd, dx, M, D, Cout, taps=3, pad=1, mode=1, Lout=L, Lsrc=L, ldc=Cin)
+    assert ops.gemm_nt_plan([d0], ops.BF16) == ops.NT_KIND_W4C
+    ops.gemm_nt([d0], ops.BF16)
+    dZT0 = torch.empty((D, M), device=dev(), dtype=torch.bfloat16)
+    dgate0 = torch.empty((B, D), device=dev())
+    dsum0 = torch.empty((B, D), device=dev())
+    ops.gate_bwd_t(dx, Cin, Z, D, gate, dZT0, dgate0, B, L, D, ops.BF16, dsum=dsum0)
+    dx1 = torch.full((M, Cin), 3.0, device=dev(), dtype=torch.bfloat16)
+    dZT1 = torch.full((D, M), float("nan"), device=dev(), dtype=torch.bfloat16)
+    dgate1 = torch.full((B, D), float("nan"), device=dev())
+    dsum1 = torch.full((B, D), float("nan"), device=dev())
+    d1 = ops.gemm_desc(dY, Wd, dx1, M, D, Cout, taps=3, pad=1, mode=1, Lout=L, Lsrc=L, ldc=Cin, gate=gate, ldg=D,
+                       gate_bwd=dict(act=Z, ld_act=D, dct=dZT1, ldt=M, dgate=dgate1, dsum=dsum1))
+    ops.gemm_nt([d1], ops.BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(dZT1, dZT0), "max |d| = %g" % float((dZT1.float() - dZT0.float()).abs().max())
+    assert float((dx1.float() - 3.0).abs().max()) == 0.0, "the plain gradient must stay unwritten"
+    close(dgate1, dgate0.double().cpu(), 2e-5 * max(1.0, L ** 0.5), "dgate")
+    close(dsum1, dsum0.double().cpu(), 2e-5 * max(1.0, L ** 0.5), "dsum")
+    # refused where the kernel cannot do it: another kernel, clips that are not 32 / 64 / 128 / 256 rows
+    tune(monkeypatch, "nt_w4c", 0)
+    with pytest.raises(Exception, match="gb_"):
+        ops.gemm_nt([d1], ops.BF16)
