@@ -691,6 +691,60 @@ extern "C" int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int l
   return drn_launch_status("drn_pairsum_add_to");
 }
 
+// The two steps of the three-level top-down backward (model/FPN.py:63-68) in ONE launch: d1 = own1 + pairs(d0), d2 = own2 + pairs(d1).
+// A level-2 thread recomputes the two d1 rows it needs from own1 and d0 -- rounded to T where the two-launch order stores and
+// re-reads them -- so the levels need no order between them and the bits are the same.
+template <typename T>
+__global__ __launch_bounds__(256) void pairsum_chain3_kernel(const T* __restrict__ d0, int ld0, const T* __restrict__ own1, int ldo1,
+                                                             T* __restrict__ d1, int ld1, const T* __restrict__ own2, int ldo2,
+                                                             T* __restrict__ d2, int ld2, int M1, int C) {
+  constexpr int N = V16<T>::N;
+  const int nvec = C / N, M2 = M1 / 2;
+  const long n1 = (long)M1 * nvec, total = n1 + (long)M2 * nvec;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i < n1) {
+      const int v = (int)(i % nvec);
+      const long m = i / nvec;
+      float d[N], a[N], b[N];
+      V16<T>::load(own1 + m * ldo1 + v * N, d);
+      V16<T>::load(d0 + (2 * m) * ld0 + v * N, a);
+      V16<T>::load(d0 + (2 * m + 1) * ld0 + v * N, b);
+#pragma unroll
+      for (int k = 0; k < N; ++k) d[k] = d[k] + (a[k] + b[k]);
+      V16<T>::store(d1 + m * ld1 + v * N, d);
+    } else {
+      const long j = i - n1;
+      const int v = (int)(j % nvec);
+      const long m = j / nvec;
+      float o[N], p[2][N], q[4][N];
+      V16<T>::load(own2 + m * ldo2 + v * N, o);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) V16<T>::load(own1 + (2 * m + u) * ldo1 + v * N, p[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) V16<T>::load(d0 + (4 * m + u) * ld0 + v * N, q[u]);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float da = DT<T>::round(p[0][k] + (q[0][k] + q[1][k])), db = DT<T>::round(p[1][k] + (q[2][k] + q[3][k]));
+        o[k] = o[k] + (da + db);
+      }
+      V16<T>::store(d2 + m * ld2 + v * N, o);
+    }
+  }
+}
+extern "C" int drn_pairsum_chain3(const void* d0, int ld0, const void* own1, int ldo1, void* d1, int ld1, const void* own2, int ldo2,
+                                  void* d2, int ld2, int M1, int C, int dtype, void* stream) {
+  drn_clear_status();
+  DRN_CHECK_ARG(d0 && own1 && d1 && own2 && d2 && M1 > 0 && M1 % 2 == 0 && C > 0, "drn_pairsum_chain3: bad args");
+  DISPATCH_DT(dtype, "drn_pairsum_chain3", {
+    constexpr int N = V16<T>::N;
+    DRN_CHECK_ARG(C % N == 0 && ld0 % N == 0 && ldo1 % N == 0 && ld1 % N == 0 && ldo2 % N == 0 && ld2 % N == 0,
+                  "drn_pairsum_chain3: C/ld must be 16-byte multiples");
+    pairsum_chain3_kernel<T><<<ew_blocks((long)(M1 + M1 / 2) * (C / N), 256), 256, 0, (hipStream_t)stream>>>(
+        (const T*)d0, ld0, (const T*)own1, ldo1, (T*)d1, ld1, (const T*)own2, ldo2, (T*)d2, ld2, M1, C);
+  });
+  return drn_launch_status("drn_pairsum_chain3");
+}
+
 // ---------------------------------------------------------------- query gate, forward, as its own pass
 // out[s,t,c] = z[s,t,c] * gate[s,c]  (model/backbone.py:28-30 for level 0: `q * x` on prop_fc's output).  The GEMM epilogue
 // applies the gate itself when the gate exists before the GEMM starts; this pass is for the schedule that runs the query encoder

@@ -991,7 +991,16 @@ class _MultiConvFn(torch.autograd.Function):
         raws, sss, saves = sv[3 * n:4 * n], sv[4 * n:5 * n], sv[5 * n:6 * n]
         dev = xs[0].device
         dtot = [None] * n
-        for l in range(n):                                    # fine to coarse: out_l also fed out_{l-1} through the upsample
+        g3 = [_grad_nlc(g, None, dt) for g in gouts] if (chain_up and n == 3) else None
+        if (g3 is not None and all(g is not None for g in g3) and geo[0][5] == geo[1][5] == geo[2][5] and geo[1][2] * 2 == geo[0][2]
+                and geo[2][2] * 2 == geo[1][2]):
+            # the usual case -- three levels, every level with a gradient of its own: both upsample-add backward steps in ONE launch
+            C3 = geo[0][5]
+            dtot[0] = g3[0]
+            dtot[1] = torch.empty((geo[1][0], geo[1][2], C3), dtype=dt, device=dev)
+            dtot[2] = torch.empty((geo[2][0], geo[2][2], C3), dtype=dt, device=dev)
+            ops.pairsum_chain3(g3[0], g3[1], dtot[1], g3[2], dtot[2], geo[1][3], C3, code)
+        for l in range(n if dtot[0] is None else 0):          # fine to coarse: out_l also fed out_{l-1} through the upsample
             B, L, Lo, M, ld, Cout = geo[l][:6]
             d = _grad_nlc(gouts[l], None, dt)
             if chain_up and l > 0:

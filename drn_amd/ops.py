@@ -534,6 +534,11 @@ def pairsum_add(dst, ld_dst, src, ld_src, Mdst, C, dtype, accumulate=True):
     check(lib().drn_pairsum_add(_p(dst), ld_dst, _p(src), ld_src, Mdst, C, int(accumulate), dtype, _stream()), "drn_pairsum_add")
 
 
+def pairsum_chain3(d0, own1, d1, own2, d2, M1, C, dtype):
+    """d1 = own1 + pairs(d0), d2 = own2 + pairs(d1) in one launch (all row strides C); the bits of two pairsum_add_to launches."""
+    check(lib().drn_pairsum_chain3(_p(d0), C, _p(own1), C, _p(d1), C, _p(own2), C, _p(d2), C, M1, C, dtype, _stream()), "drn_pairsum_chain3")
+
+
 def pairsum_add_to(dst, ld_dst, base, ld_base, src, ld_src, Mdst, C, dtype):
     check(lib().drn_pairsum_add_to(_p(dst), ld_dst, _p(base), ld_base, _p(src), ld_src, Mdst, C, dtype, _stream()), "drn_pairsum_add_to")
 

@@ -213,6 +213,10 @@ int drn_pairsum_add(void* dst, int ld_dst, const void* src, int ld_src, int Mdst
 /* out-of-place form: dst[s,t] = base[s,t] + src[s,2t] + src[s,2t+1] (base = the level's own incoming gradient) */
 int drn_pairsum_add_to(void* dst, int ld_dst, const void* base, int ld_base, const void* src, int ld_src, int Mdst, int C,
                        int dtype, void* stream);
+/* both steps of a three-level pyramid in one launch: d1 = own1 + pairs(d0) (M1 rows), d2 = own2 + pairs(d1) (M1 / 2 rows); the bits
+ * of two drn_pairsum_add_to launches */
+int drn_pairsum_chain3(const void* d0, int ld0, const void* own1, int ldo1, void* d1, int ld1, const void* own2, int ldo2, void* d2,
+                       int ld2, int M1, int C, int dtype, void* stream);
 /* out[s,t,c] = z[s,t,c] * gate[s,c]: the level-0 query gate (model/backbone.py:28-30 on prop_fc's output) as its own pass, for
  * the schedule that runs the query encoder beside the prop_fc GEMM (otherwise drn_gemm_nt's epilogue applies the gate). */
 int drn_gate_fwd(const void* z, int ld_z, const float* gate, int ldg, void* out, int ld_out, int nseq, int L, int C, int dtype,

@@ -58,6 +58,28 @@ def test_pairsum_add(dt, accumulate):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,L2,C", [(3, 5, 40), (32, 64, 512)])
+def test_pairsum_chain_in_one_launch_gives_the_bits_of_two(dt, B, L2, C):
+    """both top-down backward steps of a three-level pyramid (model/FPN.py:63-68) in one launch (drn_pairsum_chain3): level-2
+    threads recompute the level-1 rows they need, rounded where the two-launch order stores them."""
+    from drn_amd import ops
+    g = torch.Generator().manual_seed(2)
+    dev = "cuda:0"
+    d0 = torch.randn(B, 4 * L2, C, generator=g).to(dev).to(dt)
+    own1 = torch.randn(B, 2 * L2, C, generator=g).to(dev).to(dt)
+    own2 = torch.randn(B, L2, C, generator=g).to(dev).to(dt)
+    a1, a2 = torch.empty_like(own1), torch.empty_like(own2)
+    ops.pairsum_add_to(a1, C, own1, C, d0, C, B * 2 * L2, C, _code(dt))
+    ops.pairsum_add_to(a2, C, own2, C, a1, C, B * L2, C, _code(dt))
+    b1, b2 = torch.full_like(own1, float("nan")), torch.full_like(own2, float("nan"))
+    ops.pairsum_chain3(d0, own1, b1, own2, b2, B * 2 * L2, C, _code(dt))
+    torch.cuda.synchronize()
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    want1 = own1.double() + d0.double().view(B, 2 * L2, 2, C).sum(2)
+    assert torch.allclose(b1.double(), want1, **_tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,C", [(5, 8), (100, 256), (8192, 256), (9001, 264)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_pos_embed_bwd(dt, M, C, accumulate):
