@@ -136,6 +136,8 @@ class Trainer(object):
         # beside input preparation / weight gradients; the same launches and bits as the linear capture).  Worth 3.5 % in bench.py's
         # back-to-back replays, NOTHING inside this loop (2.360 vs 2.369 ms/step at T = 256, scripts/experiments/trainer_forked_probe.py:
         # the per-step input copies and stream hand-offs around the replay sit where the overlap was) -- so it is opt-in
+        if forked is None:
+            forked = os.environ.get("DRN_TRAINER_FORKED", "0") == "1"
         self.forked = bool(forked) and self.graph and world_size == 1 and hasattr(model, "forward_trunk")
         self._side = torch.cuda.Stream(device=self.device) if self.forked else None
         # graph mode: the epoch's loss sum (train_epoch's return value) is accumulated ON THE DEVICE by one add that is part of
