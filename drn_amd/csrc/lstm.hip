@@ -219,6 +219,225 @@ extern "C" int drn_lstm_step_fwd(const float* xproj, const void* Whh_f, const vo
   return drn_launch_status("drn_lstm_step_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------ forward, ALL steps in one launch
+// The fp16-state forward (the bf16 model) as ONE launch: the same (4 hidden units x all clips) workgroups, the same arithmetic in the same
+// order as lstm_step_fwd_kernel<_Float16> -- so the same bits -- but a workgroup stays for the whole sequence, keeps its own c / h in
+// registers, and receives the other workgroups' h through an exchange buffer whose elements carry their own freshness mark: |h| <= 1,
+// so bit 14 of an fp16 h (the top exponent bit) is always 0, and is set to the launch's PARITY instead.  A consumer polls the data
+// itself (one memory round trip per hand-off; the round-2 experiment's store -> drain -> ticket -> poll -> load took four and was no faster
+// than the launches) with write-through 8-byte stores (a clip's four units) and L2-bypassing loads.  Every slot of the buffer is rewritten
+// by every launch (one buffer per (B, L, H)), so stale data always has the other parity; the launch number comes from a counter every
+// workgroup increments once (launch = count / workgroups).  Needs the grid resident at once (256 workgroups of H = 512: checked).
+struct LstmSeqArgs {
+  LstmFwdArgs f;
+  unsigned long long* xch;   // [2][L][B][H / 4] words of four tagged fp16: h after step s of direction d at ((d * L + s) * B + b) * (H / 4) + j / 4
+  unsigned* counter;
+};
+static __device__ int g_lstm_seq_timeouts;
+
+template <int MT, int KU>
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_seq_fwd_kernel(const LstmSeqArgs S) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  __shared__ float red[4][MT][64][4];
+  __shared__ unsigned s_launch;
+  const LstmFwdArgs& A = S.f;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int dir = blockIdx.y, j0 = blockIdx.x * 4;
+  const int B = A.B, L = A.L, H = A.H;
+  // (launch numbers start at 1: a zero-initialised buffer reads as parity 0)
+  if (threadIdx.x == 0) s_launch = __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (gridDim.x * gridDim.y) + 1u;
+  const int e_bb = threadIdx.x >> 2, e_j = j0 + (threadIdx.x & 3);
+  const bool e_own = e_bb < B;
+  const int bq = e_own ? e_bb : 0;
+  float e_bi[4], e_bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    e_bi[g] = A.b_ih[dir][g * H + e_j];
+    e_bh[g] = A.b_hh[dir][g * H + e_j];
+  }
+  const long long e_len = A.lengths[bq];
+  float e_cp = 0.f, e_hp = 0.f;                        // this thread's (clip, unit) state: stays in registers
+  const int kq = H / 4, col = l & 15, kc = (l >> 4) * 8;
+  const long wrow = (long)((col & 3) * H + j0 + (col >> 2)) * H;
+  const float* W = (const float*)A.Whh[dir];
+  __syncthreads();
+  const unsigned long long tagm = (s_launch & 1u) ? 0x4000400040004000ull : 0ull;
+  const long long t0 = wall_clock64();
+  for (int s = 0; s < L; ++s) {
+    const int t = dir == 0 ? s : L - 1 - s;
+    float e_x[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_x[g] = A.xproj[(((long)t * B + bq) * 2 + dir) * 4 * H + g * H + e_j];
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const unsigned long long* hx = S.xch + ((long)(dir * L + s - 1) * B) * (H / 4);
+      // quiet wait: wave 0 looks at ONE word per producing workgroup (clip 0's four units of each of the H / 4 workgroups of this
+      // direction) until all carry this launch's parity; the other waves park at the barrier.  (Every thread polling the 8 + 8
+      // words it needs put 16 MB of L2-bypassing loads per round on the fabric: 7.8 us per step, slower than the launches.)
+      if (w == 0) {
+        bool ready = false;
+        for (;;) {
+          if (!ready) {
+            ready = true;
+            for (int p = l; p < H / 4; p += 64)
+              ready = ready && ((__hip_atomic_load(hx + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x4000400040004000ull) == tagm);
+          }
+          if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
+          __builtin_amdgcn_s_sleep(4);
+          if (wall_clock64() - t0 > 200000000LL) break;        // (the loads below count the timeout)
+        }
+      }
+      __syncthreads();
+      for (int k0 = w * kq; k0 < (w + 1) * kq; k0 += 32 * KU) {
+        unsigned long long alo[KU][MT], ahi[KU][MT];
+        f32x4 blo[KU], bhi[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const int k = k0 + u * 32 + kc;
+          blo[u] = *(const f32x4*)(W + wrow + k);
+          bhi[u] = *(const f32x4*)(W + wrow + k + 4);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int bb = mt * 16 + col;
+            const unsigned long long* q = hx + (long)(bb < B ? bb : 0) * (H / 4) + (k >> 2);
+            alo[u][mt] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ahi[u][mt] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          f16x8 bv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bv[e] = (_Float16)blo[u][e]; bv[4 + e] = (_Float16)bhi[u][e]; }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int bb = mt * 16 + col;
+            const unsigned long long* q = S.xch + ((long)(dir * L + s - 1) * B + (bb < B ? bb : 0)) * (H / 4) + ((k0 + u * 32 + kc) >> 2);
+            while ((alo[u][mt] & 0x4000400040004000ull) != tagm || (ahi[u][mt] & 0x4000400040004000ull) != tagm) {     // not this launch's yet
+              __builtin_amdgcn_s_sleep(2);
+              if (wall_clock64() - t0 > 200000000LL) {          // 2 s of the 100 MHz wall clock: give up (results invalid, counted)
+                __hip_atomic_fetch_add(&g_lstm_seq_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+              alo[u][mt] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ahi[u][mt] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned long long lo = alo[u][mt] & ~0x4000400040004000ull, hi = ahi[u][mt] & ~0x4000400040004000ull;
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            f16x8 av = __builtin_bit_cast(f16x8, (u64x2){lo, hi});
+            if (bb >= B)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) av[e] = (_Float16)0.f;
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[mt], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][mt][l][r] = acc[mt][r];
+    __syncthreads();
+    float h_new = 0.f;
+    if (e_own) {                                        // the statements of lstm_step_fwd_kernel's epilogue
+      const int bb = e_bb, j = e_j;
+      const int mt = bb >> 4, r16 = bb & 15, ln = (r16 >> 2) * 16 + (threadIdx.x & 3) * 4, rg = r16 & 3;
+      float pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v = red[0][mt][ln + g][rg] + red[1][mt][ln + g][rg] + red[2][mt][ln + g][rg] + red[3][mt][ln + g][rg];
+        pre[g] = v + e_x[g] + e_bi[g] + e_bh[g];
+      }
+      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+      const long st_new = ((long)(dir * (L + 1) + s + 1) * B + bb) * H + j;
+      const float cp = e_cp, hp = e_hp;
+      const float cn = fg * cp + ig * gg;
+      const float hn = og * tanhf(cn);
+      const bool valid = t < e_len;
+      e_cp = valid ? cn : cp;
+      e_hp = valid ? hn : hp;
+      h_new = e_hp;
+      A.cseq[st_new] = e_cp;
+      A.hseq[st_new] = e_hp;
+      float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
+      gs[0] = ig; gs[H] = fg; gs[2 * H] = gg; gs[3 * H] = og;
+      A.hprev_t[(((long)t * B + bb) * 2 + dir) * H + j] = hp;
+      A.out[((long)bb * L + t) * 2 * H + dir * H + j] = valid ? hn : 0.f;
+      if (A.qvec) {
+        float* qv = A.qvec + (long)bb * 4 * H + dir * H + j;
+        if (t == 0) qv[0] = valid ? hn : 0.f;
+        if (t == e_len - 1) qv[2 * H] = hn;
+      }
+    }
+    // hand-off: the four units of a clip as ONE tagged 8-byte write-through store (lanes 4q .. 4q + 3 hold them)
+    if (s + 1 < L) {
+      const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)h_new);
+      const unsigned h1 = (unsigned)__shfl_down((int)hb, 1, 64), h2 = (unsigned)__shfl_down((int)hb, 2, 64), h3 = (unsigned)__shfl_down((int)hb, 3, 64);
+      if (e_own && (threadIdx.x & 3) == 0) {
+        const unsigned long long word = ((unsigned long long)hb | ((unsigned long long)h1 << 16) | ((unsigned long long)h2 << 32) | ((unsigned long long)h3 << 48)) | tagm;
+        __hip_atomic_store(S.xch + ((long)(dir * L + s) * B + e_bb) * (H / 4) + (j0 >> 2), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();                                    // red[] is free for the next step
+  }
+}
+
+static int lstm_seq_capacity(const void* kernel) {
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, LSTM_THREADS, 0) != hipSuccess) return 0;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, kernel) != hipSuccess || fa.localSizeBytes > 0) return 0;
+  return per_cu * cus;
+}
+
+extern "C" int64_t drn_lstm_seq_fwd_ws_bytes(int B, int L, int H) { return 64 + (int64_t)2 * L * B * (H / 4) * 8; }
+
+extern "C" int drn_lstm_seq_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, const float* b_ih_f, const float* b_hh_f,
+                                const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out, float* hprev_t,
+                                float* qvec, void* xch_ws, int64_t ws_bytes, const int64_t* lengths, int B, int L, int H, void* stream_) {
+  drn_clear_status();
+  hipStream_t stream = (hipStream_t)stream_;
+  DRN_CHECK_ARG(xproj && Whh_f && Whh_r && b_ih_f && b_hh_f && b_ih_r && b_hh_r && hseq && cseq && gates && out && hprev_t && lengths && xch_ws,
+                "drn_lstm_seq_fwd: null pointer");
+  DRN_CHECK_ARG(B > 0 && B <= 16 * MAX_BT && L > 0 && H % 128 == 0, "drn_lstm_seq_fwd: need B <= 64, H %% 128 == 0");
+  DRN_CHECK_ARG(((uintptr_t)xch_ws & 63) == 0 && ws_bytes >= drn_lstm_seq_fwd_ws_bytes(B, L, H), "drn_lstm_seq_fwd: workspace too small or misaligned");
+  LstmSeqArgs S;
+  LstmFwdArgs& A = S.f;
+  A.hseq16 = nullptr;
+  A.xproj = xproj; A.Whh[0] = Whh_f; A.Whh[1] = Whh_r; A.hseq = hseq; A.cseq = cseq; A.gates = gates; A.out = out;
+  A.hprev_t = hprev_t; A.qvec = qvec; A.b_ih[0] = b_ih_f; A.b_hh[0] = b_hh_f; A.b_ih[1] = b_ih_r; A.b_hh[1] = b_hh_r;
+  A.lengths = (const long long*)lengths; A.B = B; A.L = L; A.H = H; A.s = 0;
+  S.counter = (unsigned*)xch_ws;
+  S.xch = (unsigned long long*)((char*)xch_ws + 64);
+  const int mt = cdiv(B, 16), it = H / 4 / 32;          // iterations per wave
+  const dim3 grid(H / 4, 2);
+  const int total = (H / 4) * 2;
+#define SEQ_CASE(MTV, KUV) do { \
+    static int cap = 0; \
+    if (!cap) cap = lstm_seq_capacity((const void*)lstm_seq_fwd_kernel<MTV, KUV>); \
+    if (total > cap) { drn_set_error("drn_lstm_seq_fwd: %d workgroups exceed the %d the chip holds at once", total, cap); return DRN_ERR_UNSUPPORTED; } \
+    lstm_seq_fwd_kernel<MTV, KUV><<<grid, LSTM_THREADS, 0, stream>>>(S); } while (0)
+#define SEQ_MT(KUV) do { if (mt == 1) SEQ_CASE(1, KUV); else if (mt == 2) SEQ_CASE(2, KUV); else if (mt == 3) SEQ_CASE(3, KUV); else SEQ_CASE(4, KUV); } while (0)
+  if (it % 4 == 0) SEQ_MT(4); else if (it % 2 == 0) SEQ_MT(2); else SEQ_MT(1);
+#undef SEQ_MT
+#undef SEQ_CASE
+  return drn_launch_status("drn_lstm_seq_fwd");
+}
+
+extern "C" int drn_lstm_seq_fwd_timeouts(int reset) {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lstm_seq_timeouts), sizeof(int)) != hipSuccess) return -1;
+  if (reset && v) {
+    const int z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_seq_timeouts), &z, sizeof(int));
+  }
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 struct LstmBwdArgs {
   const float* dout;     // [B][L][2H]

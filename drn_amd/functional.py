@@ -1460,6 +1460,8 @@ def _lstm_forward(emb_tm, lens, lstm_params, B, L, qvec=None, lowp=False):
     whf, whr = w_hh_f.detach().contiguous(), w_hh_r.detach().contiguous()
     # lowp (the bf16 model): the steps keep an fp16 copy of the hidden state and multiply it on the fp16 MFMA (W_hh rounded to fp16 in
     # registers, fp32 accumulation, fp32 states / outputs): 64 KB of operands per workgroup instead of 96
+    if _lstm_lowp(lowp, H) and ops.LSTM_SEQ and L > 1 and ops.lstm_seq_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev, lens, B, L, H, qvec=qvec):
+        return out, (cseq, gates, hprev)             # every step in one launch (same bits)
     hseq16 = torch.empty((2, L + 1, B, H), dtype=torch.float16, device=dev) if _lstm_lowp(lowp, H) else None
     for s in range(L):
         ops.lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev, lens, B, L, H, s, qvec=qvec, hseq16=hseq16)

@@ -866,6 +866,32 @@ def lstm_step_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens
           "drn_lstm_step_fwd")
 
 
+# 1 = the fp16-state BiLSTM forward as ONE launch (drn_lstm_seq_fwd: hidden states handed over between resident workgroups as
+# fp16 words whose spare exponent bit carries the launch parity, one wave polling one word per producer; bit-identical).  Third
+# measurement of the idea, third null: 54.1 us for 8 steps against 8 x 7.3 = 58.4, the step 1.981 vs 1.982 ms -- a hand-off through
+# memory costs ~5 us whatever replaces the kernel boundary (every thread polling its own words: 62.5 us).  Kept, tested, off.
+LSTM_SEQ = os.environ.get("DRN_LSTM_SEQ", "0") != "0"
+
+
+def lstm_seq_fwd(xproj, whf, whr, biases, hseq, cseq, gates, out, hprev_t, lens, B, L, H, qvec=None):
+    """The fp16-state forward recurrence as ONE launch (drn_lstm_seq_fwd; the bits of L lstm_step_fwd launches with hseq16).  Returns
+    False -- nothing launched -- when the grid does not fit the chip at once."""
+    _need_gpu(xproj, out)
+    assert whf.dtype == torch.float32 and whf.is_contiguous() and whr.is_contiguous()
+    nbytes = int(lib().drn_lstm_seq_fwd_ws_bytes(B, L, H))
+    ws = persistent_buffer(("lstm_seq", B, L, H), nbytes // 8, xproj.device, torch.int64)
+    rc = lib().drn_lstm_seq_fwd(_p(xproj), _p(whf), _p(whr), _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(biases[3]), _p(hseq), _p(cseq),
+                                _p(gates), _p(out), _p(hprev_t), _p(qvec), _p(ws), ctypes.c_int64(nbytes), _p(lens), B, L, H, _stream())
+    if rc == DRN_ERR_UNSUPPORTED:
+        return False
+    check(rc, "drn_lstm_seq_fwd")
+    return True
+
+
+def lstm_seq_fwd_timeouts(reset=True):
+    return int(lib().drn_lstm_seq_fwd_timeouts(int(reset)))
+
+
 def lstm_bwd_first(dout, gates, cseq, dgates, dc, dh_pass, lens, B, L, H, dqvec=None, dgates16=None):
     check(lib().drn_lstm_bwd_first(_p(dout), _p(gates), _p(cseq), _p(dgates), _p(dc), _p(dh_pass), _p(dqvec), _p(dgates16), _p(lens), B, L, H,
                                    _stream()), "drn_lstm_bwd_first")

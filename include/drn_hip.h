@@ -534,6 +534,16 @@ int drn_lgp_bwd(const void* x, int ldx, const float* qn, const float* att, const
 int drn_lstm_step_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, int w_dtype, const float* b_ih_f, const float* b_hh_f,
                       const float* b_ih_r, const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out, float* hprev_t,
                       float* qvec, void* hseq16, const int64_t* lengths, int B, int L, int H, int s, void* stream);
+/* The hseq16 forward with ALL steps in ONE launch (the bits of L drn_lstm_step_fwd launches): workgroups stay for the whole sequence and
+ * hand the hidden state over through xch_ws -- 64-byte aligned, >= drn_lstm_seq_fwd_ws_bytes(B, L, H) bytes, ZERO before its first use and
+ * then left to the library (one buffer per (B, L, H); launches on it are stream-ordered).  H % 128 == 0, fp32 W_hh.  DRN_ERR_UNSUPPORTED
+ * (nothing launched) when the grid does not fit the chip at once.  drn_lstm_seq_fwd_timeouts: workgroups that gave up waiting (2 s
+ * watchdog; 0 in a healthy run); synchronises the device. */
+int64_t drn_lstm_seq_fwd_ws_bytes(int B, int L, int H);
+int drn_lstm_seq_fwd(const float* xproj, const void* Whh_f, const void* Whh_r, const float* b_ih_f, const float* b_hh_f, const float* b_ih_r,
+                     const float* b_hh_r, float* hseq, float* cseq, float* gates, float* out, float* hprev_t, float* qvec, void* xch_ws,
+                     int64_t ws_bytes, const int64_t* lengths, int B, int L, int H, void* stream);
+int drn_lstm_seq_fwd_timeouts(int reset);
 /* Backward: drn_lstm_bwd_first does the cell backward of the last step (s = L-1) from dout [B][L][2H] alone; then
  * drn_lstm_step_bwd for s = L-1 .. 1 propagates through W_hh of step s (dgates[t(s)] x Whh) and applies the cell backward
  * of step s-1 in its epilogue (the recurrent dL/dh never goes to memory).  dgates is the operand of the weight-gradient

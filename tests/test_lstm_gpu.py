@@ -139,3 +139,37 @@ def test_padded_time_steps_change_nothing(lowp):
     for r in res[1:]:
         for a, b in zip(res[0], r):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,L,lens", [(32, 8, None), (7, 5, [5, 5, 4, 3, 2, 1, 1]), (40, 3, None), (32, 4, None)])
+def test_forward_in_one_launch_gives_the_bits_of_the_step_launches(monkeypatch, B, L, lens):
+    """drn_lstm_seq_fwd: every step of the fp16-state forward in ONE launch (workgroups stay, hidden states handed over as fp16 words
+    whose spare exponent bit carries the launch parity) -- against L drn_lstm_step_fwd launches: every output bit for bit, over several
+    launches in a row (the parity alternates, stale data of the previous launch must never be taken) and with the sentence vector."""
+    from drn_amd import functional as DF, ops
+    torch.manual_seed(5)
+    dev = "cuda:0"
+    E, H = 300, 512
+    if lens is None:
+        lens = sorted(torch.randint(1, L + 1, (B,)).tolist(), reverse=True)
+        lens[0] = L
+    lengths = torch.tensor(lens, dtype=torch.int64, device=dev)
+    mod = nn.LSTM(E, H, 1, batch_first=True, bidirectional=True).to(dev)
+    params = DF._lstm_param_list(mod)
+
+    def run(seq, emb):
+        monkeypatch.setattr(ops, "LSTM_SEQ", seq)
+        qvec = torch.full((B, 4 * H), float("nan"), device=dev)
+        out, saved = DF._lstm_forward(emb, lengths, params, B, L, qvec=qvec, lowp=True)
+        torch.cuda.synchronize()
+        return [out.clone(), qvec.clone()] + [t.clone() for t in saved]
+    for rep in range(5):                               # five launches on the same exchange buffer, different inputs each time
+        emb = torch.randn(L * B, E, device=dev) * (1.0 + rep)
+        a = run(True, emb)
+        b = run(False, emb)
+        for i, (x, y) in enumerate(zip(a, b)):
+            if i == 2 or i == 3:                       # cseq / gates: slot 0 of cseq is never written by either path
+                x, y = (x[:, 1:], y[:, 1:]) if i == 2 else (x, y)
+            assert torch.equal(x, y), "rep %d tensor %d: max |d| = %g" % (rep, i, float((x - y).abs().max()))
+    assert ops.lstm_seq_fwd_timeouts() == 0
+    assert any(k[0][0] == "lstm_seq" for k in ops._persistent if isinstance(k[0], tuple)), "the one-launch path did not run"
