@@ -90,7 +90,8 @@ class BnTrainDesc(ctypes.Structure):
 class BnBwdDesc(ctypes.Structure):
     _fields_ = [("dout", c_void_p), ("raw", c_void_p), ("scale_shift", c_void_p), ("save", c_void_p), ("gamma", c_void_p),
                 ("draw", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("ld_dout", c_int32), ("ld_raw", c_int32),
-                ("ld_draw", c_int32), ("accumulate", c_int32), ("M", c_int32)]
+                ("ld_draw", c_int32), ("accumulate", c_int32), ("M", c_int32),
+                ("gb_dg", c_void_p), ("gb_gate", c_void_p), ("gb_dgate", c_void_p), ("gb_ld_dg", c_int32), ("gb_ldg", c_int32), ("gb_L", c_int32)]
 
 
 class HeadGroup(ctypes.Structure):

@@ -1008,6 +1008,12 @@ struct BnBwd1Lv {
   unsigned long long* pairs;   // [rb][2][C] tagged
   unsigned long long* totals;  // [2][C] tagged: (dgamma, dbeta) contribution of this level
   int ld_dout, ld_raw, ld_draw, M, accumulate, rb, blk0;
+  // GB launches (DrnBnBwdDesc::gb_*): this layer's output was gated by the query (model/backbone.py:28-30); the gradient of the GATED
+  // output arrives in dg, dout (or NULL) is the gradient of the un-gated one
+  const void* dg;
+  const float* gate;
+  float* dgate;
+  int ld_dg, ldg, L;
 };
 struct BnBwd1Params {
   BnBwd1Lv lv[DRN_MAX_GROUPS];
@@ -1076,7 +1082,19 @@ __device__ __forceinline__ void bn_bwd_wait_sum64(const unsigned long long* __re
   __syncthreads();
 }
 
-template <typename T, int NP>
+template <typename T>
+__device__ __forceinline__ typename V16<T>::raw_t bn_pack_raw(const float (&v)[V16<T>::N]) {
+  typename V16<T>::raw_t r;
+#pragma unroll
+  for (int e = 0; e < V16<T>::N; ++e) r[e] = (T)v[e];
+  return r;
+}
+
+// GB: the query-gate backward of this layer (drn_gate_bwd's arithmetic, statement for statement) runs on the rows as they arrive --
+// dout_eff = T(dout + dg * gate[clip]) replaces the loaded gradient in registers, dgate[clip][c] = sum_t dg * act with the layer's
+// activation recomputed from raw (what bn_train_apply stored: T(relu(raw * scale + shift))) -- and drn_gate_bwd's launch, the write of
+// its result and its re-read are gone.  Clips must lie inside one workgroup's rows (ROWS % L == 0) and passes inside one clip (L % RP == 0).
+template <typename T, int NP, bool GB = false>
 __global__ __launch_bounds__(256, 2) void bn_bwd_one_kernel(const BnBwd1Params P) {
   constexpr int N = V16<T>::N, NV = 64 / N, RP = 256 / NV, ROWS = NP * RP;
   __shared__ float red[2][RP][65];
@@ -1100,13 +1118,70 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_one_kernel(const BnBwd1Params P
   const long ldd = G.ld_dout, ldr = G.ld_raw, ldw = G.ld_draw;
   const int row0 = rblk * ROWS + ry;
   typename V16<T>::raw_t gr[NP], xr[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {                       // everything this workgroup will ever read, in flight at once
-    const int m = min(row0 + p * RP, M - 1);           // clamped index, masked use
-    gr[p] = V16<T>::ldraw(dout + (long)m * ldd + c0);
-    xr[p] = V16<T>::ldraw(raw + (long)m * ldr + c0);
-  }
   float sc[N], sh[N];
+  if constexpr (GB) {
+    const T* __restrict__ dg = (const T*)G.dg;
+    const long ldg_rows = G.ld_dg;
+    typename V16<T>::raw_t ar[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int m = min(row0 + p * RP, M - 1);
+      gr[p] = V16<T>::ldraw(dg + (long)m * ldg_rows + c0);
+      ar[p] = dout ? V16<T>::ldraw(dout + (long)m * ldd + c0) : gr[p];
+      xr[p] = V16<T>::ldraw(raw + (long)m * ldr + c0);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      sc[k] = G.ss[c0 + k];
+      sh[k] = G.ss[C + c0 + k];
+    }
+    const int L = G.L, nclip = ROWS / L;
+    for (int q = 0; q < nclip; ++q) {                   // the clips of this row block, one after the other (workgroup-uniform)
+      const int sq = rblk * nclip + q;
+      if ((long)sq * L >= M) break;
+      float gt[N], dacc[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        gt[k] = G.gate[(long)sq * G.ldg + c0 + k];
+        dacc[k] = 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if ((p * RP) / L != q) continue;
+        const bool in = row0 + p * RP < M;
+        float g[N], x[N], a[N];
+        V16<T>::cvt(gr[p], g);
+        V16<T>::cvt(xr[p], x);
+        V16<T>::cvt(ar[p], a);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          float y = fmaf(x[k], sc[k], sh[k]);
+          y = DT<T>::round(relu ? fmaxf(y, 0.f) : y);
+          if (in) dacc[k] = fmaf(g[k], y, dacc[k]);
+          a[k] = dout ? fmaf(g[k], gt[k], a[k]) : g[k] * gt[k];
+        }
+        gr[p] = bn_pack_raw<T>(a);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) red[0][ry][v * N + k] = dacc[k];
+      __syncthreads();
+      if (tid < 64) {
+        float a0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < RP; ++r) a0 += red[0][r][tid];
+        G.dgate[(long)sq * C + cbase + tid] = a0;
+      }
+      __syncthreads();
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {                       // everything this workgroup will ever read, in flight at once
+      const int m = min(row0 + p * RP, M - 1);           // clamped index, masked use
+      gr[p] = V16<T>::ldraw(dout + (long)m * ldd + c0);
+      xr[p] = V16<T>::ldraw(raw + (long)m * ldr + c0);
+    }
+  }
   {
     float mean[N], istd[N], sg[N], sx[N];
 #pragma unroll
@@ -1266,6 +1341,15 @@ static long bn_bwd_one_grid(const DrnBnBwdDesc* d, int n, int ctiles, int rows, 
   }
   return total;
 }
+// gated levels (gb_dg): clips inside one workgroup's rows, passes inside one clip, at most 8 passes (the prologue holds a third row set)
+static bool bn_bwd_one_gb_ok(const DrnBnBwdDesc* d, int n, int rows, int RP, int idx) {
+  for (int i = 0; i < n; ++i) {
+    if (!d[i].gb_dg) continue;
+    const int L = d[i].gb_L;
+    if (idx > 2 || L <= 0 || rows % L != 0 || L % RP != 0 || d[i].M % L != 0) return false;
+  }
+  return true;
+}
 static int bn_bwd_one_plan(const DrnBnBwdDesc* d, int n, int C, int dtype, int* total_out) {
   if (C % 64 != 0 || n < 1 || n > DRN_MAX_GROUPS) return -1;
   const int max_wg = drn_tuning(DRN_TUNE_BN1_MAXWG);
@@ -1273,11 +1357,15 @@ static int bn_bwd_one_plan(const DrnBnBwdDesc* d, int n, int C, int dtype, int* 
   for (int idx = 0; idx < 4; ++idx) {
     int rbmax = 0;
     long total = bn_bwd_one_grid(d, n, ctiles, (2 << idx) * RP, &rbmax);
+    const bool ok = bn_bwd_one_gb_ok(d, n, (2 << idx) * RP, RP, idx);
     if (rbmax <= 64 && total <= max_wg) {
       if (idx < 3) {
         int rb2 = 0;
         const long t2 = bn_bwd_one_grid(d, n, ctiles, (4 << idx) * RP, &rb2);
-        if (t2 >= 256) { ++idx; total = t2; }
+        if ((t2 >= 256 || !ok) && bn_bwd_one_gb_ok(d, n, (4 << idx) * RP, RP, idx + 1)) { ++idx; total = t2; }
+        else if (!ok) continue;
+      } else if (!ok) {
+        continue;
       }
       if (total_out) *total_out = (int)total;
       return idx;
@@ -1311,14 +1399,19 @@ extern "C" int drn_bn_bwd_one(const DrnBnBwdDesc* d, int n, int C, int relu, voi
   P.gen_word = (int*)tagged_ws;
   unsigned long long* pairs = (unsigned long long*)((char*)tagged_ws + 64);
   int blk = 0;
+  bool gated = false, all_gated = true;
   for (int i = 0; i < n; ++i) {
     const DrnBnBwdDesc& s = d[i];
-    DRN_CHECK_ARG(s.dout && s.raw && s.scale_shift && s.save && s.gamma && s.draw && s.M > 0, "%s: bad level %d", who, i);
+    DRN_CHECK_ARG((s.dout || s.gb_dg) && s.raw && s.scale_shift && s.save && s.gamma && s.draw && s.M > 0, "%s: bad level %d", who, i);
     DRN_CHECK_ARG(s.ld_dout % vn == 0 && s.ld_raw % vn == 0 && s.ld_draw % vn == 0, "%s: ld must be 16-byte multiples", who);
     BnBwd1Lv& G = P.lv[i];
     G.dout = s.dout; G.raw = s.raw; G.draw = s.draw; G.ss = s.scale_shift; G.save = s.save; G.gamma = s.gamma;
     G.dgamma = s.dgamma; G.dbeta = s.dbeta; G.ld_dout = s.ld_dout; G.ld_raw = s.ld_raw; G.ld_draw = s.ld_draw; G.M = s.M;
     G.accumulate = s.accumulate;
+    G.dg = s.gb_dg; G.gate = s.gb_gate; G.dgate = s.gb_dgate; G.ld_dg = s.gb_ld_dg; G.ldg = s.gb_ldg; G.L = s.gb_L;
+    gated = gated || s.gb_dg != nullptr;
+    all_gated = all_gated && s.gb_dg != nullptr;
+    DRN_CHECK_ARG(!s.gb_dg || (s.gb_gate && s.gb_dgate && s.gb_ld_dg % vn == 0 && s.gb_ldg >= C), "%s: level %d: gb_* incomplete", who, i);
     G.rb = cdiv(s.M, rows);
     G.pairs = pairs + (long)i * 65 * 2 * C;
     G.totals = G.pairs + (long)64 * 2 * C;
@@ -1327,16 +1420,27 @@ extern "C" int drn_bn_bwd_one(const DrnBnBwdDesc* d, int n, int C, int relu, voi
   }
   static int capacity[2][4];
   int& cap = capacity[dtype == DRN_BF16][idx];
+  DRN_CHECK_ARG(!gated || all_gated, "%s: gated and plain levels do not mix in one launch", who);
+  static int capacity_gb[2][3];
 #define BN1_CASE(TT, NPV) do { \
     if (!cap) cap = bn_resident_capacity(bn_bwd_one_kernel<TT, NPV>); \
     if (total > cap) { drn_set_error("%s: %d workgroups exceed the %d the chip holds at once", who, total, cap); return DRN_ERR_UNSUPPORTED; } \
     bn_bwd_one_kernel<TT, NPV><<<total, 256, 0, stream>>>(P); } while (0)
-  if (dtype == DRN_BF16) {
+#define BN1_CASE_GB(TT, NPV) do { \
+    int& capg = capacity_gb[dtype == DRN_BF16][idx]; \
+    if (!capg) capg = bn_resident_capacity(bn_bwd_one_kernel<TT, NPV, true>); \
+    if (total > capg) { drn_set_error("%s: %d workgroups exceed the %d the chip holds at once", who, total, capg); return DRN_ERR_UNSUPPORTED; } \
+    bn_bwd_one_kernel<TT, NPV, true><<<total, 256, 0, stream>>>(P); } while (0)
+  if (gated) {
+    if (dtype == DRN_BF16) { switch (idx) { case 0: BN1_CASE_GB(bf16_t, 2); break; case 1: BN1_CASE_GB(bf16_t, 4); break; default: BN1_CASE_GB(bf16_t, 8); } }
+    else { switch (idx) { case 0: BN1_CASE_GB(float, 2); break; case 1: BN1_CASE_GB(float, 4); break; default: BN1_CASE_GB(float, 8); } }
+  } else if (dtype == DRN_BF16) {
     switch (idx) { case 0: BN1_CASE(bf16_t, 2); break; case 1: BN1_CASE(bf16_t, 4); break; case 2: BN1_CASE(bf16_t, 8); break; default: BN1_CASE(bf16_t, 16); }
   } else {
     switch (idx) { case 0: BN1_CASE(float, 2); break; case 1: BN1_CASE(float, 4); break; case 2: BN1_CASE(float, 8); break; default: BN1_CASE(float, 16); }
   }
 #undef BN1_CASE
+#undef BN1_CASE_GB
   return drn_launch_status(who);
 }
 
@@ -1356,6 +1460,7 @@ extern "C" int drn_bn_bwd_one_timeouts(int reset) {
 static int bn_bwd_launch(const DrnBnBwdDesc* d, int n, int C, int relu, float* ws, int dtype, void* stream_, const char* who) {
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(d && n >= 1 && n <= DRN_MAX_GROUPS && C > 0 && ws, "%s: bad args", who);
+  for (int i = 0; i < n; ++i) DRN_CHECK_ARG(!d[i].gb_dg, "%s: DrnBnBwdDesc::gb_* is drn_bn_bwd_one's (run drn_gate_bwd first)", who);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "%s: bad dtype %d", who, dtype);
   const int vn = dtype == DRN_BF16 ? 8 : 4;
   DRN_CHECK_ARG(C % vn == 0, "%s: C must be a 16-byte multiple", who);
@@ -1407,5 +1512,6 @@ extern "C" int drn_bn_bwd(const void* dout, int ld_dout, const void* raw, int ld
   DrnBnBwdDesc d;
   d.dout = dout; d.ld_dout = ld_dout; d.raw = raw; d.ld_raw = ld_raw; d.scale_shift = scale_shift; d.save = save; d.gamma = gamma;
   d.draw = draw; d.ld_draw = ld_draw; d.dgamma = dgamma; d.dbeta = dbeta; d.accumulate = accumulate; d.M = M;
+  d.gb_dg = nullptr; d.gb_gate = nullptr; d.gb_dgate = nullptr; d.gb_ld_dg = d.gb_ldg = d.gb_L = 0;
   return bn_bwd_launch(&d, 1, C, relu, ws, dtype, stream, "drn_bn_bwd");
 }

@@ -751,22 +751,28 @@ class _ConvBlockFn(torch.autograd.Function):
         for l in range(nl):
             B, L, Lo, M, ld = geo[l]
             d = _grad_nlc(gouts[l], None, dt)
+            gb = None
             if ctx.has_gate:
                 dG = _grad_nlc(gouts[nl], None, dt)
                 if dG is not None:
                     dgate = torch.empty((B, Cout), dtype=torch.float32, device=dev)
-                    add, d = d, torch.empty((B, Lo, Cout), dtype=dt, device=dev)
-                    ops.gate_bwd(dG, Cout, outs[l], Cout, gate, d, Cout, add, Cout, dgate, B, Lo, Cout, code)
+                    if GATE_BN_FUSE and not ctx.has_up and nl == 1:
+                        # the gate backward rides in the BatchNorm backward launch (DrnBnBwdDesc::gb_*; ops.bn_bwd_multi runs it as a
+                        # launch of its own where that kernel cannot take it)
+                        gb = dict(dg=dG, ld_dg=Cout, gate=gate, ldg=gate.stride(0), dgate=dgate, L=Lo, act=outs[l], ld_act=Cout)
+                    else:
+                        add, d = d, torch.empty((B, Lo, Cout), dtype=dt, device=dev)
+                        ops.gate_bwd(dG, Cout, outs[l], Cout, gate, d, Cout, add, Cout, dgate, B, Lo, Cout, code)
                 else:
                     dgate = torch.zeros((B, Cout), dtype=torch.float32, device=dev)
-            if d is None:
+            if d is None and gb is None:
                 d = torch.zeros((B, Lo, Cout), dtype=dt, device=dev)
             if ctx.has_up:
                 dup = torch.empty((B, Lo // 2, Cout), dtype=dt, device=dev)
                 ops.pairsum_add(dup, Cout, d, Cout, B * (Lo // 2), Cout, code, accumulate=False)
             draw = torch.empty((B, Lo, Cout), dtype=dt, device=dev)
             blevels.append(dict(dout=d, ld_dout=Cout, raw=raws[l], ld_raw=Cout, ss=sss[l], save=saves[l], gamma=gamma, draw=draw,
-                                ld_draw=Cout, dgamma=dgamma, dbeta=dbeta, accumulate=l > 0, M=M))
+                                ld_draw=Cout, dgamma=dgamma, dbeta=dbeta, accumulate=l > 0, M=M, gb=gb))
             draws.append(draw)
         ops.bn_bwd_multi(blevels, Cout, code, relu=meta.relu)             # reduce / finalize / apply once for all levels
         dW = grad_buffer(ctx.weight_obj if getattr(ctx.weight_obj, "_drn_stack_of", None) else weight)
@@ -1137,6 +1143,7 @@ def _fc_kernel_kind(B, T, D, N, xc, wfc, code, split_gate):
     return ops.gemm_nt_plan([d], code)
 
 
+GATE_BN_FUSE = os.environ.get("DRN_GATE_BN_FUSE", "1") != "0"        # (experiment switch: 0 = drn_gate_bwd in front of the BatchNorm backward)
 GATE_BWD_FUSE = os.environ.get("DRN_GATE_BWD_FUSE", "1") != "0"      # (experiment switch: 0 = drn_gate_bwd_t as a launch of its own)
 
 

@@ -690,11 +690,32 @@ _bn1_maxwg = os.environ.get("DRN_BN1_MAXWG")                  # (experiment swit
 
 def bn_bwd_multi(levels, C, dtype, relu=True):
     """levels: list of dicts(dout, ld_dout, raw, ld_raw, ss, save, gamma, draw, ld_draw, dgamma, dbeta, accumulate, M)."""
-    arr = (_lib.BnBwdDesc * len(levels))()
-    for d, v in zip(arr, levels):
-        d.dout, d.raw, d.scale_shift, d.save, d.gamma = _p(v["dout"]), _p(v["raw"]), _p(v["ss"]), _p(v["save"]), _p(v["gamma"])
-        d.draw, d.dgamma, d.dbeta = _p(v["draw"]), _p(v["dgamma"]), _p(v["dbeta"])
-        d.ld_dout, d.ld_raw, d.ld_draw, d.accumulate, d.M = v["ld_dout"], v["ld_raw"], v["ld_draw"], int(v["accumulate"]), v["M"]
+    def fill(with_gb):
+        arr = (_lib.BnBwdDesc * len(levels))()
+        for d, v in zip(arr, levels):
+            d.dout, d.raw, d.scale_shift, d.save, d.gamma = _p(v["dout"]), _p(v["raw"]), _p(v["ss"]), _p(v["save"]), _p(v["gamma"])
+            d.draw, d.dgamma, d.dbeta = _p(v["draw"]), _p(v["dgamma"]), _p(v["dbeta"])
+            d.ld_dout, d.ld_raw, d.ld_draw, d.accumulate, d.M = v["ld_dout"], v["ld_raw"], v["ld_draw"], int(v["accumulate"]), v["M"]
+            gb = v.get("gb") if with_gb else None
+            if gb is not None:
+                d.gb_dg, d.gb_gate, d.gb_dgate = _p(gb["dg"]), _p(gb["gate"]), _p(gb["dgate"])
+                d.gb_ld_dg, d.gb_ldg, d.gb_L = gb["ld_dg"], gb["ldg"], gb["L"]
+        return arr
+
+    def ungate():
+        # the query-gate backward as launches of its own (drn_gate_bwd) for the levels that asked for it inside the BatchNorm launch
+        for v in levels:
+            gb = v.get("gb")
+            if gb is not None:
+                C_ = C
+                d_new = torch.empty_like(gb["dg"]) if v["dout"] is None else torch.empty_like(v["dout"])
+                gate_bwd(gb["dg"], gb["ld_dg"], gb["act"], gb["ld_act"], gb["gate"], d_new, C_, v["dout"], v["ld_dout"], gb["dgate"],
+                         v["M"] // gb["L"], gb["L"], C_, dtype)
+                v["dout"], v["ld_dout"] = d_new, C_
+                v["gb"] = None
+
+    has_gb = any(v.get("gb") is not None for v in levels)
+    arr = fill(has_gb)
     global _bn1_maxwg
     if _bn1_maxwg:
         lib().drn_tune(b"bn1_maxwg", int(_bn1_maxwg))
@@ -703,12 +724,20 @@ def bn_bwd_multi(levels, C, dtype, relu=True):
         # one launch when the grid fits the chip at once (drn_bn_bwd_one): the tagged-pair workspace is zero at birth and keeps the
         # launch generation afterwards -- one buffer per size, launches on it are stream-ordered
         nbytes = int(lib().drn_bn_bwd_one_ws_bytes(arr, len(levels), C, dtype))
+        if nbytes == 0 and has_gb:            # not with the gate backward inside: that one as its own launch, then ask again
+            ungate()
+            has_gb = False
+            arr = fill(False)
+            nbytes = int(lib().drn_bn_bwd_one_ws_bytes(arr, len(levels), C, dtype))
         if nbytes > 0:
             tws = persistent_buffer("bn_bwd_one", nbytes // 8, levels[0]["draw"].device, torch.int64)
             rc = lib().drn_bn_bwd_one(arr, len(levels), C, int(relu), _p(tws), ctypes.c_int64(nbytes), dtype, _stream())
             if rc != DRN_ERR_UNSUPPORTED:
                 check(rc, "drn_bn_bwd_one")
                 return
+    if has_gb:
+        ungate()
+        arr = fill(False)
     ws = workspace(len(levels) * 515 * C, levels[0]["draw"].device)
     check(lib().drn_bn_bwd_multi(arr, len(levels), C, int(relu), _p(ws), dtype, _stream()), "drn_bn_bwd_multi")
 

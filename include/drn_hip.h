@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 7
+#define DRN_ABI_VERSION 8
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
@@ -334,6 +334,16 @@ typedef struct DrnBnBwdDesc {
   float* dgamma;
   float* dbeta;
   int32_t ld_dout, ld_raw, ld_draw, accumulate, M;
+  /* drn_bn_bwd_one only.  gb_dg != NULL: the layer's output was also consumed GATED by the query (model/backbone.py:28-30,
+   * gated = out * gate[clip]); gb_dg [M][gb_ld_dg] is the gradient of the gated output, dout (or NULL) the gradient of the plain one.
+   * The launch does drn_gate_bwd's work on the rows it loads: dout_eff = dtype(dout + gb_dg * gb_gate[m / gb_L]) feeds the BatchNorm
+   * backward (bit-identical to the two launches), gb_dgate[clip][c] ([M / gb_L][C] fp32) = sum_t gb_dg * out with `out` recomputed from
+   * raw.  Needs gb_L a multiple of 32 rows (bf16; 16 in fp32) that divides the launch's row block: drn_bn_bwd_one_ws_bytes() says 0
+   * otherwise, and the caller runs drn_gate_bwd itself. */
+  const void* gb_dg;
+  const float* gb_gate;
+  float* gb_dgate;
+  int32_t gb_ld_dg, gb_ldg, gb_L;
 } DrnBnBwdDesc;
 int drn_bn_bwd_multi(const DrnBnBwdDesc* descs /*host*/, int n, int C, int relu, float* ws, int dtype, void* stream);
 /* The same in ONE launch: every workgroup keeps its rows of dout and raw in registers between the sums and the apply half and

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20, names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.drn_abi_version() == 7
+    assert lib.drn_abi_version() == 8
     assert lib.drn_last_error() is not None
 
 

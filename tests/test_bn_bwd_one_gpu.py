@@ -191,3 +191,52 @@ def test_training_step_gradients_agree_with_the_two_launch_path():
     for n in grads[0]:
         a, b = grads[0][n].double(), grads[1][n].double()
         assert float((a - b).norm()) <= 2e-2 * max(float(b.norm()), 1e-6), n
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,L,C,with_add", [(32, 128, 512, True), (32, 64, 1024, True), (32, 256, 256, True), (8, 32, 128, False),
+                                            (4, 48, 64, True), (32, 128, 512, False)])
+def test_query_gate_backward_inside_the_batchnorm_launch(dt, B, L, C, with_add):
+    """DrnBnBwdDesc::gb_*: drn_gate_bwd's work (model/backbone.py:28-30 backward: dout = add + dG * gate[clip], dgate = sum_t dG * out)
+    done by drn_bn_bwd_one on the rows it loads -- against the two launches: the BatchNorm input gradient bit for bit when both use
+    the same row blocks, everything else to rounding; clips of one / two / half a row block, with and without the un-gated gradient,
+    and a clip length the kernel cannot take (48 rows: ops.bn_bwd_multi then launches drn_gate_bwd itself)."""
+    from drn_amd import ops
+    code = ops.BF16 if dt == torch.bfloat16 else ops.F32
+    M = B * L
+    lv = _levels((M,), C, dt, seed=11)[0]
+    raw, ss, save, gamma = lv["raw"], lv["ss"], lv["save"], lv["gamma"]
+    dG = rnd(M, C, seed=21).to(DEV).to(dt)
+    add = rnd(M, C, seed=22).to(DEV).to(dt) if with_add else None
+    gate = (rnd(B, C, seed=23) * 0.5 + 1.0).to(DEV)
+
+    def run(fused):
+        dgate = torch.full((B, C), float("nan"), device=DEV)
+        dgamma, dbeta = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        draw = torch.empty((M, C), device=DEV, dtype=dt)
+        if fused:
+            level = dict(dout=add, ld_dout=C, raw=raw, ld_raw=C, ss=ss, save=save, gamma=gamma, draw=draw, ld_draw=C, dgamma=dgamma,
+                         dbeta=dbeta, accumulate=False, M=M,
+                         gb=dict(dg=dG, ld_dg=C, gate=gate, ldg=C, dgate=dgate, L=L, act=act_lib, ld_act=C))
+        else:
+            d = torch.empty((M, C), device=DEV, dtype=dt)
+            ops.gate_bwd(dG, C, act_lib, C, gate, d, C, add, C, dgate, B, L, C, code)
+            level = dict(dout=d, ld_dout=C, raw=raw, ld_raw=C, ss=ss, save=save, gamma=gamma, draw=draw, ld_draw=C, dgamma=dgamma,
+                         dbeta=dbeta, accumulate=False, M=M)
+        ops.bn_bwd_multi([level], C, code, relu=True)
+        torch.cuda.synchronize()
+        return draw, dgate, dgamma, dbeta
+    # the stored activation, produced the way the forward does: relu(fma(raw, scale, shift)) rounded to dt -- through drn_bn_apply
+    act_lib = torch.empty((M, C), device=DEV, dtype=dt)
+    ops.bn_apply(raw, C, ss, act_lib, C, M, C, L, code, relu=True)
+    a = run(True)
+    b = run(False)
+    assert ops.bn_bwd_one_timeouts() == 0
+    scale = max(1.0, float(b[0].float().abs().max()))
+    tol = 2.0 ** -7 if dt == torch.bfloat16 else 2e-5
+    assert float((a[0].float() - b[0].float()).abs().max()) <= tol * scale, "draw"
+    ref = (dG.double() * act_lib.double()).view(B, L, C).sum(1)
+    assert float((a[1].double() - ref).abs().max()) <= 3e-5 * max(1.0, float(ref.abs().max())) * max(1.0, L ** 0.5 / 4), "dgate vs fp64"
+    assert float((a[1] - b[1]).abs().max()) <= 3e-5 * max(1.0, float(ref.abs().max())) * max(1.0, L ** 0.5 / 4)
+    for x, y in zip(a[2:], b[2:]):
+        assert float((x - y).abs().max()) <= 3e-5 * max(1.0, float(y.abs().max())) * max(1.0, M ** 0.5 / 16)
