@@ -1126,9 +1126,9 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_one_kernel(const BnBwd1Params P
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int m = min(row0 + p * RP, M - 1);
-      gr[p] = V16<T>::ldraw(dg + (long)m * ldg_rows + c0);
-      ar[p] = dout ? V16<T>::ldraw(dout + (long)m * ldd + c0) : gr[p];
-      xr[p] = V16<T>::ldraw(raw + (long)m * ldr + c0);
+      gr[p] = V16<T>::ldraw_nt(dg + (long)m * ldg_rows + c0);
+      ar[p] = dout ? V16<T>::ldraw_nt(dout + (long)m * ldd + c0) : gr[p];
+      xr[p] = V16<T>::ldraw_nt(raw + (long)m * ldr + c0);
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -1178,8 +1178,8 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_one_kernel(const BnBwd1Params P
 #pragma unroll
     for (int p = 0; p < NP; ++p) {                       // everything this workgroup will ever read, in flight at once
       const int m = min(row0 + p * RP, M - 1);           // clamped index, masked use
-      gr[p] = V16<T>::ldraw(dout + (long)m * ldd + c0);
-      xr[p] = V16<T>::ldraw(raw + (long)m * ldr + c0);
+      gr[p] = V16<T>::ldraw_nt(dout + (long)m * ldd + c0);          // (the gradient and the raw conv output: last readers)
+      xr[p] = V16<T>::ldraw_nt(raw + (long)m * ldr + c0);
     }
   }
   {

@@ -127,8 +127,8 @@ __device__ __forceinline__ void cast_transpose_tile(const float* __restrict__ in
     const int m = m0 + mm[u], k = k0 + kk[u];
     const bool ok = m < M && k < K;                         // K % 8 == 0 (checked by the host)
     const float* src = in + (long)m * K + k;
-    v[u][0] = ok ? *(const f32x4*)src : (f32x4){0.f, 0.f, 0.f, 0.f};
-    v[u][1] = ok ? *(const f32x4*)(src + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    v[u][0] = ok ? __builtin_nontemporal_load((const f32x4*)src) : (f32x4){0.f, 0.f, 0.f, 0.f};          // (the fp32 features are read once)
+    v[u][1] = ok ? __builtin_nontemporal_load((const f32x4*)(src + 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -150,7 +150,8 @@ __device__ __forceinline__ void cast_transpose_tile(const float* __restrict__ in
   for (int q = threadIdx.x; q < TK * CPR; q += NT) {
     const int r = q / CPR, cv = q % CPR;
     const int k = k0 + r, m = m0 + cv * VN;
-    if (k < K && m < M) *(uint4*)(outT + (long)k * M + m) = *(const uint4*)&tile[r][((cv ^ (r >> 3)) & (CPR - 1)) * VN];
+    if (k < K && m < M)        // (the transposed copy is read ~1.5 ms later, by prop_fc's weight gradient: keep it out of the caches now)
+      __builtin_nontemporal_store(*(const f32x4*)&tile[r][((cv ^ (r >> 3)) & (CPR - 1)) * VN], (f32x4*)(outT + (long)k * M + m));
   }
 }
 extern "C" int drn_cast_transpose_throttled(const float* in, void* out, void* outT, int M, int K, int dtype, int max_workgroups, void* stream) {

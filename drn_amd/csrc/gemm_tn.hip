@@ -790,9 +790,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendPa
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
       for (int z = 0; z < nsplit; ++z) {
-        s0 += p[(long)z * total];
-        s1 += p[(long)z * total + Cin];
-        s2 += p[(long)z * total + 2 * Cin];
+        s0 += __builtin_nontemporal_load(p + (long)z * total);          // (partials are read once)
+        s1 += __builtin_nontemporal_load(p + (long)z * total + Cin);
+        s2 += __builtin_nontemporal_load(p + (long)z * total + 2 * Cin);
       }
       float* o = out + n * KW + (long)c * 3;
       if (accumulate) {
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendPa
   } else {
     for (long idx = (long)b * 256 + threadIdx.x; idx < total; idx += (long)nb * 256) {
       float s = 0.f;
-      for (int z = 0; z < nsplit; ++z) s += ws[(long)z * total + idx];
+      for (int z = 0; z < nsplit; ++z) s += __builtin_nontemporal_load(ws + (long)z * total + idx);
       long o = idx;
       if (w_layout == 1) {
         const long n = idx / KW;

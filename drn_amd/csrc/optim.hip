@@ -11,6 +11,12 @@
 //      (bias-corrected, eps outside the sqrt, no weight decay).
 #include "common.h"
 #include "../../include/drn_hip.h"
+#ifndef OPT_NT_TP
+#define OPT_NT_TP 1
+#endif
+#ifndef OPT_NT
+#define OPT_NT 1      // Adam moments: read once and written once per step -- non-temporal accesses (experiment: -DOPT_NT=0)
+#endif
 
 #define OPT_THREADS 256
 #define OPT_ELEMS_PER_BLOCK 4096
@@ -253,9 +259,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
       for (int t4 = 0; t4 < 4; ++t4) {
         const int i = threadIdx.x * 4 + t4 * OPT_THREADS * 4;
         g4[t4] = *(const f32x4*)(A.g + base + i);
-        m4[t4] = *(const f32x4*)(A.m + base + i);
-        v4[t4] = *(const f32x4*)(A.v + base + i);
-        p4[t4] = *(const f32x4*)(p + i);
+        m4[t4] = OPT_NT ? __builtin_nontemporal_load((const f32x4*)(A.m + base + i)) : *(const f32x4*)(A.m + base + i);
+        v4[t4] = OPT_NT ? __builtin_nontemporal_load((const f32x4*)(A.v + base + i)) : *(const f32x4*)(A.v + base + i);
+        p4[t4] = (OPT_NT && mp) ? __builtin_nontemporal_load((const f32x4*)(p + i)) : *(const f32x4*)(p + i);      // (a parameter with a bf16 copy is read by Adam only)
       }
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) {
@@ -267,9 +273,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
           v4[t4][e] = A.beta2 * v4[t4][e] + (1.f - A.beta2) * g * g;
           p4[t4][e] -= step_size * m4[t4][e] / (sqrtf(v4[t4][e]) * inv_sqrt_bc2 + A.eps);
         }
-        *(f32x4*)(A.m + base + i) = m4[t4];
-        *(f32x4*)(A.v + base + i) = v4[t4];
-        *(f32x4*)(p + i) = p4[t4];
+        if (OPT_NT) { __builtin_nontemporal_store(m4[t4], (f32x4*)(A.m + base + i)); __builtin_nontemporal_store(v4[t4], (f32x4*)(A.v + base + i)); }
+        else { *(f32x4*)(A.m + base + i) = m4[t4]; *(f32x4*)(A.v + base + i) = v4[t4]; }
+        if (OPT_NT && mp) __builtin_nontemporal_store(p4[t4], (f32x4*)(p + i)); else *(f32x4*)(p + i) = p4[t4];
         if (mp) {                                   // the GEMM's bf16 operand, refreshed in the same pass
           bf16x4 b;
 #pragma unroll
@@ -437,9 +443,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
         e0[u] = q < nq ? tbase + (long)r * S + c4 : -1;
         if (e0[u] >= 0) {
           g4[u] = *(const f32x4*)(G + it.off + e0[u]);
-          m4[u] = *(const f32x4*)(Mo + it.off + e0[u]);
-          v4[u] = *(const f32x4*)(Vo + it.off + e0[u]);
-          p4[u] = *(const f32x4*)(it.p + e0[u]);
+          m4[u] = OPT_NT ? __builtin_nontemporal_load((const f32x4*)(Mo + it.off + e0[u])) : *(const f32x4*)(Mo + it.off + e0[u]);
+          v4[u] = OPT_NT ? __builtin_nontemporal_load((const f32x4*)(Vo + it.off + e0[u])) : *(const f32x4*)(Vo + it.off + e0[u]);
+          p4[u] = OPT_NT_TP ? __builtin_nontemporal_load((const f32x4*)(it.p + e0[u])) : *(const f32x4*)(it.p + e0[u]);
         }
       }
 #pragma unroll
@@ -455,9 +461,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
           p4[u][e] -= step_size * m4[u][e] / (sqrtf(v4[u][e]) * inv_sqrt_bc2 + eps);
           tile[r][c4 + e] = p4[u][e];
         }
-        *(f32x4*)(Mo + it.off + e0[u]) = m4[u];
-        *(f32x4*)(Vo + it.off + e0[u]) = v4[u];
-        *(f32x4*)(it.p + e0[u]) = p4[u];
+        if (OPT_NT) { __builtin_nontemporal_store(m4[u], (f32x4*)(Mo + it.off + e0[u])); __builtin_nontemporal_store(v4[u], (f32x4*)(Vo + it.off + e0[u])); }
+        else { *(f32x4*)(Mo + it.off + e0[u]) = m4[u]; *(f32x4*)(Vo + it.off + e0[u]) = v4[u]; }
+        if (OPT_NT_TP) __builtin_nontemporal_store(p4[u], (f32x4*)(it.p + e0[u])); else *(f32x4*)(it.p + e0[u]) = p4[u];
       }
     }
   } else {

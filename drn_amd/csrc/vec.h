@@ -14,6 +14,7 @@ template <> struct V16<float> {
   // the 16 bytes as loaded (conversion deferred: a prefetched vector costs 4 registers, whatever T is)
   typedef f32x4 raw_t;
   static __device__ __forceinline__ raw_t ldraw(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ raw_t ldraw_nt(const float* p) { return __builtin_nontemporal_load((const f32x4*)p); }      // read once
   static __device__ __forceinline__ void cvt(const raw_t& t, float (&v)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = t[i];
@@ -35,6 +36,7 @@ template <> struct V16<bf16_t> {
   }
   typedef bf16x8 raw_t;
   static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return *(const bf16x8*)p; }
+  static __device__ __forceinline__ raw_t ldraw_nt(const bf16_t* p) { return __builtin_nontemporal_load((const bf16x8*)p); }
   static __device__ __forceinline__ void cvt(const raw_t& t, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
