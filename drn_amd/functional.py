@@ -511,7 +511,10 @@ def take_sumsq_notes():
 
 
 NT_WGRAD = True      # prop_fc weight gradient through the NT kernel on transposed operands (bf16): 250 vs 410 us for the TN kernel
-TOUCH_W = os.environ.get("DRN_TOUCH_W", "1") != "0"       # warm the prop_fc weight copy right before its GEMM (round 2 re-measured: 2.562 vs 2.577 ms without)
+# 1 = warm the prop_fc weight copy right before its GEMM when the general kernel runs it (round 2: 2.562 vs 2.577 ms without).  Off since
+# round 5: with the Adam moments and fp32 masters accessed non-temporally the bf16 copy Adam writes is still in the Infinity Cache when the
+# GEMM starts -- T = 32, three pairs in one box: 1.208 -> 1.201 ms linear, 1.149 -> 1.148 two-branch without the touch launch
+TOUCH_W = os.environ.get("DRN_TOUCH_W", "0") != "0"
 
 # BatchNorm `num_batches_tracked` increments are collected during a forward pass and applied by ONE multi-tensor add
 # (flush_bn_counters) instead of one tiny launch per BN call.
