@@ -20,7 +20,7 @@ for _ in range(5):
     tr.train_epoch(bs)
 torch.cuda.synchronize()
 PY
-for T in 32; do
+for T in ${TLIST:-32}; do
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/trace -o t -- python /tmp/tl.py $T > /dev/null 2>&1
 python - <<PY
 import sqlite3
@@ -33,7 +33,7 @@ seg = rows[a:b + 1]
 t0 = seg[0][1]
 print("T=$T: one trainer step, from the end of a replay to the end of the next: %.1f us" % ((seg[-1][2] - seg[0][2]) / 1e3))
 prev = seg[0][2]
-for n, s, e in seg[1:14]:
+for n, s, e in seg[1:int("${NSHOW:-14}")]:
     print("  +%7.1f  gap %6.1f  dur %6.1f  %s" % ((s - seg[0][2]) / 1e3, (s - prev) / 1e3, (e - s) / 1e3, n[:60]))
     prev = e
 print("  ...")
