@@ -396,8 +396,12 @@ def main():
                         # query encoder's forward beside the Adam kernels of the pending update; built, bit-identical, measured in
                         # round 5: 2.020 ms against 2.003 here -- the two optimizer launches per kernel cost 36 us, and next to the
                         # bandwidth-bound Adam kernels every latency-bound query launch runs 3-5 x longer: the overlap bought 13 us)
+                        gkw = {}
+                        if os.environ.get("DRN_BENCH_FORK_ROTATE") == "1":      # (experiment: the optimizer-first order needs the query side's own bucket)
+                            qp = set(id(p) for p in model_f.query_parameters())
+                            gkw = {"groups": [[p for p in params_f if id(p) in qp], [p for p in params_f if id(p) not in qp]]}
                         reducer_f = ddist.GradReducer(params_f, world_size=1, overlap=True, adjacent=model_f.grad_stack_groups(),
-                                                      bucket_bytes=1 << 30)
+                                                      bucket_bytes=1 << 30, **gkw)
                         forked = ForkedStep(model_f, batch[:5], loss_of, reducer_f, _FA(reducer_f, lr=1e-3, max_norm=0.5)).warm(
                             max(args.warmup, 2)).capture()
 
