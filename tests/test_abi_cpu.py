@@ -74,3 +74,30 @@ def test_iou_loss_module_is_exported_and_has_no_cpu_fallback():
     from drn_amd.model.layers import IOULoss, SigmoidFocalLoss      # noqa: F401  (what model/layers/__init__.py exports on this path)
     with pytest.raises(_lib.DrnError):
         IOULoss()(torch.ones(3, 2), torch.ones(3, 2))
+
+
+def test_one_launch_batchnorm_backward_plan_is_host_logic():
+    """drn_bn_bwd_one_ws_bytes answers from shapes alone (no device call): the launch plan -- which row block, whether the grid fits the
+    chip at once, whether a gated level's clips lie inside one row block -- pinned here on the shapes the benchmarked step runs."""
+    from drn_amd import _lib
+    L = _lib.lib()
+    BF16, F32 = 1, 0
+
+    def ws(levels, C, dtype=BF16):
+        arr = (_lib.BnBwdDesc * len(levels))()
+        for d, (M, gl) in zip(arr, levels):
+            d.M = M
+            if gl:
+                d.gb_dg, d.gb_L = 1, gl              # (any non-NULL pointer: only its presence and the clip length matter to the plan)
+        return int(L.drn_bn_bwd_one_ws_bytes(arr, len(levels), C, dtype))
+    pyr = [(8192, 0), (4096, 0), (2048, 0)]
+    assert ws(pyr, 1024) == 64 + 3 * 65 * 2 * 1024 * 8       # heads stage: 448 workgroups of 512 rows
+    assert ws(pyr, 512) > 0 and ws(pyr, 512, F32) > 0
+    assert ws(pyr, 1024, F32) == 0                             # fp32: 256-row blocks at most -> 896 workgroups: two launches
+    assert ws([(40000, 0)], 1024) == 0                         # 79 row blocks of 512 rows
+    assert ws([(8192, 0)], 96) == 0                            # C % 64 != 0
+    # gated levels: clips inside one row block, passes inside one clip
+    assert ws([(4096, 128)], 512) > 0 and ws([(2048, 64)], 1024) > 0 and ws([(8192, 256)], 256) > 0
+    assert ws([(8192, 48)], 256) == 0                          # 48-row clips: not a multiple of a 32-row pass
+    assert ws([(8192, 1024)], 256) == 0                        # a clip longer than the largest gated row block (256 rows)
+    assert ws([(8192, 256), (4096, 0)], 256) > 0               # (mixing is refused at launch, not by the plan)
