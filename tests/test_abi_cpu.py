@@ -101,3 +101,25 @@ def test_one_launch_batchnorm_backward_plan_is_host_logic():
     assert ws([(8192, 48)], 256) == 0                          # 48-row clips: not a multiple of a 32-row pass
     assert ws([(8192, 1024)], 256) == 0                        # a clip longer than the largest gated row block (256 rows)
     assert ws([(8192, 256), (4096, 0)], 256) > 0               # (mixing is refused at launch, not by the plan)
+
+
+def test_norm_pass_block_classes_are_host_logic():
+    """drn_sumsq_block_classes: 0 = a block clear of every skipped range, 1 = inside one, 2 = on a boundary (host helper of
+    drn_sumsq_partials_skip)."""
+    import ctypes
+    from drn_amd import _lib
+    L = _lib.lib()
+    L.drn_opt_nblocks.restype = ctypes.c_int64
+    n = 40 * 4096 + 100
+    nb = int(L.drn_opt_nblocks(ctypes.c_int64(n)))
+    assert nb == 41
+    lo = (ctypes.c_int64 * 2)(4096 * 3, 4096 * 10 + 7)
+    hi = (ctypes.c_int64 * 2)(4096 * 6, 4096 * 12)
+    out = (ctypes.c_ubyte * nb)()
+    assert L.drn_sumsq_block_classes(ctypes.c_int64(n), lo, hi, 2, out) == 0
+    got = list(out)
+    want = [0] * nb
+    for b in (3, 4, 5, 11):
+        want[b] = 1
+    want[10] = 2
+    assert got == want, got
