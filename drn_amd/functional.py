@@ -1086,10 +1086,10 @@ class InputPrep(object):
     """Everything the input stage needs that does not depend on the query: the feature tensor in the compute dtype (and, for
     the bf16 weight-gradient product, its transpose), the proposal position features, the GEMM copy of the prop_fc weight
     (warmed into the caches).  Non-differentiable."""
-    __slots__ = ("xc", "xcT", "pf", "wfc", "dtype", "dims", "fc", "Z")
+    __slots__ = ("xc", "xcT", "pf", "wfc", "dtype", "dims", "fc", "Z", "G0")
 
 
-def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True, split_gate=False):
+def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True, split_gate=False, position_transform=None):
     """props_start_end: (B, T, 2) proposal boundaries, or the (B, T, 3) position features themselves.
     split_gate: also run the prop_fc GEMM here, WITHOUT the query gate (-> pr.Z, the pre-gate value backward keeps anyway); the
     input stage then applies the gate in a pass of its own (ops.gate_fwd).  For schedules that run the query encoder beside this
@@ -1130,6 +1130,14 @@ def input_prep(feats, props_start_end, prop_fc, dtype, want_wgrad=True, split_ga
         pf = torch.cat((props_start_end, duration), dim=-1).float()
     pr.pf = pf.reshape(B * T, 3).contiguous()
     pr.Z = None
+    pr.G0 = None
+    if position_transform is not None and POS_EARLY:
+        # conv0's input buffer, its position-embedding columns filled HERE: nothing of this depends on the query, so in the
+        # two-branch step the launch sits beside the query encoder instead of between the prop_fc GEMM and conv0 (-7 us on that path)
+        P = position_transform.weight.shape[0]
+        pr.G0 = torch.empty((B, T, D + P), dtype=dtype, device=xc.device)
+        ops.pos_embed_fwd(pr.pf, position_transform.weight.detach(), position_transform.bias.detach(), pr.G0.view(B * T, D + P)[:, D:], D + P,
+                          B * T, P, code)
     if split_gate:
         pr.Z = torch.empty((B, T, D), dtype=dtype, device=xc.device)
         ops.gemm_nt([ops.gemm_desc(pr.xc, pr.wfc, pr.Z, B * T, D, D, Lout=T, ldc=D, bias=prop_fc.bias.detach())], code)
@@ -1146,6 +1154,7 @@ def _fc_kernel_kind(B, T, D, N, xc, wfc, code, split_gate):
     return ops.gemm_nt_plan([d], code)
 
 
+POS_EARLY = os.environ.get("DRN_POS_EARLY", "1") != "0"              # (experiment switch: 0 = the position embedding after the prop_fc GEMM)
 GATE_BN_FUSE = os.environ.get("DRN_GATE_BN_FUSE", "1") != "0"        # (experiment switch: 0 = drn_gate_bwd in front of the BatchNorm backward)
 GATE_BWD_FUSE = os.environ.get("DRN_GATE_BWD_FUSE", "1") != "0"      # (experiment switch: 0 = drn_gate_bwd_t as a launch of its own)
 
@@ -1198,7 +1207,12 @@ class _InputStageFn(torch.autograd.Function):
         P = Wpos.shape[0]
         xc, xcT, pf, wfc = prep.xc, prep.xcT, prep.pf, prep.wfc
         dev = xc.device
-        G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
+        G0 = getattr(prep, "G0", None)                     # (input_prep may have made it, position columns filled: used once)
+        pos_done = G0 is not None and tuple(G0.shape) == (B, T, D + P)
+        if pos_done:
+            prep.G0 = None
+        else:
+            G0 = torch.empty((B, T, D + P), dtype=dtype, device=dev)
         if getattr(prep, "Z", None) is not None:
             Z = prep.Z                                    # the GEMM already ran, un-gated (input_prep(split_gate=True))
             ops.gate_fwd(Z, D, gate0, G0, D + P, B, T, D, code)
@@ -1206,8 +1220,9 @@ class _InputStageFn(torch.autograd.Function):
             Z = torch.empty((B, T, D), dtype=dtype, device=dev)
             ops.gemm_nt([ops.gemm_desc(xc, wfc, G0, B * T, D, D, Lout=T, ldc=D + P, bias=bfc, gate=gate0, ldg=gate0.stride(0),
                                        C2=Z, ldc2=D)], code)
-        pos_slice = G0.view(B * T, D + P)[:, D:]
-        ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
+        if not pos_done:
+            pos_slice = G0.view(B * T, D + P)[:, D:]
+            ops.pos_embed_fwd(pf, Wpos, bpos, pos_slice, D + P, B * T, P, code)
         ctx.dtype, ctx.dims = dtype, (B, T, D, P)
         ctx.param_refs = (Wfc, bfc, Wpos, bpos)
         ctx.tail = tail

@@ -135,7 +135,8 @@ class mainModel(nn.Module):
             fc = types.SimpleNamespace(weight=F.pad(self.prop_fc.weight, (0, pad, 0, pad)), bias=F.pad(self.prop_fc.bias, (0, pad)))
         else:
             fc = self.prop_fc
-        prep = DF.input_prep(props_features, props_start_end, fc, dt, want_wgrad, split_gate=getattr(self, "split_gate", False))
+        prep = DF.input_prep(props_features, props_start_end, fc, dt, want_wgrad, split_gate=getattr(self, "split_gate", False),
+                             position_transform=self.position_transform)
         prep.fc = fc
         return prep
 
