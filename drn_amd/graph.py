@@ -384,7 +384,9 @@ class ForkedStep(DualStreamStep):
         # full rate it stretches the latency-bound query launches 2-3 x (first dense product 18 -> 47 us, an LSTM step 7.5 -> 20);
         # held to 128 resident workgroups it takes 121 instead of 64 us -- still hidden -- and the query forward 164 instead of
         # 174 us: 2.028 / 2.019 -> 2.012 / 2.013 ms per step (64: 2.055, 96: 2.012-2.024, 192: 2.010-2.027, 256: 2.016-2.020)
-        self.prep_throttle = int(os.environ.get("DRN_FORK_PREP_THROTTLE", "128"))
+        # (re-swept at the end of round 5, non-temporal cast loads and the position embedding beside it: 64: 1.96, 96: 1.92, 128: 1.912,
+        # 192: 1.905, 256: 1.907, unthrottled 1.927 ms -- two rounds each in one box)
+        self.prep_throttle = int(os.environ.get("DRN_FORK_PREP_THROTTLE", "192"))
         if self._env_wf is not None:
             self.wgrads_first = self._env_wf == "1"
         if self._env_mf is not None:
