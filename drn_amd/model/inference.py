@@ -89,7 +89,10 @@ class FCOSPostProcessor(torch.nn.Module):
         return results
 
     def forward(self, locations, box_cls, box_regression, iou_scores):
+        # (the one-kernel path is for DRN's single foreground channel; more channels -- fcos_num_class > 2 -- take the reference's
+        # per-level procedure below, candidates over (location, class), on the device with torch ops)
         if all(getattr(x, "flat", None) is not None and x.flat.is_cuda for x in (box_cls, box_regression)) and \
+                box_cls.flat.shape[1] == 1 and \
                 (self.is_first_stage or getattr(iou_scores, "flat", None) is not None) and self.min_size == 0:
             return self.forward_flat(locations, box_cls, box_regression, iou_scores)
         sampled = [self.forward_for_single_feature_map(l, o, b, i, s)

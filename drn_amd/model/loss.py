@@ -41,8 +41,22 @@ class FCOSLossComputation(object):
                    float(self.object_sizes_of_interest[i][1])) for i, c in enumerate(box_cls)]
         logits, reg = self._flat(box_cls), self._flat(box_regression)
         iou = None if is_first_stage else self._flat(iou_scores)
+        extra = None
+        if logits.shape[1] > 1:
+            # more than one foreground channel (fcos_num_class > 2): DRN's targets carry class 1 only (model/loss.py:103-131), so
+            # channel 0 is what the fused kernel computes and every other channel is background at every location -- their focal
+            # terms come from the class-general kernel (drn_focal_fwd / _bwd) with all-zero labels and join the same
+            # normalisation, sum / (n_pos + N) (model/loss.py:209-213)
+            from .layers.sigmoid_focal_loss import sigmoid_focal_loss
+            zeros = torch.zeros(logits.shape[0], dtype=torch.int32, device=logits.device)
+            extra = sigmoid_focal_loss(logits[:, 1:].contiguous(), zeros, self.gamma, self.alpha).sum()
+            logits = logits[:, :1].contiguous()
         l_cls, l_reg, l_iou, counts, total = DF.fcos_loss(logits, reg, iou, targets, levels, B, self.gamma, self.alpha, TARGET_SCALE,
                                       not is_first_stage)
+        if extra is not None:
+            extra = (extra / (counts[0].detach() + float(B))).reshape(1)
+            l_cls = l_cls + extra
+            total = total + extra
         self.last_counts = counts
         self.last_total = total
         if is_first_stage:

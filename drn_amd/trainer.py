@@ -413,7 +413,9 @@ class Trainer(object):
         iou_topk = iou_topk or {"iou": [0.5], "topk": [1, 5]}                            # main.py:362
         results, total, n, hits = {}, None, 0, []
         selector = getattr(getattr(self.model, "fcos", None), "box_selector_test", None)
-        fast = (not with_results) and selector is not None and self.device.type == "cuda"
+        head = getattr(getattr(self.model, "fcos", None), "head", None)
+        one_class = head is None or head.cls_logits.weight.shape[0] == 1       # (more foreground channels: the records path)
+        fast = (not with_results) and selector is not None and self.device.type == "cuda" and one_class
         # (decided ONCE, from static facts, so every rank takes the same branch of the merge below; drn_eval_recall serves every
         # level table drn_postprocess accepts, so the fast path has no per-batch fallback to disagree about)
         fast0 = fast

@@ -94,14 +94,18 @@ def matched_gt(m, batch):
     return torch.tensor(gt, dtype=torch.float64)
 
 
-def run_case(name, B, T, D, stage, train=True, match=False):
+def run_case(name, B, T, D, stage, train=True, match=False, num_class=None):
     ftype = "C3D" if D == 4096 else "TINY"
     cfg = default_cfg(ftype, D, stage)
+    if num_class is not None:                              # model/fcos.py:27,43: cls_logits gets fcos_num_class - 1 channels
+        cfg["fcos_num_class"] = num_class
     m = build_reference(cfg, seed=0)
     batch = list(synthetic_batch(B, T, D, seed=1))
     if match:
         batch[4] = matched_gt(m, batch)
     out = {"B": B, "T": T, "D": D, "stage": stage, "train": int(train), "gt": batch[4].numpy()}
+    if num_class is not None:
+        out["num_class"] = num_class
     taps = {}
     hooks = []
     mods = dict(m.named_modules())
@@ -414,6 +418,12 @@ def run_keys():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     install_shims()
+    if sys.argv[1:] == ["classes"]:                        # fcos_num_class = 4: three foreground channels (off every shipped config)
+        run_case("tiny_k3_s1", 2, 32, 64, 1, num_class=4)
+        run_case("tiny_k3_s3", 2, 32, 64, 3, match=True, num_class=4)
+        run_case("tiny_k3_eval", 2, 32, 64, 3, train=False, num_class=4)
+        run_case("tiny_k2_s3", 2, 32, 64, 3, match=True, num_class=3)      # two channels: one head call, no chunking
+        sys.exit(0)
     if sys.argv[1:] == ["layers"]:
         run_layers()
         sys.exit(0)
@@ -436,6 +446,10 @@ if __name__ == "__main__":
     run_case("tiny_eval_s1", 3, 64, 64, 1, train=False)
     run_case("c3d_s1", 2, 64, 4096, 1)
     run_case("c3d_s3", 2, 64, 4096, 3, match=True)
+    run_case("tiny_k3_s1", 2, 32, 64, 1, num_class=4)
+    run_case("tiny_k3_s3", 2, 32, 64, 3, match=True, num_class=4)
+    run_case("tiny_k3_eval", 2, 32, 64, 3, train=False, num_class=4)
+    run_case("tiny_k2_s3", 2, 32, 64, 3, match=True, num_class=3)
     run_lgp()
     run_layers()
     run_metrics()

@@ -23,6 +23,8 @@ def load_golden(name):
 def case_inputs(g, device="cpu"):
     B, T, D, stage = int(g["B"]), int(g["T"]), int(g["D"]), int(g["stage"])
     cfg = default_cfg("C3D" if D == 4096 else "TINY", D, stage)
+    if "num_class" in g:                                   # (the cases recorded with more than one foreground channel)
+        cfg["fcos_num_class"] = int(g["num_class"])
     batch = list(synthetic_batch(B, T, D, seed=1, device=device))
     batch[4] = torch.from_numpy(g["gt"]).to(device)
     return cfg, batch
@@ -123,8 +125,9 @@ def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=
                                   b["scores"].detach().float().cpu().numpy()[:, None],
                                   b["locations"].detach().float().cpu().numpy()[:, None]], 1)
             ref = np.concatenate([g["det"][off:off + n], g["score"][off:off + n, None], g["loc"][off:off + n, None]], 1)
-            got = got[np.lexsort((got[:, 0], got[:, 3]))]
-            ref = ref[np.lexsort((ref[:, 0], ref[:, 3]))]
+            # (several foreground channels: one location can yield one candidate per class -- same segment, different score)
+            got = got[np.lexsort((got[:, 2], got[:, 0], got[:, 3]))]
+            ref = ref[np.lexsort((ref[:, 2], ref[:, 0], ref[:, 3]))]
             np.testing.assert_allclose(got, ref, atol=atol, rtol=0, err_msg="detections clip %d" % bi)
             lv = np.array([x for l in b["level"] for x in l])
             np.testing.assert_array_equal(np.sort(lv), np.sort(g["level"][off:off + n]))

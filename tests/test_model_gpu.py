@@ -18,7 +18,8 @@ def gpu_batch(batch):
     return [b.to(dev) if i != 1 else b for i, b in enumerate(batch)]     # query_length stays on the host
 
 
-@pytest.mark.parametrize("name", ["tiny_s1", "tiny_s3", "tiny_s2", "c3d_s1", "c3d_s3", "tiny_eval", "tiny_eval_s1"])
+@pytest.mark.parametrize("name", ["tiny_s1", "tiny_s3", "tiny_s2", "c3d_s1", "c3d_s3", "tiny_eval", "tiny_eval_s1",
+                                  "tiny_k3_s1", "tiny_k3_s3", "tiny_k3_eval", "tiny_k2_s3"])       # k3: three foreground channels (fcos_num_class = 4)
 def test_hip_model_matches_reference_golden(name):
     from drn_amd.model import mainModel
     g = load_golden(name)
