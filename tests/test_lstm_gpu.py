@@ -73,7 +73,7 @@ def test_sentence_vector_rides_in_the_step_kernels():
     assert torch.equal(d_a, d_b) and torch.equal(dgates_a, leaves_b[0]["dY"])
 
 
-@pytest.mark.parametrize("B,L,lens", [(32, 8, None), (7, 5, [5, 5, 4, 3, 2, 1, 1]), (40, 3, None)])
+@pytest.mark.parametrize("B,L,lens", [(32, 8, None), (7, 5, [5, 5, 4, 3, 2, 1, 1]), (40, 3, None), (32, 24, None), (16, 48, None)])
 def test_low_precision_recurrent_products_track_the_fp32_kernels(B, L, lens):
     """The bf16 model's BiLSTM (lowp): forward on v_mfma_f32_16x16x32_f16 with an fp16 copy of the hidden state (W_hh rounded to fp16
     in registers), backward on v_mfma_f32_16x16x32_bf16 with bf16 copies of W_hh^T and of the gate gradients; fp32 accumulation and
@@ -100,7 +100,9 @@ def test_low_precision_recurrent_products_track_the_fp32_kernels(B, L, lens):
     o16, dx16, g16 = res[True]
     assert not torch.equal(o32, o16)                                  # the bf16 path really ran
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
-    assert rel(o16, o32) <= 2e-3, rel(o16, o32)                     # fp16 forward: unit roundoff 2^-11 on both operands
+    # fp16 forward: unit roundoff 2^-11 on both operands.  The bound does not grow with the sequence (24 and 48 steps are three / six
+    # times Charades-STA's longest query): the gates squash the state every step, rounding errors do not accumulate through the recurrence
+    assert rel(o16, o32) <= 2e-3, rel(o16, o32)
     assert rel(dx16, dx32) <= 2e-2, rel(dx16, dx32)
     for k in g32:
         assert rel(g16[k], g32[k]) <= 2e-2, (k, rel(g16[k], g32[k]))
