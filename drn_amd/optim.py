@@ -13,7 +13,8 @@ from ._lib import check, lib
 # 1 = the norm pass leaves out the gradients whose producers already summed their squares (prop_fc's GEMM epilogue, the one-launch
 # reduce of the conv weight gradients): the pass drops 28 -> 16 us, and the step does not move (2.051 vs 2.050-2.067 ms, in one box) --
 # the plain pass was also pulling those 108 MB into the 256 MB infinity cache for the Adam kernels behind it (adam_tiled +9 us
-# without it), and the producers pay 1-5 us for the sums.  Kept as a measured option, off.
+# without it), and the producers pay 1-5 us for the sums.  Kept as a measured option, off.  (With it the two-branch step is deterministic
+# but no longer bit-identical to the linear one: the one-launch reduce's partial sums follow the order the weight gradients were launched in.)
 EXT_SUMSQ = os.environ.get("DRN_EXT_SUMSQ", "0") != "0"
 
 
