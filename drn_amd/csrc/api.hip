@@ -16,7 +16,7 @@ extern "C" int drn_abi_version(void) {
   drn_clear_status(); return DRN_ABI_VERSION; }
 extern "C" const char* drn_last_error(void) { return g_err; }
 
-static int g_tune[15] = {4096, 1, 256, 0, 0, 0, 0, 0, 1, 1, 0, 16, 160, 512, 2048};   // DRN_TUNE_TN3_MINROWS, DRN_TUNE_TN_FUSED, DRN_TUNE_NT_DEEP, DRN_TUNE_EXP0..4, DRN_TUNE_NT_W4, DRN_TUNE_NT_W4C
+static int g_tune[16] = {4096, 1, 256, 0, 0, 0, 0, 0, 1, 1, 0, 16, 160, 512, 2048, 1};   // DRN_TUNE_TN3_MINROWS, DRN_TUNE_TN_FUSED, DRN_TUNE_NT_DEEP, DRN_TUNE_EXP0..4, DRN_TUNE_NT_W4, DRN_TUNE_NT_W4C
 int drn_tuning(int key) { return g_tune[key]; }
 extern "C" int drn_tune(const char* key, int value) {
   drn_clear_status();
@@ -27,6 +27,7 @@ extern "C" int drn_tune(const char* key, int value) {
   if (key && !strcmp(key, "nt_deep")) { g_tune[DRN_TUNE_NT_DEEP] = value; return DRN_OK; }
   if (key && !strcmp(key, "nt_w4h")) { g_tune[DRN_TUNE_NT_W4H] = value; return DRN_OK; }
   if (key && !strcmp(key, "w4h_tapil")) { g_tune[DRN_TUNE_W4H_TAPIL] = value; return DRN_OK; }
+  if (key && !strcmp(key, "xchg_confirm")) { g_tune[DRN_TUNE_XCHG_CONFIRM] = value != 0; return DRN_OK; }
   if (key && !strcmp(key, "bn1_maxwg")) { g_tune[DRN_TUNE_BN1_MAXWG] = value; return DRN_OK; }
   if (key && !strcmp(key, "nt_deep2")) { g_tune[DRN_TUNE_NT_DEEP2] = value; return DRN_OK; }
   if (key && !strcmp(key, "nt_deep_ks")) { g_tune[DRN_TUNE_NT_DEEP_KS] = value; return DRN_OK; }

@@ -135,6 +135,7 @@ constexpr int NT_PROB_DW = (int)sizeof(GemmProb) / 4;
 static_assert(NT_HDR_DW <= 64 && NT_PROB_DW <= 64 && sizeof(GemmProb) % 4 == 0 && offsetof(GemmParams, p) % 4 == 0, "one lane per dword");
 struct NtHeader {
   int ngroups, xcd_swizzle, ksplit, nblocks;
+  int confirm;      // DRN_XCHG_CONFIRM taken out of GemmParams::ksplit
   float* ws;
   int* counters;
 };
@@ -150,6 +151,8 @@ __device__ __forceinline__ void nt_fetch(const GemmParams& P, NtHeader& H, GemmP
   H.ngroups = (int)nt_rl(hv, (int)offsetof(GemmParams, ngroups) / 4);
   H.xcd_swizzle = (int)nt_rl(hv, (int)offsetof(GemmParams, xcd_swizzle) / 4);
   H.ksplit = (int)nt_rl(hv, (int)offsetof(GemmParams, ksplit) / 4);
+  H.confirm = H.ksplit & DRN_XCHG_CONFIRM;
+  H.ksplit &= 0xffff;
   H.nblocks = (int)nt_rl(hv, (int)offsetof(GemmParams, nblocks) / 4);
   H.ws = (float*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, ws) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, ws) / 4));
   H.counters = (int*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, counters) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, counters) / 4));
@@ -1241,6 +1244,28 @@ __global__ __launch_bounds__(64 * WM * WN, (BNF && MI * NI == 8 && STAGES == 2) 
             "v"(slab + 6 * NT), "v"(slab + 7 * NT), "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[2][0]),
             "v"(acc[2][1]), "v"(acc[3][0]), "v"(acc[3][1])
           : "memory");
+      // DRN_XCHG_CONFIRM (launches that another queue's kernel may run beside; skinny_group_kernel, qdense.hip, says why: a
+      // write-through store's completion is not its visibility to the other XCDs): one returning agent-scope OR-with-zero per
+      // 64-byte request of every store (lanes 0, 4, 8, ...: four lanes share a request) -- a read-modify-write of the same address
+      // is performed behind the store -- before the workgroup counts itself in.  Issued right behind the stores or after their
+      // wait costs the same ~6 us per launch: it is the atomics' rate, not their latency.
+      if (P.confirm && (tid & 3) == 0) {
+        unsigned b0, b1, b2, b3, b4, b5, b6, b7;
+        asm volatile(
+            "global_atomic_or %0, %8, %16, off sc0 sc1\n\t"
+            "global_atomic_or %1, %9, %16, off sc0 sc1\n\t"
+            "global_atomic_or %2, %10, %16, off sc0 sc1\n\t"
+            "global_atomic_or %3, %11, %16, off sc0 sc1\n\t"
+            "global_atomic_or %4, %12, %16, off sc0 sc1\n\t"
+            "global_atomic_or %5, %13, %16, off sc0 sc1\n\t"
+            "global_atomic_or %6, %14, %16, off sc0 sc1\n\t"
+            "global_atomic_or %7, %15, %16, off sc0 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+            : "v"(slab), "v"(slab + NT), "v"(slab + 2 * NT), "v"(slab + 3 * NT), "v"(slab + 4 * NT), "v"(slab + 5 * NT),
+              "v"(slab + 6 * NT), "v"(slab + 7 * NT), "v"(0u)
+            : "memory");
+      }
       static_assert(MI == 4 && NI == 2, "the exchange is written for the 8-wave 128x128 tile");
       __syncthreads();
       int& s_last = *(int*)smem;            // (the ring is idle: everybody is past the main loop's last LDS read)

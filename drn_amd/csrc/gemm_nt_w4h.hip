@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
     const char* slab = tile_base + (long)blockIdx.y * (32 * 256 * 16);
     const unsigned lane_off = (unsigned)tid * 16u;
     asm volatile(W4H_PUBLISH_ASM : : [base] "s"(slab), [off] "v"(lane_off) : W4H_XCHG_CLOBBERS);
+    if (P_arg.ksplit & DRN_XCHG_CONFIRM) asm volatile(W4H_CONFIRM_ASM : : [base] "s"(slab), [off] "v"(lane_off) : W4H_XCHG_CLOBBERS);
     __syncthreads();
     int& s_last = *(int*)smem;
     if (tid == 0) {
@@ -287,7 +288,7 @@ int drn_nt_w4h_launch(const GemmParams& P, int total, bool conv, hipStream_t str
     const int ksteps = P.p[0].K / 64, per = (cdiv(ksteps, ksplit) + 2) / 3 * 3;
     if ((ksplit - 1) * per < ksteps) {
       GemmParams Q = P;
-      Q.ksplit = ksplit | W4H_TAPIL;
+      Q.ksplit = P.ksplit | W4H_TAPIL;        // (P.ksplit = ksplit + the DRN_XCHG_CONFIRM flag)
       gemm_nt_w4h_kernel<true><<<dim3(total, ksplit), 256, LDS, stream>>>(Q);
       return drn_launch_status("drn_gemm_nt");
     }

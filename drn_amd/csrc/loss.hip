@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256) void fcos_loss_fwd_partial_kernel(const LossPa
 #pragma unroll
       for (int k = 0; k < 5; ++k) __hip_atomic_store(p + k, v5[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // confirmed by a returning read-modify-write per address before the ticket (skinny_group_kernel, qdense.hip, says why)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        unsigned back;
+        asm volatile("global_atomic_or %0, %1, %2, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(back) : "v"(p + k), "v"(0u) : "memory");
+      }
       const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = prev == (int)gridDim.x - 1;
       if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed

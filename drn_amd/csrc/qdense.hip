@@ -41,7 +41,8 @@ struct SkGroupArgs {
 // long K is split over workgroups; the LAST-ARRIVING workgroup of a column tile adds the partial tiles in a fixed order
 // (deterministic) and applies the epilogue -- no second launch.  The partial tiles are exchanged with agent-scope relaxed
 // atomic stores / loads (write-through / L2-bypassing accesses): ordinary stores + __threadfence() cost 25 us per launch
-// here, because a device-scope release writes back the whole L2 of the XCD.
+// here, because a device-scope release writes back the whole L2 of the XCD.  Every store is confirmed by a returning atomic
+// on its own address before the workgroup counts itself in (see below: the store's completion alone is not enough).
 // Optional per-workgroup timeline (build with -DDRN_QD_TRACE, scripts/experiments/qd_trace.py): wall_clock64() (100 MHz) at
 // entry / after the K loop / after the cross-wave sum / at exit, per workgroup, read back with drn_debug_qd_trace().
 // What it showed (round 3, gate projections 32 x 1024 -> 4864, 304 workgroups): 2.5 us per 64-wide K step with 0.4 us of MFMAs
@@ -167,6 +168,15 @@ __global__ __launch_bounds__(QD_THREADS) void skinny_group_kernel(const SkGroupA
       asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(mine), "v"(pv) : "memory");
     } else {
       __hip_atomic_store(mine, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ... and CONFIRMED: s_waitcnt vmcnt(0) after a write-through store does not mean the data has reached the point the other
+    // XCDs read from -- with another queue's bandwidth-bound kernel running beside this one the ticket (a different address, a
+    // different channel) overtook a partial about once in 10^5 launches and the last arriver summed the previous launch's value
+    // (the two-branch hipGraph step; scripts/experiments/forked_race_hunt.py: 12 events in 180 k replays, none in 240 k with this).
+    // A returning agent-scope read-modify-write of the SAME address is performed behind the store at the serialisation point.
+    {
+      unsigned back;
+      asm volatile("global_atomic_or %0, %1, %2, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(back) : "v"(mine), "v"(0u) : "memory");
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's write-through stores are complete ...
     __syncthreads();                                          // ... and so are the other waves' before thread 0 counts us in

@@ -118,6 +118,11 @@ class GradReducer(object):
         self._dirty = {}
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
+        # RCCL's kernels run beside backward: the GEMM kernels' in-launch split-K exchanges confirm their stores (ops.xchg_need)
+        self._xchg = self.world > 1 and bool(self.params) and self.params[0].is_cuda
+        if self._xchg:
+            from . import ops
+            ops.xchg_need(+1)
         self.buckets, self._of, self.group_buckets = [], {}, []
         wanted = set(id(p) for p in self.params)
         plan = [self.params] if groups is None else [[p for p in g if id(p) in wanted] for g in groups]
@@ -321,6 +326,10 @@ class GradReducer(object):
         self.wait(timings)
 
     def remove(self):
+        if getattr(self, "_xchg", False):
+            from . import ops
+            ops.xchg_need(-1)
+            self._xchg = False
         self._wgrad_defer(False)
         for h in self._hooks:
             h.remove()

@@ -206,6 +206,18 @@ class DualStreamStep(object):
 
     # ---- the phases (each runs on the stream its row in the table says)
     def _phase(self, name):
+        # every phase but the trunk has the other branch beside it: the split-K exchanges confirm their stores there (ops.xchg_need)
+        from . import ops
+        beside = name != "trunk"
+        if beside:
+            ops.xchg_need(+1)
+        try:
+            self._run_phase(name)
+        finally:
+            if beside:
+                ops.xchg_need(-1)
+
+    def _run_phase(self, name):
         m, red, c = self.model, self.reducer, self._c
         tok, qlen, feats, pse, gt = self.batch[:5]
         if name == "q_fwd":
@@ -398,7 +410,7 @@ class ForkedStep(DualStreamStep):
         self.graph = None
 
     # ---- optimizer-first order
-    def _phase(self, name):
+    def _run_phase(self, name):
         red = self.reducer
         if name == "norm":
             self.opt.norm()
@@ -412,7 +424,7 @@ class ForkedStep(DualStreamStep):
         elif name == "collect":
             red.finish()                                     # (one process: gradients produced outside their sinks are moved in)
         else:
-            super(ForkedStep, self)._phase(name)
+            super(ForkedStep, self)._run_phase(name)
 
     def _schedule(self, run, M, Q):
         if not self.rotate:

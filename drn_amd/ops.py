@@ -166,7 +166,37 @@ def _ksplit_w4h(descs, dtype):
     return ks if lib().drn_gemm_nt_splitk_plan(arr, 1, ks, dtype) == NT_KIND_W4H else 1
 
 
+# The in-launch split-K exchanges (partial tiles published write-through, a ticket, the last arriver sums) must CONFIRM their stores
+# -- a returning agent-scope read-modify-write per 64-byte request -- whenever a kernel of another queue may run beside the launch:
+# with one, the ticket overtook a partial about once in 10^5 launches of skinny_group_kernel (qdense.hip has the measurements; that
+# kernel and the loss kernel always confirm, it costs them nothing).  For the GEMM kernels the confirmation costs ~6 us per split
+# launch (+76 us per step at T = 256), so they do it on demand: drn_tune "xchg_confirm" (library default 1 = always), driven from
+# here -- "auto": while somebody has declared concurrency (GradReducer with world_size > 1: RCCL kernels beside backward;
+# DualStreamStep / ForkedStep: every phase that has the other branch beside it, i.e. all but the trunk), and not in a strictly
+# single-queue step, where nothing can be beside the launch (30 k + 12 k checked replays of the linear graph, no event).
+# DRN_XCHG_CONFIRM=1 / 0 forces it.
+XCHG_CONFIRM = os.environ.get("DRN_XCHG_CONFIRM", "auto")
+_xchg_need = 0
+_xchg_set = None
+
+
+def xchg_need(delta):
+    """Declare (+1) / withdraw (-1) that kernels of another queue may run beside the launches issued from now on."""
+    global _xchg_need
+    _xchg_need += int(delta)
+    _xchg_apply()
+
+
+def _xchg_apply():
+    global _xchg_set
+    want = 1 if XCHG_CONFIRM == "1" or (XCHG_CONFIRM != "0" and _xchg_need > 0) else 0
+    if want != _xchg_set:
+        check(lib().drn_tune(b"xchg_confirm", want), "drn_tune")
+        _xchg_set = want
+
+
 def gemm_nt(descs, dtype):
+    _xchg_apply()
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
     ks = _ksplit_w4h(descs, dtype)

@@ -68,7 +68,7 @@ def first_diff(a, b):
 
 
 batch = [b.to(dev) for b in synthetic_batch(4, 32, 64, seed=1)]
-for dtype in (torch.bfloat16, torch.float32):
+for dtype in ((torch.bfloat16,) if os.environ.get("PROBE_DTYPES") == "bf16" else (torch.bfloat16, torch.float32)):
     base, sd0 = eager(dtype, 64, batch)
     for rnd in range(rounds):
         e, sde = eager(dtype, 64, batch)

@@ -420,6 +420,16 @@ with open(args.out, "w") as f:
         pub.append("global_store_dwordx4 %%[off], a[%d:%d], s[80:81] sc1" % (4 * g, 4 * g + 3))
         pub += bump(80)
     pub.append("s_waitcnt vmcnt(0)")
+    # CONFIRM (W4H_CONFIRM_ASM, run when GemmParams::ksplit carries DRN_XCHG_CONFIRM): the stores' completion is not their visibility
+    # to the other XCDs (skinny_group_kernel, qdense.hip, says why): one returning agent-scope OR-with-zero per 64-byte request
+    # (lanes 0, 4, 8, ...) of each of the 32 stores -- a read-modify-write of the same address is performed behind the store --
+    # all in flight, one wait, before the workgroup counts itself in.
+    conf = ["s_mov_b64 s[80:81], %[base]", "v_mov_b32 v113, 0", "s_mov_b32 s82, 0x11111111", "s_mov_b32 s83, 0x11111111",
+            "s_mov_b64 exec, s[82:83]"]
+    for g in range(32):
+        conf.append("global_atomic_or v%d, %%[off], v113, s[80:81] sc0 sc1" % (128 + g))
+        conf += bump(80)
+    conf += ["s_mov_b64 exec, -1", "s_waitcnt vmcnt(0)"]
     def loads(v0):
         out = []
         for g in range(16):
@@ -449,7 +459,7 @@ with open(args.out, "w") as f:
     gat.append("s_waitcnt vmcnt(0)")
     gat += add(192, 64)
     gat.append("s_nop 4")
-    for name, lines in (("W4H_PUBLISH_ASM", pub), ("W4H_GATHER_ASM", gat)):
+    for name, lines in (("W4H_PUBLISH_ASM", pub), ("W4H_CONFIRM_ASM", conf), ("W4H_GATHER_ASM", gat)):
         f.write("// %s: %d instructions\n" % (name, len(lines)))
         f.write("#define %s \\\n" % name)
         for ln in lines:

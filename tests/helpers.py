@@ -137,11 +137,11 @@ def run_and_compare(m, g, batch, atol=1e-4, grad_rtol=1e-4, taps=True, check_bn=
 
 def isolated(fn):
     """Run a GPU test in a FRESH Python process (this very test re-invoked through pytest with DRN_TEST_ISOLATED=1) and pass / fail
-    with it.  For the bit-identity tests of the two-branch hipGraph step: in round 5 `test_forked_graph_step_is_bit_identical[bf16]`
-    mismatched in 3 of ~10 full-suite runs (losses diverging a few replays after the capture) and never in a process of its own --
-    12 forced-candidate runs, 24 rounds after other test files, 2 x 1500 replays against eager all bit-identical
-    (scripts/experiments/forked_stress.py, flake_probe.py; profiles/HISTORY.md, round 5).  What the test guards is the property of
-    the step, so it gets the process a training run has; the order dependence itself is an open item in DESIGN.md."""
+    with it.  Used by the bit-identity tests of the two-branch hipGraph step, which compare a whole training run.  (Introduced while
+    `test_forked_graph_step_is_bit_identical` mismatched in 3 of ~10 full-suite runs and never on its own; the cause turned out not to
+    be the process at all -- a ticket overtaking a write-through store in the K-split exchange of skinny_group_kernel, once in ~10^5
+    launches when another branch's kernel ran beside it, fixed in qdense.hip, DESIGN.md section 3 -- the wrapper stays because a
+    failure's report then names the side that moved and lands in gpurun_out/isolated_failures.log.)"""
     import functools
     import subprocess
     import sys
@@ -156,5 +156,9 @@ def isolated(fn):
         env = dict(os.environ, DRN_TEST_ISOLATED="1")
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", node], cwd=root, env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-        assert r.returncode == 0, r.stdout.decode(errors="replace")[-4000:]
+        out = r.stdout.decode(errors="replace")
+        if r.returncode and os.path.isdir(os.path.join(root, "gpurun_out")):          # (kept with the GPU box's outputs)
+            with open(os.path.join(root, "gpurun_out", "isolated_failures.log"), "a") as f:
+                f.write("==== %s\n%s\n" % (node, out[-6000:]))
+        assert r.returncode == 0, out[-4000:]
     return wrapper

@@ -913,6 +913,61 @@ def test_w4h_kernel_splitk_in_launch(monkeypatch, shape):
         close(outs[0], outs[1].double().cpu(), 1e-2, "interleaved vs tap-major")
 
 
+@pytest.mark.parametrize("kind", ["general", "w4h"])
+def test_split_exchange_confirmation_changes_no_bits(monkeypatch, kind):
+    """drn_tune "xchg_confirm" (ops.xchg_need: set while another queue's kernels may run beside the launch): every partial-tile store
+    of the in-launch split-K exchange is followed by a returning OR-with-zero on its address before the ticket.  Values untouched:
+    the launch with and without it gives the same bits, counters re-armed, for the general 128 x 128 kernel and for gemm_nt_w4h_kernel
+    (tap-interleaved and plain)."""
+    import ctypes
+    from drn_amd import ops, _lib
+    L_ = _lib.lib()
+    outs = []
+    for confirm in (1, 0, 1):
+        monkeypatch.setattr(ops, "XCHG_CONFIRM", str(confirm))
+        monkeypatch.setattr(ops, "_xchg_set", None)
+        ops._xchg_apply()
+        if kind == "general":
+            M, N, K, ks = 512, 384, 4096, 4
+            g = torch.Generator().manual_seed(5)
+            A = torch.randn(M, K, generator=g).to(dev()).to(torch.bfloat16)
+            B = torch.randn(N, K, generator=g).to(dev()).to(torch.bfloat16)
+            C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+            arr = (_lib.GemmDesc * 1)(ops.gemm_desc(A, B, C, M, N, K))
+            L_.drn_gemm_nt_splitk_ws_elems.restype = ctypes.c_int64
+            ws = torch.full((int(L_.drn_gemm_nt_splitk_ws_elems(M, N, ks)),), float("nan"), dtype=torch.float32, device=dev())
+            counters = torch.zeros(2048, dtype=torch.int32, device=dev())
+            for _ in range(3):
+                _lib.check(L_.drn_gemm_nt_splitk(arr, ks, ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(counters.data_ptr()), ops.BF16,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "splitk")
+            torch.cuda.synchronize()
+            assert int(counters.abs().sum()) == 0
+            close(C, (A.float() @ B.float().t()).double().cpu(), 2e-2, "product")
+            outs.append([C.clone()])
+        else:
+            tune(monkeypatch, "nt_w4h", 1)
+            monkeypatch.setattr(ops, "KSPLIT_W4H", True)
+            res = []
+            for tapil in (2048, 0):
+                tune(monkeypatch, "w4h_tapil", tapil)
+                M, L, Cin, N = 512, 256, 2048, 128
+                A = rnd((M, Cin), 91, torch.bfloat16).to(dev())
+                W = (rnd((N, 3 * Cin), 92, torch.float32) * 0.02).to(torch.bfloat16).to(dev())
+                C = torch.full((M, N), 7.0, device=dev(), dtype=torch.bfloat16)
+                d = ops.gemm_desc(A, W, C, M, N, Cin, taps=3, pad=1, Lout=L, Lsrc=L)
+                assert ops._ksplit_w4h([d], ops.BF16) >= 2
+                ops.gemm_nt([d], ops.BF16)
+                torch.cuda.synchronize()
+                assert int(ops._counters(dev()).abs().sum()) == 0
+                res.append(C)
+            outs.append(res)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(ops, "_xchg_set", None)          # (the next launch re-applies the process's own setting)
+
+
 def test_deferred_wgrad_reduce_passes_in_one_launch_equal_the_immediate_ones():
     """drn_wgrad_defer / drn_wgrad_reduce_pending: three weight gradients (fused-tap k = 3, per-tap stride 2, a grouped multi launch)
     whose reduce passes run as ONE launch at the end give the bits of the launches that reduce themselves."""
