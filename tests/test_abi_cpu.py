@@ -123,3 +123,33 @@ def test_norm_pass_block_classes_are_host_logic():
         want[b] = 1
     want[10] = 2
     assert got == want, got
+
+
+def test_split_exchange_confirmation_policy_is_host_logic(monkeypatch):
+    """drn_amd.ops drives drn_tune("xchg_confirm") ("Exchange protocol"): library default on; "auto" clears it
+    while nobody has declared concurrency and sets it while somebody has (GradReducer with world_size > 1, the phases of the
+    two-branch steps that have the other branch beside them); DRN_XCHG_CONFIRM=1 / 0 force it."""
+    from drn_amd import ops
+    calls = []
+
+    class Lib(object):
+        def drn_tune(self, key, value):
+            calls.append((key, value))
+            return 0
+    monkeypatch.setattr(ops, "lib", lambda: Lib())
+    monkeypatch.setattr(ops, "XCHG_CONFIRM", "auto")
+    monkeypatch.setattr(ops, "_xchg_set", None)
+    monkeypatch.setattr(ops, "_xchg_need", 0)
+    ops._xchg_apply()
+    ops.xchg_need(+1)
+    ops.xchg_need(+1)
+    ops.xchg_need(-1)
+    ops.xchg_need(-1)
+    assert calls == [(b"xchg_confirm", 0), (b"xchg_confirm", 1), (b"xchg_confirm", 0)]       # (only changes reach the library)
+    monkeypatch.setattr(ops, "XCHG_CONFIRM", "1")
+    ops._xchg_apply()
+    monkeypatch.setattr(ops, "XCHG_CONFIRM", "0")
+    ops.xchg_need(+1)
+    ops.xchg_need(-1)
+    assert calls[3:] == [(b"xchg_confirm", 1), (b"xchg_confirm", 0)]
+    monkeypatch.setattr(ops, "_xchg_set", None)
