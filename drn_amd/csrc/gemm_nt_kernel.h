@@ -152,7 +152,7 @@ __device__ __forceinline__ void nt_fetch(const GemmParams& P, NtHeader& H, GemmP
   H.xcd_swizzle = (int)nt_rl(hv, (int)offsetof(GemmParams, xcd_swizzle) / 4);
   H.ksplit = (int)nt_rl(hv, (int)offsetof(GemmParams, ksplit) / 4);
   H.confirm = H.ksplit & DRN_XCHG_CONFIRM;
-  H.ksplit &= 0xffff;
+  H.ksplit &= ~DRN_XCHG_CONFIRM;        // (gemm_nt_w4h_kernel's own flag, W4H_TAPIL, stays)
   H.nblocks = (int)nt_rl(hv, (int)offsetof(GemmParams, nblocks) / 4);
   H.ws = (float*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, ws) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, ws) / 4));
   H.counters = (int*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, counters) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, counters) / 4));
