@@ -27,7 +27,12 @@ m = mainModel(VOCAB_SIZE, as_namespace(default_cfg("TINY" if D != 4096 else "C3D
 m.load_state_dict(seeded_state_dict(m, 0))
 m = m.to(dev).train()
 params = [p for p in m.parameters() if p.requires_grad]
-red = GradReducer(params, world_size=1, bucket_bytes=1 << 30, adjacent=m.grad_stack_groups())
+if os.environ.get("HUNT_ROTATE") == "1":          # optimizer-first order of the two-branch step (query side in buckets of its own)
+    qset = set(id(p) for p in m.query_parameters())
+    red = GradReducer(params, world_size=1, bucket_bytes=1 << 30, adjacent=m.grad_stack_groups(),
+                      groups=[[p for p in params if id(p) in qset], [p for p in params if id(p) not in qset]])
+else:
+    red = GradReducer(params, world_size=1, bucket_bytes=1 << 30, adjacent=m.grad_stack_groups())
 opt = FusedAdam(red, lr=0.0, max_norm=0.5)
 batch = [b.to(dev) for b in synthetic_batch(B, T, D, seed=1)]
 names = {id(p): n for n, p in m.named_parameters()}
