@@ -61,6 +61,7 @@ int drn_tuning(int key);
 // is followed by a returning agent-scope read-modify-write of its address before the workgroup takes its ticket -- needed whenever a
 // kernel of ANOTHER queue may run beside the launch (qdense.hip, skinny_group_kernel, has the measurements); ~6 us per launch.
 #define DRN_XCHG_CONFIRM 0x20000
+#define DRN_XCHG_READBACK 0x40000   // drn_tune "xchg_confirm" = 2: an sc1 load of every 64-byte request instead (cheaper; closed the window on the proven site just as well)
 #define DRN_TUNE_TN3_MINROWS 0
 #define DRN_TUNE_TN_FUSED 1
 #define DRN_TUNE_EXP0 3         // exp0..exp4: experiment overrides, 0 = shipped behaviour (scripts/experiments/ab_tune.sh A/Bs them inside

@@ -45,7 +45,8 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   GemmParams P;
   memset(&P, 0, sizeof(P));
   P.ngroups = ngroups;
-  P.ksplit = ksplit | (ksplit > 1 && counters && drn_tuning(DRN_TUNE_XCHG_CONFIRM) ? DRN_XCHG_CONFIRM : 0);
+  const int xc = ksplit > 1 && counters ? drn_tuning(DRN_TUNE_XCHG_CONFIRM) : 0;
+  P.ksplit = ksplit | (xc == 1 ? DRN_XCHG_CONFIRM : xc == 2 ? DRN_XCHG_READBACK : 0);
   P.ws = ws;
   P.counters = counters;
   P.xcd_swizzle = drn_exp_env("DRN_NO_XCD_SWIZZLE") ? 0 : 3;

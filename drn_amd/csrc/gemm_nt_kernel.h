@@ -151,8 +151,8 @@ __device__ __forceinline__ void nt_fetch(const GemmParams& P, NtHeader& H, GemmP
   H.ngroups = (int)nt_rl(hv, (int)offsetof(GemmParams, ngroups) / 4);
   H.xcd_swizzle = (int)nt_rl(hv, (int)offsetof(GemmParams, xcd_swizzle) / 4);
   H.ksplit = (int)nt_rl(hv, (int)offsetof(GemmParams, ksplit) / 4);
-  H.confirm = H.ksplit & DRN_XCHG_CONFIRM;
-  H.ksplit &= ~DRN_XCHG_CONFIRM;        // (gemm_nt_w4h_kernel's own flag, W4H_TAPIL, stays)
+  H.confirm = H.ksplit & (DRN_XCHG_CONFIRM | DRN_XCHG_READBACK);
+  H.ksplit &= ~(DRN_XCHG_CONFIRM | DRN_XCHG_READBACK);        // (gemm_nt_w4h_kernel's own flag, W4H_TAPIL, stays)
   H.nblocks = (int)nt_rl(hv, (int)offsetof(GemmParams, nblocks) / 4);
   H.ws = (float*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, ws) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, ws) / 4));
   H.counters = (int*)(((unsigned long long)nt_rl(hv, (int)offsetof(GemmParams, counters) / 4 + 1) << 32) | nt_rl(hv, (int)offsetof(GemmParams, counters) / 4));
@@ -1249,7 +1249,24 @@ __global__ __launch_bounds__(64 * WM * WN, (BNF && MI * NI == 8 && STAGES == 2) 
       // 64-byte request of every store (lanes 0, 4, 8, ...: four lanes share a request) -- a read-modify-write of the same address
       // is performed behind the store -- before the workgroup counts itself in.  Issued right behind the stores or after their
       // wait costs the same ~6 us per launch: it is the atomics' rate, not their latency.
-      if (P.confirm && (tid & 3) == 0) {
+      if ((P.confirm & DRN_XCHG_READBACK) && (tid & 3) == 0) {          // the cheaper variant: sc1 loads instead of read-modify-writes
+        unsigned b0, b1, b2, b3, b4, b5, b6, b7;
+        asm volatile(
+            "global_load_dword %0, %8, off sc1\n\t"
+            "global_load_dword %1, %9, off sc1\n\t"
+            "global_load_dword %2, %10, off sc1\n\t"
+            "global_load_dword %3, %11, off sc1\n\t"
+            "global_load_dword %4, %12, off sc1\n\t"
+            "global_load_dword %5, %13, off sc1\n\t"
+            "global_load_dword %6, %14, off sc1\n\t"
+            "global_load_dword %7, %15, off sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+            : "v"(slab), "v"(slab + NT), "v"(slab + 2 * NT), "v"(slab + 3 * NT), "v"(slab + 4 * NT), "v"(slab + 5 * NT),
+              "v"(slab + 6 * NT), "v"(slab + 7 * NT)
+            : "memory");
+      }
+      if ((P.confirm & DRN_XCHG_CONFIRM) && (tid & 3) == 0) {
         unsigned b0, b1, b2, b3, b4, b5, b6, b7;
         asm volatile(
             "global_atomic_or %0, %8, %16, off sc0 sc1\n\t"

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
   // split K (ksplit > 1): workgroup row y owns K-steps [k_lo, k_hi).  W4H_TAPIL (conv launches with a wide input): the K loop walks
   // (channel block, tap) instead of (tap, channel block) -- W4HT_LOOP_ASM -- and a split starts at a whole channel block
   const bool tapil = CONV && (P.ksplit & W4H_TAPIL) != 0;
-  P.ksplit &= W4H_TAPIL - 1;
+  P.ksplit &= W4H_TAPIL - 1;       // (the exchange flags DRN_XCHG_* were taken out by nt_fetch)
   const int ksteps_all = pr.K / 64;
   int kt_per = (ksteps_all + P.ksplit - 1) / P.ksplit;
   if (tapil) kt_per = (kt_per + 2) / 3 * 3;
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
     const unsigned lane_off = (unsigned)tid * 16u;
     asm volatile(W4H_PUBLISH_ASM : : [base] "s"(slab), [off] "v"(lane_off) : W4H_XCHG_CLOBBERS);
     if (P_arg.ksplit & DRN_XCHG_CONFIRM) asm volatile(W4H_CONFIRM_ASM : : [base] "s"(slab), [off] "v"(lane_off) : W4H_XCHG_CLOBBERS);
+    if (P_arg.ksplit & DRN_XCHG_READBACK) asm volatile(W4H_READBACK_ASM : : [base] "s"(slab), [off] "v"(lane_off) : W4H_XCHG_CLOBBERS);
     __syncthreads();
     int& s_last = *(int*)smem;
     if (tid == 0) {

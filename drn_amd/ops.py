@@ -167,14 +167,15 @@ def _ksplit_w4h(descs, dtype):
 
 
 # The in-launch split-K exchanges (partial tiles published write-through, a ticket, the last arriver sums) must CONFIRM their stores
-# -- a returning agent-scope read-modify-write per 64-byte request -- whenever a kernel of another queue may run beside the launch:
-# with one, the ticket overtook a partial about once in 10^5 launches of skinny_group_kernel (qdense.hip has the measurements; that
-# kernel and the loss kernel always confirm, it costs them nothing).  For the GEMM kernels the confirmation costs ~6 us per split
-# launch (+76 us per step at T = 256), so they do it on demand: drn_tune "xchg_confirm" (library default 1 = always), driven from
-# here -- "auto": while somebody has declared concurrency (GradReducer with world_size > 1: RCCL kernels beside backward;
-# DualStreamStep / ForkedStep: every phase that has the other branch beside it, i.e. all but the trunk), and not in a strictly
-# single-queue step, where nothing can be beside the launch (30 k + 12 k checked replays of the linear graph, no event).
-# DRN_XCHG_CONFIRM=1 / 0 forces it.
+# before the ticket whenever a kernel of another queue may run beside the launch: with one, the ticket overtook a partial about once
+# in 10^5 launches of skinny_group_kernel inside the replayed two-branch graph (qdense.hip has the measurements; that kernel and the
+# loss kernel always confirm with a returning read-modify-write per stored address, it costs them nothing).  The GEMM kernels'
+# exchanges have never shown the window; they confirm on demand (drn_tune "xchg_confirm": 0 off, 1 = a returning atomic per 64-byte
+# request, +20-23 us on conv0's forward, +76 us per step at T = 256; 2 = an sc1 load of every request instead, +2-3 us on conv0's
+# forward -- the variant that also closed the window on the proven kernel, 0 events in 120 k replays against 7).  Library default 1;
+# from here "auto": 2 while somebody has declared concurrency (GradReducer with world_size > 1: RCCL kernels beside backward;
+# DualStreamStep / ForkedStep: every phase that has the other branch beside it, i.e. all but the trunk), 0 in a strictly single-queue
+# step, where nothing can be beside the launch.  DRN_XCHG_CONFIRM=0 / 1 / 2 forces a mode everywhere.
 XCHG_CONFIRM = os.environ.get("DRN_XCHG_CONFIRM", "auto")
 _xchg_need = 0
 _xchg_set = None
@@ -189,7 +190,7 @@ def xchg_need(delta):
 
 def _xchg_apply():
     global _xchg_set
-    want = 1 if XCHG_CONFIRM == "1" or (XCHG_CONFIRM != "0" and _xchg_need > 0) else 0
+    want = int(XCHG_CONFIRM) if XCHG_CONFIRM in ("0", "1", "2") else (2 if _xchg_need > 0 else 0)
     if want != _xchg_set:
         check(lib().drn_tune(b"xchg_confirm", want), "drn_tune")
         _xchg_set = want

@@ -31,9 +31,9 @@ int drn_abi_version(void);
  * general 8-wave kernel also for the large plain bf16 products that gemm_nt_w4_kernel takes by default; results are bit-identical
  * either way), "nt_w4c" (the same for the k = 3 / stride 1 convolutions on 256x256 tiles and gemm_nt_w4c_kernel), "nt_deep",
  * "exp0".."exp4" (launch heuristics, 0 = shipped), "xchg_confirm" (default 1: the in-launch split-K exchanges of drn_gemm_nt_splitk* and
- * of the w4h kernel confirm every partial-tile store with a returning atomic on its address before the ticket -- required whenever a
- * kernel of another queue may run beside the launch; 0 saves ~6 us per split launch and is safe ONLY for single-queue execution;
- * values are the same either way).  The library never reads the environment (the
+ * of the w4h kernel confirm every partial-tile store with a returning atomic on its address before the ticket -- for callers whose
+ * launches may have a kernel of another queue beside them; 2: an sc1 load of every stored 64-byte request instead, a tenth of the
+ * cost; 0: nothing, for strictly single-queue execution; values are the same in every mode).  The library never reads the environment (the
  * experiment build `make EXPERIMENTS=1` does). */
 int drn_tune(const char* key, int value);
 const char* drn_last_error(void); /* thread-local, valid until the next failing call on this thread */

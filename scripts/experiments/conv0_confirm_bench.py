@@ -34,10 +34,10 @@ def timed(n=40):
 for rnd in range(2):
     for tapil in (2048, 0):
         _lib.lib().drn_tune(b"w4h_tapil", tapil)
-        for conf in (("0", "1") if os.environ.get("BASE_LIB") != "1" else ("base",)):
+        for conf in (("0", "1", "2") if os.environ.get("BASE_LIB") != "1" else ("base",)):
             if conf != "base":
-                ops.XCHG_CONFIRM = conf
-                ops._xchg_set = None
+                ops._xchg_apply = lambda: None
+                _lib.lib().drn_tune(b"xchg_confirm", int(conf))
             else:
                 ops._xchg_apply = lambda: None          # (a library from before the flag)
             print("round %d tapil %4d confirm %s: %.1f us" % (rnd, tapil, conf, timed()), flush=True)

@@ -430,6 +430,13 @@ with open(args.out, "w") as f:
         conf.append("global_atomic_or v%d, %%[off], v113, s[80:81] sc0 sc1" % (128 + g))
         conf += bump(80)
     conf += ["s_mov_b64 exec, -1", "s_waitcnt vmcnt(0)"]
+    # READ-BACK (W4H_READBACK_ASM, DRN_XCHG_READBACK): the cheaper confirmation -- an sc1 LOAD of the first dword of every 64-byte
+    # request instead of the read-modify-write (no second write, no atomic unit)
+    rdb = ["s_mov_b64 s[80:81], %[base]", "s_mov_b32 s82, 0x11111111", "s_mov_b32 s83, 0x11111111", "s_mov_b64 exec, s[82:83]"]
+    for g in range(32):
+        rdb.append("global_load_dword v%d, %%[off], s[80:81] sc1" % (128 + g))
+        rdb += bump(80)
+    rdb += ["s_mov_b64 exec, -1", "s_waitcnt vmcnt(0)"]
     def loads(v0):
         out = []
         for g in range(16):
@@ -459,7 +466,7 @@ with open(args.out, "w") as f:
     gat.append("s_waitcnt vmcnt(0)")
     gat += add(192, 64)
     gat.append("s_nop 4")
-    for name, lines in (("W4H_PUBLISH_ASM", pub), ("W4H_CONFIRM_ASM", conf), ("W4H_GATHER_ASM", gat)):
+    for name, lines in (("W4H_PUBLISH_ASM", pub), ("W4H_CONFIRM_ASM", conf), ("W4H_READBACK_ASM", rdb), ("W4H_GATHER_ASM", gat)):
         f.write("// %s: %d instructions\n" % (name, len(lines)))
         f.write("#define %s \\\n" % name)
         for ln in lines:

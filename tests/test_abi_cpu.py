@@ -128,7 +128,7 @@ def test_norm_pass_block_classes_are_host_logic():
 def test_split_exchange_confirmation_policy_is_host_logic(monkeypatch):
     """drn_amd.ops drives drn_tune("xchg_confirm") ("Exchange protocol"): library default on; "auto" clears it
     while nobody has declared concurrency and sets it while somebody has (GradReducer with world_size > 1, the phases of the
-    two-branch steps that have the other branch beside them); DRN_XCHG_CONFIRM=1 / 0 force it."""
+    two-branch steps that have the other branch beside them) -- to 2, the read-back variant; DRN_XCHG_CONFIRM=0 / 1 / 2 force a mode."""
     from drn_amd import ops
     calls = []
 
@@ -145,7 +145,7 @@ def test_split_exchange_confirmation_policy_is_host_logic(monkeypatch):
     ops.xchg_need(+1)
     ops.xchg_need(-1)
     ops.xchg_need(-1)
-    assert calls == [(b"xchg_confirm", 0), (b"xchg_confirm", 1), (b"xchg_confirm", 0)]       # (only changes reach the library)
+    assert calls == [(b"xchg_confirm", 0), (b"xchg_confirm", 2), (b"xchg_confirm", 0)]       # (only changes reach the library; 2 = read-back)
     monkeypatch.setattr(ops, "XCHG_CONFIRM", "1")
     ops._xchg_apply()
     monkeypatch.setattr(ops, "XCHG_CONFIRM", "0")

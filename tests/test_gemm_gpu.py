@@ -918,14 +918,15 @@ def test_w4h_kernel_splitk_in_launch(monkeypatch, shape):
 @pytest.mark.parametrize("kind", ["general", "w4h"])
 def test_split_exchange_confirmation_changes_no_bits(monkeypatch, kind):
     """drn_tune "xchg_confirm" (ops.xchg_need: set while another queue's kernels may run beside the launch): every partial-tile store
-    of the in-launch split-K exchange is followed by a returning OR-with-zero on its address before the ticket.  Values untouched:
+    of the in-launch split-K exchange is followed by a returning OR-with-zero on its address (1) or an sc1 load of it (2) before the
+    ticket.  Values untouched:
     the launch with and without it gives the same bits, counters re-armed, for the general 128 x 128 kernel and for gemm_nt_w4h_kernel
     (tap-interleaved and plain)."""
     import ctypes
     from drn_amd import ops, _lib
     L_ = _lib.lib()
     outs = []
-    for confirm in (1, 0, 1):
+    for confirm in (1, 0, 2):                    # returning atomics / nothing / sc1 read-back
         monkeypatch.setattr(ops, "XCHG_CONFIRM", str(confirm))
         monkeypatch.setattr(ops, "_xchg_set", None)
         ops._xchg_apply()
