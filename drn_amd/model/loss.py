@@ -33,6 +33,12 @@ class FCOSLossComputation(object):
 
     def __call__(self, locations, box_cls, box_regression, targets, iou_scores, is_first_stage=True):
         B = box_cls[0].size(0)
+        if B == 1 and not is_first_stage:
+            # model/loss.py:186,192: `squeeze()` drops the batch dimension of the IoU scores when there is one clip, and indexing the
+            # (sumL,) result with the (1, sumL) mask raises -- in train AND eval mode (model/fcos.py:176 calls the evaluator there
+            # too), with or without a tIoU > 0.9 positive.  Same exception, same text (tests/golden/errors.json, recorded from the
+            # reference): the kernels below would compute the "intended" value, which the reference never produced.
+            raise IndexError("too many indices for tensor of dimension 1")
         if self.fpn_strides is not None:
             strides = [float(s) for s in self.fpn_strides[:len(locations)]]
         else:                                                            # generic callers: read them back (host sync)

@@ -269,11 +269,14 @@ class FCOSLoss(object):
             iou_t = segment_tiou(pred, targets[:, None, :])
             iou_p = torch.cat(iou_scores, dim=-1).squeeze().sigmoid()       # A.3 #4
             mask = iou_t > 0.9
+            # loss.py:189-192 index BEFORE the empty check: with B == 1 `squeeze()` has dropped the batch dimension of iou_p and the
+            # (1, sumL) mask raises IndexError whether or not a positive exists (tests/golden/errors.json records the reference doing so)
+            pos_t, pos_p = iou_t[mask], iou_p[mask]
             if int(mask.sum()) == 0:
                 iou_loss = torch.tensor([0])                               # A.3 #3
             else:
                 # target keeps its graph (A.3 #2)
-                iou_loss = F.smooth_l1_loss(iou_p[mask], iou_t[mask])
+                iou_loss = F.smooth_l1_loss(pos_p, pos_t)
 
         pos = torch.nonzero(labels > 0).squeeze(1)
         cls_loss = sigmoid_focal_loss_sum(cls_flat, labels.int(), self.gamma, self.alpha) / (pos.numel() + N)

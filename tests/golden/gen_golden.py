@@ -66,8 +66,10 @@ TAPS = ["prop_fc", "backbone_net.forward_conv0", "backbone_net.forward_conv1", "
         "fpn.fpn_layer1", "fpn.fpn_layer2", "fpn.fpn_layer3"]
 
 
-def matched_gt(m, batch):
-    """Pick GT = one of the model's own train-mode predictions so tIoU>0.9 positives exist."""
+def matched_gt(m, batch, loc0=False):
+    """Pick GT = one of the model's own train-mode predictions so tIoU>0.9 positives exist.  loc0: match every clip at location
+    index 0, the one location model/loss.py:180-181 clamps -- its raw start (0.5 - reg) / 32 is negative, so the clamp is ACTIVE
+    on a tIoU > 0.9 positive (it decides the target and zeroes the start's gradient)."""
     state = {k: v.clone() for k, v in m.state_dict().items()}
     caught = {}
     def grab(mod, i, o):
@@ -83,8 +85,10 @@ def matched_gt(m, batch):
     B, _, T = reg0.shape
     gt = []
     for b in range(B):
-        t = (5 + 7 * b) % T
+        t = 0 if loc0 else (5 + 7 * b) % T
         loc = t + 0.5
+        if loc0:
+            assert loc - reg0[b, 0, t].item() < 0.0, "loc0 case: the raw start must be negative for the clamp to act"
         s = max((loc - reg0[b, 0, t].item()) / 32.0, 0.0)
         e = min((loc + reg0[b, 1, t].item()) / 32.0, 1.0)
         # shrink by 1.5 % per side: tIoU stays ~0.97 (> 0.9) but pred != gt, so no exact min/max ties --
@@ -94,7 +98,7 @@ def matched_gt(m, batch):
     return torch.tensor(gt, dtype=torch.float64)
 
 
-def run_case(name, B, T, D, stage, train=True, match=False, num_class=None):
+def run_case(name, B, T, D, stage, train=True, match=False, num_class=None, loc0=False):
     ftype = "C3D" if D == 4096 else "TINY"
     cfg = default_cfg(ftype, D, stage)
     if num_class is not None:                              # model/fcos.py:27,43: cls_logits gets fcos_num_class - 1 channels
@@ -102,7 +106,7 @@ def run_case(name, B, T, D, stage, train=True, match=False, num_class=None):
     m = build_reference(cfg, seed=0)
     batch = list(synthetic_batch(B, T, D, seed=1))
     if match:
-        batch[4] = matched_gt(m, batch)
+        batch[4] = matched_gt(m, batch, loc0=loc0)
     out = {"B": B, "T": T, "D": D, "stage": stage, "train": int(train), "gt": batch[4].numpy()}
     if num_class is not None:
         out["num_class"] = num_class
@@ -158,6 +162,37 @@ def run_case(name, B, T, D, stage, train=True, match=False, num_class=None):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, {k: out[k] for k in ("loss_cls", "loss_reg", "loss_iou")},
           "npos_iou" if stage != 1 else "", flush=True)
+
+
+def run_error_cases():
+    """Inputs the reference REJECTS: with one clip per batch in stages 2 / 3, `squeeze()` (model/loss.py:186) drops the batch
+    dimension of iou_pred and indexing it with the (1, sumL) mask raises (model/loss.py:192) -- whether or not a tIoU > 0.9
+    positive exists.  Stage 1 and eval mode with B = 1 run.  Recorded: exception type + message, and that the stage-1 / eval runs pass."""
+    import json
+    out = []
+    for stage, train, match in ((3, True, True), (2, True, False), (1, True, False), (3, False, False)):
+        cfg = default_cfg("TINY", 64, stage)
+        m = build_reference(cfg, seed=0)
+        batch = list(synthetic_batch(1, 32, 64, seed=1))
+        if match:                                            # (matched through the stage-1 twin: same seeded weights, and it runs)
+            batch[4] = matched_gt(build_reference(default_cfg("TINY", 64, 1), seed=0), batch)
+        m.train(train)
+        rec = {"B": 1, "T": 32, "D": 64, "stage": stage, "train": int(train), "gt": batch[4].numpy().tolist()}
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                _, losses = m(*batch)
+                rec["error"] = None
+                rec["losses"] = {k: float(v.reshape(-1)[0]) for k, v in losses.items()} if train else None
+            except Exception as e:                           # noqa: BLE001 -- the point is to record what the reference raises
+                rec["error"], rec["message"] = type(e).__name__, str(e)
+            finally:
+                os.chdir(cwd)
+        out.append(rec)
+        print("error case", {k: rec[k] for k in ("stage", "train", "error")}, flush=True)
+    with open(os.path.join(HERE, "errors.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 def run_lgp():
@@ -424,6 +459,11 @@ if __name__ == "__main__":
         run_case("tiny_k3_eval", 2, 32, 64, 3, train=False, num_class=4)
         run_case("tiny_k2_s3", 2, 32, 64, 3, match=True, num_class=3)      # two channels: one head call, no chunking
         sys.exit(0)
+    if sys.argv[1:] == ["loc0"]:                           # round 6: active clamp (loss.py:180-181) and B = 1 (squeeze, loss.py:186)
+        run_case("tiny_s3_loc0", 2, 32, 64, 3, match=True, loc0=True)
+        run_case("tiny_s2_loc0", 2, 32, 64, 2, match=True, loc0=True)
+        run_error_cases()
+        sys.exit(0)
     if sys.argv[1:] == ["layers"]:
         run_layers()
         sys.exit(0)
@@ -450,6 +490,9 @@ if __name__ == "__main__":
     run_case("tiny_k3_s3", 2, 32, 64, 3, match=True, num_class=4)
     run_case("tiny_k3_eval", 2, 32, 64, 3, train=False, num_class=4)
     run_case("tiny_k2_s3", 2, 32, 64, 3, match=True, num_class=3)
+    run_case("tiny_s3_loc0", 2, 32, 64, 3, match=True, loc0=True)
+    run_case("tiny_s2_loc0", 2, 32, 64, 2, match=True, loc0=True)
+    run_error_cases()
     run_lgp()
     run_layers()
     run_metrics()

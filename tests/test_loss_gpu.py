@@ -8,7 +8,7 @@ from oracle import drn_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def make_case(B, T, seed, matched):
+def make_case(B, T, seed, matched, loc0=False):
     g = torch.Generator().manual_seed(seed)
     Ls = [T, T // 2, T // 4]
     strides = [1, 2, 4]
@@ -19,19 +19,36 @@ def make_case(B, T, seed, matched):
     if matched:     # GT equal to one prediction per clip -> tIoU>0.9 positives with exact ties
         rows = []
         for b in range(B):
-            t = (3 + 5 * b) % T
+            # loc0: location index 0 of level 0, the one model/loss.py:180-181 clamps; its raw start (0.5 - reg) / 32 is made
+            # negative for every clip, so the clamp decides the target of a tIoU > 0.9 positive and zeroes d tIoU / d start there
+            t = 0 if loc0 and b % 2 == 0 else (3 + 5 * b) % T
+            if t == 0:
+                reg[0][b, 0, 0] = 0.9 + 0.3 * b
             loc = t + 0.5
-            rows.append([max((loc - reg[0][b, 0, t].item()) / 32.0, 0.0), min((loc + reg[0][b, 1, t].item()) / 32.0, 1.0)])
+            s, e = max((loc - reg[0][b, 0, t].item()) / 32.0, 0.0), min((loc + reg[0][b, 1, t].item()) / 32.0, 1.0)
+            if loc0:        # shrink the GT by 1.5 % per side: no exact min / max ties, so d tIoU / d pred is O(1 / width) -- with an
+                s, e = s + 0.015 * (e - s), e - 0.015 * (e - s)     # exact match it vanishes and the clamp's gradient mask would go unseen
+            rows.append([s, e])
         gt = torch.tensor(rows, dtype=torch.float64).float()
     locs = [O.FCOSModule.locations_for(L, s, "cpu") for L, s in zip(Ls, strides)]
     return Ls, strides, logits, reg, iou, gt, locs
 
 
 @pytest.mark.parametrize("B,T,stage,matched,seed", [(2, 32, 1, False, 0), (3, 32, 3, True, 1), (4, 64, 3, True, 2),
-                                                    (2, 32, 3, False, 3), (5, 256, 3, True, 4)])
+                                                    (2, 32, 3, False, 3), (5, 256, 3, True, 4),
+                                                    (4, 32, 3, "loc0", 5), (3, 64, 2, "loc0", 6), (6, 256, 3, "loc0", 7)])
 def test_loss_fwd_bwd(B, T, stage, matched, seed):
     from drn_amd import functional as DF
-    Ls, strides, logits, reg, iou, gt, locs = make_case(B, T, seed, matched)
+    Ls, strides, logits, reg, iou, gt, locs = make_case(B, T, seed, bool(matched), loc0=matched == "loc0")
+    if matched == "loc0":
+        # the case is only worth its name if the clamp changes a positive's prediction: raw start < 0 at location 0, tIoU > 0.9 there
+        for b in range(0, B, 2):
+            raw = (0.5 - reg[0][b, 0, 0].item()) / 32.0
+            assert raw < 0.0
+            pred = torch.tensor([[0.0, min((0.5 + reg[0][b, 1, 0].item()) / 32.0, 1.0)]])
+            assert float(O.segment_tiou(pred, gt[b:b + 1])) > 0.9
+            unclamped = torch.tensor([[raw, pred[0, 1].item()]])
+            assert float(O.segment_tiou(unclamped, gt[b:b + 1])) < float(O.segment_tiou(pred, gt[b:b + 1])) - 1e-3
     cfg = {"fcos_loss_gamma": 2.0, "fcos_loss_alpha": 0.25}
     lr = [x.clone().requires_grad_() for x in logits]
     rr = [x.clone().requires_grad_() for x in reg]

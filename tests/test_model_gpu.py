@@ -19,7 +19,8 @@ def gpu_batch(batch):
 
 
 @pytest.mark.parametrize("name", ["tiny_s1", "tiny_s3", "tiny_s2", "c3d_s1", "c3d_s3", "tiny_eval", "tiny_eval_s1",
-                                  "tiny_k3_s1", "tiny_k3_s3", "tiny_k3_eval", "tiny_k2_s3"])       # k3: three foreground channels (fcos_num_class = 4)
+                                  "tiny_k3_s1", "tiny_k3_s3", "tiny_k3_eval", "tiny_k2_s3",        # k3: three foreground channels (fcos_num_class = 4)
+                                  "tiny_s3_loc0", "tiny_s2_loc0"])   # GT matched at location 0: model/loss.py:180-181's clamp is ACTIVE on a positive
 def test_hip_model_matches_reference_golden(name):
     from drn_amd.model import mainModel
     g = load_golden(name)
@@ -34,6 +35,28 @@ def test_hip_model_matches_reference_golden(name):
     # a layer gradient by ~1/sqrt(#elements) ~ 3e-3 rel-L2 (DESIGN.md "parity"); tests/test_functional_gpu.py pins
     # every stage's backward at 3e-5 on identical inputs instead.
     run_and_compare(m, g, gpu_batch(batch), atol=1e-4, grad_rtol=1e-3 if int(g["D"]) == 64 else 1e-2, tap_names=GPU_TAPS)
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_hip_model_rejects_what_the_reference_rejects(i):
+    """tests/golden/errors.json (recorded from the reference): one clip per batch in stages 2 / 3 raises IndexError in train and eval
+    mode (model/loss.py:186 squeeze, :192 mask indexing); stage 1 with one clip runs and matches."""
+    import json, os
+    from helpers import GOLDEN_DIR
+    from drn_amd.model import mainModel
+    from drn_amd.utils.synthetic import default_cfg, synthetic_batch
+    rec = json.load(open(os.path.join(GOLDEN_DIR, "errors.json")))[i]
+    m = build_model(mainModel, default_cfg("TINY", rec["D"], rec["stage"]), device="cuda:0")
+    batch = list(synthetic_batch(rec["B"], rec["T"], rec["D"], seed=1))
+    batch[4] = torch.tensor(rec["gt"], dtype=torch.float64)
+    m.train(bool(rec["train"]))
+    if rec["error"] is None:
+        _, losses = m(*gpu_batch(batch))
+        for k, v in rec["losses"].items():
+            assert abs(float(losses[k].reshape(-1)[0]) - v) <= 1e-4, k
+    else:
+        with pytest.raises(IndexError, match=rec["message"]):
+            m(*gpu_batch(batch))
 
 
 def test_missing_library_fails_loudly(monkeypatch):
