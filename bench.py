@@ -402,7 +402,7 @@ def main():
                             gkw = {"groups": [[p for p in params_f if id(p) in qp], [p for p in params_f if id(p) not in qp]]}
                         reducer_f = ddist.GradReducer(params_f, world_size=1, overlap=True, adjacent=model_f.grad_stack_groups(),
                                                       bucket_bytes=1 << 30, **gkw)
-                        forked = ForkedStep(model_f, batch[:5], loss_of, reducer_f, _FA(reducer_f, lr=1e-3, max_norm=0.5)).warm(
+                        forked = ForkedStep(model_f, batch[:5], loss_of, reducer_f, _FA(reducer_f, lr=1e-3, max_norm=0.5), rotate=bool(gkw)).warm(
                             max(args.warmup, 2)).capture()
 
                         def probe(fn, n=12):

@@ -104,6 +104,20 @@ class HeadCall(ctypes.Structure):
                 ("z", c_void_p), ("dout", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("dscale", c_void_p), ("ws", c_void_p)]
 
 
+WGRAD_PEND_MAX = 24
+
+
+class WgradPendItem(ctypes.Structure):
+    _fields_ = [("ws", c_void_p), ("out", c_void_p), ("nsplit", c_int32), ("N", c_int32), ("Cin", c_int32), ("taps", c_int32),
+                ("w_layout", c_int32), ("accumulate", c_int32)]
+
+
+class WgradPending(ctypes.Structure):
+    """DrnWgradPending (include/drn_hip.h): the caller-owned list of deferred weight-gradient reduces."""
+    _fields_ = [("it", WgradPendItem * WGRAD_PEND_MAX), ("blk_start", c_int32 * (WGRAD_PEND_MAX + 1)), ("n", c_int32),
+                ("sumsq", c_void_p)]
+
+
 class AdamTiledItem(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("off", c_int64), ("m1", c_void_p), ("m2", c_void_p), ("ld1", c_int64), ("ld2", c_int64),
                 ("R", c_int32), ("C", c_int32), ("k", c_int32), ("code1", c_int32), ("code2", c_int32), ("tiles_c", c_int32)]

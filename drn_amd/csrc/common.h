@@ -57,11 +57,14 @@ static inline const char* drn_exp_env(const char*) { return nullptr; }
 // Two tuning values tests need (force the fused-tap weight-gradient kernel on small shapes / switch it off): set explicitly
 // through drn_tune(), process-wide, not read from the environment.
 int drn_tuning(int key);
-// Flag in GemmParams::ksplit (set by launch_nt from drn_tune "xchg_confirm"): every partial-tile store of the in-launch split-K exchange
-// is followed by a returning agent-scope read-modify-write of its address before the workgroup takes its ticket -- needed whenever a
-// kernel of ANOTHER queue may run beside the launch (qdense.hip, skinny_group_kernel, has the measurements); ~6 us per launch.
+// Flags in GemmParams::ksplit (= the public DRN_KSPLIT_CONFIRM_* bits of the `ksplit` argument of drn_gemm_nt_splitk*, include/drn_hip.h;
+// launch_nt maps "no bit" to READBACK): how a split confirms its partial-tile stores before it takes its ticket.  CONFIRM: a returning
+// agent-scope read-modify-write of every stored address (~6 us per launch, +76 us per step); READBACK (the default): an sc1 load of every
+// 64-byte request (+12 us per step) -- needed whenever a kernel of ANOTHER queue may run beside the launch (qdense.hip,
+// skinny_group_kernel, has the measurements), and a caller cannot prove a single queue from where it stands, so it is what ships.
 #define DRN_XCHG_CONFIRM 0x20000
-#define DRN_XCHG_READBACK 0x40000   // drn_tune "xchg_confirm" = 2: an sc1 load of every 64-byte request instead (cheaper; closed the window on the proven site just as well)
+#define DRN_XCHG_READBACK 0x40000
+#define DRN_XCHG_NONE 0x80000     // (request bit only: never reaches a kernel)
 #define DRN_TUNE_TN3_MINROWS 0
 #define DRN_TUNE_TN_FUSED 1
 #define DRN_TUNE_EXP0 3         // exp0..exp4: experiment overrides, 0 = shipped behaviour (scripts/experiments/ab_tune.sh A/Bs them inside
@@ -72,7 +75,6 @@ int drn_tuning(int key);
 #define DRN_TUNE_NT_DEEP 2       // > 0: 128x128 NT launches of at most that many workgroups run the 4-slot ring (one workgroup per CU)
 #define DRN_TUNE_NT_W4H 12       // > 0 (160; 128 loses at T = 32, where prop_fc makes 128 such tiles: 1.234 vs 1.220 ms): eligible bf16 launches that would run 128x128 tiles and make at least that many 256x128 tiles run gemm_nt_w4h_kernel
 #define DRN_TUNE_BN1_MAXWG 13   // drn_bn_bwd_one: the smallest row block whose grid is at most this many workgroups (512)
-#define DRN_TUNE_XCHG_CONFIRM 15  // 1 (default): the in-launch split-K exchanges of the GEMM kernels confirm their partial stores before the ticket (DRN_XCHG_CONFIRM below)
 #define DRN_TUNE_W4H_TAPIL 14   // > 0: split k = 3 launches of gemm_nt_w4h_kernel with at least that many input channels walk K as (channel block, tap)
 #define DRN_TUNE_NT_DEEP2 10     // > 0: ... and launches of at most THAT many workgroups too when no tile has more than DRN_TUNE_NT_DEEP_KS K-steps (the FPN
 #define DRN_TUNE_NT_DEEP_KS 11   // laterals: 448 tiles of 4-16 K-steps each, where a tile is its own load latency: three K-steps in flight instead of one)

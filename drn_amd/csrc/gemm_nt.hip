@@ -17,8 +17,11 @@ static int nt_kind(const DrnGemmDesc* d, int ngroups, int dtype, int tile, int k
   return tile == 256 ? DRN_NT_KIND_TILE256 : DRN_NT_KIND_TILE128;
 }
 
-static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit = 1, float* ws = nullptr,
+static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t stream, int ksplit_arg = 1, float* ws = nullptr,
                      int* counters = nullptr, bool planes256 = false, bool plan_only = false) {
+  // (the public `ksplit` argument: split count in the low 16 bits + DRN_KSPLIT_CONFIRM_* request bits, include/drn_hip.h)
+  const int ksplit = ksplit_arg & 0xffff;
+  const int xchg = ksplit_arg & (DRN_XCHG_CONFIRM | DRN_XCHG_NONE);
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_nt: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_nt: bad dtype %d", dtype);
   const int ch = dtype == DRN_BF16 ? 8 : 4;
@@ -45,8 +48,8 @@ static int launch_nt(const DrnGemmDesc* d, int ngroups, int dtype, hipStream_t s
   GemmParams P;
   memset(&P, 0, sizeof(P));
   P.ngroups = ngroups;
-  const int xc = ksplit > 1 && counters ? drn_tuning(DRN_TUNE_XCHG_CONFIRM) : 0;
-  P.ksplit = ksplit | (xc == 1 ? DRN_XCHG_CONFIRM : xc == 2 ? DRN_XCHG_READBACK : 0);
+  // in-launch exchanges confirm their stores by read-back unless the CALL says otherwise (per launch: no process-wide switch)
+  P.ksplit = ksplit | (ksplit > 1 && counters ? (xchg & DRN_XCHG_NONE ? 0 : xchg & DRN_XCHG_CONFIRM ? DRN_XCHG_CONFIRM : DRN_XCHG_READBACK) : 0);
   P.ws = ws;
   P.counters = counters;
   P.xcd_swizzle = drn_exp_env("DRN_NO_XCD_SWIZZLE") ? 0 : 3;
@@ -182,6 +185,7 @@ extern "C" int drn_gemm_nt_plan(const DrnGemmDesc* descs, int ngroups, int dtype
 
 extern "C" int drn_gemm_nt_splitk_plan(const DrnGemmDesc* descs, int ngroups, int ksplit, int dtype) {
   drn_clear_status();
+  ksplit &= 0xffff;
   DRN_CHECK_ARG(ksplit >= 1 && ksplit <= 64, "drn_gemm_nt_splitk_plan: bad ksplit");
   static float dummy_ws;           // (plan only: non-null workspace / counters so that the split kernels' preconditions read as met)
   static int dummy_cnt;
@@ -200,24 +204,28 @@ extern "C" int64_t drn_gemm_nt_splitk_ws_elems(int M, int N, int ksplit) {
 // The same for a GROUPED launch (pyramid levels / independent problems of one launch): workspace and counters are indexed by the
 // launch-wide tile number, every problem splits its own K range `ksplit` ways.  Short sequences (Charades-STA's 32 proposals:
 // 14-56 tiles per grouped launch on 256 CUs) are where this pays.  ws >= ksplit * (sum of 128x128 tiles) * 16384 floats.
-extern "C" int drn_gemm_nt_splitk_grouped(const DrnGemmDesc* descs, int ngroups, int ksplit, float* ws, int32_t* counters, int dtype,
+extern "C" int drn_gemm_nt_splitk_grouped(const DrnGemmDesc* descs, int ngroups, int ksplit_arg, float* ws, int32_t* counters, int dtype,
                                           void* stream) {
   drn_clear_status();
+  const int ksplit = ksplit_arg & 0xffff;
+  DRN_CHECK_ARG(!(ksplit_arg & ~(0xffff | DRN_XCHG_CONFIRM | DRN_XCHG_NONE)), "drn_gemm_nt_splitk_grouped: unknown bits in ksplit");
   DRN_CHECK_ARG(descs && ngroups >= 1 && ngroups <= DRN_MAX_GROUPS && ksplit >= 1 && ksplit <= 64 && (ksplit == 1 || (ws && counters)),
                 "drn_gemm_nt_splitk_grouped: bad groups/ksplit/workspace/counters");
   long tiles = 0;
   for (int g = 0; g < ngroups; ++g) tiles += (long)cdiv(descs[g].M, 128) * cdiv(descs[g].N, 128);
   DRN_CHECK_ARG(ksplit == 1 || (tiles <= DRN_QD_COUNTERS && (((uintptr_t)ws) & 15) == 0),
                 "drn_gemm_nt_splitk_grouped: more than %d output tiles or unaligned workspace", DRN_QD_COUNTERS);
-  return launch_nt(descs, ngroups, dtype, (hipStream_t)stream, ksplit, ws, (int*)counters);
+  return launch_nt(descs, ngroups, dtype, (hipStream_t)stream, ksplit_arg, ws, (int*)counters);
 }
 
-extern "C" int drn_gemm_nt_splitk(const DrnGemmDesc* desc, int ksplit, float* ws, int32_t* counters, int dtype, void* stream) {
+extern "C" int drn_gemm_nt_splitk(const DrnGemmDesc* desc, int ksplit_arg, float* ws, int32_t* counters, int dtype, void* stream) {
   drn_clear_status();
+  const int ksplit = ksplit_arg & 0xffff;
+  DRN_CHECK_ARG(!(ksplit_arg & ~(0xffff | DRN_XCHG_CONFIRM | DRN_XCHG_NONE)), "drn_gemm_nt_splitk: unknown bits in ksplit");
   DRN_CHECK_ARG(desc && ksplit >= 1 && ksplit <= 64 && (ksplit == 1 || (ws && counters)), "drn_gemm_nt_splitk: bad ksplit/workspace/counters");
   DRN_CHECK_ARG(ksplit == 1 || (cdiv(desc->M, 128) * cdiv(desc->N, 128) <= DRN_QD_COUNTERS && (((uintptr_t)ws) & 15) == 0),
                 "drn_gemm_nt_splitk: more than %d output tiles or unaligned workspace", DRN_QD_COUNTERS);
-  return launch_nt(desc, 1, dtype, (hipStream_t)stream, ksplit, ws, (int*)counters);
+  return launch_nt(desc, 1, dtype, (hipStream_t)stream, ksplit_arg, ws, (int*)counters);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -741,30 +741,26 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 
 // ---- deferred reduce passes.  Inside a training step six weight-gradient launches each ended with their own reduce launch
 // (wgrad_reduce*: 7-13 us apiece, most of it the launch floor and the ramp of a 2000-workgroup streaming pass over 10-50 MB).
-// With drn_wgrad_defer(1) the GEMM launches only record what their reduce would have been; drn_wgrad_reduce_pending() then runs
-// ALL of them as ONE launch -- same per-element summation order over the splits, so the same bits.  The caller keeps the workspaces
-// alive until then and must flush before anything reads the gradients (drn_amd.dist.GradReducer.collect does).
-struct WgradPendItem {
-  const float* ws;
-  float* out;
-  int nsplit, N, Cin, taps, w_layout, accumulate;
-};
-#define WGRAD_PEND_MAX 24
-struct WgradPendParams {
-  WgradPendItem it[WGRAD_PEND_MAX];
-  int blk_start[WGRAD_PEND_MAX + 1];
-  int n;
-  float* sumsq;     // or NULL: [gridDim.x] sum of the squares of what each workgroup wrote
-};
-// process-wide, NOT thread-local: autograd runs a step's backward -- and with it these launches -- on its own device thread while the
-// thread that called backward() (and that switches the mode and flushes) waits; the two never launch at the same time.
-static int g_pend_on = 0;
-static WgradPendParams g_pend;
+// Given a DrnWgradPending list (caller-owned HOST memory, include/drn_hip.h) the GEMM launches only record what their reduce would have
+// been; drn_wgrad_reduce_pending() then runs ALL of them as ONE launch -- same per-element summation order over the splits, so the
+// same bits.  The caller keeps the workspaces alive until then and must flush before anything reads the gradients
+// (drn_amd.dist.GradReducer.collect does).  No state lives in the library: two models (or two threads) hand over two lists.
+typedef DrnWgradPendItem WgradPendItem;
+#define WGRAD_PEND_MAX DRN_WGRAD_PEND_MAX
+typedef DrnWgradPending WgradPendParams;      // (plain data: goes to the kernel by value)
 
-static bool wgrad_pend_push(const float* ws, float* out, int nsplit, int N, int Cin, int taps, int w_layout, int accumulate) {
-  if (!g_pend_on || g_pend.n >= WGRAD_PEND_MAX) return false;
-  g_pend.it[g_pend.n++] = WgradPendItem{ws, out, nsplit, N, Cin, taps, w_layout, accumulate};
-  return true;
+// 1 = recorded; 0 = not deferrable (no list, list full, or an accumulating reduce: it reads `out`, which nobody may have pending);
+// < 0 = error: `out` already has a reduce recorded -- running either first would be wrong, the caller has to flush in between
+static int wgrad_pend_push(DrnWgradPending* L, const float* ws, float* out, int nsplit, int N, int Cin, int taps, int w_layout, int accumulate) {
+  if (!L || L->n < 0 || L->n >= WGRAD_PEND_MAX) return 0;
+  for (int i = 0; i < L->n; ++i)
+    if (L->it[i].out == out) {
+      drn_set_error("drn_gemm_wgrad: the output already has a deferred reduce pending in this DrnWgradPending (flush with drn_wgrad_reduce_pending first)");
+      return DRN_ERR_ARG;
+    }
+  if (accumulate) return 0;
+  L->it[L->n++] = WgradPendItem{ws, out, nsplit, N, Cin, taps, w_layout, accumulate};
+  return 1;
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendParams P) {
@@ -827,61 +823,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradPendPa
   }
 }
 
-extern "C" int drn_wgrad_defer(int on) {
-  drn_clear_status();
-  const int was = g_pend_on;
-  g_pend_on = on != 0;
-  return was;
-}
-
-extern "C" int drn_wgrad_pending(void) { return g_pend.n; }
-
-static int wgrad_pend_plan() {
+static int wgrad_pend_plan(DrnWgradPending* L) {
   int blocks = 0;
-  for (int i = 0; i < g_pend.n; ++i) {
-    const WgradPendItem& I = g_pend.it[i];
+  for (int i = 0; i < L->n; ++i) {
+    const WgradPendItem& I = L->it[i];
     const long work = (I.w_layout == 1 && I.taps == 3) ? (long)I.N * I.Cin : (long)I.N * I.taps * I.Cin;
     int nb = (int)((work + 255) / 256);
     if (nb > 2048) nb = 2048;
-    g_pend.blk_start[i] = blocks;
+    L->blk_start[i] = blocks;
     blocks += nb;
   }
-  g_pend.blk_start[g_pend.n] = blocks;
+  L->blk_start[L->n] = blocks;
   return blocks;
 }
 
-extern "C" int drn_wgrad_pending_blocks(void) { return wgrad_pend_plan(); }
+extern "C" int drn_wgrad_pending_blocks(DrnWgradPending* L) {
+  drn_clear_status();
+  DRN_CHECK_ARG(L && L->n >= 0 && L->n <= WGRAD_PEND_MAX, "drn_wgrad_pending_blocks: bad list");
+  return wgrad_pend_plan(L);
+}
 
 // bytes the pending launch will move (partials read + gradients written [+ read when accumulating]): its roofline denominator
-extern "C" int64_t drn_wgrad_pending_bytes(void) {
+extern "C" int64_t drn_wgrad_pending_bytes(const DrnWgradPending* L) {
   int64_t b = 0;
-  for (int i = 0; i < g_pend.n; ++i) {
-    const WgradPendItem& I = g_pend.it[i];
+  if (!L || L->n < 0 || L->n > WGRAD_PEND_MAX) return 0;
+  for (int i = 0; i < L->n; ++i) {
+    const WgradPendItem& I = L->it[i];
     b += (int64_t)I.N * I.taps * I.Cin * 4 * (I.nsplit + 1 + (I.accumulate ? 1 : 0));
   }
   return b;
 }
 
-extern "C" int drn_wgrad_pending_outputs(void** outs, int64_t* numels) {
-  for (int i = 0; i < g_pend.n; ++i) {
-    outs[i] = g_pend.it[i].out;
-    numels[i] = (int64_t)g_pend.it[i].N * g_pend.it[i].taps * g_pend.it[i].Cin;
-  }
-  return g_pend.n;
-}
-
-extern "C" int drn_wgrad_reduce_pending_sumsq(float* sumsq, void* stream) {
+extern "C" int drn_wgrad_reduce_pending(DrnWgradPending* L, float* sumsq, void* stream) {
   drn_clear_status();
-  if (g_pend.n == 0) return DRN_OK;
-  const int blocks = wgrad_pend_plan();
-  g_pend.sumsq = sumsq;
-  wgrad_reduce_all_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g_pend);
-  g_pend.n = 0;
-  g_pend.sumsq = nullptr;
+  DRN_CHECK_ARG(L && L->n >= 0 && L->n <= WGRAD_PEND_MAX, "drn_wgrad_reduce_pending: bad list");
+  if (L->n == 0) return DRN_OK;
+  const int blocks = wgrad_pend_plan(L);
+  L->sumsq = sumsq;
+  wgrad_reduce_all_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(*L);
+  L->n = 0;
+  L->sumsq = nullptr;
   return drn_launch_status("drn_wgrad_reduce_pending");
 }
-
-extern "C" int drn_wgrad_reduce_pending(void* stream) { return drn_wgrad_reduce_pending_sumsq(nullptr, stream); }
 
 // 256x256 tiles only when they alone fill half the chip (the 4096x4096 prop_fc gradient: 256 tiles)
 static int wgrad_tile(int N, int Cin, int taps) {
@@ -964,12 +947,15 @@ extern "C" int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps) {
 }
 
 extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int N, int Cin, int taps, int stride, int pad,
-                              int w_layout, int accumulate, float* ws, int dtype, void* stream_) {
+                              int w_layout, int accumulate, float* ws, int dtype, DrnWgradPending* pend, void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(ngroups >= 1 && ngroups <= DRN_MAX_GROUPS, "drn_gemm_wgrad: ngroups=%d out of range", ngroups);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_wgrad: bad dtype %d", dtype);
   DRN_CHECK_ARG(dW && N > 0 && Cin > 0 && taps >= 1 && stride >= 1, "drn_gemm_wgrad: bad dims");
+  if (pend)      // (checked BEFORE the GEMM launch: an output that already has a reduce recorded cannot take a second one)
+    for (int i = 0; i < pend->n && i < WGRAD_PEND_MAX; ++i)
+      DRN_CHECK_ARG(pend->it[i].out != dW, "drn_gemm_wgrad: the output already has a deferred reduce pending in this DrnWgradPending (flush first)");
   const int ch = dtype == DRN_BF16 ? 8 : 4;
   const int R = dtype == DRN_BF16 ? 64 : 32;
   WgradParams P;
@@ -1012,7 +998,9 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
     WGRAD3_LAUNCH(dim3(cdiv(N, 128), cdiv(Cin, 128), ns), P);
     int rc = drn_launch_status("drn_gemm_wgrad(fused taps)");
     if (rc) return rc;
-    if (!P.direct && !wgrad_pend_push(ws, dW, ns, N, Cin, taps, w_layout, accumulate)) {
+    const int pushed = P.direct ? 0 : wgrad_pend_push(pend, ws, dW, ns, N, Cin, taps, w_layout, accumulate);
+    if (pushed < 0) return pushed;
+    if (!P.direct && !pushed) {
       const long total = (long)N * taps * Cin;
       int nb = (int)((total + 255) / 256);
       if (nb > 2048) nb = 2048;
@@ -1061,7 +1049,9 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
   }
   int rc = drn_launch_status("drn_gemm_wgrad");
   if (rc) return rc;
-  if (!P.direct && !wgrad_pend_push(ws, dW, ns, N, Cin, taps, w_layout, accumulate)) {
+  const int pushed = P.direct ? 0 : wgrad_pend_push(pend, ws, dW, ns, N, Cin, taps, w_layout, accumulate);
+  if (pushed < 0) return pushed;
+  if (!P.direct && !pushed) {
     const long total = (long)N * taps * Cin;
     int nb = (int)((total + 255) / 256);
     if (nb > 2048) nb = 2048;
@@ -1074,10 +1064,15 @@ extern "C" int drn_gemm_wgrad(const DrnWgradDesc* d, int ngroups, float* dW, int
 // n INDEPENDENT weight gradients of equal N / Cin / taps / stride (the three FPN level convs: different weights, different
 // row counts) in ONE launch + one reduce launch; problem i: dWs[i] = dY_i^T x im2col(X_i).  ws >= n * drn_wgrad_ws_elems(max M).
 extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* dWs, int N, int Cin, const int32_t* Cins, int taps,
-                                    int stride, int pad, int w_layout, int accumulate, float* ws, int dtype, void* stream_) {
+                                    int stride, int pad, int w_layout, int accumulate, float* ws, int dtype, DrnWgradPending* pend,
+                                    void* stream_) {
   drn_clear_status();
   hipStream_t stream = (hipStream_t)stream_;
   DRN_CHECK_ARG(d && dWs && n >= 1 && n <= DRN_MAX_GROUPS, "drn_gemm_wgrad_multi: n=%d out of range", n);
+  if (pend)      // (checked BEFORE the GEMM launch: an output that already has a reduce recorded cannot take a second one)
+    for (int g = 0; g < n; ++g)
+      for (int i = 0; i < pend->n && i < WGRAD_PEND_MAX; ++i)
+        DRN_CHECK_ARG(pend->it[i].out != dWs[g], "drn_gemm_wgrad_multi: output %d already has a deferred reduce pending in this DrnWgradPending", g);
   DRN_CHECK_ARG(dtype == DRN_F32 || dtype == DRN_BF16, "drn_gemm_wgrad_multi: bad dtype %d", dtype);
   DRN_CHECK_ARG(N > 0 && Cin > 0 && taps >= 1 && stride >= 1, "drn_gemm_wgrad_multi: bad dims");
   const int ch = dtype == DRN_BF16 ? 8 : 4;
@@ -1158,9 +1153,9 @@ extern "C" int drn_gemm_wgrad_multi(const DrnWgradDesc* d, int n, float* const* 
   else conv_wgrad_tn_kernel<float, 2, 4, 4, 2><<<grid, 512, 2 * 32768, stream>>>(P);
   int rc = drn_launch_status("drn_gemm_wgrad_multi");
   if (rc || !any_split) return rc;
-  if (g_pend_on && g_pend.n + n <= WGRAD_PEND_MAX) {
+  if (pend && !accumulate && pend->n >= 0 && pend->n + n <= WGRAD_PEND_MAX) {
     for (int g = 0; g < n; ++g)
-      if (RM.nsplit[g] > 1) wgrad_pend_push(RM.ws[g], RM.out[g], RM.nsplit[g], N, RM.cin[g], taps, w_layout, accumulate);
+      if (RM.nsplit[g] > 1) (void)wgrad_pend_push(pend, RM.ws[g], RM.out[g], RM.nsplit[g], N, RM.cin[g], taps, w_layout, accumulate);
     return rc;
   }
   int nb = (int)(((long)N * taps * Cin + 255) / 256);

@@ -118,11 +118,9 @@ class GradReducer(object):
         self._dirty = {}
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
-        # RCCL's kernels run beside backward: the GEMM kernels' in-launch split-K exchanges confirm their stores (ops.xchg_need)
-        self._xchg = self.world > 1 and bool(self.params) and self.params[0].is_cuda
-        if self._xchg:
-            from . import ops
-            ops.xchg_need(+1)
+        # (RCCL's kernels run beside backward: the GEMM kernels' in-launch split-K exchanges confirm their stores -- they always do,
+        # drn_amd.ops._ksplit_arg)
+        self._pend = None                  # ops.WgradPending over this reducer's buckets: the deferred weight-gradient reduces
         self.buckets, self._of, self.group_buckets = [], {}, []
         wanted = set(id(p) for p in self.params)
         plan = [self.params] if groups is None else [[p for p in g if id(p) in wanted] for g in groups]
@@ -217,20 +215,28 @@ class GradReducer(object):
             self._launch(b)
 
     def _wgrad_defer(self, on):
-        """Between zero() and collect() the conv weight-gradient launches leave their reduce passes to ONE launch that collect()
-        issues (drn_amd.ops.wgrad_defer / wgrad_reduce_pending): nothing reads a gradient before collect() -- except the eager
-        multi-GPU mode, whose hooks hand buckets to RCCL as backward fills them; that mode keeps the per-launch reduces."""
-        if not self.params or not self.params[0].is_cuda or (self.world > 1 and self.overlap) or not WGRAD_DEFER:
+        """Between zero() and collect() the conv weight-gradient launches that write into THIS reducer's buckets leave their reduce
+        passes to ONE launch that collect() issues (drn_amd.ops.WgradPending: a list this reducer owns; a launch finds it by where
+        its dW lives): nothing reads those slices before collect().  Only with steal=True -- otherwise AccumulateGrad adds a
+        still un-reduced dW into the bucket the moment backward hands it over -- and not in the eager multi-GPU mode, whose hooks
+        hand buckets to RCCL as backward fills them.  zero() drops whatever an earlier backward that raised left recorded."""
+        if not self.params or not self.params[0].is_cuda or (self.world > 1 and self.overlap) or not WGRAD_DEFER or not self.steal:
             return
         from . import ops
         want = bool(getattr(self, "ext_sumsq", False)) and self.world == 1
+        if self._pend is None:
+            self._pend = ops.WgradPending([(b.flat.data_ptr(), b.flat.data_ptr() + b.flat.numel() * b.flat.element_size())
+                                           for b in self.buckets])
         if on:
-            ops.wgrad_defer(True)
+            self._pend.reset()
+            ops.wgrad_arm(self._pend)
             DF.want_sumsq(want)
             self.sumsq_notes = []
         else:
-            res = ops.wgrad_reduce_pending(sumsq=want)
-            ops.wgrad_defer(False)
+            if not any(q is self._pend for q in ops._armed):
+                return                                  # (collect() without a zero() before it, remove() after collect())
+            ops.wgrad_disarm(self._pend)
+            res = ops.wgrad_reduce_pending(self._pend, sumsq=want)
             if want:
                 if res is not None:
                     DF.note_sumsq(*res)
@@ -326,10 +332,6 @@ class GradReducer(object):
         self.wait(timings)
 
     def remove(self):
-        if getattr(self, "_xchg", False):
-            from . import ops
-            ops.xchg_need(-1)
-            self._xchg = False
         self._wgrad_defer(False)
         for h in self._hooks:
             h.remove()

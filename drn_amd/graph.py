@@ -206,16 +206,7 @@ class DualStreamStep(object):
 
     # ---- the phases (each runs on the stream its row in the table says)
     def _phase(self, name):
-        # every phase but the trunk has the other branch beside it: the split-K exchanges confirm their stores there (ops.xchg_need)
-        from . import ops
-        beside = name != "trunk"
-        if beside:
-            ops.xchg_need(+1)
-        try:
-            self._run_phase(name)
-        finally:
-            if beside:
-                ops.xchg_need(-1)
+        self._run_phase(name)
 
     def _run_phase(self, name):
         m, red, c = self.model, self.reducer, self._c
@@ -361,12 +352,13 @@ class ForkedStep(DualStreamStep):
     def __init__(self, model, batch, loss_of, reducer, opt, split_gate=False, main=None, side=None, rotate=None):
         """main / side: the streams to capture on (default: new ones).  `main` must be the stream every earlier step of this
         model ran on (autograd's AccumulateGrad nodes are bound to it).
-        rotate (default: whenever the reducer keeps the query side's gradients in buckets of their own, i.e. was built with
-        groups=[model.query_parameters(), the rest]): OPTIMIZER-FIRST order.  A call applies the optimizer to the gradients the
+        rotate (default False: an explicit opt-in -- it measured slower, and between calls the parameters lag one update, which a
+        caller who checkpoints or evaluates without flush() would read; needs a reducer that keeps the query side's gradients in
+        buckets of their own, i.e. built with groups=[model.query_parameters(), the rest]): OPTIMIZER-FIRST order.  A call applies the optimizer to the gradients the
         PREVIOUS call left in the reducer's buckets and then runs forward + backward of its own batch:
 
             main   norm -> Adam(query side) -> Adam(rest) + weight copies -> input prep -> (join) trunk fwd/bwd -> weight gradients
-            side                            \-> query encoder forward ---------------------/              \-> query side backward
+            side                            +-> query encoder forward ---------------------+              +-> query side backward
 
         so the query encoder's forward -- ~16 dependent, latency-bound launches, 130 us alone -- runs beside the ~200 us of
         bandwidth-bound optimizer kernels, whose short-lived workgroups leave it room, instead of in front of the prop_fc GEMM,
@@ -381,7 +373,7 @@ class ForkedStep(DualStreamStep):
             not any(id(p) in qp for g in gb[1:] for b in g for p in b.params)
         if rotate and not can:
             raise ValueError("ForkedStep(rotate=True) needs GradReducer(groups=[model.query_parameters(), the other parameters])")
-        self.rotate = can if rotate is None else bool(rotate)
+        self.rotate = bool(rotate)
         self._primed = False
         import os
         if os.environ.get("DRN_FORK_ROTATE") is not None:              # experiment switches (scripts/experiments/ab_r05_c.sh)

@@ -170,34 +170,25 @@ def _ksplit_w4h(descs, dtype):
 # before the ticket whenever a kernel of another queue may run beside the launch: with one, the ticket overtook a partial about once
 # in 10^5 launches of skinny_group_kernel inside the replayed two-branch graph (qdense.hip has the measurements; that kernel and the
 # loss kernel always confirm with a returning read-modify-write per stored address, it costs them nothing).  The GEMM kernels'
-# exchanges have never shown the window; they confirm on demand (drn_tune "xchg_confirm": 0 off, 1 = a returning atomic per 64-byte
-# request, +20-23 us on conv0's forward, +76 us per step at T = 256; 2 = an sc1 load of every request instead, +2-3 us on conv0's
-# forward -- the variant that also closed the window on the proven kernel, 0 events in 120 k replays against 7).  Library default 1;
-# from here "auto": 2 while somebody has declared concurrency (GradReducer with world_size > 1: RCCL kernels beside backward;
-# DualStreamStep / ForkedStep: every phase that has the other branch beside it, i.e. all but the trunk), 0 in a strictly single-queue
-# step, where nothing can be beside the launch.  DRN_XCHG_CONFIRM=0 / 1 / 2 forces a mode everywhere.
-XCHG_CONFIRM = os.environ.get("DRN_XCHG_CONFIRM", "auto")
-_xchg_need = 0
-_xchg_set = None
+# exchanges have never shown the window, but nobody standing here can prove a single queue (the Trainer's prefetch copies run on their
+# own stream beside the replay, RCCL's kernels beside backward, a second graph branch beside the first), so every launch confirms by
+# READ-BACK -- an sc1 load of every stored request, +12 us per step at T = 256, the variant that closed the window on the proven
+# kernel (0 events in 120 k replays against 7) -- which is what the library does when the call's `ksplit` carries no flag.  The mode
+# travels WITH THE CALL (DRN_KSPLIT_CONFIRM_* bits, include/drn_hip.h): no process-wide switch.  DRN_XCHG_CONFIRM=0 / 1 select
+# "nothing" / "returning atomics" for stress tests and A/Bs (scripts/experiments), 2 = the default.
+KSPLIT_CONFIRM_ATOMIC, KSPLIT_CONFIRM_NONE = 0x20000, 0x80000
+XCHG_CONFIRM = os.environ.get("DRN_XCHG_CONFIRM", "2")
+
+
+def _ksplit_arg(ks):
+    return ks | (KSPLIT_CONFIRM_NONE if XCHG_CONFIRM == "0" else KSPLIT_CONFIRM_ATOMIC if XCHG_CONFIRM == "1" else 0)
 
 
 def xchg_need(delta):
-    """Declare (+1) / withdraw (-1) that kernels of another queue may run beside the launches issued from now on."""
-    global _xchg_need
-    _xchg_need += int(delta)
-    _xchg_apply()
-
-
-def _xchg_apply():
-    global _xchg_set
-    want = int(XCHG_CONFIRM) if XCHG_CONFIRM in ("0", "1", "2") else (2 if _xchg_need > 0 else 0)
-    if want != _xchg_set:
-        check(lib().drn_tune(b"xchg_confirm", want), "drn_tune")
-        _xchg_set = want
+    """Kept for callers of rounds 4-5 (declare / withdraw concurrency): the exchanges now confirm unconditionally, nothing to switch."""
 
 
 def gemm_nt(descs, dtype):
-    _xchg_apply()
     arr = (GemmDesc * len(descs))(*descs)
     flops = sum(2.0 * d.M * d.N * d.taps * d.Cin for d in descs)
     ks = _ksplit_w4h(descs, dtype)
@@ -206,7 +197,7 @@ def gemm_nt(descs, dtype):
         dev = torch.device("cuda", torch.cuda.current_device())
         ws = torch.empty(ks * d0.M * d0.N, dtype=torch.float32, device=dev)
         tag = "gemm_nt[bf16] g=1 M=%d N=%d K=%d mode=%d splitK=%d(w4h)" % (d0.M, d0.N, d0.taps * d0.Cin, d0.mode, ks)
-        return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk_grouped(arr, 1, ks, _p(ws), _p(_counters(dev)), dtype, _stream()),
+        return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk_grouped(arr, 1, _ksplit_arg(ks), _p(ws), _p(_counters(dev)), dtype, _stream()),
                                                 "drn_gemm_nt_splitk_grouped"))
     ks = _ksplit256(descs, dtype)
     if ks > 1:
@@ -223,7 +214,7 @@ def gemm_nt(descs, dtype):
         ws = torch.empty(ks * tiles * 128 * 128, dtype=torch.float32, device=dev)
         tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=%d splitK=%d" % ("bf16" if dtype == BF16 else "f32", len(descs),
                                                                      sum(d.M for d in descs), d0.N, d0.taps * d0.Cin, d0.mode, ks)
-        return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk_grouped(arr, len(descs), ks, _p(ws), _p(_counters(dev)),
+        return _timed(tag, flops, lambda: check(lib().drn_gemm_nt_splitk_grouped(arr, len(descs), _ksplit_arg(ks), _p(ws), _p(_counters(dev)),
                                                                                  dtype, _stream()), "drn_gemm_nt_splitk_grouped"))
     d0 = descs[0]
     tag = "gemm_nt[%s] g=%d M=%d N=%d K=%d mode=%d" % ("bf16" if dtype == BF16 else "f32", len(descs),
@@ -238,12 +229,52 @@ def wgrad_desc(dY, X, M, Lout=None, Lsrc=None, ldy=None, ldx=None):
                      ldy=dY.shape[-1] if ldy is None else ldy, ldx=X.shape[-1] if ldx is None else ldx)
 
 
-_pending_ws = []          # workspaces of weight-gradient launches whose reduce pass is deferred (wgrad_defer): alive until the flush
+class WgradPending(object):
+    """A caller-owned list of deferred weight-gradient reduces (DrnWgradPending, include/drn_hip.h) + the workspaces it references.
+    `ranges`: [(first byte, one past the last)] of the gradient memory whose reduces may be deferred into this list -- a launch finds
+    its list by where its dW lives (pending_for), so nothing process-wide says "defer": two models in one process own two lists over
+    disjoint buckets and never see each other's items, and a gradient written anywhere else is reduced at once."""
+
+    def __init__(self, ranges=()):
+        from ._lib import WgradPending as _Struct
+        self.c = _Struct()                 # all-zero = empty
+        self.ws = []
+        self.ranges = [(int(lo), int(hi)) for lo, hi in ranges]
+
+    def __len__(self):
+        return int(self.c.n)
+
+    def reset(self):
+        """Drop whatever is recorded (a backward that raised leaves items behind: the next step must not run them)."""
+        self.c.n = 0
+        del self.ws[:]
+
+    def covers(self, ptr):
+        return any(lo <= ptr < hi for lo, hi in self.ranges)
+
+    def outputs(self):
+        return [(int(self.c.it[i].out), int(self.c.it[i].N) * int(self.c.it[i].taps) * int(self.c.it[i].Cin)) for i in range(len(self))]
 
 
-def wgrad_defer(on):
-    """Deferred reduce passes on / off (drn_wgrad_defer); returns the previous setting."""
-    return bool(lib().drn_wgrad_defer(int(bool(on))))
+_armed = []          # WgradPending lists currently accepting items (armed by their owners between zero() and collect())
+
+
+def wgrad_arm(pend):
+    if not any(q is pend for q in _armed):
+        _armed.append(pend)
+
+
+def wgrad_disarm(pend):
+    _armed[:] = [q for q in _armed if q is not pend]
+
+
+def pending_for(dWs):
+    """The armed list whose ranges hold EVERY one of the given gradients, else None (reduce at once)."""
+    ptrs = [dW.data_ptr() for dW in dWs]
+    for q in _armed:
+        if all(q.covers(x) for x in ptrs):
+            return q
+    return None
 
 
 _persistent = {}
@@ -256,8 +287,8 @@ def persistent_buffer(key, n, device, dtype=torch.float32):
     k = (key, int(n), str(device), dtype)
     buf = _persistent.get(k)
     if buf is None:
-        if len(_persistent) > 256:
-            _persistent.clear()
+        # never evicted: the addresses are baked into captured hipGraphs (BatchNorm-backward tags, the one-launch LSTM's workspace,
+        # squared-sum partials); the buffers are a few KB each
         buf = _persistent[k] = torch.zeros(int(n), dtype=dtype, device=device)
     return buf
 
@@ -265,29 +296,27 @@ def persistent_buffer(key, n, device, dtype=torch.float32):
 last_reduce_bytes = 0
 
 
-def wgrad_reduce_pending(sumsq=False):
-    """Run every deferred weight-gradient reduce in ONE launch on the current stream (drn_wgrad_reduce_pending).  sumsq=True: the
-    launch also leaves the squared sums of what it wrote; returns (ranges [(data_ptr, elements)] of the reduced gradients, partials
-    tensor) -- or None when nothing was pending."""
+def wgrad_reduce_pending(pend, sumsq=False):
+    """Run every reduce recorded in `pend` in ONE launch on the current stream (drn_wgrad_reduce_pending).  sumsq=True: the launch also
+    leaves the squared sums of what it wrote; returns (ranges [(data_ptr, elements)] of the reduced gradients, partials tensor) -- or
+    None when nothing was pending."""
     global last_reduce_bytes
     L = lib()
-    n = L.drn_wgrad_pending()
+    n = len(pend)
     res = None
+    ref = ctypes.byref(pend.c)
     if n > 0:
-        last_reduce_bytes = int(L.drn_wgrad_pending_bytes())      # (for the profile tables: the launch's HBM-roofline denominator)
+        last_reduce_bytes = int(L.drn_wgrad_pending_bytes(ref))      # (for the profile tables: the launch's HBM-roofline denominator)
     if n > 0 and sumsq:
-        outs = (ctypes.c_void_p * n)()
-        numels = (ctypes.c_int64 * n)()
-        L.drn_wgrad_pending_outputs(outs, numels)
-        ranges = [(int(outs[i]), int(numels[i])) for i in range(n)]
-        blocks = int(L.drn_wgrad_pending_blocks())
+        ranges = pend.outputs()
+        blocks = int(L.drn_wgrad_pending_blocks(ref))
         dev = torch.device("cuda", torch.cuda.current_device())
         part = persistent_buffer(("wgrad_reduce_all", ranges[0][0]), blocks, dev)
-        check(L.drn_wgrad_reduce_pending_sumsq(_p(part), _stream()), "drn_wgrad_reduce_pending_sumsq")
+        check(L.drn_wgrad_reduce_pending(ref, _p(part), _stream()), "drn_wgrad_reduce_pending")
         res = (ranges, part)
     elif n > 0:
-        check(L.drn_wgrad_reduce_pending(_stream()), "drn_wgrad_reduce_pending")
-    del _pending_ws[:]
+        check(L.drn_wgrad_reduce_pending(ref, None, _stream()), "drn_wgrad_reduce_pending")
+    del pend.ws[:]
     return res
 
 
@@ -299,13 +328,14 @@ def gemm_wgrad(descs, dW, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulat
     n_ws = lib().drn_wgrad_ws_elems(m_total, N, Cin, taps)
     ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=dW.device)
     arr = (WgradDesc * len(descs))(*descs)
+    pend = pending_for([dW])
     tag = "gemm_wgrad[%s] g=%d M=%d N=%d K=%d" % ("bf16" if dtype == BF16 else "f32", len(descs), m_total, N, taps * Cin)
     _timed(tag, 2.0 * m_total * N * taps * Cin,
            lambda: check(lib().drn_gemm_wgrad(arr, len(descs), _p(dW), N, Cin, taps, stride, pad, w_layout, int(accumulate),
-                                              _p(ws), dtype, _stream()), "drn_gemm_wgrad"))
-    _pending_ws.append((ws, dW))                    # (cheap; emptied by every flush -- and by the next one when nothing was deferred)
-    if len(_pending_ws) > 64 and lib().drn_wgrad_pending() == 0:
-        del _pending_ws[:]
+                                              _p(ws), dtype, ctypes.byref(pend.c) if pend is not None else None, _stream()),
+                         "drn_gemm_wgrad"))
+    if pend is not None:
+        pend.ws.append(ws)                          # alive until the flush
 
 
 def gemm_wgrad_multi(descs, dWs, N, Cin, taps=1, stride=1, pad=0, w_layout=0, accumulate=False, dtype=F32):
@@ -323,14 +353,15 @@ def gemm_wgrad_multi(descs, dWs, N, Cin, taps=1, stride=1, pad=0, w_layout=0, ac
     arr = (WgradDesc * len(descs))(*descs)
     ptrs = (ctypes.c_void_p * len(dWs))(*[dW.data_ptr() for dW in dWs])
     m_total = sum(d.M for d in descs)
+    pend = pending_for(dWs)
     tag = "gemm_wgrad_multi[%s] n=%d M=%d N=%d K=%d" % ("bf16" if dtype == BF16 else "f32", len(descs), m_total, N, taps * Cin)
     flops = sum(2.0 * d.M * N * taps * (cins[i] if cins is not None else Cin) for i, d in enumerate(descs))
     _timed(tag, flops,
            lambda: check(lib().drn_gemm_wgrad_multi(arr, len(descs), ptrs, N, Cin, cins, taps, stride, pad, w_layout, int(accumulate),
-                                                    _p(ws), dtype, _stream()), "drn_gemm_wgrad_multi"))
-    _pending_ws.append((ws, list(dWs)))
-    if len(_pending_ws) > 64 and lib().drn_wgrad_pending() == 0:
-        del _pending_ws[:]
+                                                    _p(ws), dtype, ctypes.byref(pend.c) if pend is not None else None, _stream()),
+                         "drn_gemm_wgrad_multi"))
+    if pend is not None:
+        pend.ws.append(ws)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -753,7 +784,8 @@ def bn_bwd_multi(levels, C, dtype, relu=True):
         _bn1_maxwg = None
     if BN_BWD_ONE:
         # one launch when the grid fits the chip at once (drn_bn_bwd_one): the tagged-pair workspace is zero at birth and keeps the
-        # launch generation afterwards -- one buffer per size, launches on it are stream-ordered
+        # launch generation afterwards -- one buffer per size AND stream (launches on one stream are ordered; two streams running
+        # same-sized passes at once must not share tags and the generation word)
         nbytes = int(lib().drn_bn_bwd_one_ws_bytes(arr, len(levels), C, dtype))
         if nbytes == 0 and has_gb:            # not with the gate backward inside: that one as its own launch, then ask again
             ungate()
@@ -761,7 +793,8 @@ def bn_bwd_multi(levels, C, dtype, relu=True):
             arr = fill(False)
             nbytes = int(lib().drn_bn_bwd_one_ws_bytes(arr, len(levels), C, dtype))
         if nbytes > 0:
-            tws = persistent_buffer("bn_bwd_one", nbytes // 8, levels[0]["draw"].device, torch.int64)
+            tws = persistent_buffer(("bn_bwd_one", torch.cuda.current_stream().cuda_stream), nbytes // 8, levels[0]["draw"].device,
+                                    torch.int64)
             rc = lib().drn_bn_bwd_one(arr, len(levels), C, int(relu), _p(tws), ctypes.c_int64(nbytes), dtype, _stream())
             if rc != DRN_ERR_UNSUPPORTED:
                 check(rc, "drn_bn_bwd_one")
@@ -771,6 +804,20 @@ def bn_bwd_multi(levels, C, dtype, relu=True):
         arr = fill(False)
     ws = workspace(len(levels) * 515 * C, levels[0]["draw"].device)
     check(lib().drn_bn_bwd_multi(arr, len(levels), C, int(relu), _p(ws), dtype, _stream()), "drn_bn_bwd_multi")
+
+
+def check_watchdogs():
+    """Raise if any in-launch exchange gave up waiting since the last call (one-launch BatchNorm backward, fused conv -> BN, the
+    one-launch BiLSTM forward): such a launch lets its outputs through INVALID and only bumps a device counter -- which somebody has to
+    read.  Synchronises; drn_amd.trainer calls it at the end of every epoch and evaluation, bench.py after every timed region."""
+    bad = {}
+    for name, fn in (("drn_bn_bwd_one", "drn_bn_bwd_one_timeouts"), ("drn_conv_bn_train", "drn_conv_bn_train_timeouts"),
+                     ("drn_lstm_seq_fwd", "drn_lstm_seq_fwd_timeouts")):
+        n = int(getattr(lib(), fn)(1))
+        if n:
+            bad[name] = n
+    if bad:
+        raise _lib.DrnError("in-launch exchange watchdog fired (workgroups that gave up waiting; the step's results are invalid): %s" % bad)
 
 
 def bn_bwd_one_timeouts(reset=True):

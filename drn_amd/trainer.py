@@ -347,7 +347,7 @@ class Trainer(object):
                 self.train_step(cur_b)
                 n += bs
             torch.cuda.current_stream().wait_stream(self.stream)
-            return float(self._loss_acc) / max(n, 1) if n else 0.0
+            return self._epoch_result(n)
         with torch.cuda.stream(self.stream) if self.graph else contextlib.nullcontext():
             self._loss_acc.zero_()
         for batch in loader:
@@ -363,7 +363,16 @@ class Trainer(object):
             n += bs
         if self.graph:
             torch.cuda.current_stream().wait_stream(self.stream)
-        return float(self._loss_acc) / max(n, 1) if n else 0.0
+        return self._epoch_result(n)
+
+    def _epoch_result(self, n):
+        """Mean loss of the epoch (the one host sync) -- and, on the device, the in-launch exchanges' watchdog counters: a workgroup
+        that gave up waiting lets invalid values through and only counts it (drn_amd.ops.check_watchdogs raises)."""
+        mean = float(self._loss_acc) / max(n, 1) if n else 0.0
+        if getattr(getattr(self, "device", None), "type", "cpu") == "cuda":
+            from . import ops
+            ops.check_watchdogs()
+        return mean
 
     def _prefetch(self, batch):
         """graph mode: start copying a batch (host or device tensors) into the input buffers of the slot its step will run from,

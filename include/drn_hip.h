@@ -22,19 +22,18 @@
 extern "C" {
 #endif
 
-#define DRN_ABI_VERSION 8
+#define DRN_ABI_VERSION 9
 #define DRN_MAX_GROUPS 4
 
 int drn_abi_version(void);
-/* Process-wide tuning values that tests use to reach kernels their shapes would not select: "tn3_minrows" (fewest rows for
- * the fused-tap weight-gradient kernel, default 4096), "tn_fused" (0 switches that kernel off), "nt_w4" (0: drn_gemm_nt runs the
- * general 8-wave kernel also for the large plain bf16 products that gemm_nt_w4_kernel takes by default; results are bit-identical
- * either way), "nt_w4c" (the same for the k = 3 / stride 1 convolutions on 256x256 tiles and gemm_nt_w4c_kernel), "nt_deep",
- * "exp0".."exp4" (launch heuristics, 0 = shipped), "xchg_confirm" (default 1: the in-launch split-K exchanges of drn_gemm_nt_splitk* and
- * of the w4h kernel confirm every partial-tile store with a returning atomic on its address before the ticket -- for callers whose
- * launches may have a kernel of another queue beside them; 2: an sc1 load of every stored 64-byte request instead, a tenth of the
- * cost; 0: nothing, for strictly single-queue execution; values are the same in every mode).  The library never reads the environment (the
- * experiment build `make EXPERIMENTS=1` does). */
+/* TEST / EXPERIMENT switches, process-wide; nothing on the product path (drn_amd/*.py outside tests) calls this.  They let tests reach
+ * kernels their shapes would not select: "tn3_minrows" (fewest rows for the fused-tap weight-gradient kernel, default 4096), "tn_fused"
+ * (0 switches that kernel off), "nt_w4" (0: drn_gemm_nt runs the general 8-wave kernel also for the large plain bf16 products that
+ * gemm_nt_w4_kernel takes by default; results are bit-identical either way), "nt_w4c" / "nt_w4h" (the same for the k = 3 convolutions on
+ * 256x256 tiles and the 256x128-tile kernel), "nt_deep*", "bn1_maxwg", "w4h_tapil", "exp0".."exp4" (launch heuristics, 0 = shipped).
+ * Per-launch behaviour (the split-K exchange's confirmation, deferred weight-gradient reduces) is NOT here: it travels in the call's own
+ * arguments (DRN_KSPLIT_CONFIRM_*, DrnWgradPending).  The library never reads the environment (the experiment build
+ * `make EXPERIMENTS=1` does). */
 int drn_tune(const char* key, int value);
 const char* drn_last_error(void); /* thread-local, valid until the next failing call on this thread */
 
@@ -102,6 +101,14 @@ int drn_gemm_nt_splitk_plan(const DrnGemmDesc* descs /*host*/, int ngroups, int 
  * launch: every split publishes its fp32 partial tile in ws (drn_gemm_nt_splitk_ws_elems floats, 16-byte aligned), the
  * split that arrives last at a tile adds them in split order (deterministic) and runs the epilogue.  counters: >= one int32
  * per 128x128 output tile (<= DRN_QD_COUNTERS), zero on entry, left zero (the buffer drn_skinny_group uses will do). */
+/* `ksplit` = the split count (1..64) in the low 16 bits, optionally OR-ed with ONE of the bits below: how a split confirms its
+ * write-through partial-tile stores before it takes the tile's ticket.  No bit (what drn_amd.ops passes): an sc1 load of every stored
+ * 64-byte request -- needed whenever a kernel of another queue may run beside the launch (a copy stream, a second graph branch, RCCL),
+ * which the library cannot rule out; + 12 us per training step at T = 256.  _ATOMIC: a returning agent-scope read-modify-write per
+ * request instead (+ 76 us per step).  _NONE: nothing -- only for a caller that owns the device's every queue (experiments, stress
+ * tests).  Values are identical in every mode. */
+#define DRN_KSPLIT_CONFIRM_ATOMIC 0x20000
+#define DRN_KSPLIT_CONFIRM_NONE   0x80000
 int64_t drn_gemm_nt_splitk_ws_elems(int M, int N, int ksplit);
 int drn_gemm_nt_splitk(const DrnGemmDesc* desc /*host*/, int ksplit, float* ws, int32_t* counters, int dtype, void* stream);
 /* ... and for a grouped launch: every problem's K loop is split ksplit ways; ws >= ksplit * (sum over the problems of their
@@ -130,8 +137,29 @@ typedef struct DrnWgradDesc {
  * feeds all three taps); everything else the per-tap kernel.  Same results to fp32 rounding (the split points differ).
  * Environment (experiments): DRN_TN_FUSED=0 disables, DRN_TN3_MINROWS, DRN_TN3_TARGET, DRN_TN3_STAGES=3|4. */
 int64_t drn_wgrad_ws_elems(int M_total, int N, int Cin, int taps);
+
+/* Deferred reduce passes.  A weight-gradient launch that splits its rows ends with a reduce launch of its own -- unless the caller hands
+ * it a DrnWgradPending list (HOST memory the caller owns; all-zero = empty; nothing about it lives in the library, so two models or two
+ * threads use two lists): the launch then only RECORDS its reduce, and drn_wgrad_reduce_pending() runs every recorded one in ONE launch
+ * (same summation order over the splits: same bits) and empties the list.  The caller keeps the workspaces alive until then and flushes
+ * before anything reads the gradients.  Not recorded (reduced at once, as with pend = NULL): an accumulating reduce (it reads `out`), and
+ * anything once the list holds DRN_WGRAD_PEND_MAX items.  An output that ALREADY has a reduce recorded in the list is an error
+ * (DRN_ERR_ARG before anything is launched): flush in between. */
+#define DRN_WGRAD_PEND_MAX 24
+typedef struct DrnWgradPendItem {
+  const float* ws; /* [nsplit][N][taps][Cin] partials */
+  float* out;      /* the gradient */
+  int32_t nsplit, N, Cin, taps, w_layout, accumulate;
+} DrnWgradPendItem;
+typedef struct DrnWgradPending {
+  DrnWgradPendItem it[DRN_WGRAD_PEND_MAX];
+  int32_t blk_start[DRN_WGRAD_PEND_MAX + 1]; /* filled by the library when it plans the flush */
+  int32_t n;                                  /* items recorded */
+  float* sumsq;                               /* set for the duration of a flush */
+} DrnWgradPending;
+
 int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, int N, int Cin, int taps, int stride,
-                   int pad, int w_layout, int accumulate, float* ws, int dtype, void* stream);
+                   int pad, int w_layout, int accumulate, float* ws, int dtype, DrnWgradPending* pend /*host or NULL*/, void* stream);
 
 /* n independent weight gradients of equal N / taps / stride / pad (different weights, different row counts: the FPN level
  * convs) in one launch; dWs is a HOST array of n device pointers; ws >= n * drn_wgrad_ws_elems(max M, N, Cin, taps).
@@ -139,21 +167,13 @@ int drn_gemm_wgrad(const DrnWgradDesc* descs /*host*/, int ngroups, float* dW, i
  * Cin is then the largest of them. */
 int drn_gemm_wgrad_multi(const DrnWgradDesc* problems /*host*/, int n, float* const* dWs /*host*/, int N, int Cin,
                          const int32_t* Cins /*host*/, int taps, int stride, int pad, int w_layout, int accumulate, float* ws,
-                         int dtype, void* stream);
-/* Deferred reduce passes (process-wide: one training step at a time).  drn_wgrad_defer(1): the drn_gemm_wgrad* launches that split their rows no longer end
- * with their own reduce launch -- they record it; drn_wgrad_reduce_pending() runs every recorded reduce in ONE launch (same
- * summation order over the splits: same bits) and empties the list.  The caller keeps the workspaces alive until then and flushes
- * before anything reads the gradients.  drn_wgrad_defer returns the previous setting; drn_wgrad_pending the number recorded. */
-int drn_wgrad_defer(int on);
-int drn_wgrad_pending(void);
-int drn_wgrad_reduce_pending(void* stream);
-/* ... with the squared sums of the reduced gradients: drn_wgrad_pending_blocks() = workgroups the flush will launch; sumsq (device,
- * that many floats, or NULL) receives one partial per workgroup.  drn_wgrad_pending_outputs lists the recorded outputs (device
- * pointer and element count each; arrays of >= drn_wgrad_pending() entries). */
-int drn_wgrad_pending_blocks(void);
-int64_t drn_wgrad_pending_bytes(void);      /* partials read + gradients written by that flush: its HBM roofline denominator */
-int drn_wgrad_pending_outputs(void** outs /*host*/, int64_t* numels /*host*/);
-int drn_wgrad_reduce_pending_sumsq(float* sumsq, void* stream);
+                         int dtype, DrnWgradPending* pend /*host or NULL*/, void* stream);
+/* The flush: one launch on `stream`; sumsq (device, drn_wgrad_pending_blocks(pend) floats, or NULL) receives one partial per workgroup of
+ * the squared sums of what it wrote.  drn_wgrad_pending_bytes: partials read + gradients written by that flush (its HBM roofline
+ * denominator). */
+int drn_wgrad_pending_blocks(DrnWgradPending* pend);
+int64_t drn_wgrad_pending_bytes(const DrnWgradPending* pend);
+int drn_wgrad_reduce_pending(DrnWgradPending* pend, float* sumsq, void* stream);
 
 /* ---- HBM-bound helpers (drn_amd/csrc/elementwise.hip) -------------------------------------------------- */
 /* fp32 -> dtype cast of n contiguous elements (feature tensor / weights; the reference is fp32-only). */

@@ -6,8 +6,7 @@ cat > /tmp/bench_base.py <<'PY'
 import os, sys, runpy
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import drn_amd.ops as o
-o._xchg_apply = lambda: None          # (the old library has no "xchg_confirm")
-o.xchg_need = lambda d: None
+# (round-5 script: compared against a library of that round; the round-6 ABI (version 9) no longer loads such a library)
 sys.argv = ["bench.py"] + sys.argv[1:]
 runpy.run_path(os.path.join(os.environ["GRAFT_REPO_ROOT"], "bench.py"), run_name="__main__")
 PY

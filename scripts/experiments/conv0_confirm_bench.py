@@ -36,8 +36,5 @@ for rnd in range(2):
         _lib.lib().drn_tune(b"w4h_tapil", tapil)
         for conf in (("0", "1", "2") if os.environ.get("BASE_LIB") != "1" else ("base",)):
             if conf != "base":
-                ops._xchg_apply = lambda: None
-                _lib.lib().drn_tune(b"xchg_confirm", int(conf))
-            else:
-                ops._xchg_apply = lambda: None          # (a library from before the flag)
+                ops.XCHG_CONFIRM = conf                 # (round 6: the mode travels in the call's `ksplit`, drn_amd.ops._ksplit_arg)
             print("round %d tapil %4d confirm %s: %.1f us" % (rnd, tapil, conf, timed()), flush=True)

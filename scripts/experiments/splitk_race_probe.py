@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 BASE = os.environ.get("BASE_LIB") == "1"          # DRN_LIB_PATH points at a library from before the fix: the positive control
 if BASE:
-    ops._xchg_apply = lambda: None
+    ops.XCHG_CONFIRM = "2"                  # (no flag bits: what a library from before the flags understands)
 g = torch.Generator().manual_seed(0)
 
 
@@ -77,7 +77,6 @@ for name, (dd, C, keep) in cases.items():
     for conf in (("0", "1") if not BASE else ("base",)):
         for load in (True, False) if conf == "0" else (True,):
             ops.XCHG_CONFIRM = conf
-            ops._xchg_set = None
             with torch.cuda.stream(sa):
                 refs = []
                 for descs in dd:                                 # two problems take turns through the same workspace: a stale

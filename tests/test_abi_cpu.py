@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20, names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.drn_abi_version() == 8
+    assert lib.drn_abi_version() == 9
     assert lib.drn_last_error() is not None
 
 
@@ -125,31 +125,82 @@ def test_norm_pass_block_classes_are_host_logic():
     assert got == want, got
 
 
-def test_split_exchange_confirmation_policy_is_host_logic(monkeypatch):
-    """drn_amd.ops drives drn_tune("xchg_confirm") ("Exchange protocol"): library default on; "auto" clears it
-    while nobody has declared concurrency and sets it while somebody has (GradReducer with world_size > 1, the phases of the
-    two-branch steps that have the other branch beside them) -- to 2, the read-back variant; DRN_XCHG_CONFIRM=0 / 1 / 2 force a mode."""
+def test_split_exchange_confirmation_travels_with_the_call(monkeypatch):
+    """The K-split exchanges' confirmation mode is an argument of the launch (DRN_KSPLIT_CONFIRM_* bits of `ksplit`, include/drn_hip.h),
+    not process state: no flag = read-back (what ships, everywhere); DRN_XCHG_CONFIRM=1 / 0 select atomics / nothing for stress
+    tests.  The product path never calls drn_tune."""
+    import re
     from drn_amd import ops
-    calls = []
-
-    class Lib(object):
-        def drn_tune(self, key, value):
-            calls.append((key, value))
-            return 0
-    monkeypatch.setattr(ops, "lib", lambda: Lib())
-    monkeypatch.setattr(ops, "XCHG_CONFIRM", "auto")
-    monkeypatch.setattr(ops, "_xchg_set", None)
-    monkeypatch.setattr(ops, "_xchg_need", 0)
-    ops._xchg_apply()
-    ops.xchg_need(+1)
-    ops.xchg_need(+1)
-    ops.xchg_need(-1)
-    ops.xchg_need(-1)
-    assert calls == [(b"xchg_confirm", 0), (b"xchg_confirm", 2), (b"xchg_confirm", 0)]       # (only changes reach the library; 2 = read-back)
+    monkeypatch.setattr(ops, "XCHG_CONFIRM", "2")
+    assert ops._ksplit_arg(4) == 4
     monkeypatch.setattr(ops, "XCHG_CONFIRM", "1")
-    ops._xchg_apply()
+    assert ops._ksplit_arg(4) == 4 | 0x20000
     monkeypatch.setattr(ops, "XCHG_CONFIRM", "0")
-    ops.xchg_need(+1)
-    ops.xchg_need(-1)
-    assert calls[3:] == [(b"xchg_confirm", 1), (b"xchg_confirm", 0)]
-    monkeypatch.setattr(ops, "_xchg_set", None)
+    assert ops._ksplit_arg(4) == 4 | 0x80000
+    hdr = open(os.path.join(ROOT, "include", "drn_hip.h")).read()
+    assert re.search(r"#define DRN_KSPLIT_CONFIRM_ATOMIC\s+0x20000", hdr) and re.search(r"#define DRN_KSPLIT_CONFIRM_NONE\s+0x80000", hdr)
+    # drn_tune is a test / experiment switch: only the BatchNorm-backward workgroup budget override (DRN_BN1_MAXWG, an experiment
+    # environment variable) may reach it from the package
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "drn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                for i, line in enumerate(open(os.path.join(dirpath, f)).read().split("\n")):
+                    if "drn_tune(" in line and not line.strip().startswith("#"):
+                        assert "bn1_maxwg" in line, (f, i + 1, line)
+
+
+def test_library_keeps_no_per_step_state():
+    """re-entrant, no mutable globals.  File-scope statics of the library sources: the thread-local error string and the
+    test-only tune table, nothing else (function-local `static bool attr_set` one-time attribute flags are idempotent)."""
+    import glob
+    import re
+    found = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "drn_amd", "csrc", "*.hip"))):
+        for line in open(f):
+            if re.match(r"^static\s+(thread_local\s+)?[A-Za-z_][A-Za-z0-9_<>\s\*]*\s+\**g_[a-z_]+(\[\d*\])?\s*(=|;)", line):
+                found.append((os.path.basename(f), line.split("=")[0].strip()))
+    host = [x for x in found if "__device__" not in x[1]]
+    assert host == [("api.hip", "static thread_local char g_err[512]"), ("api.hip", "static int g_tune[16]")], found
+    # device side: only the watchdog counters of the in-launch exchanges (diagnostics that drn_amd.ops.check_watchdogs reads and clears)
+    assert all(x[1].endswith("_timeouts;") for x in found if "__device__" in x[1]), found
+    src = open(os.path.join(ROOT, "drn_amd", "csrc", "elementwise.hip")).read()
+    assert "hipMalloc" not in src
+
+
+def test_two_models_do_not_share_deferred_reduce_state():
+    """The deferred weight-gradient reduces live in caller-owned lists (DrnWgradPending, one per GradReducer) that a launch finds by
+    where its dW lives: two models in one process own two lists over disjoint gradient buckets; a gradient outside every armed list
+    is reduced at once; disarming one leaves the other armed; reset() drops stale items (a backward that raised)."""
+    import ctypes
+    from drn_amd import _lib, ops
+
+    class FakeGrad(object):
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def data_ptr(self):
+            return self.ptr
+    a, b = ops.WgradPending([(1000, 2000), (5000, 6000)]), ops.WgradPending([(2000, 3000)])
+    assert ctypes.sizeof(a.c) == ctypes.sizeof(_lib.WgradPending) and len(a) == 0 and a.c is not b.c
+    assert ops.pending_for([FakeGrad(1500)]) is None                      # nobody armed: reduce at once
+    ops.wgrad_arm(a)
+    ops.wgrad_arm(b)
+    try:
+        assert ops.pending_for([FakeGrad(1500)]) is a and ops.pending_for([FakeGrad(5999)]) is a
+        assert ops.pending_for([FakeGrad(2000)]) is b and ops.pending_for([FakeGrad(2999)]) is b
+        assert ops.pending_for([FakeGrad(3000)]) is None and ops.pending_for([FakeGrad(999)]) is None
+        assert ops.pending_for([FakeGrad(1500), FakeGrad(2500)]) is None   # a grouped launch across two owners: not deferred
+        a.c.n = 3                                                          # (as if a backward had recorded three and then raised)
+        a.ws.append(object())
+        a.reset()
+        assert len(a) == 0 and a.ws == [] and len(b) == 0
+        ops.wgrad_disarm(a)
+        assert ops.pending_for([FakeGrad(1500)]) is None and ops.pending_for([FakeGrad(2500)]) is b
+    finally:
+        ops.wgrad_disarm(a)
+        ops.wgrad_disarm(b)
+    assert ops._armed == []
+    # the struct mirrors include/drn_hip.h: 24 items of (2 pointers + 6 ints) + 25 ints + n + pointer
+    assert _lib.WGRAD_PEND_MAX == 24 and ctypes.sizeof(_lib.WgradPendItem) == 40
+
+

@@ -927,9 +927,7 @@ def test_split_exchange_confirmation_changes_no_bits(monkeypatch, kind):
     L_ = _lib.lib()
     outs = []
     for confirm in (1, 0, 2):                    # returning atomics / nothing / sc1 read-back
-        monkeypatch.setattr(ops, "XCHG_CONFIRM", str(confirm))
-        monkeypatch.setattr(ops, "_xchg_set", None)
-        ops._xchg_apply()
+        monkeypatch.setattr(ops, "XCHG_CONFIRM", str(confirm))       # (-> the DRN_KSPLIT_CONFIRM_* bit of the call's `ksplit`)
         if kind == "general":
             M, N, K, ks = 512, 384, 4096, 4
             g = torch.Generator().manual_seed(5)
@@ -941,7 +939,7 @@ def test_split_exchange_confirmation_changes_no_bits(monkeypatch, kind):
             ws = torch.full((int(L_.drn_gemm_nt_splitk_ws_elems(M, N, ks)),), float("nan"), dtype=torch.float32, device=dev())
             counters = torch.zeros(2048, dtype=torch.int32, device=dev())
             for _ in range(3):
-                _lib.check(L_.drn_gemm_nt_splitk(arr, ks, ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(counters.data_ptr()), ops.BF16,
+                _lib.check(L_.drn_gemm_nt_splitk(arr, ops._ksplit_arg(ks), ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(counters.data_ptr()), ops.BF16,
                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "splitk")
             torch.cuda.synchronize()
             assert int(counters.abs().sum()) == 0
@@ -968,7 +966,6 @@ def test_split_exchange_confirmation_changes_no_bits(monkeypatch, kind):
         assert torch.equal(a, b)
     for a, b in zip(outs[0], outs[2]):
         assert torch.equal(a, b)
-    monkeypatch.setattr(ops, "_xchg_set", None)          # (the next launch re-applies the process's own setting)
 
 
 def test_deferred_wgrad_reduce_passes_in_one_launch_equal_the_immediate_ones():
@@ -998,17 +995,66 @@ def test_deferred_wgrad_reduce_passes_in_one_launch_equal_the_immediate_ones():
         return outs + dWs
     ref = run()
     torch.cuda.synchronize()
-    assert ops.wgrad_defer(True) is False
+    # the list is the CALLER's (DrnWgradPending): armed over the whole address space here, a launch finds it by where its dW lives
+    pend = ops.WgradPending([(0, 1 << 62)])
+    ops.wgrad_arm(pend)
     try:
         got = run()
-        n_pending = _lib.lib().drn_wgrad_pending()
-        ops.wgrad_reduce_pending()
+        n_pending = len(pend)
+        assert len(pend.ws) >= 4                              # the workspaces stay alive until the flush
+        ops.wgrad_reduce_pending(pend)
     finally:
-        ops.wgrad_defer(False)
+        ops.wgrad_disarm(pend)
     torch.cuda.synchronize()
-    assert n_pending >= 3 and _lib.lib().drn_wgrad_pending() == 0
+    assert n_pending >= 3 and len(pend) == 0 and pend.ws == []
     for a, b in zip(ref, got):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_deferred_wgrad_lists_are_independent_and_refuse_what_they_cannot_order():
+    """Two lists in one process (two models): each records only the launches whose gradients live in its ranges, flushing one leaves
+    the other's items alone, both give the immediate path's bits.  An accumulating reduce is never recorded (it reads `out`); a second
+    reduce onto an output that already has one recorded is an error before anything is launched."""
+    import ctypes
+    from drn_amd import ops, _lib
+    g = torch.Generator().manual_seed(4)
+    B, L, Cin, Cout = 32, 256, 256, 256
+    x = torch.randn(B, L, Cin, generator=g).to(torch.bfloat16).to(dev())
+    dys = [torch.randn(B, L, Cout, generator=g).to(torch.bfloat16).to(dev()) for _ in range(2)]
+
+    def wgrad(dy, dW, accumulate=False):
+        ops.gemm_wgrad([ops.wgrad_desc(dy, x, B * L, Lout=L, Lsrc=L, ldy=Cout, ldx=Cin)], dW, Cout, Cin, taps=3, stride=1, pad=1,
+                       w_layout=1, accumulate=accumulate, dtype=ops.BF16)
+    ref = [torch.empty(Cout, Cin, 3, device=dev()) for _ in range(2)]
+    for dy, dW in zip(dys, ref):
+        wgrad(dy, dW)
+    acc_ref = ref[0].clone()
+    wgrad(dys[1], acc_ref, accumulate=True)
+    torch.cuda.synchronize()
+    outs = [torch.full((Cout, Cin, 3), float("nan"), device=dev()) for _ in range(2)]
+    span = lambda t: (t.data_ptr(), t.data_ptr() + t.numel() * 4)
+    pa, pb = ops.WgradPending([span(outs[0])]), ops.WgradPending([span(outs[1])])
+    ops.wgrad_arm(pa)
+    ops.wgrad_arm(pb)
+    try:
+        wgrad(dys[0], outs[0])
+        wgrad(dys[1], outs[1])
+        assert len(pa) == 1 and len(pb) == 1 and pa.outputs()[0][0] == outs[0].data_ptr() and pb.outputs()[0][0] == outs[1].data_ptr()
+        with pytest.raises(_lib.DrnError, match="already has a deferred reduce pending"):
+            wgrad(dys[1], outs[0])
+        assert len(pa) == 1
+        ops.wgrad_reduce_pending(pa)
+        assert len(pa) == 0 and len(pb) == 1
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref[0]) and not torch.isfinite(outs[1]).all()      # b's reduce has not run
+        wgrad(dys[1], outs[0], accumulate=True)              # accumulating: reduced at once, never recorded
+        assert len(pa) == 0
+        ops.wgrad_reduce_pending(pb)
+    finally:
+        ops.wgrad_disarm(pa)
+        ops.wgrad_disarm(pb)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], ref[1]) and torch.equal(outs[0], acc_ref)
 
 
 @pytest.mark.parametrize("B,L,Cout,D", [(2, 256, 256, 512), (4, 128, 128, 256), (8, 64, 64, 256), (16, 32, 64, 512), (32, 256, 256, 4096)])

@@ -506,7 +506,7 @@ def test_forked_graph_optimizer_first_order_is_bit_identical(dtype):
         ref.append([float(ls[k].reshape(-1)[0]) for k in ("loss_cls", "loss_reg", "loss_iou")])
     r1.remove()
     m2, r2, o2 = build()
-    fs = ForkedStep(m2, batch, DF.loss_total, r2, o2)
+    fs = ForkedStep(m2, batch, DF.loss_total, r2, o2, rotate=True)          # (explicit opt-in since round 6)
     assert fs.rotate
     got = []
     for _ in range(3):                                        # call 1 = prime (gradients only), calls 2, 3 = update + gradients
@@ -557,7 +557,7 @@ def test_forked_optimizer_first_at_the_benchmarked_shape_equals_the_plain_loop()
         return m, red, FusedAdam(red, lr=1e-3, max_norm=0.5)
 
     m2, r2, o2 = setup()
-    fk = ForkedStep(m2, batch[:5], DF.loss_total, r2, o2).warm(2).capture()
+    fk = ForkedStep(m2, batch[:5], DF.loss_total, r2, o2, rotate=True).warm(2).capture()
     assert fk.rotate
     for _ in range(5):
         l2 = fk()
