@@ -506,7 +506,8 @@ def main():
                                                          zip(("trunk", "input stage", "gate projections", "query encoder")
                                                              if deferred else ["bucket %d" % i for i in range(len(reducer.buckets))],
                                                              reducer.buckets)],
-                                             "max_over_ranks": [round(max(float(t[2 + i]) for t in allr), 4) for i in range(len(reducer.buckets))]},
+                                             "max_over_ranks": [round(max(float(t[2 + i]) for t in allr), 4) for i in range(len(reducer.buckets))],
+                                             "by_rank": [[round(float(t[2 + i]), 4) for i in range(len(reducer.buckets))] for t in allr]},
                     "note": "exposed = GPU time the step's stream waits in GradReducer.finish(): per bucket, HIP events around that "
                             "bucket's wait (the exchanges are launched after the phase that produces them and overlap the next phase's "
                             "replay; the last bucket has nothing to hide behind)"}

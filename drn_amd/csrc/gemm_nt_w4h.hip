@@ -13,6 +13,9 @@
 // shifts, zero rows at the sequence edges).  Same MFMA instruction, same K order per output element, same epilogue statements
 // (nt_epi_chunk_vec) and the BatchNorm statistics in the order nt_bn_stats<2, 4, 4, 2> adds them (a 128-row slab = two 64-row wave
 // rows there, the two halves of a wave's 128 rows here): results are bit-identical to the 128 x 128 kernel these launches ran on.
+#ifdef DRN_NT_PHASES
+#define DRN_NT_PHASES_NAME drn_debug_nt_phases_w4h      // (this translation unit's own stamp table: scripts/experiments/w4_phases.py)
+#endif
 #include "gemm_nt_kernel.h"
 #include "gemm_nt_w4_loop.inc"
 
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
   NtHeader P;
   GemmProb pr;
   int g, tm, tn;
+  NT_PHASE(0);
   nt_fetch(P_arg, P, pr, g, blockIdx.x);
   nt_locate<256>(P, pr, tm, tn);
   const int m0 = tm * 256, n0 = tn * 128;
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
   const int k_lo = (int)blockIdx.y * kt_per, k_hi = min(ksteps_all, k_lo + kt_per);
   const char* sb = (const char*)pr.B + (long)n0 * pr.ldb * 2 + (long)k_lo * 128;
   const int trips = (k_hi - k_lo) - 2;
+  NT_PHASE(1);
 
   if constexpr (CONV) {
     const unsigned long long abase = (unsigned long long)(uintptr_t)pr.A + (unsigned long long)((long)(m0 - 1) * pr.lda * 2);
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
                  : W4H_LOOP_CLOBBERS);
   }
   __syncthreads();        // everybody is past its last fragment read: the LDS becomes the epilogue's staging patches
+  NT_PHASE(2);
 
   if (P.ksplit > 1) {
     const int tile_id = blockIdx.x, ks = P.ksplit;
@@ -251,8 +257,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
 #define W4H_CH(CH) w4h_acc_chunk<CH>(a2); nt_epi_chunk_vec<bf16_t, 4>(pr, a2, wbuf, m0 + wr * 128 + CH * 32, ncol0, bias_v)
   W4H_CH(0); W4H_CH(1); W4H_CH(2); W4H_CH(3);
 #undef W4H_CH
+  NT_PHASE(3);
   // statistics after the stores have been issued (as nt_epilogue does), in the LDS beyond the store patches
   if (pr.stats) w4h_bn_stats((float*)(smem + 4 * (32 * (64 * 2 + 16))), pr.stats, pr.M, pr.N, m0, n0, tm, wr, wc);
+#ifdef DRN_NT_PHASES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the stamp that follows = the stores have left the wave)
+#endif
+  NT_PHASE(4);
 }
 
 // Can every problem of this launch run on gemm_nt_w4h_kernel<conv>?  All problems of a launch must be of one kind.

@@ -129,7 +129,7 @@ def test_in_place_and_bit_identical_from_run_to_run(dt):
     Ms, C = (8192, 4096, 2048), 512
     lv = _levels(Ms, C, dt, seed=3)
     a, dga, dba, _ = _run(lv, C, dt, True, True, one=True)
-    tws = [v for k, v in ops._persistent.items() if k[0] == "bn_bwd_one"]
+    tws = [v for k, v in ops._persistent.items() if isinstance(k[0], tuple) and k[0][0] == "bn_bwd_one"]      # (keyed per stream)
     assert tws, "the one-launch path did not run"
     gens = [int(t[0].item()) for t in tws]
     b, dgb, dbb, _ = _run(lv, C, dt, True, True, one=True, inplace=True)

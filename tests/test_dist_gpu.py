@@ -139,3 +139,36 @@ def test_three_phase_graph_step_two_ranks_one_gpu(case):
     for p in procs:
         p.join(timeout=120)
     assert got == [(0, "ok"), (1, "ok")], got
+
+
+def test_bench_eight_ranks_one_gpu():
+    """`python bench.py --gpus 8` end to end at world = 8 -- the launch the driver's scaling run makes -- with the eight ranks sharing
+    this box's one GPU over gloo (DRN_FORCE_DEVICE=0, DRN_DIST_BACKEND=gloo) on tiny shapes: rank plumbing (torch.distributed.run,
+    RANK / LOCAL_RANK / WORLD_SIZE), the four-phase graph step with its bucket order, the max-over-ranks timing and the per-rank /
+    per-bucket `exposed_ms` reporting.  Replaces the reference's single-process nn.DataParallel entry (main.py:99).  RCCL itself
+    needs one GPU per rank; everything around the collective runs here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DRN_FORCE_DEVICE="0", DRN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "2",
+                        "--T", "32", "--D", "64", "--stage", "3", "--cpu-steps", "0", "--no-f32", "--no-other-configs", "--no-trainer",
+                        "--no-kernel-timing"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-4000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["rccl_ranks"] == 8
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp8" and "gloo" in d["backend"]
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]          # whole-job clips/s over the max-over-ranks time
+    pr = d["per_rank"]
+    assert len(pr["clips_per_s"]) == 8 and len(pr["allreduce_exposed_ms_per_step"]) == 8
+    names = pr["exposed_ms_by_bucket"]["buckets"]
+    assert len(names) == 4 and names[0].startswith("trunk") and names[1].startswith("input") and names[2].startswith("gate") and \
+        names[3].startswith("query"), names              # the order backward finishes the parts in
+    by_rank = pr["exposed_ms_by_bucket"]["by_rank"]
+    assert len(by_rank) == 8 and all(len(v) == 4 and all(x >= 0.0 for x in v) for v in by_rank)
+    assert pr["exposed_ms_by_bucket"]["max_over_ranks"] == [max(v[i] for v in by_rank) for i in range(4)]
