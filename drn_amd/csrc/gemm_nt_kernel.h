@@ -97,6 +97,13 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // Ordering point for LDS traffic that stays inside ONE wavefront (a per-wave staging patch): the LDS unit executes a
 // wave's DS instructions in issue order, so only the compiler must be kept from reordering -- no workgroup barrier.
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// -DDRN_NT_PHASES: cycle stamps (s_memtime) of workgroup 0 / thread 0 inside the epilogue, rows 4000.. of the phase table
+#ifdef DRN_NT_PHASES
+static __device__ long long g_nt_epi_cyc[64];
+#define EPI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_nt_epi_cyc[(i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EPI_STAMP(i) do { } while (0)
+#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -378,14 +385,22 @@ __device__ __forceinline__ void nt_epi_chunk_vec(const GemmProb& pr, const f32x4
             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
             *(u32x2_t*)(wbuf + rl * PITCH + (ni * 16 + ((l & 15) >> 2) * 4) * 2) = (u32x2_t){o0, o1};
           }
+        EPI_STAMP(10);
         wave_lds_sync();
+        EPI_STAMP(11);
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
           const int rl = it * RPI + l / LPR, cv = l % LPR;
           const uint4 raw = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
+#ifdef DRN_EPI_NOSTORE      // (timing experiment, scripts/experiments/w4_phases.py: the epilogue without its global stores)
+          asm volatile("" : : "v"(raw.x), "v"(raw.y), "v"(raw.z), "v"(raw.w));
+#else
           *(uint4*)(dst + ((long)(mrow0 + rl) * ldd + ncol0 + cv * VEC)) = raw;
+#endif
         }
+        EPI_STAMP(12);
         wave_lds_sync();
+        EPI_STAMP(13);
       }
       return;
     }

@@ -10,115 +10,20 @@
 //
 // Two kernels: plain products (1x1 convolutions / Linear, forward or data gradient: taps = 1, stride 1) and k = 3 / stride 1 / pad 1
 // convolutions (forward: mode 0, data gradient: mode 1) -- the A side of the latter is gemm_nt_w4c_kernel's (buffer descriptor, tap
-// shifts, zero rows at the sequence edges).  Same MFMA instruction, same K order per output element, same epilogue statements
-// (nt_epi_chunk_vec) and the BatchNorm statistics in the order nt_bn_stats<2, 4, 4, 2> adds them (a 128-row slab = two 64-row wave
-// rows there, the two halves of a wave's 128 rows here): results are bit-identical to the 128 x 128 kernel these launches ran on.
+// shifts, zero rows at the sequence edges).  Same MFMA instruction and K order per output element, same `+ bias`, `* gate` and rounding:
+// the OUTPUT is bit-identical to the 128 x 128 kernel these launches ran on.  Round 6: the MFMAs take the weight fragment first, so the
+// accumulator tiles come out transposed and the epilogue needs no transposition (see "epilogue" below); the per-slab BatchNorm
+// statistics are the same (sum, M2) pairs summed in this kernel's own fixed order (they agree with the 128 x 128 kernel's to fp32
+// rounding, not bit for bit).
 #ifdef DRN_NT_PHASES
 #define DRN_NT_PHASES_NAME drn_debug_nt_phases_w4h      // (this translation unit's own stamp table: scripts/experiments/w4_phases.py)
 #endif
 #include "gemm_nt_kernel.h"
+#include "w4_epilogue.h"
 #include "gemm_nt_w4_loop.inc"
-
-template <int R>
-__device__ __forceinline__ float w4h_acc_read() {
-  float v;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(R));
-  return v;
-}
-// a2[mi2][ni] = accumulator tile (2*CH + mi2, ni) of the wave's 8 x 4 grid = a[((2*CH + mi2)*4 + ni)*4 .. +3]
-template <int CH, int I = 0>
-__device__ __forceinline__ void w4h_acc_chunk(f32x4 (&a2)[2][4]) {
-  if constexpr (I < 8) {
-    constexpr int R = (CH * 8 + I) * 4;
-    a2[I / 4][I % 4] = (f32x4){w4h_acc_read<R>(), w4h_acc_read<R + 1>(), w4h_acc_read<R + 2>(), w4h_acc_read<R + 3>()};
-    w4h_acc_chunk<CH, I + 1>(a2);
-  }
-}
-// column sums of grid rows [MI0, MI0 + 4) (64 rows: one wave row of the 128 x 128 kernel), mi ascending, r ascending
-template <int MI0, int I = 0>
-__device__ __forceinline__ void w4h_colsum(float (&sm)[4]) {
-  if constexpr (I < 16) {
-    constexpr int R = ((MI0 + I / 4) * 4 + I % 4) * 4;
-    sm[I % 4] += w4h_acc_read<R>();
-    sm[I % 4] += w4h_acc_read<R + 1>();
-    sm[I % 4] += w4h_acc_read<R + 2>();
-    sm[I % 4] += w4h_acc_read<R + 3>();
-    w4h_colsum<MI0, I + 1>(sm);
-  }
-}
-template <int MI0, int I = 0>
-__device__ __forceinline__ void w4h_colsq(float (&q)[4], const float (&mean)[4], const int mrow0, const int M) {
-  if constexpr (I < 16) {
-    constexpr int R = ((MI0 + I / 4) * 4 + I % 4) * 4;
-    const int m = mrow0 + (I / 4) * 16 + ((threadIdx.x & 63) >> 4) * 4;
-    const float d0 = w4h_acc_read<R>() - mean[I % 4], d1 = w4h_acc_read<R + 1>() - mean[I % 4];
-    const float d2 = w4h_acc_read<R + 2>() - mean[I % 4], d3 = w4h_acc_read<R + 3>() - mean[I % 4];
-    q[I % 4] += m + 0 < M ? d0 * d0 : 0.f;
-    q[I % 4] += m + 1 < M ? d1 * d1 : 0.f;
-    q[I % 4] += m + 2 < M ? d2 * d2 : 0.f;
-    q[I % 4] += m + 3 < M ? d3 * d3 : 0.f;
-    w4h_colsq<MI0, I + 1>(q, mean, mrow0, M);
-  }
-}
-
-// Per-128-row-slab BatchNorm statistics of the wave's 128 rows x 64 columns, the arithmetic and ORDER of nt_bn_stats<2, 4, 4, 2>
-// (128 x 128 tile of 64 x 32 waves): there a slab's column sum is (sum over wave row 0: mi, r ascending, then lanes +16, +32) +
-// (the same over wave row 1), added as 0 + a + b; the mean is that / rows; the centred squares likewise.
-__device__ __forceinline__ void w4h_bn_stats(float* shs, float* __restrict__ stats, const int M, const int N, const int m0, const int n0,
-                                             const int tm, const int wr, const int wc) {
-  const int tid = threadIdx.x, l = tid & 63;
-  constexpr int TN = 128, SLABS = 2;
-  float* shm = shs + 2 * TN;                       // [SLABS][TN] slab means
-  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-  w4h_colsum<0>(sa);
-  w4h_colsum<4>(sb);
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    float a = sa[ni], b = sb[ni];
-    a += __shfl_xor(a, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    b += __shfl_xor(b, 16, 64);
-    b += __shfl_xor(b, 32, 64);
-    float v = 0.f;
-    v += a;
-    v += b;
-    if (l < 16) shs[wr * TN + wc * 64 + ni * 16 + l] = v;
-  }
-  __syncthreads();
-  for (int i = tid; i < SLABS * TN; i += 256) {
-    const int n = i % TN, slab = i / TN;
-    const int grow = tm * SLABS + slab;
-    const float v = shs[slab * TN + n];
-    const int rows = min(128, M - grow * 128);
-    shm[i] = rows > 0 ? v / (float)rows : 0.f;
-    if (n0 + n < N && rows > 0) stats[((long)grow * 2 + 0) * N + n0 + n] = v;
-  }
-  __syncthreads();
-  float mean[4], qa[4] = {0.f, 0.f, 0.f, 0.f}, qb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) mean[ni] = shm[wr * TN + wc * 64 + ni * 16 + (l & 15)];
-  const int mw = m0 + wr * 128;
-  w4h_colsq<0>(qa, mean, mw, M);
-  w4h_colsq<4>(qb, mean, mw + 64, M);
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    float a = qa[ni], b = qb[ni];
-    a += __shfl_xor(a, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    b += __shfl_xor(b, 16, 64);
-    b += __shfl_xor(b, 32, 64);
-    float v = 0.f;
-    v += a;
-    v += b;
-    if (l < 16) shs[wr * TN + wc * 64 + ni * 16 + l] = v;
-  }
-  __syncthreads();
-  for (int i = tid; i < SLABS * TN; i += 256) {
-    const int n = i % TN, slab = i / TN;
-    const int grow = tm * SLABS + slab;
-    if (n0 + n < N && grow * 128 < M) stats[((long)grow * 2 + 1) * N + n0 + n] = shs[slab * TN + n];
-  }
-}
+#ifdef DRN_NT_PHASES
+extern "C" int drn_debug_epi_cyc(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_epi_cyc), (size_t)n * 8); }
+#endif
 
 // ---- split-K inside the launch (conv0's forward: 64 tiles x 204 K-steps): workgroup row y owns K-steps [k_lo, k_hi), publishes its
 // 128 accumulator registers per lane as 32 write-through 16-byte pieces straight out of the AGPRs (lane-contiguous: 4 KB per wave
@@ -248,18 +153,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
     __syncthreads();
   }
 
-  const int ncol0 = n0 + wc * 64;
-  char* wbuf = smem + w * (32 * (64 * 2 + 16));
-  float bias_v[4];
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) bias_v[ni] = pr.bias ? pr.bias[ncol0 + ni * 16 + (l & 15)] : 0.f;
-  f32x4 a2[2][4];
-#define W4H_CH(CH) w4h_acc_chunk<CH>(a2); nt_epi_chunk_vec<bf16_t, 4>(pr, a2, wbuf, m0 + wr * 128 + CH * 32, ncol0, bias_v)
-  W4H_CH(0); W4H_CH(1); W4H_CH(2); W4H_CH(3);
-#undef W4H_CH
   NT_PHASE(3);
-  // statistics after the stores have been issued (as nt_epilogue does), in the LDS beyond the store patches
-  if (pr.stats) w4h_bn_stats((float*)(smem + 4 * (32 * (64 * 2 + 16))), pr.stats, pr.M, pr.N, m0, n0, tm, wr, wc);
+  w4h_epilogue<4>(pr, smem + w * (32 * (4 * 32 + 16)), m0 + wr * 128, n0 + wc * 64, tm * 2 + wr);
 #ifdef DRN_NT_PHASES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the stamp that follows = the stores have left the wave)
 #endif

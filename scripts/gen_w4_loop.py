@@ -57,6 +57,9 @@ class Cfg:
     adv = 128           # bytes the operand pointers advance per K-step (0: every K-step re-reads the first one -- L2-hit ablation)
     tapil = False       # conv mode with the taps INTERLEAVED: K-step j = (channel block j / 3, tap j % 3) -- see advance_tap_il
     half = False        # 256 x 128 output tile (gemm_nt_w4h_kernel): 128 x 64 per wave, B items of 128 rows -- see the notes at `Geo`
+    swap = False        # MFMA operands exchanged (weights fragment first): the 16 x 16 accumulator tiles come out TRANSPOSED -- lane l holds
+                        # C[16 mi + (l & 15)][16 ni + 4 (l >> 4) + r], four consecutive COLUMNS of one row, which is what a row-major bf16
+                        # store wants (8 bytes per lane, no transposition through DPP / LDS in the epilogue); same products, same K order
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -282,7 +285,8 @@ def half_step(ks, reads=True, dma=None, wait=None, barrier=False, adv_read=False
                     q = (n // 2) % 16
                     L.append("v_mfma_f32_32x32x16_bf16 a[%d:%d], %s, %s, a[%d:%d]" % (16 * q, 16 * q + 15, frag(A_SET[ks], mi), frag(B_SET[ks], ni), 16 * q, 16 * q + 15))
             else:
-                L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(mi, ni), frag(A_SET[ks], mi), frag(B_SET[ks], ni), acc(mi, ni)))
+                ops_ = (frag(B_SET[ks], ni), frag(A_SET[ks], mi)) if cfg.swap else (frag(A_SET[ks], mi), frag(B_SET[ks], ni))
+                L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(mi, ni), ops_[0], ops_[1], acc(mi, ni)))
         L += fill[n]
     L += tail
     return L
@@ -396,9 +400,18 @@ with open(args.out, "w") as f:
     for ln in lines:
         f.write('  "%s\\n\\t" \\\n' % ln)
     f.write('  ""\n')
+    cfg = Cfg(conv=True, swap=True)
+    lines = build()
+    check_scc(lines)
+    f.write("// conv mode, transposed accumulator tiles (gemm_nt_w4c_kernel<true>): %d instructions\n" % len(lines))
+    f.write("#define W4CS_LOOP_ASM \\\n")
+    for ln in lines:
+        f.write('  "%s\\n\\t" \\\n' % ln)
+    f.write('  ""\n')
     # 256 x 128 tiles (gemm_nt_w4h_kernel): 32 MFMAs per half-step -> one fragment read after every 2nd, one piece after every 3rd
-    for name, c in (("W4H_LOOP_ASM", Cfg(half=True, ds_every=2, dma_every=3)), ("W4HC_LOOP_ASM", Cfg(half=True, conv=True, ds_every=2, dma_every=3)),
-                    ("W4HT_LOOP_ASM", Cfg(half=True, conv=True, tapil=True, ds_every=2, dma_every=3))):
+    # (transposed accumulator tiles: gemm_nt_w4h_kernel's epilogue stores rows straight out of the AGPRs)
+    for name, c in (("W4H_LOOP_ASM", Cfg(half=True, swap=True, ds_every=2, dma_every=3)), ("W4HC_LOOP_ASM", Cfg(half=True, swap=True, conv=True, ds_every=2, dma_every=3)),
+                    ("W4HT_LOOP_ASM", Cfg(half=True, swap=True, conv=True, tapil=True, ds_every=2, dma_every=3))):
         cfg = c
         lines = build()
         check_scc(lines)

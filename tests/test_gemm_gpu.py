@@ -641,8 +641,8 @@ def test_w4c_conv_kernel_is_bit_identical_to_the_general_kernel(monkeypatch, cas
         torch.cuda.synchronize()
         outs.append((C, st))
     assert torch.equal(outs[0][0], outs[1][0])
-    if stats:
-        assert torch.equal(outs[0][1], outs[1][1])
+    if stats:         # (round 6: gemm_nt_w4c_kernel<true> sums the slab statistics in its own fixed order)
+        assert stats_agree(outs[0][1], outs[1][1])
     assert torch.isfinite(outs[1][0].float()).all()
 
 
@@ -739,7 +739,7 @@ def test_w4c_conv_kernel_stress_many_launches_stay_bit_identical(monkeypatch):
             ops.gemm_nt([ops.gemm_desc(A, W, C, M, N, Cin, taps=3, pad=1, mode=mode, Lout=L, Lsrc=L, stats=st)], ops.BF16)
             outs.append((C, st))
         torch.cuda.synchronize()
-        bad += int(not torch.equal(outs[0][0], outs[1][0]) or (mode == 0 and not torch.equal(outs[0][1], outs[1][1])))
+        bad += int(not torch.equal(outs[0][0], outs[1][0]) or (mode == 0 and not stats_agree(outs[0][1], outs[1][1])))
     assert bad == 0, "%d of 40 launches differ" % bad
 
 
@@ -755,6 +755,15 @@ W4H_CASES = [
     ([(8, 32)], 128, 128, 3, 1, True, False, True, 0),
     ([(2, 128)], 256, 128, 3, 0, True, False, True, 64),             # row stride != channels
 ]
+
+
+def stats_agree(sh, sg):
+    """Per-slab BatchNorm statistics (sum, M2) of two kernels that add the same fp32 accumulators in different (fixed) orders: equal to
+    fp32 rounding of a 128-term sum, not bit for bit."""
+    assert torch.isfinite(sh).all() and torch.isfinite(sg).all()
+    scale = float(sg[:, 0].abs().max()) + 1.0
+    return bool((sh[:, 0] - sg[:, 0]).abs().max() <= 2e-5 * scale) and \
+        bool(((sh[:, 1] - sg[:, 1]).abs() <= 2e-5 * sg[:, 1].abs() + 1e-5 * scale).all())
 
 
 def _w4h_launch(ops, case, flag, monkeypatch, seed=0):
@@ -782,8 +791,10 @@ def _w4h_launch(ops, case, flag, monkeypatch, seed=0):
 
 @pytest.mark.parametrize("case", W4H_CASES)
 def test_w4h_kernel_is_bit_identical_to_the_128_tile_kernel(monkeypatch, case):
-    """Same MFMAs, same K order per output element, same epilogue statements, BatchNorm statistics in nt_bn_stats<2, 4, 4, 2>'s
-    order: what the 4-wave 256 x 128 kernel writes equals what conv_gemm_nt_kernel<bf16, 2, true, 2, 4, 4, 2> writes, bit for bit."""
+    """Same MFMAs (operands exchanged: the tiles come out transposed), same K order per output element, same bias / gate / rounding:
+    the OUTPUT the 4-wave 256 x 128 kernel writes equals what conv_gemm_nt_kernel<bf16, 2, true, 2, 4, 4, 2> writes, bit for bit.  The
+    per-slab BatchNorm statistics are summed in the kernel's own fixed order since round 6 (per lane over the 8 row tiles, then over a
+    DPP row): equal to fp32 rounding, and bit-identical from run to run."""
     from drn_amd import ops
     kind_h, outs_h, _ = _w4h_launch(ops, case, 1, monkeypatch)          # from ONE 256 x 128 tile on
     kind_g, outs_g, keep = _w4h_launch(ops, case, 0, monkeypatch)
@@ -792,7 +803,10 @@ def test_w4h_kernel_is_bit_identical_to_the_128_tile_kernel(monkeypatch, case):
         assert torch.equal(Ch, Cg)
         assert torch.isfinite(Ch.float()).all()
         if sh is not None:
-            assert torch.equal(sh, sg)
+            assert stats_agree(sh, sg)
+    outs_h2 = _w4h_launch(ops, case, 1, monkeypatch)[1]
+    for (Ch, sh), (C2, s2) in zip(outs_h, outs_h2):                  # deterministic: the same bits again
+        assert torch.equal(Ch, C2) and (sh is None or torch.equal(sh, s2))
     # ... and close to the product itself (first level, plain cases without a gate)
     levels, N, Cin, taps, mode, bias, stats, gate, pad = case
     if taps == 1 and not gate:
@@ -865,7 +879,7 @@ def test_w4h_kernel_stress_many_launches_stay_bit_identical(monkeypatch):
             outs.append(res)
         torch.cuda.synchronize()
         for (Ch, sh), (Cg, sg) in zip(*outs):
-            bad += int(not torch.equal(Ch, Cg) or (mode == 0 and not torch.equal(sh, sg)))
+            bad += int(not torch.equal(Ch, Cg) or (mode == 0 and not stats_agree(sh, sg)))
     assert bad == 0, "%d level outputs of 40 launches differ" % bad
 
 

@@ -67,3 +67,33 @@ def test_one_launch_batchnorm_backward_holds_its_rows_in_registers(tmp_path):
     for k in ks:
         r = table[k]
         assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (k, r)
+
+
+def test_compiler_never_touches_the_accumulators_of_the_hand_scheduled_kernels(tmp_path):
+    """gemm_nt_w4 / w4c / w4h keep their results in AGPRs that only inline asm reads and writes -- the compiler does not know they are
+    live after the loop statement and is free to park its own values there (gfx950: a unified 512-register file, `v_accvgpr_write` as a
+    cheap spill).  Round 6 met exactly that: with the statistics folded into the store pass of the 256 x 256 epilogue it postponed 85
+    additions and kept their operands in a58..a71 -- accumulator tiles not stored yet; wrong outputs, zero spills in the metadata.
+    So: compile the two files to assembly and refuse ANY AGPR access outside the asm statements."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "drn_amd", "csrc")
+    procs = []
+    for name in ("gemm_nt_w4", "gemm_nt_w4h"):
+        out = os.path.join(str(tmp_path), name + ".s")
+        procs.append((name, out, subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+                                                   "-Wno-unused-function", "--cuda-device-only", "-S", "-o", out, name + ".hip"],
+                                                  cwd=csrc, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    for name, out, p in procs:
+        assert p.wait(timeout=900) == 0, name
+        inasm, bad, statements = False, [], 0
+        for ln in open(out):
+            if "#ASMSTART" in ln:
+                inasm, statements = True, statements + 1
+            elif "#ASMEND" in ln:
+                inasm = False
+            elif not inasm and "v_accvgpr_" in ln:
+                bad.append(ln.strip())
+        assert statements > 100, (name, statements)          # (the accumulator reads of the epilogues are asm statements of their own)
+        assert not bad, (name, len(bad), bad[:8])
