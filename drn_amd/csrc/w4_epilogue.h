@@ -19,6 +19,9 @@ __device__ __forceinline__ float w4h_acc_read() {
 // it with the global stores compiled OUT -- behind K loops of 6-23 us; one wave per SIMD hides no latency.  Now 4.0-4.4 us.)
 // Same products, same K order, same `+ bias`, `* gate`, rounding: the output bits are those of the 128 x 128 kernel.  The slab
 // statistics are the same (sum, M2) pairs in a different -- fixed -- summation order.
+// the lane number from the hardware (v_mbcnt), not from threadIdx: a value derived from threadIdx BEFORE the loop statement would have to
+// survive it in v0..v112 -- the statement owns the rest -- and with the staging offsets there already, the compiler spilled to scratch
+__device__ __forceinline__ int w4h_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 template <int CTRL>
 __device__ __forceinline__ float w4h_dpp(const float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -38,16 +41,16 @@ __device__ __forceinline__ unsigned w4h_pack_bf16(const float a, const float b) 
   return __builtin_bit_cast(unsigned, p);
 }
 // accumulator tiles (MI, ni), ni = NI0 .. NI - 1, of grid row MI into the lane's place in the patch row
-template <int NI, int MI, int NI0>
+template <int NI, int NIT, int NOFF, int MI, int NI0>
 __device__ __forceinline__ void w4h_row_tiles(const bool gated, const float (&g)[NI][4], char* wrow, const float (&bias4)[NI][4]) {
   if constexpr (NI0 < NI) {
-    constexpr int R = (MI * NI + NI0) * 4;
+    constexpr int R = (MI * NIT + NOFF + NI0) * 4;
     const float x0 = w4h_acc_read<R>(), x1 = w4h_acc_read<R + 1>(), x2 = w4h_acc_read<R + 2>(), x3 = w4h_acc_read<R + 3>();
     float v0 = x0 + bias4[NI0][0], v1 = x1 + bias4[NI0][1], v2 = x2 + bias4[NI0][2], v3 = x3 + bias4[NI0][3];
     if (gated) { v0 *= g[NI0][0]; v1 *= g[NI0][1]; v2 *= g[NI0][2]; v3 *= g[NI0][3]; }
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     *(u32x2_t*)(wrow + NI0 * 32) = (u32x2_t){w4h_pack_bf16(v0, v1), w4h_pack_bf16(v2, v3)};
-    w4h_row_tiles<NI, MI, NI0 + 1>(gated, g, wrow, bias4);
+    w4h_row_tiles<NI, NIT, NOFF, MI, NI0 + 1>(gated, g, wrow, bias4);
   }
 }
 struct W4hOut {
@@ -64,11 +67,11 @@ struct W4hOut {
 // registers -- 16 rows x 32 bytes per instruction, 16 partial lines to the memory pipeline -- 7200 clocks for the tile; these chunks
 // 4300; ONE patch for the whole tile and one wait 5100 (all 224 workgroups then store at once: ~225 clocks per 1 KB instruction is
 // the chip's write rate, not the wave's).  STATS: the raw accumulators' column sums.
-template <int NI, int CH>
+template <int NI, int NIT, int NOFF, int CH>
 __device__ __forceinline__ void w4h_store_chunk(const W4hOut& O, bf16_t* dst, const long ldd, const bool gated, char* wbuf, const int mrow0, const int ncol0,
                                                 const float (&bias4)[NI][4]) {
   constexpr int PITCH = NI * 32 + 16, LPR = NI * 2, RPI = 64 / LPR;
-  const int l = threadIdx.x & 63, rho = l & 15, q = l >> 4;
+  const int l = w4h_lane(), rho = l & 15, q = l >> 4;
   char* wrow = wbuf + rho * PITCH + q * 8;
   float g[NI][4];
 #define W4H_ROW(MI2) do { \
@@ -76,7 +79,7 @@ __device__ __forceinline__ void w4h_store_chunk(const W4hOut& O, bf16_t* dst, co
       const float* gp = O.gate + (long)((mrow0 + CH * 32 + MI2 * 16 + rho) / O.Lout) * O.ldg + ncol0 + 4 * q; \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) _Pragma("unroll") for (int r = 0; r < 4; ++r) g[ni][r] = gp[ni * 16 + r]; \
     } \
-    w4h_row_tiles<NI, 2 * CH + MI2, 0>(gated, g, wrow + MI2 * 16 * PITCH, bias4); } while (0)
+    w4h_row_tiles<NI, NIT, NOFF, 2 * CH + MI2, 0>(gated, g, wrow + MI2 * 16 * PITCH, bias4); } while (0)
   W4H_ROW(0); W4H_ROW(1);
 #undef W4H_ROW
   wave_lds_sync();
@@ -88,87 +91,103 @@ __device__ __forceinline__ void w4h_store_chunk(const W4hOut& O, bf16_t* dst, co
   }
   wave_lds_sync();
 }
-template <int NI>
+template <int NI, int NIT, int NOFF>
 __device__ __forceinline__ void w4h_store_tile(const W4hOut& O, bf16_t* dst, const long ldd, const bool gated, char* wbuf, const int mrow0, const int ncol0,
                                                const float (&bias4)[NI][4]) {
-  w4h_store_chunk<NI, 0>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
-  w4h_store_chunk<NI, 1>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
-  w4h_store_chunk<NI, 2>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
-  w4h_store_chunk<NI, 3>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
+  w4h_store_chunk<NI, NIT, NOFF, 0>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
+  w4h_store_chunk<NI, NIT, NOFF, 1>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
+  w4h_store_chunk<NI, NIT, NOFF, 2>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
+  w4h_store_chunk<NI, NIT, NOFF, 3>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
 }
 // first pass of the statistics: sum over mi of the raw accumulators per column slot.  (Passes of their own, each reading the AGPRs
 // again: folded into the store pass the compiler postponed the additions and parked the values -- in AGPRs it believes free, i.e. in
 // accumulator tiles not stored yet.  tests/test_kernel_resources_cpu.py now refuses any compiler-made AGPR access in these kernels.)
-template <int NI, int I, int I1>
+template <int NI, int NIT, int NOFF, int I, int I1>
 __device__ __forceinline__ void w4h_sum_tiles(float (&cs)[NI][4]) {
   if constexpr (I < I1) {
-    constexpr int ni = I % NI, R = I * 4;
+    constexpr int ni = I % NI, R = ((I / NI) * NIT + NOFF + ni) * 4;
     cs[ni][0] += w4h_acc_read<R>(); cs[ni][1] += w4h_acc_read<R + 1>(); cs[ni][2] += w4h_acc_read<R + 2>(); cs[ni][3] += w4h_acc_read<R + 3>();
-    w4h_sum_tiles<NI, I + 1, I1>(cs);
+    w4h_sum_tiles<NI, NIT, NOFF, I + 1, I1>(cs);
   }
 }
 // second pass of the statistics: sum over mi of (x - mean)^2 per column slot
-template <int NI, int I, int I1>
+template <int NI, int NIT, int NOFF, int I, int I1>
 __device__ __forceinline__ void w4h_sq_tiles(const float (&mean)[NI][4], float (&q)[NI][4]) {
   if constexpr (I < I1) {
-    constexpr int ni = I % NI, R = I * 4;
+    constexpr int ni = I % NI, R = ((I / NI) * NIT + NOFF + ni) * 4;
     const float d0 = w4h_acc_read<R>() - mean[ni][0], d1 = w4h_acc_read<R + 1>() - mean[ni][1];
     const float d2 = w4h_acc_read<R + 2>() - mean[ni][2], d3 = w4h_acc_read<R + 3>() - mean[ni][3];
     q[ni][0] = fmaf(d0, d0, q[ni][0]); q[ni][1] = fmaf(d1, d1, q[ni][1]); q[ni][2] = fmaf(d2, d2, q[ni][2]); q[ni][3] = fmaf(d3, d3, q[ni][3]);
-    w4h_sq_tiles<NI, I + 1, I1>(mean, q);
+    w4h_sq_tiles<NI, NIT, NOFF, I + 1, I1>(mean, q);
   }
 }
-// The whole epilogue of a wave that owns 128 rows x (16 NI) columns in transposed accumulator tiles (this kernel: NI = 4; gemm_nt_w4c_kernel
-// <true>: NI = 8).  mrow = the lane's row of grid row 0, ncolq = the lane's first column of grid column 0; slab = the wave's 128-row slab.
-template <int NI>
+// The whole epilogue of 128 rows x (16 NI) columns of a wave's transposed accumulator tiles: tile (mi, NOFF + ni) of a grid with NIT tiles per
+// row, ni < NI.  gemm_nt_w4h_kernel: NI = NIT = 4; gemm_nt_w4c_kernel<true> (8 tiles per row) runs it twice with NI = 4, NOFF = 0 / 4 --
+// as ONE 8-tile-wide pass the register allocator ran out and parked values in AGPRs (tests/test_kernel_resources_cpu.py).
+// mrow0 / ncol0 = first row / column of the sub-tile; slab = the wave's 128-row slab.
+template <int NI, int NIT = NI, int NOFF = 0>
 __device__ __forceinline__ void w4h_epilogue(const GemmProb& pr, char* wbuf, const int mrow0, const int ncol0, const int slab) {
-  const int l = threadIdx.x & 63;
+  const int l = w4h_lane();
   const int ncolq = ncol0 + 4 * (l >> 4);
-  W4hOut O{(bf16_t*)pr.C, (bf16_t*)pr.C2, pr.gate, (long)pr.ldc, (long)pr.ldc2, (long)pr.ldg, pr.Lout};
+  int Lout = pr.Lout;
+  asm volatile("" : "+s"(Lout));      // (opaque: the reciprocal the staging code derived from Lout before the loop must not be kept alive for the gate rows)
+  W4hOut O{(bf16_t*)pr.C, (bf16_t*)pr.C2, pr.gate, (long)pr.ldc, (long)pr.ldc2, (long)pr.ldg, Lout};
+  float bias4[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[ni][r] = pr.bias ? pr.bias[ncolq + ni * 16 + r] : 0.f;
+  EPI_STAMP(0);
+  if (!pr.stats) {          // (wave-uniform: descriptor fields; the eligibility rules keep statistics and gate / C2 apart)
+    if (O.C2) w4h_store_tile<NI, NIT, NOFF>(O, O.C2, O.ldc2, false, wbuf, mrow0, ncol0, bias4);          // the value before gating
+    if (O.gate) w4h_store_tile<NI, NIT, NOFF>(O, O.C, O.ldc, true, wbuf, mrow0, ncol0, bias4);
+    else w4h_store_tile<NI, NIT, NOFF>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+    return;
+  }
+  // (sum, M2) of the slab's 128 rows per column, nn.BatchNorm1d's training statistics in the form drn_bn_train_apply merges
+  // (include/drn_hip.h); the eligibility rule (M % 256 == 0) makes every slab whole.  Order: column sums first (a pass over the
+  // AGPRs of its own), then the tile goes out chunk by chunk with a quarter of the centred-squares pass behind each chunk's stores --
+  // the store pass is bound by the chip's write rate (every workgroup of the launch stores at this moment), the arithmetic hides in it.
+  float mean[NI][4], q[NI][4];
   {
-    float bias4[NI][4];
+    float cs[NI][4];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bias4[ni][r] = pr.bias ? pr.bias[ncolq + ni * 16 + r] : 0.f;
-    EPI_STAMP(0);
-    if (O.C2) w4h_store_tile<NI>(O, O.C2, O.ldc2, false, wbuf, mrow0, ncol0, bias4);          // the value before gating
-    if (O.gate) w4h_store_tile<NI>(O, O.C, O.ldc, true, wbuf, mrow0, ncol0, bias4);
-    else w4h_store_tile<NI>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
-    EPI_STAMP(1);
-  }
-  if (!pr.stats) return;          // (wave-uniform: a descriptor field)
-  float cs[NI][4];
+      for (int r = 0; r < 4; ++r) cs[ni][r] = 0.f;
+    w4h_sum_tiles<NI, NIT, NOFF, 0, 8 * NI>(cs);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cs[ni][r] = 0.f;
-  w4h_sum_tiles<NI, 0, 8 * NI>(cs);
-  // (sum, M2) of the slab's 128 rows per column, nn.BatchNorm1d's training statistics in the form drn_bn_train_apply merges
-  // (include/drn_hip.h); the eligibility rule (M % 256 == 0) makes every slab whole
-  float mean[NI][4], q[NI][4];
+      for (int r = 0; r < 4; ++r) {
+        cs[ni][r] = w4h_row16_sum(cs[ni][r]);
+        mean[ni][r] = cs[ni][r] * 0.0078125f;
+        q[ni][r] = 0.f;
+      }
+    if ((l & 15) == 0) {      // one lane per column quadruple writes; the four l >> 4 groups cover a tile's 16 columns
+      float* st = pr.stats + (long)slab * 2 * pr.N + ncolq;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      cs[ni][r] = w4h_row16_sum(cs[ni][r]);
-      mean[ni][r] = cs[ni][r] * 0.0078125f;
-      q[ni][r] = 0.f;
+      for (int ni = 0; ni < NI; ++ni) *(float4*)(st + ni * 16) = make_float4(cs[ni][0], cs[ni][1], cs[ni][2], cs[ni][3]);
     }
-  EPI_STAMP(2);
-  w4h_sq_tiles<NI, 0, 8 * NI>(mean, q);
+  }
+  EPI_STAMP(1);
+  w4h_store_chunk<NI, NIT, NOFF, 0>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  w4h_sq_tiles<NI, NIT, NOFF, 0, 2 * NI>(mean, q);
+  w4h_store_chunk<NI, NIT, NOFF, 1>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  w4h_sq_tiles<NI, NIT, NOFF, 2 * NI, 4 * NI>(mean, q);
+  w4h_store_chunk<NI, NIT, NOFF, 2>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  w4h_sq_tiles<NI, NIT, NOFF, 4 * NI, 6 * NI>(mean, q);
+  w4h_store_chunk<NI, NIT, NOFF, 3>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  w4h_sq_tiles<NI, NIT, NOFF, 6 * NI, 8 * NI>(mean, q);
   EPI_STAMP(3);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int r = 0; r < 4; ++r) q[ni][r] = w4h_row16_sum(q[ni][r]);
-  if ((l & 15) == 0) {      // one lane per column quadruple writes; the four l >> 4 groups cover the tile's 16 columns
-    float* st = pr.stats + (long)slab * 2 * pr.N + ncolq;
+  if ((l & 15) == 0) {
+    float* st = pr.stats + (long)slab * 2 * pr.N + pr.N + ncolq;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      *(float4*)(st + ni * 16) = make_float4(cs[ni][0], cs[ni][1], cs[ni][2], cs[ni][3]);
-      *(float4*)(st + pr.N + ni * 16) = make_float4(q[ni][0], q[ni][1], q[ni][2], q[ni][3]);
-    }
+    for (int ni = 0; ni < NI; ++ni) *(float4*)(st + ni * 16) = make_float4(q[ni][0], q[ni][1], q[ni][2], q[ni][3]);
   }
   EPI_STAMP(4);
 #ifdef DRN_NT_PHASES

@@ -95,5 +95,5 @@ if hasattr(lib(), "drn_debug_epi_cyc"):
     buf = (ctypes.c_longlong * 64)()
     lib().drn_debug_epi_cyc(buf, 64)
     c = np.array(buf, dtype=np.int64)
-    print("epilogue counts (level convs, wg 0 wave 0): store pass %d | row sums + means %d | square pass %d | row sums + stat stores %d | drain %d | total %d" % (
-        c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], c[5] - c[0]))
+    print("epilogue counts (level convs, wg 0 wave 0): column sums + means %d | store chunks with the square pass behind them %d | row sums + stat stores %d | drain %d | total %d" % (
+        c[1] - c[0], c[3] - c[1], c[4] - c[3], c[5] - c[4], c[5] - c[0]))
