@@ -196,3 +196,29 @@ __device__ __forceinline__ void w4h_epilogue(const GemmProb& pr, char* wbuf, con
   EPI_STAMP(5);
 }
 
+
+// fp32 destination (weight gradients of prop_fc: gemm_nt_w4_kernel<0, true>): the lane's four consecutive columns of a row are 16
+// contiguous bytes -- stored straight from the registers, + bias; no accumulate here (the launcher keeps those on the other layout).
+// NIT tiles per grid row; columns [16 I0, 16 I0 + COLS) of the wave's tile in passes of four tiles per grid row.
+template <int NIT, int I, int I1>
+__device__ __forceinline__ void w4s_f32_tiles(char* crow, const unsigned rstep, const float (&bias4)[NIT][4]) {
+  if constexpr (I < I1) {
+    constexpr int mi = I / NIT, ni = I % NIT, R = I * 4;
+    const float4 v = make_float4(w4h_acc_read<R>() + bias4[ni][0], w4h_acc_read<R + 1>() + bias4[ni][1], w4h_acc_read<R + 2>() + bias4[ni][2],
+                                 w4h_acc_read<R + 3>() + bias4[ni][3]);
+    *(float4*)(crow + ((unsigned)mi * rstep + ni * 64u)) = v;
+    w4s_f32_tiles<NIT, I + 1, I1>(crow, rstep, bias4);
+  }
+}
+template <int NIT, int NOFF_UNUSED, int COLS_UNUSED>
+__device__ __forceinline__ void w4s_store_f32(const GemmProb& pr, const int mrow0, const int ncol0) {
+  const int l = w4h_lane();
+  const int ncolq = ncol0 + 4 * (l >> 4);
+  float bias4[NIT][4];
+#pragma unroll
+  for (int ni = 0; ni < NIT; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[ni][r] = pr.bias ? pr.bias[ncolq + ni * 16 + r] : 0.f;
+  char* crow = (char*)pr.C + ((long)(mrow0 + (l & 15)) * pr.ldc + ncolq) * 4;
+  w4s_f32_tiles<NIT, 0, 8 * NIT>(crow, 64u * (unsigned)pr.ldc, bias4);          // (16 rows x ldc x 4 bytes per grid row)
+}

@@ -392,6 +392,14 @@ with open(args.out, "w") as f:
         for ln in lines:
             f.write('  "%s\\n\\t" \\\n' % ln)
         f.write('  ""\n')
+    cfg = Cfg(swap=True)
+    lines = build()
+    check_scc(lines)
+    f.write("// shipped schedule, transposed accumulator tiles (gemm_nt_w4_kernel<0, true>): %d instructions\n" % len(lines))
+    f.write("#define W4S_LOOP_ASM \\\n")
+    for ln in lines:
+        f.write('  "%s\\n\\t" \\\n' % ln)
+    f.write('  ""\n')
     cfg = Cfg(conv=True)
     lines = build()
     check_scc(lines)
