@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
   }
 
   NT_PHASE(3);
-  w4h_epilogue<4>(pr, smem + w * (32 * (4 * 32 + 16)), m0 + wr * 128, n0 + wc * 64, tm * 2 + wr);
+  w4h_epilogue<4>(pr, smem + w * (2 * 32 * (4 * 32 + 16)), m0 + wr * 128, n0 + wc * 64, tm * 2 + wr);
 #ifdef DRN_NT_PHASES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the stamp that follows = the stores have left the wave)
 #endif

@@ -40,17 +40,19 @@ __device__ __forceinline__ unsigned w4h_pack_bf16(const float a, const float b) 
   const bf16x2_t p = {(bf16_t)a, (bf16_t)b};
   return __builtin_bit_cast(unsigned, p);
 }
-// accumulator tiles (MI, ni), ni = NI0 .. NI - 1, of grid row MI into the lane's place in the patch row
-template <int NI, int NIT, int NOFF, int MI, int NI0>
-__device__ __forceinline__ void w4h_row_tiles(const bool gated, const float (&g)[NI][4], char* wrow, const float (&bias4)[NI][4]) {
+// accumulator tiles (MI, ni), ni = NI0 .. NI - 1, of grid row MI into the lane's place in the patch row(s).  DUAL: the value before the gate
+// goes to the first patch (the pre-gate copy C2), the gated value to the second, from ONE read of the accumulators.
+template <int NI, int NIT, int NOFF, int MI, int NI0, bool GATED, bool DUAL>
+__device__ __forceinline__ void w4h_row_tiles(const float (&g)[NI][4], char* wrow, char* wrow2, const float (&bias4)[NI][4]) {
   if constexpr (NI0 < NI) {
     constexpr int R = (MI * NIT + NOFF + NI0) * 4;
     const float x0 = w4h_acc_read<R>(), x1 = w4h_acc_read<R + 1>(), x2 = w4h_acc_read<R + 2>(), x3 = w4h_acc_read<R + 3>();
     float v0 = x0 + bias4[NI0][0], v1 = x1 + bias4[NI0][1], v2 = x2 + bias4[NI0][2], v3 = x3 + bias4[NI0][3];
-    if (gated) { v0 *= g[NI0][0]; v1 *= g[NI0][1]; v2 *= g[NI0][2]; v3 *= g[NI0][3]; }
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    *(u32x2_t*)(wrow + NI0 * 32) = (u32x2_t){w4h_pack_bf16(v0, v1), w4h_pack_bf16(v2, v3)};
-    w4h_row_tiles<NI, NIT, NOFF, MI, NI0 + 1>(gated, g, wrow, bias4);
+    if constexpr (DUAL) *(u32x2_t*)(wrow + NI0 * 32) = (u32x2_t){w4h_pack_bf16(v0, v1), w4h_pack_bf16(v2, v3)};
+    if constexpr (GATED) { v0 *= g[NI0][0]; v1 *= g[NI0][1]; v2 *= g[NI0][2]; v3 *= g[NI0][3]; }
+    *(u32x2_t*)((DUAL ? wrow2 : wrow) + NI0 * 32) = (u32x2_t){w4h_pack_bf16(v0, v1), w4h_pack_bf16(v2, v3)};
+    w4h_row_tiles<NI, NIT, NOFF, MI, NI0 + 1, GATED, DUAL>(g, wrow, wrow2, bias4);
   }
 }
 struct W4hOut {
@@ -59,6 +61,7 @@ struct W4hOut {
   const float* gate;   // or NULL
   long ldc, ldc2, ldg;
   int Lout;
+  bool gate_uniform;   // the wave's 128 rows belong to ONE sequence: the gate row is loaded once for the tile
 };
 // One 32-row chunk (grid rows 2 CH, 2 CH + 1) of the wave's tile: + bias, (* gate), round, and -- the lane holding 4 consecutive columns of
 // a row -- ONE ds_write_b64 per accumulator tile into the wave's private LDS patch; then whole 16-byte pieces of whole rows go out
@@ -66,38 +69,51 @@ struct W4hOut {
 // they drain.  Measured (s_memtime of one wave, -DDRN_NT_PHASES, 128 x 64 per wave): the 8 bytes per lane stored straight from the
 // registers -- 16 rows x 32 bytes per instruction, 16 partial lines to the memory pipeline -- 7200 clocks for the tile; these chunks
 // 4300; ONE patch for the whole tile and one wait 5100 (all 224 workgroups then store at once: ~225 clocks per 1 KB instruction is
-// the chip's write rate, not the wave's).  STATS: the raw accumulators' column sums.
-template <int NI, int NIT, int NOFF, int CH>
-__device__ __forceinline__ void w4h_store_chunk(const W4hOut& O, bf16_t* dst, const long ldd, const bool gated, char* wbuf, const int mrow0, const int ncol0,
-                                                const float (&bias4)[NI][4]) {
-  constexpr int PITCH = NI * 32 + 16, LPR = NI * 2, RPI = 64 / LPR;
+// the chip's write rate, not the wave's).  GATED / DUAL: prop_fc's forward writes the pre-gate value AND the gated one; as two passes
+// over the accumulators (what the old epilogue did too) the step was 10 us slower than with the old layout, as one pass with two
+// patches it is the faster one (scripts/experiments/ab_lib.sh).
+template <int NI, int NIT, int NOFF, int CH, bool GATED, bool DUAL>
+__device__ __forceinline__ void w4h_store_chunk(const W4hOut& O, char* wbuf, const int mrow0, const int ncol0, const float (&bias4)[NI][4],
+                                                float (&g)[NI][4]) {
+  constexpr int PITCH = NI * 32 + 16, LPR = NI * 2, RPI = 64 / LPR, PATCH = 32 * PITCH;
   const int l = w4h_lane(), rho = l & 15, q = l >> 4;
   char* wrow = wbuf + rho * PITCH + q * 8;
-  float g[NI][4];
 #define W4H_ROW(MI2) do { \
-    if (gated) { \
+    if (GATED && !O.gate_uniform) { \
       const float* gp = O.gate + (long)((mrow0 + CH * 32 + MI2 * 16 + rho) / O.Lout) * O.ldg + ncol0 + 4 * q; \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) _Pragma("unroll") for (int r = 0; r < 4; ++r) g[ni][r] = gp[ni * 16 + r]; \
     } \
-    w4h_row_tiles<NI, NIT, NOFF, 2 * CH + MI2, 0>(gated, g, wrow + MI2 * 16 * PITCH, bias4); } while (0)
+    w4h_row_tiles<NI, NIT, NOFF, 2 * CH + MI2, 0, GATED, DUAL>(g, wrow + MI2 * 16 * PITCH, wrow + PATCH + MI2 * 16 * PITCH, bias4); } while (0)
   W4H_ROW(0); W4H_ROW(1);
 #undef W4H_ROW
   wave_lds_sync();
 #pragma unroll
   for (int it = 0; it < 32 / RPI; ++it) {
     const int rl = it * RPI + l / LPR, cv = l % LPR;
-    const uint4 raw = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
-    *(uint4*)(dst + ((long)(mrow0 + CH * 32 + rl) * ldd + ncol0 + cv * 8)) = raw;
+    if constexpr (DUAL) {
+      const uint4 pre = *(const uint4*)(wbuf + rl * PITCH + cv * 16);
+      *(uint4*)(O.C2 + ((long)(mrow0 + CH * 32 + rl) * O.ldc2 + ncol0 + cv * 8)) = pre;
+    }
+    const uint4 raw = *(const uint4*)(wbuf + (DUAL ? PATCH : 0) + rl * PITCH + cv * 16);
+    *(uint4*)(O.C + ((long)(mrow0 + CH * 32 + rl) * O.ldc + ncol0 + cv * 8)) = raw;
   }
   wave_lds_sync();
 }
-template <int NI, int NIT, int NOFF>
-__device__ __forceinline__ void w4h_store_tile(const W4hOut& O, bf16_t* dst, const long ldd, const bool gated, char* wbuf, const int mrow0, const int ncol0,
-                                               const float (&bias4)[NI][4]) {
-  w4h_store_chunk<NI, NIT, NOFF, 0>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
-  w4h_store_chunk<NI, NIT, NOFF, 1>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
-  w4h_store_chunk<NI, NIT, NOFF, 2>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
-  w4h_store_chunk<NI, NIT, NOFF, 3>(O, dst, ldd, gated, wbuf, mrow0, ncol0, bias4);
+template <int NI, int NIT, int NOFF, bool GATED, bool DUAL>
+__device__ __forceinline__ void w4h_store_tile(const W4hOut& O, char* wbuf, const int mrow0, const int ncol0, const float (&bias4)[NI][4]) {
+  float g[NI][4];
+  if (GATED && O.gate_uniform) {
+    const int l = w4h_lane();
+    const float* gp = O.gate + (long)(mrow0 / O.Lout) * O.ldg + ncol0 + 4 * (l >> 4);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[ni][r] = gp[ni * 16 + r];
+  }
+  w4h_store_chunk<NI, NIT, NOFF, 0, GATED, DUAL>(O, wbuf, mrow0, ncol0, bias4, g);
+  w4h_store_chunk<NI, NIT, NOFF, 1, GATED, DUAL>(O, wbuf, mrow0, ncol0, bias4, g);
+  w4h_store_chunk<NI, NIT, NOFF, 2, GATED, DUAL>(O, wbuf, mrow0, ncol0, bias4, g);
+  w4h_store_chunk<NI, NIT, NOFF, 3, GATED, DUAL>(O, wbuf, mrow0, ncol0, bias4, g);
 }
 // first pass of the statistics: sum over mi of the raw accumulators per column slot.  (Passes of their own, each reading the AGPRs
 // again: folded into the store pass the compiler postponed the additions and parked the values -- in AGPRs it believes free, i.e. in
@@ -131,7 +147,7 @@ __device__ __forceinline__ void w4h_epilogue(const GemmProb& pr, char* wbuf, con
   const int ncolq = ncol0 + 4 * (l >> 4);
   int Lout = pr.Lout;
   asm volatile("" : "+s"(Lout));      // (opaque: the reciprocal the staging code derived from Lout before the loop must not be kept alive for the gate rows)
-  W4hOut O{(bf16_t*)pr.C, (bf16_t*)pr.C2, pr.gate, (long)pr.ldc, (long)pr.ldc2, (long)pr.ldg, Lout};
+  W4hOut O{(bf16_t*)pr.C, (bf16_t*)pr.C2, pr.gate, (long)pr.ldc, (long)pr.ldc2, (long)pr.ldg, Lout, mrow0 / Lout == (mrow0 + 127) / Lout};
   float bias4[NI][4];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni)
@@ -139,9 +155,17 @@ __device__ __forceinline__ void w4h_epilogue(const GemmProb& pr, char* wbuf, con
     for (int r = 0; r < 4; ++r) bias4[ni][r] = pr.bias ? pr.bias[ncolq + ni * 16 + r] : 0.f;
   EPI_STAMP(0);
   if (!pr.stats) {          // (wave-uniform: descriptor fields; the eligibility rules keep statistics and gate / C2 apart)
-    if (O.C2) w4h_store_tile<NI, NIT, NOFF>(O, O.C2, O.ldc2, false, wbuf, mrow0, ncol0, bias4);          // the value before gating
-    if (O.gate) w4h_store_tile<NI, NIT, NOFF>(O, O.C, O.ldc, true, wbuf, mrow0, ncol0, bias4);
-    else w4h_store_tile<NI, NIT, NOFF>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+    // (a pre-gate copy without a gate has no caller: it goes out as "gated by nothing" through the dual path's first patch only)
+    if (O.C2 && O.gate) w4h_store_tile<NI, NIT, NOFF, true, true>(O, wbuf, mrow0, ncol0, bias4);
+    else if (O.gate) w4h_store_tile<NI, NIT, NOFF, true, false>(O, wbuf, mrow0, ncol0, bias4);
+    else {
+      if (O.C2) {
+        W4hOut P2 = O;
+        P2.C = O.C2; P2.ldc = O.ldc2;
+        w4h_store_tile<NI, NIT, NOFF, false, false>(P2, wbuf, mrow0, ncol0, bias4);
+      }
+      w4h_store_tile<NI, NIT, NOFF, false, false>(O, wbuf, mrow0, ncol0, bias4);
+    }
     return;
   }
   // (sum, M2) of the slab's 128 rows per column, nn.BatchNorm1d's training statistics in the form drn_bn_train_apply merges
@@ -171,13 +195,14 @@ __device__ __forceinline__ void w4h_epilogue(const GemmProb& pr, char* wbuf, con
     }
   }
   EPI_STAMP(1);
-  w4h_store_chunk<NI, NIT, NOFF, 0>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  float gdummy[NI][4];
+  w4h_store_chunk<NI, NIT, NOFF, 0, false, false>(O, wbuf, mrow0, ncol0, bias4, gdummy);
   w4h_sq_tiles<NI, NIT, NOFF, 0, 2 * NI>(mean, q);
-  w4h_store_chunk<NI, NIT, NOFF, 1>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  w4h_store_chunk<NI, NIT, NOFF, 1, false, false>(O, wbuf, mrow0, ncol0, bias4, gdummy);
   w4h_sq_tiles<NI, NIT, NOFF, 2 * NI, 4 * NI>(mean, q);
-  w4h_store_chunk<NI, NIT, NOFF, 2>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  w4h_store_chunk<NI, NIT, NOFF, 2, false, false>(O, wbuf, mrow0, ncol0, bias4, gdummy);
   w4h_sq_tiles<NI, NIT, NOFF, 4 * NI, 6 * NI>(mean, q);
-  w4h_store_chunk<NI, NIT, NOFF, 3>(O, O.C, O.ldc, false, wbuf, mrow0, ncol0, bias4);
+  w4h_store_chunk<NI, NIT, NOFF, 3, false, false>(O, wbuf, mrow0, ncol0, bias4, gdummy);
   w4h_sq_tiles<NI, NIT, NOFF, 6 * NI, 8 * NI>(mean, q);
   EPI_STAMP(3);
 #pragma unroll
