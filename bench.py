@@ -462,6 +462,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     note("timed loop done")
+    ops.check_watchdogs()            # an in-launch exchange that gave up waiting lets invalid values through: such a run is not a measurement
     exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
     exposed_by_bucket = {}
     for i, a, b in ar_bucket_events:
