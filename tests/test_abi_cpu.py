@@ -204,3 +204,25 @@ def test_two_models_do_not_share_deferred_reduce_state():
     assert _lib.WGRAD_PEND_MAX == 24 and ctypes.sizeof(_lib.WgradPendItem) == 40
 
 
+
+
+def test_abi9_argument_checks_answer_before_anything_is_launched():
+    """The per-call conventions of ABI 9 are enforced at the boundary -- these calls fail (or succeed trivially) in argument validation,
+    before any device work, so they run on a box without a GPU: unknown bits in `ksplit`, a corrupt / an empty DrnWgradPending, a second
+    reduce onto an output that already has one recorded."""
+    import ctypes
+    from drn_amd import _lib
+    L = _lib.lib()
+    arr = (_lib.GemmDesc * 1)(_lib.GemmDesc())
+    assert L.drn_gemm_nt_splitk(arr, 4 | 0x100000, None, None, 1, None) != 0 and b"unknown bits in ksplit" in L.drn_last_error()
+    assert L.drn_gemm_nt_splitk_grouped(arr, 1, 2 | 0x10000, None, None, 1, None) != 0
+    p = _lib.WgradPending()
+    assert L.drn_wgrad_reduce_pending(ctypes.byref(p), None, None) == 0 and L.drn_wgrad_pending_blocks(ctypes.byref(p)) == 0      # empty: nothing to do
+    p.n = -1
+    assert L.drn_wgrad_reduce_pending(ctypes.byref(p), None, None) != 0 and b"bad list" in L.drn_last_error()
+    p.n = 1
+    p.it[0].out = 0x1000
+    wd = (_lib.WgradDesc * 1)(_lib.WgradDesc(dY=0x2000, X=0x3000, M=128, Lout=128, Lsrc=128, ldy=128, ldx=128))
+    rc = L.drn_gemm_wgrad(wd, 1, ctypes.c_void_p(0x1000), 128, 128, 1, 1, 0, 0, 0, None, 1, ctypes.byref(p), None)
+    assert rc != 0 and b"already has a deferred reduce pending" in L.drn_last_error()
+    assert p.n == 1                                                       # (the list is untouched by the refused call)
