@@ -338,6 +338,9 @@ def main():
 
     loss_of = lambda losses: losses["loss_iou"] if stage == 2 else DF.loss_total(losses)             # main.py:222-225
 
+    with torch.no_grad():            # the untrained model's loss on the resident batch (checked against the trained one after the run)
+        initial_total = float(loss_of(model(*batch)[1]).detach().float().reshape(-1)[0])
+
     ar_events = None                 # N>1: HIP events around the exchange wait of every timed step (exposed all-reduce time)
     ar_bucket_events = []            # ... and around each bucket's own wait (bucket index, start, end)
 
@@ -463,6 +466,14 @@ def main():
     dt = time.perf_counter() - t0
     note("timed loop done")
     ops.check_watchdogs()            # an in-launch exchange that gave up waiting lets invalid values through: such a run is not a measurement
+    # ... and neither is a run that did not train: the step fits ONE resident batch, so its loss must have stayed finite and not grown.
+    # (Round 6: a build with a store-data hazard in one epilogue ran 3 % FASTER -- the corrupted activations drove the loss to a constant
+    # 6.28, the degenerate operands toggled fewer bits, the chip drew less power and clocked every MFMA kernel 3-7 % higher;
+    # profiles/HISTORY.md.  The parity suite caught it; this keeps such a number out of a bench line as well.)
+    final_total = float(loss_of(losses).detach().float().reshape(-1)[0])
+    if not (final_total == final_total and abs(final_total) != float("inf")) or final_total > 2.0 * initial_total + 1e-3:
+        raise SystemExit("bench.py: the loss went from %.4g to %.4g over the run: the step is not training, not a measurement"
+                         % (initial_total, final_total))
     exposed_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events else 0.0
     exposed_by_bucket = {}
     for i, a, b in ar_bucket_events:

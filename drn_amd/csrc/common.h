@@ -20,6 +20,26 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// A pointer the compiler cannot trace to a kernel argument (assembled from lanes, loaded from a table in memory) is a GENERIC address to
+// it and every access through it a FLAT instruction: those count on the LDS counter as well as the memory one, so each wait for an LDS
+// access also waits for the loads and stores in flight (an epilogue that stages tiles through LDS serialises against its own global
+// stores), and they cannot use the scalar-base addressing mode.  as_global() states what the host guarantees -- it is device memory.
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p) {
+  typedef __attribute__((address_space(1))) T* g_t;
+  g_t g = (g_t)p;
+  asm("" : "+s"(g));        // (opaque, or the two casts fold back into the generic pointer; the addresses this is used for are wave-uniform)
+  return (T*)g;
+}
+template <typename T>
+__device__ __forceinline__ T* as_global_v(T* p) {           // the same for an address that differs from lane to lane
+  typedef __attribute__((address_space(1))) T* g_t;
+  g_t g = (g_t)p;
+  asm("" : "+v"(g));
+  return (T*)g;
+}
+
+
 void drn_set_error(const char* fmt, ...);
 
 #define DRN_CHECK_ARG(cond, ...)          \

@@ -181,6 +181,15 @@ __device__ __forceinline__ void nt_fetch(const GemmParams& P, NtHeader& H, GemmP
   for (int i = 0; i < NT_PROB_DW; ++i) q[i] = nt_rl(sel, i);
   g_out = g;
 }
+// The addresses nt_fetch put together from lanes (and the ones a kernel reads from its argument block by a computed index) are generic
+// pointers to the compiler: every access through them would be a FLAT instruction (common.h, as_global).  The 4-wave kernels call this
+// AFTER their loop statement -- the loop takes raw addresses, and nothing more should be alive across it.
+__device__ __forceinline__ void nt_globalize(GemmProb& pr) {
+  pr.A = as_global(pr.A); pr.B = as_global(pr.B); pr.C = as_global(pr.C); pr.C2 = as_global(pr.C2);
+  pr.bias = as_global(pr.bias); pr.gate = as_global(pr.gate); pr.stats = as_global(pr.stats); pr.sumsq = as_global(pr.sumsq);
+  pr.gb_act = as_global(pr.gb_act); pr.gb_dct = as_global(pr.gb_dct); pr.gb_dgate = as_global(pr.gb_dgate); pr.gb_dsum = as_global(pr.gb_dsum);
+}
+__device__ __forceinline__ void nt_globalize(NtHeader& H) { H.ws = as_global(H.ws); H.counters = as_global(H.counters); }
 
 // Workgroup -> (tile row, tile column) inside its group.
 template <int TM>
@@ -1057,6 +1066,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BNF && MI * NI == 8 && STAGES == 2) 
   GemmProb pr;
   int g, tm, tn;
   nt_fetch(P_arg, P, pr, g, blockIdx.x);
+  nt_globalize(pr);
+  nt_globalize(P);
   // conv -> BN -> ReLU launches: the launch generation (tag of this launch's statistics pairs), requested now, needed in the epilogue
   unsigned bn_gen_v = 0;
   if constexpr (BNF) bn_gen_v = (unsigned)__hip_atomic_load(P.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
                  : W4H_LOOP_CLOBBERS);
   }
   __syncthreads();        // everybody is past its last fragment read: the LDS becomes the epilogue's staging patches
+  nt_globalize(pr);       // (after the loop statement: nothing of it is alive across the loop)
+  nt_globalize(P);
   NT_PHASE(2);
 
   if (P.ksplit > 1) {

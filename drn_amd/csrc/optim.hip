@@ -248,11 +248,11 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
   // tensor, so there are no per-quad table lookups and all 16 loads of the four trips are issued before the first use.
   {
     const long s0 = A.seg_start[seg], s1 = A.seg_start[seg + 1];
-    float* pbase = A.p_ptr[seg];
+    float* pbase = as_global_v(A.p_ptr[seg]);         // (a pointer read from a table: generic to the compiler -- common.h, as_global)
     if (pbase != nullptr && base + OPT_ELEMS_PER_BLOCK <= s1 && base + OPT_ELEMS_PER_BLOCK <= A.n &&
         ((((uintptr_t)(pbase + (base - s0))) & 15) == 0)) {
       float* p = pbase + (base - s0);
-      bf16_t* mp = A.mirror ? A.mirror[seg] : nullptr;
+      bf16_t* mp = A.mirror ? as_global_v(A.mirror[seg]) : nullptr;
       if (mp) mp += base - s0;
       f32x4 g4[4], m4[4], v4[4], p4[4];
 #pragma unroll
@@ -293,10 +293,10 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_bucket_kernel(const AdamArgs
     if (k >= A.n) break;
     while (k >= A.seg_start[seg + 1]) ++seg;
     const long s0 = A.seg_start[seg], s1 = A.seg_start[seg + 1];
-    float* pbase = A.p_ptr[seg];
+    float* pbase = as_global_v(A.p_ptr[seg]);
     if (pbase == nullptr) continue;                       // padding between tensors
     float* p = pbase + (k - s0);
-    bf16_t* mq = (A.mirror && A.mirror[seg]) ? A.mirror[seg] + (k - s0) : nullptr;
+    bf16_t* mq = (A.mirror && A.mirror[seg]) ? as_global_v(A.mirror[seg]) + (k - s0) : nullptr;
     if (k + 4 <= s1 && k + 4 <= A.n && (((uintptr_t)p) & 15) == 0) {
       const f32x4 g4 = *(const f32x4*)(A.g + k);
       f32x4 m4 = *(const f32x4*)(A.m + k), v4 = *(const f32x4*)(A.v + k), p4 = *(const f32x4*)p;
@@ -416,7 +416,8 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_tiled_kernel(const float* __
                                                                 const int* __restrict__ step_counter, float lr, float beta1, float beta2,
                                                                 float eps, float max_norm, float grad_scale) {
   __shared__ float tile[64][64 * TILED_MAXK + 1];
-  const DrnAdamTiledItem it = items[blk_item[blockIdx.x]];
+  DrnAdamTiledItem it = items[blk_item[blockIdx.x]];
+  it.p = as_global(it.p); it.m1 = as_global(it.m1); it.m2 = as_global(it.m2);          // (read from a table: common.h, as_global)
   const int t = blk_tile[blockIdx.x];
   constexpr int tcw = 64;       // channels per tile (192-element tiles for k = 1 -- half as many workgroups -- measured 13 % slower)
   const int r0 = (t / it.tiles_c) * 64, c0 = (t % it.tiles_c) * tcw;
