@@ -97,3 +97,8 @@ def test_compiler_never_touches_the_accumulators_of_the_hand_scheduled_kernels(t
                 bad.append(ln.strip())
         assert statements > 100, (name, statements)          # (the accumulator reads of the epilogues are asm statements of their own)
         assert not bad, (name, len(bad), bad[:8])
+        # ... and no FLAT memory instruction: the descriptor's addresses are assembled from lanes (nt_fetch), which makes them generic
+        # pointers unless as_global() says otherwise -- 2000 flat loads + 1856 flat stores in gemm_nt_w4.hip before round 6; a FLAT access
+        # counts on the LDS counter too, so every wait for the staging patch waited for the tile stores in flight (common.h)
+        flat = [ln.strip() for ln in open(out) if ln.lstrip().startswith(("flat_load", "flat_store", "flat_atomic"))]
+        assert not flat, (name, len(flat), flat[:4])
