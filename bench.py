@@ -658,6 +658,20 @@ def main():
                         "HIP events around each launch of extra EAGER steps on the launch stream (events cannot sit inside a replayed "
                         "graph); inside the replayed graph the same launches run 5-7 % shorter: profiles/*_step_kernel_sequence.txt, "
                         "profiles/*_gemm_table.txt"}
+        if args.dtype == "bf16":
+            # `peak` is the datasheet clock.  The chip clocks to its power budget: what it SUSTAINS on bf16 MFMA with operands that toggle
+            # like data, measured here, now, by a register-only MFMA loop at the issue floor (drn_diag_mfma_sustained; after the timed
+            # region).  No scheduling gets a GEMM past this number; the zero-operand figure shows it is the data, not the loop.
+            try:
+                ops.mfma_sustained(2000)
+                sus, sus0 = ops.mfma_sustained(20000), ops.mfma_sustained(20000, zero_operands=True)
+                roof["sustained"] = {"achieved_over_sustained": round(achieved / sus["tflops"], 4),
+                                     "random_bf16_operands": {k: round(v, 2) for k, v in sus.items()},
+                                     "zero_operands": {k: round(v, 2) for k, v in sus0.items()},
+                                     "note": "256 workgroups x 4 waves of v_mfma_f32_32x32x16_bf16 on registers only, 32 cycles per MFMA and SIMD "
+                                             "= the issue floor; TFLOP/s at the clock the power budget allows (shader cycles / wall time)"}
+            except Exception as e:          # (measurement only: never costs the bench line)
+                roof["sustained"] = {"error": str(e)}
     # t_bound / t_measured with t_bound = max(FLOPs / peak_mfma, compulsory bytes / peak_hbm) over the WHOLE step
     step_flops = fl["step"] * B * world
     bytes_in = 4.0 * B * world * T * D                       # the feature tensor, read once (fp32 in HBM)

@@ -141,7 +141,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.drn_last_error.restype = ctypes.c_char_p
         for fn in ("drn_wgrad_ws_elems", "drn_skinny_group_ws_elems", "drn_opt_nblocks", "drn_gemm_nt_splitk_ws_elems", "drn_gemm_nt_splitk256_ws_elems", "drn_heads_ws_elems",
-                   "drn_conv_tail_bwd_ws_elems", "drn_conv_bn_train_ws_bytes", "drn_wgrad_pending_bytes", "drn_bn_bwd_one_ws_bytes", "drn_lstm_seq_fwd_ws_bytes"):
+                   "drn_conv_tail_bwd_ws_elems", "drn_conv_bn_train_ws_bytes", "drn_wgrad_pending_bytes", "drn_bn_bwd_one_ws_bytes", "drn_lstm_seq_fwd_ws_bytes",
+                   "drn_diag_mfma_ws_bytes"):
             if hasattr(_lib, fn):
                 getattr(_lib, fn).restype = c_int64
     return _lib

@@ -678,7 +678,10 @@ __device__ __forceinline__ void nt_epilogue(const NtHeader& P, const GemmProb& p
 // first K-tile landed / K loop done / exit, read back with drn_debug_nt_phases() -- the fixed part of a small launch.
 #ifdef DRN_NT_PHASES
 static __device__ long long g_nt_phases[4096 * 8];
-#define NT_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) g_nt_phases[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+// (slots 5 / 6: s_memtime -- shader cycles -- at phases 1 / 2, the two ends of the K loop: cycles / wall time = the clock the loop ran at,
+//  scripts/experiments/gemm_clock.py)
+#define NT_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) { g_nt_phases[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    if ((i) == 1 || (i) == 2) g_nt_phases[blockIdx.x * 8 + 4 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
 #ifndef DRN_NT_PHASES_NAME
 #define DRN_NT_PHASES_NAME drn_debug_nt_phases
 #endif

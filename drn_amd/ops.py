@@ -1086,3 +1086,14 @@ def lgp_bwd(x, ldx, qn, att, dout, dx, dqn, B, t, C, dtype):
     ws = workspace(B * ((t // 2 + 3) // 4) * C, dqn.device)
     check(lib().drn_lgp_bwd(_p(x), ldx, _p(qn), _p(att), _p(dout), C, _p(dx), C, _p(dqn), _p(ws), B, t, C, dtype, _stream()),
           "drn_lgp_bwd")
+
+
+def mfma_sustained(iters=20000, zero_operands=False):
+    """MEASUREMENT (bench.py): what the chip sustains on bf16 MFMA under its power budget -- a register-only v_mfma_f32_32x32x16_bf16 loop at
+    the issue floor, random bf16 operands (or zeros).  Returns dict(tflops, clock_ghz, cycles_per_mfma).  See include/drn_hip.h."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ws = torch.empty(int(lib().drn_diag_mfma_ws_bytes()), dtype=torch.uint8, device=dev)
+    tf, ghz, cyc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    check(lib().drn_diag_mfma_sustained(_p(ws), int(iters), int(bool(zero_operands)), ctypes.byref(tf), ctypes.byref(ghz), ctypes.byref(cyc),
+                                        _stream()), "drn_diag_mfma_sustained")
+    return {"tflops": tf.value, "clock_ghz": ghz.value, "cycles_per_mfma": cyc.value}

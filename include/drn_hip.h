@@ -639,6 +639,14 @@ int drn_adam_tiled(const float* g, float* m, float* v, const DrnAdamTiledItem* i
                    const int32_t* blk_tile_dev, int nblocks, const float* total_sumsq, const int* step_counter, float lr, float beta1,
                    float beta2, float eps, float max_norm, float grad_scale, void* stream);
 
+/* MEASUREMENT infrastructure (bench.py; nothing on the product path calls it): what this chip sustains on bf16 MFMA with operands that
+ * toggle like data.  MI355X clocks to its power budget: a register-only v_mfma_f32_32x32x16_bf16 loop at the issue floor (32 cycles per
+ * MFMA and SIMD, 256 workgroups x 4 waves, no LDS or memory traffic) runs at ~2.3 GHz on zeros and ~1.7-1.8 GHz on random bf16 operands.
+ * Launches on `stream`, waits for it, returns TFLOP/s, the effective clock (shader cycles / wall time) and cycles per MFMA.
+ * ws: drn_diag_mfma_ws_bytes() bytes of device memory.  iters: 8 MFMAs per wave each (20000 ~ 3 ms). */
+long drn_diag_mfma_ws_bytes(void);
+int drn_diag_mfma_sustained(void* ws, int iters, int zero_operands, double* tflops, double* clock_ghz, double* cycles_per_mfma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

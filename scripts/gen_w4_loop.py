@@ -55,6 +55,8 @@ class Cfg:
     mfma32 = False      # timing-only ablation: half as many v_mfma_f32_32x32x16_bf16 (same pipe time, twice the issue slack per gap)
     hoist = True        # scalar bookkeeping and M0 writes inside the MFMA stream (False: after it / in front of each piece)
     adv = 128           # bytes the operand pointers advance per K-step (0: every K-step re-reads the first one -- L2-hit ablation)
+    a_pieces = 8        # timing-only ablation (W4_A_PIECES=3 in the environment): conv mode stages only this many of an A item's 8 pieces
+                        # -- a third of the A traffic, what staging a channel block ONCE for its three taps would load (wrong results)
     tapil = False       # conv mode with the taps INTERLEAVED: K-step j = (channel block j / 3, tap j % 3) -- see advance_tap_il
     half = False        # 256 x 128 output tile (gemm_nt_w4h_kernel): 128 x 64 per wave, B items of 128 rows -- see the notes at `Geo`
     swap = False        # MFMA operands exchanged (weights fragment first): the 16 x 16 accumulator tiles come out TRANSPOSED -- lane l holds
@@ -133,7 +135,8 @@ def dma_item(op):
         # conv mode: A through a buffer descriptor (s[92:95]): lane offset v[116 + i] = row offset of the CURRENT tap, 0x80000000
         # (out of range -> the piece gets zeros) where the tap leaves the lane's sequence; s96 = channel byte offset inside the tap
         soff = "s98" if cfg.tapil else "s96"       # (interleaved taps: s98 = channel offset + the tap's row shift)
-        return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "buffer_load_dwordx4 v%d, s[92:95], %s offen lds" % (116 + i, soff)] for i in range(8)]
+        return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "buffer_load_dwordx4 v%d, s[92:95], %s offen lds" % (116 + i, soff)]
+                for i in range(int(os.environ.get("W4_A_PIECES", cfg.a_pieces)))]
     src = "s[80:81]" if op == "a" else "s[82:83]"
     return [["s_add_u32 m0, s89, %d" % (i * 1024), "s_nop 0", "global_load_lds_dwordx4 %%[vo%s%d], %s" % (op, i, src)]
             for i in range(8 if op == "a" else geo().PB)]

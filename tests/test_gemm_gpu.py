@@ -1110,3 +1110,19 @@ def test_w4c_data_gradient_with_the_gate_backward_in_its_epilogue(monkeypatch, B
     tune(monkeypatch, "nt_w4c", 0)
     with pytest.raises(Exception, match="gb_"):
         ops.gemm_nt([d1], ops.BF16)
+
+
+@pytest.mark.gpu
+def test_sustained_mfma_measurement_is_at_the_issue_floor_and_data_dependent():
+    """drn_diag_mfma_sustained (bench.py's `roofline.sustained`): the loop issues one v_mfma_f32_32x32x16_bf16 per 32 cycles and SIMD whatever
+    the operands; the CLOCK is what the operands change (power), so zeros never sustain less than random data, and neither exceeds the
+    datasheet figure."""
+    from drn_amd import ops, _lib
+    r = ops.mfma_sustained(5000)
+    z = ops.mfma_sustained(5000, zero_operands=True)
+    for m in (r, z):
+        assert 31.5 < m["cycles_per_mfma"] < 34.0, m
+        assert 0.8 < m["clock_ghz"] < 2.45 and 500.0 < m["tflops"] < 2520.0, m
+    assert z["tflops"] >= 0.98 * r["tflops"], (r, z)
+    with pytest.raises(_lib.DrnError):
+        _lib.check(_lib.lib().drn_diag_mfma_sustained(None, 0, 0, None, None, None, None), "drn_diag_mfma_sustained")
