@@ -27,6 +27,7 @@ extern "C" int drn_tune(const char* key, int value) {
   if (key && !strcmp(key, "nt_deep")) { g_tune[DRN_TUNE_NT_DEEP] = value; return DRN_OK; }
   if (key && !strcmp(key, "nt_w4h")) { g_tune[DRN_TUNE_NT_W4H] = value; return DRN_OK; }
   if (key && !strcmp(key, "w4h_tapil")) { g_tune[DRN_TUNE_W4H_TAPIL] = value; return DRN_OK; }
+  if (key && !strcmp(key, "w4h_halo")) { g_tune[DRN_TUNE_W4H_HALO] = value; return DRN_OK; }
   if (key && !strcmp(key, "bn1_maxwg")) { g_tune[DRN_TUNE_BN1_MAXWG] = value; return DRN_OK; }
   if (key && !strcmp(key, "nt_deep2")) { g_tune[DRN_TUNE_NT_DEEP2] = value; return DRN_OK; }
   if (key && !strcmp(key, "nt_deep_ks")) { g_tune[DRN_TUNE_NT_DEEP_KS] = value; return DRN_OK; }

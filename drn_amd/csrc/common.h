@@ -96,6 +96,7 @@ int drn_tuning(int key);
 #define DRN_TUNE_NT_W4H 12       // > 0 (160; 128 loses at T = 32, where prop_fc makes 128 such tiles: 1.234 vs 1.220 ms): eligible bf16 launches that would run 128x128 tiles and make at least that many 256x128 tiles run gemm_nt_w4h_kernel
 #define DRN_TUNE_BN1_MAXWG 13   // drn_bn_bwd_one: the smallest row block whose grid is at most this many workgroups (512)
 #define DRN_TUNE_W4H_TAPIL 14   // > 0: split k = 3 launches of gemm_nt_w4h_kernel with at least that many input channels walk K as (channel block, tap)
+#define DRN_TUNE_W4H_HALO 15    // 1: k = 3 launches of gemm_nt_w4h_kernel whose sequences are multiples of 64 rows stage a channel block ONCE for its three taps (W4HX_LOOP_ASM)
 #define DRN_TUNE_NT_DEEP2 10     // > 0: ... and launches of at most THAT many workgroups too when no tile has more than DRN_TUNE_NT_DEEP_KS K-steps (the FPN
 #define DRN_TUNE_NT_DEEP_KS 11   // laterals: 448 tiles of 4-16 K-steps each, where a tile is its own load latency: three K-steps in flight instead of one)
 

@@ -31,6 +31,9 @@ extern "C" int drn_debug_epi_cyc(long long* out, int n) { return (int)hipMemcpyF
 // so the sum does not depend on who was last -- into the AGPRs and runs the normal epilogue.  Same protocol as
 // conv_gemm_nt_kernel's split (gemm_nt_kernel.h); the two statements are W4H_PUBLISH_ASM / W4H_GATHER_ASM (gen_w4_loop.py).
 #define W4H_TAPIL 0x10000      // flag in GemmParams::ksplit (this kernel only)
+#define W4H_HALO 0x100000      // flag in GemmParams::ksplit: the K loop walks (channel block, tap) and stages a channel block ONCE for its three
+                               // taps (W4HX_LOOP_ASM, gen_w4_loop.py: rows -1 .. 256 of the tile as four 66-row blocks, a third of the A traffic)
+constexpr int W4H_LDS = 3 * (32768 + 16384), W4HX_A_RING = 2 * 36864, W4HX_LDS = W4HX_A_RING + 5 * 16384;
 template <bool CONV>
 __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,11 +77,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
   const unsigned lw = lds0 + (unsigned)w * 8192u, lwb = lds0 + (unsigned)w * 4096u;
   // split K (ksplit > 1): workgroup row y owns K-steps [k_lo, k_hi).  W4H_TAPIL (conv launches with a wide input): the K loop walks
   // (channel block, tap) instead of (tap, channel block) -- W4HT_LOOP_ASM -- and a split starts at a whole channel block
+  const bool halo = CONV && (P.ksplit & W4H_HALO) != 0;
   const bool tapil = CONV && (P.ksplit & W4H_TAPIL) != 0;
   P.ksplit &= W4H_TAPIL - 1;       // (the exchange flags DRN_XCHG_* were taken out by nt_fetch)
   const int ksteps_all = pr.K / 64;
   int kt_per = (ksteps_all + P.ksplit - 1) / P.ksplit;
-  if (tapil) kt_per = (kt_per + 2) / 3 * 3;
+  if (tapil || halo) kt_per = (kt_per + 2) / 3 * 3;
   const int k_lo = (int)blockIdx.y * kt_per, k_hi = min(ksteps_all, k_lo + kt_per);
   const char* sb = (const char*)pr.B + (long)n0 * pr.ldb * 2 + (long)k_lo * 128;
   const int trips = (k_hi - k_lo) - 2;
@@ -94,7 +98,45 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4h_kernel(const GemmParams P_
     const unsigned sh0 = fwd ? 0u : 2u * lda2, sh1 = lda2, sh2 = fwd ? 2u * lda2 : 0u;
     const unsigned ma = fwd ? mask_first : mask_last, mc = fwd ? mask_last : mask_first;
     const int per = pr.Cin / 64;                      // K-steps per tap
-    if (tapil) {
+    if (halo) {
+      // a channel block staged once for its three taps.  Wave w stages block w = positions 0 .. 71 = tile rows 64 w - 1 .. 64 w + 70 as nine
+      // pieces; positions 66 .. 71 are never read, the halo positions 0 / 65 come in as zeros (lane offset out of range) when their row
+      // belongs to another sequence.  Offsets relative to the descriptor base = tile row -1.
+      const bool seq_first = (m0 + 64 * w) % pr.Lout == 0, seq_last = (m0 + 64 * w + 64) % pr.Lout == 0;
+      unsigned vh[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int pos = 8 * k + (l >> 3);
+        const unsigned chunk = (unsigned)((l & 7) ^ ((((k & 1) << 2) + (l >> 4)) & 7)) * 16u;
+        const bool ok = pos <= 65 && !(pos == 0 && seq_first) && !(pos == 65 && seq_last);
+        vh[k] = ok ? (unsigned)(64 * w + pos) * lda2 + chunk : 0x80000000u;
+      }
+      // fragments: tap t of output row r reads position (r % 64) + t of block r / 64; the swizzle follows the position
+      const unsigned r16 = (unsigned)(l & 15);
+      unsigned lat[3][2];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          lat[t][ks] = lds0 + (unsigned)wr * (2u * 9216u) + (r16 + t) * 128u + (((4u * ks + (unsigned)(l >> 4)) ^ (((r16 + t) >> 1) & 7u)) * 16u);
+      // forward: weight tap k multiplies row m + k - 1 = position offset k; data gradient: row m + 1 - k = position offset 2 - k
+      const int t0 = fwd ? 0 : 2, t2 = fwd ? 2 : 0;
+      const unsigned lbx0 = lb0 + (unsigned)W4HX_A_RING, lbx1 = lb1 + (unsigned)W4HX_A_RING;           // the B ring sits behind the A slots
+      const unsigned lwa = lds0 + (unsigned)w * 9216u, lwbx = lds0 + (unsigned)W4HX_A_RING + (unsigned)w * 4096u;
+      const int c0 = (k_lo / 3) * 128, dstep = pr.Cin * 2, dwrap = 128 - 2 * dstep;
+      const char* sbt = (const char*)pr.B + (long)n0 * pr.ldb * 2 + c0;
+      const int ncb = (k_hi - k_lo) / 3;
+      asm volatile(W4HX_LOOP_ASM
+                   :
+                   : [sb] "s"(sbt), [cnt] "s"(ncb - 2), [lw] "s"(lwa), [lwb] "s"(lwbx), [d0] "s"(d0), [d1] "s"(d1), [d2] "s"(d2), [d3] "s"(d3),
+                     [c0] "s"(c0), [dstep] "s"(dstep), [dwrap] "s"(dwrap),
+                     [voa0] "v"(vh[0]), [voa1] "v"(vh[1]), [voa2] "v"(vh[2]), [voa3] "v"(vh[3]), [voa4] "v"(vh[4]), [voa5] "v"(vh[5]),
+                     [voa6] "v"(vh[6]), [voa7] "v"(vh[7]), [voa8] "v"(vh[8]),
+                     [vob0] "v"(vob[0]), [vob1] "v"(vob[1]), [vob2] "v"(vob[2]), [vob3] "v"(vob[3]),
+                     [la00] "v"(lat[t0][0]), [la01] "v"(lat[t0][1]), [la10] "v"(lat[1][0]), [la11] "v"(lat[1][1]),
+                     [la20] "v"(lat[t2][0]), [la21] "v"(lat[t2][1]), [lb0] "v"(lbx0), [lb1] "v"(lbx1)
+                   : W4HX_LOOP_CLOBBERS);
+    } else if (tapil) {
       const int c0 = (k_lo / 3) * 128, dstep = pr.Cin * 2, dwrap = 128 - 2 * dstep;
       const char* sbt = (const char*)pr.B + (long)n0 * pr.ldb * 2 + c0;
       asm volatile(W4HT_LOOP_ASM
@@ -185,11 +227,25 @@ bool drn_nt_w4h_eligible(const DrnGemmDesc* d, int ngroups, int dtype, bool* con
 
 int drn_nt_w4h_launch(const GemmParams& P, int total, bool conv, hipStream_t stream, int ksplit) {
   static bool attr_set = false;
-  constexpr int LDS = 3 * (32768 + 16384);
+  constexpr int LDS = W4H_LDS;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W4HX_LDS);
     attr_set = true;
+  }
+  if (conv && drn_tuning(DRN_TUNE_W4H_HALO) > 0) {
+    // every sequence a multiple of 64 rows (a staging block never straddles two), whole channel blocks per split, at least two of them
+    bool ok = true;
+    for (int g = 0; g < P.ngroups; ++g) ok = ok && P.p[g].Lout % 64 == 0 && P.p[g].Lout == P.p[g].Lsrc && P.p[g].Cin % 64 == 0 && P.p[g].M % 256 == 0;
+    const int ncb_all = P.p[0].Cin / 64, per = cdiv(ncb_all, ksplit);
+    for (int g = 1; g < P.ngroups; ++g) ok = ok && P.p[g].Cin == P.p[0].Cin;
+    ok = ok && per >= 2 && ncb_all - (ksplit - 1) * per >= 2;
+    if (ok) {
+      GemmParams Q = P;
+      Q.ksplit = P.ksplit | W4H_HALO;
+      gemm_nt_w4h_kernel<true><<<dim3(total, ksplit), 256, W4HX_LDS, stream>>>(Q);
+      return drn_launch_status("drn_gemm_nt");
+    }
   }
   if (conv && ksplit > 1 && drn_tuning(DRN_TUNE_W4H_TAPIL) > 0 && P.p[0].Cin >= drn_tuning(DRN_TUNE_W4H_TAPIL)) {
     // split conv launches over a wide input (conv0's forward: 4352 channels): taps interleaved, splits of whole channel blocks --

@@ -349,6 +349,189 @@ def build():
     return lines
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# k = 3 convolutions with the channel block staged ONCE for its three taps (W4HX_LOOP_ASM, gemm_nt_w4h_kernel; round 6).
+# The tap loops above stage an A item per K-step: the three taps of a channel block load the same rows shifted by one -- 3 x the
+# A traffic, and with cold operands these loops run at half the MFMA issue rate on what the L2 delivers (conv0's forward: 2170 cycles
+# per K-step against a floor of 1024; with 3 of 8 A pieces staged -- timing only -- the loop went from 57.2 to 41.5 us).  Here:
+#   * K order (channel block, tap); the loop body is one channel block = three K-steps with the tap static in each;
+#   * an A item = the 64 channels of rows -1 .. 256 of the tile as FOUR blocks, one per wave: block b holds positions 0 .. 71 =
+#     source rows 64 b - 1 .. 64 b + 70 of the tile in NINE 1 KB pieces (positions 66 .. 71 are never read); position p of a block
+#     sits at p * 128 bytes, its 16-byte chunk c at (c ^ ((p >> 1) & 7)) * 16; halo positions 0 / 65 whose row lies in another
+#     sequence come in as zeros (lane offset 0x80000000 -> out of range), which is all the padding there is (L % 64 == 0);
+#   * tap t (0 .. 2) of output row r reads position (r % 64) + t of block r / 64: a per-lane base per (t, k-slice) -- six operands
+#     %[la<t><ks>] -- because the XOR swizzle follows the position; the 16-row steps keep immediate offsets (2048 per 16 rows, 9216
+#     per block);
+#   * rings: TWO A slots of 36 KB (A(cb + 1) is staged while cb is multiplied: 5 pieces in tap 0's first half-step, 4 in tap 1's;
+#     needed at tap 2's barrier) and FIVE B slots of 16 KB behind them: B_{j+4} is staged during K-step j -- four K-steps of latency
+#     cover instead of one (the first version, 3 + 3 slots with B_{j+2}, gained a third of what the traffic ablation promised);
+#   * waits: at the barrier of K-step j the wave needs its own pieces of B_{j+1}, and of A(cb + 1) when j is a tap 2.  Loads complete
+#     in order, so the wait is vmcnt(number of loads issued after the last one needed) -- computed by SIMULATING the issue sequence
+#     for 2 .. 7 channel blocks and taking, per emitted wait, the smallest count any execution needs (hx_waits).
+# Registers: s[82:83] B pointer, s84 trips, s85 / s100 the wave's A / B staging base, s86 / s97 A / B staging slot, s87 / s88 A / B
+# read slot, s89 / s98 = s85 + s86 / s100 + s97, s[92:95] A descriptor, s96 channel byte offset of the item being staged.
+HX_ABLK, HX_ASLOT, HX_NA, HX_BSLOT, HX_NB, HX_BAHEAD = 9216, 36864, 2, 16384, 5, 4
+HX_ARING, HX_BRING = HX_ASLOT * HX_NA, HX_BSLOT * HX_NB
+HX_A_SPLIT = {0: range(0, 5), 1: range(5, 9), 2: range(0)}          # A(cb + 1)'s pieces by the tap whose first half-step issues them
+
+
+def hx_a_pieces(ks_list):
+    return [["s_add_u32 m0, s89, %d" % (k * 1024), "s_nop 0", "buffer_load_dwordx4 %%[voa%d], s[92:95], s96 offen lds" % k] for k in ks_list]
+
+
+def hx_b_pieces():
+    return [["s_add_u32 m0, s98, %d" % (i * 1024), "s_nop 0", "global_load_lds_dwordx4 %%[vob%d], s[82:83]" % i] for i in range(geo().PB)]
+
+
+def hx_adv_a_stage():
+    return [["s_add_u32 s96, s96, 128"], ["s_add_u32 s86, s86, %d" % HX_ASLOT], ["s_cmp_lt_u32 s86, %d" % HX_ARING, "s_cselect_b32 s86, s86, 0"],
+            ["s_add_u32 s89, s85, s86"]]
+
+
+def hx_adv_b_stage(staged_tap):
+    """after a B item of tap `staged_tap`: the pointer moves one tap on (%[dstep] = Cin * 2 bytes), or from tap 2 back two taps and on
+    by one channel block (%[dwrap] = 128 - 2 * Cin * 2 < 0: the high word takes the borrow)"""
+    ptr = ["s_add_u32 s82, s82, %[dwrap]", "s_addc_u32 s83, s83, -1"] if staged_tap == 2 else ["s_add_u32 s82, s82, %[dstep]", "s_addc_u32 s83, s83, 0"]
+    return [ptr, ["s_add_u32 s97, s97, %d" % HX_BSLOT], ["s_cmp_lt_u32 s97, %d" % HX_BRING, "s_cselect_b32 s97, s97, 0"], ["s_add_u32 s98, s100, s97"]]
+
+
+def hx_adv_read(which):
+    r, t, step, ring = ("s87", "s90", HX_ASLOT, HX_ARING) if which == "a" else ("s88", "s91", HX_BSLOT, HX_BRING)
+    return [["s_add_u32 %s, %s, %d" % (r, r, step), "s_sub_u32 %s, %s, %d" % (t, r, ring)], ["s_cmp_lt_u32 %s, %d" % (r, ring), "s_cselect_b32 %s, %s, %s" % (r, r, t)]]
+
+
+def hx_reads(dst_set):
+    out = ["ds_read_b128 %s, v124 offset:%d" % (frag(A_SET[dst_set], i), (i >> 2) * HX_ABLK + (i & 3) * 2048) for i in range(8)]
+    out += ["ds_read_b128 %s, v125 offset:%d" % (frag(B_SET[dst_set], i), i * 2048) for i in range(geo().NI)]
+    return out
+
+
+def hx_half_step(ks, read_tap, pieces, wait, barrier, groups_early, groups_late):
+    """MFMAs of k-slice ks out of register set ks; read_tap: None or the tap whose k-slice (1 - ks) fragments go into the other set;
+    pieces: LDS-DMA pieces issued inside the MFMA stream; groups_early: scalar groups that may run once the fragment bases exist;
+    groups_late: after the last piece."""
+    L = []
+    if wait:
+        L.append("s_waitcnt %s" % wait)
+    if barrier:
+        L.append("s_barrier")
+    if read_tap is not None:
+        L += ["v_add_u32 v124, s87, %%[la%d%d]" % (read_tap, 1 - ks), "v_add_u32 v125, s88, %%[lb%d]" % (1 - ks)]
+    NM, NI = geo().NM, geo().NI
+    fill = {n: [] for n in range(NM)}
+    for k, r in enumerate(hx_reads(1 - ks) if read_tap is not None else []):
+        fill[min(NM - 1, cfg.ds_first + k * cfg.ds_every)].append(r)
+    last = 0
+    for k, (m0w, nop, ld) in enumerate(pieces):
+        n = min(NM - 1, cfg.dma_first + k * cfg.dma_every)
+        fill[n - 1].append(m0w)
+        fill[n].append(ld)
+        last = n
+    for k, g in enumerate(groups_early):
+        fill[4 + 2 * k] += g
+    pos, tail = last + 1, []
+    for g in groups_late:
+        if pos <= NM - 1:
+            fill[pos] += g
+            pos += 1
+        else:
+            tail += g
+    for n in range(NM):
+        mi, ni = n // NI, n % NI
+        L.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(mi, ni), frag(B_SET[ks], ni), frag(A_SET[ks], mi), acc(mi, ni)))
+        L += fill[n]
+    return L + tail
+
+
+def hx_program(ncb):
+    """the K-steps one workgroup executes for ncb channel blocks: (site, tap, stage_a, stage_b); site = which emitted copy runs"""
+    out = []
+    for cb in range(ncb):
+        site = "main" if cb <= ncb - 3 else ("tail1" if cb == ncb - 2 else "tail2")
+        for tap in range(3):
+            j = 3 * cb + tap
+            out.append((site, tap, cb + 1 <= ncb - 1, j + HX_BAHEAD <= 3 * ncb - 1))
+    return out
+
+
+def hx_waits():
+    """vmcnt at the barrier of every emitted K-step: loads issued after the last one the next K-step needs, the minimum over every execution"""
+    need = {}
+    for ncb in range(2, 8):
+        log = [("A", 0)] * 9
+        for jb in range(HX_BAHEAD):
+            log += [("B", jb)] * geo().PB
+        for j, (site, tap, sa, sb) in enumerate(hx_program(ncb)):
+            cb = j // 3
+            if sa:
+                log += [("A", cb + 1)] * len(HX_A_SPLIT[tap])
+            if j + 1 <= 3 * ncb - 1:
+                req = [("B", j + 1)] + ([("A", cb + 1)] if tap == 2 else [])
+                last = max(i for i, e in enumerate(log) if e in req)
+                n = len(log) - 1 - last
+                need[(site, tap)] = min(need.get((site, tap), 63), n)
+            if sb:
+                log += [("B", j + HX_BAHEAD)] * geo().PB
+    # a site must stage the same things in every execution (the emitted code is one)
+    for ncb in range(2, 8):
+        for site, tap, sa, sb in hx_program(ncb):
+            assert (sa, sb) == hx_site_stages(site, tap), (ncb, site, tap)
+    return need
+
+
+def hx_site_stages(site, tap):
+    if site == "main":
+        return True, True
+    if site == "tail1":
+        return True, tap <= 1
+    return False, False
+
+
+def hx_k_step(site, tap, waits, next_reads=True):
+    """K-step (cb, tap) of the emitted copy `site`"""
+    sa, sb = hx_site_stages(site, tap)
+    a_ps = hx_a_pieces(HX_A_SPLIT[tap]) if sa else []
+    early = hx_adv_read("b") + (hx_adv_read("a") if tap == 2 else []) if next_reads else []
+    L = hx_half_step(0, tap, a_ps, "lgkmcnt(0)", False, early, hx_adv_a_stage() if (a_ps and tap == 1) else [])
+    if next_reads:
+        L += hx_half_step(1, (tap + 1) % 3, hx_b_pieces() if sb else [], "vmcnt(%d) lgkmcnt(0)" % waits[(site, tap)], True, [],
+                          hx_adv_b_stage((tap + HX_BAHEAD) % 3) if sb else [])
+    else:
+        L += hx_half_step(1, None, [], "lgkmcnt(0)", False, [], [])
+    return L
+
+
+def build_halo():
+    G = geo()
+    assert G.half and cfg.swap
+    waits = hx_waits()
+    lines = ["s_mov_b64 s[82:83], %[sb]", "s_mov_b32 s84, %[cnt]", "s_mov_b32 s85, %[lw]", "s_mov_b32 s100, %[lwb]",
+             "s_mov_b32 s86, 0", "s_mov_b32 s97, 0", "s_mov_b32 s87, 0", "s_mov_b32 s88, 0", "s_mov_b32 s89, s85", "s_mov_b32 s98, s100",
+             "s_mov_b32 s92, %[d0]", "s_mov_b32 s93, %[d1]", "s_mov_b32 s94, %[d2]", "s_mov_b32 s95, %[d3]", "s_mov_b32 s96, %[c0]", "s_nop 4"]
+    # prologue: A(cb0), B_0 .. B_3
+    for pc in hx_a_pieces(range(9)):
+        lines.extend(pc)
+    lines += [i for g in hx_adv_a_stage() for i in g]
+    for jb in range(HX_BAHEAD):
+        for pc in hx_b_pieces():
+            lines.extend(pc)
+        lines += [i for g in hx_adv_b_stage(jb % 3) for i in g]
+    for i in range(G.NACC):
+        lines.append("v_accvgpr_write_b32 a%d, 0" % i)
+    lines += ["s_waitcnt vmcnt(%d)" % ((HX_BAHEAD - 1) * G.PB), "s_barrier"]
+    lines += ["v_add_u32 v124, s87, %[la00]", "v_add_u32 v125, s88, %[lb0]"] + hx_reads(0)
+    # main loop: channel blocks 0 .. ncb - 3 (everything staged), then ncb - 2 (the last A item, two more B items), then ncb - 1
+    lines += ["s_cmp_eq_u32 s84, 0", "s_cbranch_scc1 L_w4_tail%=", "L_w4_loop%=:"]
+    for tap in range(3):
+        lines += hx_k_step("main", tap, waits)
+    lines += ["s_sub_u32 s84, s84, 1", "s_cmp_lg_u32 s84, 0", "s_cbranch_scc1 L_w4_loop%=", "L_w4_tail%=:"]
+    for tap in range(3):
+        lines += hx_k_step("tail1", tap, waits)
+    lines += hx_k_step("tail2", 0, waits) + hx_k_step("tail2", 1, waits) + hx_k_step("tail2", 2, waits, next_reads=False)
+    lines += ["s_nop 15", "s_nop 15"]
+    return lines
+
+
 def check_scc(lines):
     """every consumer of SCC must see the producer it was written for (the generator moves scalar instructions around)"""
     last = None
@@ -431,6 +614,14 @@ with open(args.out, "w") as f:
         for ln in lines:
             f.write('  "%s\\n\\t" \\\n' % ln)
         f.write('  ""\n')
+    cfg = Cfg(half=True, swap=True, conv=True, ds_every=2, dma_every=3)
+    lines = build_halo()
+    check_scc(lines)
+    f.write("// W4HX_LOOP_ASM: k = 3 convolutions, a channel block staged once for its three taps (%d instructions)\n" % len(lines))
+    f.write("#define W4HX_LOOP_ASM \\\n")
+    for ln in lines:
+        f.write('  "%s\\n\\t" \\\n' % ln)
+    f.write('  ""\n')
     # ---- split-K exchange of gemm_nt_w4h_kernel (accumulators a[0:127], 32 groups of 4; a lane's group g of split q lives at
     # base + ((q*32 + g)*256 + tid)*16 bytes: 4 KB per wave instruction, consecutive groups 4096 bytes apart, consecutive splits too).
     # PUBLISH: the 32 groups straight out of the AGPRs (write-through), ONE wait.  GATHER (the last arriver): a[0:127] = 0, then
@@ -500,5 +691,6 @@ with open(args.out, "w") as f:
     f.write("#define W4_VARIANTS %d\n" % len(VARIANTS))
     f.write("#define W4_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
     f.write("#define W4H_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob + ["s100"]))
+    f.write("#define W4HX_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob + ["s100", "s101"]))
     f.write("#define W4HT_LOOP_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob + ["s100", "s101"] + ["v%d" % i for i in range(97, 113)]))
 print("wrote %s: %d variant(s)" % (args.out, len(VARIANTS)))

@@ -16,7 +16,7 @@ TOL = {"f32": 2e-5, "bf16": 1e-2}
 def tune(monkeypatch, key, value):
     """drn_tune(key, value) for the duration of one test (defaults restored afterwards)."""
     from drn_amd import _lib
-    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0, "nt_w4h": 160, "w4h_tapil": 2048}
+    defaults = {"tn3_minrows": 4096, "tn_fused": 1, "nt_w4": 1, "nt_w4c": 1, "exp0": 0, "nt_w4h": 160, "w4h_tapil": 2048, "w4h_halo": 1}
     _lib.check(_lib.lib().drn_tune(key.encode(), int(value)), "drn_tune")
     _RESTORE.append((key, defaults[key]))
 
@@ -766,6 +766,14 @@ def stats_agree(sh, sg):
         bool(((sh[:, 1] - sg[:, 1]).abs() <= 2e-5 * sg[:, 1].abs() + 1e-5 * scale).all())
 
 
+def stats_agree_loose(sa, sb):
+    """... of two kernels whose bf16-rounded OUTPUTS differ in the last place here and there (another K order): the sums agree to what
+    that rounding moves"""
+    assert torch.isfinite(sa).all() and torch.isfinite(sb).all()
+    scale = float(sb[:, 0].abs().max()) + 1.0
+    return bool((sa[:, 0] - sb[:, 0]).abs().max() <= 1e-3 * scale) and bool(((sa[:, 1] - sb[:, 1]).abs() <= 1e-2 * sb[:, 1].abs() + 1e-3 * scale).all())
+
+
 def _w4h_launch(ops, case, flag, monkeypatch, seed=0):
     levels, N, Cin, taps, mode, bias, stats, gate, pad = case
     tune(monkeypatch, "nt_w4h", flag)
@@ -796,6 +804,7 @@ def test_w4h_kernel_is_bit_identical_to_the_128_tile_kernel(monkeypatch, case):
     per-slab BatchNorm statistics are summed in the kernel's own fixed order since round 6 (per lane over the 8 row tiles, then over a
     DPP row): equal to fp32 rounding, and bit-identical from run to run."""
     from drn_amd import ops
+    tune(monkeypatch, "w4h_halo", 0)                                    # the tap-major walk: the general kernel's K order
     kind_h, outs_h, _ = _w4h_launch(ops, case, 1, monkeypatch)          # from ONE 256 x 128 tile on
     kind_g, outs_g, keep = _w4h_launch(ops, case, 0, monkeypatch)
     assert kind_h == ops.NT_KIND_W4H and kind_g == ops.NT_KIND_TILE128
@@ -807,6 +816,16 @@ def test_w4h_kernel_is_bit_identical_to_the_128_tile_kernel(monkeypatch, case):
     outs_h2 = _w4h_launch(ops, case, 1, monkeypatch)[1]
     for (Ch, sh), (C2, s2) in zip(outs_h, outs_h2):                  # deterministic: the same bits again
         assert torch.equal(Ch, C2) and (sh is None or torch.equal(sh, s2))
+    # the shipped walk of the k = 3 launches whose sequences are multiples of 64 rows (round 6: a channel block staged ONCE for its three
+    # taps, K order (channel block, tap)): another fixed summation order -- equal to fp32 re-association, bit-identical from run to run
+    tune(monkeypatch, "w4h_halo", 1)
+    outs_x = _w4h_launch(ops, case, 1, monkeypatch)[1]
+    outs_x2 = _w4h_launch(ops, case, 1, monkeypatch)[1]
+    for (Cx, sx), (Cx2, sx2), (Ch, sh) in zip(outs_x, outs_x2, outs_h):
+        assert torch.equal(Cx, Cx2) and (sx is None or torch.equal(sx, sx2))
+        close(Cx, Ch.double().cpu(), 1e-2, "staged-once walk vs tap-major")
+        if sx is not None:
+            assert stats_agree_loose(sx, sh)
     # ... and close to the product itself (first level, plain cases without a gate)
     levels, N, Cin, taps, mode, bias, stats, gate, pad = case
     if taps == 1 and not gate:
@@ -907,9 +926,13 @@ def test_w4h_kernel_splitk_in_launch(monkeypatch, shape):
         ops.gemm_nt([d], ops.BF16)
         torch.cuda.synchronize()
         return ks, C, st
+    tune(monkeypatch, "w4h_halo", 0)
     ks0, C0, s0 = run(False)
     outs = []
-    for tapil in (2048, 0):          # split k = 3 launches over >= 2048 channels walk K as (channel block, tap); 0: tap-major as unsplit
+    # three walks of K: a channel block staged once for its three taps (round 6, the shipped one where every sequence is a multiple of 64
+    # rows); split k = 3 launches over >= 2048 channels as (channel block, tap) with an A item per K-step; tap-major as unsplit
+    for halo, tapil in ((1, 2048), (0, 2048), (0, 0)):
+        tune(monkeypatch, "w4h_halo", halo)
         tune(monkeypatch, "w4h_tapil", tapil)
         ks1, C1, s1 = run(True)
         ks2, C2, s2 = run(True)
@@ -923,10 +946,13 @@ def test_w4h_kernel_splitk_in_launch(monkeypatch, shape):
             close(q1, q0, 1e-4, "column M2")
         assert int(ops._counters(dev()).abs().sum()) == 0
         outs.append(C1)
-    if taps == 3:                    # another summation order: the two walks agree to rounding -- and not bit for bit: equal bits
-        close(outs[0], outs[1].double().cpu(), 1e-2, "interleaved vs tap-major")          # would mean the flag never reached the kernel
+    if taps == 3:                    # another summation order: the walks agree to rounding -- and not bit for bit: equal bits
+        close(outs[0], outs[2].double().cpu(), 1e-2, "staged-once vs tap-major")            # would mean the flag never reached the kernel
+        close(outs[1], outs[2].double().cpu(), 1e-2, "interleaved vs tap-major")
         if Cin >= 2048:
-            assert not torch.equal(outs[0], outs[1]), "the interleaved-tap walk was not taken"
+            assert not torch.equal(outs[1], outs[2]), "the interleaved-tap walk was not taken"
+        if L % 64 == 0 and Cin % 64 == 0:
+            assert not torch.equal(outs[0], outs[2]), "the staged-once walk was not taken"
 
 
 @pytest.mark.parametrize("kind", ["general", "w4h"])
@@ -1126,3 +1152,48 @@ def test_sustained_mfma_measurement_is_at_the_issue_floor_and_data_dependent():
     assert z["tflops"] >= 0.98 * r["tflops"], (r, z)
     with pytest.raises(_lib.DrnError):
         _lib.check(_lib.lib().drn_diag_mfma_sustained(None, 0, 0, None, None, None, None), "drn_diag_mfma_sustained")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels,Cin,N", [([(4, 64)], 128, 128), ([(2, 128), (4, 64)], 192, 256), ([(1, 256), (2, 128), (4, 64)], 320, 128),
+                                          ([(3, 256)], 448, 256)])
+def test_w4h_staged_once_walk_matches_the_convolution(monkeypatch, levels, Cin, N):
+    """The k = 3 walk that stages a channel block once for its three taps (W4HX_LOOP_ASM: rows -1 .. 256 of a tile as four 66-row blocks, the
+    halo rows zero where a sequence ends) against torch's float64 convolution: forward with statistics and the data gradient, grouped
+    levels whose sequences end at block edges (L = 64), inside a wave's rows (128) and nowhere (256), 2 to 7 channel blocks; and the same
+    product split over K inside the launch.  Checked to be the walk taken: the tap-major one gives other bits."""
+    from drn_amd import ops
+    tune(monkeypatch, "nt_w4h", 1)
+    w = (rnd((N, Cin, 3), 5, torch.float32) / np.sqrt(Cin * 3)).to(torch.bfloat16)
+    for mode in (0, 1):
+        res = {}
+        for halo in (1, 0):
+            tune(monkeypatch, "w4h_halo", halo)
+            descs, outs, refs = [], [], []
+            for li, (B, L) in enumerate(levels):
+                if mode == 0:
+                    x = rnd((B, Cin, L), 20 + li, torch.bfloat16)
+                    refs.append(F.conv1d(x.double(), w.double(), padding=1).permute(0, 2, 1).reshape(B * L, N))
+                    A, Wd, K, Nout = nlc(x).to(dev()), w.permute(0, 2, 1).contiguous().to(dev()), Cin, N
+                else:
+                    dy = rnd((B, N, L), 30 + li, torch.bfloat16)
+                    refs.append(F.conv_transpose1d(dy.double(), w.double(), padding=1).permute(0, 2, 1).reshape(B * L, Cin))
+                    A, Wd, K, Nout = nlc(dy).to(dev()), w.permute(1, 2, 0).contiguous().to(dev()), N, Cin
+                C = torch.full((B * L, Nout), float("nan"), dtype=torch.bfloat16, device=dev())
+                st = torch.full((B * L // 128, 2, Nout), float("nan"), device=dev()) if mode == 0 else None
+                descs.append(ops.gemm_desc(A, Wd, C, B * L, Nout, K, taps=3, pad=1, mode=mode, Lout=L, Lsrc=L, stats=st))
+                outs.append((A, Wd, C, st))
+            if mode == 1 and Cin % 128:          # (the data gradient's output width: 256 x 128 tiles)
+                continue
+            assert ops.gemm_nt_plan(descs, ops.BF16) == ops.NT_KIND_W4H
+            ops.gemm_nt(descs, ops.BF16)
+            torch.cuda.synchronize()
+            for (_, _, C, st), ref, (B, L) in zip(outs, refs, levels):
+                close(C, ref, TOL["bf16"] * 2, "mode %d halo %d L %d" % (mode, halo, L))
+                if st is not None:
+                    tot, m2 = merged_stats(st, B * L)              # (of the fp32 accumulators, not of the rounded outputs)
+                    close(tot, ref.sum(0), TOL["bf16"] * 4, "column sums")
+                    close(m2, ((ref - ref.mean(0)) ** 2).sum(0), TOL["bf16"] * 4, "column M2")
+            res[halo] = [o[2].clone() for o in outs]
+        if len(res) == 2:
+            assert any(not torch.equal(a, b) for a, b in zip(res[1], res[0])), "the staged-once walk was not taken"
