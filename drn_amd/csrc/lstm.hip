@@ -263,6 +263,20 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_seq_fwd_kernel(const LstmSe
   __syncthreads();
   const unsigned long long tagm = (s_launch & 1u) ? 0x4000400040004000ull : 0ull;
   const long long t0 = wall_clock64();
+  // W_hh does not change between the steps: when a wave's K quarter is ONE pass of the loop below (H = 128 * KU: the benchmarked H = 512
+  // with KU = 4) its fragments are converted once and stay in 4 * KU registers -- 32 KB of L2 reads and KU * 8 conversions per step and
+  // workgroup less (round 6; same values, same order)
+  const bool w_resident = kq == 32 * KU;
+  f16x8 wv[KU];
+  if (w_resident) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k = w * kq + u * 32 + kc;
+      const f32x4 lo = *(const f32x4*)(W + wrow + k), hi = *(const f32x4*)(W + wrow + k + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wv[u][e] = (_Float16)lo[e]; wv[u][4 + e] = (_Float16)hi[e]; }
+    }
+  }
   for (int s = 0; s < L; ++s) {
     const int t = dir == 0 ? s : L - 1 - s;
     float e_x[4];
@@ -296,8 +310,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_seq_fwd_kernel(const LstmSe
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
           const int k = k0 + u * 32 + kc;
-          blo[u] = *(const f32x4*)(W + wrow + k);
-          bhi[u] = *(const f32x4*)(W + wrow + k + 4);
+          if (!w_resident) {
+            blo[u] = *(const f32x4*)(W + wrow + k);
+            bhi[u] = *(const f32x4*)(W + wrow + k + 4);
+          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const int bb = mt * 16 + col;
@@ -309,8 +325,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_seq_fwd_kernel(const LstmSe
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
           f16x8 bv;
+          if (w_resident) bv = wv[u];
+          else
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { bv[e] = (_Float16)blo[u][e]; bv[4 + e] = (_Float16)bhi[u][e]; }
+            for (int e = 0; e < 4; ++e) { bv[e] = (_Float16)blo[u][e]; bv[4 + e] = (_Float16)bhi[u][e]; }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const int bb = mt * 16 + col;
@@ -359,6 +377,16 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_seq_fwd_kernel(const LstmSe
       e_cp = valid ? cn : cp;
       e_hp = valid ? hn : hp;
       h_new = e_hp;
+      // hand-off FIRST (round 6: it used to queue behind the bookkeeping stores below): the four units of a clip as ONE tagged 8-byte
+      // write-through store (lanes 4q .. 4q + 3 hold them: a clip's four lanes take this branch together)
+      if (s + 1 < L) {
+        const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)h_new);
+        const unsigned h1 = (unsigned)__shfl_down((int)hb, 1, 64), h2 = (unsigned)__shfl_down((int)hb, 2, 64), h3 = (unsigned)__shfl_down((int)hb, 3, 64);
+        if ((threadIdx.x & 3) == 0) {
+          const unsigned long long word = ((unsigned long long)hb | ((unsigned long long)h1 << 16) | ((unsigned long long)h2 << 32) | ((unsigned long long)h3 << 48)) | tagm;
+          __hip_atomic_store(S.xch + ((long)(dir * L + s) * B + e_bb) * (H / 4) + (j0 >> 2), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       A.cseq[st_new] = e_cp;
       A.hseq[st_new] = e_hp;
       float* gs = A.gates + (((long)t * B + bb) * 2 + dir) * 4 * H + j;
@@ -369,15 +397,6 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_seq_fwd_kernel(const LstmSe
         float* qv = A.qvec + (long)bb * 4 * H + dir * H + j;
         if (t == 0) qv[0] = valid ? hn : 0.f;
         if (t == e_len - 1) qv[2 * H] = hn;
-      }
-    }
-    // hand-off: the four units of a clip as ONE tagged 8-byte write-through store (lanes 4q .. 4q + 3 hold them)
-    if (s + 1 < L) {
-      const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)h_new);
-      const unsigned h1 = (unsigned)__shfl_down((int)hb, 1, 64), h2 = (unsigned)__shfl_down((int)hb, 2, 64), h3 = (unsigned)__shfl_down((int)hb, 3, 64);
-      if (e_own && (threadIdx.x & 3) == 0) {
-        const unsigned long long word = ((unsigned long long)hb | ((unsigned long long)h1 << 16) | ((unsigned long long)h2 << 32) | ((unsigned long long)h3 << 48)) | tagm;
-        __hip_atomic_store(S.xch + ((long)(dir * L + s) * B + e_bb) * (H / 4) + (j0 >> 2), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();                                    // red[] is free for the next step
